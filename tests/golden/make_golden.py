@@ -1,0 +1,306 @@
+"""Generates tests/golden/*.npz by running the REFERENCE'S OWN modules (imported read-only from /root/reference)
+on seeded synthetic inputs with deterministic weights.  Run only in the CPU container:
+
+    python tests/golden/make_golden.py [g1 g2 g3 g4]
+
+Fixtures are data (inputs, expected outputs, the config dict that produced them); no reference source is stored.
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd'))
+
+import ref_harness as rh  # noqa: E402
+from pcp_amd import synth  # noqa: E402
+
+MINI_RANGE = [-12.8, -12.8, -8.0, 12.8, 12.8, 0.0]
+
+
+def fill_weights(model):
+    sd = model.state_dict()
+    shapes = {k: [int(x) for x in v.shape] for k, v in sd.items()}
+    filled = synth.fill_state_dict(shapes)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    return shapes
+
+
+def run_modules(model, batch_dict):
+    snaps = {}
+    for name, mod in zip(_module_names(model), model.module_list):
+        batch_dict = mod(batch_dict)
+        snaps[name] = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in batch_dict.items()
+                       if k in ('spatial_features_2d',)}
+    return batch_dict, snaps
+
+
+def _module_names(model):
+    names = []
+    for m in model.module_list:
+        for n in model.module_topology:
+            if getattr(model, n, None) is m:
+                names.append(n)
+    return names
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def mini_points(layout, batch, n_per, seed_shift=0, xy_half=13.1):
+    clouds = [synth.agent_cloud(agent=10 + b, n_points=n_per, layout=layout, seed=synth.SEED_BASE + seed_shift, xy_half=xy_half)
+              for b in range(batch)]
+    return clouds
+
+
+def capture_common(model, bd, out):
+    out['voxel_coords'] = bd['voxel_coords'].numpy()
+    out['pillar_features'] = bd['pillar_features'].numpy()
+    out['spatial_features_2d'] = bd['spatial_features_2d'].numpy()
+    pd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for k, v in pd.items():
+        out['head_' + k] = v.detach().numpy()
+    for b, d in enumerate(bd['final_box_dicts']):
+        out['final_boxes_%d' % b] = d['pred_boxes'].numpy()
+        out['final_scores_%d' % b] = d['pred_scores'].numpy()
+        out['final_labels_%d' % b] = d['pred_labels'].numpy()
+
+
+def g1_single(tag, yaml_name, layout, extra_points=None, score_thresh=None):
+    ov = {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE}
+    if score_thresh is not None:
+        ov['MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH'] = score_thresh
+    cfg = rh.load_cfg(yaml_name, ov)
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    clouds = mini_points(layout, 2, 3000)
+    if extra_points is not None:
+        clouds[0] = np.concatenate([clouds[0], extra_points(clouds[0].shape[1])], axis=0)
+    pts = synth.collate(clouds)
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': [{}, {}]}
+    unq_inv_holder = {}
+    # capture unq_inv through the torch_scatter shim (it is not stored in batch_dict by the reference)
+    import torch_scatter
+    orig_mean = torch_scatter.scatter_mean
+
+    def spy_mean(src, index, dim=0, dim_size=None):
+        if src.shape[1] == 3 and 'inv' not in unq_inv_holder:
+            unq_inv_holder['inv'] = index.clone()
+        return orig_mean(src, index, dim, dim_size)
+    torch_scatter.scatter_mean = spy_mean
+    try:
+        with torch.no_grad():
+            bd, snaps = run_modules(model, bd)
+    finally:
+        torch_scatter.scatter_mean = orig_mean
+    out = {'points': pts, 'unq_inv': unq_inv_holder['inv'].numpy()}
+    capture_common(model, bd, out)
+    if 'backbone_2d' in snaps and cfg.MODEL.get('CORRECTOR', None) is not None:
+        out['backbone_out'] = snaps['backbone_2d']['spatial_features_2d'].numpy()
+    if cfg.MODEL.get('CORRECTOR', None) is not None:
+        out['points_after'] = bd['points'].numpy()      # HunterJr mutates xyz in place (quirk Q8)
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), pc_range=MINI_RANGE,
+                                                 voxel_size=[0.2, 0.2, 8.0], class_names=list(cfg.CLASS_NAMES),
+                                                 yaml=yaml_name, layout=layout, state_shapes=shapes)))
+    np.savez_compressed(os.path.join(HERE, 'g1_%s.npz' % tag), **out)
+    print('g1', tag, 'P =', out['voxel_coords'].shape[0], 'boxes', [out['final_boxes_%d' % b].shape[0] for b in range(2)])
+
+
+def hunter_edge_points(ncols):
+    """rows whose BEV coordinate is exactly 0.0 / just below the upper edge (pins the strict float mask of
+    hunter_toolbox.py:80-81) and rows outside the x/y range."""
+    rows = np.zeros((6, ncols), dtype=np.float32)
+    rows[:, 2] = -3.0
+    rows[:, 3] = 0.5
+    rows[0, 0:2] = [-12.8, 1.0]            # bev x == 0.0 exactly -> dropped by bev_scatter, kept by the VFE
+    rows[1, 0:2] = [1.0, -12.8]            # bev y == 0.0
+    rows[2, 0:2] = [12.799999, 0.3]       # just below the upper edge
+    rows[3, 0:2] = [0.3, 12.799999]
+    rows[4, 0:2] = [12.8, 0.0]            # x == max -> cell 128 -> masked by the VFE
+    rows[5, 0:2] = [-12.9, 0.0]            # negative cell
+    rows[:, -1] = -1.0
+    return rows
+
+
+def g1_disco():
+    tmp = tempfile.mkdtemp()
+    empty = os.path.join(tmp, 'empty.pth')
+    torch.save({'model_state': {}}, empty)
+    ov = {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE, 'MODEL.BEV_MAKER_RSU.CKPT': empty, 'MODEL.BEV_MAKER_CAR.CKPT': empty,
+          'MODEL.BEV_MAKER_EARLY.CKPT': empty, 'MODEL.V2X_MID_FUSION.PC_RANGE_MIN': MINI_RANGE[0],
+          'MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH': 0.02}
+    cfg = rh.load_cfg('v2x_pointpillar_disco.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    # 3 agents (0 = rsu, 1 = ego, 2 = car); batch of 2; agent 2 absent from batch element 1.
+    poses = {0: synth.agent_pose(0), 2: synth.agent_pose(2)}
+    poses[0][:3, 3] = [0.8, -0.4, 0.0]
+    poses[0][:3, :3] = synth.agent_pose(1)[:3, :3]        # yaw 0.3
+    poses[2][:3, 3] = [-1.6, 2.4, 0.0]                    # exact multiples of the 0.8 m pixel -> half-pixel cases
+    metadata = [{'se3_from_ego': {0: poses[0], 2: poses[2]}}, {'se3_from_ego': {0: poses[0]}}]
+    clouds = []
+    for b in range(2):
+        per_agent = []
+        for a in (0, 1, 2):
+            if b == 1 and a == 2:
+                continue
+            c = synth.agent_cloud(agent=20 + 3 * b + a, n_points=1500, layout='disco', xy_half=13.1)
+            c[:, -1] = float(a)
+            per_agent.append(c)
+        clouds.append(np.concatenate(per_agent, axis=0))
+    pts = synth.collate(clouds)
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': metadata}
+    with torch.no_grad():
+        bd, snaps = run_modules(model, bd)
+    out = {'points': pts}
+    capture_common(model, bd, out)
+    out['backbone_out'] = snaps['backbone_2d']['spatial_features_2d'].numpy()
+    for aid, m in bd['bev_img'].items():
+        out['bev_img_%d' % aid] = m.numpy()
+    out['bev_img_early_probe'] = bd['bev_img_early'].numpy()[:, ::4].copy()    # channels 0,4,8,...
+    out['pose_0'] = poses[0]
+    out['pose_2'] = poses[2]
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0],
+                                                 class_names=list(cfg.CLASS_NAMES), yaml='v2x_pointpillar_disco.yaml',
+                                                 layout='disco', absent=[[], [2]], state_shapes=shapes)))
+    np.savez_compressed(os.path.join(HERE, 'g1_disco.npz'), **out)
+    print('g1 disco', {k: v.shape for k, v in out.items() if k.startswith('bev_img')})
+
+
+def g2_full():
+    out = {}
+    for tag, yaml_name, layout, n_agents in (('car', 'v2x_pointpillar_basic_car.yaml', 'car', 1),
+                                             ('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', 1),
+                                             ('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', 6)):
+        cfg = rh.load_cfg(yaml_name)
+        model, ds = rh.build_model(cfg)
+        fill_weights(model)
+        cloud = np.concatenate([synth.agent_cloud(agent=a, n_points=60000, layout=layout) for a in range(n_agents)], axis=0)
+        pts = synth.collate([cloud])
+        bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{}]}
+        import torch_scatter
+        holder = {}
+        orig_mean = torch_scatter.scatter_mean
+
+        def spy_mean(src, index, dim=0, dim_size=None):
+            if src.shape[1] == 3 and 'inv' not in holder:
+                holder['inv'] = index.clone()
+            return orig_mean(src, index, dim, dim_size)
+        torch_scatter.scatter_mean = spy_mean
+        try:
+            with torch.no_grad():
+                bd, snaps = run_modules(model, bd)
+        finally:
+            torch_scatter.scatter_mean = orig_mean
+        vc = bd['voxel_coords'].numpy()
+        pf = bd['pillar_features'].numpy()
+        sf = bd['spatial_features_2d'].numpy()
+        inv = holder['inv'].numpy()
+        out[tag + '_P'] = np.array(vc.shape[0])
+        out[tag + '_N'] = np.array(pts.shape[0])
+        out[tag + '_coords_sha'] = np.array(sha(vc.astype(np.int32)))
+        out[tag + '_inv_sha'] = np.array(sha(inv.astype(np.int64)))
+        out[tag + '_cnt_hist'] = np.bincount(np.bincount(inv), minlength=16)[:64]
+        out[tag + '_pf_sum'] = pf.astype(np.float64).sum(0)
+        out[tag + '_pf_abs'] = np.abs(pf.astype(np.float64)).sum(0)
+        out[tag + '_pf_max'] = pf.max(0)
+        out[tag + '_sf2d_sum'] = sf.astype(np.float64).sum((0, 2, 3))
+        out[tag + '_sf2d_abs'] = np.abs(sf.astype(np.float64)).sum((0, 2, 3))
+        out[tag + '_sf2d_max'] = sf.max(axis=(0, 2, 3))
+        out[tag + '_sf2d_probe'] = sf[0, :, ::16, ::16].copy()
+        pd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+        out[tag + '_hm_probe'] = pd['hm'].numpy()[0, 0, ::4, ::4].copy()
+        out[tag + '_boxes'] = bd['final_box_dicts'][0]['pred_boxes'].numpy()
+        out[tag + '_scores'] = bd['final_box_dicts'][0]['pred_scores'].numpy()
+        print('g2', tag, 'N', pts.shape[0], 'P', vc.shape[0], 'final', out[tag + '_boxes'].shape[0])
+    np.savez_compressed(os.path.join(HERE, 'g2_full.npz'), **out)
+
+
+def g3_nms():
+    rh.install()
+    nmsmod = sys.modules['pcdet.ops.iou3d_nms.iou3d_nms_cuda']
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils
+    n = 500
+    s = synth.SEED_BASE + 33
+    # clustered boxes so that many pairs overlap: 60 cluster centres, jitter 1.5 m
+    cx = synth.uniform(s, 1, 60, -45, 45)
+    cy = synth.uniform(s, 2, 60, -45, 45)
+    which = (synth.uniform01(s, 3, n) * 60).astype(np.int64)
+    boxes = np.zeros((n, 7), dtype=np.float32)
+    boxes[:, 0] = cx[which] + synth.uniform(s, 4, n, -1.5, 1.5)
+    boxes[:, 1] = cy[which] + synth.uniform(s, 5, n, -1.5, 1.5)
+    boxes[:, 2] = synth.uniform(s, 6, n, -3, -1)
+    boxes[:, 3] = synth.uniform(s, 7, n, 3.0, 5.5)
+    boxes[:, 4] = synth.uniform(s, 8, n, 1.5, 2.5)
+    boxes[:, 5] = synth.uniform(s, 9, n, 1.4, 2.0)
+    boxes[:, 6] = synth.uniform(s, 10, n, -3.14159, 3.14159)
+    boxes[7, 6] = 0.0                                   # axis-aligned cases
+    boxes[8] = boxes[7]
+    boxes[8, 0] += 0.5
+    boxes[9] = boxes[7]                                  # exact duplicate
+    scores = synth.uniform(s, 11, n, 0.1, 1.0)
+    scores = (np.argsort(np.argsort(scores)).astype(np.float32) + 1.0) / np.float32(n + 1)   # distinct scores
+    out = {'boxes': boxes, 'scores': scores}
+    tb, tsc = torch.from_numpy(boxes), torch.from_numpy(scores)
+    order = torch.sort(tsc, descending=True)[1]
+    iou = torch.zeros(n, n)
+    nmsmod.ref.boxes_iou_bev_cpu(tb[order].contiguous(), tb[order].contiguous(), iou)
+    out['iou_sorted'] = iou.numpy()
+    out['order'] = order.numpy()
+    for thr in (0.2, 0.3):
+        keep, _ = iou3d_nms_utils.nms_gpu(tb, tsc, thr)
+        out['keep_%02d' % int(thr * 10)] = keep.numpy()
+        print('g3 thr', thr, 'kept', keep.shape[0])
+    np.savez_compressed(os.path.join(HERE, 'g3_nms.npz'), **out)
+
+
+def g4_warp():
+    rh.install()
+    from pcdet.models.bev_layers.v2x_fusion_disco import transform_bev_img
+    out = {}
+    cases = []
+    for (H, pc_min, pix) in ((32, -12.8, 0.8), (128, -51.2, 0.8)):
+        yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='ij')
+        img = np.stack([xx + 1.0, yy + 1.0, 1000.0 + yy * H + xx], axis=0).astype(np.float32)
+        tfs = [(0.0, 0.0, 0.0), (0.0, 0.8, 0.0), (0.0, 0.4, -0.4), (0.0, -1.2, 2.0), (np.pi / 2, 0.0, 0.0), (0.3, 3.0, -2.0),
+               (-1.1, 5.1, 0.77), (np.pi, 0.4, 0.4)]
+        for i, (yaw, tx, ty) in enumerate(tfs):
+            T = np.eye(4, dtype=np.float64)
+            c, s = np.cos(yaw), np.sin(yaw)
+            T[:2, :2] = [[c, -s], [s, c]]
+            T[0, 3], T[1, 3] = tx, ty
+            Tt = torch.from_numpy(T).float()
+            res = transform_bev_img(Tt, torch.from_numpy(img), pc_min, pix).numpy()
+            key = 'H%d_case%d' % (H, i)
+            out[key + '_T'] = Tt.numpy()
+            out[key + '_out'] = res
+            cases.append(key)
+        out['H%d_img' % H] = img
+        out['H%d_params' % H] = np.array([pc_min, pix], dtype=np.float64)
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, 'g4_warp.npz'), **out)
+    print('g4', len(cases), 'cases')
+
+
+if __name__ == '__main__':
+    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
+    torch.set_num_threads(8)
+    if 'g3' in todo:
+        g3_nms()
+    if 'g4' in todo:
+        g4_warp()
+    if 'g1' in todo:
+        g1_single('car', 'v2x_pointpillar_basic_car.yaml', 'car', extra_points=hunter_edge_points)
+        g1_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', score_thresh=0.02)
+        g1_single('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', score_thresh=0.02)
+        g1_disco()
+    if 'g2' in todo:
+        g2_full()
