@@ -1,0 +1,192 @@
+/*
+ * pcp_hip.h -- C ABI of libpcp_hip.so: the MI355X (gfx950) kernels of the PointPillars collaborative-perception hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless its name ends in _host;
+ *   - the caller owns every buffer, including scratch ("workspace"), whose size it obtains from the matching
+ *     *_workspace_bytes() query; nothing is allocated, freed or synchronised inside a call (hipGraph-capturable);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - the return value is a status (PCP_OK = 0); the library never calls exit() (the reference's op does:
+ *     pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-38) and keeps no global mutable state (re-entrant);
+ *   - dense maps are NHWC float32 ("pixel-major": channels contiguous), the layout the MFMA implicit-GEMM tiles read
+ *     coalesced; the Python host exposes them to callers as NCHW-shaped channels_last views.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference repo root).
+ */
+#ifndef PCP_HIP_H
+#define PCP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCP_ABI_VERSION 1
+
+enum {
+  PCP_OK = 0,
+  PCP_ERR_ARG = 1,          /* bad argument (null pointer, size, alignment, unsupported shape) */
+  PCP_ERR_WORKSPACE = 2,    /* workspace too small */
+  PCP_ERR_LAUNCH = 3,       /* hipGetLastError() after a launch was not hipSuccess */
+  PCP_ERR_UNSUPPORTED = 4   /* valid request this build has no kernel for */
+};
+
+int pcp_abi_version(void);
+const char *pcp_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a1 / a4  dynamic pillarisation.
+ * Replaces: pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:96-108 and :137-147
+ *           (floor((xy - min) / voxel), x/y range mask, merged id b*nx*ny + cx*ny + cy, torch.unique(sorted,
+ *           return_inverse, return_counts)) -- bit exact, without a sort: dense per-cell counts + exclusive scan.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  float min_x, min_y, min_z;      /* POINT_CLOUD_RANGE[0:3] as float32 */
+  float voxel_x, voxel_y, voxel_z;/* VOXEL_SIZE as float32 */
+  int32_t nx, ny;                 /* grid (nz must be 1) */
+  int32_t batch_size;             /* frames sharing one call; batch index = (int) points[:,0] */
+} pcp_grid_t;
+
+/* counters written by pcp_voxelize at counters[0..3]: P (pillars), N' (kept points), reserved, reserved */
+#define PCP_VOX_COUNTERS 4
+
+size_t pcp_voxelize_workspace_bytes(const pcp_grid_t *grid, int64_t max_points);
+
+/* points: (n, row_stride) float32 rows [b, x, y, z, ...].  Outputs (caller-allocated for n rows, only the first P / N'
+ * entries are written): voxel_coords (P,4) int32 [b,0,y,x]; unq_inv (N',) int64; unq_cnt (P,) int32 (may be NULL);
+ * counters (PCP_VOX_COUNTERS,) int32.  The workspace keeps the bucketed point order for pcp_pfn_scatter. */
+int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid,
+                 void *workspace, size_t workspace_bytes,
+                 int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt, int32_t *counters, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a2 / a3 / a5  point feature build + two PFN layers + scatter to the dense BEV canvas, one kernel.
+ * Replaces: dynamic_pillar_vfe.py:110-126 (scatter_mean, f_cluster, f_center, concat), :35-46 (PFNLayerV2 x2:
+ *           Linear + BatchNorm1d(eval) + ReLU + torch_scatter.scatter_max) and
+ *           pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37 (canvas zero + indexed write).
+ * BatchNorm is folded by the host: w0 (32, num_raw+6), b0 (32), w1 (64, 64), b1 (64), row-major float32.
+ * canvas: (B, ny, nx, 64) NHWC, must be zero where no pillar lands (pcp_fill_zero or a previous pcp_canvas_clear);
+ * pillar_features: (P, 64) or NULL.  Must follow pcp_voxelize on the same workspace and stream.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_pfn_scatter(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid,
+                    const void *workspace, const float *w0, const float *b0, const float *w1, const float *b1,
+                    float *pillar_features, float *canvas, void *stream);
+
+/* zero the canvas rows written by an earlier pcp_pfn_scatter (reads the pillar list still held in that call's
+ * workspace; n = the point count of that call): P * 256 B instead of re-zeroing B * ny * nx * 256 B */
+int pcp_canvas_clear(const pcp_grid_t *grid, const void *workspace, int64_t n, float *canvas, void *stream);
+int pcp_fill_zero(void *ptr, size_t bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a6 / a7 / a12 / a14  dense 2D convolutions as fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32), BN folded,
+ * bias + optional ReLU fused.
+ * Replaces: cuDNN Conv2d/ConvTranspose2d + BatchNorm2d + ReLU stacks of
+ *           pcdet/models/backbones_2d/base_bev_backbone.py:30-69, pcdet/models/dense_heads/center_head.py:24-29,75-82,
+ *           pcdet/models/bev_layers/v2x_fusion_disco.py:51-63, pcdet/models/bev_layers/hunter_jr.py:132,149-152.
+ * Tensors are NHWC; `ld*` = floats between consecutive pixels (>= channels) so channel slices of a wider buffer
+ * (the 384-channel concat, the 768-channel HunterJr input) are addressed in place.
+ * Packed weights (host packs once): 3x3 -> [Cin/16][9][cout_pad][16]; pointwise -> [K/16][n_pad][16]; bias [cout_pad].
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch, in_h, in_w;      /* input spatial size */
+  int32_t cin, cout;              /* cin % 16 == 0 */
+  int32_t cout_pad;               /* padded output channels of the packed weights (multiple of 32) */
+  int32_t stride;                 /* 1 or 2 (3x3, padding 1) */
+  int32_t ld_in, ld_out;          /* pixel strides in floats */
+  int32_t relu;                   /* 1: max(x, 0) after bias */
+} pcp_conv3x3_t;
+
+int pcp_conv3x3(const pcp_conv3x3_t *desc, const float *in, const float *w_packed, const float *bias, float *out,
+                void *stream);
+
+enum {
+  PCP_PW_PLAIN = 0,       /* rows = pixels (or points): out[m, n] = sum_k in[m, k] w[n, k]                       */
+  PCP_PW_SPACE2DEPTH = 1, /* Conv2d k=2 s=2: K = 4*cin gathered from the 2x2 input block of each output pixel    */
+  PCP_PW_DEPTH2SPACE = 2  /* ConvTranspose2d k=2 s=2: N = 4*cout scattered to the 2x2 output block               */
+};
+
+typedef struct {
+  int32_t mode;
+  int64_t rows;                   /* PLAIN: number of rows; otherwise ignored (derived from batch/h/w) */
+  int32_t batch, in_h, in_w;      /* spatial modes: input size */
+  int32_t cin, cout, cout_pad;    /* per-tap channels; cout_pad = padded n of the packed weights per tap */
+  int32_t ld_in, ld_out;
+  int32_t relu;
+} pcp_pointwise_t;
+
+int pcp_pointwise(const pcp_pointwise_t *desc, const float *in, const float *w_packed, const float *bias, float *out,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a8  CenterHead decode: sigmoid / exp / atan2, top-K over the heat map, box assembly, range + score mask.
+ * Replaces: pcdet/models/dense_heads/center_head.py:302-333 and pcdet/models/model_utils/centernet_utils.py:127-214.
+ * head: (B, H, W, ld) NHWC holding center(2), center_z(1), dim(3), rot(2) = (cos, sin) and hm(num_class) at the
+ * channel offsets given in the descriptor.  Ties in the top-K go to the lower flat (class, cell) index.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch, h, w, ld;        /* head buffer (B, H, W, ld) NHWC */
+  int32_t num_class;              /* heat-map channels; num_class * h * w <= 16384 */
+  int32_t ch_center, ch_z, ch_dim, ch_rot, ch_hm;   /* channel offsets inside a pixel */
+  int32_t k;                      /* MAX_OBJ_PER_SAMPLE (<= 1024) */
+  float stride;                   /* FEATURE_MAP_STRIDE */
+  float voxel_x, voxel_y, min_x, min_y;
+  float limit[6];                 /* POST_CENTER_LIMIT_RANGE (inclusive both ends) */
+  int32_t use_score_thresh;       /* SCORE_THRESH is not None */
+  float score_thresh;             /* strict > */
+} pcp_decode_t;
+
+size_t pcp_decode_workspace_bytes(const pcp_decode_t *desc);
+/* Outputs per frame b (capacity k rows each): boxes (B,k,7), scores (B,k), labels (B,k) int32 0-based class (may be
+ * NULL), cell (B,k) int32 flat y*w+x (may be NULL), count (B,) int32 -- rows in descending score order. */
+int pcp_centerhead_decode(const pcp_decode_t *desc, const float *head, void *workspace, size_t workspace_bytes,
+                          float *boxes, float *scores, int32_t *labels, int32_t *cell, int32_t *count, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a9  rotated BEV IoU + NMS, entirely on the device.
+ * Replaces: pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17 -> iou3d_nms.cpp:52-136 + iou3d_nms_kernel.cu:236-311
+ *           (boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu) and the score sort of iou3d_nms_utils.py:92-95.
+ * pcp_nms_rotated: boxes (n_max,7) + scores (n_max); n is read from *n_dev when n_dev != NULL (else n_max).
+ *   Sorts by descending score (bitonic, ties by lower index), builds the 64x64-tile suppression bit mask, runs the
+ *   greedy sweep in one wavefront.  keep (post_max,) int32 indices into the INPUT order; keep_count (1,) int32.
+ *   scores == NULL means "boxes are already in descending score order" (skips the sort).  n_max <= 4096.
+ * ------------------------------------------------------------------------------------------------------------------ */
+size_t pcp_nms_workspace_bytes(int32_t n_max);
+int pcp_nms_rotated(const float *boxes, const float *scores, int32_t n_max, const int32_t *n_dev, float thresh,
+                    int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+                    int32_t *keep, int32_t *keep_count, void *stream);
+/* mode 0: overlap area (boxes_overlap_bev_gpu), mode 1: IoU (boxes_iou_bev_gpu); out (na, nb) float32 */
+int pcp_boxes_bev_pairwise(const float *a, int32_t na, const float *b, int32_t nb, int32_t mode, float *out,
+                           void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a11 / a12  DiscoNet mid fusion: nearest affine warp and pixel-wise softmax-weighted sum.
+ * Replaces: pcdet/models/bev_layers/v2x_fusion_disco.py:29-45 (transform_bev_img = affine_grid + grid_sample nearest,
+ *           align_corners=False, zero padding) and :104-115 (softmax over agents + weighted sum).
+ * theta: (2,3) float32 row-major (host computes it exactly as :32-35).  src/dst: (H, W, ld) NHWC, c channels copied.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst,
+                     const float *theta_host, int32_t accumulate, void *stream);
+/* maps_host: HOST array of n_agents (<= 16) DEVICE pointers, each (pixels, ld_map); weights: (pixels, ld_w) logits, one
+ * column per agent; out[p, :] = sum_a softmax_a(weights[p, :])[a] * maps[a][p, :] */
+int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const float *weights, int32_t ld_w, int64_t pixels,
+                     int32_t c, int32_t ld_map, int32_t ld_out, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a14  HunterJr point <-> BEV ops.
+ * Replaces: pcdet/models/bev_layers/hunter_toolbox.py:8-39,94-127 (bilinear sampling of a BEV map at point locations)
+ *           and :65-91 (bev_scatter: strict float mask, truncation, torch.unique + scatter_mean).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_bev_sample_bilinear(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                            const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                            float pix_y, const uint8_t *row_mask, float *out, int32_t ld_out, void *stream);
+size_t pcp_bev_scatter_mean_workspace_bytes(int32_t batch, int32_t h, int32_t w, int64_t n);
+int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_stride, const float *feat, int32_t ld_feat,
+                         int32_t c, int32_t batch, int32_t h, int32_t w, float min_x, float min_y, float pix_x,
+                         float pix_y, void *workspace, size_t workspace_bytes, float *out, int32_t ld_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCP_HIP_H */

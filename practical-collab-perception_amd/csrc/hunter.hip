@@ -1,0 +1,233 @@
+// a14 -- HunterJr point <-> BEV operators (configs 1 and 2 only).
+//
+// Replaces pcdet/models/bev_layers/hunter_toolbox.py:8-39,94-127 (bilinear sampling of the BEV map at every point:
+// four fancy-index gathers, four weight vectors and three transposes per frame) and :65-91 (bev_scatter: float-coordinate
+// mask, truncation, torch.unique + torch_scatter.scatter_mean, dense re-layout).
+//
+//  * pcp_bev_sample_bilinear: one thread per (point, 4 channels); the four neighbour rows are contiguous C-float rows of
+//    the NHWC map (L2-resident: 25 MB at 384x128x128), products and sums in the reference's order.
+//  * pcp_bev_scatter_mean: counting sort of the kept points by BEV cell (dense B*H*W table, scan, bucket fill), then one
+//    workgroup per cell sums its rows IN POINT-INDEX ORDER (the bucket is sorted in LDS first), so the fp32 result is
+//    independent of atomic arrival order and equals a sequential index_add_; empty cells are written as zeros by the
+//    same kernel (no separate clear of the 25 MB map).
+#include "pcp_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__global__ void k_bilinear(const float *__restrict__ bev, int batch, int h, int w, int c4, int ld_bev,
+                           const float *__restrict__ points, long long n, int stride, float min_x, float min_y, float pix_x,
+                           float pix_y, const unsigned char *__restrict__ row_mask, float *__restrict__ out, int ld_out) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c4) return;
+  int q = (int)(t % c4);
+  long long i = t / c4;
+  if (row_mask && !row_mask[i]) return;
+  const float *row = points + i * stride;
+  int b = (int)row[0];
+  if (b < 0 || b >= batch) return;
+  float x = __fdiv_rn(row[1] - min_x, pix_x), y = __fdiv_rn(row[2] - min_y, pix_y);
+  // floor / +1 / clamp on the integer side, weights from the CLAMPED corners (hunter_toolbox.py:19-37)
+  float fx0 = floorf(x), fy0 = floorf(y);
+  // .long() of an out-of-range float is undefined in the reference; clamp in float first (same result in range)
+  fx0 = fminf(fmaxf(fx0, -2.0f), (float)w + 1.0f);
+  fy0 = fminf(fmaxf(fy0, -2.0f), (float)h + 1.0f);
+  int x0 = (int)fx0, y0 = (int)fy0;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  x0 = min(max(x0, 0), w - 1);
+  x1 = min(max(x1, 0), w - 1);
+  y0 = min(max(y0, 0), h - 1);
+  y1 = min(max(y1, 0), h - 1);
+  float wa = ((float)x1 - x) * ((float)y1 - y);
+  float wb = ((float)x1 - x) * (y - (float)y0);
+  float wc = (x - (float)x0) * ((float)y1 - y);
+  float wd = (x - (float)x0) * (y - (float)y0);
+  const float *img = bev + (long long)b * h * w * ld_bev + q * 4;
+  float4 Ia = *reinterpret_cast<const float4 *>(img + ((long long)y0 * w + x0) * ld_bev);
+  float4 Ib = *reinterpret_cast<const float4 *>(img + ((long long)y1 * w + x0) * ld_bev);
+  float4 Ic = *reinterpret_cast<const float4 *>(img + ((long long)y0 * w + x1) * ld_bev);
+  float4 Id = *reinterpret_cast<const float4 *>(img + ((long long)y1 * w + x1) * ld_bev);
+  float4 r;
+  r.x = Ia.x * wa + Ib.x * wb + Ic.x * wc + Id.x * wd;
+  r.y = Ia.y * wa + Ib.y * wb + Ic.y * wc + Id.y * wd;
+  r.z = Ia.z * wa + Ib.z * wb + Ic.z * wc + Id.z * wd;
+  r.w = Ia.w * wa + Ib.w * wb + Ic.w * wc + Id.w * wd;
+  *reinterpret_cast<float4 *>(out + i * ld_out + q * 4) = r;
+}
+
+struct ScLayout {
+  size_t cell_count, cell_fill, cell_start, point_cell, bucket, total;
+};
+inline ScLayout sc_layout(long long cells, long long n) {
+  ScLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = pcp_align_up(off + bytes, 256); return o; };
+  L.cell_count = take((size_t)cells * 4);
+  L.cell_fill = take((size_t)cells * 4);
+  L.cell_start = take((size_t)(cells + 1) * 4);
+  L.point_cell = take((size_t)(n > 0 ? n : 1) * 4);
+  L.bucket = take((size_t)(n > 0 ? n : 1) * 4);
+  L.total = off;
+  return L;
+}
+
+__global__ void k_sc_cells(const float *__restrict__ points, long long n, int stride, int batch, int h, int w, float min_x,
+                           float min_y, float pix_x, float pix_y, int *__restrict__ cell_count, int *__restrict__ point_cell) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *row = points + i * stride;
+  int b = (int)row[0];
+  float x = __fdiv_rn(row[1] - min_x, pix_x), y = __fdiv_rn(row[2] - min_y, pix_y);
+  // strict float comparisons BEFORE truncation (hunter_toolbox.py:80-84)
+  bool ok = (x > 0.0f) && (x < (float)w) && (y > 0.0f) && (y < (float)h) && b >= 0 && b < batch;
+  int cell = -1;
+  if (ok) {
+    cell = b * h * w + (int)y * w + (int)x;
+    atomicAdd(&cell_count[cell], 1);
+  }
+  point_cell[i] = cell;
+}
+
+__global__ __launch_bounds__(1024) void k_sc_scan(const int *__restrict__ cell_count, long long cells, int *__restrict__ cell_start) {
+  __shared__ int wave_sum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long base = 0; base < cells; base += 1024) {
+    long long idx = base + threadIdx.x;
+    int v = idx < cells ? cell_count[idx] : 0;
+    int incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      int u = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += u;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int k = 0; k < 16; k++) {
+      int s = wave_sum[k];
+      if (k < wave) wbase += s;
+      tot += s;
+    }
+    int carry = carry_s;
+    if (idx < cells) cell_start[idx] = carry + wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cell_start[cells] = carry_s;
+}
+
+__global__ void k_sc_fill(const int *__restrict__ point_cell, long long n, const int *__restrict__ cell_start,
+                          int *__restrict__ cell_fill, int *__restrict__ bucket) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int c = point_cell[i];
+  if (c < 0) return;
+  bucket[cell_start[c] + atomicAdd(&cell_fill[c], 1)] = (int)i;
+}
+
+constexpr int SC_THREADS = 128;
+constexpr int SC_SORT_CAP = 1024;
+
+__global__ __launch_bounds__(SC_THREADS) void k_sc_mean(const int *__restrict__ cell_start, const int *__restrict__ bucket,
+                                                        const float *__restrict__ feat, int ld_feat, int c4,
+                                                        float *__restrict__ out, int ld_out) {
+  __shared__ int ids[SC_SORT_CAP];
+  const long long cell = blockIdx.x;
+  const int s0 = cell_start[cell], cnt = cell_start[cell + 1] - s0;
+  float4 *orow = reinterpret_cast<float4 *>(out + cell * ld_out);
+  if (cnt == 0) {
+    for (int q = threadIdx.x; q < c4; q += SC_THREADS) orow[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const bool sorted = cnt <= SC_SORT_CAP;
+  if (sorted) {
+    int cap = 2;
+    while (cap < cnt) cap <<= 1;
+    for (int i = threadIdx.x; i < cap; i += SC_THREADS) ids[i] = i < cnt ? bucket[s0 + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= cap; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < cap / 2; t += SC_THREADS) {
+          int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          int q = i | j;
+          bool asc = (i & k) == 0;
+          int a = ids[i], b = ids[q];
+          if ((a > b) == asc) { ids[i] = b; ids[q] = a; }
+        }
+        __syncthreads();
+      }
+  }
+  const float inv_unused = 0.f;
+  (void)inv_unused;
+  for (int q = threadIdx.x; q < c4; q += SC_THREADS) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < cnt; k++) {
+      int pid = sorted ? ids[k] : bucket[s0 + k];
+      float4 v = *reinterpret_cast<const float4 *>(feat + (long long)pid * ld_feat + q * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float fc = (float)cnt;
+    acc.x /= fc; acc.y /= fc; acc.z /= fc; acc.w /= fc;
+    orow[q] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_bev_sample_bilinear(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                                       const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                                       float pix_y, const uint8_t *row_mask, float *out, int32_t ld_out, void *stream_) {
+  if (!bev || !out || n < 0 || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (ld_bev & 3) || (ld_out & 3) ||
+      row_stride < 3)
+    return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  if (!points) return PCP_ERR_ARG;
+  long long total = (long long)n * (c / 4);
+  hipLaunchKernelGGL(k_bilinear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, bev, batch, h, w, c / 4,
+                     ld_bev, points, (long long)n, row_stride, min_x, min_y, pix_x, pix_y, row_mask, out, ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" size_t pcp_bev_scatter_mean_workspace_bytes(int32_t batch, int32_t h, int32_t w, int64_t n) {
+  return sc_layout((long long)batch * h * w, n).total;
+}
+
+extern "C" int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_stride, const float *feat, int32_t ld_feat,
+                                    int32_t c, int32_t batch, int32_t h, int32_t w, float min_x, float min_y, float pix_x,
+                                    float pix_y, void *workspace, size_t workspace_bytes, float *out, int32_t ld_out,
+                                    void *stream_) {
+  if (!workspace || !out || n < 0 || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (ld_feat & 3) || (ld_out & 3) ||
+      row_stride < 3)
+    return PCP_ERR_ARG;
+  if (n > 0 && (!points || !feat)) return PCP_ERR_ARG;
+  const long long cells = (long long)batch * h * w;
+  ScLayout L = sc_layout(cells, n);
+  if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream_;
+  char *ws = (char *)workspace;
+  int *cell_count = (int *)(ws + L.cell_count), *cell_fill = (int *)(ws + L.cell_fill);
+  int *cell_start = (int *)(ws + L.cell_start), *point_cell = (int *)(ws + L.point_cell), *bucket = (int *)(ws + L.bucket);
+  if (hipMemsetAsync(cell_count, 0, L.cell_start - L.cell_count, st) != hipSuccess) return PCP_ERR_LAUNCH;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_sc_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, points, (long long)n, row_stride, batch, h, w,
+                       min_x, min_y, pix_x, pix_y, cell_count, point_cell);
+    PCP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_sc_scan, dim3(1), dim3(1024), 0, st, cell_count, cells, cell_start);
+  PCP_CHECK_LAUNCH();
+  if (n > 0) {
+    hipLaunchKernelGGL(k_sc_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, point_cell, (long long)n, cell_start,
+                       cell_fill, bucket);
+    PCP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_sc_mean, dim3((unsigned)cells), dim3(SC_THREADS), 0, st, cell_start, bucket, feat, ld_feat, c / 4, out,
+                     ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

@@ -1,0 +1,246 @@
+// a2 / a3 / a5 -- point features + PillarFeatureNet (2 layers) + scatter to the dense NHWC canvas, fused in one kernel.
+//
+// Reference path replaced (pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:110-126, :35-46 and
+// pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37):
+//   mean = scatter_mean(xyz); f = [raw, xyz - mean, xyz - cell_centre]; x = relu(bn(W0 f)); xm = scatter_max(x);
+//   y = relu(bn(W1 [x, xm[inv]])); out = scatter_max(y); canvas[:, y, x] = out.
+// Five (N', .) temporaries and three torch_scatter launches in the reference; here a workgroup owns PILLARS_PER_BLOCK
+// consecutive pillars (their points are one contiguous run of the bucket order built by pcp_voxelize), keeps the
+// per-pillar maxima in LDS and writes each finished pillar as one 256-byte row of the NHWC canvas.
+//
+// Determinism: the per-pillar mean is accumulated in 2^-24 fixed point (integer adds commute), the maxima are
+// order-independent, so the result does not depend on the bucket order.
+//
+// HBM bytes per frame (algorithmic): n * row_stride * 4 (points, read once through the bucket gather; the second and
+// third sweeps hit L2) + P * 256 (canvas rows) [+ P * 256 pillar_features when requested].
+#include "pcp_common.h"
+
+namespace {
+
+constexpr int PFN_THREADS = 256;
+constexpr int PILLARS_PER_BLOCK = 64;
+constexpr int C0 = 32;   // first PFN layer width  (NUM_FILTERS[0] / 2)
+constexpr int C1 = 64;   // second PFN layer width (NUM_FILTERS[1])
+constexpr int MAX_F = 24;  // num_raw + 6 <= 24
+
+struct PfnParams {
+  const float *points;
+  long long n;
+  int stride;
+  int num_raw;
+  pcp_grid_t g;
+  const int *bucket_order;
+  const int *pillar_cell;
+  const int *pillar_start;
+  const int *counters;
+  const float *w0, *b0, *w1, *b1;
+  float *pillar_features;
+  float *canvas;
+};
+
+__device__ __forceinline__ int find_pillar(const int *pl_start, int np, int slot) {
+  // largest p with pl_start[p] <= slot  (pl_start is ascending, pl_start[np] = end)
+  int lo = 0, hi = np - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (pl_start[mid] <= slot) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <int NUM_RAW>
+__global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
+  constexpr int F = NUM_RAW + 6;
+  __shared__ int pl_start[PILLARS_PER_BLOCK + 1];
+  __shared__ long long sum_fx[PILLARS_PER_BLOCK][3];
+  __shared__ float mean[PILLARS_PER_BLOCK][3];
+  __shared__ int xmax0[PILLARS_PER_BLOCK][C0];       // float bits; values are >= 0 after ReLU so int order == float order
+  __shared__ float pterm[PILLARS_PER_BLOCK][C1];     // b1 + W1[:, 32:64] . xmax0[pillar]
+  __shared__ int xmax1[PILLARS_PER_BLOCK][C1];
+
+  const int P = p.counters[0];
+  const int r0 = blockIdx.x * PILLARS_PER_BLOCK;
+  if (r0 >= P) return;
+  const int np = min(PILLARS_PER_BLOCK, P - r0);
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i <= np; i += PFN_THREADS) pl_start[i] = p.pillar_start[r0 + i];
+  for (int i = tid; i < PILLARS_PER_BLOCK * 3; i += PFN_THREADS) (&sum_fx[0][0])[i] = 0;
+  for (int i = tid; i < PILLARS_PER_BLOCK * C0; i += PFN_THREADS) (&xmax0[0][0])[i] = 0;
+  for (int i = tid; i < PILLARS_PER_BLOCK * C1; i += PFN_THREADS) (&xmax1[0][0])[i] = 0;
+  __syncthreads();
+  const int s0 = pl_start[0], s1 = pl_start[np];
+
+  // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (deterministic) ---------------------------------------------
+  for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+    int pl = find_pillar(pl_start, np, s);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      long long q = __double2ll_rn((double)row[1 + a] * 16777216.0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < np * 3; i += PFN_THREADS) {
+    int pl = i / 3, a = i % 3;
+    int cnt = pl_start[pl + 1] - pl_start[pl];
+    mean[pl][a] = (float)(((double)sum_fx[pl][a] * (1.0 / 16777216.0)) / (double)cnt);
+  }
+  __syncthreads();
+
+  const int plane = p.g.nx * p.g.ny;
+  // cell-centre offsets exactly as the reference constructor rounds them (dynamic_pillar_vfe.py:80-82)
+  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
+  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
+  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
+
+  auto build_features = [&](int s, int pl, float (&f)[F]) {
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+#pragma unroll
+    for (int k = 0; k < NUM_RAW; k++) f[k] = row[1 + k];
+    int cell = p.pillar_cell[r0 + pl];
+    int rem = cell % plane;
+    float cx = (float)(rem / p.g.ny), cy = (float)(rem % p.g.ny);
+    f[NUM_RAW + 0] = __fsub_rn(f[0], mean[pl][0]);
+    f[NUM_RAW + 1] = __fsub_rn(f[1], mean[pl][1]);
+    f[NUM_RAW + 2] = __fsub_rn(f[2], mean[pl][2]);
+    f[NUM_RAW + 3] = __fsub_rn(f[0], __fadd_rn(__fmul_rn(cx, p.g.voxel_x), x_off));
+    f[NUM_RAW + 4] = __fsub_rn(f[1], __fadd_rn(__fmul_rn(cy, p.g.voxel_y), y_off));
+    f[NUM_RAW + 5] = __fsub_rn(f[2], z_off);
+  };
+  auto layer0 = [&](const float (&f)[F], float (&x)[C0]) {
+#pragma unroll
+    for (int c = 0; c < C0; c++) {
+      float acc = p.b0[c];                          // wave-uniform addresses -> scalar loads, weights stay in SGPRs
+#pragma unroll
+      for (int k = 0; k < F; k++) acc = fmaf(p.w0[c * F + k], f[k], acc);
+      x[c] = fmaxf(acc, 0.0f);
+    }
+  };
+
+  // ---- sweep 2: layer 0 + per-pillar max -------------------------------------------------------------------------------
+  for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
+    int pl = find_pillar(pl_start, np, s);
+    float f[F], x[C0];
+    build_features(s, pl, f);
+    layer0(f, x);
+#pragma unroll
+    for (int c = 0; c < C0; c++) atomicMax(&xmax0[pl][c], __float_as_int(x[c]));
+  }
+  __syncthreads();
+
+  // ---- per-pillar half of layer 1: pterm = b1 + W1[:, C0:2*C0] . xmax0 ------------------------------------------------
+  for (int i = tid; i < np * C1; i += PFN_THREADS) {
+    int pl = i / C1, o = i % C1;
+    float acc = p.b1[o];
+    const float *wr = p.w1 + o * (2 * C0) + C0;
+#pragma unroll 8
+    for (int k = 0; k < C0; k++) acc = fmaf(wr[k], __int_as_float(xmax0[pl][k]), acc);
+    pterm[pl][o] = acc;
+  }
+  __syncthreads();
+
+  // ---- sweep 3: layer 1 (point half) + per-pillar max -----------------------------------------------------------------
+  for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
+    int pl = find_pillar(pl_start, np, s);
+    float f[F], x[C0];
+    build_features(s, pl, f);
+    layer0(f, x);
+#pragma unroll 2
+    for (int o = 0; o < C1; o++) {
+      float acc = pterm[pl][o];
+      const float *wr = p.w1 + o * (2 * C0);       // wave-uniform address -> scalar loads
+#pragma unroll
+      for (int k = 0; k < C0; k++) acc = fmaf(wr[k], x[k], acc);
+      atomicMax(&xmax1[pl][o], __float_as_int(fmaxf(acc, 0.0f)));
+    }
+  }
+  __syncthreads();
+
+  // ---- write-out: one 256-B row per pillar --------------------------------------------------------------------------
+  for (int i = tid; i < np * C1; i += PFN_THREADS) {
+    int pl = i / C1, o = i % C1;
+    float v = __int_as_float(xmax1[pl][o]);
+    if (p.pillar_features) p.pillar_features[(long long)(r0 + pl) * C1 + o] = v;
+    if (p.canvas) {
+      int cell = p.pillar_cell[r0 + pl];
+      int b = cell / plane, rem = cell % plane;
+      int cx = rem / p.g.ny, cy = rem % p.g.ny;
+      p.canvas[(((long long)b * p.g.ny + cy) * p.g.nx + cx) * C1 + o] = v;
+    }
+  }
+}
+
+__global__ void k_canvas_clear(const int *__restrict__ pillar_cell, const int *__restrict__ counters, pcp_grid_t g,
+                               float *__restrict__ canvas) {
+  const int P = counters[0];
+  const int plane = g.nx * g.ny;
+  // 16 lanes x float4 per pillar row (64 floats)
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = t; i < (long long)P * 16; i += stride) {
+    int r = (int)(i >> 4), q = (int)(i & 15);
+    int cell = pillar_cell[r];
+    int b = cell / plane, rem = cell % plane;
+    int cx = rem / g.ny, cy = rem % g.ny;
+    float4 *dst = reinterpret_cast<float4 *>(canvas + (((long long)b * g.ny + cy) * g.nx + cx) * C1) + q;
+    *dst = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_pfn_scatter(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid,
+                               const void *workspace, const float *w0, const float *b0, const float *w1, const float *b1,
+                               float *pillar_features, float *canvas, void *stream_) {
+  if (!grid || !workspace || !w0 || !b0 || !w1 || !b1 || n < 0) return PCP_ERR_ARG;
+  if (row_stride < 1 + num_raw || num_raw < 3) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  VoxLayout L = pcp_vox_layout(cells, n);
+  const char *ws = (const char *)workspace;
+  PfnParams p;
+  p.points = points;
+  p.n = n;
+  p.stride = row_stride;
+  p.num_raw = num_raw;
+  p.g = *grid;
+  p.bucket_order = (const int *)(ws + L.bucket_order);
+  p.pillar_cell = (const int *)(ws + L.pillar_cell);
+  p.pillar_start = (const int *)(ws + L.pillar_start);
+  p.counters = (const int *)(ws + L.counters);
+  p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
+  p.pillar_features = pillar_features;
+  p.canvas = canvas;
+  int64_t max_pillars = n < cells ? n : cells;
+  int blocks = (int)((max_pillars + PILLARS_PER_BLOCK - 1) / PILLARS_PER_BLOCK);
+  hipStream_t stream = (hipStream_t)stream_;
+  switch (num_raw) {
+    case 5: hipLaunchKernelGGL(k_pfn<5>, dim3(blocks), dim3(PFN_THREADS), 0, stream, p); break;
+    case 11: hipLaunchKernelGGL(k_pfn<11>, dim3(blocks), dim3(PFN_THREADS), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL(k_pfn<3>, dim3(blocks), dim3(PFN_THREADS), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL(k_pfn<4>, dim3(blocks), dim3(PFN_THREADS), 0, stream, p); break;
+    default: return PCP_ERR_UNSUPPORTED;
+  }
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_canvas_clear(const pcp_grid_t *grid, const void *workspace, int64_t n, float *canvas, void *stream_) {
+  if (!grid || !workspace || !canvas || n < 0) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  VoxLayout L = pcp_vox_layout(cells, n);
+  const char *ws = (const char *)workspace;
+  hipLaunchKernelGGL(k_canvas_clear, dim3(1024), dim3(256), 0, (hipStream_t)stream_, (const int *)(ws + L.pillar_cell),
+                     (const int *)(ws + L.counters), *grid, canvas);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_fill_zero(void *ptr, size_t bytes, void *stream_) {
+  if (!ptr && bytes) return PCP_ERR_ARG;
+  if (bytes == 0) return PCP_OK;
+  return hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream_) == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+}

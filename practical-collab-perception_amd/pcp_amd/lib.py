@@ -1,0 +1,97 @@
+"""ctypes binding of libpcp_hip.so (the C ABI declared in include/pcp_hip.h).
+
+The library is built in-tree by `make -C practical-collab-perception_amd/csrc` (or __graft_entry__.build()).  There is NO
+fallback: if the shared object is missing or a symbol cannot be resolved the import of the product path fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.abspath(os.path.join(_HERE, '..', 'lib', 'libpcp_hip.so'))
+
+c_f = ctypes.c_float
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_sz = ctypes.c_size_t
+vp = ctypes.c_void_p
+
+
+class Grid(ctypes.Structure):
+    _fields_ = [('min_x', c_f), ('min_y', c_f), ('min_z', c_f), ('voxel_x', c_f), ('voxel_y', c_f), ('voxel_z', c_f),
+                ('nx', c_i32), ('ny', c_i32), ('batch_size', c_i32)]
+
+
+class Conv3x3(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32), ('cout', c_i32), ('cout_pad', c_i32),
+                ('stride', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32)]
+
+
+class Pointwise(ctypes.Structure):
+    _fields_ = [('mode', c_i32), ('rows', c_i64), ('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32),
+                ('cout', c_i32), ('cout_pad', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32)]
+
+
+class Decode(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('ld', c_i32), ('num_class', c_i32), ('ch_center', c_i32),
+                ('ch_z', c_i32), ('ch_dim', c_i32), ('ch_rot', c_i32), ('ch_hm', c_i32), ('k', c_i32), ('stride', c_f),
+                ('voxel_x', c_f), ('voxel_y', c_f), ('min_x', c_f), ('min_y', c_f), ('limit', c_f * 6),
+                ('use_score_thresh', c_i32), ('score_thresh', c_f)]
+
+
+PW_PLAIN, PW_SPACE2DEPTH, PW_DEPTH2SPACE = 0, 1, 2
+
+# every symbol include/pcp_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'pcp_abi_version': (c_i32, []),
+    'pcp_status_string': (ctypes.c_char_p, [c_i32]),
+    'pcp_voxelize_workspace_bytes': (c_sz, [ctypes.POINTER(Grid), c_i64]),
+    'pcp_voxelize': (c_i32, [vp, c_i64, c_i32, ctypes.POINTER(Grid), vp, c_sz, vp, vp, vp, vp, vp]),
+    'pcp_pfn_scatter': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_canvas_clear': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp]),
+    'pcp_fill_zero': (c_i32, [vp, c_sz, vp]),
+    'pcp_conv3x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
+    'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
+    'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
+    'pcp_nms_workspace_bytes': (c_sz, [c_i32]),
+    'pcp_nms_rotated': (c_i32, [vp, vp, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
+    'pcp_boxes_bev_pairwise': (c_i32, [vp, c_i32, vp, c_i32, c_i32, vp, vp]),
+    'pcp_warp_nearest': (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp]),
+    'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
+    'pcp_bev_sample_bilinear': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp,
+                                        c_i32, vp]),
+    'pcp_bev_scatter_mean_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32, c_i64]),
+    'pcp_bev_scatter_mean': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, vp, c_sz,
+                                     vp, c_i32, vp]),
+}
+
+_LIB = None
+
+
+class PcpError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once; raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.isfile(LIB_PATH):
+        raise PcpError('libpcp_hip.so not found at %s -- build it with `make -C practical-collab-perception_amd/csrc` '
+                       '(or python -c "import __graft_entry__ as g; g.build()"); there is no CPU fallback.' % LIB_PATH)
+    import torch  # noqa: F401  -- makes sure torch's own libamdhip64 (same SONAME) is the HIP runtime both sides use
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pcp_abi_version() != 1:
+        raise PcpError('libpcp_hip.so ABI version mismatch')
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise PcpError('%s failed: %s' % (what, load().pcp_status_string(status).decode()))

@@ -1,0 +1,260 @@
+"""Tensor-level wrappers over the C ABI: argument checks, workspace allocation through torch (device memory and streams are
+torch's job; the arithmetic is not), and NHWC bookkeeping.  Every function requires CUDA tensors and raises otherwise --
+there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+from .lib import Conv3x3, Decode, Grid, Pointwise, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.PcpError('the HIP hot path needs CUDA/ROCm tensors (got a %s tensor); no CPU fallback exists' % t.device)
+
+
+def make_grid(pc_range, voxel_size, grid_size, batch_size):
+    import numpy as np
+    r = np.asarray(pc_range, dtype=np.float32)
+    v = np.asarray(voxel_size, dtype=np.float32)
+    return Grid(float(r[0]), float(r[1]), float(r[2]), float(v[0]), float(v[1]), float(v[2]), int(grid_size[0]),
+                int(grid_size[1]), int(batch_size))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NHWC helpers: a "map" is a contiguous (B, H, W, C) tensor; callers see it as an NCHW-shaped channels_last view
+# ---------------------------------------------------------------------------------------------------------------------
+
+def as_nhwc(x):
+    """(B, C, H, W) tensor of any layout -> contiguous (B, H, W, C) storage (no copy when already channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw_view(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a1-a5
+# ---------------------------------------------------------------------------------------------------------------------
+
+class VoxelizeResult:
+    __slots__ = ('workspace', 'voxel_coords', 'unq_inv', 'unq_cnt', 'counters', 'n', 'grid', 'row_stride')
+
+
+def voxelize(points, grid, want_inverse=True, want_counts=True, workspace=None):
+    """points: (N, 1+C) float32 CUDA.  Returns VoxelizeResult with max-size outputs; counters = [P, N', 0, 0] on device."""
+    _need_cuda(points)
+    L = _lib.load()
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
+    n, stride = points.shape
+    need = L.pcp_voxelize_workspace_bytes(ctypes.byref(grid), n)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=points.device)
+    res = VoxelizeResult()
+    res.workspace = workspace
+    res.n = n
+    res.grid = grid
+    res.row_stride = stride
+    cap = max(n, 1)
+    res.voxel_coords = torch.empty((cap, 4), dtype=torch.int32, device=points.device)
+    res.unq_inv = torch.empty((cap,), dtype=torch.int64, device=points.device) if want_inverse else None
+    res.unq_cnt = torch.empty((cap,), dtype=torch.int32, device=points.device) if want_counts else None
+    res.counters = torch.zeros((4,), dtype=torch.int32, device=points.device)
+    check(L.pcp_voxelize(_p(points), n, stride, ctypes.byref(grid), _p(workspace), workspace.numel(), _p(res.voxel_coords),
+                         _p(res.unq_inv), _p(res.unq_cnt), _p(res.counters), _stream()), 'pcp_voxelize')
+    return res
+
+
+def pfn_scatter(points, vox, num_raw, w0, b0, w1, b1, canvas=None, pillar_features=None):
+    """Runs the fused PFN on the buckets left in vox.workspace.  canvas: (B, ny, nx, 64) NHWC, pre-zeroed."""
+    _need_cuda(points, w0, b0, w1, b1, canvas, pillar_features)
+    L = _lib.load()
+    for t in (w0, b0, w1, b1):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert w0.shape == (32, num_raw + 6) and w1.shape == (64, 64) and b0.shape == (32,) and b1.shape == (64,)
+    check(L.pcp_pfn_scatter(_p(points), vox.n, vox.row_stride, num_raw, ctypes.byref(vox.grid), _p(vox.workspace), _p(w0), _p(b0),
+                            _p(w1), _p(b1), _p(pillar_features), _p(canvas), _stream()), 'pcp_pfn_scatter')
+
+
+def canvas_clear(vox, canvas):
+    L = _lib.load()
+    check(L.pcp_canvas_clear(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(canvas), _stream()), 'pcp_canvas_clear')
+
+
+def fill_zero(t):
+    L = _lib.load()
+    check(L.pcp_fill_zero(_p(t), t.numel() * t.element_size(), _stream()), 'pcp_fill_zero')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a6 / a7 convolutions.  x: (B, H, W, ld) NHWC storage; channel windows are expressed by (tensor, channel offset, channels)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _chan_ptr(t, ch_off):
+    return ctypes.c_void_p(t.data_ptr() + 4 * ch_off)
+
+
+def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+    """x: (B, H, W, ld_in) float32 NHWC.  out: (B, Ho, Wo, ld_out) or None (allocated with ld_out = cout)."""
+    _need_cuda(x, packed, bias, out)
+    L = _lib.load()
+    B, H, W, ld_in = x.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    assert out.shape[:3] == (B, Ho, Wo) and x.is_contiguous() and out.is_contiguous()
+    assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3]
+    d = Conv3x3(B, H, W, cin, cout, cout_pad, stride, ld_in, out.shape[3], 1 if relu else 0)
+    check(L.pcp_conv3x3(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
+          'pcp_conv3x3')
+    return out
+
+
+def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+    """mode PW_PLAIN: x (..., ld_in) rows; PW_SPACE2DEPTH / PW_DEPTH2SPACE: x (B, H, W, ld_in)."""
+    _need_cuda(x, packed, bias, out)
+    L = _lib.load()
+    ld_in = x.shape[-1]
+    if mode == _lib.PW_PLAIN:
+        rows = x.numel() // ld_in
+        B = H = W = 0
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.float32, device=x.device)
+    else:
+        B, H, W, _ = x.shape
+        rows = 0
+        if out is None:
+            shp = (B, H // 2, W // 2, cout) if mode == _lib.PW_SPACE2DEPTH else (B, 2 * H, 2 * W, cout)
+            out = torch.empty(shp, dtype=torch.float32, device=x.device)
+    assert x.is_contiguous() and out.is_contiguous()
+    d = Pointwise(mode, rows, B, H, W, cin, cout, cout_pad, ld_in, out.shape[-1], 1 if relu else 0)
+    check(L.pcp_pointwise(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
+          'pcp_pointwise')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a8 / a9
+# ---------------------------------------------------------------------------------------------------------------------
+
+def centerhead_decode(head, desc_kwargs):
+    """head: (B, H, W, ld) NHWC.  Returns (boxes (B,K,7), scores (B,K), labels (B,K) i32, cell (B,K) i32, count (B,) i32)."""
+    _need_cuda(head)
+    L = _lib.load()
+    B, H, W, ld = head.shape
+    k = desc_kwargs['k']
+    d = Decode()
+    d.batch, d.h, d.w, d.ld = B, H, W, ld
+    d.num_class = desc_kwargs.get('num_class', 1)
+    d.ch_center, d.ch_z, d.ch_dim, d.ch_rot, d.ch_hm = (desc_kwargs[n] for n in ('ch_center', 'ch_z', 'ch_dim', 'ch_rot', 'ch_hm'))
+    d.k = k
+    d.stride = float(desc_kwargs['stride'])
+    d.voxel_x, d.voxel_y = desc_kwargs['voxel_x'], desc_kwargs['voxel_y']
+    d.min_x, d.min_y = desc_kwargs['min_x'], desc_kwargs['min_y']
+    for i, v in enumerate(desc_kwargs['limit']):
+        d.limit[i] = float(v)
+    st = desc_kwargs.get('score_thresh', None)
+    d.use_score_thresh = 0 if st is None else 1
+    d.score_thresh = 0.0 if st is None else float(st)
+    dev = head.device
+    boxes = torch.zeros((B, k, 7), dtype=torch.float32, device=dev)
+    scores = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    labels = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    cell = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    check(L.pcp_centerhead_decode(ctypes.byref(d), _p(head), ctypes.c_void_p(0), 0, _p(boxes), _p(scores), _p(labels), _p(cell),
+                                  _p(count), _stream()), 'pcp_centerhead_decode')
+    return boxes, scores, labels, cell, count
+
+
+def nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=None):
+    """boxes (n_max, 7) float32; scores (n_max,) or None (= already sorted).  Returns (keep (post_max,) i32, count (1,) i32)."""
+    _need_cuda(boxes, scores, n_dev)
+    L = _lib.load()
+    n_max = boxes.shape[0]
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[1] == 7
+    need = L.pcp_nms_workspace_bytes(n_max)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+    keep = torch.zeros((post_max,), dtype=torch.int32, device=boxes.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    check(L.pcp_nms_rotated(_p(boxes), _p(scores), n_max, _p(n_dev), float(thresh), int(pre_max), int(post_max), _p(workspace),
+                            workspace.numel(), _p(keep), _p(cnt), _stream()), 'pcp_nms_rotated')
+    return keep, cnt
+
+
+def boxes_bev_pairwise(a, b, mode):
+    _need_cuda(a, b)
+    L = _lib.load()
+    a = a[:, :7].contiguous()
+    b = b[:, :7].contiguous()
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(L.pcp_boxes_bev_pairwise(_p(a), a.shape[0], _p(b), b.shape[0], mode, _p(out), _stream()), 'pcp_boxes_bev_pairwise')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a11 / a12 / a14
+# ---------------------------------------------------------------------------------------------------------------------
+
+def warp_nearest(src, dst, theta, channels, accumulate=False, src_ch_off=0, dst_ch_off=0):
+    """src, dst: (H, W, ld) NHWC single-frame maps; theta: 6 python floats (row-major 2x3)."""
+    _need_cuda(src, dst)
+    L = _lib.load()
+    H, W, ld_s = src.shape
+    th = (ctypes.c_float * 6)(*[float(v) for v in theta])
+    check(L.pcp_warp_nearest(_chan_ptr(src, src_ch_off), _chan_ptr(dst, dst_ch_off), H, W, channels, ld_s, dst.shape[2], th,
+                             1 if accumulate else 0, _stream()), 'pcp_warp_nearest')
+
+
+def softmax_fuse(maps, weights, channels, out):
+    """maps: list of (B, H, W, ld_map) tensors (same ld); weights: (B, H, W, ld_w) logits, column a <-> maps[a]."""
+    _need_cuda(weights, out, *maps)
+    L = _lib.load()
+    n = len(maps)
+    arr = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
+    pixels = weights.numel() // weights.shape[-1]
+    check(L.pcp_softmax_fuse(arr, n, _p(weights), weights.shape[-1], pixels, channels, maps[0].shape[-1], out.shape[-1], _p(out),
+                             _stream()), 'pcp_softmax_fuse')
+    return out
+
+
+def bev_sample_bilinear(bev, points, min_xy, pix_xy, out=None, row_mask=None):
+    _need_cuda(bev, points, out, row_mask)
+    L = _lib.load()
+    B, H, W, C = bev.shape
+    n, stride = points.shape
+    if out is None:
+        out = torch.empty((n, C), dtype=torch.float32, device=bev.device)
+    check(L.pcp_bev_sample_bilinear(_p(bev), B, H, W, C, C, _p(points), n, stride, float(min_xy[0]), float(min_xy[1]),
+                                    float(pix_xy[0]), float(pix_xy[1]), _p(row_mask), _p(out), out.shape[1], _stream()),
+          'pcp_bev_sample_bilinear')
+    return out
+
+
+def bev_scatter_mean(points, feat, batch, h, w, min_xy, pix_xy, out=None, out_ch_off=0, workspace=None):
+    _need_cuda(points, feat, out)
+    L = _lib.load()
+    n, stride = points.shape
+    C = feat.shape[1]
+    need = L.pcp_bev_scatter_mean_workspace_bytes(batch, h, w, n)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=feat.device)
+    if out is None:
+        out = torch.empty((batch, h, w, C), dtype=torch.float32, device=feat.device)
+    check(L.pcp_bev_scatter_mean(_p(points), n, stride, _p(feat), feat.shape[1], C, batch, h, w, float(min_xy[0]), float(min_xy[1]),
+                                 float(pix_xy[0]), float(pix_xy[1]), _p(workspace), workspace.numel(), _chan_ptr(out, out_ch_off),
+                                 out.shape[-1], _stream()), 'pcp_bev_scatter_mean')
+    return out

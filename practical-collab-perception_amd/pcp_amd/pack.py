@@ -1,0 +1,106 @@
+"""Host-side weight preparation for the HIP kernels: BatchNorm folding and repacking into the layouts of
+include/pcp_hip.h.  Pure torch (runs on CPU or GPU tensors); done once per set of weights, never per frame.
+
+Layouts (CK = 16 input channels per staged slice):
+  conv3x3      W[cout, cin, 3, 3]      -> [cin/16][9 (ky*3+kx)][cout_pad][16]
+  plain 1x1    W[cout, cin(,1,1)]      -> [cin/16][cout_pad][16]
+  conv k2 s2   W[cout, cin, 2, 2]      -> [(4*cin)/16][cout_pad][16]  with K ordered (tap = ky*2+kx, cin)
+  convT k2 s2  W[cin, cout, 2, 2]      -> [cin/16][4*cout_pad][16]    with N ordered (tap = ky*2+kx, cout)
+  convT k1 s1  W[cin, cout, 1, 1]      -> plain with W^T
+"""
+import torch
+
+CK = 16
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def fold_bn(weight, bn_weight, bn_bias, bn_mean, bn_var, eps, conv_bias=None, out_axis=0):
+    """y = bn(conv(x) + conv_bias)  ==  conv'(x) + bias' with conv' = conv * s, bias' = (conv_bias - mean) * s + beta,
+    s = gamma / sqrt(var + eps).  Computed in float64 and rounded once to float32."""
+    s = bn_weight.double() / torch.sqrt(bn_var.double() + eps)
+    shape = [1] * weight.dim()
+    shape[out_axis] = -1
+    w = (weight.double() * s.view(shape)).float()
+    b0 = conv_bias.double() if conv_bias is not None else torch.zeros_like(s)
+    b = ((b0 - bn_mean.double()) * s + bn_bias.double()).float()
+    return w, b
+
+
+def _pad_rows(mat, n_pad):
+    """mat: [n, k] -> [n_pad, k] zero padded"""
+    if mat.shape[0] == n_pad:
+        return mat
+    out = mat.new_zeros((n_pad, mat.shape[1]))
+    out[:mat.shape[0]] = mat
+    return out
+
+
+def _slice_k(mat):
+    """[n_pad, K] -> [K/16][n_pad][16] contiguous"""
+    n, k = mat.shape
+    assert k % CK == 0, 'contraction length must be a multiple of 16, got %d' % k
+    return mat.view(n, k // CK, CK).permute(1, 0, 2).contiguous()
+
+
+def pad_bias(bias, n_pad):
+    out = bias.new_zeros(n_pad)
+    out[:bias.shape[0]] = bias
+    return out.contiguous()
+
+
+def pack_conv3x3(w, bias, n_tile=32):
+    """w: [cout, cin, 3, 3] (already BN-folded).  Returns (packed, bias_pad, cout_pad)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % CK == 0
+    cout_pad = round_up(cout, 64 if cout > 32 else n_tile)
+    wp = w.new_zeros((cout_pad, cin, 3, 3))
+    wp[:cout] = w
+    # [cout_pad, cin/16, 16, 9] -> [cin/16, 9, cout_pad, 16]
+    packed = wp.view(cout_pad, cin // CK, CK, 9).permute(1, 3, 0, 2).contiguous()
+    return packed, pad_bias(bias, cout_pad), cout_pad
+
+
+def pack_plain(w, bias):
+    """w: [cout, cin] -> ([cin/16][cout_pad][16], bias_pad, cout_pad)"""
+    w = w.reshape(w.shape[0], -1)
+    cout = w.shape[0]
+    cout_pad = round_up(cout, 64 if cout > 32 else 32)
+    return _slice_k(_pad_rows(w, cout_pad)), pad_bias(bias, cout_pad), cout_pad
+
+
+def pack_conv2x2_s2(w, bias):
+    """Conv2d(k=2, s=2): w [cout, cin, 2, 2]; K index = (ky*2+kx)*cin + c."""
+    cout, cin = w.shape[0], w.shape[1]
+    mat = w.permute(0, 2, 3, 1).reshape(cout, 4 * cin)
+    cout_pad = round_up(cout, 64 if cout > 32 else 32)
+    return _slice_k(_pad_rows(mat, cout_pad)), pad_bias(bias, cout_pad), cout_pad
+
+
+def pack_convT2x2_s2(w, bias):
+    """ConvTranspose2d(k=2, s=2): w [cin, cout, 2, 2]; N index = (ky*2+kx)*cout_pad + co."""
+    cin, cout = w.shape[0], w.shape[1]
+    cout_pad = round_up(cout, 64 if cout > 32 else 32)
+    mat = w.new_zeros((4, cout_pad, cin))
+    mat[:, :cout] = w.permute(2, 3, 1, 0).reshape(4, cout, cin)
+    return _slice_k(mat.view(4 * cout_pad, cin)), pad_bias(bias, cout_pad), cout_pad
+
+
+def pack_convT1x1(w, bias):
+    """ConvTranspose2d(k=1, s=1): w [cin, cout, 1, 1] == 1x1 conv with the transposed matrix."""
+    return pack_plain(w[:, :, 0, 0].t().contiguous(), bias)
+
+
+# ---- reference evaluation of the packed forms in plain torch (used by CPU tests to validate the layouts) -----------------
+
+def unpack_conv3x3(packed, cout, cin):
+    nsl, _nine, cout_pad, _ck = packed.shape
+    w = packed.permute(2, 0, 3, 1).reshape(cout_pad, nsl * CK, 3, 3)
+    return w[:cout, :cin]
+
+
+def unpack_plain(packed, cout):
+    nsl, n_pad, _ck = packed.shape
+    return packed.permute(1, 0, 2).reshape(n_pad, nsl * CK)[:cout]

@@ -1,0 +1,423 @@
+"""Parity tests proper: every HIP kernel, called through the C ABI, against the oracle on the same seeded inputs.
+Integer / index outputs must be bit exact; floating point within the tolerance written next to each assert
+(north_star: 1e-3 on boxes / scores).  Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import arch_of, load_golden
+from oracle import bev as obev
+from oracle import nms as onms
+from oracle import pillars as opil
+from pcp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PC_RANGE = [-51.2, -51.2, -8.0, 51.2, 51.2, 0.0]
+VOXEL = [0.2, 0.2, 8.0]
+GRID = [512, 512, 1]
+
+
+def dev():
+    assert torch.cuda.is_available(), 'gpu-marked tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _ops():
+    from pcp_amd import ops
+    return ops
+
+
+def _rand(seed, shape, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return synth.uniform(seed, 5, n, lo, hi).reshape(shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a1 / a4
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['car_1x60k', 'early_6x60k', 'batch3_ragged', 'empty', 'all_masked', 'edges'])
+def test_voxelize_bit_exact(case):
+    ops = _ops()
+    B = 1
+    if case == 'car_1x60k':
+        pts = synth.collate([synth.agent_cloud(0, 60000, 'car')])
+    elif case == 'early_6x60k':
+        pts = synth.collate([np.concatenate([synth.agent_cloud(a, 60000, 'early') for a in range(6)], 0)])
+    elif case == 'batch3_ragged':
+        B = 3
+        pts = synth.collate([synth.agent_cloud(1, 5000, 'car'), synth.agent_cloud(2, 17, 'car'), synth.agent_cloud(3, 30001, 'car', dist='ring')])
+    elif case == 'empty':
+        pts = np.zeros((0, 8), np.float32)
+    elif case == 'all_masked':
+        pts = synth.collate([synth.agent_cloud(0, 1000, 'car')])
+        pts[:, 1] += 500.0
+    else:  # edges: exact cell boundaries, range ends, NaN / inf rows
+        xs = np.array([-51.2, -51.200001, 51.2, 51.199997, 0.0, 0.2, 0.19999999, -0.2, 0.6000000238, 0.6, np.nan, np.inf, -np.inf, 10.0],
+                      np.float32)
+        pts = np.zeros((xs.shape[0] * 2, 8), np.float32)
+        pts[:xs.shape[0], 1] = xs
+        pts[:xs.shape[0], 2] = 1.0
+        pts[xs.shape[0]:, 1] = 1.0
+        pts[xs.shape[0]:, 2] = xs
+        pts[:, 3] = -1.0
+    ref = opil.voxelize(pts, 5, PC_RANGE, VOXEL, GRID) if pts.shape[0] else None
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
+    res = ops.voxelize(torch.from_numpy(pts).to(dev()), g)
+    torch.cuda.synchronize()
+    P, Nv = [int(v) for v in res.counters[:2].cpu()]
+    if ref is None:
+        assert P == 0 and Nv == 0
+        return
+    assert P == ref['unq'].shape[0] and Nv == ref['inv'].shape[0]
+    assert np.array_equal(res.voxel_coords[:P].cpu().numpy(), ref['coords'])
+    assert np.array_equal(res.unq_inv[:Nv].cpu().numpy(), ref['inv'])
+    assert np.array_equal(res.unq_cnt[:P].cpu().numpy().astype(np.int64), ref['cnt'])
+
+
+def test_voxelize_is_idempotent_and_sorted_at_full_size():
+    """size-independent properties at BASELINE full size (6 x 60k points, B = 4 frames)."""
+    ops = _ops()
+    clouds = [np.concatenate([synth.agent_cloud(a + 10 * b, 60000, 'early') for a in range(6)], 0) for b in range(4)]
+    pts = torch.from_numpy(synth.collate(clouds)).to(dev())
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, 4)
+    r1 = ops.voxelize(pts, g)
+    r2 = ops.voxelize(pts, g)
+    torch.cuda.synchronize()
+    P, Nv = [int(v) for v in r1.counters[:2].cpu()]
+    assert torch.equal(r1.voxel_coords[:P], r2.voxel_coords[:P]) and torch.equal(r1.unq_inv[:Nv], r2.unq_inv[:Nv])
+    vc = r1.voxel_coords[:P].long()
+    merged = vc[:, 0] * 262144 + vc[:, 3] * 512 + vc[:, 2]
+    assert bool((merged[1:] > merged[:-1]).all())                 # strictly ascending == torch.unique order
+    assert int(r1.unq_cnt[:P].sum()) == Nv                        # counts partition the kept points
+    assert int(r1.unq_inv[:Nv].max()) == P - 1
+    assert torch.equal(torch.bincount(r1.unq_inv[:Nv], minlength=P).int(), r1.unq_cnt[:P])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a2 / a3 / a5
+# ---------------------------------------------------------------------------------------------------------------------
+def _vfe_weights(num_raw, seed=11):
+    shapes = {'vfe.pfn_layers.0.linear.weight': (32, num_raw + 6), 'vfe.pfn_layers.1.linear.weight': (64, 64)}
+    for li, c in ((0, 32), (1, 64)):
+        for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+            shapes['vfe.pfn_layers.%d.norm.%s' % (li, leaf)] = (c,)
+    return synth.fill_state_dict(shapes, seed=seed)
+
+
+@pytest.mark.parametrize('layout,num_raw,n', [('car', 5, 60000), ('lately', 11, 20000), ('car', 5, 300)])
+def test_pfn_scatter_matches_oracle(layout, num_raw, n):
+    ops = _ops()
+    from pcp_amd import pack
+    B = 2
+    pts = synth.collate([synth.agent_cloud(3, n, layout), synth.agent_cloud(4, n // 2, layout, dist='ring')])
+    st = _vfe_weights(num_raw)
+    arch = dict(num_raw=num_raw, pc_range=PC_RANGE, voxel_size=VOXEL, grid_size=GRID, vfe_filters=[64, 64])
+    ref = opil.vfe_forward(pts, st, arch)
+    t = lambda k: torch.from_numpy(st[k])
+    w0, b0 = pack.fold_bn(t('vfe.pfn_layers.0.linear.weight'), t('vfe.pfn_layers.0.norm.weight'), t('vfe.pfn_layers.0.norm.bias'),
+                          t('vfe.pfn_layers.0.norm.running_mean'), t('vfe.pfn_layers.0.norm.running_var'), 1e-3)
+    w1, b1 = pack.fold_bn(t('vfe.pfn_layers.1.linear.weight'), t('vfe.pfn_layers.1.norm.weight'), t('vfe.pfn_layers.1.norm.bias'),
+                          t('vfe.pfn_layers.1.norm.running_mean'), t('vfe.pfn_layers.1.norm.running_var'), 1e-3)
+    d = dev()
+    pd = torch.from_numpy(pts).to(d)
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
+    vox = ops.voxelize(pd, g)
+    P = int(vox.counters[0])
+    canvas = torch.zeros((B, 512, 512, 64), device=d)
+    pf = torch.zeros((max(P, 1), 64), device=d)
+    ops.pfn_scatter(pd, vox, num_raw, w0.to(d).contiguous(), b0.to(d), w1.to(d).contiguous(), b1.to(d), canvas=canvas, pillar_features=pf)
+    torch.cuda.synchronize()
+    assert P == ref['pillar_features'].shape[0]
+    # fp32 with a different summation order and folded BN: 2e-5 absolute on O(1) features
+    np.testing.assert_allclose(pf.cpu().numpy(), ref['pillar_features'], rtol=1e-4, atol=2e-5)
+    want = torch.from_numpy(ref['spatial_features']).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(canvas.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    # the canvas must hold exactly the pillar rows, bit for bit
+    vc = vox.voxel_coords[:P].long()
+    assert torch.equal(canvas[vc[:, 0], vc[:, 2], vc[:, 3]], pf[:P])
+    # clear-by-pillar-list restores an all-zero canvas (the per-frame reset used by the pipeline)
+    ops.canvas_clear(vox, canvas)
+    torch.cuda.synchronize()
+    assert float(canvas.abs().max()) == 0.0
+    # determinism (fixed-point means, order-independent maxima)
+    pf2 = torch.zeros_like(pf)
+    vox2 = ops.voxelize(pd, g)
+    ops.pfn_scatter(pd, vox2, num_raw, w0.to(d).contiguous(), b0.to(d), w1.to(d).contiguous(), b1.to(d), canvas=None, pillar_features=pf2)
+    torch.cuda.synchronize()
+    assert torch.equal(pf, pf2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a6 / a7 convolutions
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,h,w,stride,relu,batch', [
+    (64, 64, 64, 64, 1, True, 1), (64, 64, 64, 64, 2, True, 2), (64, 128, 32, 48, 2, True, 1), (128, 128, 32, 32, 1, True, 2),
+    (384, 64, 16, 16, 1, True, 1), (64, 9, 32, 32, 1, False, 2), (16, 32, 8, 8, 1, False, 1), (128, 256, 20, 12, 2, True, 1),
+    (64, 64, 13, 21, 1, True, 1), (32, 96, 9, 9, 2, True, 1)])
+def test_conv3x3_matches_torch_cpu(cin, cout, h, w, stride, relu, batch):
+    ops = _ops()
+    from pcp_amd import pack
+    x = torch.from_numpy(_rand(1, (batch, cin, h, w)))
+    wt = torch.from_numpy(_rand(2, (cout, cin, 3, 3), -0.05, 0.05))
+    b = torch.from_numpy(_rand(3, (cout,), -0.2, 0.2))
+    want = F.conv2d(x, wt, b, stride=stride, padding=1)
+    if relu:
+        want = F.relu(want)
+    packed, bp, cpad = pack.pack_conv3x3(wt, b)
+    d = dev()
+    got = ops.conv3x3(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, stride=stride, relu=relu)
+    torch.cuda.synchronize()
+    # exact-fp32 MFMA chain vs oneDNN blocking: relative 1e-5 of the accumulated magnitude
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_conv3x3_channel_windows_and_linearity():
+    """writes into a channel slice of a wider buffer (the 384-channel concat) and obeys conv(a x + y) = a conv(x) + conv(y)."""
+    ops = _ops()
+    from pcp_amd import pack
+    d = dev()
+    cin, cout = 64, 128
+    wt = torch.from_numpy(_rand(7, (cout, cin, 3, 3), -0.05, 0.05))
+    zero_b = torch.zeros(cout)
+    packed, bp, cpad = pack.pack_conv3x3(wt, zero_b)
+    x = torch.from_numpy(_rand(8, (1, 48, 40, 96))).to(d)          # NHWC buffer with ld 96; use channels 16..79
+    y = torch.from_numpy(_rand(9, (1, 48, 40, 96))).to(d)
+    out = torch.full((1, 48, 40, 384), 7.0, device=d)
+    ops.conv3x3(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=16, out_ch_off=128)
+    torch.cuda.synchronize()
+    assert float((out[..., :128] - 7.0).abs().max()) == 0.0 and float((out[..., 256:] - 7.0).abs().max()) == 0.0
+    want = F.conv2d(x[..., 16:80].permute(0, 3, 1, 2).cpu(), wt, None, padding=1)
+    np.testing.assert_allclose(out[..., 128:256].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    cx = ops.conv3x3(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, in_ch_off=16)
+    cy = ops.conv3x3(y, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, in_ch_off=16)
+    cz = ops.conv3x3((2.0 * x + y).contiguous(), packed.to(d), bp.to(d), cin, cout, cpad, relu=False, in_ch_off=16)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(cz.cpu().numpy(), (2.0 * cx + cy).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('mode,cin,cout,h,w', [('plain', 128, 128, 24, 24), ('plain', 256, 64, 16, 16), ('plain', 16, 1, 16, 16),
+                                                ('s2d', 64, 128, 32, 32), ('d2s', 128, 128, 16, 16), ('d2s', 256, 128, 8, 12),
+                                                ('plain', 384, 32, 1, 1000)])
+def test_pointwise_matches_torch_cpu(mode, cin, cout, h, w):
+    ops = _ops()
+    from pcp_amd import lib, pack
+    d = dev()
+    B = 2
+    x = torch.from_numpy(_rand(21, (B, cin, h, w)))
+    b = torch.from_numpy(_rand(23, (cout,), -0.2, 0.2))
+    if mode == 'plain':
+        wt = torch.from_numpy(_rand(22, (cout, cin), -0.1, 0.1))
+        want = F.relu(F.conv2d(x, wt[:, :, None, None], b))
+        packed, bp, cpad = pack.pack_plain(wt, b)
+        m = lib.PW_PLAIN
+    elif mode == 's2d':
+        wt = torch.from_numpy(_rand(22, (cout, cin, 2, 2), -0.1, 0.1))
+        want = F.relu(F.conv2d(x, wt, b, stride=2))
+        packed, bp, cpad = pack.pack_conv2x2_s2(wt, b)
+        m = lib.PW_SPACE2DEPTH
+    else:
+        wt = torch.from_numpy(_rand(22, (cin, cout, 2, 2), -0.1, 0.1))
+        want = F.relu(F.conv_transpose2d(x, wt, b, stride=2))
+        packed, bp, cpad = pack.pack_convT2x2_s2(wt, b)
+        m = lib.PW_DEPTH2SPACE
+    got = ops.pointwise(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), m, cin, cout, cpad, relu=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a8 decode
+# ---------------------------------------------------------------------------------------------------------------------
+def _decode_kwargs(arch, ld=16):
+    hd = arch['head']
+    return dict(k=hd['max_obj'], num_class=1, ch_center=0, ch_z=2, ch_dim=3, ch_rot=6, ch_hm=8, stride=hd['stride'],
+                voxel_x=float(np.float32(arch['voxel_size'][0])), voxel_y=float(np.float32(arch['voxel_size'][1])),
+                min_x=float(np.float32(arch['pc_range'][0])), min_y=float(np.float32(arch['pc_range'][1])),
+                limit=hd['limit_range'], score_thresh=hd['score_thresh'])
+
+
+def _head_buffer(maps, ld=16):
+    order = ['center', 'center_z', 'dim', 'rot', 'hm']
+    cat = torch.cat([torch.from_numpy(np.asarray(maps[k])) for k in order], dim=1)     # (B, 9, H, W)
+    B, C, H, W = cat.shape
+    buf = torch.zeros((B, H, W, ld))
+    buf[..., :C] = cat.permute(0, 2, 3, 1)
+    return buf
+
+
+@pytest.mark.parametrize('tag', ['car', 'ego'])
+def test_decode_matches_oracle_on_golden_head_maps(tag):
+    ops = _ops()
+    g = load_golden('g1_%s.npz' % tag)
+    arch = arch_of(g['meta'])
+    maps = {k: g['head_' + k] for k in ('center', 'center_z', 'dim', 'rot', 'hm')}
+    ref = obev.decode_boxes({k: torch.from_numpy(v) for k, v in maps.items()}, arch)
+    boxes, scores, labels, cell, count = ops.centerhead_decode(_head_buffer(maps).to(dev()), _decode_kwargs(arch))
+    torch.cuda.synchronize()
+    for b in range(2):
+        n = int(count[b])
+        assert n == ref[b]['boxes'].shape[0]
+        assert np.array_equal(cell[b, :n].cpu().numpy().astype(np.int64), ref[b]['cell'])      # same cells, same order
+        np.testing.assert_allclose(scores[b, :n].cpu().numpy(), ref[b]['scores'], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(boxes[b, :n].cpu().numpy(), ref[b]['boxes'], rtol=1e-5, atol=1e-5)
+        s = scores[b, :n]
+        assert bool((s[1:] <= s[:-1]).all())
+
+
+def test_decode_full_size_random_and_ties():
+    ops = _ops()
+    arch = dict(pc_range=PC_RANGE, voxel_size=VOXEL,
+                head=dict(max_obj=500, stride=4, limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_thresh=0.1))
+    B, H, W = 3, 128, 128
+    maps = dict(center=_rand(31, (B, 2, H, W), 0, 1), center_z=_rand(32, (B, 1, H, W), -3, 0), dim=_rand(33, (B, 3, H, W), 0, 1.5),
+                rot=_rand(34, (B, 2, H, W)), hm=_rand(35, (B, 1, H, W), -6, 2))
+    maps['hm'][1] = -1.0                    # frame 1: every score equal -> ties resolved by the lowest cell index
+    maps['hm'][2] = -9.0                    # frame 2: nothing above the score threshold
+    ref = obev.decode_boxes({k: torch.from_numpy(v) for k, v in maps.items()}, arch)
+    boxes, scores, labels, cell, count = ops.centerhead_decode(_head_buffer(maps).to(dev()), _decode_kwargs(arch))
+    torch.cuda.synchronize()
+    assert int(count[2]) == 0 and ref[2]['boxes'].shape[0] == 0
+    n1 = int(count[1])
+    assert n1 == ref[1]['boxes'].shape[0] == 500
+    assert np.array_equal(cell[1, :n1].cpu().numpy(), np.arange(500))
+    n0 = int(count[0])
+    assert n0 == ref[0]['boxes'].shape[0]
+    # random frame: identical cells except where two scores differ by less than the sigmoid ulp noise
+    same = cell[0, :n0].cpu().numpy().astype(np.int64) == ref[0]['cell']
+    assert same.mean() > 0.99
+    assert set(cell[0, :n0].cpu().numpy().tolist()) == set(ref[0]['cell'].tolist())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a9 NMS
+# ---------------------------------------------------------------------------------------------------------------------
+def test_pairwise_iou_matches_reference_values():
+    ops = _ops()
+    g = load_golden('g3_nms.npz')
+    order = g['order']
+    b = torch.from_numpy(g['boxes'][order]).to(dev())
+    iou = ops.boxes_bev_pairwise(b, b, 1).cpu().numpy()
+    # sinf/cosf/atan2f differ by ulps between ocml and glibc: 1e-5 absolute on IoU in [0, 1]
+    np.testing.assert_allclose(iou, g['iou_sorted'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('thr,key', [(0.2, 'keep_02'), (0.3, 'keep_03')])
+def test_nms_keep_list_matches_golden(thr, key):
+    ops = _ops()
+    g = load_golden('g3_nms.npz')
+    boxes, scores = g['boxes'], g['scores']
+    d = dev()
+    keep, cnt = ops.nms_rotated(torch.from_numpy(boxes).to(d), torch.from_numpy(scores).to(d), thr, 1000, 500)
+    torch.cuda.synchronize()
+    n = int(cnt[0])
+    got = keep[:n].cpu().numpy().astype(np.int64)
+    # the keep list is a function of the boolean matrix (iou > thr); sinf/cosf/atan2f ulp differences can only matter
+    # for pairs sitting on the threshold, so first check that no verdict flipped, then demand the golden list
+    order = g['order']
+    sb = torch.from_numpy(boxes[order]).to(d)
+    giou = ops.boxes_bev_pairwise(sb, sb, 1).cpu().numpy()
+    flips = (giou > thr) != (g['iou_sorted'] > thr)
+    assert flips.sum() <= 2, 'verdict flips only expected for pairs within an ulp of the threshold'
+    if flips.sum() == 0:
+        assert np.array_equal(got, g[key])
+    assert np.array_equal(got, order[onms.nms_from_iou(giou, thr)])
+    keep83, cnt83 = ops.nms_rotated(torch.from_numpy(boxes).to(d), torch.from_numpy(scores).to(d), thr, 1000, 83)
+    assert np.array_equal(keep83[:int(cnt83[0])].cpu().numpy().astype(np.int64), got[:83])
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 64, 65, 500, 1000, 4096])
+def test_nms_sizes_against_oracle(n):
+    ops = _ops()
+    s = 900 + n
+    boxes = np.zeros((max(n, 1), 7), np.float32)[:n]
+    if n:
+        k = max(n // 6, 1)
+        cx, cy = synth.uniform(s, 1, k, -40, 40), synth.uniform(s, 2, k, -40, 40)
+        which = (synth.uniform01(s, 3, n) * k).astype(np.int64)
+        boxes[:, 0] = cx[which] + synth.uniform(s, 4, n, -2, 2)
+        boxes[:, 1] = cy[which] + synth.uniform(s, 5, n, -2, 2)
+        boxes[:, 3] = synth.uniform(s, 7, n, 3.0, 5.5)
+        boxes[:, 4] = synth.uniform(s, 8, n, 1.5, 2.5)
+        boxes[:, 5] = 1.5
+        boxes[:, 6] = synth.uniform(s, 10, n, -3.14, 3.14)
+    scores = (np.argsort(np.argsort(synth.uniform01(s, 11, max(n, 1))[:n])).astype(np.float32) + 1) / np.float32(n + 1)
+    d = dev()
+    keep, cnt = ops.nms_rotated(torch.from_numpy(boxes).to(d).reshape(n, 7), torch.from_numpy(scores).to(d), 0.2, 10000, max(n, 1))
+    torch.cuda.synchronize()
+    got = keep[:int(cnt[0])].cpu().numpy().astype(np.int64)
+    if n == 0:
+        assert got.shape[0] == 0
+        return
+    order = np.argsort(-scores, kind='stable')
+    iou = onms.iou_matrix(boxes[order], boxes[order])
+    want = order[onms.nms_from_iou(iou, 0.2)]
+    if np.any(np.abs(iou - 0.2) < 2e-5):      # ulp-sensitive pairs present: compare through the GPU's own IoU matrix
+        giou = ops.boxes_bev_pairwise(torch.from_numpy(boxes[order]).to(d), torch.from_numpy(boxes[order]).to(d), 1).cpu().numpy()
+        want = order[onms.nms_from_iou(giou, 0.2)]
+    assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a11 / a12
+# ---------------------------------------------------------------------------------------------------------------------
+def test_warp_nearest_matches_golden():
+    ops = _ops()
+    from pcp_amd import fusion_host
+    g = load_golden('g4_warp.npz')
+    d = dev()
+    for key in [str(k) for k in g['cases']]:
+        H = int(key.split('_')[0][1:])
+        pc_min, pix = [float(v) for v in g['H%d_params' % H]]
+        img = torch.from_numpy(g['H%d_img' % H])                     # (3, H, W)
+        src = torch.zeros((H, H, 4))
+        src[..., :3] = img.permute(1, 2, 0)
+        theta, ambiguous = fusion_host.warp_theta(torch.from_numpy(g[key + '_T']), H, H, pc_min, pix, return_ambiguous=True)
+        dst = torch.full((H, H, 4), -5.0, device=d)
+        ops.warp_nearest(src.to(d), dst, theta, 4)
+        torch.cuda.synchronize()
+        got = dst[..., :3].permute(2, 0, 1).cpu().numpy()
+        want = g[key + '_out']
+        ok = ~ambiguous.numpy()[None]                                # pixels whose source coordinate is not on a .5 tie
+        assert np.array_equal(np.where(ok, got, 0), np.where(ok, want, 0)), key
+        assert (~ok).mean() < 0.30
+
+
+def test_softmax_fuse_matches_torch():
+    ops = _ops()
+    d = dev()
+    B, H, W, C, A = 2, 16, 16, 128, 4
+    maps = [torch.from_numpy(_rand(40 + a, (B, H, W, C))).to(d) for a in range(A)]
+    wts = torch.from_numpy(_rand(50, (B, H, W, A), 0, 3)).to(d)
+    out = torch.empty((B, H, W, C), device=d)
+    ops.softmax_fuse(maps, wts, C, out)
+    torch.cuda.synchronize()
+    sm = torch.softmax(wts.cpu(), dim=-1)
+    want = sum(maps[a].cpu() * sm[..., a:a + 1] for a in range(A))
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a14
+# ---------------------------------------------------------------------------------------------------------------------
+def test_hunter_point_ops_match_oracle():
+    ops = _ops()
+    d = dev()
+    B, H, W, C = 2, 32, 32, 64
+    bev = torch.from_numpy(_rand(60, (B, C, H, W)))
+    pts_np = synth.collate([synth.agent_cloud(5, 3000, 'car', xy_half=13.1), synth.agent_cloud(6, 2000, 'car', xy_half=13.1)])
+    extra = np.zeros((4, 8), np.float32)
+    extra[:, 1:3] = [[-12.8, 1.0], [1.0, -12.8], [12.799999, 0.3], [0.3, 12.799999]]
+    pts_np = np.concatenate([pts_np, extra], 0)
+    pts = torch.from_numpy(pts_np)
+    rng = [-12.8, -12.8, -8.0, 12.8, 12.8, 0.0]
+    want_feat, coord = obev.sample_point_features(bev, pts, rng, [0.8, 0.8])
+    got = ops.bev_sample_bilinear(ops.as_nhwc(bev.to(d)), pts.to(d), rng[:2], [np.float32(0.2) * 4, np.float32(0.2) * 4])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), want_feat.numpy(), rtol=1e-5, atol=1e-6)
+    want_img = obev.bev_scatter_mean(coord, pts[:, 0].long(), want_feat, (H, W), batch_size=B)
+    got_img = ops.bev_scatter_mean(pts.to(d), got, B, H, W, rng[:2], [np.float32(0.2) * 4, np.float32(0.2) * 4])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got_img.permute(0, 3, 1, 2).cpu().numpy(), want_img.numpy(), rtol=1e-5, atol=1e-6)
