@@ -114,6 +114,13 @@ typedef struct {
   int32_t cin, cout, cout_pad;    /* per-tap channels; cout_pad = padded n of the packed weights per tap */
   int32_t ld_in, ld_out;
   int32_t relu;
+  /* PLAIN only (NULL / 0 otherwise): a second K source -- channels [k_split, cin) are read from in2 at offset
+   * k - k_split (lets cat([a, b], channel) feed a 1x1 conv without materialising the cat) -- and a residual row
+   * added after bias / activation (out = act(x W^T + b) + residual). */
+  const float *in2;
+  int32_t ld_in2, k_split;
+  const float *residual;
+  int32_t ld_res;
 } pcp_pointwise_t;
 
 int pcp_pointwise(const pcp_pointwise_t *desc, const float *in, const float *w_packed, const float *bias, float *out,
@@ -185,6 +192,20 @@ size_t pcp_bev_scatter_mean_workspace_bytes(int32_t batch, int32_t h, int32_t w,
 int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_stride, const float *feat, int32_t ld_feat,
                          int32_t c, int32_t batch, int32_t h, int32_t w, float min_x, float min_y, float pix_x,
                          float pix_y, void *workspace, size_t workspace_bytes, float *out, int32_t ld_out, void *stream);
+/* hunter_jr.py:257-265: p = sigmoid(head[:, 0:3]); dynamic foreground = max p > thresh and argmax == 2; for those rows
+ * points[:, 1:4] += head[:, 3:6] IN PLACE; row_mask[i] = 1/0.  head: (n, ld_head) = [cls(3), flow(3), ...]. */
+int pcp_hunter_apply_flow(float *points, int64_t n, int32_t row_stride, const float *head, int32_t ld_head, float thresh,
+                          uint8_t *row_mask, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a13  BEVMaker input preparation: rows of `agent` (last column == agent) are copied with xyz mapped by the frame's
+ * 3x4 pose (x' = R x + t, row-major R|t per batch element, float32); every other row gets batch index -1 so that
+ * pcp_voxelize masks it.  Replaces pcdet/models/bev_layers/bev_maker.py:168-179 (boolean-mask copy + per-frame matmul).
+ * poses_host: (batch, 12) float32 on the HOST; present_host: (batch,) uint8, 0 = agent absent from that frame.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, float agent,
+                                int32_t batch, const float *poses_host, const uint8_t *present_host, float *out,
+                                void *stream);
 
 #ifdef __cplusplus
 }

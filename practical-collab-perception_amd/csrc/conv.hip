@@ -214,6 +214,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(Conv3Params p) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct PwParams {
   const float *in;
+  const float *in2;     // PLAIN only: second K source for k >= k_split (nullptr = single source)
+  const float *residual;// PLAIN only: added after bias/activation (nullptr = none)
+  int ld_in2, k_split, ld_res;
   const float *w;       // [K/16][n_total_pad][16], n_total_pad = taps_out * cout_pad
   const float *bias;    // [cout_pad]
   float *out;
@@ -247,17 +250,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_pointwise(PwParams p) {
 
   // row base pointers; SPACE2DEPTH rows address the top-left pixel of their 2x2 input block
   const float *a_row[A_PER];
+  const float *a_row2[A_PER];
   int a_dst[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; i++) {
     int idx = tid + i * CONV_THREADS;
     a_row[i] = nullptr;
+    a_row2[i] = nullptr;
     a_dst[i] = -1;
     if (idx < A_F4) {
       int row = idx >> 2, q = idx & 3;
       long long m = m0 + row;
       a_dst[i] = row * LDK + q * 4;
       if (m < p.rows) {
+        if (MODE == PCP_PW_PLAIN && p.in2) a_row2[i] = p.in2 + m * p.ld_in2 + q * 4;
         if (MODE == PCP_PW_SPACE2DEPTH) {
           int ow = p.in_w >> 1, oh = p.in_h >> 1;
           int ox = (int)(m % ow);
@@ -292,10 +298,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_pointwise(PwParams p) {
       c0 = (slice % slices_per_tap) * CK;
       tap_off = ((long long)(tap >> 1) * p.in_w + (tap & 1)) * p.ld_in;
     }
+    const bool second = (MODE == PCP_PW_PLAIN) && p.in2 && c0 >= p.k_split;
 #pragma unroll
     for (int i = 0; i < A_PER; i++) {
       a_reg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a_row[i]) a_reg[i] = *reinterpret_cast<const f32x4 *>(a_row[i] + tap_off + c0);
+      if (second) {
+        if (a_row2[i]) a_reg[i] = *reinterpret_cast<const f32x4 *>(a_row2[i] + (c0 - p.k_split));
+      } else if (a_row[i]) {
+        a_reg[i] = *reinterpret_cast<const f32x4 *>(a_row[i] + tap_off + c0);
+      }
     }
     const float *bs = p.w + (long long)slice * p.n_total * CK;
 #pragma unroll
@@ -364,6 +375,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_pointwise(PwParams p) {
         if (!n_ok || m >= p.rows) continue;
         float v = acc[i][j][e] + bias;
         if (p.relu) v = fmaxf(v, 0.f);
+        if (MODE == PCP_PW_PLAIN && p.residual) v += p.residual[m * p.ld_res + co];
         long long opix = m;
         if (MODE == PCP_PW_DEPTH2SPACE) {
           int ix = (int)(m % p.in_w);
@@ -434,6 +446,13 @@ extern "C" int pcp_pointwise(const pcp_pointwise_t *d, const float *in, const fl
   hipStream_t st = (hipStream_t)stream_;
   PwParams p;
   p.in = in; p.w = w_packed; p.bias = bias; p.out = out;
+  p.in2 = nullptr; p.residual = nullptr; p.ld_in2 = 0; p.k_split = 0; p.ld_res = 0;
+  if (d->mode == PCP_PW_PLAIN) {
+    p.in2 = d->in2; p.ld_in2 = d->ld_in2; p.k_split = d->k_split;
+    p.residual = d->residual; p.ld_res = d->ld_res;
+    if (p.in2 && (p.k_split <= 0 || p.k_split % CK != 0 || p.k_split >= d->cin || (p.ld_in2 & 3) || (((uintptr_t)p.in2) & 15)))
+      return PCP_ERR_ARG;
+  }
   p.in_h = d->in_h; p.in_w = d->in_w;
   p.cin = d->cin; p.cout = d->cout; p.cout_pad = d->cout_pad;
   p.ld_in = d->ld_in; p.ld_out = d->ld_out; p.relu = d->relu;

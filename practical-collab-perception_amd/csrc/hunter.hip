@@ -177,7 +177,78 @@ __global__ __launch_bounds__(SC_THREADS) void k_sc_mean(const int *__restrict__ 
   }
 }
 
+__global__ void k_apply_flow(float *__restrict__ points, long long n, int stride, const float *__restrict__ head, int ld_head,
+                             float thresh, unsigned char *__restrict__ row_mask) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *hrow = head + i * ld_head;
+  float p0 = 1.0f / (1.0f + expf(-hrow[0])), p1 = 1.0f / (1.0f + expf(-hrow[1])), p2 = 1.0f / (1.0f + expf(-hrow[2]));
+  // torch.max over dim=1 returns the FIRST maximal index: class 2 wins only when strictly larger than both
+  bool dyn = (p2 > p0) && (p2 > p1) && (p2 > thresh);
+  if (dyn) {
+    float *row = points + i * stride;
+    row[1] = row[1] + hrow[3];
+    row[2] = row[2] + hrow[4];
+    row[3] = row[3] + hrow[5];
+  }
+  row_mask[i] = dyn ? 1 : 0;
+}
+
+constexpr int MAX_POSE_BATCH = 16;
+struct PoseTable {
+  float m[MAX_POSE_BATCH][12];
+  unsigned char present[MAX_POSE_BATCH];
+};
+
+__global__ void k_select_transform(const float *__restrict__ points, long long n, int stride, int agent_col, float agent,
+                                   int batch, PoseTable pt, float *__restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *row = points + i * stride;
+  float *o = out + i * stride;
+  int b = (int)row[0];
+  bool mine = (row[agent_col] == agent) && b >= 0 && b < batch && pt.present[b];
+  for (int c = 0; c < stride; c++) o[c] = row[c];
+  if (!mine) {
+    o[0] = -1.0f;
+    return;
+  }
+  const float *T = pt.m[b];
+  float x = row[1], y = row[2], z = row[3];
+  o[1] = x * T[0] + y * T[1] + z * T[2] + T[3];
+  o[2] = x * T[4] + y * T[5] + z * T[6] + T[7];
+  o[3] = x * T[8] + y * T[9] + z * T[10] + T[11];
+}
+
 }  // namespace
+
+extern "C" int pcp_hunter_apply_flow(float *points, int64_t n, int32_t row_stride, const float *head, int32_t ld_head,
+                                     float thresh, uint8_t *row_mask, void *stream_) {
+  if (n < 0 || row_stride < 4 || ld_head < 6) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  if (!points || !head || !row_mask) return PCP_ERR_ARG;
+  hipLaunchKernelGGL(k_apply_flow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, points, (long long)n,
+                     row_stride, head, ld_head, thresh, row_mask);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, float agent,
+                                           int32_t batch, const float *poses_host, const uint8_t *present_host, float *out,
+                                           void *stream_) {
+  if (n < 0 || row_stride < 4 || agent_col < 0 || agent_col >= row_stride || batch <= 0 || batch > MAX_POSE_BATCH) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  if (!points || !poses_host || !present_host || !out || points == out) return PCP_ERR_ARG;
+  PoseTable pt;
+  for (int b = 0; b < MAX_POSE_BATCH; b++) {
+    pt.present[b] = b < batch ? present_host[b] : 0;
+    for (int k = 0; k < 12; k++) pt.m[b][k] = b < batch ? poses_host[b * 12 + k] : 0.f;
+  }
+  hipLaunchKernelGGL(k_select_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, points,
+                     (long long)n, row_stride, agent_col, agent, batch, pt, out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
 
 extern "C" int pcp_bev_sample_bilinear(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
                                        const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,

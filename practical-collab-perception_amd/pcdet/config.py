@@ -106,9 +106,13 @@ def _resolve_base(path, including_file=None):
 
 def merge_new_config(config, new_config, _file=None):
     if '_BASE_CONFIG_' in new_config:
-        with open(_resolve_base(new_config['_BASE_CONFIG_'], _file), 'r') as f:
-            config.update(EasyDict(yaml.safe_load(f)))
+        base_path = _resolve_base(new_config['_BASE_CONFIG_'], _file)
+        with open(base_path, 'r') as f:
+            merge_new_config(config, yaml.safe_load(f), str(base_path))      # bases may chain (the reference allows one level)
     for key, val in new_config.items():
+        if key == '_BASE_CONFIG_':
+            config[key] = val
+            continue
         if not isinstance(val, dict):
             config[key] = val
             continue

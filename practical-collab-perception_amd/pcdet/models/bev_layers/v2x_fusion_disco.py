@@ -1,0 +1,107 @@
+"""DiscoNet mid fusion on gfx950 (reference: pcdet/models/bev_layers/v2x_fusion_disco.py:8-126).
+
+Same parameter tree (compressor.{0,1,3}, pixel_weightor.{conv1_1,bn1_1,conv1_2,bn1_2,conv1_4}, decompressor.{0,1,3}).
+Per frame batch: compress ego + each agent map (MFMA convs), warp each compressed agent map into the ego frame
+(pcp_warp_nearest, one launch per (agent, frame), theta built on the host exactly like :32-35), evaluate the
+pixel weightor on [ego | agent] WITHOUT materialising the concat (dual-source 1x1 conv), softmax over agents + weighted
+sum in one kernel, decompress.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from pcp_amd import fusion_host, lib, ops
+
+from ..convnet import pack_conv_module
+from ..packed import PackedModule, require_eval_hip
+
+
+class PixelWeightedFusionSoftmax(nn.Module):
+    """parameter container (reference :8-26)"""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.conv1_1 = nn.Conv2d(channel * 2, 64, kernel_size=1, stride=1, padding=0)
+        self.bn1_1 = nn.BatchNorm2d(64)
+        self.conv1_2 = nn.Conv2d(64, 16, kernel_size=1, stride=1, padding=0)
+        self.bn1_2 = nn.BatchNorm2d(16)
+        self.conv1_4 = nn.Conv2d(16, 1, kernel_size=1, stride=1, padding=0)
+
+
+def transform_bev_img(dst_se3_src, bev_in_src, pc_range_min, pix_size):
+    """API twin of the reference helper (:29-45) for a single (C, H, W) CUDA map; returns the warped (C, H, W) map."""
+    assert bev_in_src.dim() == 3
+    C, H, W = bev_in_src.shape
+    src = bev_in_src.permute(1, 2, 0).contiguous()
+    cp = (C + 3) // 4 * 4
+    if cp != C:
+        pad = src.new_zeros((H, W, cp))
+        pad[..., :C] = src
+        src = pad
+    dst = torch.empty_like(src)
+    ops.warp_nearest(src, dst, fusion_host.warp_theta(dst_se3_src, H, W, pc_range_min, pix_size), cp)
+    return dst[..., :C].permute(2, 0, 1)
+
+
+class V2XMidFusionDisco(PackedModule):
+    def __init__(self, model_cfg, in_channel=384):
+        super().__init__()
+        cc = model_cfg.COMPRESSED_CHANNELS
+        self.compressor = nn.Sequential(
+            nn.Conv2d(in_channel, cc, kernel_size=3, stride=1, padding=1, bias=False), nn.BatchNorm2d(cc), nn.ReLU(inplace=True),
+            nn.Conv2d(cc, cc, kernel_size=3, stride=1, padding=1))
+        self.pixel_weightor = PixelWeightedFusionSoftmax(cc)
+        self.decompressor = nn.Sequential(
+            nn.Conv2d(cc, in_channel, kernel_size=3, stride=1, padding=1, bias=False), nn.BatchNorm2d(in_channel),
+            nn.ReLU(inplace=True), nn.Conv2d(in_channel, in_channel, kernel_size=3, stride=1, padding=1))
+        self.pc_min = model_cfg.get('PC_RANGE_MIN', -51.2)
+        self.pix_size = model_cfg.get('FINAL_BEV_PIXEL_SIZE', 0.2 * 4)
+        self.model_cfg = model_cfg
+        self.cc = cc
+        self.loss_dict = {'loss_distill': 0.0}
+
+    def _build_packed(self):
+        pw = self.pixel_weightor
+        return dict(c0=pack_conv_module(self.compressor[0], self.compressor[1], relu=True),
+                    c1=pack_conv_module(self.compressor[3], None, relu=False),
+                    w1=pack_conv_module(pw.conv1_1, pw.bn1_1, relu=True), w2=pack_conv_module(pw.conv1_2, pw.bn1_2, relu=True),
+                    w3=pack_conv_module(pw.conv1_4, None, relu=True),
+                    d0=pack_conv_module(self.decompressor[0], self.decompressor[1], relu=True),
+                    d1=pack_conv_module(self.decompressor[3], None, relu=False))
+
+    def _compress(self, pk, x_nhwc, out=None):
+        return pk['c1'].run(pk['c0'].run(x_nhwc), out=out)
+
+    def _weight(self, pk, ego, other, wbuf, col):
+        # relu(conv1_4(relu(bn(conv1_2(relu(bn(conv1_1(cat[ego, other]))))))))  -> column `col` of wbuf
+        h = ops.pointwise(ego, pk['w1'].w, pk['w1'].b, lib.PW_PLAIN, 2 * self.cc, 64, pk['w1'].cout_pad, relu=True, x2=other,
+                          k_split=self.cc)
+        h = pk['w2'].run(h)
+        pk['w3'].run(h, out=wbuf, out_ch_off=col)
+
+    def forward(self, batch_dict):
+        require_eval_hip(self, 'V2XMidFusionDisco')
+        pk = self.packed()
+        ego_in = ops.as_nhwc(batch_dict['spatial_features_2d'])
+        B, H, W, _ = ego_in.shape
+        agents = list(batch_dict['bev_img'].items())
+        n_maps = 1 + len(agents)
+        dev = ego_in.device
+        stack = torch.zeros((n_maps, B, H, W, self.cc), dtype=torch.float32, device=dev)   # ego + warped agents (zeros = absent)
+        self._compress(pk, ego_in, out=stack[0])
+        wbuf = torch.zeros((B, H, W, max(4, (n_maps + 3) // 4 * 4)), dtype=torch.float32, device=dev)
+        self._weight(pk, stack[0], stack[0], wbuf, 0)
+        for a, (agent_idx, bev_img) in enumerate(agents, start=1):
+            comp = self._compress(pk, ops.as_nhwc(bev_img))
+            for b_idx, meta in enumerate(batch_dict['metadata']):
+                if agent_idx not in meta['se3_from_ego'] or b_idx >= comp.shape[0]:
+                    continue
+                T = fusion_host.ego_se3_agent(meta['se3_from_ego'][agent_idx])
+                theta = fusion_host.warp_theta(T, H, W, self.pc_min, self.pix_size)
+                ops.warp_nearest(comp[b_idx], stack[a, b_idx], theta, self.cc)
+            self._weight(pk, stack[0], stack[a], wbuf, a)
+        fused = torch.empty((B, H, W, self.cc), dtype=torch.float32, device=dev)
+        ops.softmax_fuse([stack[a] for a in range(n_maps)], wbuf, self.cc, fused)
+        out = pk['d1'].run(pk['d0'].run(fused))
+        batch_dict['spatial_features_2d'] = ops.nchw_view(out)
+        return batch_dict

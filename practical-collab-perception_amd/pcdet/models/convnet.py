@@ -1,0 +1,76 @@
+"""Shared plumbing for the dense conv stacks: turns (Conv2d | ConvTranspose2d) [+ BatchNorm2d] parameter containers into
+packed HIP weights and launches them on NHWC buffers."""
+import torch
+import torch.nn as nn
+
+from pcp_amd import lib, ops, pack
+
+
+class PackedConv:
+    """One fused conv(+BN)(+ReLU) launch description."""
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu')
+
+    def run(self, x, out=None, in_ch_off=0, out_ch_off=0):
+        if self.kind == '3x3':
+            return ops.conv3x3(x, self.w, self.b, self.cin, self.cout, self.cout_pad, stride=self.stride, relu=self.relu, out=out,
+                               in_ch_off=in_ch_off, out_ch_off=out_ch_off)
+        mode = {'plain': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[self.kind]
+        return ops.pointwise(x, self.w, self.b, mode, self.cin, self.cout, self.cout_pad, relu=self.relu, out=out,
+                             in_ch_off=in_ch_off, out_ch_off=out_ch_off)
+
+
+def _fold(conv, bn, out_axis):
+    w = conv.weight.detach().float()
+    cb = conv.bias.detach().float() if conv.bias is not None else None
+    if bn is None:
+        n_out = w.shape[out_axis]
+        return w, (cb if cb is not None else torch.zeros(n_out, dtype=torch.float32, device=w.device))
+    return pack.fold_bn(w, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, conv_bias=cb,
+                        out_axis=out_axis)
+
+
+def pack_conv_module(conv, bn=None, relu=True):
+    """conv: nn.Conv2d (3x3 s1/s2 p1 | 1x1 | k2 s2) or nn.ConvTranspose2d (k1 s1 | k2 s2)."""
+    pc = PackedConv()
+    pc.relu = relu
+    pc.stride = 1
+    if isinstance(conv, nn.ConvTranspose2d):
+        w, b = _fold(conv, bn, out_axis=1)
+        k, s = conv.kernel_size[0], conv.stride[0]
+        pc.cin, pc.cout = w.shape[0], w.shape[1]
+        if k == 1 and s == 1:
+            pc.kind = 'plain'
+            pc.w, pc.b, pc.cout_pad = pack.pack_convT1x1(w, b)
+        elif k == 2 and s == 2:
+            pc.kind = 'd2s'
+            pc.w, pc.b, pc.cout_pad = pack.pack_convT2x2_s2(w, b)
+        else:
+            raise NotImplementedError('ConvTranspose2d k=%d s=%d has no HIP kernel in this build' % (k, s))
+        return pc
+    w, b = _fold(conv, bn, out_axis=0)
+    k, s = conv.kernel_size[0], conv.stride[0]
+    pc.cin, pc.cout = w.shape[1], w.shape[0]
+    if k == 3 and s in (1, 2):
+        pc.kind = '3x3'
+        pc.stride = s
+        pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
+    elif k == 1 and s == 1:
+        pc.kind = 'plain'
+        pc.w, pc.b, pc.cout_pad = pack.pack_plain(w, b)
+    elif k == 2 and s == 2:
+        pc.kind = 's2d'
+        pc.w, pc.b, pc.cout_pad = pack.pack_conv2x2_s2(w, b)
+    else:
+        raise NotImplementedError('Conv2d k=%d s=%d has no HIP kernel in this build' % (k, s))
+    return pc
+
+
+def pack_conv_raw(w, b, relu, stride=1):
+    """3x3 conv from an explicit (already folded) weight/bias pair, e.g. the fused CenterHead branches."""
+    pc = PackedConv()
+    pc.kind = '3x3'
+    pc.relu = relu
+    pc.stride = stride
+    pc.cin, pc.cout = w.shape[1], w.shape[0]
+    pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
+    return pc

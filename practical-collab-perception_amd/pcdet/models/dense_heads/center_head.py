@@ -1,0 +1,201 @@
+"""CenterHead on gfx950 (reference: pcdet/models/dense_heads/center_head.py:13-429).
+
+Parameter tree identical to the reference (shared_conv.{0,1}, heads_list.{h}.{name}.{i}.{0,1} / .{last}), so checkpoints load
+unchanged.  Inference forward:
+  shared 3x3 conv+BN+ReLU            -> one MFMA launch
+  all first convs of all branches    -> ONE launch (weights concatenated along cout: 5 x 64 = 320 channels)
+  all final convs                    -> ONE launch (block-diagonal weights, 9 real output channels)
+  sigmoid/exp/atan2 + top-K + decode -> one kernel per head (pcp_centerhead_decode), no host sync
+  rotated NMS                        -> sort-free (already ordered) mask + single-wavefront greedy, per frame
+  one device->host copy of the per-frame keep counts at the very end to size the returned tensors.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_normal_
+
+from pcp_amd import ops
+
+from ..convnet import pack_conv_module, pack_conv_raw, _fold
+from ..packed import PackedModule, require_eval_hip
+
+
+class SeparateHead(nn.Module):
+    """Parameter container for the per-quantity branches (reference :13-47)."""
+
+    def __init__(self, input_channels, sep_head_dict, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for cur_name in self.sep_head_dict:
+            output_channels = self.sep_head_dict[cur_name]['out_channels']
+            num_conv = self.sep_head_dict[cur_name]['num_conv']
+            fc_list = []
+            for _ in range(num_conv - 1):
+                fc_list.append(nn.Sequential(
+                    nn.Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
+                    nn.BatchNorm2d(input_channels), nn.ReLU()))
+            fc_list.append(nn.Conv2d(input_channels, output_channels, kernel_size=3, stride=1, padding=1, bias=True))
+            fc = nn.Sequential(*fc_list)
+            if 'hm' in cur_name:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        kaiming_normal_(m.weight.data)
+                        if m.bias is not None:
+                            nn.init.constant_(m.bias, 0)
+            self.__setattr__(cur_name, fc)
+
+
+class CenterHead(PackedModule):
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
+                 predict_boxes_when_training=True):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.grid_size = grid_size
+        self.point_cloud_range = np.asarray(point_cloud_range, dtype=np.float32)
+        self.voxel_size = voxel_size
+        self.feature_map_stride = self.model_cfg.TARGET_ASSIGNER_CONFIG.get('FEATURE_MAP_STRIDE', None)
+        self.class_names = class_names
+        self.class_names_each_head = []
+        self.class_id_mapping_each_head = []
+        for cur_class_names in self.model_cfg.CLASS_NAMES_EACH_HEAD:
+            self.class_names_each_head.append([x for x in cur_class_names if x in class_names])
+            self.class_id_mapping_each_head.append(
+                torch.tensor([self.class_names.index(x) for x in cur_class_names if x in class_names], dtype=torch.long))
+        total_classes = sum(len(x) for x in self.class_names_each_head)
+        assert total_classes == len(self.class_names), 'class_names_each_head=%s' % self.class_names_each_head
+        use_bias = self.model_cfg.get('USE_BIAS_BEFORE_NORM', False)
+        self.shared_conv = nn.Sequential(
+            nn.Conv2d(input_channels, self.model_cfg.SHARED_CONV_CHANNEL, 3, stride=1, padding=1, bias=use_bias),
+            nn.BatchNorm2d(self.model_cfg.SHARED_CONV_CHANNEL), nn.ReLU())
+        self.heads_list = nn.ModuleList()
+        self.separate_head_cfg = self.model_cfg.SEPARATE_HEAD_CFG
+        self.head_names = []
+        for cur_class_names in self.class_names_each_head:
+            cur_head_dict = copy.deepcopy(dict(self.separate_head_cfg.HEAD_DICT))
+            cur_head_dict = {k: dict(v) for k, v in cur_head_dict.items()}
+            cur_head_dict['hm'] = dict(out_channels=len(cur_class_names), num_conv=self.model_cfg.NUM_HM_CONV)
+            self.head_names.append(list(cur_head_dict.keys()))
+            self.heads_list.append(SeparateHead(self.model_cfg.SHARED_CONV_CHANNEL, cur_head_dict, init_bias=-2.19, use_bias=use_bias))
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.forward_ret_dict = {}
+
+    # ---- weight preparation -------------------------------------------------------------------------------------------
+    def _build_packed(self):
+        pk = dict(shared=pack_conv_module(self.shared_conv[0], self.shared_conv[1], relu=True), heads=[])
+        c = self.model_cfg.SHARED_CONV_CHANNEL
+        for head, names in zip(self.heads_list, self.head_names):
+            seqs = [getattr(head, n) for n in names]
+            outs = [head.sep_head_dict[n]['out_channels'] for n in names]
+            offs = np.concatenate([[0], np.cumsum(outs)]).astype(int)
+            entry = dict(names=names, outs=outs, offs=offs, total=int(offs[-1]))
+            if all(len(s) == 2 for s in seqs):
+                # stage 1: every branch's conv+BN+ReLU reads the same shared map -> concatenate along cout
+                ws, bs = zip(*[_fold(s[0][0], s[0][1], out_axis=0) for s in seqs])
+                entry['stage1'] = pack_conv_raw(torch.cat(ws, 0), torch.cat(bs, 0), relu=True)
+                # stage 2: branch i maps its own 64 channels to outs[i] channels -> block-diagonal dense weight
+                w2 = ws[0].new_zeros((int(offs[-1]), c * len(seqs), 3, 3))
+                b2 = ws[0].new_zeros((int(offs[-1]),))
+                for i, s in enumerate(seqs):
+                    w2[offs[i]:offs[i + 1], c * i:c * (i + 1)] = s[1].weight.detach().float()
+                    b2[offs[i]:offs[i + 1]] = s[1].bias.detach().float()
+                entry['stage2'] = pack_conv_raw(w2, b2, relu=False)
+            else:
+                entry['branches'] = []
+                for s in seqs:
+                    mods = list(s)
+                    chain = [pack_conv_module(m[0], m[1], relu=True) for m in mods[:-1]]
+                    chain.append(pack_conv_module(mods[-1], None, relu=False))
+                    entry['branches'].append(chain)
+            pk['heads'].append(entry)
+        return pk
+
+    # ---- forward ----------------------------------------------------------------------------------------------------------
+    def _run_head_convs(self, x, entry):
+        B, H, W, _ = x.shape
+        ld = max(16, (entry['total'] + 3) // 4 * 4)
+        buf = torch.zeros((B, H, W, ld), dtype=torch.float32, device=x.device)
+        if 'stage1' in entry:
+            mid = entry['stage1'].run(x)
+            entry['stage2'].run(mid, out=buf)
+        else:
+            for chain, off in zip(entry['branches'], entry['offs'][:-1]):
+                y = x
+                for conv in chain[:-1]:
+                    y = conv.run(y)
+                chain[-1].run(y, out=buf, out_ch_off=int(off))
+        return buf
+
+    def _decode_kwargs(self, entry):
+        pp = self.model_cfg.POST_PROCESSING
+        off = {n: int(o) for n, o in zip(entry['names'], entry['offs'][:-1])}
+        for need in ('center', 'center_z', 'dim', 'rot', 'hm'):
+            assert need in off, 'CenterHead decode kernel needs the %s branch' % need
+        assert 'vel' not in off and 'iou' not in off, 'vel / iou branches are not used by the five configs'
+        return dict(k=pp.MAX_OBJ_PER_SAMPLE, num_class=entry['outs'][entry['names'].index('hm')], ch_center=off['center'],
+                    ch_z=off['center_z'], ch_dim=off['dim'], ch_rot=off['rot'], ch_hm=off['hm'],
+                    stride=float(self.feature_map_stride), voxel_x=float(np.float32(self.voxel_size[0])),
+                    voxel_y=float(np.float32(self.voxel_size[1])), min_x=float(self.point_cloud_range[0]),
+                    min_y=float(self.point_cloud_range[1]), limit=list(pp.POST_CENTER_LIMIT_RANGE),
+                    score_thresh=pp.SCORE_THRESH)
+
+    def generate_predicted_boxes(self, batch_size, head_bufs, pk):
+        pp = self.model_cfg.POST_PROCESSING
+        nms_cfg = pp.NMS_CONFIG
+        assert nms_cfg.NMS_TYPE == 'nms_gpu', 'only the rotated nms_gpu of the five configs is built'
+        per_head = []
+        for idx, (buf, entry) in enumerate(zip(head_bufs, pk['heads'])):
+            boxes, scores, labels, _cell, count = ops.centerhead_decode(buf, self._decode_kwargs(entry))
+            k = boxes.shape[1]
+            keep = torch.zeros((batch_size, nms_cfg.NMS_POST_MAXSIZE), dtype=torch.int32, device=buf.device)
+            kcnt = torch.zeros((batch_size,), dtype=torch.int32, device=buf.device)
+            ws = None
+            for b in range(batch_size):
+                # candidates are already in descending score order: scores=None skips the device sort
+                kb, cb = ops.nms_rotated(boxes[b], None, nms_cfg.NMS_THRESH, min(nms_cfg.NMS_PRE_MAXSIZE, k),
+                                         nms_cfg.NMS_POST_MAXSIZE, n_dev=count[b:b + 1], workspace=ws)
+                keep[b] = kb
+                kcnt[b:b + 1] = cb
+            per_head.append((boxes, scores, labels, keep, kcnt, idx))
+        # single host sync: how many boxes survive per (head, frame)
+        counts = torch.stack([h[4] for h in per_head], 0).cpu().numpy()
+        ret = []
+        for b in range(batch_size):
+            pb, ps, pl = [], [], []
+            for hi, (boxes, scores, labels, keep, _kcnt, idx) in enumerate(per_head):
+                sel = keep[b, :int(counts[hi, b])].long()
+                pb.append(boxes[b, sel])
+                ps.append(scores[b, sel])
+                mapping = self.class_id_mapping_each_head[idx].to(labels.device)
+                pl.append(mapping[labels[b, sel].long()])
+            ret.append(dict(pred_boxes=torch.cat(pb, 0), pred_scores=torch.cat(ps, 0), pred_labels=torch.cat(pl, 0) + 1))
+        return ret
+
+    def forward(self, data_dict):
+        require_eval_hip(self, 'CenterHead')
+        pk = self.packed()
+        x = ops.as_nhwc(data_dict['spatial_features_2d'])
+        x = pk['shared'].run(x)
+        head_bufs, pred_dicts = [], []
+        for entry in pk['heads']:
+            buf = self._run_head_convs(x, entry)
+            head_bufs.append(buf)
+            view = ops.nchw_view(buf)
+            pred_dicts.append({n: view[:, int(entry['offs'][i]):int(entry['offs'][i + 1])] for i, n in enumerate(entry['names'])})
+        self.forward_ret_dict['pred_dicts'] = pred_dicts
+        final = self.generate_predicted_boxes(data_dict['batch_size'], head_bufs, pk)
+        data_dict['final_box_dicts'] = final
+        if self.model_cfg.get('RETURN_MODAR_POINTS', False):
+            for pred in final:
+                if pred['pred_boxes'].shape[0] > 0:
+                    data_dict['mo_pts'] = torch.cat([pred['pred_boxes'], pred['pred_scores'].reshape(-1, 1),
+                                                     pred['pred_labels'].reshape(-1, 1).float()], dim=1)
+        return data_dict
+
+    def get_loss(self):
+        raise NotImplementedError('training (target assignment + CenterNet losses, reference :105-300) is the next scope row; '
+                                  'round 1 ships inference')

@@ -1,0 +1,46 @@
+"""CenterPoint detector: the module chain of the reference (pcdet/models/detectors/centerpoint.py:4-78) --
+forward = for m in module_list: batch_dict = m(batch_dict); eval returns (pred_dicts, recall_dict)."""
+from .detector3d_template import Detector3DTemplate
+
+
+class CenterPoint(Detector3DTemplate):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict):
+        for cur_module in self.module_list:
+            batch_dict = cur_module(batch_dict)
+        if self.training:
+            loss, tb_dict, disp_dict = self.get_training_loss()
+            return {'loss': loss}, tb_dict, disp_dict
+        pred_dicts, recall_dicts = self.post_processing(batch_dict)
+        if self.model_cfg.get('RETURN_BATCH_DICT', False):
+            return pred_dicts, batch_dict
+        return pred_dicts, recall_dicts
+
+    def get_training_loss(self):
+        disp_dict = {}
+        loss_rpn, tb_dict = self.dense_head.get_loss()
+        tb_dict = {'loss_rpn': loss_rpn.item(), **tb_dict}
+        loss = loss_rpn
+        if self.corrector is not None:
+            loss_corrector, tb_dict = self.corrector.get_training_loss(tb_dict)
+            tb_dict['loss_corrector'] = loss_corrector.item()
+            loss = loss + loss_corrector
+        if self.v2x_mid_fusion is not None:
+            distill = self.v2x_mid_fusion.loss_dict['loss_distill']
+            loss = loss + distill
+            tb_dict['loss_mid_fusion_distill'] = distill.item() if hasattr(distill, 'item') else 0.0
+        tb_dict['loss_total'] = loss.item()
+        return loss, tb_dict, disp_dict
+
+    def post_processing(self, batch_dict):
+        post_process_cfg = self.model_cfg.POST_PROCESSING
+        final_pred_dict = batch_dict['final_box_dicts']
+        recall_dict = {}
+        for index in range(batch_dict['batch_size']):
+            recall_dict = self.generate_recall_record(
+                box_preds=final_pred_dict[index]['pred_boxes'], recall_dict=recall_dict, batch_index=index,
+                data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
+        return final_pred_dict, recall_dict

@@ -1,0 +1,40 @@
+"""Mixin that caches the HIP-side form of a module's weights (BatchNorm folded, repacked for the MFMA tiles) and drops the
+cache whenever the parameters may have changed: .to()/.cuda() (_apply), load_state_dict, train()."""
+import torch.nn as nn
+
+
+class PackedModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._pcp_cache = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        self._pcp_cache = None
+        for m in self.children():
+            if isinstance(m, PackedModule):
+                m.invalidate_packed()
+
+    def _apply(self, fn, *args, **kwargs):
+        self._pcp_cache = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        self._pcp_cache = None
+        return super().train(mode)
+
+    def packed(self):
+        """dict built lazily by the subclass's _build_packed(); valid until the next invalidation."""
+        if self._pcp_cache is None:
+            self._pcp_cache = self._build_packed()
+        return self._pcp_cache
+
+    def _build_packed(self):
+        raise NotImplementedError
+
+
+def require_eval_hip(module, what):
+    if module.training:
+        raise NotImplementedError(
+            '%s: the HIP path implements inference (eval mode); training kernels (backward) are listed as the next '
+            'scope row in DESIGN.md -- call model.eval()' % what)

@@ -1,0 +1,54 @@
+"""Python surface of the rotated-IoU / NMS op, call-compatible with the reference's
+pcdet/ops/iou3d_nms/iou3d_nms_utils.py (:10-99, :102-189), on top of libpcp_hip.so instead of iou3d_nms_cuda.
+
+Unlike the reference's nms_gpu (mask on the GPU, D2H copy, greedy loop on the CPU, `keep` returned through a CPU tensor --
+iou3d_nms.cpp:103-135) everything stays on the device; results are CUDA tensors.
+"""
+import torch
+
+from pcp_amd import ops
+
+
+def boxes_bev_iou_cpu(boxes_a, boxes_b):
+    raise NotImplementedError('the CPU IoU of the reference (iou3d_cpu.cpp) is not part of the GPU product path; '
+                              'use boxes_iou_bev on CUDA tensors')
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """(N,7) x (M,7) [x, y, z, dx, dy, dz, heading] -> (N, M) rotated BEV IoU"""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    return ops.boxes_bev_pairwise(boxes_a.float(), boxes_b.float(), 1)
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    return ops.boxes_bev_pairwise(boxes_a.float(), boxes_b.float(), 0)
+
+
+def boxes_iou3d_gpu(boxes_a, boxes_b):
+    """3-D IoU = BEV overlap x height overlap / union volume (reference :48-81)."""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    a_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
+    a_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
+    b_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(1, -1)
+    b_min = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(1, -1)
+    overlaps_bev = boxes_overlap_bev(boxes_a, boxes_b)
+    overlaps_h = torch.clamp(torch.min(a_max, b_max) - torch.max(a_min, b_min), min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
+    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(1, -1)
+    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+    """boxes (N,7), scores (N,) -> (indices of kept boxes into the input, None); sort + mask + greedy on the device."""
+    assert boxes.shape[1] == 7
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes.device), None
+    pre = int(pre_maxsize) if pre_maxsize is not None else n
+    keep, cnt = ops.nms_rotated(boxes.float().contiguous(), scores.float().contiguous(), thresh, pre, n)
+    return keep[:int(cnt.item())].long(), None
+
+
+def nms_normal_gpu(boxes, scores, thresh, **kwargs):
+    raise NotImplementedError('axis-aligned nms_normal_gpu is not on the PointPillars hot path (SURVEY.md section 2.1)')

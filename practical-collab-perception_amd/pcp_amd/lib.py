@@ -28,7 +28,8 @@ class Conv3x3(ctypes.Structure):
 
 class Pointwise(ctypes.Structure):
     _fields_ = [('mode', c_i32), ('rows', c_i64), ('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32),
-                ('cout', c_i32), ('cout_pad', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32)]
+                ('cout', c_i32), ('cout_pad', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32),
+                ('in2', vp), ('ld_in2', c_i32), ('k_split', c_i32), ('residual', vp), ('ld_res', c_i32)]
 
 
 class Decode(ctypes.Structure):
@@ -60,6 +61,9 @@ SYMBOLS = {
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
     'pcp_bev_sample_bilinear': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp,
                                         c_i32, vp]),
+    'pcp_hunter_apply_flow': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_f, vp, vp]),
+    'pcp_select_transform_points': (c_i32, [vp, c_i64, c_i32, c_i32, c_f, c_i32, ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_uint8),
+                                            vp, vp]),
     'pcp_bev_scatter_mean_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32, c_i64]),
     'pcp_bev_scatter_mean': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, vp, c_sz,
                                      vp, c_i32, vp]),

@@ -122,9 +122,11 @@ def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None,
     return out
 
 
-def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
-    """mode PW_PLAIN: x (..., ld_in) rows; PW_SPACE2DEPTH / PW_DEPTH2SPACE: x (B, H, W, ld_in)."""
-    _need_cuda(x, packed, bias, out)
+def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0, x2=None,
+              k_split=0, x2_ch_off=0, residual=None, res_ch_off=0):
+    """mode PW_PLAIN: x (..., ld_in) rows; PW_SPACE2DEPTH / PW_DEPTH2SPACE: x (B, H, W, ld_in).
+    PLAIN extras: x2 supplies contraction channels [k_split, cin) (a cat without the copy); residual is added last."""
+    _need_cuda(x, packed, bias, out, x2, residual)
     L = _lib.load()
     ld_in = x.shape[-1]
     if mode == _lib.PW_PLAIN:
@@ -140,6 +142,15 @@ def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, i
             out = torch.empty(shp, dtype=torch.float32, device=x.device)
     assert x.is_contiguous() and out.is_contiguous()
     d = Pointwise(mode, rows, B, H, W, cin, cout, cout_pad, ld_in, out.shape[-1], 1 if relu else 0)
+    if x2 is not None:
+        assert mode == _lib.PW_PLAIN and x2.is_contiguous() and x2.numel() // x2.shape[-1] == rows
+        d.in2 = x2.data_ptr() + 4 * x2_ch_off
+        d.ld_in2 = x2.shape[-1]
+        d.k_split = k_split
+    if residual is not None:
+        assert mode == _lib.PW_PLAIN and residual.is_contiguous() and residual.numel() // residual.shape[-1] == rows
+        d.residual = residual.data_ptr() + 4 * res_ch_off
+        d.ld_res = residual.shape[-1]
     check(L.pcp_pointwise(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
           'pcp_pointwise')
     return out
@@ -231,14 +242,56 @@ def softmax_fuse(maps, weights, channels, out):
     return out
 
 
-def bev_sample_bilinear(bev, points, min_xy, pix_xy, out=None, row_mask=None):
+def hunter_apply_flow(points, head, thresh):
+    """in-place xyz += flow for predicted dynamic-foreground rows; returns the uint8 row mask."""
+    _need_cuda(points, head)
+    L = _lib.load()
+    n, stride = points.shape
+    mask = torch.zeros((max(n, 1),), dtype=torch.uint8, device=points.device)
+    check(L.pcp_hunter_apply_flow(_p(points), n, stride, _p(head), head.shape[1], float(thresh), _p(mask), _stream()),
+          'pcp_hunter_apply_flow')
+    return mask[:n]
+
+
+def select_transform_points(points, agent_col, agent, poses, present):
+    """poses: (B, 12) float32 numpy (row-major R|t); present: (B,) bool.  Returns a same-shape copy of `points` where rows of
+    other agents / absent frames carry batch index -1."""
+    import numpy as np
+    _need_cuda(points)
+    L = _lib.load()
+    n, stride = points.shape
+    out = torch.empty_like(points)
+    poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1)
+    pres = np.ascontiguousarray(present, dtype=np.uint8)
+    B = pres.shape[0]
+    check(L.pcp_select_transform_points(_p(points), n, stride, agent_col % stride, float(agent), B,
+                                        poses.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                        pres.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _p(out), _stream()),
+          'pcp_select_transform_points')
+    return out
+
+
+def softmax_fuse_raw(map_ptrs, weights, channels, ld_map, out):
+    """like softmax_fuse but the maps are raw device addresses sharing one pixel stride (channel windows of one buffer)."""
+    _need_cuda(weights, out)
+    L = _lib.load()
+    n = len(map_ptrs)
+    arr = (ctypes.c_void_p * n)(*map_ptrs)
+    pixels = weights.numel() // weights.shape[-1]
+    check(L.pcp_softmax_fuse(arr, n, _p(weights), weights.shape[-1], pixels, channels, ld_map, out.shape[-1], _p(out),
+                             _stream()), 'pcp_softmax_fuse')
+    return out
+
+
+def bev_sample_bilinear(bev, points, min_xy, pix_xy, out=None, row_mask=None, channels=None, bev_ch_off=0):
     _need_cuda(bev, points, out, row_mask)
     L = _lib.load()
-    B, H, W, C = bev.shape
+    B, H, W, ld_bev = bev.shape
+    C = ld_bev if channels is None else channels
     n, stride = points.shape
     if out is None:
         out = torch.empty((n, C), dtype=torch.float32, device=bev.device)
-    check(L.pcp_bev_sample_bilinear(_p(bev), B, H, W, C, C, _p(points), n, stride, float(min_xy[0]), float(min_xy[1]),
+    check(L.pcp_bev_sample_bilinear(_chan_ptr(bev, bev_ch_off), B, H, W, C, ld_bev, _p(points), n, stride, float(min_xy[0]), float(min_xy[1]),
                                     float(pix_xy[0]), float(pix_xy[1]), _p(row_mask), _p(out), out.shape[1], _stream()),
           'pcp_bev_sample_bilinear')
     return out

@@ -1,0 +1,98 @@
+"""End-to-end parity: the reference-compatible detector (pcdet plugin surface over the HIP kernels) against golden vectors
+produced by the reference itself, through model(batch_dict) exactly as tools/test.py drives it.
+Tolerances: indices bit exact; dense maps 1e-3 absolute (north_star), measured error is ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, match_boxes
+from pcp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(g):
+    from pcdet.models import build_network_from_meta
+    model = build_network_from_meta(g['meta'])
+    st = synth.fill_state_dict(g['meta']['state_shapes'])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    return model.cuda().eval()
+
+
+def _check_common(g, batch, pred_dicts, atol_map=1e-3):
+    assert np.array_equal(batch['voxel_coords'].cpu().numpy(), g['voxel_coords'])            # bit exact
+    np.testing.assert_allclose(batch['pillar_features'].cpu().numpy(), g['pillar_features'], rtol=0, atol=1e-4)
+    sf = batch['spatial_features_2d']
+    assert tuple(sf.shape) == g['spatial_features_2d'].shape                                   # NCHW-shaped view
+    np.testing.assert_allclose(sf.cpu().numpy(), g['spatial_features_2d'], rtol=0, atol=atol_map)
+    for b, pd in enumerate(pred_dicts):
+        gb, gs = g['final_boxes_%d' % b], g['final_scores_%d' % b]
+        pb, ps = pd['pred_boxes'].cpu().numpy(), pd['pred_scores'].cpu().numpy()
+        assert pd['pred_labels'].dtype == torch.int64 and bool((pd['pred_labels'] == 1).all())
+        assert abs(pb.shape[0] - gb.shape[0]) <= 1
+        n, worst = match_boxes(gb, gs, pb, ps, tol=1e-3)
+        assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+
+
+@pytest.mark.parametrize('tag', ['ego', 'early', 'car'])
+def test_single_agent_configs_match_reference_outputs(tag):
+    g = load_golden('g1_%s.npz' % tag)
+    model = _build(g)
+    pts = torch.from_numpy(g['points']).cuda()
+    batch = {'points': pts, 'batch_size': 2, 'metadata': [{}, {}]}
+    with torch.no_grad():
+        pred_dicts, recall = model(batch)
+    torch.cuda.synchronize()
+    _check_common(g, batch, pred_dicts)
+    hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        np.testing.assert_allclose(hd[name].cpu().numpy(), g['head_' + name], rtol=0, atol=1e-3)
+    if 'points_after' in g:                                                 # HunterJr mutates the caller's points (quirk Q8)
+        np.testing.assert_allclose(batch['points'].cpu().numpy(), g['points_after'], rtol=0, atol=1e-4)
+        assert not np.array_equal(g['points_after'], g['points'])
+    assert recall == {}
+
+
+def test_disco_mid_fusion_matches_reference_outputs():
+    g = load_golden('g1_disco.npz')
+    model = _build(g)
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+    with torch.no_grad():
+        pred_dicts, _ = model(batch)
+    torch.cuda.synchronize()
+    assert sorted(batch['bev_img'].keys()) == [0, 2]
+    assert tuple(batch['bev_img'][2].shape) == g['bev_img_2'].shape         # agent 2 absent from the last frame -> batch 1
+    # the ego->agent transform runs in fp32 on the device; a point within an ulp of a cell edge may change pillar: allow a
+    # handful of pixels to differ, the rest must agree to 1e-3
+    for aid in (0, 2):
+        diff = np.abs(batch['bev_img'][aid].cpu().numpy() - g['bev_img_%d' % aid])
+        assert (diff > 1e-3).mean() < 2e-3, (aid, float((diff > 1e-3).mean()))
+    diff = np.abs(batch['bev_img_early'].cpu().numpy()[:, ::4] - g['bev_img_early_probe'])
+    assert float(diff.max()) < 1e-3
+    diff = np.abs(batch['spatial_features_2d'].cpu().numpy() - g['spatial_features_2d'])
+    assert (diff > 1e-3).mean() < 5e-3, float((diff > 1e-3).mean())
+    assert np.array_equal(batch['voxel_coords'].cpu().numpy(), g['voxel_coords'])
+
+
+def test_fast_mode_skips_pillar_materialisation_and_matches():
+    g = load_golden('g1_ego.npz')
+    model = _build(g)
+    model.vfe.materialize_pillars = False
+    model.vfe.reuse_buffers = True
+    pts = torch.from_numpy(g['points']).cuda()
+    outs = []
+    for _ in range(3):                     # buffer reuse across frames must not leak state
+        batch = {'points': pts.clone(), 'batch_size': 2, 'metadata': [{}, {}]}
+        with torch.no_grad():
+            pred_dicts, _ = model(batch)
+        outs.append(batch['spatial_features_2d'].clone())
+        assert 'pillar_features' not in batch
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(outs[0].cpu().numpy(), g['spatial_features_2d'], rtol=0, atol=1e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()

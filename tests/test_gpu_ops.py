@@ -368,6 +368,7 @@ def test_warp_nearest_matches_golden():
     from pcp_amd import fusion_host
     g = load_golden('g4_warp.npz')
     d = dev()
+    n_exact = n_total = 0
     for key in [str(k) for k in g['cases']]:
         H = int(key.split('_')[0][1:])
         pc_min, pix = [float(v) for v in g['H%d_params' % H]]
@@ -382,7 +383,24 @@ def test_warp_nearest_matches_golden():
         want = g[key + '_out']
         ok = ~ambiguous.numpy()[None]                                # pixels whose source coordinate is not on a .5 tie
         assert np.array_equal(np.where(ok, got, 0), np.where(ok, want, 0)), key
-        assert (~ok).mean() < 0.30
+        # on a .5 tie the pick depends on the last ulp of the affine evaluation (torch's CPU sgemm order is not ours):
+        # there the kernel must return one of the two (four) neighbouring source pixels, or the zero pad
+        th = np.asarray(theta, dtype=np.float64).reshape(2, 3)
+        xs = (2.0 * np.arange(H) + 1.0) / H - 1.0
+        yy, xx = np.meshgrid(xs, xs, indexing='ij')
+        fx = ((xx * th[0, 0] + yy * th[0, 1] + th[0, 2] + 1.0) * H - 1.0) / 2.0
+        fy = ((xx * th[1, 0] + yy * th[1, 1] + th[1, 2] + 1.0) * H - 1.0) / 2.0
+        img_np = img.numpy()
+        good = np.zeros((H, H), bool)
+        for cx in (np.floor(fx), np.ceil(fx)):
+            for cy in (np.floor(fy), np.ceil(fy)):
+                inb = (cx >= 0) & (cx < H) & (cy >= 0) & (cy < H)
+                cand = np.where(inb[None], img_np[:, np.clip(cy, 0, H - 1).astype(int), np.clip(cx, 0, H - 1).astype(int)], 0.0)
+                good |= (cand == got).all(0)
+        assert good[ambiguous.numpy()].all(), key
+        n_exact += int(ok.sum())
+        n_total += ok.size
+    assert n_exact / n_total > 0.6
 
 
 def test_softmax_fuse_matches_torch():
