@@ -1,0 +1,251 @@
+"""bench.py -- frames/s of the PointPillars collaborative-perception hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config car|ego|early|disco] [--batch B]
+
+A "step" is one pass of the hot path (points resident in HBM -> final boxes) over one batch of B synthetic 60k-point clouds
+per GPU.  Default workload = BASELINE.json configs[1]: v2x_pointpillar_basic_car.yaml, single-agent inference (VFE -> scatter ->
+BEV backbone -> HunterJr -> CenterHead -> decode -> rotated NMS), B = BATCH_SIZE_PER_GPU = 4.
+N > 1: launched by torch.distributed.run, one rank per GPU; frames are independent so ranks are replicas on different frames
+(weak scaling, no data-path collective); value = all ranks' frames / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  roofline     : the dominant kernel (3x3 conv, fp32 MFMA implicit GEMM) timed live with HIP events on its stream
+  cpu_baseline : the oracle (CPU restatement of the reference modules) timed on this box's host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, 'practical-collab-perception_amd')
+for _p in (REPO, PKG, os.path.join(REPO, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    'car': dict(yaml='v2x_pointpillar_basic_car.yaml', layout='car', agents_in_cloud=1,
+                name='v2x_pointpillar_basic_car single-agent inference (VFE+scatter+backbone+HunterJr+CenterHead+NMS)'),
+    'ego': dict(yaml='v2x_pointpillar_basic_ego.yaml', layout='lately', agents_in_cloud=1,
+                name='v2x_pointpillar_basic_ego lately-fusion ego pass (60k points incl. 300 MoDAR rows)'),
+    'early': dict(yaml='v2x_pointpillar_basic_ego_early.yaml', layout='early', agents_in_cloud=6,
+                  name='v2x_pointpillar_basic_ego_early early fusion (6 x 60k points merged)'),
+    'disco': dict(yaml='v2x_pointpillar_disco.yaml', layout='disco', agents_in_cloud=6,
+                  name='v2x_pointpillar_disco mid fusion (3 BEV makers + warp/fuse, 6 x 60k points)'),
+}
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def load_cfg(yaml_name):
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    cfg = cfg_from_yaml_file(os.path.join(PKG, 'tools', 'cfgs', 'v2x_sim_models', yaml_name), EasyDict())
+    for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
+        if cfg.MODEL.get(key, None) is not None:
+            cfg.MODEL[key].CKPT = None          # random-init weights: no checkpoints offline
+    return cfg
+
+
+def build_model(cfg):
+    from pcdet.models import DatasetInfo, build_network
+    from pcp_amd import synth
+    enc = cfg.DATA_CONFIG.POINT_FEATURE_ENCODING
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(enc.used_feature_list))
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    state = synth.fill_state_dict(shapes)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    return model, state, ds
+
+
+def make_points(conf, batch, rank):
+    """B frames per rank; frame f of rank r uses agent streams 100*r + 10*f + a (distinct data on every rank)."""
+    from pcp_amd import synth
+    clouds, metas = [], []
+    for f in range(batch):
+        parts = []
+        for a in range(conf['agents_in_cloud']):
+            c = synth.agent_cloud(agent=1000 * rank + 10 * f + a, n_points=60000, layout=conf['layout'])
+            if conf['layout'] == 'disco':
+                c[:, -1] = float(a)
+            parts.append(c)
+        clouds.append(np.concatenate(parts, 0))
+        metas.append({'se3_from_ego': {a: synth.agent_pose(a) for a in range(conf['agents_in_cloud']) if a != 1}})
+    return synth.collate(clouds), metas
+
+
+def cpu_baseline(conf, cfg, state, batch_points, metas, budget_s=25.0):
+    """oracle forward on the host cores: 1 frame per run (B=1), as many runs as fit the budget (at least 1)."""
+    from oracle import model as omodel
+    from pcdet.config import EasyDict
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    arch = omodel.arch_from_cfg(plain(cfg.MODEL), list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), list(vs))
+    pts = batch_points[batch_points[:, 0] == 0].copy()
+    # threads actually used: the CPUs this process may run on, capped at 32 (oneDNN convs at these sizes stop scaling
+    # well before that and oversubscribing a shared host makes the baseline meaningless)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    omodel.forward(pts, state, arch, metadata=metas[:1])          # warm-up (also builds the C NMS oracle)
+    warm = time.time() - t0
+    runs, spent = 0, 0.0
+    while runs < 1 or (spent + spent / max(runs, 1) < budget_s - warm and runs < 20):
+        t1 = time.time()
+        omodel.forward(pts, state, arch, metadata=metas[:1])
+        spent += time.time() - t1
+        runs += 1
+    return dict(value=round(runs / spent, 4), unit='frames/s', cores=cores, kind='port',
+                sample='%d x 1 frame (%d points), oracle/model.py forward incl. decode+NMS, torch CPU threads=%d' % (runs, pts.shape[0], cores))
+
+
+class ConvTimer:
+    """HIP events around every pcp_conv3x3 launch on the launch stream (instrumented pass, outside the timed region)."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from pcp_amd import ops
+        self._orig = ops.conv3x3
+        timer = self
+
+        def timed(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = timer._orig(x, packed, bias, cin, cout, cout_pad, stride=stride, relu=relu, out=out, in_ch_off=in_ch_off,
+                            out_ch_off=out_ch_off)
+            e1.record(s)
+            B, H, W, _ = x.shape
+            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+            timer.records.append((e0, e1, 2.0 * B * Ho * Wo * cout * 9 * cin, stride, cout_pad))
+            return r
+        ops.conv3x3 = timed
+        import pcdet.models.convnet as cn
+        cn.ops.conv3x3 = timed
+
+    def remove(self):
+        from pcp_amd import ops
+        ops.conv3x3 = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        # dominant kernel = the stride-1, 64-wide-N-tile instantiation (k_conv3x3<1,8,16,64,2,2>)
+        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if st == 1 and cp % 64 == 0]
+        allc = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records]
+        t, f = sum(a for a, _ in sel), sum(b for _, b in sel)
+        ta, fa = sum(a for a, _ in allc), sum(b for _, b in allc)
+        return dict(launches=len(sel), avg_us=1e6 * t / max(len(sel), 1), tflops=f / t / 1e12 if t > 0 else 0.0,
+                    all_conv_launches=len(allc), all_conv_tflops=fa / ta / 1e12 if ta > 0 else 0.0, all_conv_ms=1e3 * ta)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='car', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl')
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (the hot path has no CPU fallback)'
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+
+    conf = CONFIGS[args.config]
+    cfg = load_cfg(conf['yaml'])
+    batch = args.batch or int(cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU)
+    model, state, ds = build_model(cfg)
+    model = model.to(dev).eval()
+    for m in model.modules():
+        if hasattr(m, 'materialize_pillars'):
+            m.materialize_pillars = False       # per-pillar API tensors are not consumed downstream
+            m.reuse_buffers = True
+    pts_np, metas = make_points(conf, batch, rank)
+    pristine = torch.from_numpy(pts_np).to(dev)
+    work = torch.empty_like(pristine)
+
+    def step():
+        work.copy_(pristine)                    # HunterJr corrects xyz in place: every step starts from the same bits
+        bd = {'points': work, 'batch_size': batch, 'metadata': metas}
+        with torch.no_grad():
+            pred_dicts, _ = model(bd)
+        return pred_dicts
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_boxes = int(sum(p['pred_boxes'].shape[0] for p in preds))
+
+    if rank == 0:
+        timer = ConvTimer()
+        timer.install()
+        for _ in range(3):
+            step()
+        cs = timer.summary()
+        timer.remove()
+        frames = world * batch * args.steps
+        line = {
+            'metric': 'frames/sec (60k-pt cloud per agent) through the PointPillars hot path', 'value': round(frames / elapsed, 3),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': conf['name'], 'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
+                       'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': 'replicas x%d (frame-sharded)' % world,
+                       'final_boxes_last_step': n_boxes},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
+                         'achieved': round(cs['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(cs['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                         'avg_launch_us': round(cs['avg_us'], 2), 'launches_per_step': cs['launches'] // 3,
+                         'all_conv3x3_tflops': round(cs['all_conv_tflops'], 3), 'all_conv3x3_ms_per_step': round(cs['all_conv_ms'] / 3, 3)},
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

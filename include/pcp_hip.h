@@ -154,14 +154,15 @@ int pcp_centerhead_decode(const pcp_decode_t *desc, const float *head, void *wor
  * a9  rotated BEV IoU + NMS, entirely on the device.
  * Replaces: pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17 -> iou3d_nms.cpp:52-136 + iou3d_nms_kernel.cu:236-311
  *           (boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu) and the score sort of iou3d_nms_utils.py:92-95.
- * pcp_nms_rotated: boxes (n_max,7) + scores (n_max); n is read from *n_dev when n_dev != NULL (else n_max).
- *   Sorts by descending score (bitonic, ties by lower index), builds the 64x64-tile suppression bit mask, runs the
- *   greedy sweep in one wavefront.  keep (post_max,) int32 indices into the INPUT order; keep_count (1,) int32.
- *   scores == NULL means "boxes are already in descending score order" (skips the sort).  n_max <= 4096.
+ * pcp_nms_rotated: `batch` independent frames; boxes (batch, n_max, 7) + scores (batch, n_max); frame f uses its first
+ *   n_dev[f] rows when n_dev != NULL (else n_max).  Per frame: sort by descending score (bitonic in LDS, ties by lower
+ *   index; skipped when scores == NULL = "already sorted"), cut to pre_max, build the suppression bit mask (one
+ *   wavefront per 64-bit word), run the greedy sweep in one wavefront.  keep (batch, post_max) int32 indices into the
+ *   frame's INPUT order; keep_count (batch,) int32.  n_max <= 4096.
  * ------------------------------------------------------------------------------------------------------------------ */
-size_t pcp_nms_workspace_bytes(int32_t n_max);
-int pcp_nms_rotated(const float *boxes, const float *scores, int32_t n_max, const int32_t *n_dev, float thresh,
-                    int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+size_t pcp_nms_workspace_bytes(int32_t n_max, int32_t batch);
+int pcp_nms_rotated(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
+                    float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
                     int32_t *keep, int32_t *keep_count, void *stream);
 /* mode 0: overlap area (boxes_overlap_bev_gpu), mode 1: IoU (boxes_iou_bev_gpu); out (na, nb) float32 */
 int pcp_boxes_bev_pairwise(const float *a, int32_t na, const float *b, int32_t nb, int32_t mode, float *out,

@@ -4,7 +4,7 @@
 // boxes_iou_bev_gpu, nms_gpu) and the python-side score sort of pcdet/ops/iou3d_nms/iou3d_nms_utils.py:92-95.
 // The reference computes the 64x64-tile bit mask on the GPU, then cudaMalloc/cudaMemcpy-D2H/cudaFree and a CPU greedy
 // loop per call.  Here: (1) one-workgroup bitonic sort of (score, index) keys in LDS, (2) the
-// upper-triangle mask tiles, one wavefront per 64x64 tile with a conservative centre-distance reject, (3) a
+// upper-triangle mask, one wavefront (ballot) per 64-bit word with a conservative centre-distance reject, (3) a
 // single-wavefront greedy sweep that resolves each 64-box diagonal block in registers (v_readlane broadcasts) and ORs
 // the kept rows' mask words into the later column words, lane j owning word j.  No host round trip.
 //
@@ -150,7 +150,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_nms_sort(const float *__restri
                                                            int *__restrict__ order, float *__restrict__ sorted_boxes,
                                                            int *__restrict__ n_eff_out) {
   __shared__ u64 keys[SORT_CAP];
-  int n = n_dev ? min(*n_dev, n_max) : n_max;
+  const int fb = blockIdx.x;                       // frame
+  boxes += (size_t)fb * n_max * 7;
+  scores += (size_t)fb * n_max;
+  order += (size_t)fb * n_max;
+  sorted_boxes += (size_t)fb * n_max * 8;
+  n_eff_out += fb;
+  int n = n_dev ? min(n_dev[fb], n_max) : n_max;
   n = max(n, 0);
   int cap = 64;
   while (cap < n) cap <<= 1;
@@ -181,7 +187,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_nms_sort(const float *__restri
 // boxes already in descending score order: identity order, just repack to 8 floats
 __global__ void k_nms_identity(const float *__restrict__ boxes, int n_max, const int *__restrict__ n_dev, int pre_max,
                                int *__restrict__ order, float *__restrict__ sorted_boxes, int *__restrict__ n_eff_out) {
-  int n = n_dev ? min(*n_dev, n_max) : n_max;
+  const int fb = blockIdx.y;
+  boxes += (size_t)fb * n_max * 7;
+  order += (size_t)fb * n_max;
+  sorted_boxes += (size_t)fb * n_max * 8;
+  n_eff_out += fb;
+  int n = n_dev ? min(n_dev[fb], n_max) : n_max;
   n = min(max(n, 0), pre_max);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     order[i] = i;
@@ -192,33 +203,30 @@ __global__ void k_nms_identity(const float *__restrict__ boxes, int n_max, const
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_eff_out = n;
 }
 
-// ---- (2) suppression mask: word (row i, col block cbk) bit t = iou(i, 64*cbk + t) > thresh, for cols > i ---------------
+// ---- (2) suppression mask: word (row i, col block c) bit t = iou(i, 64c + t) > thresh, for columns > i ---------------------
+// One wavefront per 64-bit mask word: lane t evaluates the pair (i, 64c + t) and the word is the wave ballot.  The n^2/2
+// pair tests are spread over n * ceil(n/64) / 2 independent wavefronts instead of a serial 64-iteration loop per lane.
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sorted_boxes, const int *__restrict__ n_eff_p,
-                                                 int col_blocks, float thresh, u64 *__restrict__ mask) {
-  const int n = *n_eff_p;
-  const int row_blk = blockIdx.y, col_blk = blockIdx.x;
-  if (col_blk < row_blk) return;
-  if (row_blk * 64 >= n || col_blk * 64 >= n) return;
-  __shared__ float cols[64 * 8];
+                                                 int col_blocks, float thresh, u64 *__restrict__ mask, int n_max) {
+  const int fb = blockIdx.z;
+  sorted_boxes += (size_t)fb * n_max * 8;
+  mask += (size_t)fb * n_max * col_blocks;
+  const int n = n_eff_p[fb];
+  const int row = blockIdx.y, col_blk = blockIdx.x;
+  if (row >= n || col_blk * 64 >= n || col_blk < (row >> 6)) return;
   const int lane = threadIdx.x;
-  const int col_n = min(64, n - col_blk * 64);
-  if (lane < col_n) {
-    const float4 *src = reinterpret_cast<const float4 *>(sorted_boxes + (size_t)(col_blk * 64 + lane) * 8);
-    reinterpret_cast<float4 *>(cols)[lane * 2] = src[0];
-    reinterpret_cast<float4 *>(cols)[lane * 2 + 1] = src[1];
+  const int col = col_blk * 64 + lane;
+  bool hit = false;
+  if (col < n && col > row) {
+    Box a = load_box(sorted_boxes + (size_t)row * 8);
+    const float4 *src = reinterpret_cast<const float4 *>(sorted_boxes + (size_t)col * 8);
+    float4 lo = src[0], hi = src[1];
+    Box b;
+    b.x = lo.x; b.y = lo.y; b.dx = lo.w; b.dy = hi.x; b.ang = hi.z;
+    if (!far_apart(a, b)) hit = iou_of(a, b) > thresh;
   }
-  __syncthreads();
-  const int row = row_blk * 64 + lane;
-  if (row >= n) return;
-  Box a = load_box(sorted_boxes + (size_t)row * 8);
-  u64 bits = 0;
-  const int start = (row_blk == col_blk) ? lane + 1 : 0;
-  for (int t = start; t < col_n; t++) {
-    Box b = load_box(cols + t * 8);
-    if (far_apart(a, b)) continue;
-    if (iou_of(a, b) > thresh) bits |= 1ULL << t;
-  }
-  mask[(size_t)row * col_blocks + col_blk] = bits;
+  u64 word = __ballot(hit);
+  if (lane == 0) mask[(size_t)row * col_blocks + col_blk] = word;
 }
 
 // ---- (3) greedy sweep, one wavefront, n <= 4096 ---------------------------------------------------------------------------
@@ -230,8 +238,13 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
 
 __global__ __launch_bounds__(64) void k_nms_greedy(const u64 *__restrict__ mask, const int *__restrict__ n_eff_p, int col_blocks,
                                                    const int *__restrict__ order, int post_max, int *__restrict__ keep,
-                                                   int *__restrict__ keep_count) {
-  const int n = *n_eff_p;
+                                                   int *__restrict__ keep_count, int n_max) {
+  const int fb = blockIdx.x;
+  mask += (size_t)fb * n_max * col_blocks;
+  order += (size_t)fb * n_max;
+  keep += (size_t)fb * post_max;
+  keep_count += fb;
+  const int n = n_eff_p[fb];
   const int lane = threadIdx.x;
   const int nblk = (n + 63) >> 6;
   u64 remv = 0;          // lane j: removed bits of column block j
@@ -282,35 +295,35 @@ __global__ void k_pairwise(const float *__restrict__ a, int na, const float *__r
 struct NmsLayout {
   size_t order, sorted_boxes, mask, n_eff, total;
 };
-inline NmsLayout nms_layout(int n_max) {
+inline NmsLayout nms_layout(int n_max, int batch) {
   NmsLayout L;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = pcp_align_up(off + bytes, 256); return o; };
   int cb = (n_max + 63) / 64;
-  L.order = take((size_t)n_max * 4);
-  L.sorted_boxes = take((size_t)n_max * 8 * 4);
-  L.mask = take((size_t)n_max * cb * 8);
-  L.n_eff = take(64);
+  L.order = take((size_t)batch * n_max * 4);
+  L.sorted_boxes = take((size_t)batch * n_max * 8 * 4);
+  L.mask = take((size_t)batch * n_max * cb * 8);
+  L.n_eff = take((size_t)batch * 4 + 64);
   L.total = off;
   return L;
 }
 
 }  // namespace
 
-extern "C" size_t pcp_nms_workspace_bytes(int32_t n_max) {
-  if (n_max <= 0) return 256;
-  return nms_layout(n_max).total;
+extern "C" size_t pcp_nms_workspace_bytes(int32_t n_max, int32_t batch) {
+  if (n_max <= 0 || batch <= 0) return 256;
+  return nms_layout(n_max, batch).total;
 }
 
-extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t n_max, const int32_t *n_dev, float thresh,
-                               int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes, int32_t *keep,
-                               int32_t *keep_count, void *stream_) {
-  if (!keep || !keep_count || n_max < 0 || post_max <= 0 || pre_max <= 0) return PCP_ERR_ARG;
+extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
+                               float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+                               int32_t *keep, int32_t *keep_count, void *stream_) {
+  if (!keep || !keep_count || n_max < 0 || batch <= 0 || post_max <= 0 || pre_max <= 0) return PCP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
-  if (n_max == 0) return hipMemsetAsync(keep_count, 0, 4, st) == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+  if (n_max == 0) return hipMemsetAsync(keep_count, 0, 4 * (size_t)batch, st) == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
   if (!boxes || !workspace) return PCP_ERR_ARG;
-  if (n_max > SORT_CAP) return PCP_ERR_UNSUPPORTED;
-  NmsLayout L = nms_layout(n_max);
+  if (n_max > SORT_CAP || batch > 65535) return PCP_ERR_UNSUPPORTED;
+  NmsLayout L = nms_layout(n_max, batch);
   if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
   char *ws = (char *)workspace;
   int *order = (int *)(ws + L.order);
@@ -319,16 +332,16 @@ extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t 
   int *n_eff = (int *)(ws + L.n_eff);
   const int cb = (n_max + 63) / 64;
   if (scores) {
-    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(SORT_THREADS), 0, st, boxes, scores, n_max, n_dev, pre_max, order, sorted_boxes,
-                       n_eff);
-  } else {  // scores == NULL: boxes are already in descending score order
-    hipLaunchKernelGGL(k_nms_identity, dim3((n_max + 255) / 256), dim3(256), 0, st, boxes, n_max, n_dev, pre_max, order,
+    hipLaunchKernelGGL(k_nms_sort, dim3(batch), dim3(SORT_THREADS), 0, st, boxes, scores, n_max, n_dev, pre_max, order,
+                       sorted_boxes, n_eff);
+  } else {  // scores == NULL: every frame's boxes are already in descending score order
+    hipLaunchKernelGGL(k_nms_identity, dim3((n_max + 255) / 256, batch), dim3(256), 0, st, boxes, n_max, n_dev, pre_max, order,
                        sorted_boxes, n_eff);
   }
   PCP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, st, sorted_boxes, n_eff, cb, thresh, mask);
+  hipLaunchKernelGGL(k_nms_mask, dim3(cb, n_max, batch), dim3(64), 0, st, sorted_boxes, n_eff, cb, thresh, mask, n_max);
   PCP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_nms_greedy, dim3(1), dim3(64), 0, st, mask, n_eff, cb, order, post_max, keep, keep_count);
+  hipLaunchKernelGGL(k_nms_greedy, dim3(batch), dim3(64), 0, st, mask, n_eff, cb, order, post_max, keep, keep_count, n_max);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -21,7 +21,6 @@ constexpr int PFN_THREADS = 256;
 constexpr int PILLARS_PER_BLOCK = 64;
 constexpr int C0 = 32;   // first PFN layer width  (NUM_FILTERS[0] / 2)
 constexpr int C1 = 64;   // second PFN layer width (NUM_FILTERS[1])
-constexpr int MAX_F = 24;  // num_raw + 6 <= 24
 
 struct PfnParams {
   const float *points;
@@ -48,30 +47,50 @@ __device__ __forceinline__ int find_pillar(const int *pl_start, int np, int slot
   return lo;
 }
 
+__device__ __forceinline__ unsigned fkey(float v) {        // order-preserving float -> uint (handles negatives)
+  unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// One workgroup = PILLARS_PER_BLOCK consecutive pillars = one contiguous run of the bucket order.
+// Work split: lanes = points (chunks of 64), the four waves = the four quarters of the output channels, so every weight
+// address is wave-uniform (scalar loads, weights live in SGPRs) and all four waves are busy on every chunk.
+//   sweep 1: fixed-point xyz sums -> per-pillar mean
+//   sweep 2: features -> layer 0 (each wave computes all 32 channels, publishes its 8 to xmax0) -> the POINT half of layer 1
+//            d = W1[:, :32] . x for the wave's 16 output channels -> running max in dmax
+//   epilogue: out = relu(b1 + W1[:, 32:] . xmax0 + dmax)   -- exact: max_p fl(c + d_p) = fl(c + max_p d_p) (rounding is monotone)
 template <int NUM_RAW>
 __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   constexpr int F = NUM_RAW + 6;
   __shared__ int pl_start[PILLARS_PER_BLOCK + 1];
   __shared__ long long sum_fx[PILLARS_PER_BLOCK][3];
   __shared__ float mean[PILLARS_PER_BLOCK][3];
-  __shared__ int xmax0[PILLARS_PER_BLOCK][C0];       // float bits; values are >= 0 after ReLU so int order == float order
-  __shared__ float pterm[PILLARS_PER_BLOCK][C1];     // b1 + W1[:, 32:64] . xmax0[pillar]
-  __shared__ int xmax1[PILLARS_PER_BLOCK][C1];
+  __shared__ int xmax0[PILLARS_PER_BLOCK][C0];          // float bits (>= 0 after ReLU: int order == float order)
+  __shared__ unsigned dmax[PILLARS_PER_BLOCK][C1];      // fkey-encoded running max of the point half of layer 1
+  __shared__ float w1b[C0][C1 + 1];                     // W1[o][32 + k] transposed to [k][o] for the epilogue
 
   const int P = p.counters[0];
   const int r0 = blockIdx.x * PILLARS_PER_BLOCK;
   if (r0 >= P) return;
   const int np = min(PILLARS_PER_BLOCK, P - r0);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // SGPR: keeps the weight addresses scalar
 
   for (int i = tid; i <= np; i += PFN_THREADS) pl_start[i] = p.pillar_start[r0 + i];
   for (int i = tid; i < PILLARS_PER_BLOCK * 3; i += PFN_THREADS) (&sum_fx[0][0])[i] = 0;
   for (int i = tid; i < PILLARS_PER_BLOCK * C0; i += PFN_THREADS) (&xmax0[0][0])[i] = 0;
-  for (int i = tid; i < PILLARS_PER_BLOCK * C1; i += PFN_THREADS) (&xmax1[0][0])[i] = 0;
+  for (int i = tid; i < PILLARS_PER_BLOCK * C1; i += PFN_THREADS) (&dmax[0][0])[i] = 0u;
+  for (int i = tid; i < C0 * C1; i += PFN_THREADS) {
+    int o = i / C0, k = i % C0;
+    w1b[k][o] = p.w1[o * (2 * C0) + C0 + k];
+  }
   __syncthreads();
   const int s0 = pl_start[0], s1 = pl_start[np];
 
-  // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (deterministic) ---------------------------------------------
+  // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
   for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
     const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
     int pl = find_pillar(pl_start, np, s);
@@ -95,78 +114,61 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
   const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
 
-  auto build_features = [&](int s, int pl, float (&f)[F]) {
-    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+  // ---- sweep 2: lanes = points, waves = channel quarters -----------------------------------------------------------------
+  for (int base = s0; base < s1; base += 64) {
+    const int s = base + lane;
+    if (s < s1) {
+      const int pl = find_pillar(pl_start, np, s);
+      const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+      float f[F];
 #pragma unroll
-    for (int k = 0; k < NUM_RAW; k++) f[k] = row[1 + k];
-    int cell = p.pillar_cell[r0 + pl];
-    int rem = cell % plane;
-    float cx = (float)(rem / p.g.ny), cy = (float)(rem % p.g.ny);
-    f[NUM_RAW + 0] = __fsub_rn(f[0], mean[pl][0]);
-    f[NUM_RAW + 1] = __fsub_rn(f[1], mean[pl][1]);
-    f[NUM_RAW + 2] = __fsub_rn(f[2], mean[pl][2]);
-    f[NUM_RAW + 3] = __fsub_rn(f[0], __fadd_rn(__fmul_rn(cx, p.g.voxel_x), x_off));
-    f[NUM_RAW + 4] = __fsub_rn(f[1], __fadd_rn(__fmul_rn(cy, p.g.voxel_y), y_off));
-    f[NUM_RAW + 5] = __fsub_rn(f[2], z_off);
-  };
-  auto layer0 = [&](const float (&f)[F], float (&x)[C0]) {
+      for (int k = 0; k < NUM_RAW; k++) f[k] = row[1 + k];
+      const int rem = p.pillar_cell[r0 + pl] % plane;
+      const float cx = (float)(rem / p.g.ny), cy = (float)(rem % p.g.ny);
+      f[NUM_RAW + 0] = __fsub_rn(f[0], mean[pl][0]);
+      f[NUM_RAW + 1] = __fsub_rn(f[1], mean[pl][1]);
+      f[NUM_RAW + 2] = __fsub_rn(f[2], mean[pl][2]);
+      f[NUM_RAW + 3] = __fsub_rn(f[0], __fadd_rn(__fmul_rn(cx, p.g.voxel_x), x_off));
+      f[NUM_RAW + 4] = __fsub_rn(f[1], __fadd_rn(__fmul_rn(cy, p.g.voxel_y), y_off));
+      f[NUM_RAW + 5] = __fsub_rn(f[2], z_off);
+      float x[C0];
 #pragma unroll
-    for (int c = 0; c < C0; c++) {
-      float acc = p.b0[c];                          // wave-uniform addresses -> scalar loads, weights stay in SGPRs
+      for (int c = 0; c < C0; c++) {
+        float acc = p.b0[c];                          // wave-uniform addresses -> scalar loads
 #pragma unroll
-      for (int k = 0; k < F; k++) acc = fmaf(p.w0[c * F + k], f[k], acc);
-      x[c] = fmaxf(acc, 0.0f);
+        for (int k = 0; k < F; k++) acc = fmaf(p.w0[c * F + k], f[k], acc);
+        x[c] = fmaxf(acc, 0.0f);
+      }
+      // this wave publishes channels [8*wave, 8*wave + 8) of layer 0
+#pragma unroll
+      for (int c = 0; c < C0; c++)
+        if ((c >> 3) == wave) atomicMax(&xmax0[pl][c], __float_as_int(x[c]));
+      // point half of layer 1 for output channels [16*wave, 16*wave + 16)
+      const float *wq = p.w1 + (wave * 16) * (2 * C0);
+#pragma unroll 4
+      for (int o = 0; o < 16; o++) {
+        float acc = 0.0f;
+        const float *wr = wq + o * (2 * C0);
+#pragma unroll
+        for (int k = 0; k < C0; k++) acc = fmaf(wr[k], x[k], acc);
+        atomicMax(&dmax[pl][wave * 16 + o], fkey(acc));
+      }
     }
-  };
-
-  // ---- sweep 2: layer 0 + per-pillar max -------------------------------------------------------------------------------
-  for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
-    int pl = find_pillar(pl_start, np, s);
-    float f[F], x[C0];
-    build_features(s, pl, f);
-    layer0(f, x);
-#pragma unroll
-    for (int c = 0; c < C0; c++) atomicMax(&xmax0[pl][c], __float_as_int(x[c]));
   }
   __syncthreads();
 
-  // ---- per-pillar half of layer 1: pterm = b1 + W1[:, C0:2*C0] . xmax0 ------------------------------------------------
-  for (int i = tid; i < np * C1; i += PFN_THREADS) {
-    int pl = i / C1, o = i % C1;
+  // ---- epilogue: lanes = output channels, one pillar per (wave, iteration); one 256-B row per pillar --------------------------
+  for (int pl = wave; pl < np; pl += PFN_THREADS / 64) {
+    const int o = lane;
     float acc = p.b1[o];
-    const float *wr = p.w1 + o * (2 * C0) + C0;
 #pragma unroll 8
-    for (int k = 0; k < C0; k++) acc = fmaf(wr[k], __int_as_float(xmax0[pl][k]), acc);
-    pterm[pl][o] = acc;
-  }
-  __syncthreads();
-
-  // ---- sweep 3: layer 1 (point half) + per-pillar max -----------------------------------------------------------------
-  for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
-    int pl = find_pillar(pl_start, np, s);
-    float f[F], x[C0];
-    build_features(s, pl, f);
-    layer0(f, x);
-#pragma unroll 2
-    for (int o = 0; o < C1; o++) {
-      float acc = pterm[pl][o];
-      const float *wr = p.w1 + o * (2 * C0);       // wave-uniform address -> scalar loads
-#pragma unroll
-      for (int k = 0; k < C0; k++) acc = fmaf(wr[k], x[k], acc);
-      atomicMax(&xmax1[pl][o], __float_as_int(fmaxf(acc, 0.0f)));
-    }
-  }
-  __syncthreads();
-
-  // ---- write-out: one 256-B row per pillar --------------------------------------------------------------------------
-  for (int i = tid; i < np * C1; i += PFN_THREADS) {
-    int pl = i / C1, o = i % C1;
-    float v = __int_as_float(xmax1[pl][o]);
+    for (int k = 0; k < C0; k++) acc = fmaf(w1b[k][o], __int_as_float(xmax0[pl][k]), acc);
+    const float v = fmaxf(acc + fkey_inv(dmax[pl][o]), 0.0f);
     if (p.pillar_features) p.pillar_features[(long long)(r0 + pl) * C1 + o] = v;
     if (p.canvas) {
-      int cell = p.pillar_cell[r0 + pl];
-      int b = cell / plane, rem = cell % plane;
-      int cx = rem / p.g.ny, cy = rem % p.g.ny;
+      const int cell = p.pillar_cell[r0 + pl];
+      const int b = cell / plane, rem = cell % plane;
+      const int cx = rem / p.g.ny, cy = rem % p.g.ny;
       p.canvas[(((long long)b * p.g.ny + cy) * p.g.nx + cx) * C1 + o] = v;
     }
   }

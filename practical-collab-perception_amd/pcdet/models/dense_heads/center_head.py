@@ -151,15 +151,9 @@ class CenterHead(PackedModule):
         for idx, (buf, entry) in enumerate(zip(head_bufs, pk['heads'])):
             boxes, scores, labels, _cell, count = ops.centerhead_decode(buf, self._decode_kwargs(entry))
             k = boxes.shape[1]
-            keep = torch.zeros((batch_size, nms_cfg.NMS_POST_MAXSIZE), dtype=torch.int32, device=buf.device)
-            kcnt = torch.zeros((batch_size,), dtype=torch.int32, device=buf.device)
-            ws = None
-            for b in range(batch_size):
-                # candidates are already in descending score order: scores=None skips the device sort
-                kb, cb = ops.nms_rotated(boxes[b], None, nms_cfg.NMS_THRESH, min(nms_cfg.NMS_PRE_MAXSIZE, k),
-                                         nms_cfg.NMS_POST_MAXSIZE, n_dev=count[b:b + 1], workspace=ws)
-                keep[b] = kb
-                kcnt[b:b + 1] = cb
+            # candidates are already in descending score order: scores=None skips the device sort; all frames in one call
+            keep, kcnt = ops.nms_rotated(boxes, None, nms_cfg.NMS_THRESH, min(nms_cfg.NMS_PRE_MAXSIZE, k), nms_cfg.NMS_POST_MAXSIZE,
+                                         n_dev=count)
             per_head.append((boxes, scores, labels, keep, kcnt, idx))
         # single host sync: how many boxes survive per (head, frame)
         counts = torch.stack([h[4] for h in per_head], 0).cpu().numpy()

@@ -54,8 +54,8 @@ SYMBOLS = {
     'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
-    'pcp_nms_workspace_bytes': (c_sz, [c_i32]),
-    'pcp_nms_rotated': (c_i32, [vp, vp, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
+    'pcp_nms_workspace_bytes': (c_sz, [c_i32, c_i32]),
+    'pcp_nms_rotated': (c_i32, [vp, vp, c_i32, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
     'pcp_boxes_bev_pairwise': (c_i32, [vp, c_i32, vp, c_i32, c_i32, vp, vp]),
     'pcp_warp_nearest': (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp]),
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),

@@ -191,19 +191,22 @@ def centerhead_decode(head, desc_kwargs):
 
 
 def nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=None):
-    """boxes (n_max, 7) float32; scores (n_max,) or None (= already sorted).  Returns (keep (post_max,) i32, count (1,) i32)."""
+    """boxes (n_max, 7) or (B, n_max, 7) float32; scores matching or None (= already sorted); n_dev (B,) int32 or None.
+    Returns (keep (post_max,) | (B, post_max) int32 indices into each frame's input order, count (1,) | (B,) int32)."""
     _need_cuda(boxes, scores, n_dev)
     L = _lib.load()
-    n_max = boxes.shape[0]
-    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[1] == 7
-    need = L.pcp_nms_workspace_bytes(n_max)
+    single = boxes.dim() == 2
+    B = 1 if single else boxes.shape[0]
+    n_max = boxes.shape[-2]
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[-1] == 7
+    need = L.pcp_nms_workspace_bytes(n_max, B)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=boxes.device)
-    keep = torch.zeros((post_max,), dtype=torch.int32, device=boxes.device)
-    cnt = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
-    check(L.pcp_nms_rotated(_p(boxes), _p(scores), n_max, _p(n_dev), float(thresh), int(pre_max), int(post_max), _p(workspace),
+    keep = torch.zeros((B, post_max), dtype=torch.int32, device=boxes.device)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=boxes.device)
+    check(L.pcp_nms_rotated(_p(boxes), _p(scores), B, n_max, _p(n_dev), float(thresh), int(pre_max), int(post_max), _p(workspace),
                             workspace.numel(), _p(keep), _p(cnt), _stream()), 'pcp_nms_rotated')
-    return keep, cnt
+    return (keep[0], cnt) if single else (keep, cnt)
 
 
 def boxes_bev_pairwise(a, b, mode):
