@@ -1,0 +1,99 @@
+"""Dataset side of the plugin surface.  The reference's V2X-Sim datasets need the V2X-Sim data and nuscenes-devkit 1.1.9
+(pcdet/datasets/v2x_sim/, README.md:77), neither available offline, and are numpy-only code outside the hot path
+(SURVEY.md section 2).  What the hot path needs from a dataset is (a) the six attributes Detector3DTemplate reads and
+(b) the collate layout: a frame-index column prepended to every point row (pcdet/datasets/dataset.py:224-229).
+SyntheticV2XDataset provides both with the counter-based clouds of pcp_amd.synth; build_dataloader keeps the reference's
+signature (pcdet/datasets/__init__.py:54-82) and DistributedSampler semantics."""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data import DistributedSampler as _DistributedSampler
+
+from pcp_amd import synth
+
+from ..models import DatasetInfo
+from ..utils import common_utils
+
+LAYOUT_OF = {'V2XSimDataset_CAR': 'car', 'V2XSimDataset_RSU': 'car', 'V2XSimDataset_EGO': 'lately',
+             'V2XSimDataset_EGO_EARLY': 'early', 'V2XSimDataset_EGO_DISCO': 'disco'}
+AGENTS_OF = {'car': 1, 'lately': 1, 'early': 6, 'disco': 6}
+
+
+class SyntheticV2XDataset(DatasetInfo, Dataset):
+    def __init__(self, dataset_cfg, class_names, training=False, root_path=None, logger=None):
+        vs = [p.VOXEL_SIZE for p in dataset_cfg.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+        enc = dataset_cfg.POINT_FEATURE_ENCODING
+        DatasetInfo.__init__(self, class_names, dataset_cfg.POINT_CLOUD_RANGE, vs, len(enc.used_feature_list))
+        self.dataset_cfg = dataset_cfg
+        self.training = training
+        self.logger = logger
+        self.layout = LAYOUT_OF.get(dataset_cfg.DATASET, 'car')
+        syn = dataset_cfg.get('SYNTHETIC', {})
+        self.points_per_agent = int(syn.get('POINTS_PER_AGENT', 60000))
+        self.num_frames = int(syn.get('NUM_FRAMES', 16))
+        self.distribution = syn.get('DISTRIBUTION', 'uniform')
+
+    @property
+    def mode(self):
+        return 'train' if self.training else 'test'
+
+    def __len__(self):
+        return self.num_frames
+
+    def __getitem__(self, index):
+        parts = []
+        n_agents = AGENTS_OF[self.layout]
+        for a in range(n_agents):
+            c = synth.agent_cloud(agent=100 * index + a, n_points=self.points_per_agent, layout=self.layout, dist=self.distribution)
+            if self.layout == 'disco':
+                c[:, -1] = float(a)
+            parts.append(c)
+        meta = {'sample_token': 'synthetic_%06d' % index, 'lidar_id': 1,
+                'se3_from_ego': {a: synth.agent_pose(a) for a in range(n_agents) if a != 1}}
+        return {'points': np.concatenate(parts, 0), 'frame_id': index, 'metadata': meta}
+
+    @staticmethod
+    def collate_batch(batch_list, _unused=False):
+        """reference layout: `points` gets the frame index as column 0; metadata / frame_id stay python lists."""
+        ret = {'batch_size': len(batch_list)}
+        ret['points'] = synth.collate([b['points'] for b in batch_list])
+        ret['frame_id'] = np.array([b['frame_id'] for b in batch_list])
+        ret['metadata'] = [b['metadata'] for b in batch_list]
+        return ret
+
+    def generate_prediction_dicts(self, batch_dict, pred_dicts, class_names, output_path=None):
+        out = []
+        for i, pd in enumerate(pred_dicts):
+            labels = pd['pred_labels'].cpu().numpy()
+            out.append({'frame_id': batch_dict['frame_id'][i], 'boxes_lidar': pd['pred_boxes'].cpu().numpy(),
+                        'score': pd['pred_scores'].cpu().numpy(), 'pred_labels': labels,
+                        'name': np.array(class_names)[labels - 1] if labels.size else np.zeros(0, dtype='<U8')})
+        return out
+
+    def evaluation(self, det_annos, class_names, **kwargs):
+        n = sum(len(a['score']) for a in det_annos)
+        return 'synthetic data: %d detections over %d frames (no ground truth, no mAP)\n' % (n, len(det_annos)), {'num_detections': n}
+
+
+__all__ = {name: SyntheticV2XDataset for name in LAYOUT_OF}
+__all__['SyntheticV2XDataset'] = SyntheticV2XDataset
+
+
+class DistributedSampler(_DistributedSampler):
+    """round-robin shard without shuffling in eval (reference: pcdet/datasets/__init__.py:31-51)"""
+
+    def __init__(self, dataset, num_replicas=None, rank=None, shuffle=True):
+        super().__init__(dataset, num_replicas=num_replicas, rank=rank, shuffle=shuffle)
+
+
+def build_dataloader(dataset_cfg, class_names, batch_size, dist, root_path=None, workers=0, seed=None, logger=None, training=True,
+                     merge_all_iters_to_one_epoch=False, total_epochs=0):
+    dataset = __all__.get(dataset_cfg.DATASET, SyntheticV2XDataset)(dataset_cfg=dataset_cfg, class_names=class_names,
+                                                                   root_path=root_path, training=training, logger=logger)
+    sampler = None
+    if dist:
+        rank, world = common_utils.get_dist_info()
+        sampler = DistributedSampler(dataset, world, rank, shuffle=training)
+    loader = DataLoader(dataset, batch_size=batch_size, pin_memory=True, num_workers=workers, shuffle=(sampler is None) and training,
+                        collate_fn=dataset.collate_batch, drop_last=False, sampler=sampler, timeout=0)
+    return dataset, loader, sampler

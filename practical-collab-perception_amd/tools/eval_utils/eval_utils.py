@@ -1,0 +1,42 @@
+"""eval_one_epoch with the reference's signature (tools/eval_utils/eval_utils.py:22-140): the hot loop is
+`load_data_to_gpu(batch_dict); pred_dicts, ret_dict = model(batch_dict)`."""
+import time
+
+import torch
+
+from pcdet.models import load_data_to_gpu
+from pcdet.utils import common_utils
+
+
+def eval_one_epoch(cfg, args, model, dataloader, epoch_id, logger, dist_test=False, result_dir=None):
+    dataset = dataloader.dataset
+    class_names = dataset.class_names
+    det_annos = []
+    infer_meter = common_utils.AverageMeter()
+    model.eval()
+    t_start = time.time()
+    for batch_dict in dataloader:
+        load_data_to_gpu(batch_dict)
+        if getattr(args, 'infer_time', False):
+            torch.cuda.synchronize()
+            t0 = time.time()
+        with torch.no_grad():
+            pred_dicts, ret_dict = model(batch_dict)
+        if getattr(args, 'infer_time', False):
+            torch.cuda.synchronize()
+            infer_meter.update((time.time() - t0) * 1000)
+        det_annos += dataset.generate_prediction_dicts(batch_dict, pred_dicts, class_names)
+    if dist_test:
+        det_annos = common_utils.merge_results_dist(det_annos, len(dataset))
+    rank, _ = common_utils.get_dist_info()
+    if rank != 0:
+        return {}
+    sec = time.time() - t_start
+    logger.info('*************** Performance of EPOCH %s *****************' % epoch_id)
+    logger.info('Generate label finished (sec_per_example: %.4f second).' % (sec / max(len(dataset), 1)))
+    if getattr(args, 'infer_time', False):
+        logger.info('Average infer time per batch: %.3f ms' % infer_meter.avg)
+    result_str, result_dict = dataset.evaluation(det_annos, class_names)
+    logger.info(result_str)
+    result_dict['infer_time_ms'] = infer_meter.avg
+    return result_dict
