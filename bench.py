@@ -137,17 +137,32 @@ class ConvTimer:
             timer.records.append((e0, e1, 2.0 * B * Ho * Wo * cout * 9 * cin, stride, cout_pad))
             return r
         ops.conv3x3 = timed
-        import pcdet.models.convnet as cn
-        cn.ops.conv3x3 = timed
+        self._orig_w = ops.conv3x3_winograd
+
+        def timed_w(x, packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = timer._orig_w(x, packed, bias, cin, cout, cout_pad, relu=relu, out=out, in_ch_off=in_ch_off, out_ch_off=out_ch_off)
+            e1.record(s)
+            B, H, W, _ = x.shape
+            timer.records.append((e0, e1, 2.0 * B * H * W * cout * 9 * cin, 1, -1))       # cout_pad -1 marks the Winograd kernel
+            return r
+        ops.conv3x3_winograd = timed_w
 
     def remove(self):
         from pcp_amd import ops
         ops.conv3x3 = self._orig
+        ops.conv3x3_winograd = self._orig_w
 
     def summary(self):
         torch.cuda.synchronize()
-        # dominant kernel = the stride-1, 64-wide-N-tile instantiation (k_conv3x3<1,8,16,64,2,2>)
-        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if st == 1 and cp % 64 == 0]
+        # dominant kernel = the fused Winograd 3x3 kernel (k_conv3x3_wino); falls back to the direct stride-1 instantiation
+        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -1]
+        self.dominant = 'k_conv3x3_wino (3x3 s1 fused Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)'
+        if not sel:
+            sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if st == 1 and cp % 64 == 0]
+            self.dominant = 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)'
         allc = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records]
         t, f = sum(a for a, _ in sel), sum(b for _, b in sel)
         ta, fa = sum(a for a, _ in allc), sum(b for _, b in allc)
@@ -231,9 +246,12 @@ def main():
             'config': {'workload': conf['name'], 'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
                        'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': 'replicas x%d (frame-sharded)' % world,
                        'final_boxes_last_step': n_boxes},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
+            'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
                          'achieved': round(cs['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(cs['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                         # Winograd executes 16/36 of the direct convolution's multiply-adds: fraction of the MFMA peak
+                         # in EXECUTED flops (what the matrix pipe actually sustains)
+                         'executed_frac': round(cs['tflops'] * (4.0 / 9.0 if 'wino' in timer.dominant else 1.0) / MFMA_F32_PEAK_TFLOPS, 4),
                          'avg_launch_us': round(cs['avg_us'], 2), 'launches_per_step': cs['launches'] // 3,
                          'all_conv3x3_tflops': round(cs['all_conv_tflops'], 3), 'all_conv3x3_ms_per_step': round(cs['all_conv_ms'] / 3, 3)},
         }

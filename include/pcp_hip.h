@@ -101,6 +101,12 @@ typedef struct {
 int pcp_conv3x3(const pcp_conv3x3_t *desc, const float *in, const float *w_packed, const float *bias, float *out,
                 void *stream);
 
+/* Same operation for stride 1 as a fused Winograd F(2x2,3x3) kernel (2.25x fewer multiplies, still fp32 MFMA with fp32
+ * accumulation; transforms add ~1e-6 relative rounding).  Needs cin % 8 == 0, cout_pad % 64 == 0 and weights packed as
+ * U = G g G^T: [cin/8][16 (i*4+j)][cout_pad][8]. */
+int pcp_conv3x3_winograd(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                         void *stream);
+
 enum {
   PCP_PW_PLAIN = 0,       /* rows = pixels (or points): out[m, n] = sum_k in[m, k] w[n, k]                       */
   PCP_PW_SPACE2DEPTH = 1, /* Conv2d k=2 s=2: K = 4*cin gathered from the 2x2 input block of each output pixel    */

@@ -71,7 +71,7 @@ def _pack_linear(linear, bn, relu):
     else:
         b = linear.bias.detach().float() if linear.bias is not None else torch.zeros(w.shape[0], device=w.device)
     pc = PackedConv()
-    pc.kind, pc.relu, pc.stride = 'plain', relu, 1
+    pc.kind, pc.relu, pc.stride, pc.wino = 'plain', relu, 1, None
     pc.cin, pc.cout = w.shape[1], w.shape[0]
     pc.w, pc.b, pc.cout_pad = pack.pack_plain(w, b)
     return pc
@@ -105,7 +105,7 @@ class HunterJr(PackedModule):
         heads_w = torch.cat([ph.seg[0].weight, ph.reg_flow3d[0].weight, ph.instance_embedding[0].weight], 0).detach().float()
         heads_b = torch.cat([ph.seg[0].bias, ph.reg_flow3d[0].bias, ph.instance_embedding[0].bias], 0).detach().float()
         heads = PackedConv()
-        heads.kind, heads.relu, heads.stride = 'plain', False, 1
+        heads.kind, heads.relu, heads.stride, heads.wino = 'plain', False, 1, None
         heads.cin, heads.cout = heads_w.shape[1], heads_w.shape[0]
         heads.w, heads.b, heads.cout_pad = pack.pack_plain(heads_w, heads_b)
         return dict(conv_input=pack_conv_module(self.conv_input[0], self.conv_input[1], relu=True), mlp=mlp, heads=heads,

@@ -1,16 +1,36 @@
 """Shared plumbing for the dense conv stacks: turns (Conv2d | ConvTranspose2d) [+ BatchNorm2d] parameter containers into
 packed HIP weights and launches them on NHWC buffers."""
+import os
+
 import torch
 import torch.nn as nn
 
 from pcp_amd import lib, ops, pack
 
 
+# fused Winograd F(2x2,3x3) needs enough 16x16x64 workgroups to fill the 256 CUs; below that the direct kernel's smaller
+# tiles win (measured on MI355X, tools/bench_conv.py: >= 256 workgroups -> x1.4 .. x1.9, fewer -> x0.92 .. x0.99)
+WINOGRAD_MIN_WORKGROUPS = 256
+CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd
+
+
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino')
+
+    def _use_winograd(self, x):
+        if self.kind != '3x3' or getattr(self, 'wino', None) is None or CONV_ALGO == 'direct':
+            return False
+        if CONV_ALGO == 'winograd':
+            return True
+        B, H, W, _ = x.shape
+        return B * ((H + 15) // 16) * ((W + 15) // 16) * (self.wino[2] // 64) >= WINOGRAD_MIN_WORKGROUPS
 
     def run(self, x, out=None, in_ch_off=0, out_ch_off=0):
+        if self._use_winograd(x):
+            u, ub, ucp = self.wino
+            return ops.conv3x3_winograd(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                        out_ch_off=out_ch_off)
         if self.kind == '3x3':
             return ops.conv3x3(x, self.w, self.b, self.cin, self.cout, self.cout_pad, stride=self.stride, relu=self.relu, out=out,
                                in_ch_off=in_ch_off, out_ch_off=out_ch_off)
@@ -34,6 +54,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc = PackedConv()
     pc.relu = relu
     pc.stride = 1
+    pc.wino = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -54,6 +75,8 @@ def pack_conv_module(conv, bn=None, relu=True):
         pc.kind = '3x3'
         pc.stride = s
         pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
+        if s == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48:
+            pc.wino = pack.pack_conv3x3_winograd(w, b)
     elif k == 1 and s == 1:
         pc.kind = 'plain'
         pc.w, pc.b, pc.cout_pad = pack.pack_plain(w, b)
@@ -73,4 +96,5 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.stride = stride
     pc.cin, pc.cout = w.shape[1], w.shape[0]
     pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
+    pc.wino = pack.pack_conv3x3_winograd(w, b) if (stride == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48) else None
     return pc

@@ -51,6 +51,7 @@ SYMBOLS = {
     'pcp_canvas_clear': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp]),
     'pcp_fill_zero': (c_i32, [vp, c_sz, vp]),
     'pcp_conv3x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_conv3x3_winograd': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
     'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),

@@ -63,6 +63,40 @@ def pack_conv3x3(w, bias, n_tile=32):
     return packed, pad_bias(bias, cout_pad), cout_pad
 
 
+WINO_CK = 8
+_WINO_G = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
+
+
+def pack_conv3x3_winograd(w, bias):
+    """w: [cout, cin, 3, 3] (BN-folded) -> U = G g G^T in float64, rounded once, packed [cin/8][16][cout_pad][8]."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % WINO_CK == 0
+    cout_pad = round_up(cout, 64)
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum('ia,ncab,jb->ncij', G, w.double(), G).float()              # [cout, cin, 4, 4]
+    up = u.new_zeros((cout_pad, cin, 16))
+    up[:cout] = u.reshape(cout, cin, 16)
+    packed = up.view(cout_pad, cin // WINO_CK, WINO_CK, 16).permute(1, 3, 0, 2).contiguous()
+    return packed, pad_bias(bias, cout_pad), cout_pad
+
+
+def winograd_reference(x, packed, bias, cout):
+    """Plain-torch evaluation of the packed Winograd form (validates transforms + layout on the CPU): x (B, cin, H, W), H, W even."""
+    nsl, _sixteen, cout_pad, _ck = packed.shape
+    cin = nsl * WINO_CK
+    u = packed.permute(2, 0, 3, 1).reshape(cout_pad, cin, 4, 4)[:cout]           # [cout, cin, i, j]
+    B, _, H, W = x.shape
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=x.dtype)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=x.dtype)
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                        # [B, cin, H/2, W/2, 4, 4]
+    v = torch.einsum('ia,bcyxae,je->bcyxij', BT, d, BT)
+    m = torch.einsum('ncij,bcyxij->bnyxij', u, v)
+    y = torch.einsum('ia,bnyxae,je->bnyxij', AT, m, AT)                           # [B, cout, H/2, W/2, 2, 2]
+    out = y.permute(0, 1, 2, 4, 3, 5).reshape(B, cout, H, W)
+    return out + bias[:cout].view(1, -1, 1, 1)
+
+
 def pack_plain(w, bias):
     """w: [cout, cin] -> ([cin/16][cout_pad][16], bias_pad, cout_pad)"""
     w = w.reshape(w.shape[0], -1)

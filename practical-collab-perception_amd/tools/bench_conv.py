@@ -1,0 +1,53 @@
+"""Micro-benchmark of the 3x3 convolution kernels on the layer shapes of the five configs (B frames per launch):
+direct implicit GEMM (pcp_conv3x3) vs fused Winograd F(2x2,3x3) (pcp_conv3x3_winograd).  Prints algorithmic TFLOP/s
+(2*B*H*W*Cout*9*Cin / time) for both; used to choose the per-layer algorithm in pcdet/models/convnet.py."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from pcp_amd import ops, pack  # noqa: E402
+
+LAYERS = [  # (name, cin, cout, H, W)
+    ('backbone.b0 64->64 @256', 64, 64, 256, 256), ('backbone.b1 128->128 @128', 128, 128, 128, 128),
+    ('backbone.b2 128->128 @64', 128, 128, 64, 64), ('backbone.b2 256->256 @64', 256, 256, 64, 64),
+    ('head.shared 384->64 @128', 384, 64, 128, 128), ('head.stage1 64->320 @128', 64, 320, 128, 128),
+    ('hunter.conv_input 384->384 @128', 384, 384, 128, 128), ('hunter.weightor 768->768 @128', 768, 768, 128, 128),
+    ('disco.compress 384->128 @128', 384, 128, 128, 128), ('disco.decompress 128->384 @128', 128, 384, 128, 128),
+]
+
+
+def timeit(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    d = torch.device('cuda:0')
+    print('B = %d' % B)
+    for name, cin, cout, H, W in LAYERS:
+        x = torch.randn((B, H, W, cin), device=d)
+        w = torch.randn((cout, cin, 3, 3)) * 0.05
+        b = torch.zeros(cout)
+        pd, bd, cpd = pack.pack_conv3x3(w, b)
+        pw, bw, cpw = pack.pack_conv3x3_winograd(w, b)
+        pd, bd, pw, bw = pd.to(d), bd.to(d), pw.to(d), bw.to(d)
+        out = torch.empty((B, H, W, cout), device=d)
+        flops = 2.0 * B * H * W * cout * 9 * cin
+        td = timeit(lambda: ops.conv3x3(x, pd, bd, cin, cout, cpd, out=out))
+        tw = timeit(lambda: ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=out))
+        print('%-36s direct %8.1f us %6.1f TF | winograd %8.1f us %6.1f TF (algorithmic) | x%.2f' %
+              (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw))
+
+
+if __name__ == '__main__':
+    main()

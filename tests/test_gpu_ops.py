@@ -439,3 +439,42 @@ def test_hunter_point_ops_match_oracle():
     got_img = ops.bev_scatter_mean(pts.to(d), got, B, H, W, rng[:2], [np.float32(0.2) * 4, np.float32(0.2) * 4])
     torch.cuda.synchronize()
     np.testing.assert_allclose(got_img.permute(0, 3, 1, 2).cpu().numpy(), want_img.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused Winograd F(2x2, 3x3) variant of the stride-1 conv
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,h,w,relu,batch', [(64, 64, 32, 32, True, 1), (128, 128, 16, 48, True, 2), (8, 64, 16, 16, False, 1),
+                                                      (384, 64, 16, 16, True, 1), (64, 320, 32, 32, True, 1), (64, 100, 20, 36, False, 2),
+                                                      (24, 64, 7, 9, True, 1), (768, 768, 16, 16, True, 1)])
+def test_conv3x3_winograd_matches_torch_cpu(cin, cout, h, w, relu, batch):
+    ops = _ops()
+    from pcp_amd import pack
+    x = torch.from_numpy(_rand(71, (batch, cin, h, w)))
+    wt = torch.from_numpy(_rand(72, (cout, cin, 3, 3), -0.05, 0.05))
+    b = torch.from_numpy(_rand(73, (cout,), -0.2, 0.2))
+    want = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        want = F.relu(want)
+    packed, bp, cpad = pack.pack_conv3x3_winograd(wt, b)
+    d = dev()
+    got = ops.conv3x3_winograd(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
+    torch.cuda.synchronize()
+    # Winograd transforms add a few fp32 roundings on top of the accumulation-order difference
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_conv3x3_winograd_channel_windows():
+    ops = _ops()
+    from pcp_amd import pack
+    d = dev()
+    cin, cout = 64, 128
+    wt = torch.from_numpy(_rand(77, (cout, cin, 3, 3), -0.05, 0.05))
+    packed, bp, cpad = pack.pack_conv3x3_winograd(wt, torch.zeros(cout))
+    x = torch.from_numpy(_rand(78, (1, 48, 40, 96))).to(d)
+    out = torch.full((1, 48, 40, 384), 7.0, device=d)
+    ops.conv3x3_winograd(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=16, out_ch_off=128)
+    torch.cuda.synchronize()
+    assert float((out[..., :128] - 7.0).abs().max()) == 0.0 and float((out[..., 256:] - 7.0).abs().max()) == 0.0
+    want = F.conv2d(x[..., 16:80].permute(0, 3, 1, 2).cpu(), wt, None, padding=1)
+    np.testing.assert_allclose(out[..., 128:256].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
