@@ -22,19 +22,30 @@
 // algorithmic rate can therefore exceed the MFMA peak (the kernel executes 4/9 of them).
 #include "pcp_common.h"
 
+#ifdef WINO_STAMP
+__device__ unsigned long long wino_dbg[8 * 8 * 8];          // [slice 0..7][wave][stamp]
+#define STAMP(slot)                                                                             \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && s >= 16 && s < 24 && lane == 0) {                                    \
+      unsigned long long t_;                                                                    \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+      wino_dbg[((s - 16) * 8 + wave) * 8 + (slot)] = t_;                                        \
+    }                                                                                           \
+  } while (0)
+#else
+#define STAMP(slot)
+#endif
+
 namespace {
 
 constexpr int WCK = 8;                    // input channels per slice
 constexpr int WLD = 12;                   // padded V row (floats): 16 lanes of a ds_read_b128 group hit 16 distinct slots
-constexpr int WTILES = 64;                // Winograd tiles per workgroup (8 x 8)
+constexpr int RLD = 12;                   // padded raw-pixel row (floats): the 4 tiles of a 32-lane ds_read_b32 group hit 32 banks
 constexpr int WBN = 64;                   // output channels per workgroup
 constexpr int WTHREADS = 512;
 constexpr int RAW_W = 18;
-constexpr int RAW_PIX = RAW_W * RAW_W;    // 324 pixels incl. halo
-constexpr int RAW_FLOATS = RAW_PIX * WCK; // 2592
-constexpr int V_FLOATS = 16 * WTILES * WLD;  // 12288
 constexpr int MS_LD = 33;
-constexpr int MS_FLOATS = 16 * 32 * MS_LD;   // 16896 (epilogue chunk), aliases the V buffers
+constexpr int MS_FLOATS = 16 * 32 * MS_LD;   // 16896 floats: one epilogue chunk (32 tiles x 32 channels x 16 positions)
 
 struct WinoParams {
   const float *in;
@@ -57,10 +68,30 @@ __device__ __forceinline__ f32x16 mfma32w(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// RT = 32-tile row blocks per workgroup: RT = 2 -> 16x16 output pixels (64 tiles, 1 workgroup per CU, least weight traffic:
+// the large-Cin layers); RT = 1 -> 8 rows x 16 columns of pixels (32 tiles, 2 workgroups per CU so one's prologue/epilogue
+// hides under the other's main loop: the short-K layers).
+template <int RT>
+struct WinoCfg {
+  static constexpr int TILES = 32 * RT;
+  static constexpr int OUT_H = 8 * RT;                       // output rows per workgroup (16 columns always)
+  static constexpr int RAW_H = OUT_H + 2;
+  static constexpr int RAW_PIX = RAW_H * RAW_W;
+  static constexpr int RAW_FLOATS = RAW_PIX * RLD;
+  static constexpr int V_FLOATS = 16 * TILES * WLD;
+  static constexpr int MAIN_FLOATS = 2 * RAW_FLOATS + 2 * V_FLOATS;
+  static constexpr int LDS_FLOATS = MAIN_FLOATS > MS_FLOATS ? MAIN_FLOATS : MS_FLOATS;
+  static constexpr int RAW_ITEMS = RAW_PIX * 2;               // float4 items
+  static constexpr int RAW_PER = (RAW_ITEMS + WTHREADS - 1) / WTHREADS;
+};
+
+template <int RT>
 __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * RAW_FLOATS + 2 * V_FLOATS];
-  float *rawb = lds;                       // [2][RAW_FLOATS]
-  float *vb = lds + 2 * RAW_FLOATS;        // [2][V_FLOATS]   (epilogue: Ms chunk)
+  using C = WinoCfg<RT>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  float *rawb = lds;                            // [2][RAW_FLOATS]
+  float *vb = lds + 2 * C::RAW_FLOATS;          // [2][V_FLOATS]
+  float *ms = lds;                              // epilogue chunk (aliases everything; used after the last barrier)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,53 +105,62 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
   sp /= p.tiles_x;
   const int tile_y = sp % p.tiles_y;
   const int b = sp / p.tiles_y;
-  const int oy0 = tile_y * 16, ox0 = tile_x * 16;
+  const int oy0 = tile_y * C::OUT_H, ox0 = tile_x * 16;
   const int n0 = nt * WBN;
 
-  // ---- raw patch staging: 324 pixels x 2 float4; items tid and tid + 512 -----------------------------------------------
-  const float *rsrc[2];
-  int rdst[2];
+  // ---- raw patch staging: RAW_PIX pixels x 2 float4.  Loads are UNCONDITIONAL (halo pixels outside the image read a valid
+  //      address and are zeroed by a select) so that the number of outstanding VMEM operations is static and hipcc's
+  //      counted s_waitcnt never has to wait for the youngest loads. ------------------------------------------------------
+  const float *rsrc[C::RAW_PER];
+  int rdst[C::RAW_PER];
+  bool rin[C::RAW_PER];
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < C::RAW_PER; i++) {
     int idx = tid + i * WTHREADS;
-    rsrc[i] = nullptr;
+    rsrc[i] = p.in;
     rdst[i] = -1;
-    if (idx < RAW_PIX * 2) {
+    rin[i] = false;
+    if (idx < C::RAW_ITEMS) {
       int pix = idx >> 1, q = idx & 1;
       int py = pix / RAW_W, px = pix % RAW_W;
       int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-      rdst[i] = pix * WCK + q * 4;
-      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+      rdst[i] = pix * RLD + q * 4;
+      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
+        rin[i] = true;
         rsrc[i] = p.in + ((long long)(b * p.h + iy) * p.w + ix) * p.ld_in + q * 4;
+      }
     }
   }
-  f32x4 rreg[2];
+  f32x4 rreg[C::RAW_PER];
   auto raw_load = [&](int slice) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      rreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (rsrc[i]) rreg[i] = *reinterpret_cast<const f32x4 *>(rsrc[i] + slice * WCK);
-    }
+    for (int i = 0; i < C::RAW_PER; i++) rreg[i] = *reinterpret_cast<const f32x4 *>(rsrc[i] + slice * WCK);
   };
   auto raw_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-      if (rdst[i] >= 0) *reinterpret_cast<f32x4 *>(rawb + buf * RAW_FLOATS + rdst[i]) = rreg[i];
+    for (int i = 0; i < C::RAW_PER; i++)
+      if (rdst[i] >= 0) {
+        f32x4 v = rreg[i];
+        if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(rawb + buf * C::RAW_FLOATS + rdst[i]) = v;
+      }
   };
 
-  // ---- input transform item: (tile, channel) ----------------------------------------------------------------------------
-  const int t_c = tid & 7, t_t = tid >> 3;                       // 64 tiles x 8 channels = 512 items
-  const int t_src = ((t_t >> 3) * 2 * RAW_W + (t_t & 7) * 2) * WCK + t_c;
+  // ---- input transform item: (tile, channel); tiles are 8 per row -----------------------------------------------------------
+  const int t_c = tid & 7, t_t = tid >> 3;
+  const bool t_on = t_t < C::TILES;
+  const int t_src = ((t_t >> 3) * 2 * RAW_W + (t_t & 7) * 2) * RLD + t_c;
   const int t_dst = t_t * WLD + t_c;
   auto transform = [&](int rbuf, int vbuf) {
-    const float *src = rawb + rbuf * RAW_FLOATS + t_src;
-    float *dst = vb + vbuf * V_FLOATS + t_dst;
+    if (!t_on) return;
+    const float *src = rawb + rbuf * C::RAW_FLOATS + t_src;
+    float *dst = vb + vbuf * C::V_FLOATS + t_dst;
     // w = d B (row transform, one input row at a time), then V = B^T w
     float w[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-      const float d0 = src[(a * RAW_W + 0) * WCK], d1 = src[(a * RAW_W + 1) * WCK];
-      const float d2 = src[(a * RAW_W + 2) * WCK], d3 = src[(a * RAW_W + 3) * WCK];
+      const float d0 = src[(a * RAW_W + 0) * RLD], d1 = src[(a * RAW_W + 1) * RLD];
+      const float d2 = src[(a * RAW_W + 2) * RLD], d3 = src[(a * RAW_W + 3) * RLD];
       w[a][0] = d0 - d2;
       w[a][1] = d1 + d2;
       w[a][2] = d2 - d1;
@@ -128,86 +168,107 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      dst[(0 * 4 + j) * WTILES * WLD] = w[0][j] - w[2][j];
-      dst[(1 * 4 + j) * WTILES * WLD] = w[1][j] + w[2][j];
-      dst[(2 * 4 + j) * WTILES * WLD] = w[2][j] - w[1][j];
-      dst[(3 * 4 + j) * WTILES * WLD] = w[1][j] - w[3][j];
+      dst[(0 * 4 + j) * C::TILES * WLD] = w[0][j] - w[2][j];
+      dst[(1 * 4 + j) * C::TILES * WLD] = w[1][j] + w[2][j];
+      dst[(2 * 4 + j) * C::TILES * WLD] = w[2][j] - w[1][j];
+      dst[(3 * 4 + j) * C::TILES * WLD] = w[1][j] - w[3][j];
     }
   };
 
-  // ---- B fragments (transformed weights) from global: positions 2w, 2w+1; two 32-channel column tiles each ----------------
+  // ---- B fragments (transformed weights) from global: positions 2w, 2w+1; two 32-channel column tiles each.  Two register
+  //      sets: the next slice's fragments are requested at the TOP of an iteration so the barrier at its end never waits
+  //      on memory latency. -------------------------------------------------------------------------------------------------
   const float *ubase = p.u + ((long long)(2 * wave) * p.cout_pad + n0 + r) * WCK + 4 * h;
   const long long u_pos = (long long)p.cout_pad * WCK;            // floats between positions
   const long long u_slice = 16 * u_pos;
-  f32x4 bcur[2][2];
-  auto b_load_pos = [&](int slice, int pi) {
-    const float *s = ubase + slice * u_slice + pi * u_pos;
+  f32x4 b0[2][2], b1[2][2];
+  auto b_load = [&](int slice, f32x4 (&dstb)[2][2]) {
+    const float *s = ubase + slice * u_slice;
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) bcur[pi][ct] = *reinterpret_cast<const f32x4 *>(s + ct * 32 * WCK);
+    for (int pi = 0; pi < 2; pi++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) dstb[pi][ct] = *reinterpret_cast<const f32x4 *>(s + pi * u_pos + ct * 32 * WCK);
   };
 
-  f32x16 acc[2][2][2];
+  f32x16 acc[2][RT][2];
 #pragma unroll
   for (int pi = 0; pi < 2; pi++)
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int ct = 0; ct < 2; ct++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[pi][rt][ct][e] = 0.f;
 
-  const int a_off = ((2 * wave) * WTILES + r) * WLD + 4 * h;
-  // multiply slice `vbuf`'s V by the resident B fragments; as soon as a position's MFMAs are issued its B registers are
-  // refilled with the NEXT slice's weights (one register set, prefetch distance = one whole slice)
-  auto multiply = [&](int vbuf, int next_slice) {
-    const float *vsrc = vb + vbuf * V_FLOATS + a_off;
+  const int a_off = ((2 * wave) * C::TILES + r) * WLD + 4 * h;
+  auto multiply = [&](int vbuf, const f32x4 (&bf)[2][2]) {
+    const float *vsrc = vb + vbuf * C::V_FLOATS + a_off;
 #pragma unroll
-    for (int pi = 0; pi < 2; pi++) {
+    for (int pi = 0; pi < 2; pi++)
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++) {
-        f32x4 a = *reinterpret_cast<const f32x4 *>(vsrc + (pi * WTILES + rt * 32) * WLD);
+      for (int rt = 0; rt < RT; rt++) {
+        f32x4 a = *reinterpret_cast<const f32x4 *>(vsrc + (pi * C::TILES + rt * 32) * WLD);
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
-          acc[pi][rt][ct] = mfma32w(a.x, bcur[pi][ct].x, acc[pi][rt][ct]);
-          acc[pi][rt][ct] = mfma32w(a.y, bcur[pi][ct].y, acc[pi][rt][ct]);
-          acc[pi][rt][ct] = mfma32w(a.z, bcur[pi][ct].z, acc[pi][rt][ct]);
-          acc[pi][rt][ct] = mfma32w(a.w, bcur[pi][ct].w, acc[pi][rt][ct]);
+          acc[pi][rt][ct] = mfma32w(a.x, bf[pi][ct].x, acc[pi][rt][ct]);
+          acc[pi][rt][ct] = mfma32w(a.y, bf[pi][ct].y, acc[pi][rt][ct]);
+          acc[pi][rt][ct] = mfma32w(a.z, bf[pi][ct].z, acc[pi][rt][ct]);
+          acc[pi][rt][ct] = mfma32w(a.w, bf[pi][ct].w, acc[pi][rt][ct]);
         }
       }
-      if (next_slice >= 0) b_load_pos(next_slice, pi);
-    }
   };
 
   const int n_slices = p.cin / WCK;
-  // ---- prologue: raw(0) -> LDS, V(0); raw(1) -> LDS; B(0) ------------------------------------------------------------------
+  const int last = n_slices - 1;
+  // One pipeline step: V(s) x B(s) on the matrix pipe while V(s+1) is produced; at the END of the multiply the step stores
+  // raw(s+2) (fetched during the previous step) to LDS and requests B(s+1) and raw(s+3) -- every global load has a whole step
+  // to land and no wait ever targets a just-issued load.  Indices are clamped instead of predicated (static VMEM counts).
+  // SIMD partners are de-phased: waves 0-3 transform first, waves 4-7 multiply first (one copy of the MFMA code:
+  // duplicating it in two branches makes the register allocator copy the accumulators).
+  auto step = [&](int s, const f32x4 (&bcur)[2][2], f32x4 (&bnxt)[2][2]) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    const bool has1 = s + 1 < n_slices, has2 = s + 2 < n_slices;
+    STAMP(0);
+    if (has1 && wave < 4) transform(nxt, nxt);
+    STAMP(1);
+    multiply(cur, bcur);
+    STAMP(2);
+    if (has2) raw_store(cur);           // raw[cur] was consumed by transform(s) one step ago; rreg holds raw(s+2)
+    b_load(min(s + 1, last), bnxt);
+    raw_load(min(s + 3, last));
+    STAMP(3);
+    if (has1 && wave >= 4) transform(nxt, nxt);
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+  };
+
+  // ---- prologue: raw(0), raw(1) -> LDS; V(0); rreg <- raw(2); B(0) -------------------------------------------------------------
   raw_load(0);
-  b_load_pos(0, 0);
-  b_load_pos(0, 1);
+  b_load(0, b0);
   raw_store(0);
-  if (n_slices > 1) raw_load(1);
+  raw_load(min(1, last));
   __syncthreads();
   transform(0, 0);
   if (n_slices > 1) raw_store(1);
+  raw_load(min(2, last));
   __syncthreads();
 
-  for (int s = 0; s < n_slices; s++) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    const bool has1 = s + 1 < n_slices, has2 = s + 2 < n_slices;
-    if (has2) raw_load(s + 2);
-    const int nxs = has1 ? s + 1 : -1;
-    // SIMD partners run opposite orders so one multiplies while the other transforms
-    // (one copy of the MFMA code: duplicating it in two branches makes the register allocator copy the accumulators)
-    if (has1 && wave < 4) transform(nxt, nxt);
-    multiply(cur, nxs);
-    if (has1 && wave >= 4) transform(nxt, nxt);
-    if (has2) raw_store(cur);           // raw[cur] was consumed by transform(s) one iteration ago
-    __syncthreads();
+  // static priority for the multiply-first half: it must win the matrix pipe right after the barrier, finish its MFMAs first
+  // and do its transform while the (older) transform-first partner multiplies -- otherwise age arbitration lets the partner
+  // pre-empt it and its transform lands on the critical path after BOTH multiplies
+#ifdef WINO_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+  for (int s = 0; s < n_slices; s += 2) {
+    step(s, b0, b1);
+    if (s + 1 < n_slices) step(s + 1, b1, b0);
   }
+  __builtin_amdgcn_s_setprio(0);
 
-  // ---- epilogue: four chunks (row tile rt, column tile ct) through LDS ------------------------------------------------------
-  float *ms = vb;
+  // ---- epilogue: (row tile, column tile) chunks through LDS ------------------------------------------------------------------
 #pragma unroll
-  for (int rt = 0; rt < 2; rt++) {
+  for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
       if (rt + ct > 0) __syncthreads();
@@ -262,7 +323,30 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
   }
 }
 
+template <int RT>
+int launch_wino(const pcp_conv3x3_t *d, const float *in, const float *u, const float *bias, float *out, hipStream_t st) {
+  WinoParams p;
+  p.in = in; p.u = u; p.bias = bias; p.out = out;
+  p.batch = d->batch; p.h = d->in_h; p.w = d->in_w;
+  p.cin = d->cin; p.cout = d->cout; p.cout_pad = d->cout_pad;
+  p.ld_in = d->ld_in; p.ld_out = d->ld_out; p.relu = d->relu;
+  p.tiles_x = (d->in_w + 15) / 16;
+  p.tiles_y = (d->in_h + WinoCfg<RT>::OUT_H - 1) / WinoCfg<RT>::OUT_H;
+  p.n_spatial = d->batch * p.tiles_x * p.tiles_y;
+  long long blocks = (long long)p.n_spatial * (d->cout_pad / WBN);
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
+  hipLaunchKernelGGL(k_conv3x3_wino<RT>, dim3((unsigned)blocks), dim3(WTHREADS), 0, st, p);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
 }  // namespace
+
+#ifdef WINO_STAMP
+extern "C" int pcp_debug_read(void *dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wino_dbg), bytes) == hipSuccess ? 0 : 3;
+}
+#endif
 
 extern "C" int pcp_conv3x3_winograd(const pcp_conv3x3_t *d, const float *in, const float *u_packed, const float *bias, float *out,
                                     void *stream_) {
@@ -271,17 +355,9 @@ extern "C" int pcp_conv3x3_winograd(const pcp_conv3x3_t *d, const float *in, con
   if (d->cin <= 0 || d->cin % WCK != 0 || d->cout <= 0 || d->cout_pad < d->cout || d->cout_pad % WBN != 0) return PCP_ERR_ARG;
   if (d->ld_in % 4 != 0 || (((uintptr_t)in) & 15) || (((uintptr_t)u_packed) & 15)) return PCP_ERR_ARG;
   if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0) return PCP_ERR_ARG;
-  WinoParams p;
-  p.in = in; p.u = u_packed; p.bias = bias; p.out = out;
-  p.batch = d->batch; p.h = d->in_h; p.w = d->in_w;
-  p.cin = d->cin; p.cout = d->cout; p.cout_pad = d->cout_pad;
-  p.ld_in = d->ld_in; p.ld_out = d->ld_out; p.relu = d->relu;
-  p.tiles_x = (d->in_w + 15) / 16;
-  p.tiles_y = (d->in_h + 15) / 16;
-  p.n_spatial = d->batch * p.tiles_x * p.tiles_y;
-  long long blocks = (long long)p.n_spatial * (d->cout_pad / WBN);
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
-  hipLaunchKernelGGL(k_conv3x3_wino, dim3((unsigned)blocks), dim3(WTHREADS), 0, (hipStream_t)stream_, p);
-  PCP_CHECK_LAUNCH();
-  return PCP_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  // long-K layers: 64-tile workgroups (half the weight traffic per output); short-K layers: 32-tile workgroups, two per CU
+  const long long wg64 = (long long)d->batch * ((d->in_w + 15) / 16) * ((d->in_h + 15) / 16) * (d->cout_pad / WBN);
+  if (d->cin >= 256 && wg64 >= 256) return launch_wino<2>(d, in, u_packed, bias, out, st);
+  return launch_wino<1>(d, in, u_packed, bias, out, st);
 }

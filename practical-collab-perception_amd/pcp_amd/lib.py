@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.abspath(os.path.join(_HERE, '..', 'lib', 'libpcp_hip.so'))
+LIB_PATH = os.environ.get('PCP_HIP_LIB') or os.path.abspath(os.path.join(_HERE, '..', 'lib', 'libpcp_hip.so'))   # override: kernel A/B builds
 
 c_f = ctypes.c_float
 c_i32 = ctypes.c_int32

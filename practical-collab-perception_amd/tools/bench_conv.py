@@ -32,9 +32,12 @@ def timeit(fn, iters=10):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else -1            # layer index (for rocprof --pmc runs)
     d = torch.device('cuda:0')
     print('B = %d' % B)
-    for name, cin, cout, H, W in LAYERS:
+    for li, (name, cin, cout, H, W) in enumerate(LAYERS):
+        if only >= 0 and li != only:
+            continue
         x = torch.randn((B, H, W, cin), device=d)
         w = torch.randn((cout, cin, 3, 3)) * 0.05
         b = torch.zeros(cout)
