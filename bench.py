@@ -146,7 +146,9 @@ class ConvTimer:
             r = timer._orig_w(x, packed, bias, cin, cout, cout_pad, relu=relu, out=out, in_ch_off=in_ch_off, out_ch_off=out_ch_off)
             e1.record(s)
             B, H, W, _ = x.shape
-            timer.records.append((e0, e1, 2.0 * B * H * W * cout * 9 * cin, 1, -1))       # cout_pad -1 marks the Winograd kernel
+            # same dispatch rule as pcp_conv3x3_winograd (csrc/wino.hip): 64-tile instantiation <2> for the long-K layers
+            big = cin >= 256 and B * ((H + 15) // 16) * ((W + 15) // 16) * (cout_pad // 64) >= 256
+            timer.records.append((e0, e1, 2.0 * B * H * W * cout * 9 * cin, 1, -2 if big else -1))
             return r
         ops.conv3x3_winograd = timed_w
 
@@ -158,8 +160,8 @@ class ConvTimer:
     def summary(self):
         torch.cuda.synchronize()
         # dominant kernel = the fused Winograd 3x3 kernel (k_conv3x3_wino); falls back to the direct stride-1 instantiation
-        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -1]
-        self.dominant = 'k_conv3x3_wino (3x3 s1 fused Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)'
+        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -2]
+        self.dominant = 'k_conv3x3_wino<2> (3x3 s1 fused Winograd F(2x2,3x3), 64-tile workgroups, v_mfma_f32_32x32x2_f32)'
         if not sel:
             sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if st == 1 and cp % 64 == 0]
             self.dominant = 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)'
@@ -168,6 +170,18 @@ class ConvTimer:
         ta, fa = sum(a for a, _ in allc), sum(b for _, b in allc)
         return dict(launches=len(sel), avg_us=1e6 * t / max(len(sel), 1), tflops=f / t / 1e12 if t > 0 else 0.0,
                     all_conv_launches=len(allc), all_conv_tflops=fa / ta / 1e12 if ta > 0 else 0.0, all_conv_ms=1e3 * ta)
+
+
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streaming reads)."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    e = d.get(kernel_key)
+    return None if e is None else e['bytes_per_launch']
 
 
 def main():
@@ -248,7 +262,8 @@ def main():
                        'final_boxes_last_step': n_boxes},
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
                          'achieved': round(cs['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(cs['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                         'frac': round(cs['tflops'] / MFMA_F32_PEAK_TFLOPS, 4),
+                         'traffic': pmc_traffic('k_conv3x3_wino<2>') if (args.config == 'car' and 'wino' in timer.dominant) else None,
                          # Winograd executes 16/36 of the direct convolution's multiply-adds: fraction of the MFMA peak
                          # in EXECUTED flops (what the matrix pipe actually sustains)
                          'executed_frac': round(cs['tflops'] * (4.0 / 9.0 if 'wino' in timer.dominant else 1.0) / MFMA_F32_PEAK_TFLOPS, 4),

@@ -8,8 +8,8 @@ import torch.nn as nn
 from pcp_amd import lib, ops, pack
 
 
-# fused Winograd F(2x2,3x3) needs enough 16x16x64 workgroups to fill the 256 CUs; below that the direct kernel's smaller
-# tiles win (measured on MI355X, tools/bench_conv.py: >= 256 workgroups -> x1.4 .. x1.9, fewer -> x0.92 .. x0.99)
+# fused Winograd F(2x2,3x3) needs enough workgroups to fill the 256 CUs; below that the direct kernel's smaller tiles win
+# (measured on MI355X, tools/bench_conv.py: >= 256 workgroups -> x1.35 .. x2.0 over the direct kernel)
 WINOGRAD_MIN_WORKGROUPS = 256
 CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd
 
@@ -24,7 +24,8 @@ class PackedConv:
         if CONV_ALGO == 'winograd':
             return True
         B, H, W, _ = x.shape
-        return B * ((H + 15) // 16) * ((W + 15) // 16) * (self.wino[2] // 64) >= WINOGRAD_MIN_WORKGROUPS
+        # workgroups of the 32-tile instantiation (8 rows x 16 columns of pixels x 64 channels), the finest the library uses
+        return B * ((H + 7) // 8) * ((W + 15) // 16) * (self.wino[2] // 64) >= WINOGRAD_MIN_WORKGROUPS
 
     def run(self, x, out=None, in_ch_off=0, out_ch_off=0):
         if self._use_winograd(x):
