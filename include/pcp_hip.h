@@ -107,6 +107,14 @@ int pcp_conv3x3(const pcp_conv3x3_t *desc, const float *in, const float *w_packe
 int pcp_conv3x3_winograd(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
                          void *stream);
 
+/* Grouped 3x3 conv with tiny outputs (the final convs of the CenterHead branches, center_head.py:39; HunterJr's 768 -> 2
+ * weight conv, hunter_jr.py:151): group g reads input channels [g cin_g, (g+1) cin_g) and produces output channels
+ * [off[g], off[g+1]) (1..4 each), bias added, no activation.  cin_per_group % 64 == 0.
+ * weights: [n_out][9 (ky*3+kx)][cin_per_group] float32; group_out_offsets_host: (groups + 1) int32 on the HOST; groups <= 8. */
+int pcp_conv3x3_grouped_small(const float *in, int32_t batch, int32_t h, int32_t w, int32_t ld_in, int32_t groups,
+                              int32_t cin_per_group, const int32_t *group_out_offsets_host, const float *weights, const float *bias, float *out,
+                              int32_t ld_out, void *stream);
+
 enum {
   PCP_PW_PLAIN = 0,       /* rows = pixels (or points): out[m, n] = sum_k in[m, k] w[n, k]                       */
   PCP_PW_SPACE2DEPTH = 1, /* Conv2d k=2 s=2: K = 4*cin gathered from the 2x2 input block of each output pixel    */
@@ -195,6 +203,15 @@ int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const floa
 int pcp_bev_sample_bilinear(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
                             const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
                             float pix_y, const uint8_t *row_mask, float *out, int32_t ld_out, void *stream);
+/* Fused HunterJr point head (hunter_jr.py:78-101 on top of the sampling above): pf = bilinear(bev, points) (n, ld_pf) is
+ * written once; h = relu(pf W1^T + b1); f = relu(h W2^T + b2) + pf; head = f Wh^T + bh (n, n_out) = [cls(3) | flow(3) | embed(2)].
+ * Weights are BN-folded row-major float32: w1 (hidden, c), w2 (c, hidden), wh (n_out, c).  This build: c = 384, hidden = 32,
+ * n_out = 8 (PCP_ERR_UNSUPPORTED otherwise; the unfused ops remain available). */
+int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                          const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                          float pix_y, const float *w1, const float *b1, const float *w2, const float *b2, const float *wh,
+                          const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf, float *head,
+                          void *stream);
 size_t pcp_bev_scatter_mean_workspace_bytes(int32_t batch, int32_t h, int32_t w, int64_t n);
 int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_stride, const float *feat, int32_t ld_feat,
                          int32_t c, int32_t batch, int32_t h, int32_t w, float min_x, float min_y, float pix_x,

@@ -1,0 +1,211 @@
+// a14 -- HunterJr point head, fused: bilinear sampling of the BEV map at every point -> feature MLP (C -> 32 -> C, Linear+BN+ReLU
+// twice) + residual -> the three point heads (C -> 3 | 3 | 2) in ONE kernel.
+//
+// Reference: pcdet/models/bev_layers/hunter_toolbox.py:8-39,94-127 (interpolate_points_feat_from_bev_img) and
+// pcdet/models/bev_layers/hunter_jr.py:78-101 (HunterPointHead.forward).  Unfused this is five launches that stream the
+// (N, 384) fp32 point-feature matrix (369 MB at 4 x 60k points) through HBM six times (0.96 ms); fused, a workgroup keeps its
+// 32 points' features in LDS: sampled rows are written to HBM once (the scatter-mean needs them later), the hidden and final
+// activations never leave the CU, and only (N, 8) head values come out.
+//   phase 1  per-point corner indices / weights, then the 4-row gather + blend -> LDS tile F[32][C] (+ global pf)
+//   phase 2  H1 = relu(F W1^T + b1)      fp32 MFMA, K = C split over the 4 waves, partials reduced through LDS
+//   phase 3  F <- relu(H1 W2^T + b2) + F  fp32 MFMA, 3 column tiles per wave, in place (final features)
+//   phase 4  head8 = F Wh^T + bh         one dot product per thread (VALU)
+// Sampling arithmetic is bitwise that of k_bilinear / the reference (products and sums in its order, no FMA contraction).
+#include "pcp_common.h"
+
+namespace {
+
+constexpr int PH_BM = 32;           // points per workgroup
+constexpr int PH_C = 384;           // BEV channels (num_bev_features of the five configs)
+constexpr int PH_H = 32;            // hidden width (POINT_HEAD_HIDDEN_CHANNELS: [32])
+constexpr int PH_LDF = PH_C + 4;    // padded row: a ds_read_b128 group's 16 lanes hit distinct slots
+constexpr int PH_LDH = PH_H + 4;
+constexpr int PH_NOUT = 8;
+
+struct PointHeadParams {
+  const float *bev;
+  int batch, h, w, ld_bev;
+  const float *points;
+  long long n;
+  int stride;
+  float min_x, min_y, pix_x, pix_y;
+  const float *w1, *b1;   // [32][C], [32]
+  const float *w2, *b2;   // [C][32], [C]
+  const float *wh, *bh;   // [8][C], [8]
+  float *pf;              // (n, ld_pf) sampled features
+  int ld_pf;
+  float *head;            // (n, 8)
+};
+
+__device__ __forceinline__ f32x16 mfma_ph(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void k_point_head(PointHeadParams p) {
+  __shared__ __attribute__((aligned(16))) float Fs[PH_BM * PH_LDF];
+  __shared__ __attribute__((aligned(16))) float H1s[PH_BM * PH_LDH];
+  __shared__ float red[4][PH_BM][PH_H + 1];
+  __shared__ long long c_off[PH_BM][4];     // float offsets of the four corner rows (Ia, Ib, Ic, Id)
+  __shared__ float c_w[PH_BM][4];
+  __shared__ int c_ok[PH_BM];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const long long i0 = (long long)blockIdx.x * PH_BM;
+
+  // ---- phase 1a: corners and weights (hunter_toolbox.py:19-37), no FMA contraction ---------------------------------------
+  if (tid < PH_BM) {
+#pragma clang fp contract(off)
+    const long long i = i0 + tid;
+    int ok = 0;
+    if (i < p.n) {
+      const float *row = p.points + i * p.stride;
+      int b = (int)row[0];
+      if (b >= 0 && b < p.batch) {
+        ok = 1;
+        float x = __fdiv_rn(row[1] - p.min_x, p.pix_x), y = __fdiv_rn(row[2] - p.min_y, p.pix_y);
+        float fx0 = fminf(fmaxf(floorf(x), -2.0f), (float)p.w + 1.0f), fy0 = fminf(fmaxf(floorf(y), -2.0f), (float)p.h + 1.0f);
+        int x0 = (int)fx0, y0 = (int)fy0;
+        int x1 = x0 + 1, y1 = y0 + 1;
+        x0 = min(max(x0, 0), p.w - 1); x1 = min(max(x1, 0), p.w - 1);
+        y0 = min(max(y0, 0), p.h - 1); y1 = min(max(y1, 0), p.h - 1);
+        c_w[tid][0] = ((float)x1 - x) * ((float)y1 - y);
+        c_w[tid][1] = ((float)x1 - x) * (y - (float)y0);
+        c_w[tid][2] = (x - (float)x0) * ((float)y1 - y);
+        c_w[tid][3] = (x - (float)x0) * (y - (float)y0);
+        const long long img = (long long)b * p.h * p.w;
+        c_off[tid][0] = (img + (long long)y0 * p.w + x0) * p.ld_bev;
+        c_off[tid][1] = (img + (long long)y1 * p.w + x0) * p.ld_bev;
+        c_off[tid][2] = (img + (long long)y0 * p.w + x1) * p.ld_bev;
+        c_off[tid][3] = (img + (long long)y1 * p.w + x1) * p.ld_bev;
+      }
+    }
+    c_ok[tid] = ok;
+  }
+  __syncthreads();
+  // ---- phase 1b: gather + blend, 32 points x 96 float4 --------------------------------------------------------------------
+  {
+#pragma clang fp contract(off)
+    for (int idx = tid; idx < PH_BM * (PH_C / 4); idx += 256) {
+      const int pt = idx / (PH_C / 4), q = idx % (PH_C / 4);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c_ok[pt]) {
+        const float *base = p.bev + q * 4;
+        f32x4 Ia = *reinterpret_cast<const f32x4 *>(base + c_off[pt][0]);
+        f32x4 Ib = *reinterpret_cast<const f32x4 *>(base + c_off[pt][1]);
+        f32x4 Ic = *reinterpret_cast<const f32x4 *>(base + c_off[pt][2]);
+        f32x4 Id = *reinterpret_cast<const f32x4 *>(base + c_off[pt][3]);
+        const float wa = c_w[pt][0], wb = c_w[pt][1], wc = c_w[pt][2], wd = c_w[pt][3];
+        v.x = Ia.x * wa + Ib.x * wb + Ic.x * wc + Id.x * wd;
+        v.y = Ia.y * wa + Ib.y * wb + Ic.y * wc + Id.y * wd;
+        v.z = Ia.z * wa + Ib.z * wb + Ic.z * wc + Id.z * wd;
+        v.w = Ia.w * wa + Ib.w * wb + Ic.w * wc + Id.w * wd;
+      }
+      if (i0 + pt < p.n) *reinterpret_cast<f32x4 *>(p.pf + (i0 + pt) * p.ld_pf + q * 4) = v;   // rows of foreign frames stay 0
+      *reinterpret_cast<f32x4 *>(Fs + pt * PH_LDF + q * 4) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: H1 partial over this wave's K quarter (96 channels = 12 groups of 8) -----------------------------------------
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    const float *asrc = Fs + r * PH_LDF + wave * 96 + 4 * h;
+    const float *bsrc = p.w1 + r * PH_C + wave * 96 + 4 * h;          // B[k][n = r] = W1[r][k]
+#pragma unroll 4
+    for (int g = 0; g < 12; g++) {
+      f32x4 a = *reinterpret_cast<const f32x4 *>(asrc + g * 8);
+      f32x4 bq = *reinterpret_cast<const f32x4 *>(bsrc + g * 8);
+      acc = mfma_ph(a.x, bq.x, acc);
+      acc = mfma_ph(a.y, bq.y, acc);
+      acc = mfma_ph(a.z, bq.z, acc);
+      acc = mfma_ph(a.w, bq.w, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) red[wave][(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < PH_BM * PH_H; idx += 256) {
+    const int m = idx / PH_H, nn = idx % PH_H;
+    float v = red[0][m][nn] + red[1][m][nn] + red[2][m][nn] + red[3][m][nn] + p.b1[nn];
+    H1s[m * PH_LDH + nn] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+
+  // ---- phase 3: final = relu(H1 W2^T + b2) + F, three 32-channel column tiles per wave, in place -----------------------------
+  {
+    f32x4 a[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) a[g] = *reinterpret_cast<const f32x4 *>(H1s + r * PH_LDH + g * 8 + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int ct = wave * 3 + j;
+      const float *bsrc = p.w2 + (ct * 32 + r) * PH_H + 4 * h;         // B[k][n] = W2[n][k]
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        f32x4 bq = *reinterpret_cast<const f32x4 *>(bsrc + g * 8);
+        acc = mfma_ph(a[g].x, bq.x, acc);
+        acc = mfma_ph(a[g].y, bq.y, acc);
+        acc = mfma_ph(a[g].z, bq.z, acc);
+        acc = mfma_ph(a[g].w, bq.w, acc);
+      }
+      const int n = ct * 32 + r;
+      const float bias = p.b2[n];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+        float *f = Fs + m * PH_LDF + n;
+        *f = fmaxf(acc[e] + bias, 0.f) + *f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 4: the three heads as one (8 x C) matrix: one dot product per thread ---------------------------------------------
+  {
+    const int pt = tid >> 3, o = tid & 7;
+    const float *f = Fs + pt * PH_LDF;
+    const float *wr = p.wh + o * PH_C;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < PH_C; k += 4) {
+      f32x4 fv = *reinterpret_cast<const f32x4 *>(f + k);
+      f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k);
+      acc = fmaf(fv.x, wv.x, acc);
+      acc = fmaf(fv.y, wv.y, acc);
+      acc = fmaf(fv.z, wv.z, acc);
+      acc = fmaf(fv.w, wv.w, acc);
+    }
+    if (i0 + pt < p.n) p.head[(i0 + pt) * PH_NOUT + o] = acc + p.bh[o];
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                                     const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                                     float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
+                                     const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
+                                     float *head, void *stream_) {
+  if (!bev || !w1 || !b1 || !w2 || !b2 || !wh || !bh || !pf || !head || n < 0 || batch <= 0 || h <= 0 || w <= 0) return PCP_ERR_ARG;
+  if (c != PH_C || hidden != PH_H || n_out != PH_NOUT) return PCP_ERR_UNSUPPORTED;
+  if ((ld_bev & 3) || (ld_pf & 3) || row_stride < 3 || (((uintptr_t)bev) & 15) || (((uintptr_t)pf) & 15)) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  if (!points) return PCP_ERR_ARG;
+  PointHeadParams p;
+  p.bev = bev; p.batch = batch; p.h = h; p.w = w; p.ld_bev = ld_bev;
+  p.points = points; p.n = n; p.stride = row_stride;
+  p.min_x = min_x; p.min_y = min_y; p.pix_x = pix_x; p.pix_y = pix_y;
+  p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wh = wh; p.bh = bh;
+  p.pf = pf; p.ld_pf = ld_pf; p.head = head;
+  long long blocks = (n + PH_BM - 1) / PH_BM;
+  hipLaunchKernelGGL(k_point_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

@@ -86,7 +86,7 @@ struct WinoCfg {
 };
 
 template <int RT>
-__global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
+__global__ __launch_bounds__(WTHREADS, (RT == 2 ? 2 : 4)) void k_conv3x3_wino(WinoParams p) {
   using C = WinoCfg<RT>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   float *rawb = lds;                            // [2][RAW_FLOATS]
@@ -146,11 +146,16 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
       }
   };
 
-  // ---- input transform item: (tile, channel); tiles are 8 per row -----------------------------------------------------------
+  // ---- input transform V = B^T d B, LDS -> LDS: item = (tile, channel), tiles are 8 per row.  RT == 2: all eight waves,
+  //      de-phased (waves 0-3 before their multiply, waves 4-7 after); RT == 1: waves 0-3 (256 items), before the multiply.
+  //      (A 16-byte-per-lane variant on two waves was measured 3-6 % slower on the long-K layers: on gfx950 the fp32 MFMA and
+  //      the VALU contend for the SIMD and the two transform waves become the critical path.) -------------------------------
   const int t_c = tid & 7, t_t = tid >> 3;
   const bool t_on = t_t < C::TILES;
   const int t_src = ((t_t >> 3) * 2 * RAW_W + (t_t & 7) * 2) * RLD + t_c;
   const int t_dst = t_t * WLD + t_c;
+  const bool xf_first = wave < 4;
+  const bool xf_last = (RT == 2) && wave >= 4;
   auto transform = [&](int rbuf, int vbuf) {
     if (!t_on) return;
     const float *src = rawb + rbuf * C::RAW_FLOATS + t_src;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
     const int cur = s & 1, nxt = cur ^ 1;
     const bool has1 = s + 1 < n_slices, has2 = s + 2 < n_slices;
     STAMP(0);
-    if (has1 && wave < 4) transform(nxt, nxt);
+    if (has1 && xf_first) transform(nxt, nxt);
     STAMP(1);
     multiply(cur, bcur);
     STAMP(2);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_conv3x3_wino(WinoParams p) {
     b_load(min(s + 1, last), bnxt);
     raw_load(min(s + 3, last));
     STAMP(3);
-    if (has1 && wave >= 4) transform(nxt, nxt);
+    if (has1 && xf_last) transform(nxt, nxt);
     STAMP(4);
     __syncthreads();
     STAMP(5);

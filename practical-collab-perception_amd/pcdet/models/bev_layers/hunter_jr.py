@@ -108,7 +108,21 @@ class HunterJr(PackedModule):
         heads.kind, heads.relu, heads.stride, heads.wino = 'plain', False, 1, None
         heads.cin, heads.cout = heads_w.shape[1], heads_w.shape[0]
         heads.w, heads.b, heads.cout_pad = pack.pack_plain(heads_w, heads_b)
-        return dict(conv_input=pack_conv_module(self.conv_input[0], self.conv_input[1], relu=True), mlp=mlp, heads=heads,
+        fused = None
+        if len(lf) == 6 and heads_w.shape == (8, 384) and lf[0].weight.shape == (32, 384):
+            # plain row-major folded weights for the fused point-head kernel
+            f1 = pack.fold_bn(lf[0].weight.detach().float(), lf[1].weight.detach(), lf[1].bias.detach(), lf[1].running_mean,
+                              lf[1].running_var, lf[1].eps)
+            f2 = pack.fold_bn(lf[3].weight.detach().float(), lf[4].weight.detach(), lf[4].bias.detach(), lf[4].running_mean,
+                              lf[4].running_var, lf[4].eps)
+            fused = tuple(t.contiguous() for t in (f1[0], f1[1], f2[0], f2[1], heads_w, heads_b))
+        # 768 -> 2 weight conv: N = 2 would waste 15/16 of a 32-wide MFMA tile -> small-N VALU kernel
+        wlast = self.conv_weightor[1]
+        small = None
+        if wlast.weight.shape[0] <= 4 and wlast.weight.shape[1] % 64 == 0:
+            small = (wlast.weight.detach().float().permute(0, 2, 3, 1).reshape(wlast.weight.shape[0], 9, -1).contiguous(),
+                     wlast.bias.detach().float().contiguous(), [0, int(wlast.weight.shape[0])])
+        return dict(fused=fused, w1_small=small, conv_input=pack_conv_module(self.conv_input[0], self.conv_input[1], relu=True), mlp=mlp, heads=heads,
                     w0=pack_conv_module(self.conv_weightor[0][0], self.conv_weightor[0][1], relu=True),
                     w1=pack_conv_module(self.conv_weightor[1], None, relu=False))
 
@@ -123,17 +137,26 @@ class HunterJr(PackedModule):
         pk['conv_input'].run(x, out=cat, out_ch_off=0)
         min_xy = self.point_cloud_range[:2]
         pix = [np.float32(self.voxel_size[0]) * self.bev_image_stride, np.float32(self.voxel_size[1]) * self.bev_image_stride]
-        pf = ops.bev_sample_bilinear(cat, points, min_xy, pix, channels=C)
-        h = pf
-        for i, layer in enumerate(pk['mlp']):
-            last = i == len(pk['mlp']) - 1
-            h = ops.pointwise(h, layer.w, layer.b, lib.PW_PLAIN, layer.cin, layer.cout, layer.cout_pad, relu=True,
-                              residual=pf if last else None)                          # final = pf + mlp(pf)
-        head8 = pk['heads'].run(h)                                                    # (N, 8) = cls(3) | flow(3) | embed(2)
+        if pk['fused'] is not None and C == 384:
+            pf, head8 = ops.hunter_point_head(cat, points, min_xy, pix, *pk['fused'], channels=C)   # one launch
+        else:
+            pf = ops.bev_sample_bilinear(cat, points, min_xy, pix, channels=C)
+            h = pf
+            for i, layer in enumerate(pk['mlp']):
+                last = i == len(pk['mlp']) - 1
+                h = ops.pointwise(h, layer.w, layer.b, lib.PW_PLAIN, layer.cin, layer.cout, layer.cout_pad, relu=True,
+                                  residual=pf if last else None)                      # final = pf + mlp(pf)
+            head8 = pk['heads'].run(h)                                                # (N, 8) = cls(3) | flow(3) | embed(2)
         dyn = ops.hunter_apply_flow(points, head8, self.thresh_point_cls_prob)        # mutates points[:, 1:4] in place
         ops.bev_sample_bilinear(cat, points, min_xy, pix, out=pf, row_mask=dyn, channels=C)
         ops.bev_scatter_mean(points, pf, B, H, W, min_xy, pix, out=cat, out_ch_off=C)
-        logits = pk['w1'].run(pk['w0'].run(cat))                                      # (B, H, W, 2)
+        hid = pk['w0'].run(cat)
+        if pk['w1_small'] is not None:
+            wsm, bsm, offs = pk['w1_small']
+            logits = torch.empty((B, H, W, offs[-1]), dtype=torch.float32, device=dev)
+            ops.conv3x3_grouped_small(hid, wsm, bsm, offs, logits)
+        else:
+            logits = pk['w1'].run(hid)                                                # (B, H, W, 2)
         lbuf = logits                                                                 # ld 2: softmax_fuse reads columns 0..1
         fused = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
         # two "maps" that are the two channel halves of the same 768-wide buffer (pixel stride 2C)

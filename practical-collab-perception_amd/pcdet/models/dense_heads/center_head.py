@@ -104,6 +104,11 @@ class CenterHead(PackedModule):
                     w2[offs[i]:offs[i + 1], c * i:c * (i + 1)] = s[1].weight.detach().float()
                     b2[offs[i]:offs[i + 1]] = s[1].bias.detach().float()
                 entry['stage2'] = pack_conv_raw(w2, b2, relu=False)
+                if c == 64 and max(outs) <= 4 and len(seqs) <= 8:
+                    # grouped small-N VALU kernel: (n_out, 9, 64) weights, no zero blocks, no 32-wide MFMA padding
+                    wg = torch.cat([s[1].weight.detach().float() for s in seqs], 0)          # (n_out, 64, 3, 3)
+                    entry['stage2_grouped'] = (wg.permute(0, 2, 3, 1).reshape(wg.shape[0], 9, 64).contiguous(), b2.contiguous(),
+                                               [int(v) for v in offs])
             else:
                 entry['branches'] = []
                 for s in seqs:
@@ -121,7 +126,11 @@ class CenterHead(PackedModule):
         buf = torch.zeros((B, H, W, ld), dtype=torch.float32, device=x.device)
         if 'stage1' in entry:
             mid = entry['stage1'].run(x)
-            entry['stage2'].run(mid, out=buf)
+            if 'stage2_grouped' in entry:
+                wg, bg, goffs = entry['stage2_grouped']
+                ops.conv3x3_grouped_small(mid, wg, bg, goffs, buf)
+            else:
+                entry['stage2'].run(mid, out=buf)
         else:
             for chain, off in zip(entry['branches'], entry['offs'][:-1]):
                 y = x

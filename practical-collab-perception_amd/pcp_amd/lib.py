@@ -52,6 +52,7 @@ SYMBOLS = {
     'pcp_fill_zero': (c_i32, [vp, c_sz, vp]),
     'pcp_conv3x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
     'pcp_conv3x3_winograd': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_conv3x3_grouped_small': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), vp, vp, vp, c_i32, vp]),
     'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
@@ -62,6 +63,8 @@ SYMBOLS = {
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
     'pcp_bev_sample_bilinear': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp,
                                         c_i32, vp]),
+    'pcp_hunter_point_head': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp, vp, vp, vp,
+                                      vp, c_i32, c_i32, vp, c_i32, vp, vp]),
     'pcp_hunter_apply_flow': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_f, vp, vp]),
     'pcp_select_transform_points': (c_i32, [vp, c_i64, c_i32, c_i32, c_f, c_i32, ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_uint8),
                                             vp, vp]),

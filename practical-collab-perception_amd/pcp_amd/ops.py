@@ -137,6 +137,17 @@ def conv3x3_winograd(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None
     return out
 
 
+def conv3x3_grouped_small(x, weights, bias, offsets, out):
+    """x: (B, H, W, ld_in); weights (n_out, 9, cin_per_group), cin_per_group % 64 == 0; offsets: python list of groups+1 ints."""
+    _need_cuda(x, weights, bias, out)
+    L = _lib.load()
+    B, H, W, ld_in = x.shape
+    offs = (ctypes.c_int32 * len(offsets))(*[int(v) for v in offsets])
+    check(L.pcp_conv3x3_grouped_small(_p(x), B, H, W, ld_in, len(offsets) - 1, weights.shape[2], offs, _p(weights), _p(bias), _p(out), out.shape[-1],
+                                      _stream()), 'pcp_conv3x3_grouped_small')
+    return out
+
+
 def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0, x2=None,
               k_split=0, x2_ch_off=0, residual=None, res_ch_off=0):
     """mode PW_PLAIN: x (..., ld_in) rows; PW_SPACE2DEPTH / PW_DEPTH2SPACE: x (B, H, W, ld_in).
@@ -258,6 +269,20 @@ def softmax_fuse(maps, weights, channels, out):
     check(L.pcp_softmax_fuse(arr, n, _p(weights), weights.shape[-1], pixels, channels, maps[0].shape[-1], out.shape[-1], _p(out),
                              _stream()), 'pcp_softmax_fuse')
     return out
+
+
+def hunter_point_head(bev, points, min_xy, pix_xy, w1, b1, w2, b2, wh, bh, channels, bev_ch_off=0):
+    """fused sample -> MLP -> heads.  bev: (B, H, W, ld) NHWC (channel window [bev_ch_off, +channels)).  Returns (pf (N, C), head (N, 8))."""
+    _need_cuda(bev, points, w1, b1, w2, b2, wh, bh)
+    L = _lib.load()
+    B, H, W, ld_bev = bev.shape
+    n, stride = points.shape
+    pf = torch.empty((max(n, 1), channels), dtype=torch.float32, device=bev.device)
+    head = torch.empty((max(n, 1), wh.shape[0]), dtype=torch.float32, device=bev.device)
+    check(L.pcp_hunter_point_head(_chan_ptr(bev, bev_ch_off), B, H, W, channels, ld_bev, _p(points), n, stride, float(min_xy[0]),
+                                  float(min_xy[1]), float(pix_xy[0]), float(pix_xy[1]), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh), _p(bh),
+                                  w1.shape[0], wh.shape[0], _p(pf), channels, _p(head), _stream()), 'pcp_hunter_point_head')
+    return pf[:n], head[:n]
 
 
 def hunter_apply_flow(points, head, thresh):

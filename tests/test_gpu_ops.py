@@ -478,3 +478,63 @@ def test_conv3x3_winograd_channel_windows():
     assert float((out[..., :128] - 7.0).abs().max()) == 0.0 and float((out[..., 256:] - 7.0).abs().max()) == 0.0
     want = F.conv2d(x[..., 16:80].permute(0, 3, 1, 2).cpu(), wt, None, padding=1)
     np.testing.assert_allclose(out[..., 128:256].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_grouped_small_head_conv_matches_torch():
+    ops = _ops()
+    d = dev()
+    B, H, W = 2, 20, 28
+    ks = [2, 1, 3, 2, 1]
+    offs = [0, 2, 3, 6, 8, 9]
+    x = torch.from_numpy(_rand(91, (B, 320, H, W)))
+    ws = [torch.from_numpy(_rand(92 + i, (k, 64, 3, 3), -0.1, 0.1)) for i, k in enumerate(ks)]
+    bs = torch.from_numpy(_rand(99, (9,), -0.5, 0.5))
+    want = torch.cat([F.conv2d(x[:, 64 * i:64 * i + 64], ws[i], bs[offs[i]:offs[i + 1]], padding=1) for i in range(5)], 1)
+    wg = torch.cat(ws, 0).permute(0, 2, 3, 1).reshape(9, 9, 64).contiguous()
+    out = torch.full((B, H, W, 16), -3.0, device=d)
+    ops.conv3x3_grouped_small(ops.as_nhwc(x.to(d)), wg.to(d), bs.to(d), offs, out)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[..., :9].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    assert float((out[..., 9:] + 3.0).abs().max()) == 0.0
+
+
+def test_fused_point_head_matches_unfused_ops_and_torch():
+    ops = _ops()
+    d = dev()
+    B, H, W, C = 2, 32, 32, 384
+    bev = torch.from_numpy(_rand(101, (B, C, H, W)))
+    pts_np = synth.collate([synth.agent_cloud(5, 1500, 'car', xy_half=13.1), synth.agent_cloud(6, 777, 'car', xy_half=13.1)])
+    pts = torch.from_numpy(pts_np)
+    rng = [-12.8, -12.8, -8.0, 12.8, 12.8, 0.0]
+    w1, b1 = torch.from_numpy(_rand(102, (32, C), -0.05, 0.05)), torch.from_numpy(_rand(103, (32,), -0.1, 0.1))
+    w2, b2 = torch.from_numpy(_rand(104, (C, 32), -0.1, 0.1)), torch.from_numpy(_rand(105, (C,), -0.1, 0.1))
+    wh, bh = torch.from_numpy(_rand(106, (8, C), -0.05, 0.05)), torch.from_numpy(_rand(107, (8,), -0.1, 0.1))
+    want_pf, _ = obev.sample_point_features(bev, pts, rng, [0.8, 0.8])
+    h1 = torch.relu(want_pf @ w1.t() + b1)
+    final = torch.relu(h1 @ w2.t() + b2) + want_pf
+    want_head = final @ wh.t() + bh
+    pix = [np.float32(0.2) * 4, np.float32(0.2) * 4]
+    pf, head = ops.hunter_point_head(ops.as_nhwc(bev.to(d)), pts.to(d), rng[:2], pix, w1.to(d), b1.to(d), w2.to(d), b2.to(d), wh.to(d),
+                                     bh.to(d), channels=C)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pf.cpu().numpy(), want_pf.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(head.cpu().numpy(), want_head.numpy(), rtol=1e-4, atol=1e-4)
+    # the sampled rows are bitwise those of the stand-alone sampler
+    pf2 = ops.bev_sample_bilinear(ops.as_nhwc(bev.to(d)), pts.to(d), rng[:2], pix)
+    torch.cuda.synchronize()
+    assert torch.equal(pf, pf2)
+
+
+def test_small_n_conv_over_many_channels_matches_torch():
+    """the 768 -> 2 weight conv of HunterJr through the grouped small-N kernel (one group, 12 chunks of 64 channels)"""
+    ops = _ops()
+    d = dev()
+    B, H, W, C = 1, 17, 23, 768
+    x = torch.from_numpy(_rand(111, (B, C, H, W)))
+    wt = torch.from_numpy(_rand(112, (2, C, 3, 3), -0.05, 0.05))
+    bs = torch.from_numpy(_rand(113, (2,), -0.5, 0.5))
+    want = F.conv2d(x, wt, bs, padding=1)
+    out = torch.empty((B, H, W, 2), device=d)
+    ops.conv3x3_grouped_small(ops.as_nhwc(x.to(d)), wt.permute(0, 2, 3, 1).reshape(2, 9, C).contiguous().to(d), bs.to(d), [0, 2], out)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
