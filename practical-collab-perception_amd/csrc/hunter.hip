@@ -284,7 +284,7 @@ extern "C" int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_
   char *ws = (char *)workspace;
   int *cell_count = (int *)(ws + L.cell_count), *cell_fill = (int *)(ws + L.cell_fill);
   int *cell_start = (int *)(ws + L.cell_start), *point_cell = (int *)(ws + L.point_cell), *bucket = (int *)(ws + L.bucket);
-  if (hipMemsetAsync(cell_count, 0, L.cell_start - L.cell_count, st) != hipSuccess) return PCP_ERR_LAUNCH;
+  if (pcp_zero_async(cell_count, L.cell_start - L.cell_count, st) != PCP_OK) return PCP_ERR_LAUNCH;
   if (n > 0) {
     hipLaunchKernelGGL(k_sc_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, points, (long long)n, row_stride, batch, h, w,
                        min_x, min_y, pix_x, pix_y, cell_count, point_cell);

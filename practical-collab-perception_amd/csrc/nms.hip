@@ -320,7 +320,7 @@ extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t 
                                int32_t *keep, int32_t *keep_count, void *stream_) {
   if (!keep || !keep_count || n_max < 0 || batch <= 0 || post_max <= 0 || pre_max <= 0) return PCP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
-  if (n_max == 0) return hipMemsetAsync(keep_count, 0, 4 * (size_t)batch, st) == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+  if (n_max == 0) return pcp_zero_async(keep_count, 4 * (size_t)batch, st);
   if (!boxes || !workspace) return PCP_ERR_ARG;
   if (n_max > SORT_CAP || batch > 65535) return PCP_ERR_UNSUPPORTED;
   NmsLayout L = nms_layout(n_max, batch);

@@ -14,6 +14,26 @@
 
 static inline size_t pcp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Zero fill as a KERNEL node (hipMemsetAsync nodes replayed incorrectly inside captured hipGraphs on this stack: the second
+// replay of a graph containing them faulted, tools/dbg_graph.py): 16-byte stores, grid-stride.
+__global__ static void pcp_k_zero(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, size_t ntail) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+static inline int pcp_zero_async(void *ptr, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return PCP_OK;
+  if (((uintptr_t)ptr) & 15) return hipMemsetAsync(ptr, 0, bytes, stream) == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+  const size_t n16 = bytes / 16, ntail = bytes % 16;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(pcp_k_zero, dim3((unsigned)blocks), dim3(256), 0, stream, (uint4 *)ptr, n16, (unsigned char *)ptr + n16 * 16, ntail);
+  return hipGetLastError() == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -244,5 +244,5 @@ extern "C" int pcp_canvas_clear(const pcp_grid_t *grid, const void *workspace, i
 extern "C" int pcp_fill_zero(void *ptr, size_t bytes, void *stream_) {
   if (!ptr && bytes) return PCP_ERR_ARG;
   if (bytes == 0) return PCP_OK;
-  return hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream_) == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+  return pcp_zero_async(ptr, bytes, (hipStream_t)stream_);
 }

@@ -287,7 +287,7 @@ extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, 
   int *counters_ws = (int *)(ws + L.counters);
 
   // cell_count and cell_fill are adjacent (layout keeps 256-B alignment between them): one memset
-  if (hipMemsetAsync(cell_count, 0, L.cell_rank - L.cell_count, stream) != hipSuccess) return PCP_ERR_LAUNCH;
+  if (pcp_zero_async(cell_count, L.cell_rank - L.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
   if (n_pblk > 0) {
     hipLaunchKernelGGL(k_point_cells, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
                        *grid, cell_count, point_cell, pt_bs);

@@ -152,9 +152,9 @@ class CenterHead(PackedModule):
                     min_y=float(self.point_cloud_range[1]), limit=list(pp.POST_CENTER_LIMIT_RANGE),
                     score_thresh=pp.SCORE_THRESH)
 
-    def generate_predicted_boxes(self, batch_size, head_bufs, pk):
-        pp = self.model_cfg.POST_PROCESSING
-        nms_cfg = pp.NMS_CONFIG
+    def device_postprocess(self, head_bufs, pk):
+        """decode + NMS for every head, everything left on the device (hipGraph-capturable: no host sync)."""
+        nms_cfg = self.model_cfg.POST_PROCESSING.NMS_CONFIG
         assert nms_cfg.NMS_TYPE == 'nms_gpu', 'only the rotated nms_gpu of the five configs is built'
         per_head = []
         for idx, (buf, entry) in enumerate(zip(head_bufs, pk['heads'])):
@@ -164,7 +164,10 @@ class CenterHead(PackedModule):
             keep, kcnt = ops.nms_rotated(boxes, None, nms_cfg.NMS_THRESH, min(nms_cfg.NMS_PRE_MAXSIZE, k), nms_cfg.NMS_POST_MAXSIZE,
                                          n_dev=count)
             per_head.append((boxes, scores, labels, keep, kcnt, idx))
-        # single host sync: how many boxes survive per (head, frame)
+        return per_head
+
+    def finalize(self, per_head, batch_size):
+        """the one host sync of the path: how many boxes survive per (head, frame) -> exact-shape output tensors."""
         counts = torch.stack([h[4] for h in per_head], 0).cpu().numpy()
         ret = []
         for b in range(batch_size):
@@ -178,6 +181,9 @@ class CenterHead(PackedModule):
             ret.append(dict(pred_boxes=torch.cat(pb, 0), pred_scores=torch.cat(ps, 0), pred_labels=torch.cat(pl, 0) + 1))
         return ret
 
+    def generate_predicted_boxes(self, batch_size, head_bufs, pk):
+        return self.finalize(self.device_postprocess(head_bufs, pk), batch_size)
+
     def forward(self, data_dict):
         require_eval_hip(self, 'CenterHead')
         pk = self.packed()
@@ -190,6 +196,9 @@ class CenterHead(PackedModule):
             view = ops.nchw_view(buf)
             pred_dicts.append({n: view[:, int(entry['offs'][i]):int(entry['offs'][i + 1])] for i, n in enumerate(entry['names'])})
         self.forward_ret_dict['pred_dicts'] = pred_dicts
+        if getattr(self, 'defer_finalize', False):                   # graph capture: keep the host sync outside
+            data_dict['_pcp_pending_head'] = self.device_postprocess(head_bufs, pk)
+            return data_dict
         final = self.generate_predicted_boxes(data_dict['batch_size'], head_bufs, pk)
         data_dict['final_box_dicts'] = final
         if self.model_cfg.get('RETURN_MODAR_POINTS', False):

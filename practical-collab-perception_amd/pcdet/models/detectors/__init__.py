@@ -1,11 +1,13 @@
 from .centerpoint import CenterPoint
 from .detector3d_template import Detector3DTemplate
+from .v2x_late_fusion import V2XLateFusion
 
 # name -> class (reference: pcdet/models/detectors/__init__.py:19-35); the PointPillars hot path uses CenterPoint in all
 # five V2X-Sim configs
 __all__ = {
     'Detector3DTemplate': Detector3DTemplate,
     'CenterPoint': CenterPoint,
+    'V2XLateFusion': V2XLateFusion,
 }
 
 

@@ -1,0 +1,57 @@
+"""hipGraph capture of a detector's forward (MI355X pipeline mode, not in the reference).
+
+At small batch the path is launch bound (~70 launches per frame through Python/ctypes); every C-ABI entry point is
+capturable by construction (no allocation, no sync, explicit stream), so the whole module chain -- point copy-in, pillariser,
+PFN, convolutions, HunterJr, decode, NMS -- becomes one graph replay per batch; only the final "how many boxes" host read
+stays outside.  Shapes are frozen at capture time (N points, batch size); feed a batch of another size eagerly.
+Not capturable: the DiscoNet BEVMaker's agent discovery (torch.unique(...).cpu(), as in the reference bev_maker.py:156).
+"""
+import torch
+
+
+class GraphedDetector:
+    def __init__(self, model, points, batch_size, metadata, warmup=3):
+        assert points.is_cuda and not model.training
+        self.model = model
+        self.batch_size = batch_size
+        self.metadata = metadata
+        self.static_points = points.clone()
+        self._pristine_shape = tuple(points.shape)
+        for m in model.modules():
+            if hasattr(m, 'materialize_pillars'):
+                m.materialize_pillars = False          # exact-shape per-pillar tensors need a host sync
+                m.reuse_buffers = True
+        self.head = model.dense_head
+        self.head.defer_finalize = True
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    self.static_points.copy_(points)
+                    self._pending = self._run_modules()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self._pending = self._run_modules()
+        finally:
+            self.head.defer_finalize = False
+
+    def _run_modules(self):
+        bd = {'points': self.static_points, 'batch_size': self.batch_size, 'metadata': self.metadata}
+        for m in self.model.module_list:
+            bd = m(bd)
+        self._last = bd
+        return bd['_pcp_pending_head']
+
+    def __call__(self, points):
+        assert tuple(points.shape) == self._pristine_shape, 'graph was captured for a different point count'
+        self.static_points.copy_(points, non_blocking=True)
+        self.graph.replay()
+        return self.head.finalize(self._pending, self.batch_size)
+
+    @property
+    def batch_dict(self):
+        """static tensors of the captured forward (overwritten by every replay)"""
+        return self._last

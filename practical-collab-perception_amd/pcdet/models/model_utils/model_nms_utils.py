@@ -16,6 +16,8 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
         keep_idx, _ = getattr(iou3d_nms_utils, nms_config.NMS_TYPE)(
             box_preds[:, 0:7], box_scores, nms_config.NMS_THRESH, pre_maxsize=nms_config.NMS_PRE_MAXSIZE)
         selected = keep_idx[:nms_config.NMS_POST_MAXSIZE]
+    if not torch.is_tensor(selected):
+        selected = torch.zeros((0,), dtype=torch.long, device=src_box_scores.device)
     if score_thresh is not None:
         original_idxs = scores_mask.nonzero().view(-1)
         selected = original_idxs[selected]
