@@ -144,3 +144,46 @@ def test_hipgraph_replay_equals_eager(tag):
         eager2, _ = model({'points': pts2.clone(), 'batch_size': 2, 'metadata': [{}, {}]})
     torch.cuda.synchronize()
     assert torch.equal(out2[0]['pred_boxes'], eager2[0]['pred_boxes'])
+
+
+@pytest.mark.parametrize('case', ['first_frame_empty', 'all_out_of_range', 'single_point', 'batch_of_one'])
+def test_degenerate_inputs_match_oracle(case):
+    """edge cases the reference never tests: empty / ragged frames, nothing in range, one point, B = 1"""
+    from helpers import arch_of
+    from oracle import model as omodel
+    g = load_golden('g1_ego.npz')
+    arch = arch_of(g['meta'])
+    state = synth.fill_state_dict(g['meta']['state_shapes'])
+    pts = g['points'].copy()
+    B = 2
+    if case == 'first_frame_empty':
+        pts = pts[pts[:, 0] == 1]
+    elif case == 'all_out_of_range':
+        pts[:, 1] += 1000.0
+    elif case == 'single_point':
+        pts = pts[pts[:, 0] == 1][:1]
+    else:
+        pts = pts[pts[:, 0] == 0]
+        B = 1
+    model = _build(g)
+    batch = {'points': torch.from_numpy(pts).cuda(), 'batch_size': B, 'metadata': [{}] * B}
+    with torch.no_grad():
+        pred, _ = model(batch)
+    torch.cuda.synchronize()
+    assert len(pred) == B and tuple(batch['spatial_features_2d'].shape)[0] == B
+    if case == 'all_out_of_range':
+        assert batch['voxel_coords'].shape[0] == 0 and batch['pillar_features'].shape == (0, 64)
+        # nothing scattered: the maps are the network's response to an all-zero canvas, identical for both frames
+        sf = batch['spatial_features_2d']
+        assert torch.equal(sf[0], sf[1])
+        return
+    want = omodel.forward(pts, state, arch)
+    assert np.array_equal(batch['voxel_coords'].cpu().numpy(), want['voxel_coords'])
+    got = batch['spatial_features_2d'].cpu().numpy()
+    # the oracle (like the reference) sizes its canvas by the largest frame index present; compare the frames it has
+    nb = want['spatial_features_2d'].shape[0]
+    np.testing.assert_allclose(got[:nb], want['spatial_features_2d'], rtol=0, atol=1e-3)
+    for b in range(nb):
+        fb = want['final_box_dicts'][b]
+        n, worst = match_boxes(fb['pred_boxes'], fb['pred_scores'], pred[b]['pred_boxes'].cpu().numpy(), pred[b]['pred_scores'].cpu().numpy())
+        assert n >= fb['pred_boxes'].shape[0] - 1, (case, n, worst)
