@@ -111,13 +111,13 @@ __global__ __launch_bounds__(WTHREADS, (RT == 2 ? 2 : 4)) void k_conv3x3_wino(Wi
   // ---- raw patch staging: RAW_PIX pixels x 2 float4.  Loads are UNCONDITIONAL (halo pixels outside the image read a valid
   //      address and are zeroed by a select) so that the number of outstanding VMEM operations is static and hipcc's
   //      counted s_waitcnt never has to wait for the youngest loads. ------------------------------------------------------
-  const float *rsrc[C::RAW_PER];
+  unsigned roff[C::RAW_PER];        // byte offset from p.in (uniform base + 32-bit lane offset -> no 64-bit VALU address math)
   int rdst[C::RAW_PER];
   bool rin[C::RAW_PER];
 #pragma unroll
   for (int i = 0; i < C::RAW_PER; i++) {
     int idx = tid + i * WTHREADS;
-    rsrc[i] = p.in;
+    roff[i] = 0u;
     rdst[i] = -1;
     rin[i] = false;
     if (idx < C::RAW_ITEMS) {
@@ -127,14 +127,15 @@ __global__ __launch_bounds__(WTHREADS, (RT == 2 ? 2 : 4)) void k_conv3x3_wino(Wi
       rdst[i] = pix * RLD + q * 4;
       if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
         rin[i] = true;
-        rsrc[i] = p.in + ((long long)(b * p.h + iy) * p.w + ix) * p.ld_in + q * 4;
+        roff[i] = (unsigned)((((long long)(b * p.h + iy) * p.w + ix) * p.ld_in + q * 4) * 4);
       }
     }
   }
   f32x4 rreg[C::RAW_PER];
   auto raw_load = [&](int slice) {
+    const char *base = reinterpret_cast<const char *>(p.in + slice * WCK);       // wave-uniform
 #pragma unroll
-    for (int i = 0; i < C::RAW_PER; i++) rreg[i] = *reinterpret_cast<const f32x4 *>(rsrc[i] + slice * WCK);
+    for (int i = 0; i < C::RAW_PER; i++) rreg[i] = *reinterpret_cast<const f32x4 *>(base + roff[i]);
   };
   auto raw_store = [&](int buf) {
 #pragma unroll
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(WTHREADS, (RT == 2 ? 2 : 4)) void k_conv3x3_wino(Wi
   // ---- B fragments (transformed weights) from global: positions 2w, 2w+1; two 32-channel column tiles each.  Two register
   //      sets: the next slice's fragments are requested at the TOP of an iteration so the barrier at its end never waits
   //      on memory latency. -------------------------------------------------------------------------------------------------
-  const float *ubase = p.u + ((long long)(2 * wave) * p.cout_pad + n0 + r) * WCK + 4 * h;
+  const float *ubase = p.u + ((long long)(2 * wave) * p.cout_pad + n0) * WCK;        // wave-uniform
+  const unsigned u_lane = (unsigned)((r * WCK + 4 * h) * 4);                             // bytes
   const long long u_pos = (long long)p.cout_pad * WCK;            // floats between positions
   const long long u_slice = 16 * u_pos;
   f32x4 b0[2][2], b1[2][2];
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(WTHREADS, (RT == 2 ? 2 : 4)) void k_conv3x3_wino(Wi
 #pragma unroll
     for (int pi = 0; pi < 2; pi++)
 #pragma unroll
-      for (int ct = 0; ct < 2; ct++) dstb[pi][ct] = *reinterpret_cast<const f32x4 *>(s + pi * u_pos + ct * 32 * WCK);
+      for (int ct = 0; ct < 2; ct++)
+        dstb[pi][ct] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(s + pi * u_pos + ct * 32 * WCK) + u_lane);
   };
 
   f32x16 acc[2][RT][2];
@@ -259,17 +262,11 @@ __global__ __launch_bounds__(WTHREADS, (RT == 2 ? 2 : 4)) void k_conv3x3_wino(Wi
   raw_load(min(2, last));
   __syncthreads();
 
-  // static priority for the multiply-first half: it must win the matrix pipe right after the barrier, finish its MFMAs first
-  // and do its transform while the (older) transform-first partner multiplies -- otherwise age arbitration lets the partner
-  // pre-empt it and its transform lands on the critical path after BOTH multiplies
-#ifdef WINO_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
+  // (static s_setprio for either half of the block was measured: no gain -- fp32 MFMA and VALU of SIMD partners serialise)
   for (int s = 0; s < n_slices; s += 2) {
     step(s, b0, b1);
     if (s + 1 < n_slices) step(s + 1, b1, b0);
   }
-  __builtin_amdgcn_s_setprio(0);
 
   // ---- epilogue: (row tile, column tile) chunks through LDS ------------------------------------------------------------------
 #pragma unroll
