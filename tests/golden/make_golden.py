@@ -1,7 +1,7 @@
 """Generates tests/golden/*.npz by running the REFERENCE'S OWN modules (imported read-only from /root/reference)
 on seeded synthetic inputs with deterministic weights.  Run only in the CPU container:
 
-    python tests/golden/make_golden.py [g1 g2 g3 g4]
+    python tests/golden/make_golden.py [g1 g2 g3 g4 g7]
 
 Fixtures are data (inputs, expected outputs, the config dict that produced them); no reference source is stored.
 """
@@ -290,6 +290,123 @@ def g4_warp():
     print('g4', len(cases), 'cases')
 
 
+def train_gt_boxes(batch, m_max, seed_shift):
+    """(B, M, 8) [x, y, z, dx, dy, dz, heading, class]; rows past the per-frame count are zero (collate_batch padding,
+    dataset.py:260-266); one box with its centre outside the range (clamped by center_head.py:131-132)."""
+    s = synth.SEED_BASE + 700 + seed_shift
+    gt = np.zeros((batch, m_max, 8), dtype=np.float32)
+    for b in range(batch):
+        n = m_max - 2 * b
+        gt[b, :n, 0] = synth.uniform(s, 10 * b + 1, n, -12.0, 12.0)
+        gt[b, :n, 1] = synth.uniform(s, 10 * b + 2, n, -12.0, 12.0)
+        gt[b, :n, 2] = synth.uniform(s, 10 * b + 3, n, -3.0, -1.0)
+        gt[b, :n, 3] = synth.uniform(s, 10 * b + 4, n, 3.0, 5.5)
+        gt[b, :n, 4] = synth.uniform(s, 10 * b + 5, n, 1.5, 2.5)
+        gt[b, :n, 5] = synth.uniform(s, 10 * b + 6, n, 1.4, 2.0)
+        gt[b, :n, 6] = synth.uniform(s, 10 * b + 7, n, -3.14159, 3.14159)
+        gt[b, :n, 7] = 1.0
+    gt[0, 0, 0:2] = [12.9, -13.5]          # centre outside the map -> clamped to the border cell
+    gt[0, 1, 0:2] = gt[0, 2, 0:2] + 0.3    # two boxes in neighbouring / the same cell (gaussian max blending)
+    return gt
+
+
+def _digest(t):
+    a = t.detach().double().reshape(-1)
+    return np.array([float(a.norm()), float(a.sum()), float(a.abs().max())], dtype=np.float64)
+
+
+def _sample(t, cap=4096):
+    a = t.detach().reshape(-1)
+    if a.numel() <= cap:
+        return a.numpy().copy()
+    step = a.numel() // 1024
+    return a[::step][:1024].numpy().copy()
+
+
+def g7_train():
+    """Config 5 (disco) training contract on the mini geometry: two iterations of the reference's own train step
+    (tools/train_utils/train_utils.py:39-65) with its own optimizer / scheduler builders."""
+    tmp = tempfile.mkdtemp()
+    empty = os.path.join(tmp, 'empty.pth')
+    torch.save({'model_state': {}}, empty)
+    ov = {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE, 'MODEL.BEV_MAKER_RSU.CKPT': empty, 'MODEL.BEV_MAKER_CAR.CKPT': empty,
+          'MODEL.BEV_MAKER_EARLY.CKPT': empty, 'MODEL.V2X_MID_FUSION.PC_RANGE_MIN': MINI_RANGE[0]}
+    cfg = rh.load_cfg('v2x_pointpillar_disco.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    poses = {0: synth.agent_pose(0), 2: synth.agent_pose(2)}
+    poses[0][:3, 3] = [0.8, -0.4, 0.0]
+    poses[0][:3, :3] = synth.agent_pose(1)[:3, :3]
+    poses[2][:3, 3] = [-1.6, 2.4, 0.0]
+    metadata = [{'se3_from_ego': {0: poses[0], 2: poses[2]}}, {'se3_from_ego': {0: poses[0]}}]
+    clouds = []
+    for b in range(2):
+        per_agent = []
+        for a in (0, 1, 2):
+            if b == 1 and a == 2:
+                continue
+            c = synth.agent_cloud(agent=40 + 3 * b + a, n_points=1500, layout='disco', xy_half=13.1)
+            c[:, -1] = float(a)
+            per_agent.append(c)
+        clouds.append(np.concatenate(per_agent, axis=0))
+    pts = synth.collate(clouds)
+    gt = train_gt_boxes(2, 7, 0)
+    total_it_each_epoch, epochs = 5, cfg.OPTIMIZATION.NUM_EPOCHS
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=total_it_each_epoch, total_epochs=epochs,
+                                      last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
+    out = {'points': pts, 'gt_boxes': gt, 'pose_0': poses[0], 'pose_2': poses[2]}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out['trainable'] = np.array(names)
+    for it in range(2):
+        lr_scheduler.step(it)
+        out['it%d_lr' % it] = np.array(float(optimizer.lr))
+        out['it%d_mom' % it] = np.array(float(optimizer.mom))
+        model.train()
+        optimizer.zero_grad()
+        bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': metadata, 'gt_boxes': torch.from_numpy(gt.copy())}
+        ret, tb, _disp = model(bd)
+        loss = ret['loss']
+        model.update_global_step()
+        loss.backward()
+        out['it%d_loss' % it] = np.array(float(loss))
+        out['it%d_tb_json' % it] = np.array(json.dumps({k: float(v) for k, v in tb.items()}))
+        if it == 0:
+            td = model.dense_head.forward_ret_dict['target_dicts']
+            out['tgt_heatmap'] = td['heatmaps'][0].numpy()
+            out['tgt_boxes'] = td['target_boxes'][0].numpy()
+            out['tgt_inds'] = td['inds'][0].numpy()
+            out['tgt_mask'] = td['masks'][0].numpy()
+            out['fused_probe'] = bd['spatial_features_2d'].detach().numpy()[:, ::8].copy()
+        params = dict(model.named_parameters())
+        out['it%d_grad_digest' % it] = np.stack([_digest(params[n].grad) for n in names])
+        if it == 0:
+            for n in names:
+                out['g0/' + n] = _sample(params[n].grad)
+        norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        out['it%d_grad_norm' % it] = np.array(float(norm))
+        optimizer.step()
+        out['it%d_param_digest' % it] = np.stack([_digest(params[n]) for n in names])
+        if it == 0:
+            for n in names:
+                out['p1/' + n] = _sample(params[n])
+            sd = model.state_dict()
+            bn_keys = [k for k in sd if ('running_' in k) and not k.startswith('bev_maker')]
+            out['bn_keys'] = np.array(bn_keys)
+            out['it0_bn_digest'] = np.stack([_digest(sd[k]) for k in bn_keys])
+        print('g7 it', it, 'loss', float(loss), 'norm', float(norm), tb)
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), optimization=rh.to_plain(cfg.OPTIMIZATION),
+                                                 pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0],
+                                                 class_names=list(cfg.CLASS_NAMES), yaml='v2x_pointpillar_disco.yaml',
+                                                 layout='disco', absent=[[], [2]], state_shapes=shapes,
+                                                 total_it_each_epoch=total_it_each_epoch)))
+    np.savez_compressed(os.path.join(HERE, 'g7_train.npz'), **out)
+    print('g7 saved', os.path.getsize(os.path.join(HERE, 'g7_train.npz')) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
@@ -304,3 +421,5 @@ if __name__ == '__main__':
         g1_disco()
     if 'g2' in todo:
         g2_full()
+    if 'g7' in todo:
+        g7_train()
