@@ -1,0 +1,294 @@
+// Training-mode BatchNorm (batch statistics) + ReLU on NHWC / row-major (rows, c) fp32 tensors, forward and backward, plus the
+// small row-wise helpers the backward pass needs (column sums for bias gradients, accumulate, 2x zero-insertion).
+//
+// Replaces, for the trainable branch of config 5, what cuDNN/ATen do behind
+//   nn.BatchNorm2d / nn.BatchNorm1d in train() mode + nn.ReLU and their autograd nodes
+//   (pcdet/models/backbones_2d/base_bev_backbone.py:37-44,56,67; backbones_3d/vfe/dynamic_pillar_vfe.py:29,40-43;
+//    dense_heads/center_head.py:26,80; bev_layers/v2x_fusion_disco.py:13-16,53,60).
+//
+// All of it is HBM-bound streaming: one read for the statistics, one read + one write for the normalisation; backward is one
+// read of (dout, x) for the two per-channel sums and one read + write for dx.  Per-channel sums are accumulated in float64
+// (per-thread partials, LDS tree, one f64 atomic per block and channel): the result does not depend on the summation order at
+// fp32 resolution, so training stays reproducible without a second pass.
+#include "pcp_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+enum { RED_STATS = 0, RED_BNBWD = 1, RED_COLSUM = 2 };
+
+struct RedParams {
+  const float *x;        // STATS / COLSUM: the tensor; BNBWD: pre-BN conv output
+  const float *dout;     // BNBWD: upstream gradient
+  long long rows;
+  int c, ld_x, ld_d;
+  const float *scale, *shift, *mean, *invstd;   // BNBWD
+  int relu;
+  double *acc;           // [2][c]
+};
+
+// thread layout: cg = c/4 float4 column groups, rpb = RED_THREADS / cg row slots per block pass
+template <int MODE>
+__global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
+  __shared__ double red[2][RED_THREADS][4];
+  const int cg = p.c >> 2;
+  const int rpb = RED_THREADS / cg;
+  const int tid = threadIdx.x;
+  const int slot = tid / cg, g = tid - slot * cg;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (slot < rpb) {
+    float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), mu = sh, is = sc;
+    if (MODE == RED_BNBWD) {
+      sc = *reinterpret_cast<const float4 *>(p.scale + g * 4);
+      sh = *reinterpret_cast<const float4 *>(p.shift + g * 4);
+      mu = *reinterpret_cast<const float4 *>(p.mean + g * 4);
+      is = *reinterpret_cast<const float4 *>(p.invstd + g * 4);
+    }
+    for (long long r = (long long)blockIdx.x * rpb + slot; r < p.rows; r += (long long)gridDim.x * rpb) {
+      const float4 v = *reinterpret_cast<const float4 *>(p.x + r * p.ld_x + g * 4);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+      if (MODE == RED_STATS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0[i] += (double)xv[i]; s1[i] += (double)xv[i] * (double)xv[i]; }
+      } else if (MODE == RED_COLSUM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s0[i] += (double)xv[i];
+      } else {
+        const float4 d = *reinterpret_cast<const float4 *>(p.dout + r * p.ld_d + g * 4);
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float act = fmaf(xv[i], scv[i], shv[i]);
+          const float dz = (p.relu && !(act > 0.f)) ? 0.f : dv[i];
+          const float xh = (xv[i] - muv[i]) * isv[i];
+          s0[i] += (double)dz;
+          s1[i] += (double)dz * (double)xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[0][tid][i] = s0[i]; red[1][tid][i] = s1[i]; }
+  __syncthreads();
+  if (slot == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double a = 0, b = 0;
+      for (int s = 0; s < rpb; ++s) { a += red[0][s * cg + g][i]; b += red[1][s * cg + g][i]; }
+      atomicAdd(p.acc + g * 4 + i, a);
+      if (MODE != RED_COLSUM) atomicAdd(p.acc + p.c + g * 4 + i, b);
+    }
+  }
+}
+
+__global__ void k_bn_finalize(const double *acc, long long rows, int c, const float *gamma, const float *beta, float eps,
+                              float momentum, float *running_mean, float *running_var, float *scale, float *shift,
+                              float *mean, float *invstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double n = (double)rows;
+  const double m = acc[i] / n;
+  double var = acc[c + i] / n - m * m;
+  if (var < 0) var = 0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)((double)gamma[i] * is);
+  scale[i] = sc;
+  shift[i] = (float)((double)beta[i] - m * (double)gamma[i] * is);
+  mean[i] = (float)m;
+  invstd[i] = (float)is;
+  if (running_mean) {
+    const double unb = rows > 1 ? var * n / (n - 1.0) : var;
+    running_mean[i] = (float)((1.0 - (double)momentum) * (double)running_mean[i] + (double)momentum * m);
+    running_var[i] = (float)((1.0 - (double)momentum) * (double)running_var[i] + (double)momentum * unb);
+  }
+}
+
+// dgamma = sum dz xhat, dbeta = sum dz; coef[0][c] = dbeta / n, coef[1][c] = dgamma / n for the apply pass
+__global__ void k_bnbwd_finalize(const double *acc, long long rows, int c, float *dgamma, float *dbeta, int accumulate,
+                                 float *coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double n = (double)rows;
+  const float db = (float)acc[i], dg = (float)acc[c + i];
+  if (accumulate) { dbeta[i] += db; dgamma[i] += dg; } else { dbeta[i] = db; dgamma[i] = dg; }
+  coef[i] = (float)(acc[i] / n);
+  coef[c + i] = (float)(acc[c + i] / n);
+}
+
+__global__ void k_colsum_finalize(const double *acc, int c, float *out, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  if (accumulate) out[i] += (float)acc[i]; else out[i] = (float)acc[i];
+}
+
+__global__ void k_scale_shift_act(const float *__restrict__ x, long long rows, int cg, int ld_x, const float *__restrict__ scale,
+                                  const float *__restrict__ shift, int relu, float *__restrict__ out, int ld_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cg) return;
+  const int g = (int)(t % cg);
+  const long long r = t / cg;
+  const float4 v = *reinterpret_cast<const float4 *>(x + r * ld_x + g * 4);
+  const float4 sc = *reinterpret_cast<const float4 *>(scale + g * 4);
+  const float4 sh = *reinterpret_cast<const float4 *>(shift + g * 4);
+  float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+  *reinterpret_cast<float4 *>(out + r * ld_out + g * 4) = o;
+}
+
+__global__ void k_bnbwd_apply(const float *__restrict__ dout, int ld_d, const float *__restrict__ x, int ld_x, long long rows, int cg,
+                              int c, const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+                              const float *__restrict__ invstd, int relu, const float *__restrict__ coef, float *__restrict__ dx,
+                              int ld_dx) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cg) return;
+  const int g = (int)(t % cg);
+  const long long r = t / cg;
+  const float4 v = *reinterpret_cast<const float4 *>(x + r * ld_x + g * 4);
+  const float4 d = *reinterpret_cast<const float4 *>(dout + r * ld_d + g * 4);
+  const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = g * 4 + i;
+    const float act = fmaf(xv[i], scale[ch], shift[ch]);
+    const float dz = (relu && !(act > 0.f)) ? 0.f : dv[i];
+    const float xh = (xv[i] - mean[ch]) * invstd[ch];
+    o[i] = scale[ch] * (dz - coef[ch] - xh * coef[c + ch]);
+  }
+  *reinterpret_cast<float4 *>(dx + r * ld_dx + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void k_accumulate(float *__restrict__ dst, int ld_dst, const float *__restrict__ src, int ld_src, long long rows, int cg,
+                             float alpha) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cg) return;
+  const int g = (int)(t % cg);
+  const long long r = t / cg;
+  float4 a = *reinterpret_cast<const float4 *>(dst + r * ld_dst + g * 4);
+  const float4 b = *reinterpret_cast<const float4 *>(src + r * ld_src + g * 4);
+  a.x = fmaf(alpha, b.x, a.x); a.y = fmaf(alpha, b.y, a.y); a.z = fmaf(alpha, b.z, a.z); a.w = fmaf(alpha, b.w, a.w);
+  *reinterpret_cast<float4 *>(dst + r * ld_dst + g * 4) = a;
+}
+
+// out (B, 2h, 2w, c): out[b, 2y, 2x] = in[b, y, x], zero elsewhere (gradient of a stride-2 3x3 conv = stride-1 conv of this)
+__global__ void k_dilate2x(const float *__restrict__ in, int batch, int h, int w, int cg, int ld_in, float *__restrict__ out,
+                           int ld_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)batch * 2 * h * 2 * w * cg;
+  if (t >= total) return;
+  const int g = (int)(t % cg);
+  long long pix = t / cg;
+  const int ox = (int)(pix % (2 * w));
+  pix /= 2 * w;
+  const int oy = (int)(pix % (2 * h));
+  const int b = (int)(pix / (2 * h));
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(ox & 1) && !(oy & 1)) v = *reinterpret_cast<const float4 *>(in + (((long long)b * h + (oy >> 1)) * w + (ox >> 1)) * ld_in + g * 4);
+  *reinterpret_cast<float4 *>(out + (((long long)b * 2 * h + oy) * 2 * w + ox) * ld_out + g * 4) = v;
+}
+
+inline bool red_shape_ok(long long rows, int c, int ld) { return rows > 0 && c >= 4 && (c & 3) == 0 && (c >> 2) <= RED_THREADS && (ld & 3) == 0 && ld >= c; }
+inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+inline int red_grid(long long rows, int c) {
+  const int rpb = RED_THREADS / (c >> 2);
+  long long blocks = (rows + (long long)rpb * 16 - 1) / ((long long)rpb * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pcp_bn_workspace_bytes(int32_t c) { return (size_t)c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float); }
+
+int pcp_bn_train_stats(const float *x, int64_t rows, int32_t c, int32_t ld, const float *gamma, const float *beta, float eps,
+                       float momentum, float *running_mean, float *running_var, void *workspace, float *scale, float *shift,
+                       float *mean, float *invstd, void *stream) {
+  if (!x || !gamma || !beta || !workspace || !scale || !shift || !mean || !invstd || !red_shape_ok(rows, c, ld) || !al16(x))
+    return PCP_ERR_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  if (pcp_zero_async(acc, (size_t)c * 2 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  RedParams p{};
+  p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
+  hipLaunchKernelGGL(k_col_reduce<RED_STATS>, dim3(red_grid(rows, c)), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, acc, (long long)rows, c, gamma, beta, eps, momentum,
+                     running_mean, running_var, scale, shift, mean, invstd);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_scale_shift_act(const float *x, int64_t rows, int32_t c, int32_t ld_x, const float *scale, const float *shift, int32_t relu,
+                        float *out, int32_t ld_out, void *stream) {
+  if (!x || !scale || !shift || !out || rows <= 0 || c < 4 || (c & 3) || (ld_x & 3) || (ld_out & 3) || !al16(x) || !al16(out))
+    return PCP_ERR_ARG;
+  const long long total = (long long)rows * (c >> 2);
+  hipLaunchKernelGGL(k_scale_shift_act, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows,
+                     c >> 2, ld_x, scale, shift, relu, out, ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
+                        const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, float *dgamma,
+                        float *dbeta, int32_t accumulate, float *dx, int32_t ld_dx, void *stream) {
+  if (!dout || !x || !scale || !shift || !mean || !invstd || !workspace || !dgamma || !dbeta || !dx || !red_shape_ok(rows, c, ld_x) ||
+      (ld_dout & 3) || (ld_dx & 3) || !al16(dout) || !al16(x) || !al16(dx))
+    return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  float *coef = (float *)(acc + 2 * (size_t)c);
+  if (pcp_zero_async(acc, (size_t)c * 2 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  RedParams p{};
+  p.x = x; p.dout = dout; p.rows = rows; p.c = c; p.ld_x = ld_x; p.ld_d = ld_dout;
+  p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.relu = relu; p.acc = acc;
+  hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(red_grid(rows, c)), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_bnbwd_finalize, dim3((c + 127) / 128), dim3(128), 0, s, acc, (long long)rows, c, dgamma, dbeta, accumulate, coef);
+  const long long total = (long long)rows * (c >> 2);
+  hipLaunchKernelGGL(k_bnbwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, ld_dout, x, ld_x, (long long)rows,
+                     c >> 2, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_colsum(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, float *out, int32_t accumulate, void *stream) {
+  if (!x || !workspace || !out || !red_shape_ok(rows, c, ld) || !al16(x)) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  if (pcp_zero_async(acc, (size_t)c * 2 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  RedParams p{};
+  p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
+  hipLaunchKernelGGL(k_col_reduce<RED_COLSUM>, dim3(red_grid(rows, c)), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_colsum_finalize, dim3((c + 127) / 128), dim3(128), 0, s, acc, c, out, accumulate);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_accumulate(float *dst, int32_t ld_dst, const float *src, int32_t ld_src, int64_t rows, int32_t c, float alpha, void *stream) {
+  if (!dst || !src || rows <= 0 || c < 4 || (c & 3) || (ld_dst & 3) || (ld_src & 3) || !al16(dst) || !al16(src)) return PCP_ERR_ARG;
+  const long long total = (long long)rows * (c >> 2);
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src,
+                     (long long)rows, c >> 2, alpha);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_dilate2x(const float *in, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_in, float *out, int32_t ld_out,
+                 void *stream) {
+  if (!in || !out || batch <= 0 || h <= 0 || w <= 0 || c < 4 || (c & 3) || (ld_in & 3) || (ld_out & 3) || !al16(in) || !al16(out))
+    return PCP_ERR_ARG;
+  const long long total = (long long)batch * 4 * h * w * (c >> 2);
+  hipLaunchKernelGGL(k_dilate2x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, batch, h, w, c >> 2, ld_in,
+                     out, ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/pcp_hip.h"
+#include "../../include/pcp_hip_train.h"
 
 #define PCP_WAVE 64
 

@@ -39,6 +39,11 @@ class Decode(ctypes.Structure):
                 ('use_score_thresh', c_i32), ('score_thresh', c_f)]
 
 
+class RowMap(ctypes.Structure):
+    _fields_ = [('ptr', vp), ('ld', c_i32), ('channels', c_i32), ('lattice', c_i32), ('grid_h', c_i32), ('grid_w', c_i32),
+                ('ky', c_i32), ('kx', c_i32)]
+
+
 PW_PLAIN, PW_SPACE2DEPTH, PW_DEPTH2SPACE = 0, 1, 2
 
 # every symbol include/pcp_hip.h declares: name -> (restype, argtypes)
@@ -72,6 +77,21 @@ SYMBOLS = {
     'pcp_bev_scatter_mean': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, vp, c_sz,
                                      vp, c_i32, vp]),
 }
+
+# include/pcp_hip_train.h
+SYMBOLS.update({
+    'pcp_bn_workspace_bytes': (c_sz, [c_i32]),
+    'pcp_bn_train_stats': (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp, c_f, c_f, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_scale_shift_act': (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp, c_i32, vp, c_i32, vp]),
+    'pcp_bn_act_backward': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, vp, c_i32, vp, c_i32, vp]),
+    'pcp_colsum': (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp, c_i32, vp]),
+    'pcp_accumulate': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, vp]),
+    'pcp_dilate2x': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp]),
+    'pcp_conv3x3_wgrad_workspace_bytes': (c_sz, [ctypes.POINTER(Conv3x3)]),
+    'pcp_conv3x3_wgrad': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, c_sz, vp, c_i32, vp]),
+    'pcp_pointwise_wgrad_workspace_bytes': (c_sz, [c_i64, c_i32, c_i32]),
+    'pcp_pointwise_wgrad': (c_i32, [ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), c_i64, vp, c_sz, vp, c_i32, c_i32, vp]),
+})
 
 _LIB = None
 

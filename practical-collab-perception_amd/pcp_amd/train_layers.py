@@ -1,0 +1,234 @@
+"""Hand-rolled forward/backward of the dense layers for the training path (no torch.autograd inside): every layer saves what its
+backward needs, `backward(dout)` writes parameter gradients straight into `param.grad` and returns the input gradient.
+
+A conv layer of the trainable branch is  y = conv(x) [+ bias];  a = relu?(bn_train?(y)).
+  forward   conv    -> pcp_conv3x3 / pcp_conv3x3_winograd / pcp_pointwise with the RAW weights (no BN folding, relu = 0)
+            bn      -> pcp_bn_train_stats (batch statistics, running stats updated) + pcp_scale_shift_act
+  backward  bn+relu -> pcp_bn_act_backward (in place on the incoming gradient)
+            bias    -> pcp_colsum
+            wgrad   -> pcp_conv3x3_wgrad / pcp_pointwise_wgrad (pixel-contraction MFMA GEMMs)
+            dgrad   -> the FORWARD kernels again with flipped / transposed weights (stride-2 3x3: on the zero-dilated gradient)
+
+Reference modules these stand for: nn.Conv2d / nn.ConvTranspose2d + nn.BatchNorm2d + nn.ReLU stacks of
+pcdet/models/backbones_2d/base_bev_backbone.py:30-69, dense_heads/center_head.py:24-29,75-82, bev_layers/v2x_fusion_disco.py:11-17,51-63.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import lib, ops, pack
+from . import train_ops as tops
+
+
+class StepClock:
+    """Packed weights are rebuilt when the optimizer has stepped (weights change through raw pointers, torch cannot tell)."""
+    step = 0
+
+    @classmethod
+    def tick(cls):
+        cls.step += 1
+
+
+def ensure_grad(p):
+    if p.grad is None or p.grad.shape != p.shape or p.grad.device != p.device or not p.grad.is_contiguous():
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+class Act:
+    """a channel window of an NHWC (or row-major) buffer"""
+    __slots__ = ('t', 'off', 'c')
+
+    def __init__(self, t, off=0, c=None):
+        self.t, self.off, self.c = t, off, (t.shape[-1] - off if c is None else c)
+
+    @property
+    def rows(self):
+        return self.t.numel() // self.t.shape[-1]
+
+
+def _zeros_like_cache(cache, key, n, device):
+    z = cache.get(key)
+    if z is None or z.numel() < n or z.device != device:
+        z = torch.zeros(n, dtype=torch.float32, device=device)
+        cache[key] = z
+    return z
+
+
+_ZERO_BIAS = {}
+
+
+class ConvBNAct:
+    """kind: '3x3' (stride 1 | 2, padding 1), 'plain' (Conv2d 1x1), 'plainT' (ConvTranspose2d 1x1), 's2d' (Conv2d k2 s2),
+    'd2s' (ConvTranspose2d k2 s2)."""
+
+    def __init__(self, conv, bn=None, relu=True, name=''):
+        self.conv, self.bn, self.relu, self.name = conv, bn, relu, name
+        k, s = conv.kernel_size[0], conv.stride[0]
+        if isinstance(conv, nn.ConvTranspose2d):
+            self.cin, self.cout = conv.weight.shape[0], conv.weight.shape[1]
+            self.kind = {(1, 1): 'plainT', (2, 2): 'd2s'}.get((k, s))
+        else:
+            self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
+            self.kind = {(3, 1): '3x3', (3, 2): '3x3', (1, 1): 'plain', (2, 2): 's2d'}.get((k, s))
+        if self.kind is None:
+            raise NotImplementedError('%s: conv k=%d s=%d has no training kernel' % (name, k, s))
+        self.stride = s if self.kind == '3x3' else 1
+        self._packed_step = -1
+        self._fw = self._bw = None
+        self.saved = None
+        self.vec = None
+
+    # ---- weight forms ----------------------------------------------------------------------------------------------------
+    def _zero_bias(self, n, dev):
+        return _zeros_like_cache(_ZERO_BIAS, (dev, 'z'), max(n, 1024), dev)
+
+    def _repack(self):
+        if self._packed_step == StepClock.step:
+            return
+        w = self.conv.weight.detach()
+        dev = w.device
+        b = self.conv.bias.detach() if self.conv.bias is not None else None
+        zb = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        fb = lambda n: (b if b is not None else zb(n))
+        k = self.kind
+        if k == '3x3':
+            fw = dict(direct=pack.pack_conv3x3(w, fb(self.cout)))
+            if self.stride == 1 and self.cin % pack.WINO_CK == 0 and self.cout >= 48:
+                fw['wino'] = pack.pack_conv3x3_winograd(w, fb(self.cout))
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()             # (cin, cout, 3, 3): conv weight of the data gradient
+            bw = dict(direct=pack.pack_conv3x3(wt, zb(self.cin)))
+            if self.cout % pack.WINO_CK == 0 and self.cin >= 48:
+                bw['wino'] = pack.pack_conv3x3_winograd(wt, zb(self.cin))
+        elif k == 'plain':
+            m = w.reshape(self.cout, self.cin)
+            fw = pack.pack_plain(m, fb(self.cout))
+            bw = pack.pack_plain(m.t().contiguous(), zb(self.cin))
+        elif k == 'plainT':
+            m = w.reshape(self.cin, self.cout)
+            fw = pack.pack_plain(m.t().contiguous(), fb(self.cout))
+            bw = pack.pack_plain(m.contiguous(), zb(self.cin))
+        elif k == 's2d':
+            fw = pack.pack_conv2x2_s2(w, fb(self.cout))
+            bw = pack.pack_convT2x2_s2(w, zb(self.cin))                 # (cout, cin, 2, 2) read as a ConvTranspose2d weight
+        else:  # d2s
+            fw = pack.pack_convT2x2_s2(w, fb(self.cout))
+            bw = pack.pack_conv2x2_s2(w, zb(self.cin))                  # (cin, cout, 2, 2) read as a Conv2d weight
+        self._fw, self._bw = fw, bw
+        self._packed_step = StepClock.step
+
+    # ---- launches --------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _run3x3(forms, x, cin, cout, stride, out, in_off, out_off):
+        B, H, W, _ = x.shape
+        algo = os.environ.get('PCP_CONV_ALGO', 'auto')                  # auto | direct | winograd (same switch as inference)
+        big = B * ((H + 7) // 8) * ((W + 15) // 16) * (forms['wino'][2] // 64) >= 256 if 'wino' in forms else False
+        if stride == 1 and 'wino' in forms and algo != 'direct' and (big or algo == 'winograd'):
+            u, ub, ucp = forms['wino']
+            return ops.conv3x3_winograd(x, u, ub, cin, cout, ucp, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
+        w, b, cp = forms['direct']
+        return ops.conv3x3(x, w, b, cin, cout, cp, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
+
+    def out_shape(self, x):
+        B, H, W = x.t.shape[0], x.t.shape[1], x.t.shape[2]
+        if self.kind == '3x3':
+            return (B, H // self.stride, W // self.stride)
+        if self.kind == 's2d':
+            return (B, H // 2, W // 2)
+        if self.kind == 'd2s':
+            return (B, 2 * H, 2 * W)
+        return (B, H, W)
+
+    def forward(self, x, out=None):
+        """x: Act.  out: Act to write the activation into (a channel window of a wider buffer) or None.  Returns Act."""
+        self._repack()
+        dev = x.t.device
+        shp = self.out_shape(x)
+        need_post = self.bn is not None or self.relu
+        y_t = torch.empty(shp + (self.cout,), dtype=torch.float32, device=dev) if (need_post or out is None) else None
+        y = Act(y_t, 0, self.cout) if y_t is not None else out
+        k = self.kind
+        if k == '3x3':
+            self._run3x3(self._fw, x.t, self.cin, self.cout, self.stride, y.t, x.off, y.off)
+        else:
+            mode = {'plain': lib.PW_PLAIN, 'plainT': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[k]
+            w, b, cp = self._fw
+            ops.pointwise(x.t, w, b, mode, self.cin, self.cout, cp, relu=False, out=y.t, in_ch_off=x.off, out_ch_off=y.off)
+        if not need_post:
+            self.saved = (x, y)
+            return y
+        if out is None:
+            out = Act(torch.empty(shp + (self.cout,), dtype=torch.float32, device=dev), 0, self.cout)
+        if self.bn is not None:
+            bn = self.bn
+            self.vec = tops.bn_train_stats(y.t, self.cout, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
+                                           bn.running_mean, bn.running_var, vec=self.vec, ch_off=y.off)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        else:
+            if self.vec is None:
+                self.vec = tops.BNVectors(self.cout, dev)
+                self.vec.scale.fill_(1.0)
+                self.vec.shift.zero_()
+        tops.scale_shift_act(y.t, self.cout, self.vec, self.relu, out.t, in_ch_off=y.off, out_ch_off=out.off)
+        self.saved = (x, y)
+        return out
+
+    def backward(self, dout, need_dx=True, accumulate=False, dx_out=None):
+        """dout: Act (gradient of the layer output; overwritten in place by the gradient of the conv output).
+        Returns Act dx (or None).  accumulate: add to param.grad instead of overwriting (a module applied several times)."""
+        x, y = self.saved
+        dev = dout.t.device
+        acc = 1 if accumulate else 0
+        if self.bn is not None:
+            g_w, g_b = ensure_grad(self.bn.weight), ensure_grad(self.bn.bias)
+            tops.bn_act_backward(dout.t, y.t, self.cout, self.vec, self.relu, g_w, g_b, accumulate=accumulate, dout_ch_off=dout.off,
+                                 x_ch_off=y.off)
+        elif self.relu:
+            raise NotImplementedError('%s: ReLU without BatchNorm is handled by the fused fusion kernels' % self.name)
+        dy = dout
+        if self.conv.bias is not None:
+            tops.colsum(dy.t, self.cout, ensure_grad(self.conv.bias), accumulate=accumulate, ch_off=dy.off)
+        gw = ensure_grad(self.conv.weight)
+        k = self.kind
+        rows = x.rows
+        if k == '3x3':
+            tops.conv3x3_wgrad(x.t, dy.t, self.cin, self.cout, self.stride, gw, accumulate=accumulate, x_ch_off=x.off, dy_ch_off=dy.off)
+        elif k == 'plain':
+            tops.pointwise_wgrad(tops.rowmap(dy.t, self.cout, dy.off), tops.rowmap(x.t, self.cin, x.off), rows,
+                                 gw.view(self.cout, self.cin), accumulate=accumulate)
+        elif k == 'plainT':
+            tops.pointwise_wgrad(tops.rowmap(x.t, self.cin, x.off), tops.rowmap(dy.t, self.cout, dy.off), rows,
+                                 gw.view(self.cin, self.cout), accumulate=accumulate)
+        elif k == 's2d':
+            Ho, Wo = dy.t.shape[1], dy.t.shape[2]
+            tmp = torch.empty((4, self.cout, self.cin), dtype=torch.float32, device=dev)
+            for tap in range(4):
+                tops.pointwise_wgrad(tops.rowmap(dy.t, self.cout, dy.off),
+                                     tops.rowmap(x.t, self.cin, x.off, lattice=(Ho, Wo, tap // 2, tap % 2)), dy.rows, tmp[tap])
+            g = tmp.permute(1, 2, 0).reshape(self.cout, self.cin, 2, 2)
+            gw.add_(g) if accumulate else gw.copy_(g)
+        else:  # d2s
+            H, W = x.t.shape[1], x.t.shape[2]
+            tmp = torch.empty((4, self.cin, self.cout), dtype=torch.float32, device=dev)
+            for tap in range(4):
+                tops.pointwise_wgrad(tops.rowmap(x.t, self.cin, x.off),
+                                     tops.rowmap(dy.t, self.cout, dy.off, lattice=(H, W, tap // 2, tap % 2)), rows, tmp[tap])
+            g = tmp.permute(1, 2, 0).reshape(self.cin, self.cout, 2, 2)
+            gw.add_(g) if accumulate else gw.copy_(g)
+        if not need_dx:
+            return None
+        self._repack()
+        if dx_out is None:
+            dx_out = Act(torch.empty(tuple(x.t.shape[:-1]) + (self.cin,), dtype=torch.float32, device=dev), 0, self.cin)
+        if k == '3x3':
+            src = dy
+            if self.stride == 2:
+                src = Act(tops.dilate2x(dy.t, self.cout, ch_off=dy.off), 0, self.cout)
+            self._run3x3(self._bw, src.t, self.cout, self.cin, 1, dx_out.t, src.off, dx_out.off)
+        else:
+            mode = {'plain': lib.PW_PLAIN, 'plainT': lib.PW_PLAIN, 's2d': lib.PW_DEPTH2SPACE, 'd2s': lib.PW_SPACE2DEPTH}[k]
+            w, b, cp = self._bw
+            ops.pointwise(dy.t, w, b, mode, self.cout, self.cin, cp, relu=False, out=dx_out.t, in_ch_off=dy.off, out_ch_off=dx_out.off)
+        return dx_out

@@ -1,0 +1,143 @@
+"""Tensor-level wrappers over the training half of the C ABI (include/pcp_hip_train.h).  Same rules as ops.py: CUDA tensors
+only, torch supplies memory and the stream, no eager fallback."""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+from .lib import Conv3x3, RowMap, check
+from .ops import _chan_ptr, _need_cuda, _p, _stream
+
+
+class Scratch:
+    """grow-only byte buffer reused by every call that needs a workspace (all calls are stream ordered)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_BN_WS = Scratch()
+_WG_WS = Scratch()
+
+
+def _rows_c(x):
+    """(..., ld) contiguous tensor -> (rows, ld)"""
+    assert x.is_contiguous() and x.dtype == torch.float32
+    return x.numel() // x.shape[-1], x.shape[-1]
+
+
+class BNVectors:
+    __slots__ = ('scale', 'shift', 'mean', 'invstd')
+
+    def __init__(self, c, device):
+        buf = torch.empty((4, c), dtype=torch.float32, device=device)
+        self.scale, self.shift, self.mean, self.invstd = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_train_stats(x, c, gamma, beta, eps, momentum, running_mean, running_var, vec=None, ch_off=0):
+    """x: (..., ld) NHWC / row-major.  Returns BNVectors; running stats are updated in place (pass None to skip)."""
+    _need_cuda(x, gamma, beta)
+    L = _lib.load()
+    rows, ld = _rows_c(x)
+    if vec is None:
+        vec = BNVectors(c, x.device)
+    ws = _BN_WS.get(L.pcp_bn_workspace_bytes(c), x.device)
+    check(L.pcp_bn_train_stats(_chan_ptr(x, ch_off), rows, c, ld, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                               _p(running_var), _p(ws), _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), _stream()),
+          'pcp_bn_train_stats')
+    return vec
+
+
+def scale_shift_act(x, c, vec, relu, out, in_ch_off=0, out_ch_off=0):
+    _need_cuda(x, out)
+    L = _lib.load()
+    rows, ld = _rows_c(x)
+    rows_o, ld_o = _rows_c(out)
+    assert rows == rows_o
+    check(L.pcp_scale_shift_act(_chan_ptr(x, in_ch_off), rows, c, ld, _p(vec.scale), _p(vec.shift), 1 if relu else 0,
+                                _chan_ptr(out, out_ch_off), ld_o, _stream()), 'pcp_scale_shift_act')
+    return out
+
+
+def bn_act_backward(dout, x, c, vec, relu, dgamma, dbeta, accumulate=False, dx=None, dout_ch_off=0, x_ch_off=0, dx_ch_off=0):
+    """dx defaults to dout (in place).  dgamma / dbeta: (c,) float32."""
+    _need_cuda(dout, x, dgamma, dbeta)
+    L = _lib.load()
+    rows, ld_d = _rows_c(dout)
+    rows_x, ld_x = _rows_c(x)
+    assert rows == rows_x
+    if dx is None:
+        dx, dx_ch_off = dout, dout_ch_off
+    ld_dx = dx.shape[-1]
+    ws = _BN_WS.get(L.pcp_bn_workspace_bytes(c), x.device)
+    check(L.pcp_bn_act_backward(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale), _p(vec.shift),
+                                _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(dgamma), _p(dbeta), 1 if accumulate else 0,
+                                _chan_ptr(dx, dx_ch_off), ld_dx, _stream()), 'pcp_bn_act_backward')
+    return dx
+
+
+def colsum(x, c, out, accumulate=False, ch_off=0):
+    _need_cuda(x, out)
+    L = _lib.load()
+    rows, ld = _rows_c(x)
+    ws = _BN_WS.get(L.pcp_bn_workspace_bytes(c), x.device)
+    check(L.pcp_colsum(_chan_ptr(x, ch_off), rows, c, ld, _p(ws), _p(out), 1 if accumulate else 0, _stream()), 'pcp_colsum')
+    return out
+
+
+def accumulate(dst, src, c, alpha=1.0, dst_ch_off=0, src_ch_off=0):
+    _need_cuda(dst, src)
+    L = _lib.load()
+    rows, ld_d = _rows_c(dst)
+    rows_s, ld_s = _rows_c(src)
+    assert rows == rows_s
+    check(L.pcp_accumulate(_chan_ptr(dst, dst_ch_off), ld_d, _chan_ptr(src, src_ch_off), ld_s, rows, c, float(alpha), _stream()),
+          'pcp_accumulate')
+    return dst
+
+
+def dilate2x(x, c, out=None, ch_off=0):
+    _need_cuda(x, out)
+    L = _lib.load()
+    B, H, W, ld = x.shape
+    if out is None:
+        out = torch.empty((B, 2 * H, 2 * W, c), dtype=torch.float32, device=x.device)
+    check(L.pcp_dilate2x(_chan_ptr(x, ch_off), B, H, W, c, ld, _p(out), out.shape[-1], _stream()), 'pcp_dilate2x')
+    return out
+
+
+def conv3x3_wgrad(x, dy, cin, cout, stride, dw, accumulate=False, x_ch_off=0, dy_ch_off=0):
+    """x: (B, H, W, ld_x) input of the conv, dy: (B, Ho, Wo, ld_dy) gradient of its output; dw: (cout, cin, 3, 3) contiguous."""
+    _need_cuda(x, dy, dw)
+    L = _lib.load()
+    B, H, W, ld_x = x.shape
+    assert dw.shape == (cout, cin, 3, 3) and dw.is_contiguous() and x.is_contiguous() and dy.is_contiguous()
+    assert dy.shape[0] == B and dy.shape[1] == H // stride and dy.shape[2] == W // stride
+    d = Conv3x3(B, H, W, cin, cout, 0, stride, ld_x, dy.shape[3], 0)
+    need = L.pcp_conv3x3_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = _WG_WS.get(need, x.device)
+    check(L.pcp_conv3x3_wgrad(ctypes.byref(d), _chan_ptr(x, x_ch_off), _chan_ptr(dy, dy_ch_off), _p(ws), ws.numel(), _p(dw),
+                              1 if accumulate else 0, _stream()), 'pcp_conv3x3_wgrad')
+    return dw
+
+
+def rowmap(t, channels, ch_off=0, lattice=None):
+    """lattice: None (row r = pixel r) or (grid_h, grid_w, ky, kx)"""
+    gh, gw, ky, kx = lattice if lattice is not None else (0, 0, 0, 0)
+    return RowMap(t.data_ptr() + 4 * ch_off, t.shape[-1], channels, 0 if lattice is None else 1, gh, gw, ky, kx)
+
+
+def pointwise_wgrad(a, b, rows, out, accumulate=False):
+    """out[n, k] (+)= sum_r a[map(r), n] * b[map(r), k];  a, b: RowMap (see rowmap());  out: (n, k) row-major (ld = out.stride(0))."""
+    L = _lib.load()
+    assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.shape == (a.channels, b.channels)
+    need = L.pcp_pointwise_wgrad_workspace_bytes(rows, a.channels, b.channels)
+    ws = _WG_WS.get(need, out.device)
+    check(L.pcp_pointwise_wgrad(ctypes.byref(a), ctypes.byref(b), rows, _p(ws), ws.numel(), _p(out), out.stride(0),
+                                1 if accumulate else 0, _stream()), 'pcp_pointwise_wgrad')
+    return out

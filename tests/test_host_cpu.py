@@ -19,7 +19,7 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 def test_library_exports_every_symbol_of_the_header():
     from pcp_amd import lib
     L = lib.load()
-    header = open(os.path.join(REPO, 'include', 'pcp_hip.h')).read()
+    header = ''.join(open(os.path.join(REPO, 'include', h)).read() for h in sorted(os.listdir(os.path.join(REPO, 'include'))))
     declared = set(re.findall(r'\b(pcp_[a-z0-9_]+)\s*\(', header))
     assert declared, 'no declarations parsed'
     for name in declared:
