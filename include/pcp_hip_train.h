@@ -68,6 +68,102 @@ size_t pcp_pointwise_wgrad_workspace_bytes(int64_t rows, int32_t n, int32_t k);
 int pcp_pointwise_wgrad(const pcp_rowmap_t *a, const pcp_rowmap_t *b, int64_t rows, void *workspace, size_t workspace_bytes,
                         float *out, int32_t ld_out, int32_t accumulate, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * a15  CenterHead training: target assignment, focal + L1 losses and their gradients, DiscoNet distillation loss.
+ * Replaces: pcdet/models/dense_heads/center_head.py:104-164,166-268 (assign_targets: per-frame .cpu() + python loop over
+ *           boxes), pcdet/models/model_utils/centernet_utils.py:8-68 (gaussian_radius, gaussian2D, draw_gaussian_to_heatmap),
+ *           center_head.py:270-300 (get_loss), pcdet/utils/loss_utils.py:264-375 (neg_loss_cornernet, _reg_loss,
+ *           RegLossCenterNet) and pcdet/models/bev_layers/v2x_fusion_disco.py:119-123 (loss_distill), plus their autograd.
+ * One head (all five configs); classes of gt_boxes[..., 7] in 1..num_class, 0 = padding row (dataset.py collate_batch).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch, h, w;            /* feature map */
+  int32_t num_class;
+  int32_t k;                      /* NUM_MAX_OBJS */
+  float stride;                   /* FEATURE_MAP_STRIDE */
+  float voxel_x, voxel_y, min_x, min_y;
+  float gaussian_overlap;         /* GAUSSIAN_OVERLAP */
+  int32_t min_radius;             /* MIN_RADIUS */
+} pcp_target_t;
+
+/* gt_boxes (B, max_boxes, 8) [x,y,z,dx,dy,dz,heading,class] (max_boxes <= 1024).  Outputs: heatmap (B, H, W, num_class) NHWC,
+ * target_boxes (B, k, 8) = [dx, dy, z, log dims(3), cos, sin], inds (B, k) int32 flat y*W+x, mask (B, k) int32. */
+int pcp_centerhead_targets(const pcp_target_t *desc, const float *gt_boxes, int32_t max_boxes, float *heatmap, float *target_boxes,
+                           int32_t *inds, int32_t *mask, void *stream);
+
+typedef struct {
+  int32_t batch, h, w;
+  int32_t ld;                     /* pixel stride of the head-map buffer */
+  int32_t ld_d;                   /* pixel stride of the gradient buffer (channel numbering identical to the head buffer) */
+  int32_t num_class, ch_hm;       /* heat-map logits at channels [ch_hm, ch_hm + num_class) */
+  int32_t reg_ch[8];              /* channel of each regression code in HEAD_ORDER: center(2), center_z, dim(3), rot(2) */
+  int32_t k;
+  float cls_weight, loc_weight, code_weights[8];
+} pcp_headloss_t;
+
+size_t pcp_loss_workspace_bytes(void);
+/* losses (4,) float32 device: [hm_loss * cls_weight, loc_loss * loc_weight, their sum, num_pos].  dhead (B, H, W, ld_d) or NULL:
+ * every channel written (zero where no loss term reads the map), scaled by grad_scale. */
+int pcp_centerhead_loss(const pcp_headloss_t *desc, const float *head, const float *heatmap, const float *target_boxes,
+                        const int32_t *inds, const int32_t *mask, float grad_scale, void *workspace, float *losses, float *dhead,
+                        void *stream);
+/* loss (1,) = weight * mean smooth_l1(softmax_c(fused) - softmax_c(early)); dfused (pixels, ld_d) written or accumulated (NULL: none);
+ * c <= 512.  Shares the workspace of pcp_centerhead_loss. */
+int pcp_distill_loss(const float *fused, int32_t ld_f, const float *early, int32_t ld_e, int64_t pixels, int32_t c, float weight,
+                     float grad_scale, void *workspace, float *loss, float *dfused, int32_t ld_d, int32_t accumulate, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training-mode PillarFeatureNet (BatchNorm1d with batch statistics splits the fused inference kernel at its two global
+ * reductions).  Per-point tensors are in BUCKET ORDER (the counting sort pcp_voxelize leaves in its workspace; slot s, 0 <= s < N');
+ * the Linear layers run on pcp_pointwise, their gradients on pcp_pointwise / pcp_pointwise_wgrad, BatchNorm on pcp_bn_*.
+ * Replaces dynamic_pillar_vfe.py:110-126 (features), :35-46 (scatter_max + concat) and their autograd (scatter_max backward
+ * routes to one arg-max row per (pillar, channel); ties -> first row in bucket order), pointpillar_scatter.py:14-37.
+ *   features      fbuf (N', 16) = [raw(num_raw), f_cluster(3), f_center(3), 0...]; slot_pillar (N',) int32 pillar rank of each slot
+ *   mid           in1 (N', 64) = [relu(x0 * scale0 + shift0), per-pillar max of it]; arg0 (P, 32) int32 arg-max slot
+ *   out           pillar_features (P, 64) (may be NULL), arg1 (P, 64), canvas (B, ny, nx, 64) rows (may be NULL)
+ *   route_out     dz1 (kept_rows, 64) = 0 except dz1[arg1[p, c], c] = dcanvas[cell(p), c]  (or dpillar[p, c]; exactly one non-NULL)
+ *   route_mid     da0 (N', 32) = din1[:, :32] + [slot == arg0] * sum over the pillar of din1[:, 32:]
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_pfn_train_features(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid,
+                           const void *vox_workspace, float *fbuf, int32_t *slot_pillar, void *stream);
+int pcp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
+                      const float *shift0, float *in1, int32_t *arg0, void *stream);
+int pcp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+                      const float *shift1, float *pillar_features, int32_t *arg1, float *canvas, void *stream);
+int pcp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const float *dcanvas,
+                                 const float *dpillar, const int32_t *arg1, float *dz1, void *stream);
+int pcp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *din1, const int32_t *arg0,
+                                 float *da0, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * DiscoNet mid fusion, training: last weightor stage and the backward of softmax-over-agents + weighted sum.
+ * Replaces the autograd graph of pcdet/models/bev_layers/v2x_fusion_disco.py:22-24 and :109-115.  Agent maps are constants
+ * (transform_bev_img is @torch.no_grad, :29): only map 0 (ego) receives a gradient.  n_agents <= 8, c <= 256.
+ * pcp_disco_weight_logits: logits[p, a] = relu(<h2_a[p, 0:16], w4> + b4).
+ * pcp_disco_fuse_backward: dmap0 = softmax_a(logits)[0] * dfused;  dh2_a[p, :] = dlogit_a * [logit_a > 0] * w4;
+ *   dw4 (16), db4 (1) written or accumulated.  *_host arrays are HOST arrays of device pointers.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_disco_weight_logits(const float *const *h2_host, int32_t n_agents, int32_t ld_h, const float *w4, const float *b4,
+                            int64_t pixels, float *logits, int32_t ld_w, void *stream);
+size_t pcp_disco_fuse_backward_workspace_bytes(void);
+int pcp_disco_fuse_backward(const float *const *maps_host, int32_t n_agents, int32_t ld_map, int32_t c, const float *logits, int32_t ld_w,
+                            const float *dfused, int32_t ld_df, const float *const *h2_host, int32_t ld_h, const float *w4,
+                            int64_t pixels, float *dmap0, int32_t ld_dm, float *const *dh2_host, void *workspace, float *dw4, float *db4,
+                            int32_t accumulate, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Optimizer step on flat buffers: global-norm clipping + Adam with decoupled weight decay.
+ * Replaces tools/train_utils/train_utils.py:57-58 (clip_grad_norm_ + optimizer.step()) and
+ *          tools/train_utils/optimization/fastai_optim.py:104-122 (p.mul_(1 - wd * lr); torch.optim.Adam.step, betas (mom, 0.99)).
+ * pcp_grad_sqnorm: *sqnorm (double, device) (+)= sum g^2.
+ * pcp_adam_step (torch.optim.Adam arithmetic, amsgrad off, bias-corrected):
+ *   g = grad * grad_scale * min(1, max_norm / (sqrt(*sqnorm) * |grad_scale| + 1e-6))   (sqnorm NULL: no clipping)
+ *   p *= 1 - weight_decay * lr;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1-b1^step) * m / (sqrt(v) / sqrt(1-b2^step) + eps)
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_grad_sqnorm(const float *grad, int64_t n, double *sqnorm, int32_t accumulate, void *stream);
+int pcp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, float max_norm, const double *sqnorm, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

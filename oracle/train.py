@@ -220,7 +220,7 @@ def _pixel_weight_train(x, st, p):
     return F.relu(_conv(x, st, p + '.conv1_4'))
 
 
-def fusion_train(ego_map, agent_maps, se3, st, arch, prefix='v2x_mid_fusion'):
+def fusion_train(ego_map, agent_maps, se3, st, arch, prefix='v2x_mid_fusion', probe=None):
     fu = arch['fusion']
     ego = _compress_train(ego_map, st, prefix + '.compressor')
     B = ego.shape[0]
@@ -240,6 +240,10 @@ def fusion_train(ego_map, agent_maps, se3, st, arch, prefix='v2x_mid_fusion'):
     fused = sum(all_bev[a] * w[:, a:a + 1] for a in range(len(all_bev)))
     p = prefix + '.decompressor'
     y = F.relu(_bn_train(_conv(fused, st, p + '.0', padding=1), st, p + '.1', 1e-5, 0.1))
+    if probe is not None:                      # intermediate tensors for gradient bisection in tests / tools
+        probe.update(ego_compressed=ego, fused_in=fused, decomp_mid=y, weights=w)
+        for t in (ego, fused, y):
+            t.retain_grad()
     return _conv(y, st, p + '.3', padding=1)
 
 
@@ -280,7 +284,7 @@ def make_state(state):
     return st
 
 
-def train_forward(points, gt_boxes, metadata, st, arch):
+def train_forward(points, gt_boxes, metadata, st, arch, probe=None):
     """One train-mode forward.  st: make_state() output (running stats are updated in place).  Returns (loss, tb, aux)."""
     pts = np.ascontiguousarray(points, dtype=F32)
     st_np = {k: v.detach().numpy() for k, v in st.items()}
@@ -311,7 +315,10 @@ def train_forward(points, gt_boxes, metadata, st, arch):
     loss_distill = None
     if arch.get('fusion') is not None:
         se3 = [md['se3_from_ego'] for md in metadata]
-        m = fusion_train(m, {a: t.to(dt) for a, t in bev_img.items()}, se3, st, arch)
+        m = fusion_train(m, {a: t.to(dt) for a, t in bev_img.items()}, se3, st, arch, probe=probe)
+        if probe is not None:
+            m.retain_grad()
+            aux['backbone_out'].retain_grad()
         loss_distill = distill_loss(m, bev_early.to(dt))
         aux['fused'] = m
     maps = head_train(m, st, arch)

@@ -1,0 +1,392 @@
+// a15 -- CenterHead target assignment and training losses on the device, plus the DiscoNet distillation loss.
+//
+// Replaces (all host-side python / numpy loops or chains of small ATen ops in the reference):
+//   CenterHead.assign_targets / assign_target_of_single_head   pcdet/models/dense_heads/center_head.py:104-164,166-268
+//     (.cpu() -> per-box python loop -> .to(device), one host round trip per iteration)
+//   gaussian_radius / gaussian2D / draw_gaussian_to_heatmap    pcdet/models/model_utils/centernet_utils.py:8-68
+//   CenterHead.get_loss, sigmoid clamp                          center_head.py:270-300
+//   neg_loss_cornernet, _reg_loss, RegLossCenterNet             pcdet/utils/loss_utils.py:264-375
+//   loss_distill = 10 * smooth_l1(softmax_c(fused), softmax_c(bev_img_early))   bev_layers/v2x_fusion_disco.py:119-123
+// and the autograd nodes behind them: the loss kernels also emit dL/d(head maps) and dL/d(fused map).
+//
+// Latency-bound integer/float work (<= 500 boxes, 16 384 cells): one workgroup per frame for the targets, flat streaming
+// kernels for the losses; every reduction is float64 (atomics per block), so the scalar losses are order independent.
+#include "pcp_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int TGT_THREADS = 256;
+constexpr int TGT_MAX_BOXES = 1024;
+
+// centernet_utils.py:8-35 in float32 (tensor arithmetic of the reference); python scalars enter as float32 constants
+__device__ float gaussian_radius_f32(float height, float width, float min_overlap) {
+  const float b1 = height + width;
+  const float c1 = width * height * ((1.f - min_overlap) / (1.f + min_overlap));
+  const float sq1 = sqrtf(b1 * b1 - 4.f * c1);
+  const float r1 = (b1 + sq1) / 2.f;
+  const float b2 = 2.f * (height + width);
+  const float c2 = (1.f - min_overlap) * width * height;
+  const float sq2 = sqrtf(b2 * b2 - 16.f * c2);
+  const float r2 = (b2 + sq2) / 2.f;
+  const float a3 = 4.f * min_overlap;
+  const float b3 = -2.f * min_overlap * (height + width);
+  const float c3 = (min_overlap - 1.f) * width * height;
+  const float sq3 = sqrtf(b3 * b3 - 4.f * a3 * c3);
+  const float r3 = (b3 + sq3) / 2.f;
+  return fminf(fminf(r1, r2), r3);
+}
+
+struct BoxT { int valid, x, y, r, cls; };
+
+__global__ __launch_bounds__(TGT_THREADS) void k_targets(pcp_target_t d, const float *__restrict__ gt, int m, float *__restrict__ heat,
+                                                        float *__restrict__ tbox, int *__restrict__ inds, int *__restrict__ mask) {
+  __shared__ BoxT boxes[TGT_MAX_BOXES];
+  __shared__ int rank_of[TGT_MAX_BOXES];
+  __shared__ int wave_tot[TGT_THREADS / 64];
+  __shared__ int base;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float *g = gt + (long long)b * m * 8;
+  if (tid == 0) base = 0;
+  // zero this frame's sparse outputs
+  for (int i = tid; i < d.k * 8; i += TGT_THREADS) tbox[(long long)b * d.k * 8 + i] = 0.f;
+  for (int i = tid; i < d.k; i += TGT_THREADS) { inds[(long long)b * d.k + i] = 0; mask[(long long)b * d.k + i] = 0; }
+  __syncthreads();
+  // rank of each foreground row among the rows of this head (class filter of center_head.py:192-204 keeps order)
+  for (int start = 0; start < m; start += TGT_THREADS) {
+    const int i = start + tid;
+    int fg = 0;
+    if (i < m) {
+      const float c = g[i * 8 + 7];
+      fg = (c >= 1.f && c <= (float)d.num_class) ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(fg);
+    const int lane = tid & 63, wv = tid >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wv; ++w) off += wave_tot[w];
+    if (i < m) rank_of[i] = fg ? off + before : -1;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < TGT_THREADS / 64; ++w) t += wave_tot[w]; base += t; }
+    __syncthreads();
+  }
+  for (int i = tid; i < m; i += TGT_THREADS) {
+    BoxT bx{0, 0, 0, 0, 0};
+    const int k = rank_of[i];
+    if (k >= 0 && k < d.k) {
+      const float *r = g + i * 8;
+      float cx = (r[0] - d.min_x) / d.voxel_x / d.stride;
+      float cy = (r[1] - d.min_y) / d.voxel_y / d.stride;
+      cx = fminf(fmaxf(cx, 0.f), (float)d.w - 0.5f);
+      cy = fminf(fmaxf(cy, 0.f), (float)d.h - 0.5f);
+      const int ix = (int)cx, iy = (int)cy;
+      const float dx = r[3] / d.voxel_x / d.stride;
+      const float dy = r[4] / d.voxel_y / d.stride;
+      if (dx > 0.f && dy > 0.f) {
+        float rad = gaussian_radius_f32(dx, dy, d.gaussian_overlap);
+        int ri = (rad == rad) ? (int)rad : 0;
+        if (ri < d.min_radius) ri = d.min_radius;
+        bx.valid = 1; bx.x = ix; bx.y = iy; bx.r = ri; bx.cls = (int)r[7] - 1;
+        const long long o = ((long long)b * d.k + k);
+        inds[o] = iy * d.w + ix;
+        mask[o] = 1;
+        float *t = tbox + o * 8;
+        t[0] = cx - (float)ix;
+        t[1] = cy - (float)iy;
+        t[2] = r[2];
+        t[3] = logf(r[3]);
+        t[4] = logf(r[4]);
+        t[5] = logf(r[5]);
+        t[6] = cosf(r[6]);
+        t[7] = sinf(r[6]);
+      }
+    }
+    if (i < TGT_MAX_BOXES) boxes[i] = bx;
+  }
+  __syncthreads();
+  // gaussian splat with max blending (order independent); float64 exp then one rounding, like numpy float64 -> .float()
+  int *hm = reinterpret_cast<int *>(heat + (long long)b * d.h * d.w * d.num_class);
+  for (int i = 0; i < m && i < TGT_MAX_BOXES; ++i) {
+    const BoxT bx = boxes[i];
+    if (!bx.valid) continue;
+    const int r = bx.r;
+    const int left = min(bx.x, r), right = min(d.w - bx.x, r + 1);
+    const int top = min(bx.y, r), bottom = min(d.h - bx.y, r + 1);
+    const int ww = left + right, hh = top + bottom;
+    if (ww <= 0 || hh <= 0) continue;
+    const double sigma = (double)(2 * r + 1) / 6.0;
+    const double inv = 1.0 / (2.0 * sigma * sigma);
+    for (int p = tid; p < ww * hh; p += TGT_THREADS) {
+      const int py = p / ww - top, px = p % ww - left;
+      const float v = (float)exp(-(double)(px * px + py * py) * inv);
+      atomicMax(hm + ((long long)(bx.y + py) * d.w + (bx.x + px)) * d.num_class + bx.cls, __float_as_int(v));
+    }
+  }
+}
+
+// ---- losses ---------------------------------------------------------------------------------------------------------------
+// acc (double): [0] pos_loss  [1] neg_loss  [2] num_pos  [3] num (mask sum)  [4..11] per-code L1 sums  [12] distill sum
+constexpr int ACC_N = 16;
+
+__device__ __forceinline__ float clamped_sigmoid(float x, int *inside) {
+  const float s = 1.f / (1.f + expf(-x));
+  *inside = (s >= 1e-4f && s <= 1.f - 1e-4f) ? 1 : 0;
+  return fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  double t = 0;
+  if (threadIdx.x == 0) for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t += sh[w];
+  return t;   // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void k_focal_reduce(pcp_headloss_t d, const float *__restrict__ head, const float *__restrict__ heat,
+                                                     double *acc) {
+  __shared__ double sh[4];
+  const long long total = (long long)d.batch * d.h * d.w * d.num_class;
+  double pos = 0, neg = 0, npos = 0;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % d.num_class);
+    const long long pix = t / d.num_class;
+    int inside;
+    const float p = clamped_sigmoid(head[pix * d.ld + d.ch_hm + c], &inside);
+    const float gtv = heat[t];
+    if (gtv == 1.f) {
+      pos += (double)(logf(p) * (1.f - p) * (1.f - p));
+      npos += 1.0;
+    } else if (gtv < 1.f) {
+      const float w = (1.f - gtv) * (1.f - gtv);
+      neg += (double)(logf(1.f - p) * p * p * (w * w));
+    }
+  }
+  double s = block_sum(pos, sh);
+  if (threadIdx.x == 0) atomicAdd(acc + 0, s);
+  s = block_sum(neg, sh);
+  if (threadIdx.x == 0) atomicAdd(acc + 1, s);
+  s = block_sum(npos, sh);
+  if (threadIdx.x == 0) atomicAdd(acc + 2, s);
+}
+
+__global__ __launch_bounds__(256) void k_reg_reduce(pcp_headloss_t d, const float *__restrict__ head, const float *__restrict__ tbox,
+                                                   const int *__restrict__ inds, const int *__restrict__ mask, double *acc) {
+  __shared__ double sh[4];
+  const int total = d.batch * d.k;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, num = 0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    if (!mask[t]) continue;
+    num += 1.0;
+    const int b = t / d.k;
+    const float *px = head + ((long long)b * d.h * d.w + inds[t]) * d.ld;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float tv = tbox[(long long)t * 8 + j];
+      if (tv != tv) continue;                               // isnotnan mask of _reg_loss
+      s[j] += (double)fabsf(px[d.reg_ch[j]] - tv);
+    }
+  }
+  double r = block_sum(num, sh);
+  if (threadIdx.x == 0) atomicAdd(acc + 3, r);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    r = block_sum(s[j], sh);
+    if (threadIdx.x == 0) atomicAdd(acc + 4 + j, r);
+  }
+}
+
+// losses_out: [0] hm_loss (weighted)  [1] loc_loss (weighted)  [2] hm + loc  [3] num_pos
+__global__ void k_headloss_finalize(pcp_headloss_t d, const double *acc, float *losses_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double npos = acc[2];
+  const double hm = (npos == 0.0 ? -acc[1] : -(acc[0] + acc[1]) / npos) * (double)d.cls_weight;
+  const double num = acc[3] < 1.0 ? 1.0 : acc[3];
+  double loc = 0;
+  for (int j = 0; j < 8; ++j) loc += (double)(float)(acc[4 + j] / num) * (double)d.code_weights[j];
+  loc *= (double)d.loc_weight;
+  losses_out[0] = (float)hm;
+  losses_out[1] = (float)loc;
+  losses_out[2] = (float)(hm + loc);
+  losses_out[3] = (float)npos;
+}
+
+// dense part of dL/d(head): heat-map channels get the focal gradient, every other channel of the ld_d-wide row is zeroed
+__global__ __launch_bounds__(256) void k_focal_grad(pcp_headloss_t d, const float *__restrict__ head, const float *__restrict__ heat,
+                                                   const double *acc, float grad_scale, float *__restrict__ dhead) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)d.batch * d.h * d.w * d.ld_d;
+  if (t >= total) return;
+  const int ch = (int)(t % d.ld_d);
+  const long long pix = t / d.ld_d;
+  float gval = 0.f;
+  const int c = ch - d.ch_hm;
+  if (c >= 0 && c < d.num_class) {
+    const double npos = acc[2];
+    const float coef = -d.cls_weight * grad_scale / (float)(npos == 0.0 ? 1.0 : npos);
+    int inside;
+    const float p = clamped_sigmoid(head[pix * d.ld + ch], &inside);
+    const float gtv = heat[pix * d.num_class + c];
+    float dldp = 0.f;
+    if (gtv == 1.f) {
+      if (npos != 0.0) dldp = (1.f - p) * (1.f - p) / p - 2.f * (1.f - p) * logf(p);
+    } else if (gtv < 1.f) {
+      const float w = (1.f - gtv) * (1.f - gtv);
+      dldp = (w * w) * (-(p * p) / (1.f - p) + 2.f * p * logf(1.f - p));
+    }
+    gval = inside ? coef * dldp * p * (1.f - p) : 0.f;
+  }
+  dhead[t] = gval;
+}
+
+__global__ __launch_bounds__(256) void k_reg_grad(pcp_headloss_t d, const float *__restrict__ head, const float *__restrict__ tbox,
+                                                 const int *__restrict__ inds, const int *__restrict__ mask, const double *acc,
+                                                 float grad_scale, float *__restrict__ dhead) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.batch * d.k || !mask[t]) return;
+  const double num = acc[3] < 1.0 ? 1.0 : acc[3];
+  const int b = t / d.k;
+  const long long pix = (long long)b * d.h * d.w + inds[t];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float tv = tbox[(long long)t * 8 + j];
+    if (tv != tv) continue;
+    const float diff = head[pix * d.ld + d.reg_ch[j]] - tv;
+    const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+    if (sg != 0.f) atomicAdd(dhead + pix * d.ld_d + d.reg_ch[j], sg * d.loc_weight * d.code_weights[j] * grad_scale / (float)num);
+  }
+}
+
+// ---- distillation: one wavefront per pixel, c <= 512 -----------------------------------------------------------------------
+constexpr int DIST_MAXV = 8;
+
+__global__ __launch_bounds__(256) void k_distill(const float *__restrict__ fused, int ld_f, const float *__restrict__ early, int ld_e,
+                                                long long pixels, int c, float weight, float grad_scale, double *acc,
+                                                float *__restrict__ dfused, int ld_d, int accumulate) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  const double inv_n = 1.0 / ((double)pixels * (double)c);
+  double loss = 0;
+  for (long long pix = wave0; pix < pixels; pix += nw) {
+    float f[DIST_MAXV], e[DIST_MAXV];
+    float mf = -INFINITY, me = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < DIST_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      f[i] = ch < c ? fused[pix * ld_f + ch] : -INFINITY;
+      e[i] = ch < c ? early[pix * ld_e + ch] : -INFINITY;
+      mf = fmaxf(mf, f[i]);
+      me = fmaxf(me, e[i]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mf = fmaxf(mf, __shfl_xor(mf, o)); me = fmaxf(me, __shfl_xor(me, o)); }
+    float sf = 0.f, se = 0.f;
+#pragma unroll
+    for (int i = 0; i < DIST_MAXV; ++i) {
+      f[i] = expf(f[i] - mf);
+      e[i] = expf(e[i] - me);
+      sf += f[i];
+      se += e[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) { sf += __shfl_xor(sf, o); se += __shfl_xor(se, o); }
+    float dot = 0.f;
+    float gs[DIST_MAXV];
+#pragma unroll
+    for (int i = 0; i < DIST_MAXV; ++i) {
+      f[i] = f[i] / sf;
+      const float diff = f[i] - e[i] / se;
+      const float ad = fabsf(diff);
+      const int ch = lane + 64 * i;
+      if (ch < c) loss += (double)(ad < 1.f ? 0.5f * diff * diff : ad - 0.5f);
+      gs[i] = ad < 1.f ? diff : (diff > 0.f ? 1.f : -1.f);
+      dot += ch < c ? gs[i] * f[i] : 0.f;
+    }
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (dfused) {
+      const float k = weight * grad_scale * (float)inv_n;
+#pragma unroll
+      for (int i = 0; i < DIST_MAXV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < c) {
+          const float gv = k * f[i] * (gs[i] - dot);
+          float *o = dfused + pix * ld_d + ch;
+          *o = accumulate ? *o + gv : gv;
+        }
+      }
+    }
+  }
+  const double s = block_sum(loss, sh);
+  if (threadIdx.x == 0) atomicAdd(acc + 12, s);
+}
+
+__global__ void k_distill_finalize(const double *acc, long long pixels, int c, float weight, float *loss_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) loss_out[0] = (float)(acc[12] / ((double)pixels * (double)c) * (double)weight);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcp_centerhead_targets(const pcp_target_t *d, const float *gt_boxes, int32_t max_boxes, float *heatmap, float *target_boxes,
+                           int32_t *inds, int32_t *mask, void *stream) {
+  if (!d || !gt_boxes || !heatmap || !target_boxes || !inds || !mask) return PCP_ERR_ARG;
+  if (d->batch <= 0 || d->h <= 0 || d->w <= 0 || d->num_class <= 0 || d->k <= 0 || max_boxes < 0) return PCP_ERR_ARG;
+  if (max_boxes > TGT_MAX_BOXES) return PCP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (pcp_zero_async(heatmap, (size_t)d->batch * d->h * d->w * d->num_class * sizeof(float), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_targets, dim3(d->batch), dim3(TGT_THREADS), 0, s, *d, gt_boxes, max_boxes, heatmap, target_boxes, inds, mask);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+size_t pcp_loss_workspace_bytes(void) { return ACC_N * sizeof(double); }
+
+int pcp_centerhead_loss(const pcp_headloss_t *d, const float *head, const float *heatmap, const float *target_boxes,
+                        const int32_t *inds, const int32_t *mask, float grad_scale, void *workspace, float *losses, float *dhead,
+                        void *stream) {
+  if (!d || !head || !heatmap || !target_boxes || !inds || !mask || !workspace || !losses) return PCP_ERR_ARG;
+  if (d->batch <= 0 || d->h <= 0 || d->w <= 0 || d->num_class <= 0 || d->k <= 0 || d->ld <= 0) return PCP_ERR_ARG;
+  if (dhead && d->ld_d <= 0) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  if (pcp_zero_async(acc, 12 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;     // [12] belongs to the distillation loss
+  const long long cells = (long long)d->batch * d->h * d->w * d->num_class;
+  int blocks = (int)((cells + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_focal_reduce, dim3(blocks), dim3(256), 0, s, *d, head, heatmap, acc);
+  const int nk = d->batch * d->k;
+  hipLaunchKernelGGL(k_reg_reduce, dim3((nk + 255) / 256 > 64 ? 64 : (nk + 255) / 256), dim3(256), 0, s, *d, head, target_boxes, inds,
+                     mask, acc);
+  hipLaunchKernelGGL(k_headloss_finalize, dim3(1), dim3(64), 0, s, *d, acc, losses);
+  if (dhead) {
+    const long long total = (long long)d->batch * d->h * d->w * d->ld_d;
+    hipLaunchKernelGGL(k_focal_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *d, head, heatmap, acc, grad_scale, dhead);
+    hipLaunchKernelGGL(k_reg_grad, dim3((nk + 255) / 256), dim3(256), 0, s, *d, head, target_boxes, inds, mask, acc, grad_scale, dhead);
+  }
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_distill_loss(const float *fused, int32_t ld_f, const float *early, int32_t ld_e, int64_t pixels, int32_t c, float weight,
+                     float grad_scale, void *workspace, float *loss, float *dfused, int32_t ld_d, int32_t accumulate, void *stream) {
+  if (!fused || !early || !workspace || !loss || pixels <= 0 || c <= 0 || c > 64 * DIST_MAXV) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  if (pcp_zero_async(acc + 12, 4 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  long long blocks = (pixels + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_distill, dim3((unsigned)blocks), dim3(256), 0, s, fused, ld_f, early, ld_e, (long long)pixels, c, weight,
+                     grad_scale, acc, dfused, ld_d, accumulate);
+  hipLaunchKernelGGL(k_distill_finalize, dim3(1), dim3(64), 0, s, acc, (long long)pixels, c, weight, loss);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+}  // extern "C"

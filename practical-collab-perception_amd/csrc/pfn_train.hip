@@ -1,0 +1,294 @@
+// Training-mode PillarFeatureNet: the gather / per-pillar max / argmax-routing pieces around the two Linear layers.
+//
+// In train() mode the two BatchNorm1d layers (dynamic_pillar_vfe.py:29,40) normalise with statistics over ALL points of the batch,
+// so the fused single-kernel PFN of the inference path (pfn.hip) cannot be used: the statistics sit between the Linear and the
+// ReLU / scatter_max.  The step is split at those two global reductions; per-point tensors live in BUCKET ORDER (slot s of the
+// counting sort pcp_voxelize leaves in its workspace: the points of a pillar are one contiguous run), the Linear layers and
+// their weight / data gradients run on the MFMA pointwise kernels, BatchNorm on bn_train.hip, and this file supplies
+//   forward   features  (scatter_mean, f_cluster, f_center, concat: dynamic_pillar_vfe.py:110-126)  -> F (N', 16)
+//             mid       a0 = relu(bn0(x0)); m0 = scatter_max(a0); in1 = [a0, m0[inv]]   (:35-46, first PFNLayerV2)
+//             out       scatter_max(relu(bn1(x1))) -> pillar_features, canvas            (:35-46 last layer; pointpillar_scatter.py:14-37)
+//   backward  route_out dL/d relu(bn1(x1)) = dL/d pillar at the arg-max row, 0 elsewhere (scatter_max backward)
+//             route_mid dL/d a0 = d in1[:, :32] + [row is arg-max] * sum_pillar d in1[:, 32:]
+// Arg-max ties go to the first row in bucket order (torch_scatter keeps one index; ties need bit-identical rows).
+#include "pcp_common.h"
+
+namespace {
+
+constexpr int PT_THREADS = 256;
+constexpr int PT_PILLARS = 64;
+constexpr int FW = 16;    // padded feature width
+constexpr int C0 = 32, C1 = 64;
+
+struct FeatParams {
+  const float *points;
+  int stride;
+  pcp_grid_t g;
+  const int *bucket_order, *pillar_cell, *pillar_start, *counters;
+  float *fbuf;
+  int *slot_pillar;
+};
+
+__device__ __forceinline__ int find_pillar(const int *pl_start, int np, int slot) {
+  int lo = 0, hi = np - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pl_start[mid] <= slot) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <int NUM_RAW>
+__global__ __launch_bounds__(PT_THREADS) void k_pfnt_feat(FeatParams p) {
+  constexpr int F = NUM_RAW + 6;
+  static_assert(F <= FW, "feature row is padded to 16 floats");
+  __shared__ int pl_start[PT_PILLARS + 1];
+  __shared__ long long sum_fx[PT_PILLARS][3];
+  __shared__ float mean[PT_PILLARS][3];
+  const int P = p.counters[0];
+  const int r0 = blockIdx.x * PT_PILLARS;
+  if (r0 >= P) return;
+  const int np = min(PT_PILLARS, P - r0);
+  const int tid = threadIdx.x;
+  for (int i = tid; i <= np; i += PT_THREADS) pl_start[i] = p.pillar_start[r0 + i];
+  for (int i = tid; i < PT_PILLARS * 3; i += PT_THREADS) (&sum_fx[0][0])[i] = 0;
+  __syncthreads();
+  const int s0 = pl_start[0], s1 = pl_start[np];
+  // per-pillar mean exactly as the inference kernel: 2^-24 fixed point sums (deterministic), one division
+  for (int s = s0 + tid; s < s1; s += PT_THREADS) {
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+    const int pl = find_pillar(pl_start, np, s);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const long long q = __double2ll_rn((double)row[1 + a] * 16777216.0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < np * 3; i += PT_THREADS) {
+    const int pl = i / 3, a = i % 3;
+    const int cnt = pl_start[pl + 1] - pl_start[pl];
+    mean[pl][a] = (float)(((double)sum_fx[pl][a] * (1.0 / 16777216.0)) / (double)cnt);
+  }
+  __syncthreads();
+  const int plane = p.g.nx * p.g.ny;
+  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
+  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
+  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
+  for (int s = s0 + tid; s < s1; s += PT_THREADS) {
+    const int pl = find_pillar(pl_start, np, s);
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+    float f[FW];
+#pragma unroll
+    for (int k = 0; k < FW; k++) f[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NUM_RAW; k++) f[k] = row[1 + k];
+    const int rem = p.pillar_cell[r0 + pl] % plane;
+    const float cx = (float)(rem / p.g.ny), cy = (float)(rem % p.g.ny);
+    f[NUM_RAW + 0] = __fsub_rn(f[0], mean[pl][0]);
+    f[NUM_RAW + 1] = __fsub_rn(f[1], mean[pl][1]);
+    f[NUM_RAW + 2] = __fsub_rn(f[2], mean[pl][2]);
+    f[NUM_RAW + 3] = __fsub_rn(f[0], __fadd_rn(__fmul_rn(cx, p.g.voxel_x), x_off));
+    f[NUM_RAW + 4] = __fsub_rn(f[1], __fadd_rn(__fmul_rn(cy, p.g.voxel_y), y_off));
+    f[NUM_RAW + 5] = __fsub_rn(f[2], z_off);
+    float4 *o = reinterpret_cast<float4 *>(p.fbuf + (long long)s * FW);
+#pragma unroll
+    for (int q = 0; q < FW / 4; q++) o[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+    p.slot_pillar[s] = r0 + pl;
+  }
+}
+
+// wave per pillar; lane = (half, channel): the two halves take alternate rows
+__global__ __launch_bounds__(PT_THREADS) void k_pfnt_mid(const int *__restrict__ pillar_start, const int *__restrict__ counters,
+                                                        const float *__restrict__ x0, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, float *__restrict__ in1, int *__restrict__ arg0) {
+  const int P = counters[0];
+  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  const float sc = scale[c], sh = shift[c];
+  for (long long p = wave0; p < P; p += nw) {
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    float best = -1.f;
+    int arg = se;
+    for (int s = sb + half; s < se; s += 2) {
+      const float v = fmaxf(fmaf(x0[(long long)s * C0 + c], sc, sh), 0.f);
+      in1[(long long)s * C1 + c] = v;
+      if (v > best) { best = v; arg = s; }
+    }
+    const float ob = __shfl_xor(best, 32);
+    const int oa = __shfl_xor(arg, 32);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    if (half == 0) arg0[p * C0 + c] = arg;
+    for (int s = sb + half; s < se; s += 2) in1[(long long)s * C1 + C0 + c] = best;
+  }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
+                                                        const int *__restrict__ counters, pcp_grid_t g, const float *__restrict__ x1,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        float *__restrict__ pf, int *__restrict__ arg1, float *__restrict__ canvas) {
+  const int P = counters[0];
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  const float sc = scale[lane], sh = shift[lane];
+  const int plane = g.nx * g.ny;
+  for (long long p = wave0; p < P; p += nw) {
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    float best = -1.f;
+    int arg = sb;
+    for (int s = sb; s < se; ++s) {
+      const float v = fmaxf(fmaf(x1[(long long)s * C1 + lane], sc, sh), 0.f);
+      if (v > best) { best = v; arg = s; }
+    }
+    if (pf) pf[p * C1 + lane] = best;
+    arg1[p * C1 + lane] = arg;
+    if (canvas) {
+      const int cell = pillar_cell[p];
+      const int b = cell / plane, rem = cell % plane;
+      const int cx = rem / g.ny, cy = rem % g.ny;
+      canvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + lane] = best;
+    }
+  }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__restrict__ pillar_cell, const int *__restrict__ counters,
+                                                              pcp_grid_t g, const float *__restrict__ dcanvas, const float *__restrict__ dpf,
+                                                              const int *__restrict__ arg1, float *__restrict__ dz1) {
+  const int P = counters[0];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)P * C1) return;
+  const long long p = t >> 6;
+  const int c = (int)(t & 63);
+  float gval;
+  if (dcanvas) {
+    const int plane = g.nx * g.ny;
+    const int cell = pillar_cell[p];
+    const int b = cell / plane, rem = cell % plane;
+    const int cx = rem / g.ny, cy = rem % g.ny;
+    gval = dcanvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + c];
+  } else {
+    gval = dpf[t];
+  }
+  dz1[(long long)arg1[t] * C1 + c] = gval;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_mid(const int *__restrict__ pillar_start, const int *__restrict__ counters,
+                                                              const float *__restrict__ din1, const int *__restrict__ arg0,
+                                                              float *__restrict__ da0) {
+  const int P = counters[0];
+  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long p = wave0; p < P; p += nw) {
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    // fixed summation order (ascending slot) so the result does not depend on the lane split
+    float dm = 0.f;
+    for (int s = sb; s < se; ++s) dm += din1[(long long)s * C1 + C0 + c];
+    const int a = arg0[p * C0 + c];
+    for (int s = sb + half; s < se; s += 2) da0[(long long)s * C0 + c] = din1[(long long)s * C1 + c] + (s == a ? dm : 0.f);
+  }
+}
+
+struct WsView { const int *bucket_order, *pillar_cell, *pillar_start, *counters; };
+
+inline WsView view_ws(const void *workspace, const pcp_grid_t *grid, int64_t n) {
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  const VoxLayout L = pcp_vox_layout(cells, n);
+  const char *ws = (const char *)workspace;
+  WsView v;
+  v.bucket_order = (const int *)(ws + L.bucket_order);
+  v.pillar_cell = (const int *)(ws + L.pillar_cell);
+  v.pillar_start = (const int *)(ws + L.pillar_start);
+  v.counters = (const int *)(ws + L.counters);
+  return v;
+}
+
+inline int pillar_wave_blocks(int64_t max_pillars) {
+  int64_t b = (max_pillars + 3) / 4;          // 4 waves per block
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcp_pfn_train_features(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid,
+                           const void *vox_workspace, float *fbuf, int32_t *slot_pillar, void *stream) {
+  if (!points || !grid || !vox_workspace || !fbuf || !slot_pillar || n < 0 || row_stride < 1 + num_raw || num_raw < 3) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const WsView v = view_ws(vox_workspace, grid, n);
+  FeatParams p;
+  p.points = points; p.stride = row_stride; p.g = *grid;
+  p.bucket_order = v.bucket_order; p.pillar_cell = v.pillar_cell; p.pillar_start = v.pillar_start; p.counters = v.counters;
+  p.fbuf = fbuf; p.slot_pillar = slot_pillar;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  const int64_t max_pillars = n < cells ? n : cells;
+  const int blocks = (int)((max_pillars + PT_PILLARS - 1) / PT_PILLARS);
+  hipStream_t s = (hipStream_t)stream;
+  switch (num_raw) {
+    case 3: hipLaunchKernelGGL(k_pfnt_feat<3>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(k_pfnt_feat<4>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
+    case 5: hipLaunchKernelGGL(k_pfnt_feat<5>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
+    default: return PCP_ERR_UNSUPPORTED;
+  }
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
+                      const float *shift0, float *in1, int32_t *arg0, void *stream) {
+  if (!grid || !vox_workspace || !x0 || !scale0 || !shift0 || !in1 || !arg0 || n < 0) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const WsView v = view_ws(vox_workspace, grid, n);
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  hipLaunchKernelGGL(k_pfnt_mid, dim3(pillar_wave_blocks(n < cells ? n : cells)), dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start,
+                     v.counters, x0, scale0, shift0, in1, arg0);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+                      const float *shift1, float *pillar_features, int32_t *arg1, float *canvas, void *stream) {
+  if (!grid || !vox_workspace || !x1 || !scale1 || !shift1 || !arg1 || n < 0) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const WsView v = view_ws(vox_workspace, grid, n);
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  hipLaunchKernelGGL(k_pfnt_out, dim3(pillar_wave_blocks(n < cells ? n : cells)), dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start,
+                     v.pillar_cell, v.counters, *grid, x1, scale1, shift1, pillar_features, arg1, canvas);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const float *dcanvas,
+                                 const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
+  if (!grid || !vox_workspace || !arg1 || !dz1 || n < 0 || kept_rows < 0 || kept_rows > n) return PCP_ERR_ARG;
+  if ((dcanvas == nullptr) == (dpillar == nullptr)) return PCP_ERR_ARG;
+  if (n == 0 || kept_rows == 0) return PCP_OK;
+  const WsView v = view_ws(vox_workspace, grid, n);
+  hipStream_t s = (hipStream_t)stream;
+  if (pcp_zero_async(dz1, (size_t)kept_rows * C1 * sizeof(float), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  const int64_t max_pillars = kept_rows < cells ? kept_rows : cells;
+  hipLaunchKernelGGL(k_pfnt_route_out, dim3((unsigned)((max_pillars * C1 + PT_THREADS - 1) / PT_THREADS)), dim3(PT_THREADS), 0, s,
+                     v.pillar_cell, v.counters, *grid, dcanvas, dpillar, arg1, dz1);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *din1, const int32_t *arg0,
+                                 float *da0, void *stream) {
+  if (!grid || !vox_workspace || !din1 || !arg0 || !da0 || n < 0) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const WsView v = view_ws(vox_workspace, grid, n);
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  hipLaunchKernelGGL(k_pfnt_route_mid, dim3(pillar_wave_blocks(n < cells ? n : cells)), dim3(PT_THREADS), 0, (hipStream_t)stream,
+                     v.pillar_start, v.counters, din1, arg0, da0);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+}  // extern "C"

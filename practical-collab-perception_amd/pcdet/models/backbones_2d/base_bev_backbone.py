@@ -11,7 +11,7 @@ import torch.nn as nn
 from pcp_amd import ops
 
 from ..convnet import pack_conv_module
-from ..packed import PackedModule, require_eval_hip
+from ..packed import PackedModule, train_tape
 
 
 class BaseBEVBackbone(PackedModule):
@@ -73,8 +73,20 @@ class BaseBEVBackbone(PackedModule):
         deblocks = [pack_conv_module(seq[0], seq[1], relu=True) for seq in self.deblocks]
         return dict(blocks=blocks, deblocks=deblocks)
 
+    def _forward_train(self, data_dict):
+        from ..train_path import BackboneTrain
+        from pcp_amd.train_layers import Act
+        if getattr(self, '_pcp_train', None) is None:
+            self._pcp_train = BackboneTrain(self)
+        self.invalidate_packed()
+        out = self._pcp_train.forward(Act(ops.as_nhwc(data_dict['spatial_features'])))
+        data_dict['spatial_features_2d'] = ops.nchw_view(out.t)
+        train_tape(data_dict).append(('backbone_2d', self._pcp_train.backward))
+        return data_dict
+
     def forward(self, data_dict):
-        require_eval_hip(self, 'BaseBEVBackbone')
+        if self.training:
+            return self._forward_train(data_dict)
         pk = self.packed()
         sf = data_dict['spatial_features']
         x = ops.as_nhwc(sf)

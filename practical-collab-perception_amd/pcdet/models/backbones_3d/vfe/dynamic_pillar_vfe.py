@@ -10,7 +10,7 @@ import torch.nn as nn
 from pcp_amd import ops, pack
 
 from .vfe_template import VFETemplate
-from ...packed import require_eval_hip
+from ...packed import train_tape
 
 
 class PFNLayerV2(nn.Module):
@@ -66,6 +66,15 @@ class DynamicPillarVFE(VFETemplate):
         self._prev_vox = None
         self._workspace = None
 
+    def _forward_train(self, batch_dict):
+        from ...train_path import VFETrain
+        if getattr(self, '_pcp_train', None) is None:
+            self._pcp_train = VFETrain(self)
+        self.invalidate_packed()
+        batch_dict = self._pcp_train.forward(batch_dict)
+        train_tape(batch_dict).append(('vfe', lambda g: self._pcp_train.backward(g.t)))
+        return batch_dict
+
     def get_output_feature_dim(self):
         return self.num_filters[-1]
 
@@ -75,7 +84,8 @@ class DynamicPillarVFE(VFETemplate):
         return dict(w0=w0.contiguous(), b0=b0.contiguous(), w1=w1.contiguous(), b1=b1.contiguous())
 
     def forward(self, batch_dict, **kwargs):
-        require_eval_hip(self, 'DynamicPillarVFE')
+        if self.training:
+            return self._forward_train(batch_dict)
         points = batch_dict['points']
         if points.dtype != torch.float32 or not points.is_contiguous():
             points = points.float().contiguous()

@@ -35,6 +35,10 @@ class BEVMaker(nn.Module):
         for param in self.parameters():
             param.requires_grad = False
 
+    def train(self, mode=True):
+        """frozen teacher: always evaluated in eval mode (the reference calls self.eval() inside every forward, bev_maker.py:151,213)"""
+        return super().train(False)
+
     def build_networks(self):
         info = {'module_list': [], 'num_rawpoint_features': self.dataset.point_feature_encoder.num_point_features,
                 'num_point_features': self.dataset.point_feature_encoder.num_point_features, 'grid_size': self.dataset.grid_size,

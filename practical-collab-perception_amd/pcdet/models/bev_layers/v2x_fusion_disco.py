@@ -13,7 +13,7 @@ import torch.nn as nn
 from pcp_amd import fusion_host, lib, ops
 
 from ..convnet import pack_conv_module
-from ..packed import PackedModule, require_eval_hip
+from ..packed import PackedModule, train_tape
 
 
 class PixelWeightedFusionSoftmax(nn.Module):
@@ -79,8 +79,23 @@ class V2XMidFusionDisco(PackedModule):
         h = pk['w2'].run(h)
         pk['w3'].run(h, out=wbuf, out_ch_off=col)
 
+    def _forward_train(self, batch_dict):
+        from ..train_path import FusionTrain
+        from pcp_amd.train_layers import Act
+        if getattr(self, '_pcp_train', None) is None:
+            self._pcp_train = FusionTrain(self)
+        self.invalidate_packed()
+        out, loss = self._pcp_train.forward(Act(ops.as_nhwc(batch_dict['spatial_features_2d'])), batch_dict['bev_img'],
+                                            batch_dict['metadata'], batch_dict.get('bev_img_early', None))
+        if loss is not None:
+            self.loss_dict['loss_distill'] = loss[0]
+        batch_dict['spatial_features_2d'] = ops.nchw_view(out.t)
+        train_tape(batch_dict).append(('v2x_mid_fusion', self._pcp_train.backward))
+        return batch_dict
+
     def forward(self, batch_dict):
-        require_eval_hip(self, 'V2XMidFusionDisco')
+        if self.training:
+            return self._forward_train(batch_dict)
         pk = self.packed()
         ego_in = ops.as_nhwc(batch_dict['spatial_features_2d'])
         B, H, W, _ = ego_in.shape

@@ -19,7 +19,7 @@ from torch.nn.init import kaiming_normal_
 from pcp_amd import ops
 
 from ..convnet import pack_conv_module, pack_conv_raw, _fold
-from ..packed import PackedModule, require_eval_hip
+from ..packed import PackedModule, train_tape
 
 
 class SeparateHead(nn.Module):
@@ -185,7 +185,8 @@ class CenterHead(PackedModule):
         return self.finalize(self.device_postprocess(head_bufs, pk), batch_size)
 
     def forward(self, data_dict):
-        require_eval_hip(self, 'CenterHead')
+        if self.training:
+            return self._forward_train(data_dict)
         pk = self.packed()
         x = ops.as_nhwc(data_dict['spatial_features_2d'])
         x = pk['shared'].run(x)
@@ -208,6 +209,76 @@ class CenterHead(PackedModule):
                                                      pred['pred_labels'].reshape(-1, 1).float()], dim=1)
         return data_dict
 
+    # ---- training (reference :104-300, 377-392) -------------------------------------------------------------------------
+    def _head_channels(self):
+        names = self.head_names[0]
+        outs = [self.heads_list[0].sep_head_dict[n]['out_channels'] for n in names]
+        offs = np.concatenate([[0], np.cumsum(outs)]).astype(int)
+        off = {n: int(o) for n, o in zip(names, offs[:-1])}
+        order = list(self.separate_head_cfg.HEAD_ORDER)
+        reg = []
+        for n in order:
+            reg += [off[n] + j for j in range(outs[names.index(n)])]
+        if len(reg) != 8 or 'hm' not in off:
+            raise NotImplementedError('loss kernel covers the 8 regression codes center/center_z/dim/rot + hm (all five configs)')
+        return off, outs, reg, names
+
+    def _forward_train(self, data_dict):
+        from pcp_amd import lib
+        from pcp_amd import train_ops as tops
+        from pcp_amd.train_layers import Act
+        from ..train_path import HeadTrain
+        if self.predict_boxes_when_training:
+            raise NotImplementedError('predict_boxes_when_training needs a RoI head (not on the PointPillars path)')
+        if getattr(self, '_pcp_train', None) is None:
+            self._pcp_train = HeadTrain(self)
+        self.invalidate_packed()
+        x = ops.as_nhwc(data_dict['spatial_features_2d'])
+        buf = self._pcp_train.forward(Act(x))
+        B, H, W, ld = buf.shape
+        off, outs, reg, names = self._head_channels()
+        view = ops.nchw_view(buf)
+        offs = np.concatenate([[0], np.cumsum(outs)]).astype(int)
+        self.forward_ret_dict['pred_dicts'] = [{n: view[:, int(offs[i]):int(offs[i + 1])] for i, n in enumerate(names)}]
+        ta = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        gt = data_dict['gt_boxes']
+        if gt.dtype != torch.float32 or not gt.is_contiguous():
+            gt = gt.float().contiguous()
+        if gt.shape[-1] != 8:
+            raise NotImplementedError('gt_boxes with velocity columns are not used by the V2X-Sim configs')
+        ncls = outs[names.index('hm')]
+        tdesc = lib.Target(B, H, W, ncls, int(ta.NUM_MAX_OBJS), float(ta.FEATURE_MAP_STRIDE), float(np.float32(self.voxel_size[0])),
+                           float(np.float32(self.voxel_size[1])), float(self.point_cloud_range[0]), float(self.point_cloud_range[1]),
+                           float(ta.GAUSSIAN_OVERLAP), int(ta.MIN_RADIUS))
+        heat, tb, inds, mask = tops.centerhead_targets(gt, tdesc)
+        self.forward_ret_dict['target_dicts'] = {'heatmaps': [ops.nchw_view(heat)], 'target_boxes': [tb], 'inds': [inds.long()],
+                                                 'masks': [mask.long()]}
+        self._train_state = dict(buf=buf, heat=heat, tb=tb, inds=inds, mask=mask, off=off, reg=reg, ncls=ncls)
+        train_tape(data_dict).append(('dense_head', self._backward_from_loss))
+        return data_dict
+
     def get_loss(self):
-        raise NotImplementedError('training (target assignment + CenterNet losses, reference :105-300) is the next scope row; '
-                                  'round 1 ships inference')
+        """focal + L1 losses AND dL/d(head maps) in one pass (the gradient is consumed by loss.backward())."""
+        from pcp_amd import lib
+        from pcp_amd import train_ops as tops
+        st = self._train_state
+        buf = st['buf']
+        B, H, W, ld = buf.shape
+        lw = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        d = lib.HeadLoss()
+        d.batch, d.h, d.w, d.ld, d.ld_d = B, H, W, ld, ld
+        d.num_class, d.ch_hm = st['ncls'], st['off']['hm']
+        for j in range(8):
+            d.reg_ch[j] = st['reg'][j]
+            d.code_weights[j] = float(lw['code_weights'][j])
+        d.k = int(self.model_cfg.TARGET_ASSIGNER_CONFIG.NUM_MAX_OBJS)
+        d.cls_weight, d.loc_weight = float(lw['cls_weight']), float(lw['loc_weight'])
+        dhead = torch.empty_like(buf)
+        losses = tops.centerhead_loss(buf, d, st['heat'], st['tb'], st['inds'], st['mask'], dhead=dhead)
+        st['dhead'] = dhead
+        vals = losses.tolist()
+        tb_dict = {'hm_loss_head_0': vals[0], 'loc_loss_head_0': vals[1], 'rpn_loss': vals[2]}
+        return losses[2], tb_dict
+
+    def _backward_from_loss(self, _unused):
+        return self._pcp_train.backward(self._train_state['dhead'])

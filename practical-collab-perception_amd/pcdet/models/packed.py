@@ -20,7 +20,8 @@ class PackedModule(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def train(self, mode=True):
-        self._pcp_cache = None
+        if mode != self.training:          # a frozen teacher flipped to eval() every forward keeps its packed weights
+            self._pcp_cache = None
         return super().train(mode)
 
     def packed(self):
@@ -36,5 +37,10 @@ class PackedModule(nn.Module):
 def require_eval_hip(module, what):
     if module.training:
         raise NotImplementedError(
-            '%s: the HIP path implements inference (eval mode); training kernels (backward) are listed as the next '
-            'scope row in DESIGN.md -- call model.eval()' % what)
+            '%s: this module has no training kernels (the HIP training path covers config 5: DynPillarVFE, PointPillarScatter, '
+            'BaseBEVBackbone, V2XMidFusionDisco, CenterHead) -- call model.eval()' % what)
+
+
+def train_tape(batch_dict):
+    """list of backward closures, appended in forward order by the train-mode modules; the detector runs it reversed."""
+    return batch_dict.setdefault('_pcp_tape', [])

@@ -44,6 +44,16 @@ class RowMap(ctypes.Structure):
                 ('ky', c_i32), ('kx', c_i32)]
 
 
+class Target(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('num_class', c_i32), ('k', c_i32), ('stride', c_f), ('voxel_x', c_f),
+                ('voxel_y', c_f), ('min_x', c_f), ('min_y', c_f), ('gaussian_overlap', c_f), ('min_radius', c_i32)]
+
+
+class HeadLoss(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('ld', c_i32), ('ld_d', c_i32), ('num_class', c_i32), ('ch_hm', c_i32),
+                ('reg_ch', c_i32 * 8), ('k', c_i32), ('cls_weight', c_f), ('loc_weight', c_f), ('code_weights', c_f * 8)]
+
+
 PW_PLAIN, PW_SPACE2DEPTH, PW_DEPTH2SPACE = 0, 1, 2
 
 # every symbol include/pcp_hip.h declares: name -> (restype, argtypes)
@@ -91,6 +101,21 @@ SYMBOLS.update({
     'pcp_conv3x3_wgrad': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, c_sz, vp, c_i32, vp]),
     'pcp_pointwise_wgrad_workspace_bytes': (c_sz, [c_i64, c_i32, c_i32]),
     'pcp_pointwise_wgrad': (c_i32, [ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), c_i64, vp, c_sz, vp, c_i32, c_i32, vp]),
+    'pcp_centerhead_targets': (c_i32, [ctypes.POINTER(Target), vp, c_i32, vp, vp, vp, vp, vp]),
+    'pcp_loss_workspace_bytes': (c_sz, []),
+    'pcp_centerhead_loss': (c_i32, [ctypes.POINTER(HeadLoss), vp, vp, vp, vp, vp, c_f, vp, vp, vp, vp]),
+    'pcp_distill_loss': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, c_f, vp, vp, vp, c_i32, c_i32, vp]),
+    'pcp_pfn_train_features': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, vp, vp, vp]),
+    'pcp_pfn_train_mid': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp]),
+    'pcp_pfn_train_out': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_pfn_train_route_out_grad': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, c_i64, vp, vp, vp, vp, vp]),
+    'pcp_pfn_train_route_mid_grad': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp]),
+    'pcp_disco_weight_logits': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, vp, vp, c_i64, vp, c_i32, vp]),
+    'pcp_disco_fuse_backward_workspace_bytes': (c_sz, []),
+    'pcp_disco_fuse_backward': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, c_i32, vp, c_i32, vp, c_i32, ctypes.POINTER(vp), c_i32, vp,
+                                        c_i64, vp, c_i32, ctypes.POINTER(vp), vp, vp, vp, c_i32, vp]),
+    'pcp_grad_sqnorm': (c_i32, [vp, c_i64, vp, c_i32, vp]),
+    'pcp_adam_step': (c_i32, [vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, vp, c_f, vp]),
 })
 
 _LIB = None

@@ -141,3 +141,135 @@ def pointwise_wgrad(a, b, rows, out, accumulate=False):
     check(L.pcp_pointwise_wgrad(ctypes.byref(a), ctypes.byref(b), rows, _p(ws), ws.numel(), _p(out), out.stride(0),
                                 1 if accumulate else 0, _stream()), 'pcp_pointwise_wgrad')
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a15: targets + losses
+# ---------------------------------------------------------------------------------------------------------------------
+
+_LOSS_WS = {}
+
+
+def _loss_ws(device):
+    ws = _LOSS_WS.get(device)
+    if ws is None:
+        ws = torch.zeros(_lib.load().pcp_loss_workspace_bytes(), dtype=torch.uint8, device=device)
+        _LOSS_WS[device] = ws
+    return ws
+
+
+def centerhead_targets(gt_boxes, desc):
+    """gt_boxes: (B, M, 8) float32 CUDA.  desc: lib.Target.  Returns heatmap (B,H,W,ncls), target_boxes (B,K,8), inds, mask (B,K) i32."""
+    _need_cuda(gt_boxes)
+    L = _lib.load()
+    assert gt_boxes.dtype == torch.float32 and gt_boxes.dim() == 3 and gt_boxes.shape[2] == 8 and gt_boxes.is_contiguous()
+    B, M, _ = gt_boxes.shape
+    assert B == desc.batch
+    dev = gt_boxes.device
+    heat = torch.empty((B, desc.h, desc.w, desc.num_class), dtype=torch.float32, device=dev)
+    tb = torch.empty((B, desc.k, 8), dtype=torch.float32, device=dev)
+    inds = torch.empty((B, desc.k), dtype=torch.int32, device=dev)
+    mask = torch.empty((B, desc.k), dtype=torch.int32, device=dev)
+    check(L.pcp_centerhead_targets(ctypes.byref(desc), _p(gt_boxes), M, _p(heat), _p(tb), _p(inds), _p(mask), _stream()),
+          'pcp_centerhead_targets')
+    return heat, tb, inds, mask
+
+
+def centerhead_loss(head, desc, heat, tb, inds, mask, dhead=None, grad_scale=1.0):
+    """head: (B,H,W,ld) raw maps.  Returns losses (4,) float32 device [hm, loc, hm+loc, num_pos]; fills dhead (B,H,W,ld_d) if given."""
+    _need_cuda(head, heat, tb, inds, mask, dhead)
+    L = _lib.load()
+    losses = torch.empty(4, dtype=torch.float32, device=head.device)
+    check(L.pcp_centerhead_loss(ctypes.byref(desc), _p(head), _p(heat), _p(tb), _p(inds), _p(mask), float(grad_scale),
+                                _p(_loss_ws(head.device)), _p(losses), _p(dhead), _stream()), 'pcp_centerhead_loss')
+    return losses
+
+
+def distill_loss(fused, early, c, weight=10.0, dfused=None, accumulate=False, grad_scale=1.0):
+    """fused, early: (B,H,W,ld) NHWC.  Returns loss (1,) float32 device."""
+    _need_cuda(fused, early, dfused)
+    L = _lib.load()
+    pixels = fused.numel() // fused.shape[-1]
+    loss = torch.empty(1, dtype=torch.float32, device=fused.device)
+    check(L.pcp_distill_loss(_p(fused), fused.shape[-1], _p(early), early.shape[-1], pixels, c, float(weight), float(grad_scale),
+                             _p(_loss_ws(fused.device)), _p(loss), _p(dfused), dfused.shape[-1] if dfused is not None else 0,
+                             1 if accumulate else 0, _stream()), 'pcp_distill_loss')
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PFN (train mode)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def pfn_train_features(points, vox, num_raw, fbuf, slot_pillar):
+    L = _lib.load()
+    check(L.pcp_pfn_train_features(_p(points), vox.n, vox.row_stride, num_raw, ctypes.byref(vox.grid), _p(vox.workspace), _p(fbuf),
+                                   _p(slot_pillar), _stream()), 'pcp_pfn_train_features')
+
+
+def pfn_train_mid(vox, x0, vec0, in1, arg0):
+    L = _lib.load()
+    check(L.pcp_pfn_train_mid(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x0), _p(vec0.scale), _p(vec0.shift), _p(in1), _p(arg0),
+                              _stream()), 'pcp_pfn_train_mid')
+
+
+def pfn_train_out(vox, x1, vec1, pillar_features, arg1, canvas):
+    L = _lib.load()
+    check(L.pcp_pfn_train_out(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x1), _p(vec1.scale), _p(vec1.shift),
+                              _p(pillar_features), _p(arg1), _p(canvas), _stream()), 'pcp_pfn_train_out')
+
+
+def pfn_train_route_out_grad(vox, kept_rows, arg1, dz1, dcanvas=None, dpillar=None):
+    L = _lib.load()
+    check(L.pcp_pfn_train_route_out_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, kept_rows, _p(dcanvas), _p(dpillar), _p(arg1),
+                                         _p(dz1), _stream()), 'pcp_pfn_train_route_out_grad')
+
+
+def pfn_train_route_mid_grad(vox, din1, arg0, da0):
+    L = _lib.load()
+    check(L.pcp_pfn_train_route_mid_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(din1), _p(arg0), _p(da0), _stream()),
+          'pcp_pfn_train_route_mid_grad')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DiscoNet fusion (train mode)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def disco_weight_logits(h2_list, w4, b4, logits):
+    """h2_list: list of (B,H,W,16) tensors; logits: (B,H,W,ld_w) -> column a = relu(conv1_4(h2_a))"""
+    L = _lib.load()
+    pixels = logits.numel() // logits.shape[-1]
+    check(L.pcp_disco_weight_logits(_ptr_array([t.data_ptr() for t in h2_list]), len(h2_list), h2_list[0].shape[-1], _p(w4), _p(b4), pixels,
+                                    _p(logits), logits.shape[-1], _stream()), 'pcp_disco_weight_logits')
+
+
+def disco_fuse_backward(map_ptrs, ld_map, c, logits, dfused, h2_list, w4, dmap0, dh2_list, dw4, db4, accumulate=False):
+    L = _lib.load()
+    pixels = logits.numel() // logits.shape[-1]
+    ws = _BN_WS.get(L.pcp_disco_fuse_backward_workspace_bytes(), logits.device)
+    check(L.pcp_disco_fuse_backward(_ptr_array(map_ptrs), len(map_ptrs), ld_map, c, _p(logits), logits.shape[-1], _p(dfused),
+                                    dfused.shape[-1], _ptr_array([t.data_ptr() for t in h2_list]), h2_list[0].shape[-1], _p(w4), pixels,
+                                    _p(dmap0), dmap0.shape[-1], _ptr_array([t.data_ptr() for t in dh2_list]), _p(ws), _p(dw4), _p(db4),
+                                    1 if accumulate else 0, _stream()), 'pcp_disco_fuse_backward')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------------------------------
+
+def grad_sqnorm(flat_grad, out=None, accumulate=False):
+    L = _lib.load()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=flat_grad.device)
+    check(L.pcp_grad_sqnorm(_p(flat_grad), flat_grad.numel(), _p(out), 1 if accumulate else 0, _stream()), 'pcp_grad_sqnorm')
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, sqnorm=None, grad_scale=1.0):
+    L = _lib.load()
+    check(L.pcp_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                          float(weight_decay), int(step), float(max_norm), _p(sqnorm), float(grad_scale), _stream()), 'pcp_adam_step')

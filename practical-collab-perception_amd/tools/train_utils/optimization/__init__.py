@@ -1,0 +1,136 @@
+"""build_optimizer / build_scheduler with the reference's signatures (tools/train_utils/optimization/__init__.py:11-62) for the
+`adam_onecycle` recipe every V2X-Sim config uses (OPTIMIZATION section of v2x_pointpillar_disco.yaml:175-194).
+
+MI355X-first design: all trainable parameters live in ONE flat fp32 buffer (param.data become views of it, param.grad views of
+a flat gradient buffer), so
+  * gradient clipping is one squared-norm reduction (pcp_grad_sqnorm) whose result never leaves the device,
+  * the optimizer step is ONE launch (pcp_adam_step: clip coefficient, decoupled weight decay, Adam moments, update),
+  * data-parallel training needs ONE RCCL all-reduce of the flat gradient buffer per step (19 MB for config 5).
+The reference's OptimWrapper splits BN / non-BN groups but applies the same lr, wd (bn_wd=True, true_wd=True) and betas to
+both (fastai_optim.py:104-122), so one flat group is arithmetically identical.
+"""
+import math
+
+import numpy as np
+import torch
+
+from pcp_amd import train_layers as tl
+from pcp_amd import train_ops as tops
+
+
+def annealing_cos(start, end, pct):
+    return end + (start - end) / 2 * (np.cos(np.pi * pct) + 1)
+
+
+class FlatAdamOneCycle:
+    """optimizer.zero_grad() / .step() / .lr / .mom like the reference's OptimWrapper; `clip_grad_norm(max_norm)` replaces
+    torch.nn.utils.clip_grad_norm_ (it only records max_norm: the scaling happens inside the fused step)."""
+
+    def __init__(self, model, wd=0.01, beta2=0.99, eps=1e-8, process_group=None):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev = self.params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('the fused optimizer runs on the GPU: move the model first (model.cuda())')
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]            # 16-byte aligned views
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p, sz in zip(self.params, sizes):
+            view = self.flat_p[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+            off += sz
+        self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.wd, self.beta2, self.eps = wd, beta2, eps
+        self.lr, self.mom = 0.0, 0.9
+        self.t = 0
+        self.max_norm = None
+        self.process_group = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and
+                                                                          torch.distributed.is_initialized()) else 1
+
+    def zero_grad(self):
+        off = 0
+        for p in self.params:                                               # re-attach views a foreign zero_grad(set_to_none) dropped
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+            off += (n + 3) // 4 * 4
+        tops_zero(self.flat_g)
+
+    def clip_grad_norm(self, max_norm):
+        """Records the clipping threshold; returns the device scalar holding the squared global norm (valid after step())."""
+        self.max_norm = float(max_norm)
+        return self.sqnorm
+
+    def all_reduce_grads(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_g, group=self.process_group)       # RCCL, one bucket
+
+    def step(self):
+        self.all_reduce_grads()
+        self.t += 1
+        scale = 1.0 / self.world                                            # DDP averages gradients
+        if self.max_norm is not None:
+            tops.grad_sqnorm(self.flat_g, out=self.sqnorm)
+        tops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.mom, self.beta2, self.eps, self.wd, self.t,
+                       max_norm=self.max_norm or 0.0, sqnorm=self.sqnorm if self.max_norm is not None else None, grad_scale=scale)
+        tl.StepClock.tick()                                                 # packed weight forms are stale now
+
+    def grad_norm(self):
+        """host value of the last global gradient norm (syncs; logging only)"""
+        return math.sqrt(float(self.sqnorm.item())) / self.world
+
+    def state_dict(self):
+        return {'t': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr, 'mom': self.mom}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd['t'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.lr, self.mom = float(sd['lr']), float(sd['mom'])
+
+
+def tops_zero(t):
+    from pcp_amd import ops
+    ops.fill_zero(t)
+
+
+class OneCycle:
+    """learning_schedules_fastai.py:44-77: cosine lr low -> max over the first pct_start, then max -> low / 1e4; beta1 moms[0] ->
+    moms[1] -> moms[0].  step(it) is called BEFORE each iteration (train_utils.py:39)."""
+
+    def __init__(self, optimizer, total_step, lr_max, moms, div_factor, pct_start):
+        self.optimizer, self.total_step = optimizer, total_step
+        self.lr_max, self.moms, self.div_factor, self.pct_start = lr_max, list(moms), div_factor, pct_start
+        low = lr_max / div_factor
+        a1 = int(pct_start * total_step)
+        self.lr_phases = ((0, a1, low, lr_max), (a1, total_step, lr_max, low / 1e4))
+        self.mom_phases = ((0, a1, self.moms[0], self.moms[1]), (a1, total_step, self.moms[1], self.moms[0]))
+        optimizer.lr, optimizer.mom = low, self.moms[0]
+
+    def step(self, step):
+        for s, e, a, b in self.lr_phases:
+            if step >= s:
+                self.optimizer.lr = float(annealing_cos(a, b, (step - s) / (e - s)))
+        for s, e, a, b in self.mom_phases:
+            if step >= s:
+                self.optimizer.mom = float(annealing_cos(a, b, (step - s) / (e - s)))
+
+
+def build_optimizer(model, optim_cfg):
+    if optim_cfg.OPTIMIZER != 'adam_onecycle':
+        raise NotImplementedError('the fused optimizer implements adam_onecycle (the recipe of every V2X-Sim config), got %s' % optim_cfg.OPTIMIZER)
+    return FlatAdamOneCycle(model, wd=optim_cfg.WEIGHT_DECAY, beta2=0.99)
+
+
+def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):
+    total_steps = total_iters_each_epoch * total_epochs
+    sched = OneCycle(optimizer, total_steps, optim_cfg.LR, list(optim_cfg.MOMS), optim_cfg.DIV_FACTOR, optim_cfg.PCT_START)
+    return sched, None

@@ -1,0 +1,134 @@
+"""Config-5 (DiscoNet) training step on MI355X against the reference's own train loop (tests/golden/g7_train.npz) and the CPU
+oracle (oracle/train.py, float64 = exact gradients, float32 = the noise floor of this ill-conditioned fixture)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import arch_of, load_golden
+from pcp_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(g):
+    from pcdet.models import build_network_from_meta
+    model = build_network_from_meta(g['meta'])
+    st = synth.fill_state_dict(g['meta']['state_shapes'])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    return model.to(DEV)
+
+
+def _batch(g):
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    return {'points': torch.from_numpy(g['points']).to(DEV), 'batch_size': 2, 'metadata': metadata,
+            'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}, metadata
+
+
+def _sample(t, cap=4096):
+    a = t.detach().reshape(-1)
+    if a.numel() <= cap:
+        return a.cpu().numpy()
+    return a[::a.numel() // 1024][:1024].cpu().numpy()
+
+
+def _oracle_grads(g, metadata, dtype):
+    from oracle import train as otr
+    meta = g['meta']
+    arch = otr.add_train_arch(arch_of(meta), meta['model'])
+    st = otr.make_state(synth.fill_state_dict(meta['state_shapes']))
+    if dtype == torch.float64:
+        st = {k: (v.detach().double().requires_grad_(v.requires_grad) if (v.dtype == torch.float32 and not k.startswith('bev_maker')) else v)
+              for k, v in st.items()}
+    loss, tb, aux = otr.train_forward(g['points'], g['gt_boxes'], metadata, st, arch)
+    loss.backward()
+    names = [str(n) for n in g['trainable']]
+    return {n: st[n].grad.detach().double() for n in names}, float(loss.detach()), tb, st
+
+
+def test_disco_train_step_matches_reference_and_oracle():
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from pcdet.config import EasyDict
+    g = load_golden('g7_train.npz')
+    meta = g['meta']
+    names = [str(n) for n in g['trainable']]
+    model = _build(g)
+    ocfg = EasyDict(meta['optimization'])
+    opt = build_optimizer(model, ocfg)
+    sched, _ = build_scheduler(opt, meta['total_it_each_epoch'], ocfg.NUM_EPOCHS, -1, ocfg)
+    params = dict(model.named_parameters())
+    assert set(names) == set(n for n, p in params.items() if p.requires_grad)
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    batch, metadata = _batch(g)
+    g64, loss64, _tb64, st64 = _oracle_grads(g, metadata, torch.float64)
+    g32, _loss32, _tb32, _ = _oracle_grads(g, metadata, torch.float32)
+
+    for it in range(2):
+        sched.step(it)
+        assert abs(opt.lr - float(g['it%d_lr' % it])) < 1e-12 and abs(opt.mom - float(g['it%d_mom' % it])) < 1e-12
+        model.train()
+        opt.zero_grad()
+        batch, _ = _batch(g)
+        ret, tb, _disp = model(batch)
+        loss = ret['loss']
+        model.update_global_step()
+        loss.backward()
+        ref_tb = json.loads(str(g['it%d_tb_json' % it]))
+        tol = 2e-5 if it == 0 else 2e-3
+        lv = float(loss.detach())
+        assert abs(lv - float(g['it%d_loss' % it])) <= tol * abs(float(g['it%d_loss' % it])), (lv, float(g['it%d_loss' % it]))
+        for k, v in ref_tb.items():
+            assert abs(tb[k] - v) <= max(tol, 2e-4) * abs(v) + 1e-9, (k, tb[k], v)
+        if it == 0:
+            assert abs(lv - loss64) <= 1e-5 * abs(loss64)
+            td = model.dense_head.forward_ret_dict['target_dicts']
+            np.testing.assert_allclose(td['heatmaps'][0].cpu().numpy(), g['tgt_heatmap'], atol=1e-6)
+            assert np.array_equal(td['inds'][0].cpu().numpy(), g['tgt_inds']) and np.array_equal(td['masks'][0].cpu().numpy(), g['tgt_mask'])
+            np.testing.assert_allclose(td['target_boxes'][0].cpu().numpy(), g['tgt_boxes'], atol=2e-6)
+            # Gradients vs the float64 oracle (exact).  Tensors downstream of the last BatchNorm+ReLU of the graph (head, last fusion
+            # conv) must agree to 1e-4.  Further upstream the comparison is bounded by the fixture, not the kernels: a forward
+            # difference of 1e-5 flips the ReLU mask of the few pre-activations that sit within 1e-5 of zero, and with only
+            # 2 x 32 x 32 samples per channel one flipped element moves a BatchNorm bias gradient by ~1 %; the float32 CPU oracle
+            # shows the same effect (tools/dbg_train.py prints both columns).  There: 3e-2 per tensor, 5e-3 global relative L2.
+            num = den = 0.0
+            gmax = max(float(v.abs().max()) for v in g64.values())
+            for n in names:
+                mine = params[n].grad.detach().double().cpu()
+                exact = g64[n]
+                scale = max(float(exact.abs().max()), 1e-4 * gmax)
+                err = float((mine - exact).abs().max())
+                floor = float((g32[n] - exact).abs().max())
+                tight = n.startswith('dense_head.') or n.startswith('v2x_mid_fusion.decompressor.3')
+                assert err <= (max(1e-4 * scale, 3.0 * floor) if tight else 3e-2 * scale), (n, err, scale, floor)
+                num += float(((mine - exact) ** 2).sum())
+                den += float((exact ** 2).sum())
+                ref = g['g0/' + n]
+                assert np.abs(_sample(params[n].grad) - ref).max() <= 3e-2 * max(float(np.abs(ref).max()), 1e-4 * gmax), n
+            assert num <= (5e-3 ** 2) * den, (num / den) ** 0.5
+            print('global relative L2 gradient error vs float64 oracle: %.3e' % ((num / den) ** 0.5))
+        opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+        opt.step()
+        if it == 0:
+            assert abs(opt.grad_norm() - float(g['it0_grad_norm'])) <= 2e-4 * float(g['it0_grad_norm'])
+            for n in names:
+                assert np.abs(_sample(params[n]) - g['p1/' + n]).max() <= 2.1 * opt.lr, n
+            sd = model.state_dict()
+            for i, k in enumerate(str(k) for k in g['bn_keys']):
+                if 'num_batches' in k:
+                    continue
+                a = sd[k].double()
+                d = np.array([float(a.norm()), float(a.sum()), float(a.abs().max())])
+                np.testing.assert_allclose(d, g['it0_bn_digest'][i], rtol=2e-4, atol=1e-6, err_msg=k)
+    # the trained model still runs the inference path
+    model.eval()
+    batch, _ = _batch(g)
+    batch.pop('gt_boxes')
+    with torch.no_grad():
+        pred, _ = model(batch)
+    assert len(pred) == 2 and all(torch.isfinite(p['pred_boxes']).all() for p in pred)

@@ -54,9 +54,16 @@ def test_product_path_fails_loudly_without_gpu():
     batch = {'points': torch.from_numpy(g['points']), 'batch_size': 2, 'metadata': [{}, {}]}
     with pytest.raises((PcpError, RuntimeError)):
         model(batch)
+    # train mode has no CPU path either: the HIP training kernels refuse host tensors
     model.train()
-    with pytest.raises(NotImplementedError):
+    batch = {'points': torch.from_numpy(g['points']), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.zeros(2, 1, 8)}
+    with pytest.raises((PcpError, RuntimeError)):
         model(batch)
+    # modules without training kernels say so (HunterJr: inference branch only)
+    gc = load_golden('g1_car.npz')
+    car = build_network_from_meta(gc['meta']).train()
+    with pytest.raises((NotImplementedError, PcpError, RuntimeError)):
+        car({'points': torch.from_numpy(gc['points']), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.zeros(2, 1, 8)})
 
 
 def test_bn_folding_and_conv3x3_packing_roundtrip():
