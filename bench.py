@@ -193,6 +193,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
+    ap.add_argument('--train', action='store_true', help='config disco only: time full training iterations (forward + backward + '
+                    'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -209,6 +211,8 @@ def main():
     cfg = load_cfg(conf['yaml'])
     batch = args.batch or int(cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU)
     model, state, ds = build_model(cfg)
+    if args.train and args.config != 'disco':
+        raise SystemExit('--train: the training kernels cover config 5 (--config disco)')
     model = model.to(dev).eval()
     for m in model.modules():
         if hasattr(m, 'materialize_pillars'):
@@ -223,7 +227,45 @@ def main():
         from pcdet.models.graphed import GraphedDetector
         graphed = GraphedDetector(model, pristine, batch, metas)
 
+    train_state = None
+    if args.train:
+        sys.path.insert(0, os.path.join(PKG, 'tools'))
+        from train_utils.optimization import build_optimizer, build_scheduler
+        from pcp_amd import synth
+        opt = build_optimizer(model, cfg.OPTIMIZATION)
+        sched, _ = build_scheduler(opt, 1000, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
+        gt = np.zeros((batch, 40, 8), dtype=np.float32)
+        for f in range(batch):
+            n = 40 - 3 * f
+            sd = synth.SEED_BASE + 900 + 100 * rank + f
+            gt[f, :n, 0] = synth.uniform(sd, 1, n, -50.0, 50.0)
+            gt[f, :n, 1] = synth.uniform(sd, 2, n, -50.0, 50.0)
+            gt[f, :n, 2] = synth.uniform(sd, 3, n, -3.0, -1.0)
+            gt[f, :n, 3] = synth.uniform(sd, 4, n, 3.0, 5.5)
+            gt[f, :n, 4] = synth.uniform(sd, 5, n, 1.5, 2.5)
+            gt[f, :n, 5] = synth.uniform(sd, 6, n, 1.4, 2.0)
+            gt[f, :n, 6] = synth.uniform(sd, 7, n, -3.14159, 3.14159)
+            gt[f, :n, 7] = 1.0
+        train_state = dict(opt=opt, sched=sched, gt=torch.from_numpy(gt).to(dev), it=0)
+
+    def train_step():
+        ts = train_state
+        ts['sched'].step(ts['it'])
+        model.train()
+        ts['opt'].zero_grad()
+        bd = {'points': pristine, 'batch_size': batch, 'metadata': metas, 'gt_boxes': ts['gt']}
+        ret, tb, _ = model(bd)
+        model.update_global_step()
+        ret['loss'].backward()
+        ts['opt'].clip_grad_norm(cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        ts['opt'].step()
+        ts['it'] += 1
+        ts['last_loss'] = tb['loss_total']
+        return []
+
     def step():
+        if train_state is not None:
+            return train_step()
         if graphed is not None:
             return graphed(pristine)            # copy-in + every kernel of the path = one graph replay
         work.copy_(pristine)                    # HunterJr corrects xyz in place: every step starts from the same bits
@@ -266,9 +308,12 @@ def main():
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': conf['name'], 'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
-                       'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': 'replicas x%d (frame-sharded)' % world, 'hipgraph': bool(args.graph),
-                       'final_boxes_last_step': n_boxes},
+            'config': {'workload': conf['name'] if not args.train else 'v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
+                       'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)',
+                       'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
+                       'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': ('replicas x%d (frame-sharded)' % world) if not args.train else
+                       ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
+                       'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
                          'achieved': round(cs['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(cs['tflops'] / MFMA_F32_PEAK_TFLOPS, 4),

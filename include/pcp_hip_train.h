@@ -164,6 +164,15 @@ int pcp_grad_sqnorm(const float *grad, int64_t n, double *sqnorm, int32_t accumu
 int pcp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float max_norm, const double *sqnorm, float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-step weight repacking of a 3x3 conv (the optimizer rewrites the weights every iteration): w is PyTorch's (cout, cin, 3, 3);
+ * transpose = 0 packs the forward conv, transpose = 1 the conv that computes its DATA gradient (channel roles swapped, taps
+ * flipped: the autograd "conv_transpose" of nn.Conv2d).  direct: [I/16][9][O_pad][16]; winograd: U = G g G^T as [I/8][16][O_pad][8]
+ * (layouts of pcp_conv3x3 / pcp_conv3x3_winograd); either may be NULL.  (I, O) = (cin, cout) or swapped.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *direct, int32_t direct_cout_pad,
+                     float *winograd, int32_t winograd_cout_pad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

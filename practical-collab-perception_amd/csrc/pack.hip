@@ -1,0 +1,85 @@
+// Weight repacking for the training step: the optimizer changes every weight every iteration, so the MFMA layouts of the forward
+// conv AND of its data-gradient conv (flipped taps, swapped channel roles) are rebuilt per step.  One launch per 3x3 layer writes
+// up to two layouts (direct implicit-GEMM [I/16][9][O_pad][16] and Winograd U = G g G^T [I/8][16][O_pad][8], float64 transform,
+// one rounding -- same arithmetic as pcp_amd/pack.py) instead of ~20 small ATen launches + two einsum GEMMs.
+#include "pcp_common.h"
+
+namespace {
+
+struct PackParams {
+  const float *w;        // (cout, cin, 3, 3) PyTorch layout
+  int cout, cin;
+  int transpose;         // 0: E[o][i][t] = w[o][i][t];  1 (data gradient): E[o][i][ky][kx] = w[i][o][2-ky][2-kx]
+  float *direct;         // may be NULL
+  int direct_opad;
+  float *wino;           // may be NULL
+  int wino_opad;
+};
+
+__device__ __forceinline__ float eff(const PackParams &p, int o, int i, int tap) {
+  if (!p.transpose) return p.w[((long long)o * p.cin + i) * 9 + tap];
+  return p.w[((long long)i * p.cin + o) * 9 + (8 - tap)];
+}
+
+__global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
+  const int O = p.transpose ? p.cin : p.cout, I = p.transpose ? p.cout : p.cin;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p.direct) {
+    const long long total = (long long)(I / 16) * 9 * p.direct_opad * 16;
+    if (t < total) {
+      const int k = (int)(t & 15);
+      long long r = t >> 4;
+      const int o = (int)(r % p.direct_opad);
+      r /= p.direct_opad;
+      const int tap = (int)(r % 9);
+      const int s = (int)(r / 9);
+      p.direct[t] = o < O ? eff(p, o, s * 16 + k, tap) : 0.f;
+    }
+  }
+  if (p.wino) {
+    const long long total = (long long)(I / 8) * p.wino_opad * 8;
+    if (t < total) {
+      const int k = (int)(t & 7);
+      long long r = t >> 3;
+      const int o = (int)(r % p.wino_opad);
+      const int s = (int)(r / p.wino_opad);
+      double g[3][3];
+#pragma unroll
+      for (int a = 0; a < 9; ++a) g[a / 3][a % 3] = o < O ? (double)eff(p, o, s * 8 + k, a) : 0.0;
+      // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+      double gg[4][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        gg[0][j] = g[0][j];
+        gg[1][j] = 0.5 * (g[0][j] + g[1][j] + g[2][j]);
+        gg[2][j] = 0.5 * (g[0][j] - g[1][j] + g[2][j]);
+        gg[3][j] = g[2][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double u0 = gg[i][0], u1 = 0.5 * (gg[i][0] + gg[i][1] + gg[i][2]), u2 = 0.5 * (gg[i][0] - gg[i][1] + gg[i][2]), u3 = gg[i][2];
+        const double u[4] = {u0, u1, u2, u3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          p.wino[(((long long)s * 16 + i * 4 + j) * p.wino_opad + o) * 8 + k] = (float)u[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *direct, int32_t direct_cout_pad,
+                                float *winograd, int32_t winograd_cout_pad, void *stream) {
+  if (!w || cout <= 0 || cin <= 0 || (!direct && !winograd)) return PCP_ERR_ARG;
+  const int O = transpose ? cin : cout, I = transpose ? cout : cin;
+  if (direct && ((I & 15) || direct_cout_pad < O)) return PCP_ERR_ARG;
+  if (winograd && ((I & 7) || winograd_cout_pad < O)) return PCP_ERR_ARG;
+  PackParams p{w, cout, cin, transpose, direct, direct_cout_pad, winograd, winograd_cout_pad};
+  long long n = 0;
+  if (direct) n = (long long)(I / 16) * 9 * direct_cout_pad * 16;
+  if (winograd) { const long long m = (long long)(I / 8) * winograd_cout_pad * 8; if (m > n) n = m; }
+  hipLaunchKernelGGL(k_pack3x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

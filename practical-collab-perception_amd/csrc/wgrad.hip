@@ -98,21 +98,31 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad3x3(Wg3Params p) {
     }
 }
 
-// dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci]
-__global__ void k_wgrad3x3_reduce(const float *__restrict__ part, int nsplit, int cout, int cin, int cout_r, int cin_r,
-                                  float *__restrict__ dw, int accumulate) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci].  Block = 64 consecutive outputs x 4 split lanes (coalesced 256-B reads per
+// split, four independent load streams), combined in a fixed order.
+__global__ __launch_bounds__(256) void k_wgrad3x3_reduce(const float *__restrict__ part, int nsplit, int cout, int cin, int cout_r, int cin_r,
+                                                        float *__restrict__ dw, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long t = (long long)blockIdx.x * 64 + lane;
   const long long total = (long long)9 * cout * cin;
-  if (t >= total) return;
-  const int ci = (int)(t % cin);
-  const int co = (int)((t / cin) % cout);
-  const int tap = (int)(t / ((long long)cin * cout));
-  const long long stride = (long long)9 * cout_r * cin_r;
-  const float *src = part + ((long long)tap * cout_r + co) * cin_r + ci;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += src[k * stride];
-  float *d = dw + ((long long)co * cin + ci) * 9 + tap;
-  *d = accumulate ? *d + s : s;
+  int ci = 0, co = 0, tap = 0;
+  if (t < total) {
+    ci = (int)(t % cin);
+    co = (int)((t / cin) % cout);
+    tap = (int)(t / ((long long)cin * cout));
+    const long long stride = (long long)9 * cout_r * cin_r;
+    const float *src = part + ((long long)tap * cout_r + co) * cin_r + ci;
+    for (int k = sl; k < nsplit; k += 4) s += src[k * stride];
+  }
+  red[sl][lane] = s;
+  __syncthreads();
+  if (sl == 0 && t < total) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float *d = dw + ((long long)co * cin + ci) * 9 + tap;
+    *d = accumulate ? *d + v : v;
+  }
 }
 
 // ---- pointwise family -------------------------------------------------------------------------------------------------------
@@ -182,17 +192,27 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_pw(WgPwParams p) {
   }
 }
 
-__global__ void k_wgrad_pw_reduce(const float *__restrict__ part, int nsplit, int n, int k, int n_r, int k_r, float *__restrict__ out,
-                                  int ld_out, int accumulate) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * k) return;
-  const int kk = (int)(t % k), nn = (int)(t / k);
-  const float *src = part + (long long)nn * k_r + kk;
-  const long long stride = (long long)n_r * k_r;
+__global__ __launch_bounds__(256) void k_wgrad_pw_reduce(const float *__restrict__ part, int nsplit, int n, int k, int n_r, int k_r,
+                                                        float *__restrict__ out, int ld_out, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long t = (long long)blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int i = 0; i < nsplit; ++i) s += src[i * stride];
-  float *d = out + (long long)nn * ld_out + kk;
-  *d = accumulate ? *d + s : s;
+  int kk = 0, nn = 0;
+  if (t < (long long)n * k) {
+    kk = (int)(t % k);
+    nn = (int)(t / k);
+    const float *src = part + (long long)nn * k_r + kk;
+    const long long stride = (long long)n_r * k_r;
+    for (int i = sl; i < nsplit; i += 4) s += src[i * stride];
+  }
+  red[sl][lane] = s;
+  __syncthreads();
+  if (sl == 0 && t < (long long)n * k) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float *d = out + (long long)nn * ld_out + kk;
+    *d = accumulate ? *d + v : v;
+  }
 }
 
 inline int round64(int v) { return (v + 63) / 64 * 64; }
@@ -211,6 +231,7 @@ inline Wg3Plan plan3(const pcp_conv3x3_t *d) {
   pl.cin_r = round64(d->cin);
   const int pairs = (pl.cout_r / 64) * (pl.cin_r / 64);
   int ns = (512 + pairs - 1) / pairs;
+  if (ns > 256) ns = 256;
   if (ns > pl.n_tiles) ns = pl.n_tiles;
   if (ns < 1) ns = 1;
   pl.nsplit = ns;
@@ -221,6 +242,7 @@ inline int pw_split(long long rows, int n_r, int k_r, int *chunks) {
   const int ch = (int)((rows + PW_ROWS - 1) / PW_ROWS);
   const int pairs = (n_r / 64) * (k_r / 64);
   int ns = (512 + pairs - 1) / pairs;
+  if (ns > 256) ns = 256;
   if (ns > ch) ns = ch;
   if (ns < 1) ns = 1;
   *chunks = ch;
@@ -262,7 +284,7 @@ int pcp_conv3x3_wgrad(const pcp_conv3x3_t *d, const float *x, const float *dy, v
     hipLaunchKernelGGL((k_wgrad3x3<2, 4, 8>), grid, dim3(WG_THREADS), 0, s, p);
   }
   const long long total = (long long)9 * d->cout * d->cin;
-  hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)workspace, pl.nsplit,
+  hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float *)workspace, pl.nsplit,
                      d->cout, d->cin, pl.cout_r, pl.cin_r, dw, accumulate);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
@@ -298,7 +320,7 @@ int pcp_pointwise_wgrad(const pcp_rowmap_t *a, const pcp_rowmap_t *b, int64_t ro
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_wgrad_pw, dim3((p.n_r / 64) * p.k_tiles, p.nsplit), dim3(WG_THREADS), 0, s, p);
   const long long total = (long long)a->channels * b->channels;
-  hipLaunchKernelGGL(k_wgrad_pw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)workspace, p.nsplit,
+  hipLaunchKernelGGL(k_wgrad_pw_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float *)workspace, p.nsplit,
                      a->channels, b->channels, p.n_r, p.k_r, out, ld_out, accumulate);
   PCP_CHECK_LAUNCH();
   return PCP_OK;

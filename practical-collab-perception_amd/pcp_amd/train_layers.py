@@ -75,48 +75,71 @@ class ConvBNAct:
         if self.kind is None:
             raise NotImplementedError('%s: conv k=%d s=%d has no training kernel' % (name, k, s))
         self.stride = s if self.kind == '3x3' else 1
-        self._packed_step = -1
         self._fw = self._bw = None
         self.saved = None
         self.vec = None
 
     # ---- weight forms ----------------------------------------------------------------------------------------------------
-    def _zero_bias(self, n, dev):
-        return _zeros_like_cache(_ZERO_BIAS, (dev, 'z'), max(n, 1024), dev)
-
+    # cached ON THE CONV MODULE (several layer instances may share one module: the weightor runs once per agent) and rebuilt
+    # once per optimizer step; 3x3 layouts are written by pcp_pack_conv3x3 into persistent buffers (one launch per direction)
     def _repack(self):
-        if self._packed_step == StepClock.step:
+        cache = getattr(self.conv, '_pcp_train_pack', None)
+        if cache is None:
+            cache = self.conv._pcp_train_pack = dict(step=-1)
+        if cache['step'] == StepClock.step:
+            self._fw, self._bw = cache['fw'], cache['bw']
             return
         w = self.conv.weight.detach()
         dev = w.device
+        zeros = _zeros_like_cache(_ZERO_BIAS, dev, 2048, dev)
         b = self.conv.bias.detach() if self.conv.bias is not None else None
-        zb = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
-        fb = lambda n: (b if b is not None else zb(n))
         k = self.kind
+
+        def bias_for(n_pad, n):
+            if b is None:
+                return zeros
+            return b if n_pad == n else pack.pad_bias(b, n_pad)
         if k == '3x3':
-            fw = dict(direct=pack.pack_conv3x3(w, fb(self.cout)))
-            if self.stride == 1 and self.cin % pack.WINO_CK == 0 and self.cout >= 48:
-                fw['wino'] = pack.pack_conv3x3_winograd(w, fb(self.cout))
-            wt = w.flip(2, 3).transpose(0, 1).contiguous()             # (cin, cout, 3, 3): conv weight of the data gradient
-            bw = dict(direct=pack.pack_conv3x3(wt, zb(self.cin)))
-            if self.cout % pack.WINO_CK == 0 and self.cin >= 48:
-                bw['wino'] = pack.pack_conv3x3_winograd(wt, zb(self.cin))
-        elif k == 'plain':
-            m = w.reshape(self.cout, self.cin)
-            fw = pack.pack_plain(m, fb(self.cout))
-            bw = pack.pack_plain(m.t().contiguous(), zb(self.cin))
-        elif k == 'plainT':
-            m = w.reshape(self.cin, self.cout)
-            fw = pack.pack_plain(m.t().contiguous(), fb(self.cout))
-            bw = pack.pack_plain(m.contiguous(), zb(self.cin))
-        elif k == 's2d':
-            fw = pack.pack_conv2x2_s2(w, fb(self.cout))
-            bw = pack.pack_convT2x2_s2(w, zb(self.cin))                 # (cout, cin, 2, 2) read as a ConvTranspose2d weight
-        else:  # d2s
-            fw = pack.pack_convT2x2_s2(w, fb(self.cout))
-            bw = pack.pack_conv2x2_s2(w, zb(self.cin))                  # (cin, cout, 2, 2) read as a Conv2d weight
+            if 'buf' not in cache:
+                rp = lambda o: pack.round_up(o, 64 if o > 32 else 32)
+                bufs = dict(fw_d=torch.empty((self.cin // 16, 9, rp(self.cout), 16), dtype=torch.float32, device=dev),
+                            bw_d=torch.empty((self.cout // 16, 9, rp(self.cin), 16), dtype=torch.float32, device=dev))
+                if self.stride == 1 and self.cin % pack.WINO_CK == 0 and self.cout >= 48:
+                    bufs['fw_w'] = torch.empty((self.cin // 8, 16, pack.round_up(self.cout, 64), 8), dtype=torch.float32, device=dev)
+                if self.cout % pack.WINO_CK == 0 and self.cin >= 48:
+                    bufs['bw_w'] = torch.empty((self.cout // 8, 16, pack.round_up(self.cin, 64), 8), dtype=torch.float32, device=dev)
+                cache['buf'] = bufs
+            bufs = cache['buf']
+            wc = w.contiguous()
+            fo, bo = bufs['fw_d'].shape[2], bufs['bw_d'].shape[2]
+            fww, bww = bufs.get('fw_w'), bufs.get('bw_w')
+            tops.pack_conv3x3(wc, False, bufs['fw_d'], fo, fww, fww.shape[2] if fww is not None else 0)
+            tops.pack_conv3x3(wc, True, bufs['bw_d'], bo, bww, bww.shape[2] if bww is not None else 0)
+            fw = dict(direct=(bufs['fw_d'], bias_for(fo, self.cout), fo))
+            if fww is not None:
+                fw['wino'] = (fww, bias_for(fww.shape[2], self.cout), fww.shape[2])
+            bw = dict(direct=(bufs['bw_d'], zeros, bo))
+            if bww is not None:
+                bw['wino'] = (bww, zeros, bww.shape[2])
+        else:
+            zb = lambda n: zeros[:n]
+            fb = lambda n: (b if b is not None else zeros[:n])
+            if k == 'plain':
+                m = w.reshape(self.cout, self.cin)
+                fw = pack.pack_plain(m, fb(self.cout))
+                bw = pack.pack_plain(m.t().contiguous(), zb(self.cin))
+            elif k == 'plainT':
+                m = w.reshape(self.cin, self.cout)
+                fw = pack.pack_plain(m.t().contiguous(), fb(self.cout))
+                bw = pack.pack_plain(m.contiguous(), zb(self.cin))
+            elif k == 's2d':
+                fw = pack.pack_conv2x2_s2(w, fb(self.cout))
+                bw = pack.pack_convT2x2_s2(w, zb(self.cin))             # (cout, cin, 2, 2) read as a ConvTranspose2d weight
+            else:  # d2s
+                fw = pack.pack_convT2x2_s2(w, fb(self.cout))
+                bw = pack.pack_conv2x2_s2(w, zb(self.cin))              # (cin, cout, 2, 2) read as a Conv2d weight
+        cache['fw'], cache['bw'], cache['step'] = fw, bw, StepClock.step
         self._fw, self._bw = fw, bw
-        self._packed_step = StepClock.step
 
     # ---- launches --------------------------------------------------------------------------------------------------------
     @staticmethod
