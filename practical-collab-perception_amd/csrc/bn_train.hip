@@ -8,13 +8,14 @@
 //
 // All of it is HBM-bound streaming: one read for the statistics, one read + one write for the normalisation; backward is one
 // read of (dout, x) for the two per-channel sums and one read + write for dx.  Per-channel sums are accumulated in float64
-// (per-thread partials, LDS tree, one f64 atomic per block and channel): the result does not depend on the summation order at
-// fp32 resolution, so training stays reproducible without a second pass.
+// (per-thread partials, LDS tree, one partial per block and channel in the workspace, reduced in a fixed order by the finalize
+// kernel): bitwise reproducible, no atomics.
 #include "pcp_common.h"
 
 namespace {
 
 constexpr int RED_THREADS = 256;
+constexpr int RED_MAX_BLOCKS = 1024;
 
 enum { RED_STATS = 0, RED_BNBWD = 1, RED_COLSUM = 2 };
 
@@ -45,8 +46,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
       mu = *reinterpret_cast<const float4 *>(p.mean + g * 4);
       is = *reinterpret_cast<const float4 *>(p.invstd + g * 4);
     }
-    for (long long r = (long long)blockIdx.x * rpb + slot; r < p.rows; r += (long long)gridDim.x * rpb) {
-      const float4 v = *reinterpret_cast<const float4 *>(p.x + r * p.ld_x + g * 4);
+    // four rows per trip: the loads are issued back to back (independent), so a thread keeps 64-128 B in flight -- with one row per
+    // trip the kernel was latency bound at ~1 TB/s
+    const long long step = (long long)gridDim.x * rpb;
+    auto accum = [&](const float4 &v, const float4 &d) {
       const float xv[4] = {v.x, v.y, v.z, v.w};
       if (MODE == RED_STATS) {
 #pragma unroll
@@ -55,7 +58,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) s0[i] += (double)xv[i];
       } else {
-        const float4 d = *reinterpret_cast<const float4 *>(p.dout + r * p.ld_d + g * 4);
         const float dv[4] = {d.x, d.y, d.z, d.w};
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
         const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
@@ -68,6 +70,22 @@ __global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
           s1[i] += (double)dz * (double)xh;
         }
       }
+    };
+    long long r = (long long)blockIdx.x * rpb + slot;
+    for (; r + 3 * step < p.rows; r += 4 * step) {
+      float4 v[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const float4 *>(p.x + (r + u * step) * p.ld_x + g * 4);
+        d[u] = MODE == RED_BNBWD ? *reinterpret_cast<const float4 *>(p.dout + (r + u * step) * p.ld_d + g * 4) : v[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(v[u], d[u]);
+    }
+    for (; r < p.rows; r += step) {
+      const float4 v = *reinterpret_cast<const float4 *>(p.x + r * p.ld_x + g * 4);
+      const float4 d = MODE == RED_BNBWD ? *reinterpret_cast<const float4 *>(p.dout + r * p.ld_d + g * 4) : v;
+      accum(v, d);
     }
   }
 #pragma unroll
@@ -78,20 +96,47 @@ __global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
     for (int i = 0; i < 4; ++i) {
       double a = 0, b = 0;
       for (int s = 0; s < rpb; ++s) { a += red[0][s * cg + g][i]; b += red[1][s * cg + g][i]; }
-      atomicAdd(p.acc + g * 4 + i, a);
-      if (MODE != RED_COLSUM) atomicAdd(p.acc + p.c + g * 4 + i, b);
+      // block partial (no atomics: 1024 f64 atomics per address serialise at L2 for ~40 us; the finalize kernels reduce the
+      // partials in a fixed order, which also makes the sums bitwise reproducible)
+      double *part = p.acc + (long long)blockIdx.x * 2 * p.c;
+      part[g * 4 + i] = a;
+      part[p.c + g * 4 + i] = b;
     }
   }
 }
 
-__global__ void k_bn_finalize(const double *acc, long long rows, int c, const float *gamma, const float *beta, float eps,
-                              float momentum, float *running_mean, float *running_var, float *scale, float *shift,
-                              float *mean, float *invstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
+constexpr int FIN_PARTS = 64;     // threads cooperating on one channel
+constexpr int FIN_CH = 4;         // channels per block
+
+// sum over the nb block partials of channel ch: returns (sum0, sum1) on the thread with part == 0
+__device__ __forceinline__ void reduce_partials(const double *acc, int nb, int c, int ch, int part, int lc, double &o0, double &o1) {
+  __shared__ double sh[2][FIN_CH][FIN_PARTS];
+  double a = 0, b = 0;
+  if (ch < c)
+    for (int blk = part; blk < nb; blk += FIN_PARTS) {
+      a += acc[(long long)blk * 2 * c + ch];
+      b += acc[(long long)blk * 2 * c + c + ch];
+    }
+  sh[0][lc][part] = a;
+  sh[1][lc][part] = b;
+  __syncthreads();
+  o0 = o1 = 0;
+  if (part == 0)
+    for (int i = 0; i < FIN_PARTS; ++i) { o0 += sh[0][lc][i]; o1 += sh[1][lc][i]; }
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_bn_finalize(const double *acc, int nb, long long rows, int c, const float *gamma,
+                                                                  const float *beta, float eps, float momentum, float *running_mean,
+                                                                  float *running_var, float *scale, float *shift, float *mean,
+                                                                  float *invstd) {
+  const int lc = threadIdx.x / FIN_PARTS, part = threadIdx.x % FIN_PARTS;
+  const int i = blockIdx.x * FIN_CH + lc;
+  double s0, s1;
+  reduce_partials(acc, nb, c, i, part, lc, s0, s1);
+  if (part != 0 || i >= c) return;
   const double n = (double)rows;
-  const double m = acc[i] / n;
-  double var = acc[c + i] / n - m * m;
+  const double m = s0 / n;
+  double var = s1 / n - m * m;
   if (var < 0) var = 0;
   const double is = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[i] * is);
@@ -107,21 +152,27 @@ __global__ void k_bn_finalize(const double *acc, long long rows, int c, const fl
 }
 
 // dgamma = sum dz xhat, dbeta = sum dz; coef[0][c] = dbeta / n, coef[1][c] = dgamma / n for the apply pass
-__global__ void k_bnbwd_finalize(const double *acc, long long rows, int c, float *dgamma, float *dbeta, int accumulate,
-                                 float *coef) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
+__global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_bnbwd_finalize(const double *acc, int nb, long long rows, int c, float *dgamma,
+                                                                     float *dbeta, int accumulate, float *coef) {
+  const int lc = threadIdx.x / FIN_PARTS, part = threadIdx.x % FIN_PARTS;
+  const int i = blockIdx.x * FIN_CH + lc;
+  double s0, s1;
+  reduce_partials(acc, nb, c, i, part, lc, s0, s1);
+  if (part != 0 || i >= c) return;
   const double n = (double)rows;
-  const float db = (float)acc[i], dg = (float)acc[c + i];
+  const float db = (float)s0, dg = (float)s1;
   if (accumulate) { dbeta[i] += db; dgamma[i] += dg; } else { dbeta[i] = db; dgamma[i] = dg; }
-  coef[i] = (float)(acc[i] / n);
-  coef[c + i] = (float)(acc[c + i] / n);
+  coef[i] = (float)(s0 / n);
+  coef[c + i] = (float)(s1 / n);
 }
 
-__global__ void k_colsum_finalize(const double *acc, int c, float *out, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
-  if (accumulate) out[i] += (float)acc[i]; else out[i] = (float)acc[i];
+__global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_colsum_finalize(const double *acc, int nb, int c, float *out, int accumulate) {
+  const int lc = threadIdx.x / FIN_PARTS, part = threadIdx.x % FIN_PARTS;
+  const int i = blockIdx.x * FIN_CH + lc;
+  double s0, s1;
+  reduce_partials(acc, nb, c, i, part, lc, s0, s1);
+  if (part != 0 || i >= c) return;
+  if (accumulate) out[i] += (float)s0; else out[i] = (float)s0;
 }
 
 __global__ void k_scale_shift_act(const float *__restrict__ x, long long rows, int cg, int ld_x, const float *__restrict__ scale,
@@ -198,7 +249,7 @@ inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 inline int red_grid(long long rows, int c) {
   const int rpb = RED_THREADS / (c >> 2);
   long long blocks = (rows + (long long)rpb * 8 - 1) / ((long long)rpb * 8);
-  if (blocks > 512) blocks = 512;
+  if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -207,7 +258,7 @@ inline int red_grid(long long rows, int c) {
 
 extern "C" {
 
-size_t pcp_bn_workspace_bytes(int32_t c) { return (size_t)c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float); }
+size_t pcp_bn_workspace_bytes(int32_t c) { return (size_t)RED_MAX_BLOCKS * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float); }
 
 int pcp_bn_train_stats(const float *x, int64_t rows, int32_t c, int32_t ld, const float *gamma, const float *beta, float eps,
                        float momentum, float *running_mean, float *running_var, void *workspace, float *scale, float *shift,
@@ -217,12 +268,12 @@ int pcp_bn_train_stats(const float *x, int64_t rows, int32_t c, int32_t ld, cons
   if ((running_mean == nullptr) != (running_var == nullptr)) return PCP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   double *acc = (double *)workspace;
-  if (pcp_zero_async(acc, (size_t)c * 2 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
   RedParams p{};
   p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
-  hipLaunchKernelGGL(k_col_reduce<RED_STATS>, dim3(red_grid(rows, c)), dim3(RED_THREADS), 0, s, p);
-  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 127) / 128), dim3(128), 0, s, acc, (long long)rows, c, gamma, beta, eps, momentum,
-                     running_mean, running_var, scale, shift, mean, invstd);
+  const int nb = red_grid(rows, c);
+  hipLaunchKernelGGL(k_col_reduce<RED_STATS>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, (long long)rows, c, gamma, beta,
+                     eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
@@ -246,13 +297,14 @@ int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int3
     return PCP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   double *acc = (double *)workspace;
-  float *coef = (float *)(acc + 2 * (size_t)c);
-  if (pcp_zero_async(acc, (size_t)c * 2 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  float *coef = (float *)(acc + 2 * (size_t)c * RED_MAX_BLOCKS);
   RedParams p{};
   p.x = x; p.dout = dout; p.rows = rows; p.c = c; p.ld_x = ld_x; p.ld_d = ld_dout;
   p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.relu = relu; p.acc = acc;
-  hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(red_grid(rows, c)), dim3(RED_THREADS), 0, s, p);
-  hipLaunchKernelGGL(k_bnbwd_finalize, dim3((c + 127) / 128), dim3(128), 0, s, acc, (long long)rows, c, dgamma, dbeta, accumulate, coef);
+  const int nb = red_grid(rows, c);
+  hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_bnbwd_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, (long long)rows, c, dgamma,
+                     dbeta, accumulate, coef);
   const long long total = (long long)rows * (c >> 2);
   hipLaunchKernelGGL(k_bnbwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, ld_dout, x, ld_x, (long long)rows,
                      c >> 2, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx);
@@ -264,11 +316,11 @@ int pcp_colsum(const float *x, int64_t rows, int32_t c, int32_t ld, void *worksp
   if (!x || !workspace || !out || !red_shape_ok(rows, c, ld) || !al16(x)) return PCP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   double *acc = (double *)workspace;
-  if (pcp_zero_async(acc, (size_t)c * 2 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
   RedParams p{};
   p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
-  hipLaunchKernelGGL(k_col_reduce<RED_COLSUM>, dim3(red_grid(rows, c)), dim3(RED_THREADS), 0, s, p);
-  hipLaunchKernelGGL(k_colsum_finalize, dim3((c + 127) / 128), dim3(128), 0, s, acc, c, out, accumulate);
+  const int nb = red_grid(rows, c);
+  hipLaunchKernelGGL(k_col_reduce<RED_COLSUM>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_colsum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, out, accumulate);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

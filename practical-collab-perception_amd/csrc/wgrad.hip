@@ -72,19 +72,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad3x3(Wg3Params p) {
       *reinterpret_cast<float4 *>(xP + pp * TILE_C + q * 4) = v;
     }
     __syncthreads();
-#pragma unroll 2
-    for (int kk = 0; kk < NPIX / 2; ++kk) {
-      const int pix = 2 * kk + hl;
-      const int py = pix / TW, px = pix % TW;
-      const float a = dyT[pix * TILE_C + wco + l32];
-      const float *xb = xP + ((py * S) * PW + px * S) * TILE_C + wci + l32;
+    // one tile row per trip, the TW/2 pixel pairs fully unrolled: every LDS address is a loop-invariant base + an immediate, so the
+    // body is ds_read_b32 + MFMA only (fp32 MFMA and VALU do not overlap on a gfx950 SIMD: address arithmetic is lost matrix time)
+    for (int py = 0; py < TH; ++py) {
+      const float *ab = dyT + (py * TW + hl) * TILE_C + wco + l32;
+      const float *xb = xP + ((py * S) * PW + hl * S) * TILE_C + wci + l32;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int pp = 0; pp < TW / 2; ++pp) {
+        const float a = ab[2 * pp * TILE_C];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float bv = xb[(ky * PW + kx) * TILE_C];
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * 3 + kx], 0, 0, 0);
-        }
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float bv = xb[(ky * PW + kx + 2 * pp * S) * TILE_C];
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * 3 + kx], 0, 0, 0);
+          }
+      }
     }
   }
   // partial tile -> workspace [split][tap][co][ci]
@@ -230,7 +233,7 @@ inline Wg3Plan plan3(const pcp_conv3x3_t *d) {
   pl.cout_r = round64(d->cout);
   pl.cin_r = round64(d->cin);
   const int pairs = (pl.cout_r / 64) * (pl.cin_r / 64);
-  int ns = (512 + pairs - 1) / pairs;
+  int ns = 512 / pairs;          // <= 512 blocks: one full wave of 2 workgroups per CU, no second partial wave
   if (ns > 256) ns = 256;
   if (ns > pl.n_tiles) ns = pl.n_tiles;
   if (ns < 1) ns = 1;
@@ -241,7 +244,7 @@ inline Wg3Plan plan3(const pcp_conv3x3_t *d) {
 inline int pw_split(long long rows, int n_r, int k_r, int *chunks) {
   const int ch = (int)((rows + PW_ROWS - 1) / PW_ROWS);
   const int pairs = (n_r / 64) * (k_r / 64);
-  int ns = (512 + pairs - 1) / pairs;
+  int ns = 512 / pairs;
   if (ns > 256) ns = 256;
   if (ns > ch) ns = ch;
   if (ns < 1) ns = 1;
