@@ -207,3 +207,224 @@ def test_conv_bn_act_layer_forward_backward(kind, cin, cout, bias, with_bn, relu
             # a conv bias in front of a BatchNorm has an analytically zero gradient: both sides hold rounding noise there
             floor = 1.0 if (k == 'dbias' and with_bn) else 1e-6
             _close(mine, ref, 3e-4, '%s/%s/%s' % (kind, algo, k), floor=floor)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a15: targets, losses
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _head_arch(ncls=1, K=500, H=32, W=32):
+    return dict(pc_range=[-12.8, -12.8, -8.0, 12.8, 12.8, 0.0], voxel_size=[0.2, 0.2, 8.0],
+                head=dict(heads=[('center', 2), ('center_z', 1), ('dim', 3), ('rot', 2), ('hm', ncls)], stride=4, num_max_objs=K,
+                          gaussian_overlap=0.1, min_radius=2, cls_weight=1.0, loc_weight=0.25, code_weights=[1.0, 1.0, 1.0, 1.0, 2.0, 1.0, 0.5, 1.0]))
+
+
+def _rand_gt(seed, B, M, ncls, n_valid):
+    gt = np.zeros((B, M, 8), dtype=np.float32)
+    for b in range(B):
+        n = n_valid[b]
+        s = 8100 + 10 * seed + b
+        rows = np.sort(np.argsort(synth.uniform01(s, 0, M))[:n])            # valid rows interleaved with padding rows
+        gt[b, rows, 0] = synth.uniform(s, 1, n, -14.0, 14.0)                 # some centres outside the range (clamped)
+        gt[b, rows, 1] = synth.uniform(s, 2, n, -14.0, 14.0)
+        gt[b, rows, 2] = synth.uniform(s, 3, n, -3.0, -1.0)
+        gt[b, rows, 3] = synth.uniform(s, 4, n, 0.5, 9.0)
+        gt[b, rows, 4] = synth.uniform(s, 5, n, 0.5, 4.0)
+        gt[b, rows, 5] = synth.uniform(s, 6, n, 1.0, 3.0)
+        gt[b, rows, 6] = synth.uniform(s, 7, n, -3.14159, 3.14159)
+        gt[b, rows, 7] = np.floor(synth.uniform(s, 8, n, 1.0, ncls + 0.999))
+        if n > 3:
+            gt[b, rows[1], 3] = 0.0                                          # degenerate box: skipped (center_head.py:143)
+            gt[b, rows[2], 0:2] = gt[b, rows[0], 0:2]                        # two boxes in one cell
+    return gt
+
+
+def _target_desc(arch, B, H, W, ncls):
+    from pcp_amd import lib
+    hd = arch['head']
+    return lib.Target(B, H, W, ncls, hd['num_max_objs'], float(hd['stride']), 0.2, 0.2, -12.8, -12.8, hd['gaussian_overlap'], hd['min_radius'])
+
+
+@pytest.mark.parametrize('ncls,K,M,n_valid', [(1, 500, 40, [25, 0, 40]), (3, 500, 64, [64, 10, 33]), (1, 8, 30, [30, 3, 12]), (2, 500, 1, [1, 0, 1])])
+def test_centerhead_targets_match_oracle(ncls, K, M, n_valid):
+    from oracle import train as otr
+    from pcp_amd import train_ops as tops
+    H = W = 32
+    arch = _head_arch(ncls, K, H, W)
+    gt = _rand_gt(ncls * 7 + K, 3, M, ncls, n_valid)
+    heat, tb, inds, mask = otr.assign_targets(gt, arch, (H, W))
+    gh, gtb, ginds, gmask = tops.centerhead_targets(torch.from_numpy(gt).to(DEV), _target_desc(arch, 3, H, W, ncls))
+    assert np.array_equal(ginds.cpu().numpy(), inds) and np.array_equal(gmask.cpu().numpy(), mask)
+    np.testing.assert_allclose(gh.permute(0, 3, 1, 2).cpu().numpy(), heat, atol=1e-6)
+    assert np.array_equal(gh.permute(0, 3, 1, 2).cpu().numpy() == 1.0, heat == 1.0)       # the positives of the focal loss
+    np.testing.assert_allclose(gtb.cpu().numpy(), tb, atol=2e-6)
+
+
+@pytest.mark.parametrize('ncls,n_valid', [(1, [25, 0, 40]), (3, [30, 10, 33]), (1, [0, 0, 0])])
+def test_centerhead_loss_and_gradient_match_autograd(ncls, n_valid):
+    from oracle import train as otr
+    from pcp_amd import lib
+    from pcp_amd import train_ops as tops
+    H = W = 32
+    B = 3
+    arch = _head_arch(ncls, 500, H, W)
+    gt = _rand_gt(50 + ncls, B, 48, ncls, n_valid)
+    targets = otr.assign_targets(gt, arch, (H, W))
+    nch = 8 + ncls
+    ld = 16
+    maps_t = _u(60 + ncls, 1, (B, nch, H, W), -3.0, 3.0)
+    maps_t[:, 8:] -= 1.0
+    maps_t[0, 8, 0, 0] = 12.0                                   # sigmoid clamped from above: zero gradient
+    maps_t[0, 8, 0, 1] = -12.0                                  # ... and from below
+    maps_t.requires_grad_(True)
+    names = ['center', 'center_z', 'dim', 'rot', 'hm']
+    sizes = [2, 1, 3, 2, ncls]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    maps = {n: maps_t[:, offs[i]:offs[i + 1]] for i, n in enumerate(names)}
+    loss, hm_loss, loc_loss = otr.head_loss(maps, targets, arch)
+    loss.backward()
+    buf = torch.zeros((B, H, W, ld))
+    buf[..., :nch] = maps_t.detach().permute(0, 2, 3, 1)
+    buf = buf.to(DEV)
+    d = lib.HeadLoss()
+    d.batch, d.h, d.w, d.ld, d.ld_d, d.num_class, d.ch_hm, d.k = B, H, W, ld, ld, ncls, 8, 500
+    for j in range(8):
+        d.reg_ch[j] = j
+        d.code_weights[j] = arch['head']['code_weights'][j]
+    d.cls_weight, d.loc_weight = 1.0, 0.25
+    heat, tb, inds, mask = (torch.from_numpy(np.ascontiguousarray(t)).to(DEV) for t in targets)
+    dhead = torch.full((B, H, W, ld), 9.0, device=DEV)
+    losses = tops.centerhead_loss(buf, d, heat.permute(0, 2, 3, 1).contiguous(), tb, inds.int(), mask.int(), dhead=dhead)
+    lv = losses.cpu().numpy()
+    assert abs(lv[0] - float(hm_loss.detach())) <= 2e-5 * max(abs(float(hm_loss.detach())), 1e-3)
+    assert abs(lv[1] - float(loc_loss.detach())) <= 2e-5 * max(abs(float(loc_loss.detach())), 1e-3)
+    assert abs(lv[2] - float(loss.detach())) <= 2e-5 * max(abs(float(loss.detach())), 1e-3)
+    assert lv[3] == float((targets[0] == 1).sum())
+    g = dhead.cpu()
+    assert float(g[..., nch:].abs().max()) == 0.0
+    _close(g[..., :nch].permute(0, 3, 1, 2), maps_t.grad, 2e-4, 'dhead')
+
+
+def test_distill_loss_and_gradient():
+    from oracle import train as otr
+    from pcp_amd import train_ops as tops
+    f = _u(71, 1, (2, 384, 12, 10), -2, 2).requires_grad_(True)
+    e = _u(71, 2, (2, 384, 12, 10), -2, 2)
+    loss = otr.distill_loss(f, e)
+    loss.backward()
+    fg, eg = _nhwc(f.detach()), _nhwc(e)
+    df = torch.zeros_like(fg)
+    lv = tops.distill_loss(fg, eg, 384, dfused=df)
+    assert abs(float(lv) - float(loss.detach())) <= 1e-5 * float(loss.detach())
+    _close(_nchw(df), f.grad, 2e-4, 'dfused')
+    lv2 = tops.distill_loss(fg, eg, 384, dfused=df, accumulate=True)
+    _close(_nchw(df), 2 * f.grad, 2e-4, 'dfused accumulate')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PFN (train mode) through the module-level driver
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_vfe_train_forward_backward_matches_autograd():
+    from helpers import arch_of, load_golden
+    from oracle import pillars as opil
+    from oracle import train as otr
+    from pcdet.models import build_network_from_meta
+    from pcdet.models.train_path import VFETrain
+    from pcp_amd import train_layers as tl
+    g = load_golden('g7_train.npz')
+    meta = g['meta']
+    arch = arch_of(meta)
+    model = build_network_from_meta(meta)
+    stf = synth.fill_state_dict(meta['state_shapes'])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in stf.items()})
+    vfe = model.vfe.to(DEV).train()
+    tl.StepClock.tick()
+    pts = g['points']
+    bd = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 2}
+    drv = VFETrain(vfe)
+    bd = drv.forward(bd)
+    # oracle
+    st = otr.make_state(stf)
+    vox = opil.voxelize(pts, arch['num_raw'], arch['pc_range'], arch['voxel_size'], arch['grid_size'])
+    feats, _ = opil.point_features(pts, arch['num_raw'], vox, arch['pc_range'], arch['voxel_size'])
+    P = vox['unq'].shape[0]
+    pf = otr.pfn_train(torch.from_numpy(feats), torch.from_numpy(vox['inv']), P, st)
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy(), vox['coords'])
+    _close(bd['pillar_features'], pf, 2e-5, 'pillar_features (train-mode BN)')
+    for li in range(2):
+        for k in ('running_mean', 'running_var'):
+            _close(getattr(vfe.pfn_layers[li].norm, k), st['vfe.pfn_layers.%d.norm.%s' % (li, k)], 1e-5, k)
+    nx, ny = arch['grid_size'][0], arch['grid_size'][1]
+    R = _u(81, 1, (2, ny, nx, 64))
+    co = torch.from_numpy(vox['coords'].astype(np.int64))
+    (pf * R[co[:, 0], co[:, 2], co[:, 3]]).sum().backward()
+    drv.backward(R.to(DEV))
+    for name, p in (('pfn_layers.0.linear.weight', vfe.pfn_layers[0].linear.weight), ('pfn_layers.0.norm.weight', vfe.pfn_layers[0].norm.weight),
+                    ('pfn_layers.0.norm.bias', vfe.pfn_layers[0].norm.bias), ('pfn_layers.1.linear.weight', vfe.pfn_layers[1].linear.weight),
+                    ('pfn_layers.1.norm.weight', vfe.pfn_layers[1].norm.weight), ('pfn_layers.1.norm.bias', vfe.pfn_layers[1].norm.bias)):
+        _close(p.grad, st['vfe.' + name].grad, 5e-4, name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DiscoNet fusion kernels, optimizer
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_disco_weight_logits_and_fuse_backward():
+    import torch.nn.functional as F
+    from pcp_amd import ops
+    from pcp_amd import train_ops as tops
+    A, B, H, W, C = 3, 2, 6, 10, 128
+    maps = [_u(91, a, (B, H, W, C)).requires_grad_(a == 0) for a in range(A)]
+    h2 = [_u(92, a, (B, H, W, 16), -0.5, 1.0).requires_grad_(True) for a in range(A)]
+    w4 = _u(93, 1, (16,), -0.5, 0.5).requires_grad_(True)
+    b4 = _u(93, 2, (1,), -0.1, 0.3).requires_grad_(True)
+    logits = torch.stack([F.relu(h @ w4 + b4) for h in h2], dim=-1)
+    wgt = torch.softmax(logits, dim=-1)
+    fused = sum(maps[a] * wgt[..., a:a + 1] for a in range(A))
+    dfused = _u(94, 1, (B, H, W, C))
+    fused.backward(dfused)
+    gm = [m.detach().to(DEV) for m in maps]
+    gh = [h.detach().to(DEV) for h in h2]
+    lg = torch.zeros((B, H, W, 8), device=DEV)
+    tops.disco_weight_logits(gh, w4.detach().to(DEV), b4.detach().to(DEV), lg)
+    _close(lg[..., :A], logits, 1e-5, 'logits')
+    out = torch.empty((B, H, W, C), device=DEV)
+    ops.softmax_fuse_raw([m.data_ptr() for m in gm], lg, C, C, out)
+    _close(out, fused, 1e-5, 'fused')
+    dmap0 = torch.empty((B, H, W, C), device=DEV)
+    dh2 = [torch.empty((B, H, W, 16), device=DEV) for _ in range(A)]
+    dw4, db4 = torch.zeros(16, device=DEV), torch.zeros(1, device=DEV)
+    tops.disco_fuse_backward([m.data_ptr() for m in gm], C, C, lg, dfused.to(DEV), gh, w4.detach().to(DEV), dmap0, dh2, dw4, db4)
+    _close(dmap0, maps[0].grad, 1e-5, 'dmap0')
+    for a in range(A):
+        _close(dh2[a], h2[a].grad, 1e-4, 'dh2[%d]' % a)
+    _close(dw4, w4.grad, 1e-4, 'dw4')
+    _close(db4, b4.grad, 1e-4, 'db4')
+
+
+def test_fused_adam_step_matches_torch_adam_with_clipping():
+    from pcp_amd import train_ops as tops
+    n = 100003
+    p0 = _u(95, 1, (n,), -0.5, 0.5)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=0.0, betas=(0.9, 0.99))
+    p = torch.zeros(n + 1, device=DEV)[:n]
+    p.copy_(p0)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sq = torch.zeros(1, dtype=torch.float64, device=DEV)
+    for step in range(1, 4):
+        g = _u(95, 10 + step, (n,), -1.0, 1.0) * (5.0 if step == 2 else 0.01)       # step 2 is clipped, the others are not
+        lr, mom, wd, max_norm = 1e-3 * step, 0.95 - 0.01 * step, 0.01, 10.0
+        ref.grad = g.clone()
+        norm = torch.nn.utils.clip_grad_norm_([ref], max_norm)
+        for grp in opt.param_groups:
+            grp['lr'], grp['betas'] = lr, (mom, 0.99)
+        with torch.no_grad():
+            ref.mul_(1 - wd * lr)
+        opt.step()
+        gg = g.to(DEV)
+        tops.grad_sqnorm(gg, out=sq)
+        assert abs(float(sq.sqrt()) - float(norm)) <= 1e-5 * float(norm)
+        tops.adam_step(p, gg, m, v, lr, mom, 0.99, 1e-8, wd, step, max_norm=max_norm, sqnorm=sq)
+        _close(p, ref, 2e-6, 'param after step %d' % step)
