@@ -50,7 +50,26 @@ class SyntheticV2XDataset(DatasetInfo, Dataset):
             parts.append(c)
         meta = {'sample_token': 'synthetic_%06d' % index, 'lidar_id': 1,
                 'se3_from_ego': {a: synth.agent_pose(a) for a in range(n_agents) if a != 1}}
-        return {'points': np.concatenate(parts, 0), 'frame_id': index, 'metadata': meta}
+        item = {'points': np.concatenate(parts, 0), 'frame_id': index, 'metadata': meta}
+        if self.training:
+            item['gt_boxes'] = self.synthetic_gt_boxes(index)
+        return item
+
+    def synthetic_gt_boxes(self, index, n_max=40):
+        """(n, 8) [x, y, z, dx, dy, dz, heading, class] car-sized boxes inside the range, n varies with the frame"""
+        n = n_max - (index % 7)
+        s = synth.SEED_BASE + 5000 + index
+        r = self.point_cloud_range
+        gt = np.zeros((n, 8), dtype=np.float32)
+        gt[:, 0] = synth.uniform(s, 1, n, float(r[0]) + 1.0, float(r[3]) - 1.0)
+        gt[:, 1] = synth.uniform(s, 2, n, float(r[1]) + 1.0, float(r[4]) - 1.0)
+        gt[:, 2] = synth.uniform(s, 3, n, -3.0, -1.0)
+        gt[:, 3] = synth.uniform(s, 4, n, 3.0, 5.5)
+        gt[:, 4] = synth.uniform(s, 5, n, 1.5, 2.5)
+        gt[:, 5] = synth.uniform(s, 6, n, 1.4, 2.0)
+        gt[:, 6] = synth.uniform(s, 7, n, -3.14159, 3.14159)
+        gt[:, 7] = np.floor(synth.uniform(s, 8, n, 1.0, len(self.class_names) + 0.999))
+        return gt
 
     @staticmethod
     def collate_batch(batch_list, _unused=False):
@@ -59,6 +78,13 @@ class SyntheticV2XDataset(DatasetInfo, Dataset):
         ret['points'] = synth.collate([b['points'] for b in batch_list])
         ret['frame_id'] = np.array([b['frame_id'] for b in batch_list])
         ret['metadata'] = [b['metadata'] for b in batch_list]
+        if 'gt_boxes' in batch_list[0]:
+            # zero-padded to the longest frame (pcdet/datasets/dataset.py:260-266)
+            m = max(b['gt_boxes'].shape[0] for b in batch_list)
+            gt = np.zeros((len(batch_list), m, batch_list[0]['gt_boxes'].shape[1]), dtype=np.float32)
+            for i, b in enumerate(batch_list):
+                gt[i, :b['gt_boxes'].shape[0]] = b['gt_boxes']
+            ret['gt_boxes'] = gt
         return ret
 
     def generate_prediction_dicts(self, batch_dict, pred_dicts, class_names, output_path=None):

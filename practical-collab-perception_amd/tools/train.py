@@ -1,0 +1,103 @@
+"""tools/train.py with the reference's command line (tools/train.py:24-60 of the reference):
+
+    python train.py --cfg_file cfgs/v2x_sim_models/v2x_pointpillar_disco.yaml [--batch_size 4] [--epochs 20] [--ckpt X.pth]
+                    [--launcher none|pytorch] [--set KEY VALUE ...]
+
+Config 5 (DiscoNet) is the configuration with training kernels.  Multi-GPU:
+`torchrun --nproc-per-node N train.py --launcher pytorch ...` -- one process per GPU, frames sharded by DistributedSampler, ONE
+RCCL all-reduce of the flat fp32 gradient buffer per iteration inside optimizer.step() (no DistributedDataParallel wrapper: the
+backward pass is hand written, there are no autograd hooks to bucket on).  Without V2X-Sim on disk the loader is the synthetic one.
+"""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE))
+
+from pcdet.config import cfg, cfg_from_list, cfg_from_yaml_file, log_config_to_file  # noqa: E402
+from pcdet.datasets import build_dataloader  # noqa: E402
+from pcdet.models import build_network, model_fn_decorator  # noqa: E402
+from pcdet.utils import common_utils  # noqa: E402
+from train_utils.optimization import build_optimizer, build_scheduler  # noqa: E402
+from train_utils.train_utils import train_model  # noqa: E402
+
+
+def parse_config():
+    p = argparse.ArgumentParser(description='arg parser')
+    p.add_argument('--cfg_file', type=str, required=True)
+    p.add_argument('--batch_size', type=int, default=None)
+    p.add_argument('--epochs', type=int, default=None)
+    p.add_argument('--workers', type=int, default=0)
+    p.add_argument('--extra_tag', type=str, default='default')
+    p.add_argument('--ckpt', type=str, default=None)
+    p.add_argument('--pretrained_model', type=str, default=None)
+    p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm'], default='none')
+    p.add_argument('--tcp_port', type=int, default=18888)
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--ckpt_save_interval', type=int, default=1)
+    p.add_argument('--max_ckpt_save_num', type=int, default=30)
+    p.add_argument('--output_dir', type=str, default=None)
+    p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
+    args = p.parse_args()
+    cfg_from_yaml_file(args.cfg_file, cfg)
+    cfg.TAG = Path(args.cfg_file).stem
+    if args.set_cfgs is not None:
+        cfg_from_list(args.set_cfgs, cfg)
+    return args, cfg
+
+
+def main():
+    args, cfg = parse_config()
+    dist_train = args.launcher != 'none'
+    if dist_train:
+        common_utils.init_dist_pytorch(args.tcp_port, int(os.environ.get('LOCAL_RANK', args.local_rank)), backend='nccl')
+    if args.batch_size is None:
+        args.batch_size = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU
+    args.epochs = cfg.OPTIMIZATION.NUM_EPOCHS if args.epochs is None else args.epochs
+    logger = common_utils.create_logger(None, rank=cfg.LOCAL_RANK)
+    log_config_to_file(cfg, logger=logger)
+    out_dir = Path(args.output_dir) if args.output_dir else None
+    ckpt_dir = None
+    if out_dir is not None:
+        ckpt_dir = out_dir / 'ckpt'
+        ckpt_dir.mkdir(parents=True, exist_ok=True)
+    train_set, train_loader, train_sampler = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, args.batch_size, dist_train,
+                                                              workers=args.workers, logger=logger, training=True, total_epochs=args.epochs)
+    for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
+        if cfg.MODEL.get(key, None) is not None and not os.path.isfile(str(cfg.MODEL[key].CKPT)):
+            logger.info('%s.CKPT %s not found: synthetic teacher weights' % (key, cfg.MODEL[key].CKPT))
+            cfg.MODEL[key].CKPT = None
+    model = build_network(model_cfg=cfg.MODEL, num_class=len(cfg.CLASS_NAMES), dataset=train_set)
+    start_epoch = it = 0
+    if args.pretrained_model is not None:
+        model.load_params_from_file(filename=args.pretrained_model, logger=logger, to_cpu=True)
+    elif args.ckpt is None:
+        from pcp_amd import synth
+        st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model.cuda()
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    if args.ckpt is not None:
+        disk = torch.load(args.ckpt, map_location='cpu', weights_only=False)
+        model.load_state_dict(disk['model_state'])
+        if disk.get('optimizer_state') is not None:
+            optimizer.load_state_dict(disk['optimizer_state'])
+        start_epoch, it = int(disk.get('epoch', 0)), int(disk.get('it', 0))
+    lr_scheduler, lr_warmup = build_scheduler(optimizer, total_iters_each_epoch=len(train_loader), total_epochs=args.epochs,
+                                              last_epoch=start_epoch - 1, optim_cfg=cfg.OPTIMIZATION)
+    logger.info('**********************Start training %s (%d trainable tensors, %.2f M parameters)**********************'
+                % (cfg.TAG, len(optimizer.params), sum(p.numel() for p in optimizer.params) / 1e6))
+    train_model(model, optimizer, train_loader, model_func=model_fn_decorator(), lr_scheduler=lr_scheduler, optim_cfg=cfg.OPTIMIZATION,
+                start_epoch=start_epoch, total_epochs=args.epochs, start_iter=it, rank=cfg.LOCAL_RANK, tb_log=None, ckpt_save_dir=ckpt_dir,
+                train_sampler=train_sampler, lr_warmup_scheduler=lr_warmup, ckpt_save_interval=args.ckpt_save_interval,
+                max_ckpt_save_num=args.max_ckpt_save_num, logger=logger)
+    logger.info('**********************End training**********************')
+
+
+if __name__ == '__main__':
+    main()

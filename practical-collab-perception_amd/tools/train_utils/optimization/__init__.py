@@ -22,6 +22,15 @@ def annealing_cos(start, end, pct):
     return end + (start - end) / 2 * (np.cos(np.pi * pct) + 1)
 
 
+def all_reduce_flat_gradient(flat_g, group=None):
+    """the ONE collective of a data-parallel training step: sum of the flat fp32 gradient over ranks (RCCL on GPUs, gloo in the CPU
+    tests); the 1 / world averaging of DistributedDataParallel is folded into the optimizer kernel's grad_scale"""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        torch.distributed.all_reduce(flat_g, group=group)
+        return 1.0 / torch.distributed.get_world_size(group)
+    return 1.0
+
+
 class FlatAdamOneCycle:
     """optimizer.zero_grad() / .step() / .lr / .mom like the reference's OptimWrapper; `clip_grad_norm(max_norm)` replaces
     torch.nn.utils.clip_grad_norm_ (it only records max_norm: the scaling happens inside the fused step)."""
@@ -69,14 +78,9 @@ class FlatAdamOneCycle:
         self.max_norm = float(max_norm)
         return self.sqnorm
 
-    def all_reduce_grads(self):
-        if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.process_group)       # RCCL, one bucket
-
     def step(self):
-        self.all_reduce_grads()
+        scale = all_reduce_flat_gradient(self.flat_g, self.process_group)   # RCCL, one bucket; DDP-style averaging via grad_scale
         self.t += 1
-        scale = 1.0 / self.world                                            # DDP averages gradients
         if self.max_norm is not None:
             tops.grad_sqnorm(self.flat_g, out=self.sqnorm)
         tops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.mom, self.beta2, self.eps, self.wd, self.t,

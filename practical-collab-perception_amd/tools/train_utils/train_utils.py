@@ -1,0 +1,86 @@
+"""train_one_epoch / train_model / checkpointing with the reference's signatures (tools/train_utils/train_utils.py:11-190).
+The iteration body is the reference's (:39-58): lr_scheduler.step(it); model.train(); optimizer.zero_grad(); forward;
+loss.backward(); clip; optimizer.step() -- with clipping folded into the fused optimizer step (optimizer.clip_grad_norm records
+the threshold, the scaling happens inside pcp_adam_step from a device-resident norm, no host sync)."""
+import glob
+import os
+import time
+
+import torch
+
+
+def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, tbar=None,
+                    total_it_each_epoch=None, dataloader_iter=None, tb_log=None, leave_pbar=False, logger=None, log_every=10):
+    if total_it_each_epoch is None:
+        total_it_each_epoch = len(train_loader)
+    if dataloader_iter is None:
+        dataloader_iter = iter(train_loader)
+    t0 = time.time()
+    disp = {}
+    for cur_it in range(total_it_each_epoch):
+        try:
+            batch = next(dataloader_iter)
+        except StopIteration:
+            dataloader_iter = iter(train_loader)
+            batch = next(dataloader_iter)
+        lr_scheduler.step(accumulated_iter)
+        cur_lr = float(optimizer.lr)
+        if tb_log is not None:
+            tb_log.add_scalar('meta_data/learning_rate', cur_lr, accumulated_iter)
+        model.train()
+        optimizer.zero_grad()
+        loss, tb_dict, disp_dict = model_func(model, batch)
+        loss.backward()
+        optimizer.clip_grad_norm(optim_cfg.GRAD_NORM_CLIP)
+        optimizer.step()
+        accumulated_iter += 1
+        disp = {'loss': tb_dict.get('loss_total', float('nan')), 'lr': cur_lr}
+        if tb_log is not None:
+            tb_log.add_scalar('train/loss', disp['loss'], accumulated_iter)
+            for key, val in tb_dict.items():
+                tb_log.add_scalar('train/' + key, val, accumulated_iter)
+        if rank == 0 and logger is not None and (cur_it % log_every == 0 or cur_it == total_it_each_epoch - 1):
+            logger.info('iter %d/%d  loss %.4f  lr %.3e  %.2f it/s' % (cur_it + 1, total_it_each_epoch, disp['loss'], cur_lr,
+                                                                       (cur_it + 1) / max(time.time() - t0, 1e-9)))
+    return accumulated_iter
+
+
+def model_state_to_cpu(model_state):
+    return type(model_state)((k, v.cpu()) for k, v in model_state.items())
+
+
+def checkpoint_state(model=None, optimizer=None, epoch=None, it=None):
+    """{'epoch', 'it', 'model_state', 'optimizer_state', 'version'} (reference :165-183)"""
+    optim_state = optimizer.state_dict() if optimizer is not None else None
+    if optim_state is not None:
+        optim_state = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optim_state.items()}
+    model_state = None
+    if model is not None:
+        m = model.module if hasattr(model, 'module') else model
+        model_state = model_state_to_cpu(m.state_dict())
+    return {'epoch': epoch, 'it': it, 'model_state': model_state, 'optimizer_state': optim_state, 'version': 'pcdet+pcp_amd'}
+
+
+def save_checkpoint(state, filename='checkpoint'):
+    torch.save(state, '%s.pth' % filename)
+
+
+def train_model(model, optimizer, train_loader, model_func, lr_scheduler, optim_cfg, start_epoch, total_epochs, start_iter, rank,
+                tb_log, ckpt_save_dir, train_sampler=None, lr_warmup_scheduler=None, ckpt_save_interval=1, max_ckpt_save_num=50,
+                merge_all_iters_to_one_epoch=False, logger=None):
+    accumulated_iter = start_iter
+    total_it_each_epoch = len(train_loader)
+    for cur_epoch in range(start_epoch, total_epochs):
+        if train_sampler is not None:
+            train_sampler.set_epoch(cur_epoch)
+        accumulated_iter = train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler=lr_scheduler,
+                                           accumulated_iter=accumulated_iter, optim_cfg=optim_cfg, rank=rank, tb_log=tb_log,
+                                           total_it_each_epoch=total_it_each_epoch, logger=logger)
+        trained_epoch = cur_epoch + 1
+        if trained_epoch % ckpt_save_interval == 0 and rank == 0 and ckpt_save_dir is not None:
+            ckpts = sorted(glob.glob(os.path.join(str(ckpt_save_dir), 'checkpoint_epoch_*.pth')), key=os.path.getmtime)
+            for old in ckpts[:max(0, len(ckpts) - max_ckpt_save_num + 1)]:
+                os.remove(old)
+            save_checkpoint(checkpoint_state(model, optimizer, trained_epoch, accumulated_iter),
+                            filename=os.path.join(str(ckpt_save_dir), 'checkpoint_epoch_%d' % trained_epoch))
+    return accumulated_iter

@@ -116,3 +116,31 @@ def test_frame_sharding_and_result_merge_keep_dataset_order():
     assert r0[0] == [0, 2, 4, 6] and r1[0] == [1, 3, 5]
     assert [d['frame'] for d in r0[1]] == list(range(7))
     assert r1[1] is None
+
+
+def _body_flat_gradient_allreduce(rank, world):
+    """data-parallel training contract: every rank ends an iteration with identical parameters, equal to a single process that saw
+    the mean gradient (the fused optimizer folds 1 / world into its grad_scale)"""
+    sys.path.insert(0, os.path.join(PKG, 'tools'))
+    from train_utils.optimization import all_reduce_flat_gradient
+    from oracle import train as otr
+    from pcp_amd import synth
+    n = 1000
+    p0 = torch.from_numpy(synth.uniform(77, 1, n, -1, 1))
+    grads = [torch.from_numpy(synth.uniform(77, 10 + r, n, -1, 1)) for r in range(world)]
+    flat = grads[rank].clone()
+    scale = all_reduce_flat_gradient(flat)
+    st = {'w': p0.clone()}
+    opt = otr.AdamOneCycle(['w'])
+    opt.step(st, {'w': flat * scale}, 1e-3, 0.95)
+    ref = {'w': p0.clone()}
+    opt2 = otr.AdamOneCycle(['w'])
+    opt2.step(ref, {'w': sum(grads) / world}, 1e-3, 0.95)
+    return float((st['w'] - ref['w']).abs().max()), float(scale), st['w'].numpy().tolist()[:8]
+
+
+def test_flat_gradient_allreduce_gives_identical_replicas():
+    out = _run('_body_flat_gradient_allreduce')
+    assert out[0][1] == 0.5 and out[1][1] == 0.5
+    assert out[0][0] < 1e-7 and out[1][0] < 1e-7
+    assert out[0][2] == out[1][2]

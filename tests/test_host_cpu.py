@@ -143,3 +143,32 @@ def test_shipped_yaml_configs_build_all_five_models():
         model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
         assert [type(m).__name__ for m in model.module_list] == mods, name
         assert list(ds.grid_size) == [512, 512, 1]
+
+
+def test_training_dataset_and_onecycle_schedule():
+    """synthetic training items carry zero-padded gt_boxes (collate_batch contract, dataset.py:260-266); the one-cycle schedule
+    reproduces the lr / beta1 values the reference's scheduler produced for the golden run"""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.datasets import build_dataloader
+    from train_utils.optimization import OneCycle
+    cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_disco.yaml'),
+                             EasyDict())
+    cfg.DATA_CONFIG.SYNTHETIC = EasyDict(POINTS_PER_AGENT=200, NUM_FRAMES=5)
+    ds, loader, _ = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, 3, False, training=True)
+    batch = next(iter(loader))
+    gt = batch['gt_boxes']
+    assert gt.shape[0] == 3 and gt.shape[2] == 8 and batch['points'].shape[1] == 7
+    assert (gt[..., 7] >= 0).all() and (gt[..., 7] <= len(cfg.CLASS_NAMES)).all()
+    lens = [(gt[b, :, 7] > 0).sum() for b in range(3)]
+    assert len(set(lens)) > 1 and (gt[np.argmin(lens), min(lens):] == 0).all()       # ragged frames, zero padding
+    g = load_golden('g7_train.npz')
+    oc = g['meta']['optimization']
+
+    class Opt:
+        lr = mom = 0.0
+    sched = OneCycle(Opt, g['meta']['total_it_each_epoch'] * oc['NUM_EPOCHS'], oc['LR'], oc['MOMS'], oc['DIV_FACTOR'], oc['PCT_START'])
+    for it in range(2):
+        sched.step(it)
+        assert abs(Opt.lr - float(g['it%d_lr' % it])) < 1e-15 and abs(Opt.mom - float(g['it%d_mom' % it])) < 1e-15
