@@ -231,6 +231,26 @@ int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stri
                                 int32_t batch, const float *poses_host, const uint8_t *present_host, float *out,
                                 void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * SURVEY 8(f) rows 1-2  lately-fusion exchange: producer rows and ego-side MoDAR ingestion.
+ * pcp_points_in_boxes   replaces pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_api (points_in_boxes_gpu,
+ *   roiaware_pool3d_kernel.cu:23-36,313-336): boxes (B, n_boxes, box_stride >= 7) [x,y,z,dx,dy,dz,heading,...], points
+ *   (B, n_points, point_stride >= 3); box_idx (B, n_points) int32 = first containing box or -1.
+ * pcp_hunter_foreground_rows   replaces pcdet/models/bev_layers/hunter_jr.py:377-397: rows i with sigmoid(head[i, 0]) < thresh_bg
+ *   are written IN ORDER as [points[i, 1:], sigmoid(head[i, 0:3]), head[i, 3:6]] (row_stride - 1 + 6 columns) with their frame
+ *   index in row_batch; count (1,) int32 on the device.  rows / row_batch have capacity n.
+ * pcp_modar_ingest   replaces pcdet/datasets/v2x_sim/v2x_sim_dataset_ego.py:196-232: modar (n, 9) [box7, score, label];
+ *   foreground (m, cols) [x,y,z, ..., flow(3) in the last three columns] or NULL; target_se3_lidar_host: 12 doubles (row-major
+ *   3x4, HOST); rows (n, 13) = [x,y,z, 0, 0, dx,dy,dz, heading, score, label, max_sweep_idx, -1].
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_points_in_boxes(const float *boxes, int32_t batch, int32_t n_boxes, int32_t box_stride, const float *points, int32_t n_points,
+                        int32_t point_stride, int32_t *box_idx, void *stream);
+size_t pcp_hunter_foreground_workspace_bytes(int64_t n);
+int pcp_hunter_foreground_rows(const float *points, int64_t n, int32_t row_stride, const float *head, int32_t ld_head, float thresh_bg,
+                               void *workspace, size_t workspace_bytes, float *rows, int32_t *row_batch, int32_t *count, void *stream);
+int pcp_modar_ingest(const float *modar, int32_t n_modar, const float *foreground, int32_t n_foreground, int32_t foreground_cols,
+                     const double *target_se3_lidar_host, float max_sweep_idx, float *rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

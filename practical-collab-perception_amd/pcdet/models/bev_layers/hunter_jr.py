@@ -163,9 +163,28 @@ class HunterJr(PackedModule):
         ops.softmax_fuse_raw([cat.data_ptr(), cat.data_ptr() + 4 * C], lbuf, C, 2 * C, fused)
         batch_dict.pop('spatial_features_2d')
         batch_dict['spatial_features_2d'] = ops.nchw_view(fused)
-        if self.model_cfg.get('RETURN_SCENE_FLOW', False):
-            batch_dict['hunter_point_heads'] = head8
+        if self.model_cfg.get('GENERATING_EXCHANGE_DATA', False) or self.model_cfg.get('RETURN_SCENE_FLOW', False):
+            self._emit_foreground(batch_dict, points, head8)
         return batch_dict
+
+    def _emit_foreground(self, batch_dict, points, head8):
+        """rows sent to the other agents (reference :377-397): points whose background probability is < 0.3, as
+        [point features without the frame index (xyz already flow-corrected in place), sigmoid(cls)(3), flow(3)]; one compaction
+        kernel instead of boolean-mask copies.  GENERATING_EXCHANGE_DATA writes one file per frame, RETURN_SCENE_FLOW keeps the
+        reference's behaviour of leaving the LAST non-empty frame in batch_dict['scene_flow']."""
+        rows, row_batch = ops.hunter_foreground_rows(points, head8, 0.3)
+        batch_dict['hunter_point_heads'] = head8
+        if rows.shape[0] == 0:
+            return
+        for b_idx, metadata in enumerate(batch_dict['metadata']):
+            sample_points = rows[row_batch == b_idx]
+            if sample_points.shape[0] == 0:
+                continue
+            if self.model_cfg.get('GENERATING_EXCHANGE_DATA', False):
+                torch.save(sample_points, '%s/%s_id%s_foreground.pth' % (self.model_cfg.DATABASE_EXCHANGE_DATA, metadata['sample_token'],
+                                                                         metadata['lidar_id']))
+            else:
+                batch_dict['scene_flow'] = sample_points
 
     def get_training_loss(self, tb_dict=None):
         raise NotImplementedError('HunterJr training losses are outside round 1 (inference path only)')

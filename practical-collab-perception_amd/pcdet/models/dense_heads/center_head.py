@@ -202,11 +202,18 @@ class CenterHead(PackedModule):
             return data_dict
         final = self.generate_predicted_boxes(data_dict['batch_size'], head_bufs, pk)
         data_dict['final_box_dicts'] = final
-        if self.model_cfg.get('RETURN_MODAR_POINTS', False):
-            for pred in final:
-                if pred['pred_boxes'].shape[0] > 0:
-                    data_dict['mo_pts'] = torch.cat([pred['pred_boxes'], pred['pred_scores'].reshape(-1, 1),
-                                                     pred['pred_labels'].reshape(-1, 1).float()], dim=1)
+        if self.model_cfg.get('GENERATING_EXCHANGE_DATA', False) or self.model_cfg.get('RETURN_MODAR_POINTS', False):
+            # MoDAR "points": the wire / on-disk format that feeds config 3 (reference :409-427)
+            for batch_idx, pred in enumerate(final):
+                if pred['pred_boxes'].shape[0] == 0:
+                    continue
+                mo_pts = torch.cat([pred['pred_boxes'], pred['pred_scores'].reshape(-1, 1), pred['pred_labels'].reshape(-1, 1).float()], dim=1)
+                if self.model_cfg.get('GENERATING_EXCHANGE_DATA', False):
+                    metadata = data_dict['metadata'][batch_idx]
+                    torch.save(mo_pts, '%s/%s_id%s_modar.pth' % (self.model_cfg.DATABASE_EXCHANGE_DATA, metadata['sample_token'],
+                                                                 metadata['lidar_id']))
+                else:
+                    data_dict['mo_pts'] = mo_pts
         return data_dict
 
     # ---- training (reference :104-300, 377-392) -------------------------------------------------------------------------

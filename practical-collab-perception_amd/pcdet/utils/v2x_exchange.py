@@ -71,3 +71,37 @@ def shard_frames(num_frames, world, rank):
     """frame indices rank `rank` detects on when frames are dealt round-robin (DistributedSampler order,
     pcdet/datasets/__init__.py:31-51 of the reference)."""
     return list(range(rank, num_frames, world))
+
+
+# ---- lately fusion (config 3): MoDAR exchange, GPU to GPU ---------------------------------------------------------------------
+
+def ingest_modar(ego_points13, modar, foreground, target_se3_lidar, max_sweep_idx=None):
+    """Ego-side ingestion of one remote agent's message (reference: the dataloader does this on the host from a disk database,
+    pcdet/datasets/v2x_sim/v2x_sim_dataset_ego.py:196-232): shifts each MoDAR box by twice the mean flow of the foreground points
+    inside it, maps it to the ego frame and appends the 13-column rows to the ego cloud.  Everything stays on the device.
+    ego_points13: (N, 13) CUDA rows WITHOUT the frame index column [x,y,z,i,t, dx,dy,dz,heading,score,label, sweep_idx, inst_idx];
+    modar: (n, 9) CUDA; foreground: (m, 13) CUDA or None; target_se3_lidar: (4, 4) float64 numpy."""
+    from pcp_amd import ops
+    if max_sweep_idx is None:
+        max_sweep_idx = float(ego_points13[:, -2].max().item())
+    rows = ops.modar_ingest(modar, foreground, target_se3_lidar, max_sweep_idx)
+    return torch.cat([ego_points13, rows], dim=0)
+
+
+def gather_modar(modar, foreground, dst, group=None):
+    """RCCL gather of the (<= 83 x 9) MoDAR rows and the foreground rows of every agent on the ego's rank (README: 0.02 MB per agent):
+    two ragged row gathers; returns lists indexed by rank on `dst`, (None, None) elsewhere."""
+    world, rank = _world(group)
+    if world == 1:
+        return [modar], [foreground]
+    allm, cm = all_gather_v_rows(modar, group)
+    allf, cf = all_gather_v_rows(foreground, group)
+    if rank != dst:
+        return None, None
+    om, of, a, b = [], [], 0, 0
+    for r in range(world):
+        om.append(allm[a:a + cm[r]])
+        of.append(allf[b:b + cf[r]])
+        a += cm[r]
+        b += cf[r]
+    return om, of

@@ -354,3 +354,57 @@ def bev_scatter_mean(points, feat, batch, h, w, min_xy, pix_xy, out=None, out_ch
                                  float(pix_xy[0]), float(pix_xy[1]), _p(workspace), workspace.numel(), _chan_ptr(out, out_ch_off),
                                  out.shape[-1], _stream()), 'pcp_bev_scatter_mean')
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# exchange producer / consumer
+# ---------------------------------------------------------------------------------------------------------------------
+
+def points_in_boxes(points, boxes):
+    """points (B, M, 3+), boxes (B, T, 7+) float32 CUDA -> (B, M) int32 (first containing box, -1 = none)"""
+    _need_cuda(points, boxes)
+    L = _lib.load()
+    points = points.float().contiguous()
+    boxes = boxes.float().contiguous()
+    B, M, ps = points.shape
+    T, bs = boxes.shape[1], boxes.shape[2]
+    out = torch.full((B, M), -1, dtype=torch.int32, device=points.device)
+    if M and T:
+        check(L.pcp_points_in_boxes(_p(boxes), B, T, bs, _p(points), M, ps, _p(out), _stream()), 'pcp_points_in_boxes')
+    return out
+
+
+def hunter_foreground_rows(points, head, thresh_bg=0.3):
+    """points (N, 1+F) with the frame index in column 0, head (N, >=6) = [cls logits(3), flow(3), ...].
+    Returns (rows (n_send, F+6), row_batch (n_send,) int32) in the original row order; one host sync for n_send."""
+    _need_cuda(points, head)
+    L = _lib.load()
+    n, stride = points.shape
+    dev = points.device
+    ws = torch.empty(L.pcp_hunter_foreground_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    rows = torch.empty((max(n, 1), stride - 1 + 6), dtype=torch.float32, device=dev)
+    rb = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.pcp_hunter_foreground_rows(_p(points), n, stride, _p(head), head.shape[1], float(thresh_bg), _p(ws), ws.numel(), _p(rows), _p(rb),
+                                       _p(cnt), _stream()), 'pcp_hunter_foreground_rows')
+    k = int(cnt.item())
+    return rows[:k], rb[:k]
+
+
+def modar_ingest(modar, foreground, target_se3_lidar, max_sweep_idx):
+    """modar (n, 9) CUDA [box7, score, label]; foreground (m, cols) CUDA or None; target_se3_lidar (4, 4) float64 numpy.
+    Returns (n, 13) CUDA float32 rows in the ego frame (the columns config 3's VFE reads)."""
+    import numpy as np
+    _need_cuda(modar, foreground)
+    L = _lib.load()
+    modar = modar.float().contiguous()
+    n = modar.shape[0]
+    rows = torch.empty((n, 13), dtype=torch.float32, device=modar.device)
+    T = np.ascontiguousarray(np.asarray(target_se3_lidar, dtype=np.float64)[:3, :4]).reshape(-1)
+    m, cols = (0, 0)
+    if foreground is not None and foreground.shape[0] > 0:
+        foreground = foreground.float().contiguous()
+        m, cols = foreground.shape
+    check(L.pcp_modar_ingest(_p(modar), n, _p(foreground) if m else ctypes.c_void_p(0), m, cols,
+                             T.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), float(max_sweep_idx), _p(rows), _stream()), 'pcp_modar_ingest')
+    return rows

@@ -1,7 +1,7 @@
 """Generates tests/golden/*.npz by running the REFERENCE'S OWN modules (imported read-only from /root/reference)
 on seeded synthetic inputs with deterministic weights.  Run only in the CPU container:
 
-    python tests/golden/make_golden.py [g1 g2 g3 g4 g7]
+    python tests/golden/make_golden.py [g1 g2 g3 g4 g7 g8]
 
 Fixtures are data (inputs, expected outputs, the config dict that produced them); no reference source is stored.
 """
@@ -407,6 +407,71 @@ def g7_train():
     print('g7 saved', os.path.getsize(os.path.join(HERE, 'g7_train.npz')) // 1024, 'KiB')
 
 
+def g8_exchange():
+    """Lately-fusion exchange: runs the reference's own apply_se3_ and the lines of v2x_sim_dataset_ego.py:196-232
+    (torch.unique + scatter(mean) through the shim) on seeded MoDAR boxes / foreground points.  points_in_boxes_gpu is CUDA-only in
+    the reference; its indices come from oracle/exchange.py (restated from the kernel source) and are stored as data."""
+    rh.install()
+    sys.path.insert(0, REPO)
+    from oracle import exchange as oex
+    from pcdet.datasets.nuscenes.nuscenes_temporal_utils import apply_se3_
+    from torch_scatter import scatter
+    s = synth.SEED_BASE + 88
+    n, m = 40, 3000
+    modar = np.zeros((n, 9), dtype=np.float32)
+    modar[:, 0] = synth.uniform(s, 1, n, -30, 30)
+    modar[:, 1] = synth.uniform(s, 2, n, -30, 30)
+    modar[:, 2] = synth.uniform(s, 3, n, -3, -1)
+    modar[:, 3] = synth.uniform(s, 4, n, 3.0, 5.5)
+    modar[:, 4] = synth.uniform(s, 5, n, 1.5, 2.5)
+    modar[:, 5] = synth.uniform(s, 6, n, 1.4, 2.0)
+    modar[:, 6] = synth.uniform(s, 7, n, -3.14159, 3.14159)
+    modar[:, 7] = synth.uniform(s, 8, n, 0.1, 1.0)
+    modar[:, 8] = 1.0
+    modar[5, :7] = modar[4, :7]                                  # overlapping boxes: the first one wins the points
+    modar[5, 0] += 0.4
+    which = (synth.uniform01(s, 9, m) * (n + 8)).astype(np.int64)        # some points belong to no box
+    fg = np.zeros((m, 13), dtype=np.float32)
+    ctr = np.concatenate([modar[:, :3], np.full((8, 3), 80.0, dtype=np.float32)], 0)[which]
+    fg[:, 0] = ctr[:, 0] + synth.uniform(s, 10, m, -2.5, 2.5)
+    fg[:, 1] = ctr[:, 1] + synth.uniform(s, 11, m, -2.5, 2.5)
+    fg[:, 2] = ctr[:, 2] + synth.uniform(s, 12, m, -1.0, 1.0)
+    fg[:, 3:10] = synth.uniform(s, 13, m * 7, 0, 1).reshape(m, 7)
+    fg[:, 10:13] = synth.uniform(s, 14, m * 3, -1.5, 1.5).reshape(m, 3)
+    T = synth.agent_pose(3)
+    max_sweep_idx = 10.0
+    # ---- the reference's lines (v2x_sim_dataset_ego.py:203-232) ----
+    modar_t, foregr = torch.from_numpy(modar.copy()), torch.from_numpy(fg.copy())
+    box_idx = torch.from_numpy(oex.points_in_boxes(fg[:, :3], modar[:, :7])).long()
+    mask_valid = box_idx > -1
+    foregr = foregr[mask_valid]
+    bi = box_idx[mask_valid]
+    unq, inv = torch.unique(bi, return_inverse=True)
+    boxes_offset = scatter(foregr[:, -3:], inv, dim=0, reduce='mean') * 2.
+    modar_t[unq, :3] += boxes_offset
+    mod = modar_t.numpy()
+    mod[:, :7] = apply_se3_(T, boxes_=mod[:, :7], return_transformed=True)
+    rows = np.zeros((mod.shape[0], 13))
+    rows[:, :3] = mod[:, :3]
+    rows[:, 4] = 0.
+    rows[:, 5:11] = mod[:, 3:]
+    rows[:, -2] = max_sweep_idx
+    rows[:, -1] = -1
+    out = dict(modar=modar, foreground=fg, pose=T, max_sweep_idx=np.array(max_sweep_idx), box_idx=box_idx.numpy().astype(np.int32),
+               rows=rows.astype(np.float32))
+    # no-foreground variant (path_foregr missing, :205)
+    mod2 = modar.copy()
+    mod2[:, :7] = apply_se3_(T, boxes_=mod2[:, :7], return_transformed=True)
+    rows2 = np.zeros((n, 13))
+    rows2[:, :3] = mod2[:, :3]
+    rows2[:, 5:11] = mod2[:, 3:]
+    rows2[:, -2] = max_sweep_idx
+    rows2[:, -1] = -1
+    out['rows_no_foreground'] = rows2.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'g8_exchange.npz'), **out)
+    print('g8 boxes with points:', len(unq), 'points in boxes:', int(mask_valid.sum()))
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
@@ -423,3 +488,5 @@ if __name__ == '__main__':
         g2_full()
     if 'g7' in todo:
         g7_train()
+    if 'g8' in todo:
+        g8_exchange()

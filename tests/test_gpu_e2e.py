@@ -187,3 +187,63 @@ def test_degenerate_inputs_match_oracle(case):
         fb = want['final_box_dicts'][b]
         n, worst = match_boxes(fb['pred_boxes'], fb['pred_scores'], pred[b]['pred_boxes'].cpu().numpy(), pred[b]['pred_scores'].cpu().numpy())
         assert n >= fb['pred_boxes'].shape[0] - 1, (case, n, worst)
+
+
+def test_exchange_outputs_of_a_remote_agent(tmp_path):
+    """what a car / RSU agent sends for lately fusion -- MoDAR rows (n, 9) from the head (center_head.py:409-427)
+    and foreground rows (m, 13) from HunterJr (hunter_jr.py:377-397) -- against the oracle's forward on the same frame, both as
+    batch_dict entries (RETURN_*) and as the on-disk database files (GENERATING_EXCHANGE_DATA)."""
+    from helpers import arch_of
+    from oracle import exchange as oex
+    from oracle import model as omodel
+    g = load_golden('g1_car.npz')
+    g['meta']['model']['CORRECTOR']['RETURN_SCENE_FLOW'] = True
+    g['meta']['model']['DENSE_HEAD']['RETURN_MODAR_POINTS'] = True
+    state = synth.fill_state_dict(g['meta']['state_shapes'])
+    # the synthetic weights put every background probability near 0.49: shift the background logit so that the 0.3 threshold of
+    # hunter_jr.py:380 splits the cloud
+    state['corrector.point_head.seg.0.bias'] = state['corrector.point_head.seg.0.bias'].copy()
+    state['corrector.point_head.seg.0.bias'][0] -= 0.83
+
+    def _build(gg):
+        from pcdet.models import build_network_from_meta
+        mdl = build_network_from_meta(gg['meta'])
+        mdl.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        return mdl.cuda().eval()
+    model = _build(g)
+    metadata = [{'sample_token': 'tokA', 'lidar_id': 2}, {'sample_token': 'tokB', 'lidar_id': 2}]
+    batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+    with torch.no_grad():
+        pred_dicts, _ = model(batch)
+    arch = arch_of(g['meta'])
+    out = omodel.forward(g['points'], state, arch)
+    hj = out['hunter']
+    want_rows, want_b = oex.foreground_rows(hj['points'].numpy(), hj['cls_logit'].numpy(), hj['flow'].numpy())
+    assert 100 < want_rows.shape[0] < hj['points'].shape[0] - 100
+    got = batch['scene_flow'].cpu().numpy()                                  # the LAST non-empty frame (reference behaviour)
+    last = int(want_b.max())
+    ref_last = want_rows[want_b == last]
+    # a point whose background probability sits within float noise of 0.3 may be on the other side of the threshold
+    assert abs(got.shape[0] - ref_last.shape[0]) <= 8 and got.shape[1] == 13
+    if got.shape[0] == ref_last.shape[0]:
+        np.testing.assert_allclose(got, ref_last, rtol=0, atol=2e-3)
+    mo = batch['mo_pts'].cpu().numpy()
+    assert mo.shape[1] == 9 and mo.shape[0] == pred_dicts[-1]['pred_boxes'].shape[0]
+    np.testing.assert_allclose(mo[:, :7], pred_dicts[-1]['pred_boxes'].cpu().numpy())
+    assert np.all(mo[:, 8] == 1.0)
+    # database mode
+    g['meta']['model']['CORRECTOR']['GENERATING_EXCHANGE_DATA'] = True
+    g['meta']['model']['CORRECTOR']['DATABASE_EXCHANGE_DATA'] = str(tmp_path)
+    g['meta']['model']['DENSE_HEAD']['GENERATING_EXCHANGE_DATA'] = True
+    g['meta']['model']['DENSE_HEAD']['DATABASE_EXCHANGE_DATA'] = str(tmp_path)
+    model = _build(g)
+    batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+    with torch.no_grad():
+        pred2, _ = model(batch)
+    import os
+    for b, tok in enumerate(('tokA', 'tokB')):
+        fgr = torch.load(os.path.join(str(tmp_path), '%s_id2_foreground.pth' % tok), weights_only=False)
+        assert fgr.shape[1] == 13 and abs(fgr.shape[0] - int((want_b == b).sum())) <= 8
+        if pred2[b]['pred_boxes'].shape[0]:
+            mod = torch.load(os.path.join(str(tmp_path), '%s_id2_modar.pth' % tok), weights_only=False)
+            assert mod.shape == (pred2[b]['pred_boxes'].shape[0], 9)

@@ -538,3 +538,46 @@ def test_small_n_conv_over_many_channels_matches_torch():
     ops.conv3x3_grouped_small(ops.as_nhwc(x.to(d)), wt.permute(0, 2, 3, 1).reshape(2, 9, C).contiguous().to(d), bs.to(d), [0, 2], out)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
+
+
+# ---- exchange producer / consumer ---------------------------------------------------------------------
+
+def test_points_in_boxes_and_modar_ingest_match_oracle_and_golden():
+    ops = _ops()
+    from helpers import load_golden
+    from oracle import exchange as oex
+    from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
+    g = load_golden('g8_exchange.npz')
+    fg = torch.from_numpy(g['foreground']).cuda()
+    modar = torch.from_numpy(g['modar']).cuda()
+    idx = roiaware_pool3d_utils.points_in_boxes_gpu(fg[None, :, :3].contiguous(), modar[None, :, :7].contiguous())[0].cpu().numpy()
+    want = oex.points_in_boxes(g['foreground'][:, :3], g['modar'][:, :7])
+    # a point within float rounding of a box face may flip (cosf/sinf ulps): none here
+    assert np.array_equal(idx, want) and np.array_equal(idx, g['box_idx'])
+    # two frames with different box sets in one call
+    pts2 = torch.stack([fg[:1500, :3], fg[1500:3000, :3]]).contiguous()
+    bx2 = torch.stack([modar[:20, :7], modar[20:40, :7]]).contiguous()
+    idx2 = ops.points_in_boxes(pts2, bx2).cpu().numpy()
+    assert np.array_equal(idx2[0], oex.points_in_boxes(g['foreground'][:1500, :3], g['modar'][:20, :7]))
+    assert np.array_equal(idx2[1], oex.points_in_boxes(g['foreground'][1500:, :3], g['modar'][20:, :7]))
+    rows = ops.modar_ingest(modar, fg, g['pose'], float(g['max_sweep_idx'])).cpu().numpy()
+    np.testing.assert_allclose(rows, g['rows'], rtol=0, atol=5e-6)
+    rows2 = ops.modar_ingest(modar, None, g['pose'], float(g['max_sweep_idx'])).cpu().numpy()
+    np.testing.assert_allclose(rows2, g['rows_no_foreground'], rtol=0, atol=5e-6)
+    assert ops.modar_ingest(modar[:0], fg, g['pose'], 10.0).shape == (0, 13)
+
+
+def test_hunter_foreground_rows_compaction():
+    ops = _ops()
+    from oracle import exchange as oex
+    n = 70001
+    pts = np.zeros((n, 8), dtype=np.float32)
+    pts[:, 0] = np.floor(synth.uniform(5, 1, n, 0, 3.999))
+    pts[:, 1:] = synth.uniform(5, 2, n * 7, -50, 50).reshape(n, 7)
+    head = synth.uniform(5, 3, n * 8, -4, 4).reshape(n, 8).astype(np.float32)
+    want_rows, want_b = oex.foreground_rows(pts, head[:, :3], head[:, 3:6])
+    rows, rb = ops.hunter_foreground_rows(torch.from_numpy(pts).cuda(), torch.from_numpy(head).cuda(), 0.3)
+    assert rows.shape == want_rows.shape and np.array_equal(rb.cpu().numpy(), want_b)       # same rows, same ORDER
+    np.testing.assert_allclose(rows.cpu().numpy(), want_rows, rtol=0, atol=1e-6)
+    none, nb = ops.hunter_foreground_rows(torch.from_numpy(pts).cuda(), torch.full((n, 8), 9.0).cuda(), 0.3)
+    assert none.shape[0] == 0 and nb.shape[0] == 0

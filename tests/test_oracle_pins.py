@@ -176,3 +176,16 @@ def test_g7_training_step():
                 a = st[k].double()
                 d = np.array([float(a.norm()), float(a.sum()), float(a.abs().max())])
                 np.testing.assert_allclose(d, g['it0_bn_digest'][i], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_g8_exchange_modar_ingest():
+    """oracle/exchange.py against the reference's own apply_se3_ + scatter(mean) lines (tests/golden/g8_exchange.npz)"""
+    from oracle import exchange as oex
+    g = load_golden('g8_exchange.npz')
+    idx = oex.points_in_boxes(g['foreground'][:, :3], g['modar'][:, :7])
+    assert np.array_equal(idx, g['box_idx'])
+    rows = oex.modar_ingest(g['modar'], g['foreground'], g['pose'], float(g['max_sweep_idx']))
+    np.testing.assert_allclose(rows, g['rows'], rtol=0, atol=2e-6)
+    rows2 = oex.modar_ingest(g['modar'], None, g['pose'], float(g['max_sweep_idx']))
+    np.testing.assert_allclose(rows2, g['rows_no_foreground'], rtol=0, atol=2e-6)
+    assert np.all(rows[:, 3:5] == 0) and np.all(rows[:, 12] == -1) and np.all(rows[:, 11] == g['max_sweep_idx'])
