@@ -29,6 +29,7 @@ class BEVMaker(nn.Module):
         self.module_topology = ['vfe', 'map_to_bev_module', 'backbone_2d']
         self.module_list = self.build_networks()
         self.maker_type = model_cfg.MAKER_TYPE
+        self.only_agents = None            # agent-sharded execution (pcdet/models/sharded.py): encode just these agents on this rank
         ckpt = model_cfg.get('CKPT', None)
         if ckpt not in (None, '', 'none', 'None'):
             self.load_params_from_file(ckpt, logger or logging.getLogger(), to_cpu=True)
@@ -80,6 +81,8 @@ class BEVMaker(nn.Module):
         batch_dict['bev_img'] = dict()
         for agent_idx in agent_ids:
             if agent_idx == 1 or (self.maker_type == 'rsu' and agent_idx != 0):
+                continue
+            if self.only_agents is not None and int(agent_idx) not in self.only_agents:
                 continue
             poses = np.zeros((batch_size, 12), dtype=np.float32)
             present = np.zeros((batch_size,), dtype=np.uint8)

@@ -72,6 +72,10 @@ class V2XMidFusionDisco(PackedModule):
     def _compress(self, pk, x_nhwc, out=None):
         return pk['c1'].run(pk['c0'].run(x_nhwc), out=out)
 
+    def compress_maps(self, bev_img_nchw):
+        """the shared compressor on one agent's (B', 384, H, W) map -> (B', H, W, cc) NHWC (eval): what a remote GPU sends"""
+        return self._compress(self.packed(), ops.as_nhwc(bev_img_nchw))
+
     def _weight(self, pk, ego, other, wbuf, col):
         # relu(conv1_4(relu(bn(conv1_2(relu(bn(conv1_1(cat[ego, other]))))))))  -> column `col` of wbuf
         h = ops.pointwise(ego, pk['w1'].w, pk['w1'].b, lib.PW_PLAIN, 2 * self.cc, 64, pk['w1'].cout_pad, relu=True, x2=other,
@@ -106,8 +110,9 @@ class V2XMidFusionDisco(PackedModule):
         self._compress(pk, ego_in, out=stack[0])
         wbuf = torch.zeros((B, H, W, max(4, (n_maps + 3) // 4 * 4)), dtype=torch.float32, device=dev)
         self._weight(pk, stack[0], stack[0], wbuf, 0)
+        pre = batch_dict.get('bev_img_compressed', None)      # agent-sharded execution: maps compressed on the agent's own GPU
         for a, (agent_idx, bev_img) in enumerate(agents, start=1):
-            comp = self._compress(pk, ops.as_nhwc(bev_img))
+            comp = pre[agent_idx] if pre is not None else self._compress(pk, ops.as_nhwc(bev_img))
             for b_idx, meta in enumerate(batch_dict['metadata']):
                 if agent_idx not in meta['se3_from_ego'] or b_idx >= comp.shape[0]:
                     continue
