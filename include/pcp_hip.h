@@ -251,6 +251,33 @@ int pcp_hunter_foreground_rows(const float *points, int64_t n, int32_t row_strid
 int pcp_modar_ingest(const float *modar, int32_t n_modar, const float *foreground, int32_t n_foreground, int32_t foreground_cols,
                      const double *target_se3_lidar_host, float max_sweep_idx, float *rows, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * SURVEY 8(f) row 3  AnchorHeadSingle: box decoding + class-agnostic candidate selection.
+ * Replaces pcdet/models/dense_heads/anchor_head_template.py:225-272 (generate_predicted_boxes), pcdet/utils/box_coder_utils.py:46-78
+ *          (ResidualCoder.decode_torch), common_utils.limit_period, and detector3d_template.py:262-326 up to the NMS call
+ *          (sigmoid, max over classes, score mask >=, torch.topk).
+ * head: (B, H, W, ld) NHWC map of the fused 1x1 convs: class logits at channel ch_cls + a * num_class + c, box code at
+ *   ch_box + a * 7 + j, direction logits at ch_dir + a * num_dir_bins + k (num_dir_bins = 0: no direction classifier).
+ * anchors: (H * W * anchors_per_loc, 7) in the reference's order (y, x, size, rotation).
+ * pcp_anchor_decode outputs, N = H * W * anchors_per_loc: boxes (B, N, 7) = batch_box_preds; cls_logits (B, N, num_class) =
+ *   batch_cls_preds; score_keys (B, N) uint32 = bits(sigmoid(max logit)) + 1, or 0 when below score_thresh; labels (B, N) int32 arg-max.
+ * pcp_topk_boxes: per frame the k (<= 4096) largest keys, descending, ties to the lower index -> gathered boxes (B, k, 7), scores,
+ *   labels, source indices, count (B,) = min(k, number of non-zero keys).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch, h, w, ld;
+  int32_t anchors_per_loc, num_class, num_dir_bins;
+  int32_t ch_cls, ch_box, ch_dir;
+  float dir_offset, dir_limit_offset, dir_period;      /* DIR_OFFSET, DIR_LIMIT_OFFSET, 2 pi / NUM_DIR_BINS */
+  int32_t use_score_thresh;
+  float score_thresh;
+} pcp_anchor_t;
+
+int pcp_anchor_decode(const pcp_anchor_t *desc, const float *head, const float *anchors, float *boxes, float *cls_logits,
+                      uint32_t *score_keys, int32_t *labels, void *stream);
+int pcp_topk_boxes(const uint32_t *score_keys, const int32_t *labels, const float *boxes, int32_t batch, int64_t n, int32_t k,
+                   float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_index, int32_t *count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
 from .centerpoint import CenterPoint
 from .detector3d_template import Detector3DTemplate
+from .pointpillar import PointPillar
 from .v2x_late_fusion import V2XLateFusion
 
 # name -> class (reference: pcdet/models/detectors/__init__.py:19-35); the PointPillars hot path uses CenterPoint in all
@@ -7,6 +8,7 @@ from .v2x_late_fusion import V2XLateFusion
 __all__ = {
     'Detector3DTemplate': Detector3DTemplate,
     'CenterPoint': CenterPoint,
+    'PointPillar': PointPillar,
     'V2XLateFusion': V2XLateFusion,
 }
 

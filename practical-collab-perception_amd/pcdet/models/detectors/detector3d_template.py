@@ -150,6 +150,35 @@ class Detector3DTemplate(nn.Module):
     def forward(self, **kwargs):
         raise NotImplementedError
 
+    # ---- post-processing of anchor heads (reference :239-345), class-agnostic branch on the device ----------------------------
+    def post_processing(self, batch_dict):
+        """batch_cls_preds (B, N, C) logits + batch_box_preds (B, N, 7) -> per frame {pred_boxes, pred_scores, pred_labels}.
+        sigmoid / max / score mask ran in pcp_anchor_decode; here: top-k + gather (pcp_topk_boxes), rotated NMS (pcp_nms_rotated),
+        one host sync for the keep counts."""
+        from pcp_amd import ops
+        cfg = self.model_cfg.POST_PROCESSING
+        nms = cfg.NMS_CONFIG
+        if nms.MULTI_CLASSES_NMS:
+            raise NotImplementedError('MULTI_CLASSES_NMS with a single anchor head trips the reference\'s own assertion '
+                                      '(detector3d_template.py:283,295); only the class-agnostic branch is defined')
+        if nms.NMS_TYPE != 'nms_gpu' or cfg.get('OUTPUT_RAW_SCORE', False):
+            raise NotImplementedError('post-processing kernels cover NMS_TYPE nms_gpu without OUTPUT_RAW_SCORE')
+        st = batch_dict['_pcp_anchor']
+        boxes = batch_dict['batch_box_preds']
+        B, N, _ = boxes.shape
+        k = int(min(nms.NMS_PRE_MAXSIZE, N))
+        cb, cs, cl, _ci, cnt = ops.topk_boxes(st['keys'], st['labels'], boxes, k)
+        keep, kcnt = ops.nms_rotated(cb, None, nms.NMS_THRESH, k, nms.NMS_POST_MAXSIZE, n_dev=cnt)
+        counts = kcnt.cpu().numpy()
+        pred_dicts, recall_dict = [], {}
+        for b in range(B):
+            sel = keep[b, :int(counts[b])].long()
+            final_boxes = cb[b, sel]
+            recall_dict = self.generate_recall_record(box_preds=final_boxes, recall_dict=recall_dict, batch_index=b, data_dict=batch_dict,
+                                                      thresh_list=cfg.RECALL_THRESH_LIST)
+            pred_dicts.append({'pred_boxes': final_boxes, 'pred_scores': cs[b, sel], 'pred_labels': cl[b, sel].long() + 1})
+        return pred_dicts, recall_dict
+
     # ---- recall bookkeeping (reference :347-389) --------------------------------------------------------------------------
     @staticmethod
     def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):

@@ -39,6 +39,12 @@ class Decode(ctypes.Structure):
                 ('use_score_thresh', c_i32), ('score_thresh', c_f)]
 
 
+class Anchor(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('ld', c_i32), ('anchors_per_loc', c_i32), ('num_class', c_i32),
+                ('num_dir_bins', c_i32), ('ch_cls', c_i32), ('ch_box', c_i32), ('ch_dir', c_i32), ('dir_offset', c_f),
+                ('dir_limit_offset', c_f), ('dir_period', c_f), ('use_score_thresh', c_i32), ('score_thresh', c_f)]
+
+
 class RowMap(ctypes.Structure):
     _fields_ = [('ptr', vp), ('ld', c_i32), ('channels', c_i32), ('lattice', c_i32), ('grid_h', c_i32), ('grid_w', c_i32),
                 ('ky', c_i32), ('kx', c_i32)]
@@ -86,6 +92,8 @@ SYMBOLS = {
     'pcp_bev_scatter_mean_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32, c_i64]),
     'pcp_bev_scatter_mean': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, vp, c_sz,
                                      vp, c_i32, vp]),
+    'pcp_anchor_decode': (c_i32, [ctypes.POINTER(Anchor), vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_topk_boxes': (c_i32, [vp, vp, vp, c_i32, c_i64, c_i32, vp, vp, vp, vp, vp, vp]),
     'pcp_points_in_boxes': (c_i32, [vp, c_i32, c_i32, c_i32, vp, c_i32, c_i32, vp, vp]),
     'pcp_hunter_foreground_workspace_bytes': (c_sz, [c_i64]),
     'pcp_hunter_foreground_rows': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_f, vp, c_sz, vp, vp, vp, vp]),

@@ -408,3 +408,40 @@ def modar_ingest(modar, foreground, target_se3_lidar, max_sweep_idx):
     check(L.pcp_modar_ingest(_p(modar), n, _p(foreground) if m else ctypes.c_void_p(0), m, cols,
                              T.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), float(max_sweep_idx), _p(rows), _stream()), 'pcp_modar_ingest')
     return rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AnchorHeadSingle decode + candidate selection
+# ---------------------------------------------------------------------------------------------------------------------
+
+def anchor_decode(head, anchors, desc):
+    """head (B, H, W, ld) NHWC; anchors (N, 7) CUDA; desc: lib.Anchor.  Returns boxes (B, N, 7), cls logits (B, N, ncls), score keys
+    (B, N) int32 storage of uint32 bits, labels (B, N) int32."""
+    _need_cuda(head, anchors)
+    L = _lib.load()
+    B = head.shape[0]
+    N = anchors.shape[0]
+    dev = head.device
+    boxes = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, N, desc.num_class), dtype=torch.float32, device=dev)
+    keys = torch.empty((B, N), dtype=torch.int32, device=dev)
+    labels = torch.empty((B, N), dtype=torch.int32, device=dev)
+    check(L.pcp_anchor_decode(ctypes.byref(desc), _p(head), _p(anchors), _p(boxes), _p(cls), _p(keys), _p(labels), _stream()),
+          'pcp_anchor_decode')
+    return boxes, cls, keys, labels
+
+
+def topk_boxes(keys, labels, boxes, k):
+    """Per frame the k best candidates (descending score, ties to the lower index), gathered.  Returns boxes (B, k, 7), scores (B, k),
+    labels (B, k) int32, index (B, k) int32, count (B,) int32."""
+    _need_cuda(keys, labels, boxes)
+    L = _lib.load()
+    B, N = keys.shape
+    dev = keys.device
+    ob = torch.zeros((B, k, 7), dtype=torch.float32, device=dev)
+    os_ = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    ol = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    oi = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    check(L.pcp_topk_boxes(_p(keys), _p(labels), _p(boxes), B, N, k, _p(ob), _p(os_), _p(ol), _p(oi), _p(cnt), _stream()), 'pcp_topk_boxes')
+    return ob, os_, ol, oi, cnt

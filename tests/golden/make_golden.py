@@ -1,7 +1,7 @@
 """Generates tests/golden/*.npz by running the REFERENCE'S OWN modules (imported read-only from /root/reference)
 on seeded synthetic inputs with deterministic weights.  Run only in the CPU container:
 
-    python tests/golden/make_golden.py [g1 g2 g3 g4 g7 g8]
+    python tests/golden/make_golden.py [g1 g2 g3 g4 g7 g8 g9]
 
 Fixtures are data (inputs, expected outputs, the config dict that produced them); no reference source is stored.
 """
@@ -472,6 +472,53 @@ def g8_exchange():
     print('g8 boxes with points:', len(unq), 'points in boxes:', int(mask_valid.sum()))
 
 
+ANCHOR_HEAD = {
+    'NAME': 'AnchorHeadSingle', 'CLASS_AGNOSTIC': False, 'USE_DIRECTION_CLASSIFIER': True, 'DIR_OFFSET': 0.78539, 'DIR_LIMIT_OFFSET': 0.0,
+    'NUM_DIR_BINS': 2,
+    'ANCHOR_GENERATOR_CONFIG': [
+        {'class_name': 'car', 'anchor_sizes': [[3.9, 1.6, 1.56]], 'anchor_rotations': [0, 1.57], 'anchor_bottom_heights': [-1.78],
+         'align_center': False, 'feature_map_stride': 4, 'matched_threshold': 0.6, 'unmatched_threshold': 0.45},
+        {'class_name': 'pedestrian', 'anchor_sizes': [[0.8, 0.6, 1.73]], 'anchor_rotations': [0, 1.57], 'anchor_bottom_heights': [-0.6],
+         'align_center': False, 'feature_map_stride': 4, 'matched_threshold': 0.5, 'unmatched_threshold': 0.35},
+        {'class_name': 'cyclist', 'anchor_sizes': [[1.76, 0.6, 1.73]], 'anchor_rotations': [0, 1.57], 'anchor_bottom_heights': [-0.6],
+         'align_center': False, 'feature_map_stride': 4, 'matched_threshold': 0.5, 'unmatched_threshold': 0.35}],
+    'TARGET_ASSIGNER_CONFIG': {'NAME': 'AxisAlignedTargetAssigner', 'POS_FRACTION': -1.0, 'SAMPLE_SIZE': 512, 'NORM_BY_NUM_EXAMPLES': False,
+                               'MATCH_HEIGHT': False, 'BOX_CODER': 'ResidualCoder'},
+    'LOSS_CONFIG': {'LOSS_WEIGHTS': {'cls_weight': 1.0, 'loc_weight': 2.0, 'dir_weight': 0.2,
+                                     'code_weights': [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]}}}
+
+
+def g9_anchor(tag, multi_class):
+    """MODEL.NAME PointPillar with AnchorHeadSingle (no YAML of the V2X-Sim set uses it: the head block is the one
+    of tools/cfgs/custom_models/second.yaml with three anchor classes at stride 4), trunk of v2x_pointpillar_basic_ego.yaml."""
+    post = {'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'SCORE_THRESH': 0.5, 'OUTPUT_RAW_SCORE': False, 'EVAL_METRIC': 'kitti',
+            'NMS_CONFIG': {'MULTI_CLASSES_NMS': multi_class, 'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.1, 'NMS_PRE_MAXSIZE': 1024,
+                           'NMS_POST_MAXSIZE': 100}}
+    ov = {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE, 'CLASS_NAMES': ['car', 'pedestrian', 'cyclist'], 'MODEL.NAME': 'PointPillar',
+          'MODEL.DENSE_HEAD': rh.AttrDict(ANCHOR_HEAD), 'MODEL.POST_PROCESSING': rh.AttrDict(post)}
+    cfg = rh.load_cfg('v2x_pointpillar_basic_ego.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    clouds = mini_points('lately', 2, 3000)
+    pts = synth.collate(clouds)
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': [{}, {}]}
+    with torch.no_grad():
+        for mod in model.module_list:
+            bd = mod(bd)
+        pred_dicts, _ = model.post_processing(bd)
+    out = {'points': pts, 'spatial_features_2d_probe': bd['spatial_features_2d'].numpy()[:, ::8].copy(), 'batch_cls_preds': bd['batch_cls_preds'].numpy(),
+           'batch_box_preds': bd['batch_box_preds'].numpy(), 'anchors': torch.cat(model.dense_head.anchors, dim=-3).numpy()}
+    for b, d in enumerate(pred_dicts):
+        out['final_boxes_%d' % b] = d['pred_boxes'].numpy()
+        out['final_scores_%d' % b] = d['pred_scores'].numpy()
+        out['final_labels_%d' % b] = d['pred_labels'].numpy()
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0],
+                                                 class_names=list(cfg.CLASS_NAMES), layout='lately', state_shapes=shapes)))
+    np.savez_compressed(os.path.join(HERE, 'g9_anchor_%s.npz' % tag), **out)
+    print('g9', tag, 'anchors', out['batch_box_preds'].shape, 'final', [out['final_boxes_%d' % b].shape[0] for b in range(2)],
+          'labels', [np.bincount(out['final_labels_%d' % b], minlength=4).tolist() for b in range(2)])
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
@@ -490,3 +537,6 @@ if __name__ == '__main__':
         g7_train()
     if 'g8' in todo:
         g8_exchange()
+    if 'g9' in todo:
+        g9_anchor('agnostic', False)     # MULTI_CLASSES_NMS with a single (non multi-head) AnchorHeadSingle trips the reference's own
+                                         # assertion (detector3d_template.py:283,295: arange(1, num_class) has num_class - 1 entries)

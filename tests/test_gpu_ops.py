@@ -581,3 +581,31 @@ def test_hunter_foreground_rows_compaction():
     np.testing.assert_allclose(rows.cpu().numpy(), want_rows, rtol=0, atol=1e-6)
     none, nb = ops.hunter_foreground_rows(torch.from_numpy(pts).cuda(), torch.full((n, 8), 9.0).cuda(), 0.3)
     assert none.shape[0] == 0 and nb.shape[0] == 0
+
+
+def test_topk_boxes_selection_ties_and_masks():
+    """pcp_topk_boxes: k largest keys, descending, ties to the LOWER index; count = min(k, number of valid keys)"""
+    ops = _ops()
+    B, N = 3, 50000
+    sc = synth.uniform(9, 1, B * N, 0.0, 1.0).reshape(B, N).astype(np.float32)
+    sc[0, 100:140] = 0.987654                                   # a plateau that straddles the k-th place
+    sc[0, 40000:40040] = 0.987654
+    sc[1] = np.where(sc[1] > 0.999, sc[1], 0.0)                 # frame 1: only ~50 valid candidates (< k)
+    sc[2] = 0.0                                                  # frame 2: nothing passes the score mask
+    keys = np.where(sc > 0, sc.view(np.uint32) + 1, 0).astype(np.uint32)
+    boxes = synth.uniform(9, 2, B * N * 7, -1, 1).reshape(B, N, 7).astype(np.float32)
+    labels = (np.arange(B * N) % 3).reshape(B, N).astype(np.int32)
+    k = 4096
+    ob, os_, ol, oi, cnt = ops.topk_boxes(torch.from_numpy(keys.view(np.int32)).cuda(), torch.from_numpy(labels).cuda(),
+                                          torch.from_numpy(boxes).cuda(), k)
+    cnt = cnt.cpu().numpy()
+    for b in range(B):
+        valid = np.nonzero(sc[b] > 0)[0]
+        order = valid[np.lexsort((valid, -sc[b, valid].astype(np.float64)))][:k]
+        assert cnt[b] == order.shape[0]
+        got = oi[b, :cnt[b]].cpu().numpy()
+        assert np.array_equal(got, order), b
+        assert np.array_equal(os_[b, :cnt[b]].cpu().numpy(), sc[b, order])
+        assert np.array_equal(ob[b, :cnt[b]].cpu().numpy(), boxes[b, order])
+        assert np.array_equal(ol[b, :cnt[b]].cpu().numpy(), labels[b, order])
+    assert cnt[2] == 0 and 0 < cnt[1] < k and cnt[0] == k

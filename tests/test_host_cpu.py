@@ -131,7 +131,8 @@ def test_shipped_yaml_configs_build_all_five_models():
                 'v2x_pointpillar_basic_ego.yaml': ['DynamicPillarVFE', 'PointPillarScatter', 'BaseBEVBackbone', 'CenterHead'],
                 'v2x_pointpillar_basic_ego_early.yaml': ['DynamicPillarVFE', 'PointPillarScatter', 'BaseBEVBackbone', 'CenterHead'],
                 'v2x_pointpillar_disco.yaml': ['BEVMaker', 'BEVMaker', 'BEVMaker', 'DynamicPillarVFE', 'PointPillarScatter',
-                                               'BaseBEVBackbone', 'V2XMidFusionDisco', 'CenterHead']}
+                                               'BaseBEVBackbone', 'V2XMidFusionDisco', 'CenterHead'],
+                'v2x_pointpillar_anchor.yaml': ['DynamicPillarVFE', 'PointPillarScatter', 'BaseBEVBackbone', 'AnchorHeadSingle']}
     for name, mods in expected.items():
         cfg = cfg_from_yaml_file(os.path.join(cfg_dir, name), EasyDict())
         for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
@@ -143,6 +144,12 @@ def test_shipped_yaml_configs_build_all_five_models():
         model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
         assert [type(m).__name__ for m in model.module_list] == mods, name
         assert list(ds.grid_size) == [512, 512, 1]
+        if name == 'v2x_pointpillar_anchor.yaml':
+            assert type(model).__name__ == 'PointPillar' and model.dense_head.num_anchors_per_location == 2
+            assert tuple(model.dense_head.anchors[0].shape) == (1, 128, 128, 1, 2, 7)
+            assert sorted(k for k in model.state_dict() if k.startswith('dense_head.')) == [
+                'dense_head.conv_box.bias', 'dense_head.conv_box.weight', 'dense_head.conv_cls.bias', 'dense_head.conv_cls.weight',
+                'dense_head.conv_dir_cls.bias', 'dense_head.conv_dir_cls.weight']
 
 
 def test_training_dataset_and_onecycle_schedule():

@@ -189,3 +189,31 @@ def test_g8_exchange_modar_ingest():
     rows2 = oex.modar_ingest(g['modar'], None, g['pose'], float(g['max_sweep_idx']))
     np.testing.assert_allclose(rows2, g['rows_no_foreground'], rtol=0, atol=2e-6)
     assert np.all(rows[:, 3:5] == 0) and np.all(rows[:, 12] == -1) and np.all(rows[:, 11] == g['max_sweep_idx'])
+
+
+def test_g9_anchor_head_pointpillar():
+    """oracle/anchor.py against the reference's PointPillar detector with AnchorHeadSingle (class-agnostic post-processing)"""
+    from oracle import anchor as oan
+    g = load_golden('g9_anchor_agnostic.npz')
+    meta = g['meta']
+    arch = arch_of(meta) if 'CORRECTOR' in meta['model'] else None
+    st_np = _filled_state(meta['state_shapes'])
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in st_np.items()}
+    a = dict(pc_range=meta['pc_range'], voxel_size=meta['voxel_size'], grid_size=[128, 128, 1], num_raw=meta['model']['VFE']['NUM_RAW_POINT_FEATURES'],
+             vfe_filters=meta['model']['VFE']['NUM_FILTERS'],
+             backbone=dict(layer_nums=meta['model']['BACKBONE_2D']['LAYER_NUMS'], strides=meta['model']['BACKBONE_2D']['LAYER_STRIDES'],
+                           filters=meta['model']['BACKBONE_2D']['NUM_FILTERS'], up_strides=meta['model']['BACKBONE_2D']['UPSAMPLE_STRIDES'],
+                           up_filters=meta['model']['BACKBONE_2D']['NUM_UPSAMPLE_FILTERS']))
+    v, m, _ = omodel.vfe_to_map(g['points'], st_np, st, a, '')
+    np.testing.assert_allclose(m.numpy()[:, ::8], g['spatial_features_2d_probe'], rtol=1e-4, atol=5e-5)
+    cls, boxes, anchors = oan.head_forward(m, st, meta['model']['DENSE_HEAD'], a['grid_size'], a['pc_range'])
+    assert np.array_equal(anchors.numpy(), g['anchors'].reshape(-1, 7))
+    np.testing.assert_allclose(cls.numpy(), g['batch_cls_preds'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(boxes.numpy(), g['batch_box_preds'], rtol=1e-4, atol=5e-5)
+    res = oan.post_process(cls, boxes, meta['model']['POST_PROCESSING'])
+    for b, r in enumerate(res):
+        gb, gs = g['final_boxes_%d' % b], g['final_scores_%d' % b]
+        assert abs(r['boxes'].shape[0] - gb.shape[0]) <= 1
+        n, worst = match_boxes(gb, gs, r['boxes'], r['scores'], tol=1e-3)
+        assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+        assert set(np.unique(r['labels'])) <= {1, 2, 3}
