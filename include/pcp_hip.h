@@ -70,6 +70,11 @@ int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, const pcp_g
  * canvas: (B, ny, nx, 64) NHWC, must be zero where no pillar lands (pcp_fill_zero or a previous pcp_canvas_clear);
  * pillar_features: (P, 64) or NULL.  Must follow pcp_voxelize on the same workspace and stream.
  * ------------------------------------------------------------------------------------------------------------------ */
+/* A processing order for per-point kernels that gather from BEV maps: order[0..N') = the pillariser's bucket order (spatially
+ * sorted), then the rows it masked; every row exactly once.  Must follow pcp_voxelize on the same workspace.  cursor_scratch: 1 int. */
+int pcp_voxelize_row_order(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t *order, int32_t *cursor_scratch,
+                           void *stream);
+
 int pcp_pfn_scatter(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid,
                     const void *workspace, const float *w0, const float *b0, const float *w1, const float *b1,
                     float *pillar_features, float *canvas, void *stream);
@@ -212,6 +217,13 @@ int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h, int32_t w,
                           float pix_y, const float *w1, const float *b1, const float *w2, const float *b2, const float *wh,
                           const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf, float *head,
                           void *stream);
+/* Same, visiting the rows in `order` (length *order_count, or n when order_count is NULL; e.g. pcp_voxelize_row_order): results
+ * are written at the ORIGINAL row index, so the output is identical -- only the gather locality changes. */
+int pcp_hunter_point_head_ordered(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                                  const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                                  float pix_y, const float *w1, const float *b1, const float *w2, const float *b2, const float *wh,
+                                  const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf, float *head,
+                                  const int32_t *order, const int32_t *order_count, void *stream);
 size_t pcp_bev_scatter_mean_workspace_bytes(int32_t batch, int32_t h, int32_t w, int64_t n);
 int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_stride, const float *feat, int32_t ld_feat,
                          int32_t c, int32_t batch, int32_t h, int32_t w, float min_x, float min_y, float pix_x,

@@ -35,7 +35,16 @@ struct PointHeadParams {
   float *pf;              // (n, ld_pf) sampled features
   int ld_pf;
   float *head;            // (n, 8)
+  const int *order;       // optional: process rows order[0 .. *order_count) (results still land at the ORIGINAL row index)
+  const int *order_count; // device scalar, NULL: n
 };
+
+// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a CONTIGUOUS run of point tiles, so that in the spatially
+// sorted visiting order each XCD's 4 MiB L2 holds only its own stripe of the BEV map (bijective remap)
+__device__ __forceinline__ long long xcd_remap_ph(long long bid, long long nwg) {
+  const long long q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 
 __device__ __forceinline__ f32x16 mfma_ph(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -48,18 +57,27 @@ __global__ __launch_bounds__(256, 2) void k_point_head(PointHeadParams p) {
   __shared__ long long c_off[PH_BM][4];     // float offsets of the four corner rows (Ia, Ib, Ic, Id)
   __shared__ float c_w[PH_BM][4];
   __shared__ int c_ok[PH_BM];
+  __shared__ long long c_row[PH_BM];        // original row index of the tile's points (-1: none)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const long long i0 = (long long)blockIdx.x * PH_BM;
+  const long long i0 = (p.order ? xcd_remap_ph(blockIdx.x, gridDim.x) : (long long)blockIdx.x) * PH_BM;
+  const long long n_rows = p.order ? (p.order_count ? (long long)*p.order_count : p.n) : p.n;
+  if (i0 >= n_rows) return;
 
   // ---- phase 1a: corners and weights (hunter_toolbox.py:19-37), no FMA contraction ---------------------------------------
   if (tid < PH_BM) {
 #pragma clang fp contract(off)
-    const long long i = i0 + tid;
+    const long long t = i0 + tid;
+    const long long i = t < n_rows ? (p.order ? (long long)p.order[t] : t) : -1;
+    c_row[tid] = i;
     int ok = 0;
-    if (i < p.n) {
+    // masked rows gather the map's first row (valid memory) with zero weights: the gather loop below has no data-dependent
+    // control flow, so all 16 loads of an unroll group are in flight together
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c_off[tid][k] = 0; c_w[tid][k] = 0.f; }
+    if (i >= 0) {
       const float *row = p.points + i * p.stride;
       int b = (int)row[0];
       if (b >= 0 && b < p.batch) {
@@ -87,27 +105,44 @@ __global__ __launch_bounds__(256, 2) void k_point_head(PointHeadParams p) {
   // ---- phase 1b: gather + blend, 32 points x 96 float4 --------------------------------------------------------------------
   {
 #pragma clang fp contract(off)
-    for (int idx = tid; idx < PH_BM * (PH_C / 4); idx += 256) {
-      const int pt = idx / (PH_C / 4), q = idx % (PH_C / 4);
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c_ok[pt]) {
-        const float *base = p.bev + q * 4;
-        f32x4 Ia = *reinterpret_cast<const f32x4 *>(base + c_off[pt][0]);
-        f32x4 Ib = *reinterpret_cast<const f32x4 *>(base + c_off[pt][1]);
-        f32x4 Ic = *reinterpret_cast<const f32x4 *>(base + c_off[pt][2]);
-        f32x4 Id = *reinterpret_cast<const f32x4 *>(base + c_off[pt][3]);
-        const float wa = c_w[pt][0], wb = c_w[pt][1], wc = c_w[pt][2], wd = c_w[pt][3];
-        v.x = Ia.x * wa + Ib.x * wb + Ic.x * wc + Id.x * wd;
-        v.y = Ia.y * wa + Ib.y * wb + Ic.y * wc + Id.y * wd;
-        v.z = Ia.z * wa + Ib.z * wb + Ic.z * wc + Id.z * wd;
-        v.w = Ia.w * wa + Ib.w * wb + Ic.w * wc + Id.w * wd;
+    // 12 (point, float4) items per thread; the 16 corner loads of four items are issued before any is consumed (the kernel was
+    // latency bound with 4 loads in flight per thread: 3.2 TB/s of L2-resident gathers)
+    constexpr int ITEMS = PH_BM * (PH_C / 4) / 256;      // 12
+    static_assert(ITEMS % 4 == 0, "unroll group");
+    for (int it = 0; it < ITEMS; it += 4) {
+      f32x4 Ia[4], Ib[4], Ic[4], Id[4];
+      int pts[4], qs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + (it + u) * 256;
+        pts[u] = idx / (PH_C / 4);
+        qs[u] = idx % (PH_C / 4);
+        const int pt = pts[u];
+        const float *base = p.bev + qs[u] * 4;
+        Ia[u] = *reinterpret_cast<const f32x4 *>(base + c_off[pt][0]);
+        Ib[u] = *reinterpret_cast<const f32x4 *>(base + c_off[pt][1]);
+        Ic[u] = *reinterpret_cast<const f32x4 *>(base + c_off[pt][2]);
+        Id[u] = *reinterpret_cast<const f32x4 *>(base + c_off[pt][3]);
       }
-      if (i0 + pt < p.n) *reinterpret_cast<f32x4 *>(p.pf + (i0 + pt) * p.ld_pf + q * 4) = v;   // rows of foreign frames stay 0
-      *reinterpret_cast<f32x4 *>(Fs + pt * PH_LDF + q * 4) = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pt = pts[u], q = qs[u];
+        const float wa = c_w[pt][0], wb = c_w[pt][1], wc = c_w[pt][2], wd = c_w[pt][3];
+        f32x4 v;
+        v.x = Ia[u].x * wa + Ib[u].x * wb + Ic[u].x * wc + Id[u].x * wd;
+        v.y = Ia[u].y * wa + Ib[u].y * wb + Ic[u].y * wc + Id[u].y * wd;
+        v.z = Ia[u].z * wa + Ib[u].z * wb + Ic[u].z * wc + Id[u].z * wd;
+        v.w = Ia[u].w * wa + Ib[u].w * wb + Ic[u].w * wc + Id[u].w * wd;
+        const bool okp = c_ok[pt] != 0;                        // select, not a branch (0 * inf must not leak a NaN)
+        v.x = okp ? v.x : 0.f; v.y = okp ? v.y : 0.f; v.z = okp ? v.z : 0.f; v.w = okp ? v.w : 0.f;
+        if (c_row[pt] >= 0) *reinterpret_cast<f32x4 *>(p.pf + c_row[pt] * p.ld_pf + q * 4) = v;   // rows of foreign frames stay 0
+        *reinterpret_cast<f32x4 *>(Fs + pt * PH_LDF + q * 4) = v;
+      }
     }
   }
   __syncthreads();
 
+#ifndef PH_DIAG_GATHER_ONLY
   // ---- phase 2: H1 partial over this wave's K quarter (96 channels = 12 groups of 8) -----------------------------------------
   {
     f32x16 acc;
@@ -135,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void k_point_head(PointHeadParams p) {
   }
   __syncthreads();
 
+#ifndef PH_DIAG_SKIP34
   // ---- phase 3: final = relu(H1 W2^T + b2) + F, three 32-channel column tiles per wave, in place -----------------------------
   {
     f32x4 a[4];
@@ -167,32 +203,49 @@ __global__ __launch_bounds__(256, 2) void k_point_head(PointHeadParams p) {
   }
   __syncthreads();
 
-  // ---- phase 4: the three heads as one (8 x C) matrix: one dot product per thread ---------------------------------------------
+#endif
+#if !defined(PH_DIAG_SKIP34) && !defined(PH_DIAG_SKIP4)
+  // ---- phase 4: the three heads as one (8 x C) matrix, as an MFMA GEMM with N padded 8 -> 32 (lanes r >= 8 feed zeros): K = C split
+  //      over the four waves like phase 2, partials reduced through LDS.  (A per-thread 384-long dot product cost 250 us per launch:
+  //      8 threads walking each LDS row serialise on the banks.)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    const float *asrc = Fs + r * PH_LDF + wave * 96 + 4 * h;
+    const float *bsrc = p.wh + (r < PH_NOUT ? r : 0) * PH_C + wave * 96 + 4 * h;      // B[k][n = r] = Wh[r][k]
+    const float bmask = r < PH_NOUT ? 1.f : 0.f;
+#pragma unroll 4
+    for (int g = 0; g < 12; g++) {
+      f32x4 a = *reinterpret_cast<const f32x4 *>(asrc + g * 8);
+      f32x4 bq = *reinterpret_cast<const f32x4 *>(bsrc + g * 8);
+      acc = mfma_ph(a.x, bq.x * bmask, acc);
+      acc = mfma_ph(a.y, bq.y * bmask, acc);
+      acc = mfma_ph(a.z, bq.z * bmask, acc);
+      acc = mfma_ph(a.w, bq.w * bmask, acc);
+    }
+    if (r < PH_NOUT) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) red[wave][(e & 3) + 8 * (e >> 2) + 4 * h][r] = acc[e];
+    }
+  }
+  __syncthreads();
   {
     const int pt = tid >> 3, o = tid & 7;
-    const float *f = Fs + pt * PH_LDF;
-    const float *wr = p.wh + o * PH_C;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < PH_C; k += 4) {
-      f32x4 fv = *reinterpret_cast<const f32x4 *>(f + k);
-      f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k);
-      acc = fmaf(fv.x, wv.x, acc);
-      acc = fmaf(fv.y, wv.y, acc);
-      acc = fmaf(fv.z, wv.z, acc);
-      acc = fmaf(fv.w, wv.w, acc);
-    }
-    if (i0 + pt < p.n) p.head[(i0 + pt) * PH_NOUT + o] = acc + p.bh[o];
+    const float v = red[0][pt][o] + red[1][pt][o] + red[2][pt][o] + red[3][pt][o] + p.bh[o];
+    if (c_row[pt] >= 0) p.head[c_row[pt] * PH_NOUT + o] = v;
   }
+#endif
+#endif  // PH_DIAG_GATHER_ONLY
 }
 
 }  // namespace
 
-extern "C" int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
-                                     const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
-                                     float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
-                                     const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
-                                     float *head, void *stream_) {
+static int point_head_launch(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                             const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                             float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
+                             const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
+                             float *head, const int32_t *order, const int32_t *order_count, void *stream_) {
   if (!bev || !w1 || !b1 || !w2 || !b2 || !wh || !bh || !pf || !head || n < 0 || batch <= 0 || h <= 0 || w <= 0) return PCP_ERR_ARG;
   if (c != PH_C || hidden != PH_H || n_out != PH_NOUT) return PCP_ERR_UNSUPPORTED;
   if ((ld_bev & 3) || (ld_pf & 3) || row_stride < 3 || (((uintptr_t)bev) & 15) || (((uintptr_t)pf) & 15)) return PCP_ERR_ARG;
@@ -204,8 +257,28 @@ extern "C" int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h,
   p.min_x = min_x; p.min_y = min_y; p.pix_x = pix_x; p.pix_y = pix_y;
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wh = wh; p.bh = bh;
   p.pf = pf; p.ld_pf = ld_pf; p.head = head;
+  p.order = order; p.order_count = order_count;
   long long blocks = (n + PH_BM - 1) / PH_BM;
   hipLaunchKernelGGL(k_point_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+extern "C" int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                                     const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                                     float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
+                                     const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
+                                     float *head, void *stream_) {
+  return point_head_launch(bev, batch, h, w, c, ld_bev, points, n, row_stride, min_x, min_y, pix_x, pix_y, w1, b1, w2, b2, wh, bh, hidden,
+                           n_out, pf, ld_pf, head, nullptr, nullptr, stream_);
+}
+
+extern "C" int pcp_hunter_point_head_ordered(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
+                                             const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
+                                             float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
+                                             const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
+                                             float *head, const int32_t *order, const int32_t *order_count, void *stream_) {
+  if (!order) return PCP_ERR_ARG;
+  return point_head_launch(bev, batch, h, w, c, ld_bev, points, n, row_stride, min_x, min_y, pix_x, pix_y, w1, b1, w2, b2, wh, bh, hidden,
+                           n_out, pf, ld_pf, head, order, order_count, stream_);
 }

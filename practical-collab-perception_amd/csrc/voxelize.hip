@@ -308,3 +308,51 @@ extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, 
   }
   return PCP_OK;
 }
+
+
+// ---- a processing order for per-point kernels that gather from BEV maps (HunterJr point head) -------------------------------------
+// order[0 .. N') = the bucket order (points grouped by pillar, pillars ascending in (frame, x, y): neighbours in this order
+// sample neighbouring BEV pixels, so their 4 x C-float gathers hit L2 instead of HBM); order[N' .. n) = the rows the pillariser
+// masked (out of range / foreign frame), in arbitrary order.  Every row appears exactly once.
+namespace {
+__global__ __launch_bounds__(256) void k_row_order(const int *__restrict__ point_cell, const int *__restrict__ bucket_order,
+                                                  const int *__restrict__ counters, long long n, int *__restrict__ order,
+                                                  int *__restrict__ cursor) {
+  __shared__ int wave_cnt[4];
+  __shared__ int block_base;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kept = counters[1];
+  if (t < n && t < kept) order[t] = bucket_order[t];
+  const int rej = (t < n && point_cell[t] < 0) ? 1 : 0;
+  // one atomic per workgroup (a single hot cursor serialises: 7 k per-thread atomics cost 40 us)
+  const unsigned long long bal = __ballot(rej);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wv] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    block_base = tot ? atomicAdd(cursor, tot) : 0;
+  }
+  __syncthreads();
+  if (rej) {
+    int off = block_base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+    order[kept + off] = (int)t;
+  }
+}
+}  // namespace
+
+extern "C" int pcp_voxelize_row_order(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t *order, int32_t *cursor_scratch,
+                                      void *stream_) {
+  if (!grid || !workspace || !order || !cursor_scratch || n < 0) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  const VoxLayout L = pcp_vox_layout(cells, n);
+  const char *ws = (const char *)workspace;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (pcp_zero_async(cursor_scratch, sizeof(int32_t), stream) != PCP_OK) return PCP_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_row_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int *)(ws + L.point_cell),
+                     (const int *)(ws + L.bucket_order), (const int *)(ws + L.counters), (long long)n, order, cursor_scratch);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

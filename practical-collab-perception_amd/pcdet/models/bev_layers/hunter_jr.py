@@ -93,6 +93,7 @@ class HunterJr(PackedModule):
         # always creates it too (hunter_jr.py:139-142) and checkpoints contain its weights
         self.object_head = HunterObjectHead(num_bev_features, list(model_cfg.get('OBJ_HEAD_HIDDEN_CHANNELS')), use_drop_out=False)
         self.thresh_point_cls_prob = model_cfg.get('THRESHOLD_POINT_CLS_PROB', 0.3)
+        self.sorted_gather = True          # MI355X knob: point-head gathers in spatially sorted order (output unchanged)
         self.conv_weightor = nn.Sequential(
             conv_bn_relu(2 * num_bev_features, 2 * num_bev_features, padding=1, norm_layer=norm),
             nn.Conv2d(2 * num_bev_features, 2, kernel_size=3, padding=1))
@@ -138,7 +139,13 @@ class HunterJr(PackedModule):
         min_xy = self.point_cloud_range[:2]
         pix = [np.float32(self.voxel_size[0]) * self.bev_image_stride, np.float32(self.voxel_size[1]) * self.bev_image_stride]
         if pk['fused'] is not None and C == 384:
-            pf, head8 = ops.hunter_point_head(cat, points, min_xy, pix, *pk['fused'], channels=C)   # one launch
+            # visit the points in the pillariser's bucket order (spatially sorted): the 4 x 384-float gathers of neighbouring
+            # points then hit L2; results are written at the original rows, so the output does not change
+            stash = batch_dict.get('_pcp_vfe', None)
+            order = None
+            if self.sorted_gather and stash is not None and stash['vox'].n == points.shape[0]:
+                order = ops.voxelize_row_order(stash['vox'])
+            pf, head8 = ops.hunter_point_head(cat, points, min_xy, pix, *pk['fused'], channels=C, order=order)   # one launch
         else:
             pf = ops.bev_sample_bilinear(cat, points, min_xy, pix, channels=C)
             h = pf

@@ -271,14 +271,31 @@ def softmax_fuse(maps, weights, channels, out):
     return out
 
 
-def hunter_point_head(bev, points, min_xy, pix_xy, w1, b1, w2, b2, wh, bh, channels, bev_ch_off=0):
-    """fused sample -> MLP -> heads.  bev: (B, H, W, ld) NHWC (channel window [bev_ch_off, +channels)).  Returns (pf (N, C), head (N, 8))."""
-    _need_cuda(bev, points, w1, b1, w2, b2, wh, bh)
+def voxelize_row_order(vox):
+    """spatially sorted visiting order of ALL rows of the cloud pcp_voxelize just bucketed (see include/pcp_hip.h)"""
+    L = _lib.load()
+    dev = vox.workspace.device
+    order = torch.empty((max(vox.n, 1),), dtype=torch.int32, device=dev)
+    cur = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(L.pcp_voxelize_row_order(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(order), _p(cur), _stream()), 'pcp_voxelize_row_order')
+    return order
+
+
+def hunter_point_head(bev, points, min_xy, pix_xy, w1, b1, w2, b2, wh, bh, channels, bev_ch_off=0, order=None):
+    """fused sample -> MLP -> heads.  bev: (B, H, W, ld) NHWC (channel window [bev_ch_off, +channels)).  Returns (pf (N, C), head (N, 8)).
+    order: optional int32 permutation of the rows (voxelize_row_order): same results, better gather locality."""
+    _need_cuda(bev, points, w1, b1, w2, b2, wh, bh, order)
     L = _lib.load()
     B, H, W, ld_bev = bev.shape
     n, stride = points.shape
     pf = torch.empty((max(n, 1), channels), dtype=torch.float32, device=bev.device)
     head = torch.empty((max(n, 1), wh.shape[0]), dtype=torch.float32, device=bev.device)
+    if order is not None:
+        check(L.pcp_hunter_point_head_ordered(_chan_ptr(bev, bev_ch_off), B, H, W, channels, ld_bev, _p(points), n, stride, float(min_xy[0]),
+                                              float(min_xy[1]), float(pix_xy[0]), float(pix_xy[1]), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh),
+                                              _p(bh), w1.shape[0], wh.shape[0], _p(pf), channels, _p(head), _p(order), ctypes.c_void_p(0),
+                                              _stream()), 'pcp_hunter_point_head_ordered')
+        return pf[:n], head[:n]
     check(L.pcp_hunter_point_head(_chan_ptr(bev, bev_ch_off), B, H, W, channels, ld_bev, _p(points), n, stride, float(min_xy[0]),
                                   float(min_xy[1]), float(pix_xy[0]), float(pix_xy[1]), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh), _p(bh),
                                   w1.shape[0], wh.shape[0], _p(pf), channels, _p(head), _stream()), 'pcp_hunter_point_head')
