@@ -217,13 +217,16 @@ int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h, int32_t w,
                           float pix_y, const float *w1, const float *b1, const float *w2, const float *b2, const float *wh,
                           const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf, float *head,
                           void *stream);
-/* Same, visiting the rows in `order` (length *order_count, or n when order_count is NULL; e.g. pcp_voxelize_row_order): results
- * are written at the ORIGINAL row index, so the output is identical -- only the gather locality changes. */
-int pcp_hunter_point_head_ordered(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
-                                  const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
-                                  float pix_y, const float *w1, const float *b1, const float *w2, const float *b2, const float *wh,
-                                  const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf, float *head,
-                                  const int32_t *order, const int32_t *order_count, void *stream);
+/* Extended form.  order (NULL: index order): visit the rows order[0 .. *order_count) (order_count NULL: n; e.g.
+ * pcp_voxelize_row_order) -- results are written at the ORIGINAL row index, only the gather locality changes.
+ * apply_flow != 0 fuses pcp_hunter_apply_flow and the masked re-sampling that follows it in correct_bev_image (hunter_jr.py:257-275):
+ * rows predicted dynamic foreground get points[:, 1:4] += flow IN PLACE, dyn_mask[i] (may be NULL) = 1, and their pf row is re-sampled
+ * at the corrected location (rows of foreign frames are moved but not re-sampled, like the unfused pair). */
+int pcp_hunter_point_head_ex(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev, float *points, int64_t n,
+                             int32_t row_stride, float min_x, float min_y, float pix_x, float pix_y, const float *w1, const float *b1,
+                             const float *w2, const float *b2, const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf,
+                             int32_t ld_pf, float *head, const int32_t *order, const int32_t *order_count, int32_t apply_flow,
+                             float flow_thresh, uint8_t *dyn_mask, void *stream);
 size_t pcp_bev_scatter_mean_workspace_bytes(int32_t batch, int32_t h, int32_t w, int64_t n);
 int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_stride, const float *feat, int32_t ld_feat,
                          int32_t c, int32_t batch, int32_t h, int32_t w, float min_x, float min_y, float pix_x,

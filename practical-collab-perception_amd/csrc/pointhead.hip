@@ -37,6 +37,11 @@ struct PointHeadParams {
   float *head;            // (n, 8)
   const int *order;       // optional: process rows order[0 .. *order_count) (results still land at the ORIGINAL row index)
   const int *order_count; // device scalar, NULL: n
+  // optional fusion of hunter_jr.py:257-265 + the re-sampling of the corrected points (correct_bev_image): rows predicted dynamic
+  // foreground get xyz += flow IN PLACE and their pf row re-sampled at the corrected location
+  float *points_mut;      // NULL: disabled
+  float flow_thresh;
+  unsigned char *dyn_mask;
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a CONTIGUOUS run of point tiles, so that in the spatially
@@ -234,6 +239,70 @@ __global__ __launch_bounds__(256, 2) void k_point_head(PointHeadParams p) {
     const int pt = tid >> 3, o = tid & 7;
     const float v = red[0][pt][o] + red[1][pt][o] + red[2][pt][o] + red[3][pt][o] + p.bh[o];
     if (c_row[pt] >= 0) p.head[c_row[pt] * PH_NOUT + o] = v;
+    if (p.points_mut) H1s[pt * PH_LDH + o] = v;               // H1s is free now: keep the 8 head values for the flow stage
+  }
+  if (p.points_mut) {
+    // ---- phase 5 (optional): dynamic-foreground correction + re-sampling, same arithmetic as k_apply_flow / k_bilinear ----------
+    __shared__ int dyn_list[PH_BM];
+    __shared__ int n_dyn;
+    if (tid == 0) n_dyn = 0;
+    __syncthreads();
+    if (tid < PH_BM) {
+#pragma clang fp contract(off)
+      const long long i = c_row[tid];
+      if (i >= 0) {
+        const float *hv = H1s + tid * PH_LDH;
+        const float p0 = 1.0f / (1.0f + expf(-hv[0])), p1 = 1.0f / (1.0f + expf(-hv[1])), p2 = 1.0f / (1.0f + expf(-hv[2]));
+        const bool dyn = (p2 > p0) && (p2 > p1) && (p2 > p.flow_thresh);
+        if (p.dyn_mask) p.dyn_mask[i] = dyn ? 1 : 0;
+        if (dyn) {
+          float *row = p.points_mut + i * p.stride;
+          const float nx = row[1] + hv[3], ny = row[2] + hv[4];
+          row[1] = nx;
+          row[2] = ny;
+          row[3] = row[3] + hv[5];
+          const int b = (int)row[0];
+          if (b >= 0 && b < p.batch) {
+            const float x = __fdiv_rn(nx - p.min_x, p.pix_x), y = __fdiv_rn(ny - p.min_y, p.pix_y);
+            const float fx0 = fminf(fmaxf(floorf(x), -2.0f), (float)p.w + 1.0f), fy0 = fminf(fmaxf(floorf(y), -2.0f), (float)p.h + 1.0f);
+            int x0 = (int)fx0, y0 = (int)fy0;
+            int x1 = x0 + 1, y1 = y0 + 1;
+            x0 = min(max(x0, 0), p.w - 1); x1 = min(max(x1, 0), p.w - 1);
+            y0 = min(max(y0, 0), p.h - 1); y1 = min(max(y1, 0), p.h - 1);
+            c_w[tid][0] = ((float)x1 - x) * ((float)y1 - y);
+            c_w[tid][1] = ((float)x1 - x) * (y - (float)y0);
+            c_w[tid][2] = (x - (float)x0) * ((float)y1 - y);
+            c_w[tid][3] = (x - (float)x0) * (y - (float)y0);
+            const long long img = (long long)b * p.h * p.w;
+            c_off[tid][0] = (img + (long long)y0 * p.w + x0) * p.ld_bev;
+            c_off[tid][1] = (img + (long long)y1 * p.w + x0) * p.ld_bev;
+            c_off[tid][2] = (img + (long long)y0 * p.w + x1) * p.ld_bev;
+            c_off[tid][3] = (img + (long long)y1 * p.w + x1) * p.ld_bev;
+            dyn_list[atomicAdd(&n_dyn, 1)] = tid;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+#pragma clang fp contract(off)
+      const int items = n_dyn * (PH_C / 4);
+      for (int idx = tid; idx < items; idx += 256) {
+        const int pt = dyn_list[idx / (PH_C / 4)], q = idx % (PH_C / 4);
+        const float *base = p.bev + q * 4;
+        const f32x4 Ia = *reinterpret_cast<const f32x4 *>(base + c_off[pt][0]);
+        const f32x4 Ib = *reinterpret_cast<const f32x4 *>(base + c_off[pt][1]);
+        const f32x4 Ic = *reinterpret_cast<const f32x4 *>(base + c_off[pt][2]);
+        const f32x4 Id = *reinterpret_cast<const f32x4 *>(base + c_off[pt][3]);
+        const float wa = c_w[pt][0], wb = c_w[pt][1], wc = c_w[pt][2], wd = c_w[pt][3];
+        f32x4 v;
+        v.x = Ia.x * wa + Ib.x * wb + Ic.x * wc + Id.x * wd;
+        v.y = Ia.y * wa + Ib.y * wb + Ic.y * wc + Id.y * wd;
+        v.z = Ia.z * wa + Ib.z * wb + Ic.z * wc + Id.z * wd;
+        v.w = Ia.w * wa + Ib.w * wb + Ic.w * wc + Id.w * wd;
+        *reinterpret_cast<f32x4 *>(p.pf + c_row[pt] * p.ld_pf + q * 4) = v;
+      }
+    }
   }
 #endif
 #endif  // PH_DIAG_GATHER_ONLY
@@ -245,7 +314,8 @@ static int point_head_launch(const float *bev, int32_t batch, int32_t h, int32_t
                              const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
                              float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
                              const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
-                             float *head, const int32_t *order, const int32_t *order_count, void *stream_) {
+                             float *head, const int32_t *order, const int32_t *order_count, float *points_mut, float flow_thresh,
+                             unsigned char *dyn_mask, void *stream_) {
   if (!bev || !w1 || !b1 || !w2 || !b2 || !wh || !bh || !pf || !head || n < 0 || batch <= 0 || h <= 0 || w <= 0) return PCP_ERR_ARG;
   if (c != PH_C || hidden != PH_H || n_out != PH_NOUT) return PCP_ERR_UNSUPPORTED;
   if ((ld_bev & 3) || (ld_pf & 3) || row_stride < 3 || (((uintptr_t)bev) & 15) || (((uintptr_t)pf) & 15)) return PCP_ERR_ARG;
@@ -258,6 +328,7 @@ static int point_head_launch(const float *bev, int32_t batch, int32_t h, int32_t
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wh = wh; p.bh = bh;
   p.pf = pf; p.ld_pf = ld_pf; p.head = head;
   p.order = order; p.order_count = order_count;
+  p.points_mut = points_mut; p.flow_thresh = flow_thresh; p.dyn_mask = dyn_mask;
   long long blocks = (n + PH_BM - 1) / PH_BM;
   hipLaunchKernelGGL(k_point_head, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p);
   PCP_CHECK_LAUNCH();
@@ -270,15 +341,14 @@ extern "C" int pcp_hunter_point_head(const float *bev, int32_t batch, int32_t h,
                                      const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
                                      float *head, void *stream_) {
   return point_head_launch(bev, batch, h, w, c, ld_bev, points, n, row_stride, min_x, min_y, pix_x, pix_y, w1, b1, w2, b2, wh, bh, hidden,
-                           n_out, pf, ld_pf, head, nullptr, nullptr, stream_);
+                           n_out, pf, ld_pf, head, nullptr, nullptr, nullptr, 0.f, nullptr, stream_);
 }
 
-extern "C" int pcp_hunter_point_head_ordered(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev,
-                                             const float *points, int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x,
-                                             float pix_y, const float *w1, const float *b1, const float *w2, const float *b2,
-                                             const float *wh, const float *bh, int32_t hidden, int32_t n_out, float *pf, int32_t ld_pf,
-                                             float *head, const int32_t *order, const int32_t *order_count, void *stream_) {
-  if (!order) return PCP_ERR_ARG;
+extern "C" int pcp_hunter_point_head_ex(const float *bev, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_bev, float *points,
+                                        int64_t n, int32_t row_stride, float min_x, float min_y, float pix_x, float pix_y, const float *w1,
+                                        const float *b1, const float *w2, const float *b2, const float *wh, const float *bh, int32_t hidden,
+                                        int32_t n_out, float *pf, int32_t ld_pf, float *head, const int32_t *order,
+                                        const int32_t *order_count, int32_t apply_flow, float flow_thresh, uint8_t *dyn_mask, void *stream_) {
   return point_head_launch(bev, batch, h, w, c, ld_bev, points, n, row_stride, min_x, min_y, pix_x, pix_y, w1, b1, w2, b2, wh, bh, hidden,
-                           n_out, pf, ld_pf, head, order, order_count, stream_);
+                           n_out, pf, ld_pf, head, order, order_count, apply_flow ? points : nullptr, flow_thresh, dyn_mask, stream_);
 }

@@ -145,7 +145,9 @@ class HunterJr(PackedModule):
             order = None
             if self.sorted_gather and stash is not None and stash['vox'].n == points.shape[0]:
                 order = ops.voxelize_row_order(stash['vox'])
-            pf, head8 = ops.hunter_point_head(cat, points, min_xy, pix, *pk['fused'], channels=C, order=order)   # one launch
+            # one launch: sample -> MLP -> heads -> dynamic-foreground correction (in place) -> re-sampling of the corrected rows
+            pf, head8, dyn = ops.hunter_point_head(cat, points, min_xy, pix, *pk['fused'], channels=C, order=order,
+                                                   flow_thresh=self.thresh_point_cls_prob)
         else:
             pf = ops.bev_sample_bilinear(cat, points, min_xy, pix, channels=C)
             h = pf
@@ -154,8 +156,8 @@ class HunterJr(PackedModule):
                 h = ops.pointwise(h, layer.w, layer.b, lib.PW_PLAIN, layer.cin, layer.cout, layer.cout_pad, relu=True,
                                   residual=pf if last else None)                      # final = pf + mlp(pf)
             head8 = pk['heads'].run(h)                                                # (N, 8) = cls(3) | flow(3) | embed(2)
-        dyn = ops.hunter_apply_flow(points, head8, self.thresh_point_cls_prob)        # mutates points[:, 1:4] in place
-        ops.bev_sample_bilinear(cat, points, min_xy, pix, out=pf, row_mask=dyn, channels=C)
+            dyn = ops.hunter_apply_flow(points, head8, self.thresh_point_cls_prob)    # mutates points[:, 1:4] in place
+            ops.bev_sample_bilinear(cat, points, min_xy, pix, out=pf, row_mask=dyn, channels=C)
         ops.bev_scatter_mean(points, pf, B, H, W, min_xy, pix, out=cat, out_ch_off=C)
         hid = pk['w0'].run(cat)
         if pk['w1_small'] is not None:

@@ -281,21 +281,24 @@ def voxelize_row_order(vox):
     return order
 
 
-def hunter_point_head(bev, points, min_xy, pix_xy, w1, b1, w2, b2, wh, bh, channels, bev_ch_off=0, order=None):
-    """fused sample -> MLP -> heads.  bev: (B, H, W, ld) NHWC (channel window [bev_ch_off, +channels)).  Returns (pf (N, C), head (N, 8)).
-    order: optional int32 permutation of the rows (voxelize_row_order): same results, better gather locality."""
+def hunter_point_head(bev, points, min_xy, pix_xy, w1, b1, w2, b2, wh, bh, channels, bev_ch_off=0, order=None, flow_thresh=None):
+    """fused sample -> MLP -> heads.  bev: (B, H, W, ld) NHWC (channel window [bev_ch_off, +channels)).  Returns (pf (N, C), head (N, 8))
+    or, with flow_thresh, (pf, head, dyn_mask): the dynamic-foreground correction (points[:, 1:4] += flow IN PLACE) and the re-sampling
+    of the corrected rows run inside the same kernel.  order: optional int32 permutation of the rows (voxelize_row_order)."""
     _need_cuda(bev, points, w1, b1, w2, b2, wh, bh, order)
     L = _lib.load()
     B, H, W, ld_bev = bev.shape
     n, stride = points.shape
     pf = torch.empty((max(n, 1), channels), dtype=torch.float32, device=bev.device)
     head = torch.empty((max(n, 1), wh.shape[0]), dtype=torch.float32, device=bev.device)
-    if order is not None:
-        check(L.pcp_hunter_point_head_ordered(_chan_ptr(bev, bev_ch_off), B, H, W, channels, ld_bev, _p(points), n, stride, float(min_xy[0]),
-                                              float(min_xy[1]), float(pix_xy[0]), float(pix_xy[1]), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh),
-                                              _p(bh), w1.shape[0], wh.shape[0], _p(pf), channels, _p(head), _p(order), ctypes.c_void_p(0),
-                                              _stream()), 'pcp_hunter_point_head_ordered')
-        return pf[:n], head[:n]
+    if order is not None or flow_thresh is not None:
+        dyn = torch.zeros((max(n, 1),), dtype=torch.uint8, device=bev.device) if flow_thresh is not None else None
+        check(L.pcp_hunter_point_head_ex(_chan_ptr(bev, bev_ch_off), B, H, W, channels, ld_bev, _p(points), n, stride, float(min_xy[0]),
+                                         float(min_xy[1]), float(pix_xy[0]), float(pix_xy[1]), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh),
+                                         _p(bh), w1.shape[0], wh.shape[0], _p(pf), channels, _p(head), _p(order), ctypes.c_void_p(0),
+                                         0 if flow_thresh is None else 1, 0.0 if flow_thresh is None else float(flow_thresh), _p(dyn),
+                                         _stream()), 'pcp_hunter_point_head_ex')
+        return (pf[:n], head[:n]) if flow_thresh is None else (pf[:n], head[:n], dyn[:n])
     check(L.pcp_hunter_point_head(_chan_ptr(bev, bev_ch_off), B, H, W, channels, ld_bev, _p(points), n, stride, float(min_xy[0]),
                                   float(min_xy[1]), float(pix_xy[0]), float(pix_xy[1]), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh), _p(bh),
                                   w1.shape[0], wh.shape[0], _p(pf), channels, _p(head), _stream()), 'pcp_hunter_point_head')

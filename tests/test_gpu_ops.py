@@ -523,6 +523,24 @@ def test_fused_point_head_matches_unfused_ops_and_torch():
     pf2 = ops.bev_sample_bilinear(ops.as_nhwc(bev.to(d)), pts.to(d), rng[:2], pix)
     torch.cuda.synchronize()
     assert torch.equal(pf, pf2)
+    # extended form: sorted visiting order + fused flow correction / re-sampling == the unfused three-op sequence, bit for bit
+    bev_d = ops.as_nhwc(bev.to(d))
+    wts = [t.to(d) for t in (w1, b1, w2, b2, wh, bh)]
+    wts[5] = wts[5].clone()
+    hd = head.float()
+    wts[5][2] += float((torch.maximum(hd[:, 0], hd[:, 1]) - hd[:, 2]).median())      # about half of the rows become dynamic foreground
+    p_ref = pts.to(d).clone()
+    pf_a, head_a = ops.hunter_point_head(bev_d, p_ref, rng[:2], pix, *wts, channels=C)
+    dyn_a = ops.hunter_apply_flow(p_ref, head_a, 0.3)
+    ops.bev_sample_bilinear(bev_d, p_ref, rng[:2], pix, out=pf_a, row_mask=dyn_a, channels=C)
+    grid = ops.make_grid(rng, [0.2, 0.2, 8.0], [128, 128, 1], B)
+    p_fused = pts.to(d).clone()
+    order = ops.voxelize_row_order(ops.voxelize(p_fused, grid, want_inverse=False, want_counts=False))
+    assert sorted(order.cpu().tolist()) == list(range(p_fused.shape[0]))                 # a permutation of ALL rows
+    pf_b, head_b, dyn_b = ops.hunter_point_head(bev_d, p_fused, rng[:2], pix, *wts, channels=C, order=order, flow_thresh=0.3)
+    torch.cuda.synchronize()
+    assert 50 < int(dyn_a.sum()) < p_ref.shape[0] - 50
+    assert torch.equal(dyn_a, dyn_b) and torch.equal(head_a, head_b) and torch.equal(p_ref, p_fused) and torch.equal(pf_a, pf_b)
 
 
 def test_small_n_conv_over_many_channels_matches_torch():
