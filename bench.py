@@ -200,12 +200,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (the hot path has no CPU fallback)'
+    # one rank per GPU; PCP_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices round-robin -- a functional check, not a measurement)
+    dev_index = local_rank % torch.cuda.device_count() if world > 1 else 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl')
-    assert torch.cuda.is_available(), 'bench.py needs the MI355X (the hot path has no CPU fallback)'
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend=os.environ.get('PCP_BENCH_BACKEND', 'nccl'))
+    dev = torch.device('cuda', dev_index)
 
     conf = CONFIGS[args.config]
     cfg = load_cfg(conf['yaml'])
@@ -294,12 +297,17 @@ def main():
         elapsed = float(t.item())
     n_boxes = int(sum(p['pred_boxes'].shape[0] for p in preds))
 
+    # instrumented pass (HIP events around the conv launches).  A training step contains a collective (the gradient all-reduce), so in
+    # that mode every rank has to take part in the three extra steps; only rank 0 records.
+    timer = None
     if rank == 0:
         graphed = None                          # the instrumented pass runs eagerly (events around individual launches)
         timer = ConvTimer()
         timer.install()
+    if rank == 0 or (args.train and world > 1):
         for _ in range(3):
             step()
+    if rank == 0:
         cs = timer.summary()
         timer.remove()
         frames = world * batch * args.steps

@@ -45,47 +45,66 @@ __global__ __launch_bounds__(256) void k_head_grouped(HeadConvParams p) {
   const int py = lane >> 3, px = lane & 7;
 
   const int cg = HG_CG * p.chunks;
-  for (int g = 0; g < p.groups; g++) {
+  // software pipeline over the (group, chunk) slices: the next slice's 10x10x64 patch is loaded global -> registers while the
+  // current one is multiplied (the kernel was bound by the exposed global-load latency between its two barriers per slice)
+  constexpr int NLD = (HG_P * HG_P * 16 + 255) / 256;       // 7 float4 per thread
+  const int n_slices = p.groups * p.chunks;
+  f32x4 pre[NLD];
+  auto load_slice = [&](int s) {
+    const int g = s / p.chunks, ch = s % p.chunks;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + u * 256;
+      const int pix = idx >> 4, q = idx & 15;
+      const int iy = oy0 - 1 + pix / HG_P, ix = ox0 - 1 + pix % HG_P;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < HG_P * HG_P * 16 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w_)
+        v = *reinterpret_cast<const f32x4 *>(p.in + ((long long)(b * p.h + iy) * p.w_ + ix) * p.ld_in + g * cg + ch * HG_CG + q * 4);
+      pre[u] = v;
+    }
+  };
+  auto store_slice = [&]() {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < HG_P * HG_P * 16) *reinterpret_cast<f32x4 *>(patch + (idx >> 4) * HG_LD + (idx & 15) * 4) = pre[u];
+    }
+  };
+  load_slice(0);
+  float acc[HG_MAX_K] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < n_slices; s++) {
+    const int g = s / p.chunks, ch = s % p.chunks;
     const int o0 = p.goff[g], kg = p.goff[g + 1] - o0;
-    float acc[HG_MAX_K] = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < p.chunks; ch++) {
-      __syncthreads();
-      // stage 10x10 pixels x 64 channels of this chunk: 100 pixels x 16 float4
-      for (int idx = tid; idx < HG_P * HG_P * 16; idx += 256) {
-        int pix = idx >> 4, q = idx & 15;
-        int iy = oy0 - 1 + pix / HG_P, ix = ox0 - 1 + pix % HG_P;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w_)
-          v = *reinterpret_cast<const f32x4 *>(p.in + ((long long)(b * p.h + iy) * p.w_ + ix) * p.ld_in + g * cg + ch * HG_CG + q * 4);
-        *reinterpret_cast<f32x4 *>(patch + pix * HG_LD + q * 4) = v;
-      }
-      __syncthreads();
+    __syncthreads();                       // previous slice's reads of `patch` (and of `part`) are done
+    store_slice();
+    __syncthreads();
+    if (s + 1 < n_slices) load_slice(s + 1);
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const float *src = patch + ((py + tap / 3) * HG_P + px + tap % 3) * HG_LD + wave * 16;
-        f32x4 x0 = *reinterpret_cast<const f32x4 *>(src), x1 = *reinterpret_cast<const f32x4 *>(src + 4);
-        f32x4 x2 = *reinterpret_cast<const f32x4 *>(src + 8), x3 = *reinterpret_cast<const f32x4 *>(src + 12);
-        const float xs[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+    for (int tap = 0; tap < 9; tap++) {
+      const float *src = patch + ((py + tap / 3) * HG_P + px + tap % 3) * HG_LD + wave * 16;
+      f32x4 x0 = *reinterpret_cast<const f32x4 *>(src), x1 = *reinterpret_cast<const f32x4 *>(src + 4);
+      f32x4 x2 = *reinterpret_cast<const f32x4 *>(src + 8), x3 = *reinterpret_cast<const f32x4 *>(src + 12);
+      const float xs[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
 #pragma unroll
-        for (int k = 0; k < HG_MAX_K; k++) {
-          if (k < kg) {                                           // wave-uniform
-            const float *wr = p.w + ((long long)(o0 + k) * 9 + tap) * cg + ch * HG_CG + wave * 16;   // wave-uniform address
+      for (int k = 0; k < HG_MAX_K; k++) {
+        if (k < kg) {                                           // wave-uniform
+          const float *wr = p.w + ((long long)(o0 + k) * 9 + tap) * cg + ch * HG_CG + wave * 16;   // wave-uniform address
 #pragma unroll
-            for (int c = 0; c < 16; c++) acc[k] = fmaf(wr[c], xs[c], acc[k]);
-          }
+          for (int c = 0; c < 16; c++) acc[k] = fmaf(wr[c], xs[c], acc[k]);
         }
       }
     }
-    __syncthreads();
+    if (ch == p.chunks - 1) {              // group finished: combine the four channel quarters
 #pragma unroll
-    for (int k = 0; k < HG_MAX_K; k++) part[wave][lane][k] = acc[k];
-    __syncthreads();
-    if (wave == 0) {
-      const int oy = oy0 + py, ox = ox0 + px;
-      if (oy < p.h && ox < p.w_) {
-        float *dst = p.out + ((long long)(b * p.h + oy) * p.w_ + ox) * p.ld_out + o0;
-        for (int k = 0; k < kg; k++)
-          dst[k] = part[0][lane][k] + part[1][lane][k] + part[2][lane][k] + part[3][lane][k] + p.bias[o0 + k];
+      for (int k = 0; k < HG_MAX_K; k++) { part[wave][lane][k] = acc[k]; acc[k] = 0.f; }
+      __syncthreads();
+      if (wave == 0) {
+        const int oy = oy0 + py, ox = ox0 + px;
+        if (oy < p.h && ox < p.w_) {
+          float *dst = p.out + ((long long)(b * p.h + oy) * p.w_ + ox) * p.ld_out + o0;
+          for (int k = 0; k < kg; k++)
+            dst[k] = part[0][lane][k] + part[1][lane][k] + part[2][lane][k] + part[3][lane][k] + p.bias[o0 + k];
+        }
       }
     }
   }
