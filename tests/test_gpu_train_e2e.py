@@ -150,3 +150,36 @@ def test_train_py_runs_and_loss_decreases(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), 'ckpt', 'checkpoint_epoch_2.pth'), map_location='cpu', weights_only=False)
     assert ck['epoch'] == 2 and ck['it'] == 8 and 'vfe.pfn_layers.0.linear.weight' in ck['model_state']
     assert all(torch.isfinite(v).all() for v in ck['model_state'].values() if v.dtype.is_floating_point)
+
+
+def test_training_step_degenerate_batches():
+    """frames without ground truth, without remote agents, and a batch of one frame: the step runs, losses and gradients stay finite"""
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer
+    from pcdet.config import EasyDict
+    g = load_golden('g7_train.npz')
+    model = _build(g)
+    opt = build_optimizer(model, EasyDict(g['meta']['optimization']))
+    opt.lr, opt.mom = 1e-4, 0.9
+    pts = g['points']
+    cases = []
+    gt0 = g['gt_boxes'].copy()
+    gt0[1] = 0.0                                                        # frame 1 has no boxes at all
+    cases.append((pts, gt0, [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}], 2))
+    cases.append((pts, np.zeros_like(g['gt_boxes']), [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}], 2))
+    one = pts[pts[:, 0] == 0]
+    cases.append((one, g['gt_boxes'][:1], [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}], 1))
+    ego_only = pts[pts[:, -1] == 1.0]                                   # no remote agent sent anything: fusion over the ego map alone
+    cases.append((ego_only, g['gt_boxes'], [{'se3_from_ego': {}}, {'se3_from_ego': {}}], 2))
+    for pts_c, gt_c, md, bs in cases:
+        model.train()
+        opt.zero_grad()
+        batch = {'points': torch.from_numpy(np.ascontiguousarray(pts_c)).to(DEV), 'batch_size': bs, 'metadata': md,
+                 'gt_boxes': torch.from_numpy(np.ascontiguousarray(gt_c)).to(DEV)}
+        ret, tb, _ = model(batch)
+        ret['loss'].backward()
+        assert np.isfinite(tb['loss_total']), tb
+        assert bool(torch.isfinite(opt.flat_g).all())
+        opt.clip_grad_norm(10.0)
+        opt.step()
+        assert bool(torch.isfinite(opt.flat_p).all())
