@@ -1,11 +1,12 @@
-"""Diagnostic: per-parameter gradient error of the HIP training step vs the float64 CPU oracle on the g7 fixture."""
+"""Diagnostic (not a test; run by hand on the GPU box: python tests/dbg_train_grad_bisect.py): per-parameter gradient error of the HIP
+training step vs the float64 / float32 CPU oracle on the g7 fixture, plus a bisection of the fusion backward against oracle probes."""
 import os
 import sys
 
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd'))
