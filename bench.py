@@ -193,6 +193,10 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
+    ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
+                    "agent: configs early / disco only -- each rank holds the points of ITS agents, one all-gather of raw points (early) or "
+                    "of compressed BEV maps (disco) per step, then the frames of the batch are dealt to the ranks (pcdet/models/sharded.py; "
+                    "strong scaling: the group processes ONE batch per step)")
     ap.add_argument('--train', action='store_true', help='config disco only: time full training iterations (forward + backward + '
                     'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
     args = ap.parse_args()
@@ -266,7 +270,22 @@ def main():
         ts['last_loss'] = tb['loss_total']
         return []
 
+    sharded_runner = None
+    if args.shard == 'agent':
+        if args.config not in ('early', 'disco') or args.train or args.graph:
+            raise SystemExit('--shard agent: inference of --config early | disco')
+        from pcdet.models import sharded
+        sharded_runner = (sharded.AgentShardedEarlyFusion if args.config == 'early' else sharded.AgentShardedMidFusion)(model)
+        # every rank generated the SAME batch (rank 0's streams); it keeps only the rows of its agents (round-robin over agents)
+        pts_np, metas = make_points(conf, batch, 0)
+        agent_of_row = pts_np[:, -1] if conf['layout'] == 'disco' else np.repeat(np.arange(conf['agents_in_cloud']), 60000)[None].repeat(batch, 0).reshape(-1)
+        mine = pts_np[(agent_of_row.astype(np.int64) % world) == rank]
+        pristine = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+
     def step():
+        if sharded_runner is not None:
+            _frames, preds_local = sharded_runner(pristine, batch, metas)
+            return preds_local
         if train_state is not None:
             return train_step()
         if graphed is not None:
@@ -297,29 +316,30 @@ def main():
         elapsed = float(t.item())
     n_boxes = int(sum(p['pred_boxes'].shape[0] for p in preds))
 
-    # instrumented pass (HIP events around the conv launches).  A training step contains a collective (the gradient all-reduce), so in
-    # that mode every rank has to take part in the three extra steps; only rank 0 records.
+    # instrumented pass (HIP events around the conv launches).  Training and agent-sharded steps contain collectives, so in those modes
+    # every rank has to take part in the three extra steps; only rank 0 records.
     timer = None
     if rank == 0:
         graphed = None                          # the instrumented pass runs eagerly (events around individual launches)
         timer = ConvTimer()
         timer.install()
-    if rank == 0 or (args.train and world > 1):
+    if rank == 0 or ((args.train or args.shard == 'agent') and world > 1):
         for _ in range(3):
             step()
     if rank == 0:
         cs = timer.summary()
         timer.remove()
-        frames = world * batch * args.steps
+        frames = (world if args.shard == 'frame' else 1) * batch * args.steps
         line = {
             'metric': 'frames/sec (60k-pt cloud per agent) through the PointPillars hot path', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': conf['name'] if not args.train else 'v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)',
                        'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
-                       'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': ('replicas x%d (frame-sharded)' % world) if not args.train else
+                       'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))
+                       if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
