@@ -151,20 +151,42 @@ class ConvTimer:
             timer.records.append((e0, e1, 2.0 * B * H * W * cout * 9 * cin, 1, -2 if big else -1))
             return r
         ops.conv3x3_winograd = timed_w
+        self._orig_b3 = ops.conv3x3_bf16x3
+
+        def timed_b3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = timer._orig_b3(x, packed, bias, cin, cout, cout_pad, stride=stride, relu=relu, out=out, in_ch_off=in_ch_off,
+                               out_ch_off=out_ch_off)
+            e1.record(s)
+            B, H, W, _ = x.shape
+            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+            timer.records.append((e0, e1, 2.0 * B * Ho * Wo * cout * 9 * cin, stride, -3))
+            return r
+        ops.conv3x3_bf16x3 = timed_b3
 
     def remove(self):
         from pcp_amd import ops
         ops.conv3x3 = self._orig
         ops.conv3x3_winograd = self._orig_w
+        ops.conv3x3_bf16x3 = self._orig_b3
 
     def summary(self):
         torch.cuda.synchronize()
         # dominant kernel = the fused Winograd 3x3 kernel (k_conv3x3_wino); falls back to the direct stride-1 instantiation
-        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -2]
-        self.dominant = 'k_conv3x3_wino<2> (3x3 s1 fused Winograd F(2x2,3x3), 64-tile workgroups, v_mfma_f32_32x32x2_f32)'
+        self.peak, self.exec_mult = MFMA_F32_PEAK_TFLOPS, 4.0 / 9.0
+        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -3 and st == 1]
+        self.dominant = 'k_conv3x3_bf16x3 (3x3 implicit GEMM, split-bf16 operands, 3 x v_mfma_f32_32x32x16_bf16 per product) [opt-in mode]'
+        if sel:
+            self.peak, self.exec_mult = 2500.0, 3.0                     # dense bf16 MFMA peak; three MFMAs per algorithmic product
+        else:
+            sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -2]
+            self.dominant = 'k_conv3x3_wino<2> (3x3 s1 fused Winograd F(2x2,3x3), 64-tile workgroups, v_mfma_f32_32x32x2_f32)'
         if not sel:
             sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if st == 1 and cp % 64 == 0]
             self.dominant = 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)'
+            self.exec_mult = 1.0
         allc = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records]
         t, f = sum(a for a, _ in sel), sum(b for _, b in sel)
         ta, fa = sum(a for a, _ in allc), sum(b for _, b in allc)
@@ -193,6 +215,9 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'bf16x3'],
+                    help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
+                         '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
     ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
                     "agent: configs early / disco only -- each rank holds the points of ITS agents, one all-gather of raw points (early) or "
                     "of compressed BEV maps (disco) per step, then the frames of the batch are dealt to the ranks (pcdet/models/sharded.py; "
@@ -201,6 +226,8 @@ def main():
                     'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
     args = ap.parse_args()
 
+    if args.conv_algo is not None:
+        os.environ['PCP_CONV_ALGO'] = args.conv_algo
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -334,7 +361,8 @@ def main():
             'metric': 'frames/sec (60k-pt cloud per agent) through the PointPillars hot path', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if os.environ.get('PCP_CONV_ALGO', 'auto') != 'bf16x3' else 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
+            'data': 'synthetic',
             'config': {'workload': conf['name'] if not args.train else 'v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)',
                        'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
@@ -343,15 +371,37 @@ def main():
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
-                         'achieved': round(cs['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(cs['tflops'] / MFMA_F32_PEAK_TFLOPS, 4),
+                         'achieved': round(cs['tflops'], 3), 'peak': timer.peak, 'unit': 'TFLOP/s',
+                         'frac': round(cs['tflops'] / timer.peak, 4),
                          'traffic': pmc_traffic('k_conv3x3_wino<2>') if (args.config == 'car' and 'wino' in timer.dominant) else None,
                          # Winograd executes 16/36 of the direct convolution's multiply-adds: fraction of the MFMA peak
                          # in EXECUTED flops (what the matrix pipe actually sustains)
-                         'executed_frac': round(cs['tflops'] * (4.0 / 9.0 if 'wino' in timer.dominant else 1.0) / MFMA_F32_PEAK_TFLOPS, 4),
+                         'executed_frac': round(cs['tflops'] * timer.exec_mult / timer.peak, 4),
                          'avg_launch_us': round(cs['avg_us'], 2), 'launches_per_step': cs['launches'] // 3,
                          'all_conv3x3_tflops': round(cs['all_conv_tflops'], 3), 'all_conv3x3_ms_per_step': round(cs['all_conv_ms'] / 3, 3)},
         }
+        if world == 1 and not args.train and not args.graph and args.shard == 'frame' and os.environ.get('PCP_CONV_ALGO', 'auto') == 'auto':
+            # informational: the same workload with the OPT-IN split-bf16 convolution arithmetic (never part of `value`)
+            os.environ['PCP_CONV_ALGO'] = 'bf16x3'
+            for m in model.modules():
+                if hasattr(m, 'invalidate_packed'):
+                    m.invalidate_packed()
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            alt = time.perf_counter() - t1
+            os.environ['PCP_CONV_ALGO'] = 'auto'
+            for m in model.modules():
+                if hasattr(m, 'invalidate_packed'):
+                    m.invalidate_packed()
+            line['optin_bf16x3'] = {'value': round(batch * args.steps / alt, 3), 'unit': 'frames/s', 'ms_per_step': round(1e3 * alt / args.steps, 4),
+                                    'note': 'NOT the headline: 3x3 conv products as split bf16 (hi + lo, 16 mantissa bits; 3 bf16 MFMAs per '
+                                            'product, f32 accumulate), ~1e-5 relative error, all parity tests pass at unchanged tolerances; '
+                                            'enable with --conv-algo bf16x3 / PCP_CONV_ALGO=bf16x3'}
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
         else:

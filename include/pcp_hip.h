@@ -112,6 +112,12 @@ int pcp_conv3x3(const pcp_conv3x3_t *desc, const float *in, const float *w_packe
 int pcp_conv3x3_winograd(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
                          void *stream);
 
+/* OPT-IN alternative arithmetic for the same operation (stride 1 or 2): fp32 tensors in and out, products on the BF16 matrix cores with
+ * every operand split in two bf16 halves (hi + lo, 16 mantissa bits) and three MFMAs per product, fp32 accumulation: ~1e-5 relative
+ * error (the reference's own GPU path, cuDNN with TF32 allowed, keeps 10 bits).  cin % 16 == 0, cout_pad % 64 == 0; weights packed by
+ * pcp_amd/pack.py::pack_conv3x3_bf16x3 as bf16 [cin/16][cout_pad/64][hi|lo][9][2][64][8].  Never selected by default. */
+int pcp_conv3x3_bf16x3(const pcp_conv3x3_t *desc, const float *in, const void *w_packed, const float *bias, float *out, void *stream);
+
 /* Grouped 3x3 conv with tiny outputs (the final convs of the CenterHead branches, center_head.py:39; HunterJr's 768 -> 2
  * weight conv, hunter_jr.py:151): group g reads input channels [g cin_g, (g+1) cin_g) and produces output channels
  * [off[g], off[g+1]) (1..4 each), bias added, no activation.  cin_per_group % 64 == 0.

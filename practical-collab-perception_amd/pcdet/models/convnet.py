@@ -11,23 +11,41 @@ from pcp_amd import lib, ops, pack
 # fused Winograd F(2x2,3x3) needs enough workgroups to fill the 256 CUs; below that the direct kernel's smaller tiles win
 # (measured on MI355X, tools/bench_conv.py: >= 256 workgroups -> x1.35 .. x2.0 over the direct kernel)
 WINOGRAD_MIN_WORKGROUPS = 256
-CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd
+CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd | bf16x3 (opt-in: split-bf16 products, fp32 accumulate)
+
+
+def conv_algo():
+    return os.environ.get('PCP_CONV_ALGO', CONV_ALGO)
 
 
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3')
 
     def _use_winograd(self, x):
-        if self.kind != '3x3' or getattr(self, 'wino', None) is None or CONV_ALGO == 'direct':
+        algo = conv_algo()
+        if self.kind != '3x3' or getattr(self, 'wino', None) is None or algo == 'direct':
             return False
-        if CONV_ALGO == 'winograd':
+        if algo == 'winograd':
             return True
         B, H, W, _ = x.shape
         # workgroups of the 32-tile instantiation (8 rows x 16 columns of pixels x 64 channels), the finest the library uses
         return B * ((H + 7) // 8) * ((W + 15) // 16) * (self.wino[2] // 64) >= WINOGRAD_MIN_WORKGROUPS
 
+    def _use_bf16x3(self, x):
+        """opt-in only (PCP_CONV_ALGO=bf16x3), and only where the launch fills the chip (>= 256 workgroups of 16x16 px x 64 ch)"""
+        if self.kind != '3x3' or getattr(self, 'b3', None) is None or conv_algo() != 'bf16x3':
+            return False
+        B, H, W, _ = x.shape
+        Ho, Wo = (H - 1) // self.stride + 1, (W - 1) // self.stride + 1
+        th = 16 if self.stride == 1 else 8
+        return B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (self.b3[2] // 64) >= 256
+
     def run(self, x, out=None, in_ch_off=0, out_ch_off=0):
+        if self._use_bf16x3(x):
+            w3, b3, cp3 = self.b3
+            return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
+                                      in_ch_off=in_ch_off, out_ch_off=out_ch_off)
         if self._use_winograd(x):
             u, ub, ucp = self.wino
             return ops.conv3x3_winograd(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
@@ -56,6 +74,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc.relu = relu
     pc.stride = 1
     pc.wino = None
+    pc.b3 = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -78,6 +97,8 @@ def pack_conv_module(conv, bn=None, relu=True):
         pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
         if s == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48:
             pc.wino = pack.pack_conv3x3_winograd(w, b)
+        if conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48:
+            pc.b3 = pack.pack_conv3x3_bf16x3(w, b)
     elif k == 1 and s == 1:
         pc.kind = 'plain'
         pc.w, pc.b, pc.cout_pad = pack.pack_plain(w, b)
@@ -98,4 +119,5 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.cin, pc.cout = w.shape[1], w.shape[0]
     pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
     pc.wino = pack.pack_conv3x3_winograd(w, b) if (stride == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48) else None
+    pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
     return pc

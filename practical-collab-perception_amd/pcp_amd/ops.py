@@ -137,6 +137,22 @@ def conv3x3_winograd(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None
     return out
 
 
+def conv3x3_bf16x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+    """opt-in split-bf16 arithmetic (see include/pcp_hip.h); same tensor contract as conv3x3"""
+    _need_cuda(x, packed, bias, out)
+    L = _lib.load()
+    B, H, W, ld_in = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    assert out.shape[:3] == (B, Ho, Wo) and x.is_contiguous() and out.is_contiguous()
+    assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3]
+    d = Conv3x3(B, H, W, cin, cout, cout_pad, stride, ld_in, out.shape[3], 1 if relu else 0)
+    check(L.pcp_conv3x3_bf16x3(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
+          'pcp_conv3x3_bf16x3')
+    return out
+
+
 def conv3x3_grouped_small(x, weights, bias, offsets, out):
     """x: (B, H, W, ld_in); weights (n_out, 9, cin_per_group), cin_per_group % 64 == 0; offsets: python list of groups+1 ints."""
     _need_cuda(x, weights, bias, out)

@@ -80,6 +80,22 @@ def pack_conv3x3_winograd(w, bias):
     return packed, pad_bias(bias, cout_pad), cout_pad
 
 
+def pack_conv3x3_bf16x3(w, bias):
+    """w: [cout, cin, 3, 3] (BN-folded) -> split hi = bf16(w), lo = bf16(w - hi), packed bf16 [cin/16][cout_pad/64][hi|lo][9][2][64][8]
+    (k-half, cout, 8 channels: the fragment image of v_mfma_f32_32x32x16_bf16).  Returns (packed int16 view, bias_pad, cout_pad)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % CK == 0
+    cout_pad = round_up(cout, 64)
+    wp = w.new_zeros((cout_pad, cin, 9))
+    wp[:cout] = w.reshape(cout, cin, 9).float()
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    x = torch.stack([hi, lo], 0)                                                   # (hl, cout_pad, cin, tap)
+    x = x.view(2, cout_pad // 64, 64, cin // CK, 2, 8, 9)                          # (hl, ct, n, s, h, j, tap)
+    packed = x.permute(3, 1, 0, 6, 4, 2, 5).contiguous()                           # (s, ct, hl, tap, h, n, j)
+    return packed.view(torch.int16), pad_bias(bias, cout_pad), cout_pad
+
+
 def winograd_reference(x, packed, bias, cout):
     """Plain-torch evaluation of the packed Winograd form (validates transforms + layout on the CPU): x (B, cin, H, W), H, W even."""
     nsl, _sixteen, cout_pad, _ck = packed.shape

@@ -43,13 +43,15 @@ def main():
         b = torch.zeros(cout)
         pd, bd, cpd = pack.pack_conv3x3(w, b)
         pw, bw, cpw = pack.pack_conv3x3_winograd(w, b)
-        pd, bd, pw, bw = pd.to(d), bd.to(d), pw.to(d), bw.to(d)
+        p3, b3, cp3 = pack.pack_conv3x3_bf16x3(w, b)
+        pd, bd, pw, bw, p3, b3 = pd.to(d), bd.to(d), pw.to(d), bw.to(d), p3.to(d), b3.to(d)
         out = torch.empty((B, H, W, cout), device=d)
         flops = 2.0 * B * H * W * cout * 9 * cin
         td = timeit(lambda: ops.conv3x3(x, pd, bd, cin, cout, cpd, out=out))
         tw = timeit(lambda: ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=out))
-        print('%-36s direct %8.1f us %6.1f TF | winograd %8.1f us %6.1f TF (algorithmic) | x%.2f' %
-              (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw))
+        t3 = timeit(lambda: ops.conv3x3_bf16x3(x, p3, b3, cin, cout, cp3, out=out))
+        print('%-36s direct %8.1f us %6.1f TF | winograd %8.1f us %6.1f TF (algorithmic) | x%.2f | bf16x3 (opt-in) %8.1f us %6.1f TF' %
+              (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw, t3 * 1e6, flops / t3 / 1e12))
 
 
 if __name__ == '__main__':

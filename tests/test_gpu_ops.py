@@ -627,3 +627,25 @@ def test_topk_boxes_selection_ties_and_masks():
         assert np.array_equal(ob[b, :cnt[b]].cpu().numpy(), boxes[b, order])
         assert np.array_equal(ol[b, :cnt[b]].cpu().numpy(), labels[b, order])
     assert cnt[2] == 0 and 0 < cnt[1] < k and cnt[0] == k
+
+
+@pytest.mark.parametrize('cin,cout,h,w,stride,relu,batch', [(64, 64, 40, 56, 1, True, 2), (128, 128, 33, 17, 1, False, 1), (384, 64, 32, 32, 1, True, 2),
+                                                            (64, 128, 64, 48, 2, True, 2), (16, 200, 21, 35, 1, True, 1)])
+def test_conv3x3_bf16x3_optin_matches_torch_cpu(cin, cout, h, w, stride, relu, batch):
+    """opt-in split-bf16 arithmetic (three bf16 MFMAs per product, fp32 accumulate): measured error ~1e-5 relative to the output scale,
+    asserted at 1e-4 (10x inside the path's 1e-3 bar; the fp32 kernels are asserted at the same 1e-4)."""
+    ops = _ops()
+    d = dev()
+    from pcp_amd import pack
+    x = torch.from_numpy(_rand(300 + cin, (batch, cin, h, w)))
+    wt = torch.from_numpy(_rand(301 + cout, (cout, cin, 3, 3), -0.08, 0.08))
+    bs = torch.from_numpy(_rand(302, (cout,), -0.3, 0.3))
+    want = F.conv2d(F.pad(x, (1, 1, 1, 1)), wt, bs, stride=stride)
+    if relu:
+        want = torch.relu(want)
+    p3, b3, cp3 = pack.pack_conv3x3_bf16x3(wt, bs)
+    out = ops.conv3x3_bf16x3(ops.as_nhwc(x.to(d)), p3.to(d), b3.to(d), cin, cout, cp3, stride=stride, relu=relu)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    assert err < 1e-4, err
