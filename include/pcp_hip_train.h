@@ -168,10 +168,11 @@ int pcp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
  * Per-step weight repacking of a 3x3 conv (the optimizer rewrites the weights every iteration): w is PyTorch's (cout, cin, 3, 3);
  * transpose = 0 packs the forward conv, transpose = 1 the conv that computes its DATA gradient (channel roles swapped, taps
  * flipped: the autograd "conv_transpose" of nn.Conv2d).  direct: [I/16][9][O_pad][16]; winograd: U = G g G^T as [I/8][16][O_pad][8]
- * (layouts of pcp_conv3x3 / pcp_conv3x3_winograd); either may be NULL.  (I, O) = (cin, cout) or swapped.
+ * (layouts of pcp_conv3x3 / pcp_conv3x3_winograd); split_bf16: the hi / lo bf16 layout of pcp_conv3x3_bf16x3 (opt-in arithmetic).
+ * Any of the three may be NULL.  (I, O) = (cin, cout) or swapped.
  * ------------------------------------------------------------------------------------------------------------------ */
 int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *direct, int32_t direct_cout_pad,
-                     float *winograd, int32_t winograd_cout_pad, void *stream);
+                     float *winograd, int32_t winograd_cout_pad, void *split_bf16, int32_t split_cout_pad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,8 @@ struct PackParams {
   int direct_opad;
   float *wino;           // may be NULL
   int wino_opad;
+  __bf16 *b3;            // may be NULL: split-bf16 layout of conv_bf16x3.hip [I/16][O_pad/64][hi|lo][9][2][64][8]
+  int b3_opad;
 };
 
 __device__ __forceinline__ float eff(const PackParams &p, int o, int i, int tap) {
@@ -34,6 +36,28 @@ __global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
       const int tap = (int)(r % 9);
       const int s = (int)(r / 9);
       p.direct[t] = o < O ? eff(p, o, s * 16 + k, tap) : 0.f;
+    }
+  }
+  if (p.b3) {
+    const long long total = (long long)(I / 16) * p.b3_opad * 9 * 16;              // one thread per (slice, cout, tap, channel)
+    if (t < total) {
+      const int j = (int)(t & 7), hh = (int)((t >> 3) & 1);
+      long long r = t >> 4;
+      const int n = (int)(r & 63);
+      r >>= 6;
+      const int tap = (int)(r % 9);
+      r /= 9;
+      const int n_ct = p.b3_opad / 64;
+      const int ct = (int)(r % n_ct);
+      const int sl = (int)(r / n_ct);
+      const int o = ct * 64 + n;
+      const float v = o < O ? eff(p, o, sl * 16 + hh * 8 + j, tap) : 0.f;
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      const long long base = ((long long)sl * n_ct + ct) * (2 * 9 * 2 * 64 * 8);
+      const long long off = ((long long)(tap * 2 + hh) * 64 + n) * 8 + j;
+      p.b3[base + off] = hi;
+      p.b3[base + 9 * 2 * 64 * 8 + off] = lo;
     }
   }
   if (p.wino) {
@@ -70,14 +94,16 @@ __global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
 }  // namespace
 
 extern "C" int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *direct, int32_t direct_cout_pad,
-                                float *winograd, int32_t winograd_cout_pad, void *stream) {
-  if (!w || cout <= 0 || cin <= 0 || (!direct && !winograd)) return PCP_ERR_ARG;
+                                float *winograd, int32_t winograd_cout_pad, void *split_bf16, int32_t split_cout_pad, void *stream) {
+  if (!w || cout <= 0 || cin <= 0 || (!direct && !winograd && !split_bf16)) return PCP_ERR_ARG;
   const int O = transpose ? cin : cout, I = transpose ? cout : cin;
   if (direct && ((I & 15) || direct_cout_pad < O)) return PCP_ERR_ARG;
   if (winograd && ((I & 7) || winograd_cout_pad < O)) return PCP_ERR_ARG;
-  PackParams p{w, cout, cin, transpose, direct, direct_cout_pad, winograd, winograd_cout_pad};
+  if (split_bf16 && ((I & 15) || split_cout_pad < O || (split_cout_pad & 63))) return PCP_ERR_ARG;
+  PackParams p{w, cout, cin, transpose, direct, direct_cout_pad, winograd, winograd_cout_pad, (__bf16 *)split_bf16, split_cout_pad};
   long long n = 0;
-  if (direct) n = (long long)(I / 16) * 9 * direct_cout_pad * 16;
+  if (split_bf16) n = (long long)(I / 16) * split_cout_pad * 9 * 16;
+  if (direct) { const long long m = (long long)(I / 16) * 9 * direct_cout_pad * 16; if (m > n) n = m; }
   if (winograd) { const long long m = (long long)(I / 8) * winograd_cout_pad * 8; if (m > n) n = m; }
   hipLaunchKernelGGL(k_pack3x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
   PCP_CHECK_LAUNCH();

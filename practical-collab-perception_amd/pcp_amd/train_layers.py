@@ -108,19 +108,29 @@ class ConvBNAct:
                     bufs['fw_w'] = torch.empty((self.cin // 8, 16, pack.round_up(self.cout, 64), 8), dtype=torch.float32, device=dev)
                 if self.cout % pack.WINO_CK == 0 and self.cin >= 48:
                     bufs['bw_w'] = torch.empty((self.cout // 8, 16, pack.round_up(self.cin, 64), 8), dtype=torch.float32, device=dev)
+                if os.environ.get('PCP_CONV_ALGO', 'auto') == 'bf16x3':            # opt-in split-bf16 arithmetic (conv_bf16x3.hip)
+                    if self.cin % 16 == 0 and self.cout >= 48:
+                        bufs['fw_3'] = torch.empty((self.cin // 16) * pack.round_up(self.cout, 64) * 9 * 16 * 2, dtype=torch.int16, device=dev)
+                    if self.cout % 16 == 0 and self.cin >= 48:
+                        bufs['bw_3'] = torch.empty((self.cout // 16) * pack.round_up(self.cin, 64) * 9 * 16 * 2, dtype=torch.int16, device=dev)
                 cache['buf'] = bufs
             bufs = cache['buf']
             wc = w.contiguous()
             fo, bo = bufs['fw_d'].shape[2], bufs['bw_d'].shape[2]
             fww, bww = bufs.get('fw_w'), bufs.get('bw_w')
-            tops.pack_conv3x3(wc, False, bufs['fw_d'], fo, fww, fww.shape[2] if fww is not None else 0)
-            tops.pack_conv3x3(wc, True, bufs['bw_d'], bo, bww, bww.shape[2] if bww is not None else 0)
+            f3, b3 = bufs.get('fw_3'), bufs.get('bw_3')
+            tops.pack_conv3x3(wc, False, bufs['fw_d'], fo, fww, fww.shape[2] if fww is not None else 0, f3, pack.round_up(self.cout, 64))
+            tops.pack_conv3x3(wc, True, bufs['bw_d'], bo, bww, bww.shape[2] if bww is not None else 0, b3, pack.round_up(self.cin, 64))
             fw = dict(direct=(bufs['fw_d'], bias_for(fo, self.cout), fo))
             if fww is not None:
                 fw['wino'] = (fww, bias_for(fww.shape[2], self.cout), fww.shape[2])
+            if f3 is not None:
+                fw['b3'] = (f3, bias_for(pack.round_up(self.cout, 64), self.cout), pack.round_up(self.cout, 64))
             bw = dict(direct=(bufs['bw_d'], zeros, bo))
             if bww is not None:
                 bw['wino'] = (bww, zeros, bww.shape[2])
+            if b3 is not None:
+                bw['b3'] = (b3, zeros, pack.round_up(self.cin, 64))
         else:
             zb = lambda n: zeros[:n]
             fb = lambda n: (b if b is not None else zeros[:n])
@@ -145,7 +155,13 @@ class ConvBNAct:
     @staticmethod
     def _run3x3(forms, x, cin, cout, stride, out, in_off, out_off):
         B, H, W, _ = x.shape
-        algo = os.environ.get('PCP_CONV_ALGO', 'auto')                  # auto | direct | winograd (same switch as inference)
+        algo = os.environ.get('PCP_CONV_ALGO', 'auto')                  # auto | direct | winograd | bf16x3 (same switch as inference)
+        if algo == 'bf16x3' and 'b3' in forms:
+            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+            th = 16 if stride == 1 else 8
+            if B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (forms['b3'][2] // 64) >= 256:
+                w3, b3, cp3 = forms['b3']
+                return ops.conv3x3_bf16x3(x, w3, b3, cin, cout, cp3, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
         big = B * ((H + 7) // 8) * ((W + 15) // 16) * (forms['wino'][2] // 64) >= 256 if 'wino' in forms else False
         if stride == 1 and 'wino' in forms and algo != 'direct' and (big or algo == 'winograd'):
             u, ub, ucp = forms['wino']

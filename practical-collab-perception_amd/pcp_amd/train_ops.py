@@ -279,10 +279,10 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
 # per-step weight repacking
 # ---------------------------------------------------------------------------------------------------------------------
 
-def pack_conv3x3(w, transpose, direct=None, direct_opad=0, wino=None, wino_opad=0):
+def pack_conv3x3(w, transpose, direct=None, direct_opad=0, wino=None, wino_opad=0, b3=None, b3_opad=0):
     """w: (cout, cin, 3, 3) contiguous CUDA.  Fills the given pre-allocated layout buffers in one launch."""
-    _need_cuda(w, direct, wino)
+    _need_cuda(w, direct, wino, b3)
     L = _lib.load()
     assert w.is_contiguous() and w.dtype == torch.float32
-    check(L.pcp_pack_conv3x3(_p(w), w.shape[0], w.shape[1], 1 if transpose else 0, _p(direct), direct_opad, _p(wino), wino_opad, _stream()),
-          'pcp_pack_conv3x3')
+    check(L.pcp_pack_conv3x3(_p(w), w.shape[0], w.shape[1], 1 if transpose else 0, _p(direct), direct_opad, _p(wino), wino_opad, _p(b3), b3_opad,
+                             _stream()), 'pcp_pack_conv3x3')

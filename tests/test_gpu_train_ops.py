@@ -428,3 +428,18 @@ def test_fused_adam_step_matches_torch_adam_with_clipping():
         assert abs(float(sq.sqrt()) - float(norm)) <= 1e-5 * float(norm)
         tops.adam_step(p, gg, m, v, lr, mom, 0.99, 1e-8, wd, step, max_norm=max_norm, sqnorm=sq)
         _close(p, ref, 2e-6, 'param after step %d' % step)
+
+
+def test_conv_bn_act_layer_with_optin_bf16x3(monkeypatch):
+    """training layer forward + data gradient through the opt-in split-bf16 conv kernel (weights re-split on the device every step by
+    pcp_pack_conv3x3); same 3e-4 bar as the fp32 kernels.  No ReLU here: a 1e-5 forward difference flips the mask of the few
+    pre-activations within 1e-5 of zero, which moves single dx elements by O(|dout|) -- a property of the discontinuity, not of the
+    kernel (the e2e training test bounds that effect globally)"""
+    monkeypatch.setenv('PCP_CONV_ALGO', 'bf16x3')
+    seed = 977
+    conv = _mk_conv('c3s1', 64, 128, False, seed)
+    bn = _mk_bn(128, seed)
+    x = _u(seed, 5, (4, 64, 128, 128))
+    pairs = _layer_case(conv, bn, False, x, seed)
+    for k, (mine, ref) in pairs.items():
+        _close(mine, ref, 3e-4, 'bf16x3/' + k)
