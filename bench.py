@@ -165,12 +165,26 @@ class ConvTimer:
             timer.records.append((e0, e1, 2.0 * B * Ho * Wo * cout * 9 * cin, stride, -3))
             return r
         ops.conv3x3_bf16x3 = timed_b3
+        self._orig_w4 = ops.conv3x3_winograd4
+        self.w4 = []
+
+        def timed_w4(x, packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+            # three launches (input transform, batched GEMM, output transform): the library's measurement entry point brackets each with
+            # HIP events on the launch stream (pcp_conv3x3_winograd4_timed)
+            st = []
+            r = timer._orig_w4(x, packed, bias, cin, cout, cout_pad, relu=relu, out=out, in_ch_off=in_ch_off, out_ch_off=out_ch_off,
+                               stage_times=st)
+            B, H, W, _ = x.shape
+            timer.w4.append(st[0] + (2.0 * B * H * W * cout * 9 * cin,))
+            return r
+        ops.conv3x3_winograd4 = timed_w4
 
     def remove(self):
         from pcp_amd import ops
         ops.conv3x3 = self._orig
         ops.conv3x3_winograd = self._orig_w
         ops.conv3x3_bf16x3 = self._orig_b3
+        ops.conv3x3_winograd4 = self._orig_w4
 
     def summary(self):
         torch.cuda.synchronize()
@@ -188,10 +202,23 @@ class ConvTimer:
             self.dominant = 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)'
             self.exec_mult = 1.0
         allc = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records]
+        allc += [((a + b + c) * 1e-3, alg) for (a, b, c, _gf, alg) in self.w4]
+        extra = {}
+        if self.w4 and self.peak == MFMA_F32_PEAK_TFLOPS:
+            # dominant kernel = the batched GEMM of the F(4x4,3x3) path: its executed flops ARE its algorithmic work
+            sel = [(b * 1e-3, gf) for (_a, b, _c, gf, _alg) in self.w4]
+            self.dominant = ('k_w4_gemm (36 batched GEMMs [tiles x cin] x [cin x cout] of the Winograd F(4x4,3x3) wide-layer convolutions, '
+                             '128x128x32 LDS tiles, v_mfma_f32_32x32x2_f32)')
+            self.exec_mult = 1.0
+            n = len(self.w4)
+            extra = {'winograd4_avg_us': {'input_transform': round(1e3 * sum(r[0] for r in self.w4) / n, 2),
+                                          'gemm': round(1e3 * sum(r[1] for r in self.w4) / n, 2),
+                                          'output_transform': round(1e3 * sum(r[2] for r in self.w4) / n, 2)},
+                     'winograd4_conv_algorithmic_tflops': round(sum(r[4] for r in self.w4) / sum(r[0] + r[1] + r[2] for r in self.w4) / 1e9, 3)}
         t, f = sum(a for a, _ in sel), sum(b for _, b in sel)
         ta, fa = sum(a for a, _ in allc), sum(b for _, b in allc)
         return dict(launches=len(sel), avg_us=1e6 * t / max(len(sel), 1), tflops=f / t / 1e12 if t > 0 else 0.0,
-                    all_conv_launches=len(allc), all_conv_tflops=fa / ta / 1e12 if ta > 0 else 0.0, all_conv_ms=1e3 * ta)
+                    all_conv_launches=len(allc), all_conv_tflops=fa / ta / 1e12 if ta > 0 else 0.0, all_conv_ms=1e3 * ta, extra=extra)
 
 
 def pmc_traffic(kernel_key):
@@ -215,7 +242,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
-    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'bf16x3'],
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3'],
                     help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
                          '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
     ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
@@ -373,10 +400,11 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
                          'achieved': round(cs['tflops'], 3), 'peak': timer.peak, 'unit': 'TFLOP/s',
                          'frac': round(cs['tflops'] / timer.peak, 4),
-                         'traffic': pmc_traffic('k_conv3x3_wino<2>') if (args.config == 'car' and 'wino' in timer.dominant) else None,
-                         # Winograd executes 16/36 of the direct convolution's multiply-adds: fraction of the MFMA peak
-                         # in EXECUTED flops (what the matrix pipe actually sustains)
-                         'executed_frac': round(cs['tflops'] * timer.exec_mult / timer.peak, 4),
+                         'traffic': (pmc_traffic('k_w4_gemm' if 'k_w4_gemm' in timer.dominant else 'k_conv3x3_wino<2>')
+                                     if (args.config == 'car' and ('wino' in timer.dominant or 'k_w4_gemm' in timer.dominant)) else None),
+                         # the fused Winograd F(2x2) kernel executes 16/36 of the direct convolution's multiply-adds: fraction of the MFMA
+                         # peak in EXECUTED flops (what the matrix pipe actually sustains); 1:1 for the GEMM kernel
+                         'executed_frac': round(cs['tflops'] * timer.exec_mult / timer.peak, 4), **cs['extra'],
                          'avg_launch_us': round(cs['avg_us'], 2), 'launches_per_step': cs['launches'] // 3,
                          'all_conv3x3_tflops': round(cs['all_conv_tflops'], 3), 'all_conv3x3_ms_per_step': round(cs['all_conv_ms'] / 3, 3)},
         }

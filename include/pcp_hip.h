@@ -112,6 +112,21 @@ int pcp_conv3x3(const pcp_conv3x3_t *desc, const float *in, const float *w_packe
 int pcp_conv3x3_winograd(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
                          void *stream);
 
+/* Same operation for the wide stride-1 layers (cin >= 256) as Winograd F(4x4,3x3) in three launches through a caller-owned
+ * workspace: input transform -> 36 batched fp32-MFMA GEMMs [tiles x cin] x [cin x cout] -> output transform + bias + ReLU.  4x fewer
+ * multiplies than the direct form, fp32 arithmetic and accumulation throughout; transform rounding ~2e-5 of the output scale.
+ * cin % 32 == 0, cout % 4 == 0, cout_pad % 128 == 0, ld_in % 4 == 0, ld_out % 4 == 0, all pointers 16-byte aligned;
+ * weights packed by pcp_amd/pack.py::pack_conv3x3_winograd4 as U = G g G^T: [36 (i*6+j)][cout_pad][cin].
+ * workspace: pcp_conv3x3_winograd4_workspace_bytes(desc) bytes of device memory (contents undefined before and after). */
+int pcp_conv3x3_winograd4_workspace_bytes(const pcp_conv3x3_t *desc, size_t *bytes);
+int pcp_conv3x3_winograd4(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                          void *workspace, void *stream);
+/* Measurement variant (bench.py's instrumented pass): same launches bracketed by HIP events on `stream`; waits for them and returns
+ * the duration of each launch in milliseconds (stage_ms_host[3] = input transform, batched GEMM, output transform) and the flops the
+ * GEMM launch executes (2 * 36 * tiles_padded * cin * cout_pad; may be NULL). */
+int pcp_conv3x3_winograd4_timed(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                                void *workspace, void *stream, float *stage_ms_host, double *gemm_flops_host);
+
 /* OPT-IN alternative arithmetic for the same operation (stride 1 or 2): fp32 tensors in and out, products on the BF16 matrix cores with
  * every operand split in two bf16 halves (hi + lo, 16 mantissa bits) and three MFMAs per product, fp32 accumulation: ~1e-5 relative
  * error (the reference's own GPU path, cuDNN with TF32 allowed, keeps 10 bits).  cin % 16 == 0, cout_pad % 64 == 0; weights packed by

@@ -11,7 +11,12 @@ from pcp_amd import lib, ops, pack
 # fused Winograd F(2x2,3x3) needs enough workgroups to fill the 256 CUs; below that the direct kernel's smaller tiles win
 # (measured on MI355X, tools/bench_conv.py: >= 256 workgroups -> x1.35 .. x2.0 over the direct kernel)
 WINOGRAD_MIN_WORKGROUPS = 256
-CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd | bf16x3 (opt-in: split-bf16 products, fp32 accumulate)
+# F(4x4,3x3) through memory (three launches, csrc/wino4.hip) wins on the wide layers once its batched GEMM fills the chip twice over
+# (tools/bench_conv.py on MI355X, 4 frames: 768->768 @128 x1.50, 384->384 @128 x1.26, 128->384 @128 x1.20, 256->256 @64 x1.16 over the fused
+# F(2x2) kernel; narrower outputs or fewer tiles lose)
+WINOGRAD4_MIN_COUT = 256
+WINOGRAD4_MIN_WORKGROUPS = 512
+CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | bf16x3 (opt-in: split-bf16 products)
 
 
 def conv_algo():
@@ -20,7 +25,17 @@ def conv_algo():
 
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4')
+
+    def _use_winograd4(self, x):
+        algo = conv_algo()
+        if self.kind != '3x3' or getattr(self, 'w4', None) is None or algo in ('direct', 'winograd', 'bf16x3'):
+            return False
+        if algo == 'winograd4':
+            return True
+        B, H, W, _ = x.shape
+        tiles = B * ((H + 3) // 4) * ((W + 3) // 4)
+        return 36 * ((tiles + 127) // 128) * (self.w4[2] // 128) >= WINOGRAD4_MIN_WORKGROUPS
 
     def _use_winograd(self, x):
         algo = conv_algo()
@@ -46,6 +61,10 @@ class PackedConv:
             w3, b3, cp3 = self.b3
             return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
                                       in_ch_off=in_ch_off, out_ch_off=out_ch_off)
+        if self._use_winograd4(x):
+            u, ub, ucp = self.w4
+            return ops.conv3x3_winograd4(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                         out_ch_off=out_ch_off)
         if self._use_winograd(x):
             u, ub, ucp = self.wino
             return ops.conv3x3_winograd(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
@@ -56,6 +75,11 @@ class PackedConv:
         mode = {'plain': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[self.kind]
         return ops.pointwise(x, self.w, self.b, mode, self.cin, self.cout, self.cout_pad, relu=self.relu, out=out,
                              in_ch_off=in_ch_off, out_ch_off=out_ch_off)
+
+
+def _winograd4_shape(cin, cout, stride):
+    return (stride == 1 and cin % pack.WINO4_CK == 0 and cin >= 128 and cout % 4 == 0 and cout >= WINOGRAD4_MIN_COUT
+            and conv_algo() not in ('direct', 'winograd', 'bf16x3'))
 
 
 def _fold(conv, bn, out_axis):
@@ -75,6 +99,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc.stride = 1
     pc.wino = None
     pc.b3 = None
+    pc.w4 = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -99,6 +124,8 @@ def pack_conv_module(conv, bn=None, relu=True):
             pc.wino = pack.pack_conv3x3_winograd(w, b)
         if conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48:
             pc.b3 = pack.pack_conv3x3_bf16x3(w, b)
+        if _winograd4_shape(pc.cin, pc.cout, s):
+            pc.w4 = pack.pack_conv3x3_winograd4(w, b)
     elif k == 1 and s == 1:
         pc.kind = 'plain'
         pc.w, pc.b, pc.cout_pad = pack.pack_plain(w, b)
@@ -120,4 +147,5 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
     pc.wino = pack.pack_conv3x3_winograd(w, b) if (stride == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48) else None
     pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
+    pc.w4 = pack.pack_conv3x3_winograd4(w, b) if _winograd4_shape(pc.cin, pc.cout, stride) else None
     return pc

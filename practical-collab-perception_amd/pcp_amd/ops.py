@@ -137,6 +137,46 @@ def conv3x3_winograd(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None
     return out
 
 
+_W4_WORKSPACE = {}
+
+
+def _w4_workspace(device, nbytes):
+    """one grow-only scratch buffer per device for the F(4x4,3x3) transforms (V and M, ~0.9 GB for 768 -> 768 at 4 frames); the three
+    launches of a call consume it in stream order, so consecutive calls on the same stream can share it"""
+    buf = _W4_WORKSPACE.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _W4_WORKSPACE[device] = buf
+    return buf
+
+
+def conv3x3_winograd4(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0, stage_times=None):
+    """stride-1 3x3 conv of a wide layer through Winograd F(4x4,3x3) (transform, 36 batched MFMA GEMMs, transform); same tensor
+    contract as conv3x3.  stage_times: optional list; when given the call is synchronous and appends
+    (input_ms, gemm_ms, output_ms, gemm_flops) measured with HIP events on the launch stream."""
+    _need_cuda(x, u_packed, bias, out)
+    L = _lib.load()
+    B, H, W, ld_in = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    assert out.shape[:3] == (B, H, W) and x.is_contiguous() and out.is_contiguous()
+    assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3]
+    d = Conv3x3(B, H, W, cin, cout, cout_pad, 1, ld_in, out.shape[3], 1 if relu else 0)
+    nbytes = ctypes.c_size_t(0)
+    check(L.pcp_conv3x3_winograd4_workspace_bytes(ctypes.byref(d), ctypes.byref(nbytes)), 'pcp_conv3x3_winograd4_workspace_bytes')
+    ws = _w4_workspace(x.device, nbytes.value)
+    if stage_times is not None:
+        ms = (ctypes.c_float * 3)()
+        fl = ctypes.c_double(0.0)
+        check(L.pcp_conv3x3_winograd4_timed(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(u_packed), _p(bias), _chan_ptr(out, out_ch_off),
+                                            _p(ws), _stream(), ms, ctypes.byref(fl)), 'pcp_conv3x3_winograd4_timed')
+        stage_times.append((ms[0], ms[1], ms[2], fl.value))
+        return out
+    check(L.pcp_conv3x3_winograd4(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(u_packed), _p(bias), _chan_ptr(out, out_ch_off), _p(ws),
+                                  _stream()), 'pcp_conv3x3_winograd4')
+    return out
+
+
 def conv3x3_bf16x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
     """opt-in split-bf16 arithmetic (see include/pcp_hip.h); same tensor contract as conv3x3"""
     _need_cuda(x, packed, bias, out)

@@ -80,6 +80,42 @@ def pack_conv3x3_winograd(w, bias):
     return packed, pad_bias(bias, cout_pad), cout_pad
 
 
+_WINO4_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
+WINO4_CK = 32          # K slice of the batched GEMM
+WINO4_BN = 128         # its N tile
+
+
+def pack_conv3x3_winograd4(w, bias):
+    """w: [cout, cin, 3, 3] (BN-folded) -> F(4x4,3x3) filter transform U = G g G^T in float64, rounded once, packed
+    [36 (i*6+j)][cout_pad][cin] (K contiguous: the B operand rows of the batched GEMM)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % WINO4_CK == 0 and cout % 4 == 0
+    cout_pad = round_up(cout, WINO4_BN)
+    G = torch.tensor(_WINO4_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum('ia,ncab,jb->ijnc', G, w.double(), G).float()              # [6, 6, cout, cin]
+    up = u.new_zeros((36, cout_pad, cin))
+    up[:, :cout] = u.reshape(36, cout, cin)
+    return up.contiguous(), pad_bias(bias, cout_pad), cout_pad
+
+
+def winograd4_reference(x, packed, bias, cout):
+    """Plain-torch evaluation of the packed F(4x4,3x3) form with the transforms of csrc/wino4.hip (validates matrices + layout on the
+    CPU): x (B, cin, H, W), H, W multiples of 4."""
+    _p36, cout_pad, cin = packed.shape
+    u = packed.view(6, 6, cout_pad, cin)[:, :, :cout]                               # [i, j, cout, cin]
+    B, _, H, W = x.shape
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
+    BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                       [0, 4, 0, -5, 0, 1]], dtype=x.dtype)
+    AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=x.dtype)
+    d = xp.unfold(2, 6, 4).unfold(3, 6, 4)                                        # [B, cin, H/4, W/4, 6, 6]
+    v = torch.einsum('ia,bcyxae,je->bcyxij', BT, d, BT)
+    m = torch.einsum('ijnc,bcyxij->bnyxij', u.to(x.dtype), v)
+    y = torch.einsum('ki,bnyxij,lj->bnyxkl', AT, m, AT)                          # [B, cout, H/4, W/4, 4, 4]
+    out = y.permute(0, 1, 2, 4, 3, 5).reshape(B, cout, H, W)
+    return out + bias[:cout].to(x.dtype).view(1, -1, 1, 1)
+
+
 def pack_conv3x3_bf16x3(w, bias):
     """w: [cout, cin, 3, 3] (BN-folded) -> split hi = bf16(w), lo = bf16(w - hi), packed bf16 [cin/16][cout_pad/64][hi|lo][9][2][64][8]
     (k-half, cout, 8 channels: the fragment image of v_mfma_f32_32x32x16_bf16).  Returns (packed int16 view, bias_pad, cout_pad)."""

@@ -50,8 +50,17 @@ def main():
         td = timeit(lambda: ops.conv3x3(x, pd, bd, cin, cout, cpd, out=out))
         tw = timeit(lambda: ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=out))
         t3 = timeit(lambda: ops.conv3x3_bf16x3(x, p3, b3, cin, cout, cp3, out=out))
-        print('%-36s direct %8.1f us %6.1f TF | winograd %8.1f us %6.1f TF (algorithmic) | x%.2f | bf16x3 (opt-in) %8.1f us %6.1f TF' %
-              (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw, t3 * 1e6, flops / t3 / 1e12))
+        line = ('%-36s direct %8.1f us %6.1f TF | winograd %8.1f us %6.1f TF (algorithmic) | x%.2f | bf16x3 (opt-in) %8.1f us %6.1f TF' %
+                (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw, t3 * 1e6, flops / t3 / 1e12))
+        if cin % pack.WINO4_CK == 0 and cout % 4 == 0 and cin >= 128:
+            ref = out.clone()                                    # bf16x3 result ran last; recompute the fp32 Winograd result as the yardstick
+            ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=ref)
+            p4, b4, cp4 = pack.pack_conv3x3_winograd4(w, b)
+            p4, b4 = p4.to(d), b4.to(d)
+            t4 = timeit(lambda: ops.conv3x3_winograd4(x, p4, b4, cin, cout, cp4, out=out))
+            err = float((out - ref).abs().max() / ref.abs().max())
+            line += ' | F(4x4) %8.1f us %6.1f TF  (max diff vs F(2x2) %.1e of scale)' % (t4 * 1e6, flops / t4 / 1e12, err)
+        print(line)
 
 
 if __name__ == '__main__':

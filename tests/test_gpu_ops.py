@@ -480,6 +480,59 @@ def test_conv3x3_winograd_channel_windows():
     np.testing.assert_allclose(out[..., 128:256].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Winograd F(4x4, 3x3) through memory (input transform, 36 batched MFMA GEMMs, output transform): the wide layers
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,h,w,relu,batch', [(128, 256, 16, 16, True, 1), (384, 384, 32, 32, True, 2), (768, 768, 16, 16, True, 1),
+                                                      (128, 384, 13, 18, False, 2), (256, 260, 7, 9, True, 1), (32, 4, 5, 6, False, 3),
+                                                      (256, 256, 64, 64, True, 1)])
+def test_conv3x3_winograd4_matches_torch_cpu(cin, cout, h, w, relu, batch):
+    """covers: tiles not a multiple of the 128-row GEMM tile, H / W not multiples of 4 (zero-padded patches, clipped stores), cout below
+    and beyond one 128-channel N tile.  F(4x4,3x3) rounding is ~2e-5 of the output scale (fp64 study in csrc/wino4.hip); bar 2e-4 of scale"""
+    ops = _ops()
+    from pcp_amd import pack
+    x = torch.from_numpy(_rand(171, (batch, cin, h, w)))
+    wt = torch.from_numpy(_rand(172, (cout, cin, 3, 3), -0.05, 0.05))
+    b = torch.from_numpy(_rand(173, (cout,), -0.2, 0.2))
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    if relu:
+        want = F.relu(want)
+    packed, bp, cpad = pack.pack_conv3x3_winograd4(wt, b)
+    d = dev()
+    got = ops.conv3x3_winograd4(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    err = float((got.permute(0, 3, 1, 2).cpu().double() - want).abs().max())
+    assert err <= 2e-4 * scale, 'max err %.3e vs scale %.3e' % (err, scale)
+    # timed entry point: same result, three positive launch durations, the GEMM's flop count
+    st = []
+    got2 = ops.conv3x3_winograd4(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu, stage_times=st)
+    assert torch.equal(got, got2)
+    tiles = batch * ((h + 3) // 4) * ((w + 3) // 4)
+    assert len(st) == 1 and min(st[0][:3]) > 0.0 and st[0][3] == 2.0 * 36 * ((tiles + 127) // 128 * 128) * cin * cpad
+
+
+def test_conv3x3_winograd4_channel_windows_and_bad_arguments():
+    ops = _ops()
+    from pcp_amd import pack
+    d = dev()
+    cin, cout = 128, 256
+    wt = torch.from_numpy(_rand(177, (cout, cin, 3, 3), -0.05, 0.05))
+    packed, bp, cpad = pack.pack_conv3x3_winograd4(wt, torch.zeros(cout))
+    x = torch.from_numpy(_rand(178, (1, 24, 20, 192))).to(d)
+    out = torch.full((1, 24, 20, 512), 7.0, device=d)
+    ops.conv3x3_winograd4(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=32, out_ch_off=128)
+    torch.cuda.synchronize()
+    assert float((out[..., :128] - 7.0).abs().max()) == 0.0 and float((out[..., 384:] - 7.0).abs().max()) == 0.0
+    want = F.conv2d(x[..., 32:160].permute(0, 3, 1, 2).cpu().double(), wt.double(), None, padding=1)
+    err = float((out[..., 128:384].permute(0, 3, 1, 2).cpu().double() - want).abs().max())
+    assert err <= 2e-4 * float(want.abs().max())
+    with pytest.raises(RuntimeError):       # cin not a multiple of the GEMM K slice
+        ops.conv3x3_winograd4(x, packed.to(d), bp.to(d), 100, cout, cpad, relu=False, out=out)
+    with pytest.raises(RuntimeError):       # window offset that breaks 16-byte alignment
+        ops.conv3x3_winograd4(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
+
+
 def test_grouped_small_head_conv_matches_torch():
     ops = _ops()
     d = dev()

@@ -84,6 +84,20 @@ def test_bn_folding_and_conv3x3_packing_roundtrip():
     assert float(packed[:, :, cout:].abs().max()) == 0.0            # padded output channels are zero
 
 
+def test_winograd4_packing_evaluates_to_the_convolution():
+    """F(4x4,3x3) filter transform + [36][cout_pad][cin] layout: the packed form evaluated with the kernel's transform matrices in
+    float64 equals the direct convolution (the fp32 rounding of the device path is bounded in tests/test_gpu_ops.py)"""
+    cin, cout = 32, 12
+    w = torch.from_numpy(synth.uniform(7, 1, cout * cin * 9, -0.1, 0.1).reshape(cout, cin, 3, 3))
+    b = torch.from_numpy(synth.uniform(7, 2, cout, -0.2, 0.2))
+    x = torch.from_numpy(synth.uniform(7, 3, 2 * cin * 8 * 12, -1, 1).reshape(2, cin, 8, 12))
+    packed, bp, cpad = pack.pack_conv3x3_winograd4(w, b)
+    assert packed.shape == (36, 128, cin) and cpad == 128 and float(packed[:, cout:].abs().max()) == 0.0
+    got = pack.winograd4_reference(x.double(), packed.double(), bp.double(), cout)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=5e-6)      # U is rounded to fp32 once; A^T amplifies by <= 8 x 8
+
+
 def test_pointwise_packings_match_torch_convs():
     cin, cout = 32, 24
     x = torch.from_numpy(synth.uniform(2, 1, 1 * cin * 6 * 8, -1, 1).reshape(1, cin, 6, 8))
