@@ -221,15 +221,13 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_w4_gemm(GemmParams p) {
       for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const f32x4 *>(pa + i * 32 * G_LD + j * 8);
 #pragma unroll
       for (int c = 0; c < 2; c++) bf[c] = *reinterpret_cast<const f32x4 *>(pb + c * 32 * G_LD + j * 8);
+      // k component outermost: four independent accumulators between two MFMAs on the same one
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-          acc[i][c] = mfma32g(af[i].x, bf[c].x, acc[i][c]);
-          acc[i][c] = mfma32g(af[i].y, bf[c].y, acc[i][c]);
-          acc[i][c] = mfma32g(af[i].z, bf[c].z, acc[i][c]);
-          acc[i][c] = mfma32g(af[i].w, bf[c].w, acc[i][c]);
-        }
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int c = 0; c < 2; c++) acc[i][c] = mfma32g(af[i][kk], bf[c][kk], acc[i][c]);
     }
   };
 
