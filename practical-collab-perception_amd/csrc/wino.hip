@@ -23,13 +23,19 @@
 #include "pcp_common.h"
 
 #ifdef WINO_STAMP
+#ifndef WINO_STAMP_S0
+#define WINO_STAMP_S0 16
+#endif
+#ifndef WINO_STAMP_BLOCK
+#define WINO_STAMP_BLOCK 0
+#endif
 __device__ unsigned long long wino_dbg[8 * 8 * 8];          // [slice 0..7][wave][stamp]
 #define STAMP(slot)                                                                             \
   do {                                                                                          \
-    if (blockIdx.x == 0 && s >= 16 && s < 24 && lane == 0) {                                    \
+    if (blockIdx.x == WINO_STAMP_BLOCK && s >= WINO_STAMP_S0 && s < WINO_STAMP_S0 + 8 && lane == 0) {                                    \
       unsigned long long t_;                                                                    \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
-      wino_dbg[((s - 16) * 8 + wave) * 8 + (slot)] = t_;                                        \
+      wino_dbg[((s - WINO_STAMP_S0) * 8 + wave) * 8 + (slot)] = t_;                                        \
     }                                                                                           \
   } while (0)
 #else

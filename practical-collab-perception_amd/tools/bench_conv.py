@@ -59,7 +59,12 @@ def main():
             p4, b4 = p4.to(d), b4.to(d)
             t4 = timeit(lambda: ops.conv3x3_winograd4(x, p4, b4, cin, cout, cp4, out=out))
             err = float((out - ref).abs().max() / ref.abs().max())
-            line += ' | F(4x4) %8.1f us %6.1f TF  (max diff vs F(2x2) %.1e of scale)' % (t4 * 1e6, flops / t4 / 1e12, err)
+            st = []
+            for _ in range(5):
+                ops.conv3x3_winograd4(x, p4, b4, cin, cout, cp4, out=out, stage_times=st)
+            st = [min(r[i] for r in st) * 1e3 for i in range(3)]
+            line += ' | F(4x4) %8.1f us %6.1f TF  (max diff vs F(2x2) %.1e of scale; input / gemm / output %.0f / %.0f / %.0f us)' % (
+                t4 * 1e6, flops / t4 / 1e12, err, st[0], st[1], st[2])
         print(line)
 
 

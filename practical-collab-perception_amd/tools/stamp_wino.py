@@ -2,7 +2,7 @@ import sys, ctypes, numpy as np, torch
 sys.path.insert(0, 'practical-collab-perception_amd')
 from pcp_amd import ops, pack, lib
 d = torch.device('cuda:0')
-B, H, W, cin, cout = 4, 128, 128, 768, 768
+B, H, W, cin, cout = [int(v) for v in sys.argv[1:6]] if len(sys.argv) > 5 else (4, 128, 128, 768, 768)
 x = torch.randn((B, H, W, cin), device=d); w = torch.randn((cout, cin, 3, 3)) * 0.05
 pw, bw, cpw = pack.pack_conv3x3_winograd(w, torch.zeros(cout)); pw, bw = pw.to(d), bw.to(d)
 out = torch.empty((B, H, W, cout), device=d)

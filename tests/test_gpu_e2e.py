@@ -75,6 +75,24 @@ def test_disco_mid_fusion_matches_reference_outputs():
     assert np.array_equal(batch['voxel_coords'].cpu().numpy(), g['voxel_coords'])
 
 
+@pytest.mark.parametrize('tag', ['car', 'disco'])
+def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monkeypatch):
+    """the mini geometry never reaches the workgroup count at which `auto` picks the F(4x4,3x3) path (csrc/wino4.hip); force it on every
+    eligible layer (HunterJr conv_input / conv_weightor, DiscoNet decompressor, 256-channel backbone blocks) and hold the same goldens
+    at the same tolerances"""
+    monkeypatch.setenv('PCP_CONV_ALGO', 'winograd4')
+    from pcp_amd import ops
+    calls = []
+    orig = ops.conv3x3_winograd4
+    monkeypatch.setattr(ops, 'conv3x3_winograd4', lambda *a, **k: (calls.append(a[3:5]), orig(*a, **k))[1])
+    if tag == 'car':
+        test_single_agent_configs_match_reference_outputs('car')
+        assert (768, 768) in calls and (384, 384) in calls
+    else:
+        test_disco_mid_fusion_matches_reference_outputs()
+        assert (128, 384) in calls and (384, 384) in calls
+
+
 def test_fast_mode_skips_pillar_materialisation_and_matches():
     g = load_golden('g1_ego.npz')
     model = _build(g)
