@@ -241,6 +241,8 @@ def main():
     ap.add_argument('--config', default='car', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-optin', action='store_true', help='skip the informational opt-in (bf16x3) pass after the fp32 measurement (clean '
+                    'rocprofv3 kernel statistics of the headline path)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
     ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3'],
                     help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
@@ -408,7 +410,8 @@ def main():
                          'avg_launch_us': round(cs['avg_us'], 2), 'launches_per_step': cs['launches'] // 3,
                          'all_conv3x3_tflops': round(cs['all_conv_tflops'], 3), 'all_conv3x3_ms_per_step': round(cs['all_conv_ms'] / 3, 3)},
         }
-        if world == 1 and not args.train and not args.graph and args.shard == 'frame' and os.environ.get('PCP_CONV_ALGO', 'auto') == 'auto':
+        if (world == 1 and not args.train and not args.graph and args.shard == 'frame' and os.environ.get('PCP_CONV_ALGO', 'auto') == 'auto'
+                and not args.no_optin):
             # informational: the same workload with the OPT-IN split-bf16 convolution arithmetic (never part of `value`)
             os.environ['PCP_CONV_ALGO'] = 'bf16x3'
             for m in model.modules():
