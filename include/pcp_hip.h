@@ -190,6 +190,24 @@ size_t pcp_decode_workspace_bytes(const pcp_decode_t *desc);
 int pcp_centerhead_decode(const pcp_decode_t *desc, const float *head, void *workspace, size_t workspace_bytes,
                           float *boxes, float *scores, int32_t *labels, int32_t *cell, int32_t *count, void *stream);
 
+/* a8/a9 tail: final per-frame detections.  Replaces the per-frame python of center_head.py:335-357 (boxes[keep], scores[keep],
+ * class_id_mapping[labels[keep]] + 1, torch.cat over heads) with one launch for all frames and heads.  Head h contributes its
+ * min(keep_count[b], keep_max) kept candidates in keep order; heads are concatenated in array order.
+ * out_boxes (B, out_max, 7), out_scores (B, out_max), out_labels (B, out_max) int64 1-based, out_count (B,) int32;
+ * rows beyond out_count[b] are left untouched. */
+#define PCP_DET_MAX_HEADS 8
+typedef struct {
+  const float *boxes;         /* (B, k, 7)  decode output */
+  const float *scores;        /* (B, k) */
+  const int32_t *labels;      /* (B, k) 0-based class inside the head; NULL = 0 */
+  const int32_t *keep;        /* (B, keep_max) indices into the k candidates (pcp_nms_rotated) */
+  const int32_t *keep_count;  /* (B,) */
+  const int32_t *class_map;   /* head class -> global 0-based class id (device); NULL = identity */
+  int32_t k, keep_max;
+} pcp_det_head_t;
+int pcp_gather_detections(const pcp_det_head_t *heads, int32_t n_heads, int32_t batch, int32_t out_max, float *out_boxes,
+                          float *out_scores, int64_t *out_labels, int32_t *out_count, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * a9  rotated BEV IoU + NMS, entirely on the device.
  * Replaces: pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17 -> iou3d_nms.cpp:52-136 + iou3d_nms_kernel.cu:236-311

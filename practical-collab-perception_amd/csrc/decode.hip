@@ -211,6 +211,40 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecParams p) {
   if (tid == 0) p.count[b] = n_ok;
 }
 
+
+// ---- a8 / a9 tail: the per-frame "boxes[keep], scores[keep], mapping[labels[keep]] + 1, cat over heads" of
+//      center_head.py:335-357 as ONE launch for all frames and heads -------------------------------------------------------------
+struct GatherParams {
+  pcp_det_head_t heads[PCP_DET_MAX_HEADS];
+  int n_heads, batch, out_max;
+  float *out_boxes;
+  float *out_scores;
+  long long *out_labels;
+  int *out_count;
+};
+
+__global__ __launch_bounds__(256) void k_gather_detections(GatherParams p) {
+  const int b = blockIdx.x;
+  int base = 0;
+  for (int hi = 0; hi < p.n_heads; hi++) {
+    const pcp_det_head_t &h = p.heads[hi];
+    int cnt = h.keep_count[b];
+    cnt = cnt < h.keep_max ? cnt : h.keep_max;
+    if (base + cnt > p.out_max) cnt = p.out_max - base;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const int src = h.keep[(long long)b * h.keep_max + i];
+      const long long so = (long long)b * h.k + src, dq = (long long)b * p.out_max + base + i;
+#pragma unroll
+      for (int c = 0; c < 7; c++) p.out_boxes[dq * 7 + c] = h.boxes[so * 7 + c];
+      p.out_scores[dq] = h.scores[so];
+      const int lab = h.labels ? h.labels[so] : 0;
+      p.out_labels[dq] = (long long)(h.class_map ? h.class_map[lab] : lab) + 1;
+    }
+    base += cnt;
+  }
+  if (threadIdx.x == 0) p.out_count[b] = base;
+}
+
 }  // namespace
 
 extern "C" size_t pcp_decode_workspace_bytes(const pcp_decode_t *desc) {
@@ -232,6 +266,23 @@ extern "C" int pcp_centerhead_decode(const pcp_decode_t *desc, const float *head
   p.head = head;
   p.boxes = boxes; p.scores = scores; p.labels = labels; p.cell = cell; p.count = count;
   hipLaunchKernelGGL(k_decode, dim3(desc->batch), dim3(DEC_THREADS), 0, (hipStream_t)stream_, p);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_gather_detections(const pcp_det_head_t *heads, int32_t n_heads, int32_t batch, int32_t out_max, float *out_boxes,
+                                     float *out_scores, int64_t *out_labels, int32_t *out_count, void *stream_) {
+  if (!heads || n_heads <= 0 || n_heads > PCP_DET_MAX_HEADS || batch <= 0 || out_max <= 0) return PCP_ERR_ARG;
+  if (!out_boxes || !out_scores || !out_labels || !out_count) return PCP_ERR_ARG;
+  GatherParams p;
+  for (int i = 0; i < n_heads; i++) {
+    if (!heads[i].boxes || !heads[i].scores || !heads[i].keep || !heads[i].keep_count || heads[i].k <= 0 || heads[i].keep_max <= 0)
+      return PCP_ERR_ARG;
+    p.heads[i] = heads[i];
+  }
+  p.n_heads = n_heads; p.batch = batch; p.out_max = out_max;
+  p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_labels = reinterpret_cast<long long *>(out_labels); p.out_count = out_count;
+  hipLaunchKernelGGL(k_gather_detections, dim3(batch), dim3(256), 0, (hipStream_t)stream_, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

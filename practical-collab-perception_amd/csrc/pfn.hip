@@ -91,6 +91,7 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   const int s0 = pl_start[0], s1 = pl_start[np];
 
   // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
+#ifndef PFN_DIAG_NO_SWEEP1
   for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
     const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
     int pl = find_pillar(pl_start, np, s);
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
     }
   }
+#endif
   __syncthreads();
   for (int i = tid; i < np * 3; i += PFN_THREADS) {
     int pl = i / 3, a = i % 3;
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
 
   // ---- sweep 2: lanes = points, waves = channel quarters -----------------------------------------------------------------
+#ifndef PFN_DIAG_NO_SWEEP2
   for (int base = s0; base < s1; base += 64) {
     const int s = base + lane;
     if (s < s1) {
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
 #pragma unroll
       for (int c = 0; c < C0; c++)
         if ((c >> 3) == wave) atomicMax(&xmax0[pl][c], __float_as_int(x[c]));
+#ifndef PFN_DIAG_NO_L1
       // point half of layer 1 for output channels [16*wave, 16*wave + 16)
       const float *wq = p.w1 + (wave * 16) * (2 * C0);
 #pragma unroll 4
@@ -153,16 +157,20 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
         for (int k = 0; k < C0; k++) acc = fmaf(wr[k], x[k], acc);
         atomicMax(&dmax[pl][wave * 16 + o], fkey(acc));
       }
+#endif
     }
   }
+#endif
   __syncthreads();
 
   // ---- epilogue: lanes = output channels, one pillar per (wave, iteration); one 256-B row per pillar --------------------------
   for (int pl = wave; pl < np; pl += PFN_THREADS / 64) {
     const int o = lane;
     float acc = p.b1[o];
+#ifndef PFN_DIAG_NO_EPI
 #pragma unroll 8
     for (int k = 0; k < C0; k++) acc = fmaf(w1b[k][o], __int_as_float(xmax0[pl][k]), acc);
+#endif
     const float v = fmaxf(acc + fkey_inv(dmax[pl][o]), 0.0f);
     if (p.pillar_features) p.pillar_features[(long long)(r0 + pl) * C1 + o] = v;
     if (p.canvas) {

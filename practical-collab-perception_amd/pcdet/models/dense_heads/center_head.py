@@ -167,19 +167,21 @@ class CenterHead(PackedModule):
         return per_head
 
     def finalize(self, per_head, batch_size):
-        """the one host sync of the path: how many boxes survive per (head, frame) -> exact-shape output tensors."""
-        counts = torch.stack([h[4] for h in per_head], 0).cpu().numpy()
-        ret = []
-        for b in range(batch_size):
-            pb, ps, pl = [], [], []
-            for hi, (boxes, scores, labels, keep, _kcnt, idx) in enumerate(per_head):
-                sel = keep[b, :int(counts[hi, b])].long()
-                pb.append(boxes[b, sel])
-                ps.append(scores[b, sel])
-                mapping = self.class_id_mapping_each_head[idx].to(labels.device)
-                pl.append(mapping[labels[b, sel].long()])
-            ret.append(dict(pred_boxes=torch.cat(pb, 0), pred_scores=torch.cat(ps, 0), pred_labels=torch.cat(pl, 0) + 1))
-        return ret
+        """one gather launch for all frames and heads (boxes[keep], scores[keep], class_id_mapping[labels[keep]] + 1, concatenated over
+        heads: reference :335-357), then the one host sync of the path: how many boxes survive per frame -> exact-shape views."""
+        heads = []
+        for boxes, scores, labels, keep, kcnt, idx in per_head:
+            cmap = self._class_maps.get(idx) if hasattr(self, '_class_maps') else None
+            if cmap is None or cmap.device != boxes.device:
+                if not hasattr(self, '_class_maps'):
+                    self._class_maps = {}
+                cmap = self.class_id_mapping_each_head[idx].to(device=boxes.device, dtype=torch.int32).contiguous()
+                self._class_maps[idx] = cmap
+            heads.append(dict(boxes=boxes, scores=scores, labels=labels, keep=keep, keep_count=kcnt, class_map=cmap))
+        ob, os_, ol, cnt = ops.gather_detections(heads, batch_size)
+        counts = cnt.cpu().numpy()
+        return [dict(pred_boxes=ob[b, :int(counts[b])], pred_scores=os_[b, :int(counts[b])], pred_labels=ol[b, :int(counts[b])])
+                for b in range(batch_size)]
 
     def generate_predicted_boxes(self, batch_size, head_bufs, pk):
         return self.finalize(self.device_postprocess(head_bufs, pk), batch_size)

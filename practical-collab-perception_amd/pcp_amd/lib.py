@@ -32,6 +32,11 @@ class Pointwise(ctypes.Structure):
                 ('in2', vp), ('ld_in2', c_i32), ('k_split', c_i32), ('residual', vp), ('ld_res', c_i32)]
 
 
+class DetHead(ctypes.Structure):
+    _fields_ = [('boxes', vp), ('scores', vp), ('labels', vp), ('keep', vp), ('keep_count', vp), ('class_map', vp), ('k', c_i32),
+                ('keep_max', c_i32)]
+
+
 class Decode(ctypes.Structure):
     _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('ld', c_i32), ('num_class', c_i32), ('ch_center', c_i32),
                 ('ch_z', c_i32), ('ch_dim', c_i32), ('ch_rot', c_i32), ('ch_hm', c_i32), ('k', c_i32), ('stride', c_f),
@@ -82,6 +87,7 @@ SYMBOLS = {
     'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
+    'pcp_gather_detections': (c_i32, [ctypes.POINTER(DetHead), c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     'pcp_nms_workspace_bytes': (c_sz, [c_i32, c_i32]),
     'pcp_nms_rotated': (c_i32, [vp, vp, c_i32, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
     'pcp_boxes_bev_pairwise': (c_i32, [vp, c_i32, vp, c_i32, c_i32, vp, vp]),

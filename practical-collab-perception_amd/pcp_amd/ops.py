@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import lib as _lib
-from .lib import Conv3x3, Decode, Grid, Pointwise, check
+from .lib import Conv3x3, Decode, DetHead, Grid, Pointwise, check
 
 
 def _stream():
@@ -22,6 +22,26 @@ def _need_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise _lib.PcpError('the HIP hot path needs CUDA/ROCm tensors (got a %s tensor); no CPU fallback exists' % t.device)
+
+
+def _zeros_views(device, specs):
+    """several zero-initialised output tensors carved out of ONE allocation (one fill launch instead of one per tensor).
+    specs: [(shape, dtype)], all 4-byte dtypes; every view starts 16-byte aligned."""
+    sizes = []
+    for shape, _dt in specs:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        sizes.append((n + 3) // 4 * 4)
+    buf = torch.zeros((max(sum(sizes), 1),), dtype=torch.int32, device=device)
+    out, off = [], 0
+    for (shape, dt), sz in zip(specs, sizes):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        out.append(buf[off:off + n].view(dt).view(*shape))
+        off += sz
+    return out
 
 
 def make_grid(pc_range, voxel_size, grid_size, batch_size):
@@ -262,11 +282,8 @@ def centerhead_decode(head, desc_kwargs):
     d.use_score_thresh = 0 if st is None else 1
     d.score_thresh = 0.0 if st is None else float(st)
     dev = head.device
-    boxes = torch.zeros((B, k, 7), dtype=torch.float32, device=dev)
-    scores = torch.zeros((B, k), dtype=torch.float32, device=dev)
-    labels = torch.zeros((B, k), dtype=torch.int32, device=dev)
-    cell = torch.zeros((B, k), dtype=torch.int32, device=dev)
-    count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    boxes, scores, labels, cell, count = _zeros_views(dev, [((B, k, 7), torch.float32), ((B, k), torch.float32), ((B, k), torch.int32),
+                                                            ((B, k), torch.int32), ((B,), torch.int32)])
     check(L.pcp_centerhead_decode(ctypes.byref(d), _p(head), ctypes.c_void_p(0), 0, _p(boxes), _p(scores), _p(labels), _p(cell),
                                   _p(count), _stream()), 'pcp_centerhead_decode')
     return boxes, scores, labels, cell, count
@@ -284,11 +301,32 @@ def nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=
     need = L.pcp_nms_workspace_bytes(n_max, B)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=boxes.device)
-    keep = torch.zeros((B, post_max), dtype=torch.int32, device=boxes.device)
-    cnt = torch.zeros((B,), dtype=torch.int32, device=boxes.device)
+    keep, cnt = _zeros_views(boxes.device, [((B, post_max), torch.int32), ((B,), torch.int32)])
     check(L.pcp_nms_rotated(_p(boxes), _p(scores), B, n_max, _p(n_dev), float(thresh), int(pre_max), int(post_max), _p(workspace),
                             workspace.numel(), _p(keep), _p(cnt), _stream()), 'pcp_nms_rotated')
     return (keep[0], cnt) if single else (keep, cnt)
+
+
+def gather_detections(heads, batch):
+    """heads: list of dicts(boxes (B,k,7), scores (B,k), labels (B,k) int32 | None, keep (B,keep_max) int32, keep_count (B,) int32,
+    class_map int32 device tensor | None).  One launch for all frames and heads; returns (boxes (B,M,7), scores (B,M), labels (B,M) int64
+    1-based, count (B,) int32) with M = sum of keep_max; rows beyond count[b] are zero."""
+    L = _lib.load()
+    arr = (DetHead * len(heads))()
+    out_max = 0
+    for i, h in enumerate(heads):
+        _need_cuda(h['boxes'], h['scores'], h['labels'], h['keep'], h['keep_count'], h.get('class_map'))
+        assert h['boxes'].is_contiguous() and h['scores'].is_contiguous() and h['keep'].is_contiguous() and h['keep'].dtype == torch.int32
+        assert h['boxes'].shape[0] == batch and h['keep'].shape[0] == batch
+        arr[i].boxes, arr[i].scores, arr[i].labels = _p(h['boxes']), _p(h['scores']), _p(h['labels'])
+        arr[i].keep, arr[i].keep_count, arr[i].class_map = _p(h['keep']), _p(h['keep_count']), _p(h.get('class_map'))
+        arr[i].k, arr[i].keep_max = int(h['boxes'].shape[1]), int(h['keep'].shape[1])
+        out_max += int(h['keep'].shape[1])
+    dev = heads[0]['boxes'].device
+    ob, os_, cnt = _zeros_views(dev, [((batch, out_max, 7), torch.float32), ((batch, out_max), torch.float32), ((batch,), torch.int32)])
+    ol = torch.zeros((batch, out_max), dtype=torch.int64, device=dev)
+    check(L.pcp_gather_detections(arr, len(heads), batch, out_max, _p(ob), _p(os_), _p(ol), _p(cnt), _stream()), 'pcp_gather_detections')
+    return ob, os_, ol, cnt
 
 
 def boxes_bev_pairwise(a, b, mode):
