@@ -284,6 +284,10 @@ int pcp_hunter_apply_flow(float *points, int64_t n, int32_t row_stride, const fl
 int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, float agent,
                                 int32_t batch, const float *poses_host, const uint8_t *present_host, float *out,
                                 void *stream);
+/* Which agents have points (bev_maker.py:156 `torch.unique(points[:, -1])`, a sort + host sync in the reference): out2[0] = bit mask
+ * of the integer values 0..63 found in column `col`, out2[1] = number of rows holding anything else (then the caller sorts).
+ * out2: 2 x uint64 on the device, 16-byte aligned; zeroed by the call. */
+int pcp_column_id_mask(const float *points, int64_t n, int32_t row_stride, int32_t col, uint64_t *out2, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * SURVEY 8(f) rows 1-2  lately-fusion exchange: producer rows and ego-side MoDAR ingestion.

@@ -220,6 +220,29 @@ __global__ void k_select_transform(const float *__restrict__ points, long long n
   o[3] = x * T[8] + y * T[9] + z * T[10] + T[11];
 }
 
+
+// ---- a13: which agent ids occur in a column (bev_maker.py:156 torch.unique(points[:, -1])): 64-bit presence mask of the integer
+//      values 0..63; out[1] counts rows whose value is not such an integer (the caller then falls back to a sort) ----------------
+__global__ __launch_bounds__(256) void k_column_id_mask(const float *__restrict__ points, long long n, int stride, int col,
+                                                        unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long s_mask, s_bad;
+  if (threadIdx.x == 0) { s_mask = 0ULL; s_bad = 0ULL; }
+  __syncthreads();
+  unsigned long long m = 0ULL, bad = 0ULL;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = points[i * stride + col];
+    const int iv = (int)v;
+    if (v >= 0.f && v < 64.f && (float)iv == v) m |= 1ULL << iv; else bad++;
+  }
+  if (m) atomicOr(&s_mask, m);
+  if (bad) atomicAdd(&s_bad, bad);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_mask) atomicOr(&out[0], s_mask);
+    if (s_bad) atomicAdd(&out[1], s_bad);
+  }
+}
+
 }  // namespace
 
 extern "C" int pcp_hunter_apply_flow(float *points, int64_t n, int32_t row_stride, const float *head, int32_t ld_head,
@@ -299,6 +322,20 @@ extern "C" int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_
   }
   hipLaunchKernelGGL(k_sc_mean, dim3((unsigned)cells), dim3(SC_THREADS), 0, st, cell_start, bucket, feat, ld_feat, c / 4, out,
                      ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_column_id_mask(const float *points, int64_t n, int32_t row_stride, int32_t col, uint64_t *out2, void *stream_) {
+  if (!out2 || n < 0 || row_stride <= 0 || col < 0 || col >= row_stride) return PCP_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream_;
+  int rc = pcp_zero_async(out2, 16, st);
+  if (rc != PCP_OK || n == 0) return rc;
+  if (!points) return PCP_ERR_ARG;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_column_id_mask, dim3((unsigned)blocks), dim3(256), 0, st, points, (long long)n, row_stride, col,
+                     reinterpret_cast<unsigned long long *>(out2));
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

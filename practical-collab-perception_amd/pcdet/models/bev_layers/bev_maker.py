@@ -77,7 +77,14 @@ class BEVMaker(nn.Module):
         self.eval()
         points = batch_dict['points']
         batch_size = batch_dict['batch_size']
-        agent_ids = torch.unique(points[:, -1]).cpu().numpy().astype(np.int64)          # one sync, as in the reference (:156)
+        # which agents have points: one sync, as in the reference (:156), but a presence-mask launch instead of a sort; the rsu and
+        # car makers of one forward see the same (unmodified) points, so the second one reuses the answer
+        cached = batch_dict.get('_pcp_agent_ids', None)
+        if cached is not None and cached[0] is points:
+            agent_ids = cached[1]
+        else:
+            agent_ids = ops.column_ids(points, -1)
+            batch_dict['_pcp_agent_ids'] = (points, agent_ids)
         batch_dict['bev_img'] = dict()
         for agent_idx in agent_ids:
             if agent_idx == 1 or (self.maker_type == 'rsu' and agent_idx != 0):

@@ -87,6 +87,7 @@ SYMBOLS = {
     'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
+    'pcp_column_id_mask': (c_i32, [vp, ctypes.c_int64, c_i32, c_i32, vp, vp]),
     'pcp_gather_detections': (c_i32, [ctypes.POINTER(DetHead), c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     'pcp_nms_workspace_bytes': (c_sz, [c_i32, c_i32]),
     'pcp_nms_rotated': (c_i32, [vp, vp, c_i32, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),

@@ -410,6 +410,22 @@ def hunter_apply_flow(points, head, thresh):
     return mask[:n]
 
 
+def column_ids(points, col):
+    """sorted distinct values of an id column (torch.unique(points[:, col]) of bev_maker.py:156) as a numpy int64 array: one
+    presence-mask launch + one 16-byte read-back when every value is an integer in 0..63, the sort otherwise."""
+    import numpy as np
+    _need_cuda(points)
+    L = _lib.load()
+    n, stride = points.shape
+    out = torch.empty((2,), dtype=torch.int64, device=points.device)
+    check(L.pcp_column_id_mask(_p(points), n, stride, col % stride, _p(out), _stream()), 'pcp_column_id_mask')
+    mask, bad = [int(v) for v in out.cpu().tolist()]
+    if bad:
+        return torch.unique(points[:, col]).cpu().numpy().astype(np.int64)
+    mask &= (1 << 64) - 1
+    return np.asarray([i for i in range(64) if (mask >> i) & 1], dtype=np.int64)
+
+
 def select_transform_points(points, agent_col, agent, poses, present):
     """poses: (B, 12) float32 numpy (row-major R|t); present: (B,) bool.  Returns a same-shape copy of `points` where rows of
     other agents / absent frames carry batch index -1."""

@@ -34,7 +34,8 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
         step()
         torch.cuda.synchronize()
     tally = collections.Counter()
@@ -43,8 +44,8 @@ def main():
             continue
         where = '?'
         for fr in ev.stack:
-            if 'practical-collab-perception_amd' in fr or '/bench.py' in fr:
-                where = fr.split('practical-collab-perception_amd/')[-1]
+            if (fr.startswith('pcdet/') or fr.startswith('pcp_amd/') or 'bench.py' in fr) and '_zeros_views' not in fr:
+                where = fr
                 break
         tally[(ev.name, where)] += 1
     for (op, where), n in sorted(tally.items(), key=lambda kv: -kv[1]):

@@ -533,6 +533,55 @@ def test_conv3x3_winograd4_channel_windows_and_bad_arguments():
         ops.conv3x3_winograd4(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
 
 
+def test_column_ids_equals_torch_unique():
+    """agent ids present in the cloud (bev_maker.py:156): presence-mask kernel == torch.unique, incl. the fallback for values that are
+    not integers in 0..63 and the empty cloud"""
+    ops = _ops()
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand((5000, 7), generator=g)
+    pts[:, -1] = torch.tensor([0, 2, 5, 63])[torch.randint(0, 4, (5000,), generator=g)].float()
+    assert ops.column_ids(pts.to(d), -1).tolist() == [0, 2, 5, 63]
+    pts[17, -1] = 2.5
+    pts[99, -1] = -1.0
+    assert ops.column_ids(pts.to(d), -1).tolist() == torch.unique(pts[:, -1]).numpy().astype(np.int64).tolist()
+    assert ops.column_ids(torch.zeros((0, 7), device=d), -1).tolist() == []
+
+
+def test_gather_detections_equals_the_reference_python_tail():
+    """pcp_gather_detections vs the per-frame indexing of center_head.py:335-357 (boxes[keep], scores[keep],
+    class_id_mapping[labels[keep]] + 1, cat over heads): two heads, ragged counts incl. 0 and the full keep_max, bit exact"""
+    ops = _ops()
+    d = dev()
+    B, k, keep_max = 3, 50, (7, 12)
+    g = torch.Generator().manual_seed(5)
+    heads, want = [], [dict(b=[], s=[], l=[]) for _ in range(B)]
+    cmaps = [torch.tensor([2, 0], dtype=torch.int32), torch.tensor([1], dtype=torch.int32)]
+    counts = [[0, 7, 3], [12, 0, 5]]
+    for hi in range(2):
+        boxes = torch.rand((B, k, 7), generator=g)
+        scores = torch.rand((B, k), generator=g)
+        labels = torch.randint(0, len(cmaps[hi]), (B, k), generator=g, dtype=torch.int32)
+        keep = torch.stack([torch.randperm(k, generator=g)[:keep_max[hi]] for _ in range(B)]).int()
+        cnt = torch.tensor(counts[hi], dtype=torch.int32)
+        heads.append(dict(boxes=boxes.to(d), scores=scores.to(d), labels=labels.to(d), keep=keep.to(d), keep_count=cnt.to(d),
+                          class_map=cmaps[hi].to(d)))
+        for b in range(B):
+            sel = keep[b, :counts[hi][b]].long()
+            want[b]['b'].append(boxes[b, sel])
+            want[b]['s'].append(scores[b, sel])
+            want[b]['l'].append(cmaps[hi][labels[b, sel].long()].long() + 1)
+    ob, os_, ol, cnt = ops.gather_detections(heads, B)
+    torch.cuda.synchronize()
+    assert ol.dtype == torch.int64 and tuple(ob.shape) == (B, sum(keep_max), 7)
+    for b in range(B):
+        n = counts[0][b] + counts[1][b]
+        assert int(cnt[b]) == n
+        assert torch.equal(ob[b, :n].cpu(), torch.cat(want[b]['b'])) and torch.equal(os_[b, :n].cpu(), torch.cat(want[b]['s']))
+        assert torch.equal(ol[b, :n].cpu(), torch.cat(want[b]['l']))
+        assert float(ob[b, n:].abs().max()) == 0.0 if n < sum(keep_max) else True
+
+
 def test_grouped_small_head_conv_matches_torch():
     ops = _ops()
     d = dev()
