@@ -55,22 +55,32 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// One workgroup = PILLARS_PER_BLOCK consecutive pillars = one contiguous run of the bucket order.
-// Work split: lanes = points (chunks of 64), the four waves = the four quarters of the output channels, so every weight
-// address is wave-uniform (scalar loads, weights live in SGPRs) and all four waves are busy on every chunk.
+// One workgroup = PILLARS_PER_BLOCK consecutive pillars = one contiguous run of the bucket order, processed in chunks of 64 points.
 //   sweep 1: fixed-point xyz sums -> per-pillar mean
-//   sweep 2: features -> layer 0 (each wave computes all 32 channels, publishes its 8 to xmax0) -> the POINT half of layer 1
-//            d = W1[:, :32] . x for the wave's 16 output channels -> running max in dmax
-//   epilogue: out = relu(b1 + W1[:, 32:] . xmax0 + dmax)   -- exact: max_p fl(c + d_p) = fl(c + max_p d_p) (rounding is monotone)
+//   sweep 2, per chunk: lanes = points; wave w computes layer-0 channels [8w, 8w+8) (its 88 weights stay in SGPRs), publishes them to
+//            xmax0 (running per-pillar max) and to the chunk's x tile in LDS; after one barrier the POINT half of layer 1,
+//            d = x . W1[:, :32]^T  ([64 points x 32] x [32 x 64]), runs on the matrix pipe: wave = (32-point tile, 32-channel tile),
+//            16 v_mfma_f32_32x32x2_f32 with the W1 fragments resident in VGPRs; the accumulators go to the running max dmax[pillar][o]
+//   epilogue: out = relu(b1 + xmax0 . W1[:, 32:]^T + dmax): the same MFMA tiling over [64 pillars x 32] x [32 x 64], one 128-byte
+//            segment of a canvas row per half-wave store.
+//   Exact w.r.t. the reference's order of operations up to the summation order inside the two 32-deep dot products:
+//   max_p fl(c + d_p) = fl(c + max_p d_p) (rounding is monotone).
+constexpr int XLD = 36;           // padded row of the x / xmax0 tiles (floats): conflict-free ds_read_b128 groups
+
+__device__ __forceinline__ f32x16 mfma32p(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
 template <int NUM_RAW>
 __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   constexpr int F = NUM_RAW + 6;
   __shared__ int pl_start[PILLARS_PER_BLOCK + 1];
   __shared__ long long sum_fx[PILLARS_PER_BLOCK][3];
   __shared__ float mean[PILLARS_PER_BLOCK][3];
-  __shared__ int xmax0[PILLARS_PER_BLOCK][C0];          // float bits (>= 0 after ReLU: int order == float order)
+  __shared__ long long row_off[PILLARS_PER_BLOCK];      // canvas row (in floats) of each pillar
+  __shared__ float cell_xy[PILLARS_PER_BLOCK][2];       // cell indices of each pillar as floats
+  __shared__ __attribute__((aligned(16))) float xmax0[PILLARS_PER_BLOCK * XLD];   // >= 0 after ReLU: int order == float order
   __shared__ unsigned dmax[PILLARS_PER_BLOCK][C1];      // fkey-encoded running max of the point half of layer 1
-  __shared__ float w1b[C0][C1 + 1];                     // W1[o][32 + k] transposed to [k][o] for the epilogue
+  __shared__ __attribute__((aligned(16))) float xs[2][64 * XLD];                  // layer-0 output of the current chunk
+  __shared__ int pl_s[2][64];                           // pillar of each point of the chunk (-1: past the end)
 
   const int P = p.counters[0];
   const int r0 = blockIdx.x * PILLARS_PER_BLOCK;
@@ -78,20 +88,44 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   const int np = min(PILLARS_PER_BLOCK, P - r0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // SGPR: keeps the weight addresses scalar
+  const int r = lane & 31, h = lane >> 5;
+  const int rt = wave >> 1, ct = wave & 1;
+  const int plane = p.g.nx * p.g.ny;
 
   for (int i = tid; i <= np; i += PFN_THREADS) pl_start[i] = p.pillar_start[r0 + i];
   for (int i = tid; i < PILLARS_PER_BLOCK * 3; i += PFN_THREADS) (&sum_fx[0][0])[i] = 0;
-  for (int i = tid; i < PILLARS_PER_BLOCK * C0; i += PFN_THREADS) (&xmax0[0][0])[i] = 0;
+  for (int i = tid; i < PILLARS_PER_BLOCK * XLD; i += PFN_THREADS) xmax0[i] = 0.f;
   for (int i = tid; i < PILLARS_PER_BLOCK * C1; i += PFN_THREADS) (&dmax[0][0])[i] = 0u;
-  for (int i = tid; i < C0 * C1; i += PFN_THREADS) {
-    int o = i / C0, k = i % C0;
-    w1b[k][o] = p.w1[o * (2 * C0) + C0 + k];
+  for (int i = tid; i < PILLARS_PER_BLOCK; i += PFN_THREADS) {
+    long long off = 0;
+    float cxf = 0.f, cyf = 0.f;
+    if (i < np) {
+      const int cell = p.pillar_cell[r0 + i];
+      const int b = cell / plane, rem = cell % plane;
+      const int cx = rem / p.g.ny, cy = rem % p.g.ny;
+      off = (((long long)b * p.g.ny + cy) * p.g.nx + cx) * C1;
+      cxf = (float)cx;
+      cyf = (float)cy;
+    }
+    row_off[i] = off;
+    cell_xy[i][0] = cxf;
+    cell_xy[i][1] = cyf;
+  }
+  // W1 fragments of this wave's 32 output channels, k permuted as the ds_read_b128 of the A tiles delivers it:
+  // MFMA (j, i) multiplies k = 8j + 4h + i.  wp: point half (k < 32), wm: max half (k >= 32)
+  f32x4 wp[4], wm[4];
+  {
+    const float *wr = p.w1 + (ct * 32 + r) * (2 * C0) + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      wp[j] = *reinterpret_cast<const f32x4 *>(wr + 8 * j);
+      wm[j] = *reinterpret_cast<const f32x4 *>(wr + C0 + 8 * j);
+    }
   }
   __syncthreads();
   const int s0 = pl_start[0], s1 = pl_start[np];
 
   // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
-#ifndef PFN_DIAG_NO_SWEEP1
   for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
     const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
     int pl = find_pillar(pl_start, np, s);
@@ -101,7 +135,6 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
     }
   }
-#endif
   __syncthreads();
   for (int i = tid; i < np * 3; i += PFN_THREADS) {
     int pl = i / 3, a = i % 3;
@@ -110,74 +143,93 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   }
   __syncthreads();
 
-  const int plane = p.g.nx * p.g.ny;
   // cell-centre offsets exactly as the reference constructor rounds them (dynamic_pillar_vfe.py:80-82)
   const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
   const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
   const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
 
-  // ---- sweep 2: lanes = points, waves = channel quarters -----------------------------------------------------------------
-#ifndef PFN_DIAG_NO_SWEEP2
-  for (int base = s0; base < s1; base += 64) {
+  // ---- sweep 2 -----------------------------------------------------------------------------------------------------------
+  int buf = 0;
+  for (int base = s0; base < s1; base += 64, buf ^= 1) {
     const int s = base + lane;
+    int pl = -1;
+    float x8[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) x8[c] = 0.f;
     if (s < s1) {
-      const int pl = find_pillar(pl_start, np, s);
+      pl = find_pillar(pl_start, np, s);
       const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
       float f[F];
 #pragma unroll
       for (int k = 0; k < NUM_RAW; k++) f[k] = row[1 + k];
-      const int rem = p.pillar_cell[r0 + pl] % plane;
-      const float cx = (float)(rem / p.g.ny), cy = (float)(rem % p.g.ny);
       f[NUM_RAW + 0] = __fsub_rn(f[0], mean[pl][0]);
       f[NUM_RAW + 1] = __fsub_rn(f[1], mean[pl][1]);
       f[NUM_RAW + 2] = __fsub_rn(f[2], mean[pl][2]);
-      f[NUM_RAW + 3] = __fsub_rn(f[0], __fadd_rn(__fmul_rn(cx, p.g.voxel_x), x_off));
-      f[NUM_RAW + 4] = __fsub_rn(f[1], __fadd_rn(__fmul_rn(cy, p.g.voxel_y), y_off));
+      f[NUM_RAW + 3] = __fsub_rn(f[0], __fadd_rn(__fmul_rn(cell_xy[pl][0], p.g.voxel_x), x_off));
+      f[NUM_RAW + 4] = __fsub_rn(f[1], __fadd_rn(__fmul_rn(cell_xy[pl][1], p.g.voxel_y), y_off));
       f[NUM_RAW + 5] = __fsub_rn(f[2], z_off);
-      float x[C0];
 #pragma unroll
-      for (int c = 0; c < C0; c++) {
-        float acc = p.b0[c];                          // wave-uniform addresses -> scalar loads
+      for (int c = 0; c < 8; c++) {
+        const int ch = wave * 8 + c;
+        float acc = p.b0[ch];                          // wave-uniform addresses -> scalar loads
 #pragma unroll
-        for (int k = 0; k < F; k++) acc = fmaf(p.w0[c * F + k], f[k], acc);
-        x[c] = fmaxf(acc, 0.0f);
+        for (int k = 0; k < F; k++) acc = fmaf(p.w0[ch * F + k], f[k], acc);
+        x8[c] = fmaxf(acc, 0.0f);
+        atomicMax(reinterpret_cast<int *>(&xmax0[pl * XLD + ch]), __float_as_int(x8[c]));
       }
-      // this wave publishes channels [8*wave, 8*wave + 8) of layer 0
-#pragma unroll
-      for (int c = 0; c < C0; c++)
-        if ((c >> 3) == wave) atomicMax(&xmax0[pl][c], __float_as_int(x[c]));
-#ifndef PFN_DIAG_NO_L1
-      // point half of layer 1 for output channels [16*wave, 16*wave + 16)
-      const float *wq = p.w1 + (wave * 16) * (2 * C0);
-#pragma unroll 4
-      for (int o = 0; o < 16; o++) {
-        float acc = 0.0f;
-        const float *wr = wq + o * (2 * C0);
-#pragma unroll
-        for (int k = 0; k < C0; k++) acc = fmaf(wr[k], x[k], acc);
-        atomicMax(&dmax[pl][wave * 16 + o], fkey(acc));
-      }
-#endif
     }
+    *reinterpret_cast<f32x4 *>(&xs[buf][lane * XLD + wave * 8]) = f32x4{x8[0], x8[1], x8[2], x8[3]};
+    *reinterpret_cast<f32x4 *>(&xs[buf][lane * XLD + wave * 8 + 4]) = f32x4{x8[4], x8[5], x8[6], x8[7]};
+    if (wave == 0) pl_s[buf][lane] = pl;
+    __syncthreads();
+    // point half of layer 1 on the matrix pipe: rows = points rt*32 .. +31, columns = channels ct*32 .. +31
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    const float *xa = &xs[buf][(rt * 32 + r) * XLD + 4 * h];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + 8 * j);
+      acc = mfma32p(a.x, wp[j].x, acc);
+      acc = mfma32p(a.y, wp[j].y, acc);
+      acc = mfma32p(a.z, wp[j].z, acc);
+      acc = mfma32p(a.w, wp[j].w, acc);
+    }
+    const int o = ct * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int prow = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int ppl = pl_s[buf][prow];
+      if (ppl >= 0) atomicMax(&dmax[ppl][o], fkey(acc[e]));
+    }
+    // xs / pl_s are double buffered: the next chunk writes the other buffer, and the barrier of the chunk after that orders the reuse
   }
-#endif
   __syncthreads();
 
-  // ---- epilogue: lanes = output channels, one pillar per (wave, iteration); one 256-B row per pillar --------------------------
-  for (int pl = wave; pl < np; pl += PFN_THREADS / 64) {
-    const int o = lane;
-    float acc = p.b1[o];
-#ifndef PFN_DIAG_NO_EPI
-#pragma unroll 8
-    for (int k = 0; k < C0; k++) acc = fmaf(w1b[k][o], __int_as_float(xmax0[pl][k]), acc);
-#endif
-    const float v = fmaxf(acc + fkey_inv(dmax[pl][o]), 0.0f);
-    if (p.pillar_features) p.pillar_features[(long long)(r0 + pl) * C1 + o] = v;
-    if (p.canvas) {
-      const int cell = p.pillar_cell[r0 + pl];
-      const int b = cell / plane, rem = cell % plane;
-      const int cx = rem / p.g.ny, cy = rem % p.g.ny;
-      p.canvas[(((long long)b * p.g.ny + cy) * p.g.nx + cx) * C1 + o] = v;
+  // ---- epilogue: out = relu(b1 + xmax0 . W1[:, 32:]^T + dmax) for rows = pillars rt2*32 .. +31 --------------------------------
+  const int o = ct * 32 + r;
+  const float bias = p.b1[o];
+  for (int rt2 = rt; rt2 * 32 < np; rt2 += 2) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    const float *xa = &xmax0[(rt2 * 32 + r) * XLD + 4 * h];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + 8 * j);
+      acc = mfma32p(a.x, wm[j].x, acc);
+      acc = mfma32p(a.y, wm[j].y, acc);
+      acc = mfma32p(a.z, wm[j].z, acc);
+      acc = mfma32p(a.w, wm[j].w, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int pl = rt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (pl < np) {
+        const float v = fmaxf((bias + acc[e]) + fkey_inv(dmax[pl][o]), 0.0f);
+        if (p.pillar_features) p.pillar_features[(long long)(r0 + pl) * C1 + o] = v;
+        if (p.canvas) p.canvas[row_off[pl] + o] = v;
+      }
     }
   }
 }
