@@ -70,8 +70,10 @@ constexpr int XLD = 36;           // padded row of the x / xmax0 tiles (floats):
 __device__ __forceinline__ f32x16 mfma32p(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 template <int NUM_RAW>
-__global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
+__global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
   constexpr int F = NUM_RAW + 6;
+  constexpr int PL_CAP = 512;                            // points of the block with a direct point -> pillar table
+  __shared__ unsigned char pl_of[PL_CAP];
   __shared__ int pl_start[PILLARS_PER_BLOCK + 1];
   __shared__ long long sum_fx[PILLARS_PER_BLOCK][3];
   __shared__ float mean[PILLARS_PER_BLOCK][3];
@@ -124,11 +126,29 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   }
   __syncthreads();
   const int s0 = pl_start[0], s1 = pl_start[np];
+  // point -> pillar of the block's first PL_CAP points (a pillar is a run of consecutive slots); later points (crowded pillars) search
+  for (int i = tid; i < np; i += PFN_THREADS) {
+    const int a = pl_start[i] - s0, b = min(pl_start[i + 1] - s0, PL_CAP);
+    for (int q = a; q < b; q++) pl_of[q] = (unsigned char)i;
+  }
+  auto pillar_of = [&](int s) { return (s - s0 < PL_CAP) ? (int)pl_of[s - s0] : find_pillar(pl_start, np, s); };
+  // rows of the first chunk and the bucket order of the second: in flight during sweep 1
+  float rawc[NUM_RAW], rawn[NUM_RAW];
+  int bo_n = 0;
+  {
+    const int sa = s0 + lane, sb = s0 + 64 + lane;
+    const int bo = sa < s1 ? p.bucket_order[sa] : 0;
+    if (sb < s1) bo_n = p.bucket_order[sb];
+    const float *row = p.points + (long long)bo * p.stride;
+#pragma unroll
+    for (int k = 0; k < NUM_RAW; k++) rawc[k] = row[1 + k];             // slot past the end: row 0, never used
+  }
+  __syncthreads();
 
   // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
   for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
     const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
-    int pl = find_pillar(pl_start, np, s);
+    int pl = pillar_of(s);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       long long q = __double2ll_rn((double)row[1 + a] * 16777216.0);
@@ -152,16 +172,27 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
   int buf = 0;
   for (int base = s0; base < s1; base += 64, buf ^= 1) {
     const int s = base + lane;
+    // software pipeline: the next chunk's rows (their bucket order arrived during the previous iteration) and the bucket order of the
+    // chunk after it are requested now and consumed one iteration later
+    int bo_nn = 0;
+    {
+      const int sn = s + 64, sn2 = s + 128;
+      if (sn < s1) {
+        const float *rown = p.points + (long long)bo_n * p.stride;
+#pragma unroll
+        for (int k = 0; k < NUM_RAW; k++) rawn[k] = rown[1 + k];
+      }
+      if (sn2 < s1) bo_nn = p.bucket_order[sn2];
+    }
     int pl = -1;
     float x8[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) x8[c] = 0.f;
     if (s < s1) {
-      pl = find_pillar(pl_start, np, s);
-      const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+      pl = pillar_of(s);
       float f[F];
 #pragma unroll
-      for (int k = 0; k < NUM_RAW; k++) f[k] = row[1 + k];
+      for (int k = 0; k < NUM_RAW; k++) f[k] = rawc[k];
       f[NUM_RAW + 0] = __fsub_rn(f[0], mean[pl][0]);
       f[NUM_RAW + 1] = __fsub_rn(f[1], mean[pl][1]);
       f[NUM_RAW + 2] = __fsub_rn(f[2], mean[pl][2]);
@@ -202,6 +233,9 @@ __global__ __launch_bounds__(PFN_THREADS, 2) void k_pfn(PfnParams p) {
       const int ppl = pl_s[buf][prow];
       if (ppl >= 0) atomicMax(&dmax[ppl][o], fkey(acc[e]));
     }
+#pragma unroll
+    for (int k = 0; k < NUM_RAW; k++) rawc[k] = rawn[k];
+    bo_n = bo_nn;
     // xs / pl_s are double buffered: the next chunk writes the other buffer, and the barrier of the chunk after that orders the reuse
   }
   __syncthreads();
