@@ -251,7 +251,7 @@ def main():
                     "agent: configs early / disco only -- each rank holds the points of ITS agents, one all-gather of raw points (early) or "
                     "of compressed BEV maps (disco) per step, then the frames of the batch are dealt to the ranks (pcdet/models/sharded.py; "
                     "strong scaling: the group processes ONE batch per step)")
-    ap.add_argument('--train', action='store_true', help='config disco only: time full training iterations (forward + backward + '
+    ap.add_argument('--train', action='store_true', help='configs ego / early / disco: time full training iterations (forward + backward + '
                     'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
     args = ap.parse_args()
 
@@ -274,8 +274,8 @@ def main():
     cfg = load_cfg(conf['yaml'])
     batch = args.batch or int(cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU)
     model, state, ds = build_model(cfg)
-    if args.train and args.config != 'disco':
-        raise SystemExit('--train: the training kernels cover config 5 (--config disco)')
+    if args.train and args.config == 'car':
+        raise SystemExit('--train: HunterJr (basic_car) has no training kernels; use --config ego | early | disco')
     model = model.to(dev).eval()
     for m in model.modules():
         if hasattr(m, 'materialize_pillars'):
@@ -392,8 +392,10 @@ def main():
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
             'dtype': 'f32' if os.environ.get('PCP_CONV_ALGO', 'auto') != 'bf16x3' else 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
             'data': 'synthetic',
-            'config': {'workload': conf['name'] if not args.train else 'v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
-                       'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)',
+            'config': {'workload': conf['name'] if not args.train else ('v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
+                       'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)'
+                       if args.config == 'disco' else conf['name'] + ' -- TRAINING iteration (VFE/backbone/head forward+backward, CenterNet '
+                       'losses, clip, Adam one-cycle)'),
                        'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
                        'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else

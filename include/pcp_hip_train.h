@@ -118,7 +118,8 @@ int pcp_distill_loss(const float *fused, int32_t ld_f, const float *early, int32
  * the Linear layers run on pcp_pointwise, their gradients on pcp_pointwise / pcp_pointwise_wgrad, BatchNorm on pcp_bn_*.
  * Replaces dynamic_pillar_vfe.py:110-126 (features), :35-46 (scatter_max + concat) and their autograd (scatter_max backward
  * routes to one arg-max row per (pillar, channel); ties -> first row in bucket order), pointpillar_scatter.py:14-37.
- *   features      fbuf (N', 16) = [raw(num_raw), f_cluster(3), f_center(3), 0...]; slot_pillar (N',) int32 pillar rank of each slot
+ *   features      fbuf (N', FW) = [raw(num_raw), f_cluster(3), f_center(3), 0...], FW = 16 if num_raw + 6 <= 16 else 32 (num_raw 3, 4, 5, 11);
+ *                 slot_pillar (N',) int32 pillar rank of each slot
  *   mid           in1 (N', 64) = [relu(x0 * scale0 + shift0), per-pillar max of it]; arg0 (P, 32) int32 arg-max slot
  *   out           pillar_features (P, 64) (may be NULL), arg1 (P, 64), canvas (B, ny, nx, 64) rows (may be NULL)
  *   route_out     dz1 (kept_rows, 64) = 0 except dz1[arg1[p, c], c] = dcanvas[cell(p), c]  (or dpillar[p, c]; exactly one non-NULL)

@@ -17,7 +17,7 @@ namespace {
 
 constexpr int PT_THREADS = 256;
 constexpr int PT_PILLARS = 64;
-constexpr int FW = 16;    // padded feature width
+// padded feature width: 16 floats for num_raw + 6 <= 16 (the 5-feature configs), 32 for the 11-feature lately-fusion cloud
 constexpr int C0 = 32, C1 = 64;
 
 struct FeatParams {
@@ -41,7 +41,8 @@ __device__ __forceinline__ int find_pillar(const int *pl_start, int np, int slot
 template <int NUM_RAW>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_feat(FeatParams p) {
   constexpr int F = NUM_RAW + 6;
-  static_assert(F <= FW, "feature row is padded to 16 floats");
+  constexpr int FW = F <= 16 ? 16 : 32;
+  static_assert(F <= FW, "feature row is padded to 16 or 32 floats");
   __shared__ int pl_start[PT_PILLARS + 1];
   __shared__ long long sum_fx[PT_PILLARS][3];
   __shared__ float mean[PT_PILLARS][3];
@@ -233,6 +234,7 @@ int pcp_pfn_train_features(const float *points, int64_t n, int32_t row_stride, i
     case 3: hipLaunchKernelGGL(k_pfnt_feat<3>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
     case 4: hipLaunchKernelGGL(k_pfnt_feat<4>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
     case 5: hipLaunchKernelGGL(k_pfnt_feat<5>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
+    case 11: hipLaunchKernelGGL(k_pfnt_feat<11>, dim3(blocks), dim3(PT_THREADS), 0, s, p); break;
     default: return PCP_ERR_UNSUPPORTED;
   }
   PCP_CHECK_LAUNCH();

@@ -40,12 +40,13 @@ class VFETrain:
         w0 = l0.linear.weight.detach()                       # (32, F)
         dev = w0.device
         F = w0.shape[1]
-        w0p = torch.zeros((32, 16), dtype=torch.float32, device=dev)
+        fw = 16 if F <= 16 else 32                              # feature rows are padded to 16 / 32 floats (pcp_pfn_train_features)
+        w0p = torch.zeros((32, fw), dtype=torch.float32, device=dev)
         w0p[:, :F] = w0
         w1 = l1.linear.weight.detach()                       # (64, 64)
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         self._w = dict(w0=pack.pack_plain(w0p, z(32)), w1=pack.pack_plain(w1.contiguous(), z(64)),
-                       w1t=pack.pack_plain(w1.t().contiguous(), z(64)), F=F)
+                       w1t=pack.pack_plain(w1.t().contiguous(), z(64)), F=F, fw=fw)
         self._step = tl.StepClock.step
         return self._w
 
@@ -61,7 +62,7 @@ class VFETrain:
         P, Nk = (int(v) for v in vox.counters[:2].tolist())                # host sync: row counts of the per-point GEMMs
         n = max(points.shape[0], 1)
         w = self._weights()
-        fbuf = _empty((n, 16), dev)
+        fbuf = _empty((n, w['fw']), dev)
         slot_pillar = _empty((n,), dev, torch.int32)
         tops.pfn_train_features(points, vox, m.num_raw_point_features, fbuf, slot_pillar)
         nx, ny = m.grid_size[0], m.grid_size[1]
@@ -70,7 +71,7 @@ class VFETrain:
         l0, l1 = m.pfn_layers[0], m.pfn_layers[1]
         if Nk > 0:
             fk = fbuf[:Nk]
-            x0 = ops.pointwise(fk, w['w0'][0], w['w0'][1], lib.PW_PLAIN, 16, 32, w['w0'][2], relu=False)
+            x0 = ops.pointwise(fk, w['w0'][0], w['w0'][1], lib.PW_PLAIN, w['fw'], 32, w['w0'][2], relu=False)
             self.vec0 = tops.bn_train_stats(x0, 32, l0.norm.weight.detach(), l0.norm.bias.detach(), l0.norm.eps, l0.norm.momentum,
                                             l0.norm.running_mean, l0.norm.running_var, vec=self.vec0)
             in1 = _empty((Nk, 64), dev)
@@ -108,8 +109,8 @@ class VFETrain:
         da0 = _empty((Nk, 32), dev)
         tops.pfn_train_route_mid_grad(s['vox'], din1, s['arg0'], da0)
         tops.bn_act_backward(da0, s['x0'], 32, self.vec0, True, ensure_grad(l0.norm.weight), ensure_grad(l0.norm.bias))
-        g0 = torch.empty((32, 16), dtype=torch.float32, device=dev)
-        tops.pointwise_wgrad(tops.rowmap(da0, 32), tops.rowmap(s['fk'], 16), Nk, g0)
+        g0 = torch.empty((32, w['fw']), dtype=torch.float32, device=dev)
+        tops.pointwise_wgrad(tops.rowmap(da0, 32), tops.rowmap(s['fk'], w['fw']), Nk, g0)
         ensure_grad(l0.linear.weight).copy_(g0[:, :w['F']])
         return None
 

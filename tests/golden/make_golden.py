@@ -407,6 +407,64 @@ def g7_train():
     print('g7 saved', os.path.getsize(os.path.join(HERE, 'g7_train.npz')) // 1024, 'KiB')
 
 
+def g7b_train_single(tag, yaml_name, layout):
+    """Training contract of a single-model config (VFE -> scatter -> backbone -> CenterHead, no fusion: configs 3 / 4) on the mini
+    geometry: two iterations of the reference's own train step with its own optimizer / scheduler builders."""
+    cfg = rh.load_cfg(yaml_name, {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE})
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    pts = synth.collate(mini_points(layout, 2, 2500))
+    gt = train_gt_boxes(2, 6, 1)
+    total_it_each_epoch, epochs = 5, cfg.OPTIMIZATION.NUM_EPOCHS
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=total_it_each_epoch, total_epochs=epochs,
+                                      last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
+    out = {'points': pts, 'gt_boxes': gt}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out['trainable'] = np.array(names)
+    for it in range(2):
+        lr_scheduler.step(it)
+        out['it%d_lr' % it] = np.array(float(optimizer.lr))
+        out['it%d_mom' % it] = np.array(float(optimizer.mom))
+        model.train()
+        optimizer.zero_grad()
+        bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.from_numpy(gt.copy())}
+        ret, tb, _disp = model(bd)
+        loss = ret['loss']
+        model.update_global_step()
+        loss.backward()
+        out['it%d_loss' % it] = np.array(float(loss))
+        out['it%d_tb_json' % it] = np.array(json.dumps({k: float(v) for k, v in tb.items()}))
+        params = dict(model.named_parameters())
+        out['it%d_grad_digest' % it] = np.stack([_digest(params[n].grad) for n in names])
+        if it == 0:
+            out['map_probe'] = bd['spatial_features_2d'].detach().numpy()[:, ::8].copy()
+            for n in names:
+                out['g0/' + n] = _sample(params[n].grad)
+        norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        out['it%d_grad_norm' % it] = np.array(float(norm))
+        optimizer.step()
+        if it == 0:
+            for n in names:
+                out['p1/' + n] = _sample(params[n])
+            sd = model.state_dict()
+            bn_keys = [k for k in sd if 'running_' in k]
+            out['bn_keys'] = np.array(bn_keys)
+            out['it0_bn_digest'] = np.stack([_digest(sd[k]) for k in bn_keys])
+        print('g7b', tag, 'it', it, 'loss', float(loss), 'norm', float(norm), tb)
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), optimization=rh.to_plain(cfg.OPTIMIZATION),
+                                                 pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(cfg.CLASS_NAMES),
+                                                 yaml=yaml_name, layout=layout, state_shapes=shapes,
+                                                 num_point_features=int(ds.point_feature_encoder.num_point_features),
+                                                 total_it_each_epoch=total_it_each_epoch)))
+    path = os.path.join(HERE, 'g7b_train_%s.npz' % tag)
+    np.savez_compressed(path, **out)
+    print('g7b saved', tag, os.path.getsize(path) // 1024, 'KiB')
+
+
 def g8_exchange():
     """Lately-fusion exchange: runs the reference's own apply_se3_ and the lines of v2x_sim_dataset_ego.py:196-232
     (torch.unique + scatter(mean) through the shim) on seeded MoDAR boxes / foreground points.  points_in_boxes_gpu is CUDA-only in
@@ -535,6 +593,8 @@ if __name__ == '__main__':
         g2_full()
     if 'g7' in todo:
         g7_train()
+    if 'g7b' in todo:
+        g7b_train_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately')
     if 'g8' in todo:
         g8_exchange()
     if 'g9' in todo:
