@@ -435,7 +435,7 @@ def main():
                                     'note': 'NOT the headline: 3x3 conv products as split bf16 (hi + lo, 16 mantissa bits; 3 bf16 MFMAs per '
                                             'product, f32 accumulate), ~1e-5 relative error, all parity tests pass at unchanged tolerances; '
                                             'enable with --conv-algo bf16x3 / PCP_CONV_ALGO=bf16x3'}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                    # rank 0 at N = 1 only (the contract); N > 1 lines carry null
             line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
         else:
             line['cpu_baseline'] = None
