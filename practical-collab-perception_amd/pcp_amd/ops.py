@@ -158,13 +158,18 @@ def conv3x3_winograd(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None
 
 
 _W4_WORKSPACE = {}
+_W4_RETIRED = []
 
 
 def _w4_workspace(device, nbytes):
     """one grow-only scratch buffer per device for the F(4x4,3x3) transforms (V and M, ~0.9 GB for 768 -> 768 at 4 frames); the three
-    launches of a call consume it in stream order, so consecutive calls on the same stream can share it"""
+    launches of a call consume it in stream order, so consecutive calls on the same stream can share it (callers that run convolutions
+    on several streams at once must pass their own workspace through the C ABI).  A buffer that is outgrown stays referenced: a
+    captured hipGraph may have its address baked in."""
     buf = _W4_WORKSPACE.get(device)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _W4_RETIRED.append(buf)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _W4_WORKSPACE[device] = buf
     return buf
