@@ -24,6 +24,7 @@ namespace {
 
 constexpr int G_BM = 128, G_BN = 128, G_KS = 32, G_LD = 36, G_THREADS = 256;
 constexpr int G_TILE_FLOATS = G_BM * G_LD;
+constexpr int G_PERSISTENT_WGS = 512;       // 256 CUs x 2 resident workgroups
 
 struct W4Geom {
   int batch, h, w;
@@ -168,14 +169,27 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_w4_gemm(GemmParams p) {
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
 
-  int lid = xcd_remap_g(blockIdx.x, gridDim.x);
-  const int nt = lid % p.n_tiles;
-  lid /= p.n_tiles;
-  const int mt = lid % p.m_tiles;
-  const int pos = lid / p.m_tiles;
+  // Persistent workgroups: XCD x (= blockIdx & 7; blocks are dealt round-robin over the XCDs) owns the contiguous tile range
+  // [x * per_xcd, (x + 1) * per_xcd) and its workgroups take tiles j, j + wgs_per_xcd, ... of it: at any time one XCD works on
+  // consecutive tiles (N tile fastest: the workgroups sharing a V tile run together, a position's U stays in that L2), and the
+  // (tile, K slice) sequence of a workgroup is ONE software pipeline -- the first slice of the next tile is fetched under the last
+  // multiply of the current one, the accumulators are stored while the next tile's slices are already in flight.
+  const int total = 36 * p.m_tiles * p.n_tiles;
+  const int xcd = blockIdx.x & 7, wgs_per_xcd = (gridDim.x + 7 - xcd) >> 3, j0 = blockIdx.x >> 3;
+  const int per_xcd = (total + 7) >> 3;
+  const int t_begin = xcd * per_xcd, t_end = min(total, t_begin + per_xcd);
+  int tile = t_begin + j0;
+  if (tile >= t_end) return;
 
-  const float *ga = p.a + ((long long)pos * p.m_pad + (long long)mt * G_BM) * p.k;        // workgroup-uniform
-  const float *gb = p.b + ((long long)pos * p.n_pad + (long long)nt * G_BN) * p.k;
+  const float *ga, *gb;
+  auto tile_ptrs = [&](int t) {
+    const int nt = t % p.n_tiles;
+    const int q = t / p.n_tiles;
+    const int mt = q % p.m_tiles;
+    const int pos = q / p.m_tiles;
+    ga = p.a + ((long long)pos * p.m_pad + (long long)mt * G_BM) * p.k;        // workgroup-uniform
+    gb = p.b + ((long long)pos * p.n_pad + (long long)nt * G_BN) * p.k;
+  };
   // staging: thread -> (row = tid >> 3 (+32 i), 16-byte column tid & 7): 8 lanes cover one 128-byte row segment
   const int s_row = tid >> 3, s_c4 = tid & 7;
   unsigned goff[4];
@@ -230,30 +244,47 @@ __global__ __launch_bounds__(G_THREADS, 2) void k_w4_gemm(GemmParams p) {
           for (int c = 0; c < 2; c++) acc[i][c] = mfma32g(af[i][kk], bf[c][kk], acc[i][c]);
     }
   };
+  auto store_tile = [&](int t) {
+    const int nt = t % p.n_tiles;
+    const int q = t / p.n_tiles;
+    const int mt = q % p.m_tiles;
+    const int pos = q / p.m_tiles;
+    float *gc = p.c + ((long long)pos * p.m_pad + (long long)mt * G_BM + wm * 64) * p.n_pad + nt * G_BN + wn * 64 + r;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          gc[(long long)row * p.n_pad + c * 32] = acc[i][c][e];
+          acc[i][c][e] = 0.f;
+        }
+  };
 
   const int n_slices = p.k / G_KS;
+  tile_ptrs(tile);
   g_load(0);
   s_store(0);
   __syncthreads();
-  for (int s = 0; s < n_slices; s++) {
-    const int cur = s & 1;
-    const bool more = s + 1 < n_slices;
-    if (more) g_load(s + 1);
-    multiply(cur);
-    if (more) s_store(cur ^ 1);
-    __syncthreads();
-  }
-
-  float *gc = p.c + ((long long)pos * p.m_pad + (long long)mt * G_BM + wm * 64) * p.n_pad + nt * G_BN + wn * 64 + r;
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        gc[(long long)row * p.n_pad + c * 32] = acc[i][c][e];
+  int cur = 0;
+  while (true) {
+    for (int s = 0; s < n_slices; s++, cur ^= 1) {
+      const bool last_slice = s + 1 == n_slices;
+      const int next_tile = tile + wgs_per_xcd;
+      const bool more = !last_slice || next_tile < t_end;
+      if (more) {
+        if (last_slice) tile_ptrs(next_tile);
+        g_load(last_slice ? 0 : s + 1);
       }
+      multiply(cur);
+      if (last_slice) store_tile(tile);
+      if (more) s_store(cur ^ 1);
+      __syncthreads();
+    }
+    tile += wgs_per_xcd;
+    if (tile >= t_end) break;
+  }
 }
 
 int w4_geom(const pcp_conv3x3_t *d, W4Geom *g) {
@@ -303,8 +334,10 @@ static int w4_run(const pcp_conv3x3_t *d, const float *in, const float *u_packed
   p.m_pad = g.m_pad; p.n_pad = g.n_pad; p.k = g.cin;
   p.m_tiles = (int)(g.m_pad / G_BM);
   p.n_tiles = g.n_pad / G_BN;
-  const long long gemm_blocks = 36LL * p.m_tiles * p.n_tiles;
-  if (in_blocks > 0x7fffffffLL || out_blocks > 0x7fffffffLL || gemm_blocks > 0x7fffffffLL) return PCP_ERR_ARG;
+  const long long gemm_tiles = 36LL * p.m_tiles * p.n_tiles;
+  if (in_blocks > 0x7fffffffLL || out_blocks > 0x7fffffffLL || gemm_tiles > 0x7fffffffLL) return PCP_ERR_ARG;
+  // persistent: two workgroups per CU (the kernel's LDS footprint allows no more), fewer when there are fewer tiles
+  const long long gemm_blocks = gemm_tiles < G_PERSISTENT_WGS ? gemm_tiles : G_PERSISTENT_WGS;
   if ((long long)G_BM * g.cin * 4 > 0x7fffffffLL) return PCP_ERR_ARG;
 
   if (ev && hipEventRecord(ev[0], st) != hipSuccess) return PCP_ERR_LAUNCH;
