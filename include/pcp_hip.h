@@ -280,10 +280,12 @@ int pcp_hunter_apply_flow(float *points, int64_t n, int32_t row_stride, const fl
  * 3x4 pose (x' = R x + t, row-major R|t per batch element, float32); every other row gets batch index -1 so that
  * pcp_voxelize masks it.  Replaces pcdet/models/bev_layers/bev_maker.py:168-179 (boolean-mask copy + per-frame matmul).
  * poses_host: (batch, 12) float32 on the HOST; present_host: (batch,) uint8, 0 = agent absent from that frame.
+ * out_batch_offset is added to the frame index of the rows kept: several agents' clouds can then be stacked into ONE pass of the shared
+ * frozen chain (agent slot i -> frames [i * batch, (i + 1) * batch)), which is bit-identical per frame to separate passes.
  * ------------------------------------------------------------------------------------------------------------------ */
 int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, float agent,
                                 int32_t batch, const float *poses_host, const uint8_t *present_host, float *out,
-                                void *stream);
+                                int32_t out_batch_offset, void *stream);
 /* Which agents have points (bev_maker.py:156 `torch.unique(points[:, -1])`, a sort + host sync in the reference): out2[0] = bit mask
  * of the integer values 0..63 found in column `col`, out2[1] = number of rows holding anything else (then the caller sorts).
  * out2: 2 x uint64 on the device, 16-byte aligned; zeroed by the call. */

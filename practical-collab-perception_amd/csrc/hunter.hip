@@ -235,7 +235,7 @@ struct PoseTable {
 };
 
 __global__ void k_select_transform(const float *__restrict__ points, long long n, int stride, int agent_col, float agent,
-                                   int batch, PoseTable pt, float *__restrict__ out) {
+                                   int batch, PoseTable pt, float *__restrict__ out, float batch_offset) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float *row = points + i * stride;
@@ -249,6 +249,7 @@ __global__ void k_select_transform(const float *__restrict__ points, long long n
   }
   const float *T = pt.m[b];
   float x = row[1], y = row[2], z = row[3];
+  o[0] = row[0] + batch_offset;
   o[1] = x * T[0] + y * T[1] + z * T[2] + T[3];
   o[2] = x * T[4] + y * T[5] + z * T[6] + T[7];
   o[3] = x * T[8] + y * T[9] + z * T[10] + T[11];
@@ -292,8 +293,9 @@ extern "C" int pcp_hunter_apply_flow(float *points, int64_t n, int32_t row_strid
 
 extern "C" int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, float agent,
                                            int32_t batch, const float *poses_host, const uint8_t *present_host, float *out,
-                                           void *stream_) {
-  if (n < 0 || row_stride < 4 || agent_col < 0 || agent_col >= row_stride || batch <= 0 || batch > MAX_POSE_BATCH) return PCP_ERR_ARG;
+                                           int32_t out_batch_offset, void *stream_) {
+  if (n < 0 || row_stride < 4 || agent_col < 0 || agent_col >= row_stride || batch <= 0 || batch > MAX_POSE_BATCH || out_batch_offset < 0)
+    return PCP_ERR_ARG;
   if (n == 0) return PCP_OK;
   if (!points || !poses_host || !present_host || !out || points == out) return PCP_ERR_ARG;
   PoseTable pt;
@@ -302,7 +304,7 @@ extern "C" int pcp_select_transform_points(const float *points, int64_t n, int32
     for (int k = 0; k < 12; k++) pt.m[b][k] = b < batch ? poses_host[b * 12 + k] : 0.f;
   }
   hipLaunchKernelGGL(k_select_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, points,
-                     (long long)n, row_stride, agent_col, agent, batch, pt, out);
+                     (long long)n, row_stride, agent_col, agent, batch, pt, out, (float)out_batch_offset);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -30,6 +30,7 @@ class BEVMaker(nn.Module):
         self.module_list = self.build_networks()
         self.maker_type = model_cfg.MAKER_TYPE
         self.only_agents = None            # agent-sharded execution (pcdet/models/sharded.py): encode just these agents on this rank
+        self.max_agents_per_pass = 8       # agents stacked into one pass of the frozen chain (1 = the reference's one pass per agent)
         ckpt = model_cfg.get('CKPT', None)
         if ckpt not in (None, '', 'none', 'None'):
             self.load_params_from_file(ckpt, logger or logging.getLogger(), to_cpu=True)
@@ -86,6 +87,7 @@ class BEVMaker(nn.Module):
             agent_ids = ops.column_ids(points, -1)
             batch_dict['_pcp_agent_ids'] = (points, agent_ids)
         batch_dict['bev_img'] = dict()
+        jobs = []
         for agent_idx in agent_ids:
             if agent_idx == 1 or (self.maker_type == 'rsu' and agent_idx != 0):
                 continue
@@ -101,12 +103,25 @@ class BEVMaker(nn.Module):
                 present[b_idx] = 1
             if not present.any():
                 continue
-            agent_points = ops.select_transform_points(points, points.shape[1] - 1, float(agent_idx), poses, present)
             # the reference derives the map's batch dimension from the largest frame index that has points (quirk of
             # pointpillar_scatter.py:17); reproduce it so downstream shapes match
-            last = int(np.nonzero(present)[0].max()) + 1
-            bev = self._run_chain(agent_points, batch_size)
-            batch_dict['bev_img'][int(agent_idx)] = bev[:last]
+            jobs.append((int(agent_idx), poses, present, int(np.nonzero(present)[0].max()) + 1))
+        if not jobs:
+            return batch_dict
+        # The agents share this maker's frozen chain and frames are independent in it (eval-mode BatchNorm, per-frame pillars and
+        # tiles), so their clouds are stacked into ONE pass: agent slot i -> frames [i * B, (i + 1) * B).  Bit-identical per frame to
+        # the reference's one pass per agent (:168-190), with 1/len(jobs) of the launches and better-filled small layers.
+        n, c = points.shape
+        group = max(1, min(len(jobs), self.max_agents_per_pass))
+        for g0 in range(0, len(jobs), group):
+            chunk = jobs[g0:g0 + group]
+            stacked = points.new_empty((len(chunk) * n, c))
+            for slot, (agent_idx, poses, present, _last) in enumerate(chunk):
+                ops.select_transform_points(points, c - 1, float(agent_idx), poses, present, out=stacked[slot * n:(slot + 1) * n],
+                                            batch_offset=slot * batch_size)
+            bev = self._run_chain(stacked, batch_size * len(chunk))
+            for slot, (agent_idx, _poses, _present, last) in enumerate(chunk):
+                batch_dict['bev_img'][agent_idx] = bev[slot * batch_size:slot * batch_size + last]
         return batch_dict
 
     @torch.no_grad()

@@ -103,7 +103,7 @@ SYMBOLS = {
     'pcp_voxelize_row_order': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp]),
     'pcp_hunter_apply_flow': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_f, vp, vp]),
     'pcp_select_transform_points': (c_i32, [vp, c_i64, c_i32, c_i32, c_f, c_i32, ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_uint8),
-                                            vp, vp]),
+                                            vp, c_i32, vp]),
     'pcp_bev_scatter_mean_workspace_bytes': (c_sz, [c_i32, c_i32, c_i32, c_i64]),
     'pcp_bev_scatter_mean': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, vp, c_sz,
                                      vp, c_i32, vp]),

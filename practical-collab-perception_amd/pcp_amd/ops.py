@@ -431,20 +431,23 @@ def column_ids(points, col):
     return np.asarray([i for i in range(64) if (mask >> i) & 1], dtype=np.int64)
 
 
-def select_transform_points(points, agent_col, agent, poses, present):
+def select_transform_points(points, agent_col, agent, poses, present, out=None, batch_offset=0):
     """poses: (B, 12) float32 numpy (row-major R|t); present: (B,) bool.  Returns a same-shape copy of `points` where rows of
-    other agents / absent frames carry batch index -1."""
+    other agents / absent frames carry batch index -1 and the rows kept carry frame index + batch_offset (out: optional (N, C)
+    destination, e.g. a slice of a buffer that stacks several agents for one pass of a shared chain)."""
     import numpy as np
-    _need_cuda(points)
+    _need_cuda(points, out)
     L = _lib.load()
     n, stride = points.shape
-    out = torch.empty_like(points)
+    if out is None:
+        out = torch.empty_like(points)
+    assert out.shape == points.shape and out.is_contiguous() and out.dtype == torch.float32
     poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1)
     pres = np.ascontiguousarray(present, dtype=np.uint8)
     B = pres.shape[0]
     check(L.pcp_select_transform_points(_p(points), n, stride, agent_col % stride, float(agent), B,
                                         poses.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                                        pres.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _p(out), _stream()),
+                                        pres.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _p(out), int(batch_offset), _stream()),
           'pcp_select_transform_points')
     return out
 

@@ -93,6 +93,31 @@ def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monke
         assert (128, 384) in calls and (384, 384) in calls
 
 
+def test_stacked_agent_pass_is_bitwise_the_per_agent_passes():
+    """BEVMaker stacks the agents that share a frozen chain into one pass (slot i -> frames [i B, (i + 1) B)); per frame that must be
+    bit-identical to the reference's one pass per agent (bev_maker.py:168-190), incl. the frame from which an agent is absent"""
+    g = load_golden('g1_disco.npz')
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    outs = []
+    for per_pass in (1, 8):
+        model = _build(g)
+        for m in model.modules():
+            if hasattr(m, 'max_agents_per_pass'):
+                m.max_agents_per_pass = per_pass
+        batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+        with torch.no_grad():
+            pred_dicts, _ = model(batch)
+        torch.cuda.synchronize()
+        outs.append((batch, pred_dicts))
+    (b1, p1), (b8, p8) = outs
+    assert sorted(b1['bev_img'].keys()) == sorted(b8['bev_img'].keys()) == [0, 2]
+    for aid in (0, 2):
+        assert b1['bev_img'][aid].shape == b8['bev_img'][aid].shape and torch.equal(b1['bev_img'][aid], b8['bev_img'][aid])
+    assert torch.equal(b1['spatial_features_2d'], b8['spatial_features_2d'])
+    for a, b in zip(p1, p8):
+        assert torch.equal(a['pred_boxes'], b['pred_boxes']) and torch.equal(a['pred_scores'], b['pred_scores'])
+
+
 def test_fast_mode_skips_pillar_materialisation_and_matches():
     g = load_golden('g1_ego.npz')
     model = _build(g)
