@@ -33,6 +33,7 @@ struct HeadConvParams {
 
 __global__ __launch_bounds__(256) void k_head_grouped(HeadConvParams p) {
   __shared__ __attribute__((aligned(16))) float patch[HG_P * HG_P * HG_LD];
+  __shared__ __attribute__((aligned(16))) float wsl[HG_MAX_K * 9 * HG_CG];     // the slice's weights [k][tap][64 channels]
   __shared__ float part[4][64][HG_MAX_K];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,8 +51,21 @@ __global__ __launch_bounds__(256) void k_head_grouped(HeadConvParams p) {
   constexpr int NLD = (HG_P * HG_P * 16 + 255) / 256;       // 7 float4 per thread
   const int n_slices = p.groups * p.chunks;
   f32x4 pre[NLD];
+  constexpr int WLD4 = (HG_MAX_K * 9 * HG_CG / 4 + 255) / 256;     // 3 float4 per thread (576 items for k = 4)
+  f32x4 prew[WLD4];
   auto load_slice = [&](int s) {
     const int g = s / p.chunks, ch = s % p.chunks;
+    {
+      const int o0 = p.goff[g], kg = p.goff[g + 1] - o0;
+#pragma unroll
+      for (int u = 0; u < WLD4; ++u) {
+        const int idx = tid + u * 256;                       // (k * 9 + tap) * 16 + q
+        const int kt = idx >> 4, q = idx & 15;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < kg * 9) v = *reinterpret_cast<const f32x4 *>(p.w + ((long long)o0 * 9 + kt) * cg + ch * HG_CG + q * 4);
+        prew[u] = v;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int idx = tid + u * 256;
@@ -68,6 +82,11 @@ __global__ __launch_bounds__(256) void k_head_grouped(HeadConvParams p) {
     for (int u = 0; u < NLD; ++u) {
       const int idx = tid + u * 256;
       if (idx < HG_P * HG_P * 16) *reinterpret_cast<f32x4 *>(patch + (idx >> 4) * HG_LD + (idx & 15) * 4) = pre[u];
+    }
+#pragma unroll
+    for (int u = 0; u < WLD4; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < HG_MAX_K * 9 * 16) *reinterpret_cast<f32x4 *>(wsl + idx * 4) = prew[u];
     }
   };
   load_slice(0);
@@ -88,9 +107,13 @@ __global__ __launch_bounds__(256) void k_head_grouped(HeadConvParams p) {
 #pragma unroll
       for (int k = 0; k < HG_MAX_K; k++) {
         if (k < kg) {                                           // wave-uniform
-          const float *wr = p.w + ((long long)(o0 + k) * 9 + tap) * cg + ch * HG_CG + wave * 16;   // wave-uniform address
+          // all lanes read the same 64 bytes: LDS broadcast (the first version fetched them with 18 dependent s_load_dwordx16 per slice)
+          const float *wr = wsl + (k * 9 + tap) * HG_CG + wave * 16;
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wr), w1 = *reinterpret_cast<const f32x4 *>(wr + 4);
+          const f32x4 w2 = *reinterpret_cast<const f32x4 *>(wr + 8), w3 = *reinterpret_cast<const f32x4 *>(wr + 12);
+          const float ws[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
 #pragma unroll
-          for (int c = 0; c < 16; c++) acc[k] = fmaf(wr[c], xs[c], acc[k]);
+          for (int c = 0; c < 16; c++) acc[k] = fmaf(ws[c], xs[c], acc[k]);
         }
       }
     }
