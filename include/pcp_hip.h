@@ -106,6 +106,17 @@ typedef struct {
 int pcp_conv3x3(const pcp_conv3x3_t *desc, const float *in, const float *w_packed, const float *bias, float *out,
                 void *stream);
 
+/* a5 + a6, first backbone layer from the pillar list: ZeroPad2d(1) + Conv2d(64, cout, 3, stride 2) + folded BN + ReLU
+ * (base_bev_backbone.py:36-44) WITHOUT the dense canvas of pointpillar_scatter.py:14-37 -- the occupied input cells of every tap are
+ * found in the cell -> pillar-rank table pcp_voxelize left in its workspace, their pillar rows gathered and multiplied on the matrix
+ * cores, products added per output pixel in a fixed order (deterministic, no atomics).
+ * pillar_features: (P, 64) in pillar-rank order (pcp_pfn_scatter's optional output); grid / vox_workspace / n: as passed to pcp_voxelize;
+ * w_packed: [9 (ky*3+kx)][64][64 (cin)] float32 (rows >= cout zero), bias [64]; cout <= 64, cout % 4 == 0;
+ * out: (B, (ny-1)/2+1, (nx-1)/2+1, ld_out) NHWC. */
+int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n,
+                          const float *w_packed, const float *bias, int32_t cout, int32_t relu, float *out, int32_t ld_out,
+                          void *stream);
+
 /* Same operation for stride 1 as a fused Winograd F(2x2,3x3) kernel (2.25x fewer multiplies, still fp32 MFMA with fp32
  * accumulation; transforms add ~1e-6 relative rounding).  Needs cin % 8 == 0, cout_pad % 64 == 0 and weights packed as
  * U = G g G^T: [cin/8][16 (i*4+j)][cout_pad][8]. */

@@ -1,0 +1,259 @@
+// a5 + a6 (first layer) -- the stride-2 3x3 convolution that opens the BEV backbone (base_bev_backbone.py:36-44: ZeroPad2d(1),
+// Conv2d(64, C, 3, stride 2), BN, ReLU) computed from the PILLAR LIST instead of the dense canvas.
+//
+// The canvas PointPillarScatter builds (pointpillar_scatter.py:14-37) is zero except at the P pillars (20 % of the 512 x 512 cells for a
+// 60 k-point cloud, less for real sweeps).  The dense kernel reads 67 MB per frame and multiplies 80 % zeros; here a workgroup owns
+// 8 x 16 output pixels and, tap by tap in a fixed order,
+//   looks the 128 input cells of the tap up in the pillariser's cell -> pillar-rank table (pcp_voxelize workspace),
+//   compacts the occupied ones (ballot prefix, pixel order) into rows of at most 32,
+//   gathers their 64-float pillar rows into an LDS A tile and multiplies [32 x 64] x [64 x C] on v_mfma_f32_32x32x2_f32
+//   (wave = 32-channel column tile x K half; the tap's weights go from L2 straight into registers),
+//   adds the product rows into the pixels' accumulators in LDS.
+// No atomics and a fixed summation order (taps ascending, K halves fixed): deterministic.  Work: 2.25 products per pillar instead of
+// 9 per output pixel, i.e. ~4x fewer MFMAs at 20 % occupancy after padding the row tiles to 32; the dense canvas is neither read nor
+// (when no caller asks for `spatial_features`) written.
+#include "pcp_common.h"
+
+namespace {
+
+constexpr int SP_TH = 8, SP_TW = 16, SP_PIX = SP_TH * SP_TW;     // output pixels per workgroup
+constexpr int SP_CIN = 64;
+constexpr int SP_ALD = 68;                                        // padded A row: conflict-free ds_read_b128 groups
+constexpr int SP_THREADS = 256;
+
+struct SpParams {
+  const float *pf;          // (P, 64) pillar features in pillar-rank order
+  const int *cell_rank;     // [B * nx * ny]: merged id b*nx*ny + cx*ny + cy -> pillar rank, -1 = empty
+  const float *w;           // [9][64 (cout)][64 (cin)], k contiguous
+  const float *bias;        // [64]
+  float *out;               // (B, ho, wo, ld_out)
+  int batch, nx, ny, ho, wo, ld_out, cout, relu;
+  int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ f32x16 mfma32s(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
+  __shared__ __attribute__((aligned(16))) float acc[SP_PIX * 64];          // per-pixel accumulators
+  __shared__ __attribute__((aligned(16))) float atile[32 * SP_ALD];         // gathered pillar rows of the chunk
+  __shared__ __attribute__((aligned(16))) float res[2][32 * 64];            // product rows, one copy per K half
+  __shared__ int row_rank[9][SP_PIX];                                       // compacted (tap-wise) pillar ranks ...
+  __shared__ unsigned char row_pix[9][SP_PIX];                              // ... and the output pixel each row belongs to
+  __shared__ int cnt[9][2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int sp = blockIdx.x;
+  const int tile_x = sp % p.tiles_x;
+  sp /= p.tiles_x;
+  const int tile_y = sp % p.tiles_y;
+  const int b = sp / p.tiles_y;
+  const int oy0 = tile_y * SP_TH, ox0 = tile_x * SP_TW;
+  const int plane = p.nx * p.ny;
+
+  // ---- occupancy of the 9 x 128 (tap, pixel) input cells, compacted per tap in pixel order ------------------------------------------
+  int rank[9];
+  {
+    const int py = tid >> 4, px = tid & 15;                                 // threads 0..127 <-> pixels
+    const int oy = oy0 + py, ox = ox0 + px;
+    const bool pix_ok = tid < SP_PIX && oy < p.ho && ox < p.wo;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+      rank[t] = -1;
+      if (pix_ok && iy >= 0 && iy < p.ny && ix >= 0 && ix < p.nx) rank[t] = p.cell_rank[(long long)b * plane + ix * p.ny + iy];
+    }
+  }
+  for (int i = tid; i < SP_PIX * 64; i += SP_THREADS) acc[i] = 0.f;
+  int pre[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const unsigned long long bal = __ballot(rank[t] >= 0);
+    pre[t] = __popcll(bal & ((1ULL << lane) - 1ULL));
+    if (lane == 0 && wave < 2) cnt[t][wave] = __popcll(bal);
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const int c0 = cnt[t][0], c1 = cnt[t][1];
+    total += c0 + c1;
+    if (tid < SP_PIX && rank[t] >= 0) {
+      const int row = (wave == 1 ? c0 : 0) + pre[t];
+      row_rank[t][row] = rank[t];
+      row_pix[t][row] = (unsigned char)tid;
+    }
+  }
+  __syncthreads();
+
+  if (total > 0) {
+    const int nt = wave & 1, kh = wave >> 1;                                // this wave's column tile and K half
+    const int g_row = tid >> 3, g_q = (tid & 7) * 2;                       // gather: row, first of two 16-byte columns
+    // work items = (tap, 32-row chunk) in ascending order (thread 0 lists them; at most 9 taps x 4 chunks)
+    __shared__ unsigned char item_tap[36], item_chunk[36];
+    __shared__ int n_items_s;
+    if (tid == 0) {
+      int k = 0;
+      for (int t = 0; t < 9; t++)
+        for (int c0 = 0; c0 < cnt[t][0] + cnt[t][1]; c0 += 32) { item_tap[k] = (unsigned char)t; item_chunk[k] = (unsigned char)(c0 >> 5); k++; }
+      n_items_s = k;
+    }
+    __syncthreads();
+    const int n_items = n_items_s;
+    // The gather of an item's pillar rows is a dependent L2 / HBM access of ~2 us against ~0.5 us of work per item: four items are
+    // kept in flight in a register ring (statically indexed through the 4x unrolled loop), the tap's weight fragments one tap ahead.
+    constexpr int DEPTH = 4;
+    f32x4 g[DEPTH][2];
+    // UNCONDITIONAL loads with clamped indices (rows past the chunk re-read a valid row and are zeroed when they are stored to LDS):
+    // a static number of outstanding loads lets hipcc's counted s_waitcnt wait for the oldest ring slot only -- with predicated loads
+    // it waited for the request it had just issued, one L2 / HBM round trip per item
+    auto gather = [&](int k, f32x4 (&dst)[2]) {
+      const int kc = min(k, n_items - 1);
+      const int t = item_tap[kc], c0 = item_chunk[kc] * 32;
+      const int row = min(c0 + g_row, cnt[t][0] + cnt[t][1] - 1);
+      const float *src = p.pf + (long long)row_rank[t][row] * SP_CIN + g_q * 4;
+      dst[0] = *reinterpret_cast<const f32x4 *>(src);
+      dst[1] = *reinterpret_cast<const f32x4 *>(src + 4);
+    };
+    // weight fragments of ALL nine taps stay in registers (144 VGPRs): W[t][nt*32 + r][kh*32 + 8j + 4h .. +3].  Streaming them tap by
+    // tap exposed an L2 round trip per item (most taps are a single item): 127 us for the layer.
+    f32x4 wall[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const float *wr = p.w + ((long long)(t * 64 + nt * 32 + r)) * SP_CIN + kh * 32 + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 4; j++) wall[t][j] = *reinterpret_cast<const f32x4 *>(wr + 8 * j);
+    }
+    // issue order matters to the counted waits (vmcnt retires in order): weights first, then ring slots 0..3 -- keep the scheduler
+    // from moving slot 0 behind the others
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < DEPTH; u++) {
+      gather(u, g[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k0 = 0; k0 < n_items; k0 += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; u++) {
+        const int k = k0 + u;
+        if (k < n_items) {                                                  // workgroup-uniform
+          const int t = item_tap[k], c0 = item_chunk[k] * 32;
+          const int rows = min(32, cnt[t][0] + cnt[t][1] - c0);
+          const bool live = g_row < rows;
+          const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4 *>(atile + g_row * SP_ALD + g_q * 4) = live ? g[u][0] : zero4;
+          *reinterpret_cast<f32x4 *>(atile + g_row * SP_ALD + g_q * 4 + 4) = live ? g[u][1] : zero4;
+          __builtin_amdgcn_sched_barrier(0);
+          gather(k + DEPTH, g[u]);
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+          f32x16 a16, b16;                                                  // two independent chains: half the dependent-MFMA latency
+#pragma unroll
+          for (int e = 0; e < 16; e++) { a16[e] = 0.f; b16[e] = 0.f; }
+          const float *xa = atile + r * SP_ALD + kh * 32 + 4 * h;
+          f32x4 af[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) af[j] = *reinterpret_cast<const f32x4 *>(xa + 8 * j);
+          auto multiply = [&](const f32x4 (&wf)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+              a16 = mfma32s(af[j].x, wf[j].x, a16);
+              b16 = mfma32s(af[j + 1].x, wf[j + 1].x, b16);
+              a16 = mfma32s(af[j].y, wf[j].y, a16);
+              b16 = mfma32s(af[j + 1].y, wf[j + 1].y, b16);
+              a16 = mfma32s(af[j].z, wf[j].z, a16);
+              b16 = mfma32s(af[j + 1].z, wf[j + 1].z, b16);
+              a16 = mfma32s(af[j].w, wf[j].w, a16);
+              b16 = mfma32s(af[j + 1].w, wf[j + 1].w, b16);
+            }
+          };
+          switch (t) {                                                      // workgroup-uniform; keeps `wall` statically indexed
+            case 0: multiply(wall[0]); break;
+            case 1: multiply(wall[1]); break;
+            case 2: multiply(wall[2]); break;
+            case 3: multiply(wall[3]); break;
+            case 4: multiply(wall[4]); break;
+            case 5: multiply(wall[5]); break;
+            case 6: multiply(wall[6]); break;
+            case 7: multiply(wall[7]); break;
+            default: multiply(wall[8]); break;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; e++) res[kh][((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + nt * 32 + r] = a16[e] + b16[e];
+          __syncthreads();
+          // scatter-add: the rows of one chunk belong to DISTINCT pixels, so all reads are issued before any write (written as a
+          // read-modify-write loop the compiler has to assume aliasing and serialises eight LDS round trips)
+          const int n = tid & 63;
+          int pixs[8];
+          float sum[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int row = (tid >> 6) + 4 * i;
+            pixs[i] = row < rows ? (int)row_pix[t][c0 + row] : -1;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int row = (tid >> 6) + 4 * i;
+            const int pa = pixs[i] >= 0 ? pixs[i] : 0;
+            sum[i] = acc[pa * 64 + n] + (res[0][row * 64 + n] + res[1][row * 64 + n]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            if (pixs[i] >= 0) acc[pixs[i] * 64 + n] = sum[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + ReLU, one 256-byte row per pixel --------------------------------------------------------------------------
+  {
+    const int n4 = (tid & 15) * 4;
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.bias + n4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int pix = (tid >> 4) + 16 * i;
+      const int oy = oy0 + (pix >> 4), ox = ox0 + (pix & 15);
+      if (oy < p.ho && ox < p.wo && n4 < p.cout) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(acc + pix * 64 + n4) + bv;
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<f32x4 *>(p.out + ((long long)(b * p.ho + oy) * p.wo + ox) * p.ld_out + n4) = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n,
+                                     const float *w_packed, const float *bias, int32_t cout, int32_t relu, float *out, int32_t ld_out,
+                                     void *stream_) {
+  if (!pillar_features || !grid || !vox_workspace || !w_packed || !bias || !out || n < 0) return PCP_ERR_ARG;
+  if (cout <= 0 || cout > 64 || cout % 4 != 0 || ld_out % 4 != 0 || ld_out < cout) return PCP_ERR_UNSUPPORTED;
+  if ((((uintptr_t)pillar_features) & 15) || (((uintptr_t)w_packed) & 15) || (((uintptr_t)bias) & 15) || (((uintptr_t)out) & 15))
+    return PCP_ERR_ARG;
+  if (grid->batch_size <= 0 || grid->nx <= 0 || grid->ny <= 0) return PCP_ERR_ARG;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  VoxLayout L = pcp_vox_layout(cells, n);
+  SpParams p;
+  p.pf = pillar_features;
+  p.cell_rank = reinterpret_cast<const int *>(reinterpret_cast<const char *>(vox_workspace) + L.cell_rank);
+  p.w = w_packed; p.bias = bias; p.out = out;
+  p.batch = grid->batch_size; p.nx = grid->nx; p.ny = grid->ny;
+  p.ho = (grid->ny - 1) / 2 + 1;
+  p.wo = (grid->nx - 1) / 2 + 1;
+  p.ld_out = ld_out; p.cout = cout; p.relu = relu;
+  p.tiles_x = (p.wo + SP_TW - 1) / SP_TW;
+  p.tiles_y = (p.ho + SP_TH - 1) / SP_TH;
+  const long long blocks = (long long)p.batch * p.tiles_x * p.tiles_y;
+  if (blocks > 0x7fffffffLL) return PCP_ERR_ARG;
+  hipLaunchKernelGGL(k_sparse_conv_s2, dim3((unsigned)blocks), dim3(SP_THREADS), 0, (hipStream_t)stream_, p);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

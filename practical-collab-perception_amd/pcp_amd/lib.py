@@ -77,6 +77,7 @@ SYMBOLS = {
     'pcp_canvas_clear': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp]),
     'pcp_fill_zero': (c_i32, [vp, c_sz, vp]),
     'pcp_conv3x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_sparse_conv3x3_s2': (c_i32, [vp, ctypes.POINTER(Grid), vp, c_i64, vp, vp, c_i32, c_i32, vp, c_i32, vp]),
     'pcp_conv3x3_winograd': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
     'pcp_conv3x3_winograd4_workspace_bytes': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(c_sz)]),
     'pcp_conv3x3_winograd4': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp, vp]),

@@ -142,6 +142,21 @@ def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None,
     return out
 
 
+def sparse_conv3x3_s2(pillar_features, vox, w_packed, bias, cout, relu=True, out=None):
+    """first backbone layer (ZeroPad2d(1) + 3x3 stride-2 conv + folded BN + ReLU) straight from the pillar list: pillar_features (>= P, 64)
+    in pillar-rank order and the voxelize result whose workspace still holds the cell -> rank table.  Returns (B, ny/2, nx/2, cout)."""
+    _need_cuda(pillar_features, w_packed, bias, out)
+    L = _lib.load()
+    g = vox.grid
+    B, ho, wo = g.batch_size, (g.ny - 1) // 2 + 1, (g.nx - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=pillar_features.device)
+    assert out.shape[:3] == (B, ho, wo) and out.is_contiguous() and pillar_features.is_contiguous() and pillar_features.shape[1] == 64
+    check(L.pcp_sparse_conv3x3_s2(_p(pillar_features), ctypes.byref(g), _p(vox.workspace), vox.n, _p(w_packed), _p(bias), cout,
+                                  1 if relu else 0, _p(out), out.shape[3], _stream()), 'pcp_sparse_conv3x3_s2')
+    return out
+
+
 def conv3x3_winograd(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
     """stride-1 3x3 conv through the fused Winograd F(2x2,3x3) kernel; same tensor contract as conv3x3."""
     _need_cuda(x, u_packed, bias, out)

@@ -116,6 +116,15 @@ def winograd4_reference(x, packed, bias, cout):
     return out + bias[:cout].to(x.dtype).view(1, -1, 1, 1)
 
 
+def pack_conv3x3_sparse_s2(w, bias):
+    """w: [cout <= 64, 64, 3, 3] (BN-folded) -> [9 (ky*3+kx)][64][64 (cin)] for pcp_sparse_conv3x3_s2 (rows >= cout zero)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin == 64 and cout <= 64 and cout % 4 == 0
+    wp = w.new_zeros((9, 64, 64), dtype=torch.float32)
+    wp[:, :cout] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin)
+    return wp.contiguous(), pad_bias(bias, 64)
+
+
 def pack_conv3x3_bf16x3(w, bias):
     """w: [cout, cin, 3, 3] (BN-folded) -> split hi = bf16(w), lo = bf16(w - hi), packed bf16 [cin/16][cout_pad/64][hi|lo][9][2][64][8]
     (k-half, cout, 8 channels: the fragment image of v_mfma_f32_32x32x16_bf16).  Returns (packed int16 view, bias_pad, cout_pad)."""

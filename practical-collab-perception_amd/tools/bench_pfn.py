@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from pcp_amd import ops, synth  # noqa: E402
+from pcp_amd import ops, pack, synth  # noqa: E402
 
 
 def timeit(fn, iters=20):
@@ -43,6 +43,22 @@ def main():
     P = int(vox.counters[0])
     tv = timeit(lambda: ops.voxelize(pts, grid, want_inverse=False, want_counts=False, workspace=vox.workspace))
     tp = timeit(lambda: ops.pfn_scatter(pts, vox, 5, w0, b0, w1, b1, canvas=canvas))
+    # first backbone layer: dense stride-2 conv on the canvas vs the sparse form on the pillar list
+    pf = torch.empty((pts.shape[0], 64), device=d)
+    ops.pfn_scatter(pts, vox, 5, w0, b0, w1, b1, canvas=canvas, pillar_features=pf)
+    wc = (torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1
+    bc = torch.zeros(64)
+    pd, bd, cpd = pack.pack_conv3x3(wc, bc)
+    pd, bd = pd.to(d), bd.to(d)
+    wsp, bsp = pack.pack_conv3x3_sparse_s2(wc, bc)
+    wsp, bsp = wsp.to(d), bsp.to(d)
+    out = torch.empty((B, 256, 256, 64), device=d)
+    out2 = torch.empty_like(out)
+    td = timeit(lambda: ops.conv3x3(canvas, pd, bd, 64, 64, cpd, stride=2, out=out))
+    ts = timeit(lambda: ops.sparse_conv3x3_s2(pf, vox, wsp, bsp, 64, out=out2))
+    tpf = timeit(lambda: ops.pfn_scatter(pts, vox, 5, w0, b0, w1, b1, canvas=None, pillar_features=pf))
+    print('first layer 64->64 s2: dense %.1f us | sparse %.1f us (max diff %.2e) | pfn writing pillar rows only %.1f us' % (
+        td, ts, float((out - out2).abs().max()), tpf))
     n = pts.shape[0]
     print('B %d agents %d: N %d P %d | voxelize %.1f us | pfn+scatter %.1f us = %.2f G points/s | canvas checksum %.6e' % (
         B, agents, n, P, tv, tp, n / tp * 1e-3, float(canvas.double().sum())))

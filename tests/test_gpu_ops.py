@@ -582,6 +582,46 @@ def test_gather_detections_equals_the_reference_python_tail():
         assert float(ob[b, n:].abs().max()) == 0.0 if n < sum(keep_max) else True
 
 
+@pytest.mark.parametrize('n_points,batch,xy_half,grid_n,cout', [(3000, 2, 13.1, 128, 64), (200, 1, 13.1, 128, 64), (40000, 2, 13.1, 128, 64),
+                                                                   (2500, 3, 6.6, 66, 32), (0, 1, 13.1, 128, 64)])
+def test_sparse_first_layer_equals_dense_conv_on_the_canvas(n_points, batch, xy_half, grid_n, cout):
+    """pcp_sparse_conv3x3_s2 (pillar list + cell -> rank table) vs the dense path it replaces: PFN canvas -> ZeroPad2d(1) + 3x3 stride-2
+    conv + bias + ReLU (torch CPU on the canvas the PFN wrote).  Cases: 18 % occupancy, nearly empty tiles, crowded cells (> 32 occupied
+    rows per tap and tile -> several chunks), a grid that is not a multiple of the 8 x 16 tile (66 -> 33 outputs), cout 32, empty cloud."""
+    ops = _ops()
+    from pcp_amd import pack
+    d = dev()
+    half = 0.1 * grid_n
+    rng = [-half, -half, -8.0, half, half, 0.0]
+    clouds = [synth.agent_cloud(31 + f, max(n_points, 1), 'car', xy_half=xy_half) for f in range(batch)]
+    pts_np = synth.collate(clouds)
+    if n_points == 0:
+        pts_np = pts_np[:0]
+    pts = torch.from_numpy(pts_np).to(d)
+    grid = ops.make_grid(rng, [0.2, 0.2, 8.0], [grid_n, grid_n, 1], batch)
+    g = torch.Generator().manual_seed(11)
+    w0 = ((torch.rand(32, 11, generator=g) - 0.5) * 0.6).to(d)
+    b0 = ((torch.rand(32, generator=g) - 0.5) * 0.2).to(d)
+    w1 = ((torch.rand(64, 64, generator=g) - 0.5) * 0.3).to(d)
+    b1 = ((torch.rand(64, generator=g) - 0.5) * 0.2).to(d)
+    canvas = torch.zeros((batch, grid_n, grid_n, 64), device=d)
+    vox = ops.voxelize(pts, grid, want_inverse=False, want_counts=False)
+    pf = torch.zeros((max(pts.shape[0], 1), 64), device=d)
+    if pts.shape[0]:
+        ops.pfn_scatter(pts, vox, 5, w0, b0, w1, b1, canvas=canvas, pillar_features=pf)
+    wc = (torch.rand(cout, 64, 3, 3, generator=g) - 0.5) * 0.1
+    bc = (torch.rand(cout, generator=g) - 0.5) * 0.2
+    wp, bp = pack.pack_conv3x3_sparse_s2(wc, bc)
+    got = ops.sparse_conv3x3_s2(pf, vox, wp.to(d), bp.to(d), cout, relu=True)
+    torch.cuda.synchronize()
+    want = F.relu(F.conv2d(canvas.permute(0, 3, 1, 2).cpu().double(), wc.double(), bc.double(), stride=2, padding=1))
+    assert tuple(got.shape) == (batch, (grid_n - 1) // 2 + 1, (grid_n - 1) // 2 + 1, cout)
+    err = float((got.permute(0, 3, 1, 2).cpu().double() - want).abs().max())
+    assert err <= 2e-5 * max(float(want.abs().max()), 1.0), err
+    if pts.shape[0]:
+        assert int(vox.counters[0]) > 0 and float(want.abs().max()) > 0.1
+
+
 def test_grouped_small_head_conv_matches_torch():
     ops = _ops()
     d = dev()
