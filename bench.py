@@ -241,6 +241,8 @@ def main():
     ap.add_argument('--config', default='car', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dense-first-layer', action='store_true', help='A/B switch: always write the dense canvas and run the first backbone '
+                    'layer as the dense stride-2 conv (default in pipeline mode: from the pillar list when the cloud is sparse)')
     ap.add_argument('--no-optin', action='store_true', help='skip the informational opt-in (bf16x3) pass after the fp32 measurement (clean '
                     'rocprofv3 kernel statistics of the headline path)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
@@ -281,6 +283,7 @@ def main():
         if hasattr(m, 'materialize_pillars'):
             m.materialize_pillars = False       # per-pillar API tensors are not consumed downstream
             m.reuse_buffers = True
+            m.sparse_first_layer = not args.dense_first_layer   # sparse clouds: first backbone layer from the pillar list, no dense canvas
     pts_np, metas = make_points(conf, batch, rank)
     pristine = torch.from_numpy(pts_np).to(dev)
     work = torch.empty_like(pristine)

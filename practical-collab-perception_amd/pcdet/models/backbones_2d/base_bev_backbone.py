@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from pcp_amd import ops
+from pcp_amd import ops, pack
 
 from ..convnet import pack_conv_module
 from ..packed import PackedModule, train_tape
@@ -71,7 +71,15 @@ class BaseBEVBackbone(PackedModule):
                 i += 3
             blocks.append(convs)
         deblocks = [pack_conv_module(seq[0], seq[1], relu=True) for seq in self.deblocks]
-        return dict(blocks=blocks, deblocks=deblocks)
+        # the first layer once more in the layout of pcp_sparse_conv3x3_s2 (it can run from the pillar list instead of the dense canvas)
+        sparse0 = None
+        c0 = list(self.blocks[0])[1] if len(self.blocks) else None
+        if c0 is not None and c0.kernel_size == (3, 3) and c0.stride == (2, 2) and c0.in_channels == 64 and c0.out_channels <= 64 \
+                and c0.out_channels % 4 == 0:
+            from ..convnet import _fold
+            w, b = _fold(c0, list(self.blocks[0])[2], out_axis=0)
+            sparse0 = pack.pack_conv3x3_sparse_s2(w, b) + (c0.out_channels,)
+        return dict(blocks=blocks, deblocks=deblocks, sparse0=sparse0)
 
     def _forward_train(self, data_dict):
         from ..train_path import BackboneTrain
@@ -89,13 +97,27 @@ class BaseBEVBackbone(PackedModule):
             return self._forward_train(data_dict)
         pk = self.packed()
         sf = data_dict['spatial_features']
-        x = ops.as_nhwc(sf)
-        in_h = x.shape[1]
+        first_done = False
+        if sf is None:
+            # pipeline mode: the VFE handed over the pillar list instead of a dense canvas (dynamic_pillar_vfe.py, sparse_first_layer)
+            stash = data_dict['_pcp_vfe']
+            if pk['sparse0'] is None:
+                raise RuntimeError('the VFE skipped the dense canvas but this backbone has no sparse first layer '
+                                   '(needs Conv2d(64, <= 64, 3, stride 2)); unset sparse_first_layer')
+            wsp, bsp, c0 = pk['sparse0']
+            x = ops.sparse_conv3x3_s2(stash['pillar_rows'], stash['vox'], wsp, bsp, c0, relu=True)
+            in_h = stash['vox'].grid.ny
+            first_done = True
+        else:
+            x = ops.as_nhwc(sf)
+            in_h = x.shape[1]
         n_levels = len(pk['blocks'])
         ups, out = [], None
         ch_off = 0
         for i in range(n_levels):
-            for conv in pk['blocks'][i]:
+            for j, conv in enumerate(pk['blocks'][i]):
+                if i == 0 and j == 0 and first_done:
+                    continue
                 x = conv.run(x)
             stride = int(in_h / x.shape[1])
             data_dict['spatial_features_%dx' % stride] = ops.nchw_view(x)

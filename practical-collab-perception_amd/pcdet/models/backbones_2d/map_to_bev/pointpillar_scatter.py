@@ -19,6 +19,9 @@ class PointPillarScatter(nn.Module):
         stash = batch_dict.get('_pcp_vfe', None)
         if stash is not None:
             canvas = stash['canvas']
+            if canvas is None:            # pipeline mode, sparse first layer: the backbone consumes the pillar list (no dense canvas)
+                batch_dict['spatial_features'] = None
+                return batch_dict
         else:
             # foreign producer: pillar_features (P, C) + voxel_coords (P, 4) -> indexed row write into an NHWC canvas
             pf, vc = batch_dict['pillar_features'], batch_dict['voxel_coords'].long()

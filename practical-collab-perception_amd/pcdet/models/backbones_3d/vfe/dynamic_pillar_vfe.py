@@ -35,6 +35,9 @@ class PFNLayerV2(nn.Module):
         return w.float(), b.detach().float()
 
 
+SPARSE_MAX_FILL = 0.35        # points per cell below which the first backbone layer runs from the pillar list (pipeline mode)
+
+
 class DynamicPillarVFE(VFETemplate):
     def __init__(self, model_cfg, num_point_features, voxel_size, grid_size, point_cloud_range, **kwargs):
         super().__init__(model_cfg=model_cfg)
@@ -62,6 +65,11 @@ class DynamicPillarVFE(VFETemplate):
         # knobs of the MI355X pipeline (not in the reference)
         self.materialize_pillars = True     # expose exact-shape pillar_features / voxel_coords (costs one host sync)
         self.reuse_buffers = False          # keep canvas + workspace across frames, clear by pillar list
+        # pipeline mode only: hand the pillar list (pillar rows + the pillariser's cell -> rank table) to the backbone, whose first layer
+        # then runs from it (pcp_sparse_conv3x3_s2) and NO dense canvas is written; `spatial_features` is None in that case.  Used when
+        # the cloud is sparse enough (points <= SPARSE_MAX_FILL x cells) -- a crowded canvas is faster through the dense kernel.
+        self.sparse_first_layer = False
+        self._pf_buf = None
         self._canvas = None
         self._prev_vox = None
         self._workspace = None
@@ -96,6 +104,19 @@ class DynamicPillarVFE(VFETemplate):
         pk = self.packed()
         dev = points.device
         nx, ny = self.grid_size[0], self.grid_size[1]
+        n_eff = batch_dict.get('_pcp_valid_points_hint', points.shape[0])
+        if (self.sparse_first_layer and not self.materialize_pillars and self.num_filters[-1] == 64
+                and n_eff <= SPARSE_MAX_FILL * batch_size * nx * ny):
+            vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=self._workspace if self.reuse_buffers else None)
+            rows = max(points.shape[0], 1)
+            if self._pf_buf is None or self._pf_buf.shape[0] < rows or self._pf_buf.device != dev or not self.reuse_buffers:
+                self._pf_buf = torch.empty((rows, 64), dtype=torch.float32, device=dev)
+            ops.pfn_scatter(points, vox, self.num_raw_point_features, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=None,
+                            pillar_features=self._pf_buf)
+            if self.reuse_buffers:
+                self._workspace = vox.workspace
+            batch_dict['_pcp_vfe'] = dict(canvas=None, vox=vox, pillar_rows=self._pf_buf)
+            return batch_dict
         if self.reuse_buffers:
             if self._canvas is None or self._canvas.shape[0] != batch_size or self._canvas.device != dev:
                 self._canvas = torch.zeros((batch_size, ny, nx, 64), dtype=torch.float32, device=dev)

@@ -67,8 +67,10 @@ class BEVMaker(nn.Module):
         self.load_state_dict(own)
         print('[TEACHER] ==> Done (loaded %d/%d)' % (len(update), len(own)))
 
-    def _run_chain(self, points, batch_size):
+    def _run_chain(self, points, batch_size, valid_points_hint=None):
         d = {'points': points, 'batch_size': batch_size}
+        if valid_points_hint is not None:          # rows of other agents are masked out (frame index -1): what the pillariser will keep
+            d['_pcp_valid_points_hint'] = valid_points_hint
         for m in self.module_list:
             d = m(d)
         return d['spatial_features_2d']
@@ -119,7 +121,7 @@ class BEVMaker(nn.Module):
             for slot, (agent_idx, poses, present, _last) in enumerate(chunk):
                 ops.select_transform_points(points, c - 1, float(agent_idx), poses, present, out=stacked[slot * n:(slot + 1) * n],
                                             batch_offset=slot * batch_size)
-            bev = self._run_chain(stacked, batch_size * len(chunk))
+            bev = self._run_chain(stacked, batch_size * len(chunk), valid_points_hint=len(chunk) * n / max(len(agent_ids), 1))
             for slot, (agent_idx, _poses, _present, last) in enumerate(chunk):
                 batch_dict['bev_img'][agent_idx] = bev[slot * batch_size:slot * batch_size + last]
         return batch_dict

@@ -136,6 +136,53 @@ def test_fast_mode_skips_pillar_materialisation_and_matches():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize('tag', ['ego', 'car', 'disco'])
+def test_pipeline_mode_with_the_first_layer_from_the_pillar_list(tag):
+    """pipeline mode + sparse_first_layer: no dense canvas (`spatial_features` is None), the backbone's first layer runs from the pillar
+    list (pcp_sparse_conv3x3_s2); same goldens at the same tolerances, repeatable across frames with reused buffers.  In `disco` the
+    stacked remote-agent pass takes the sparse path through the valid-points hint while the crowded merged cloud stays dense."""
+    g = load_golden('g1_%s.npz' % tag)
+    model = _build(g)
+    flagged = 0
+    for m in model.modules():
+        if hasattr(m, 'sparse_first_layer'):
+            m.materialize_pillars = False
+            m.reuse_buffers = True
+            m.sparse_first_layer = True
+            flagged += 1
+    assert flagged >= 1
+    from pcp_amd import ops
+    calls = []
+    orig = ops.sparse_conv3x3_s2
+    ops.sparse_conv3x3_s2 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        if tag == 'disco':
+            metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+        else:
+            metadata = [{}, {}]
+        outs = []
+        for _ in range(2):
+            batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+            with torch.no_grad():
+                pred_dicts, _ = model(batch)
+            outs.append((batch['spatial_features_2d'].clone(), pred_dicts))
+        torch.cuda.synchronize()
+    finally:
+        ops.sparse_conv3x3_s2 = orig
+    assert len(calls) >= 2
+    assert torch.equal(outs[0][0], outs[1][0])
+    if tag == 'disco':
+        diff = np.abs(outs[0][0].cpu().numpy() - g['spatial_features_2d'])
+        assert (diff > 1e-3).mean() < 5e-3, float((diff > 1e-3).mean())
+    else:
+        assert batch['spatial_features'] is None
+        np.testing.assert_allclose(outs[0][0].cpu().numpy(), g['spatial_features_2d'], rtol=0, atol=1e-3)
+        for b, pd in enumerate(outs[0][1]):
+            gb, gs = g['final_boxes_%d' % b], g['final_scores_%d' % b]
+            n, worst = match_boxes(gb, gs, pd['pred_boxes'].cpu().numpy(), pd['pred_scores'].cpu().numpy(), tol=1e-3)
+            assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
