@@ -36,7 +36,7 @@ def parse_config():
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
     p.add_argument('--infer_time', action='store_true', default=False)
-    p.add_argument('--fast', action='store_true', help='MI355X pipeline mode: no per-pillar API tensors, persistent buffers')
+    p.add_argument('--fast', action='store_true', help='MI355X pipeline mode: no per-pillar API tensors, persistent buffers, first backbone layer from the pillar list')
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem
@@ -72,6 +72,7 @@ def main():
         for m in model.modules():
             if hasattr(m, 'materialize_pillars'):
                 m.materialize_pillars, m.reuse_buffers = False, True
+                m.sparse_first_layer = True          # sparse clouds: no dense canvas, first backbone layer from the pillar list
     eval_utils.eval_one_epoch(cfg, args, model, test_loader, 'synthetic' if args.ckpt is None else Path(args.ckpt).stem, logger,
                               dist_test=dist_test)
 
