@@ -279,6 +279,38 @@ def test_degenerate_inputs_match_oracle(case):
         assert n >= fb['pred_boxes'].shape[0] - 1, (case, n, worst)
 
 
+@pytest.mark.parametrize('case', ['first_frame_empty', 'all_out_of_range', 'single_point', 'no_points'])
+def test_pipeline_mode_degenerate_inputs_equal_the_plugin_mode(case):
+    """the sparse first layer (pillar list, no dense canvas) on empty / ragged / out-of-range clouds: maps and detections equal the
+    default (dense canvas) mode of the same model to 1e-5"""
+    g = load_golden('g1_ego.npz')
+    pts = g['points'].copy()
+    if case == 'first_frame_empty':
+        pts = pts[pts[:, 0] == 1]
+    elif case == 'all_out_of_range':
+        pts[:, 1] += 1000.0
+    elif case == 'single_point':
+        pts = pts[pts[:, 0] == 1][:1]
+    else:
+        pts = pts[:0]
+    outs = []
+    for sparse in (False, True):
+        model = _build(g)
+        if sparse:
+            model.vfe.materialize_pillars, model.vfe.reuse_buffers, model.vfe.sparse_first_layer = False, True, True
+        for _ in range(2):
+            batch = {'points': torch.from_numpy(pts).cuda(), 'batch_size': 2, 'metadata': [{}, {}]}
+            with torch.no_grad():
+                pred, _ = model(batch)
+        torch.cuda.synchronize()
+        assert (batch['spatial_features'] is None) == sparse
+        outs.append((batch['spatial_features_2d'].clone(), pred))
+    np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=1e-5)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert a['pred_boxes'].shape == b['pred_boxes'].shape
+        np.testing.assert_allclose(a['pred_boxes'].cpu().numpy(), b['pred_boxes'].cpu().numpy(), rtol=0, atol=1e-4)
+
+
 def test_exchange_outputs_of_a_remote_agent(tmp_path):
     """what a car / RSU agent sends for lately fusion -- MoDAR rows (n, 9) from the head (center_head.py:409-427)
     and foreground rows (m, 13) from HunterJr (hunter_jr.py:377-397) -- against the oracle's forward on the same frame, both as
