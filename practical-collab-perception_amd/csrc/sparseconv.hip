@@ -6,9 +6,10 @@
 // 8 x 16 output pixels and, tap by tap in a fixed order,
 //   looks the 128 input cells of the tap up in the pillariser's cell -> pillar-rank table (pcp_voxelize workspace),
 //   compacts the occupied ones (ballot prefix, pixel order) into rows of at most 32,
-//   gathers their 64-float pillar rows into an LDS A tile and multiplies [32 x 64] x [64 x C] on v_mfma_f32_32x32x2_f32
-//   (wave = 32-channel column tile x K half; the tap's weights go from L2 straight into registers),
-//   adds the product rows into the pixels' accumulators in LDS.
+//   gathers their 64-float pillar rows into an LDS A tile (four chunks in flight in a register ring) and multiplies
+//   [32 x 64] x [64 x C] on v_mfma_f32_16x16x4_f32 (wave = 16-row half x 32-channel half over the whole K, the tap's weight fragments
+//   from L2 straight into registers, two items ahead),
+//   adds its final product block straight into the pixels' accumulators in LDS (one barrier per chunk).
 // No atomics and a fixed summation order (taps ascending, K halves fixed): deterministic.  Work: 2.25 products per pillar instead of
 // 9 per output pixel, i.e. ~4x fewer MFMAs at 20 % occupancy after padding the row tiles to 32; the dense canvas is neither read nor
 // (when no caller asks for `spatial_features`) written.
@@ -31,19 +32,16 @@ struct SpParams {
   int tiles_x, tiles_y;
 };
 
-__device__ __forceinline__ f32x16 mfma32s(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
   __shared__ __attribute__((aligned(16))) float acc[SP_PIX * 64];          // per-pixel accumulators
-  __shared__ __attribute__((aligned(16))) float atile[32 * SP_ALD];         // gathered pillar rows of the chunk
-  __shared__ __attribute__((aligned(16))) float res[2][32 * 64];            // product rows, one copy per K half
+  __shared__ __attribute__((aligned(16))) float atile[2][32 * SP_ALD];      // gathered pillar rows of the chunk (double buffered)
   __shared__ int row_rank[9][SP_PIX];                                       // compacted (tap-wise) pillar ranks ...
   __shared__ unsigned char row_pix[9][SP_PIX];                              // ... and the output pixel each row belongs to
   __shared__ int cnt[9][2];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
   int sp = blockIdx.x;
   const int tile_x = sp % p.tiles_x;
   sp /= p.tiles_x;
@@ -88,7 +86,12 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
   __syncthreads();
 
   if (total > 0) {
-    const int nt = wave & 1, kh = wave >> 1;                                // this wave's column tile and K half
+    // wave = (16-row half of the chunk, 32-channel half of the outputs): its product block [16 x 32] over the whole K = 64 is final, so
+    // it is added straight into the accumulators of its rows' pixels -- no partial sums, no result tile in LDS, ONE barrier per item
+    // (in-kernel stamps of the first version, which split K over the waves: result tile write 430 + second barrier 150 +
+    // scatter-add 1 450 of 4 300 cycles per item)
+    const int rh = wave >> 1, nh = wave & 1;
+    const int m16 = lane & 15, q4 = lane >> 4;
     const int g_row = tid >> 3, g_q = (tid & 7) * 2;                       // gather: row, first of two 16-byte columns
     // work items = (tap, 32-row chunk) in ascending order (thread 0 lists them; at most 9 taps x 4 chunks)
     __shared__ unsigned char item_tap[36], item_chunk[36];
@@ -101,13 +104,13 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
     }
     __syncthreads();
     const int n_items = n_items_s;
-    // The gather of an item's pillar rows is a dependent L2 / HBM access of ~2 us against ~0.5 us of work per item: four items are
-    // kept in flight in a register ring (statically indexed through the 4x unrolled loop), the tap's weight fragments one tap ahead.
+    // Register rings, statically indexed through the 4x unrolled loop: the pillar rows of four items and the weight fragments of two
+    // items ahead are in flight (a dependent L2 / HBM access costs ~2 us, an item ~1 us).  All loads are UNCONDITIONAL with clamped
+    // indices (rows past the chunk re-read a valid row and are zeroed when they are stored to LDS), so the number of outstanding
+    // loads is static and hipcc's counted s_waitcnt waits for the oldest slot only.
     constexpr int DEPTH = 4;
     f32x4 g[DEPTH][2];
-    // UNCONDITIONAL loads with clamped indices (rows past the chunk re-read a valid row and are zeroed when they are stored to LDS):
-    // a static number of outstanding loads lets hipcc's counted s_waitcnt wait for the oldest ring slot only -- with predicated loads
-    // it waited for the request it had just issued, one L2 / HBM round trip per item
+    f32x4 wq[2][2][4];                                   // [ring slot][16-channel subtile][k group j]: W[t][32 nh + 16 s + m16][16 j + 4 q4 ..]
     auto gather = [&](int k, f32x4 (&dst)[2]) {
       const int kc = min(k, n_items - 1);
       const int t = item_tap[kc], c0 = item_chunk[kc] * 32;
@@ -116,17 +119,18 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
       dst[0] = *reinterpret_cast<const f32x4 *>(src);
       dst[1] = *reinterpret_cast<const f32x4 *>(src + 4);
     };
-    // weight fragments of ALL nine taps stay in registers (144 VGPRs): W[t][nt*32 + r][kh*32 + 8j + 4h .. +3].  Streaming them tap by
-    // tap exposed an L2 round trip per item (most taps are a single item): 127 us for the layer.
-    f32x4 wall[9][4];
+    auto wload = [&](int k, f32x4 (&dst)[2][4]) {
+      const int t = item_tap[min(k, n_items - 1)];
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-      const float *wr = p.w + ((long long)(t * 64 + nt * 32 + r)) * SP_CIN + kh * 32 + 4 * h;
+      for (int s2 = 0; s2 < 2; s2++) {
+        const float *wr = p.w + ((long long)(t * 64 + nh * 32 + s2 * 16 + m16)) * SP_CIN + 4 * q4;
 #pragma unroll
-      for (int j = 0; j < 4; j++) wall[t][j] = *reinterpret_cast<const f32x4 *>(wr + 8 * j);
-    }
-    // issue order matters to the counted waits (vmcnt retires in order): weights first, then ring slots 0..3 -- keep the scheduler
-    // from moving slot 0 behind the others
+        for (int j = 0; j < 4; j++) dst[s2][j] = *reinterpret_cast<const f32x4 *>(wr + 16 * j);
+      }
+    };
+    wload(0, wq[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    wload(1, wq[1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < DEPTH; u++) {
@@ -140,71 +144,52 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
         if (k < n_items) {                                                  // workgroup-uniform
           const int t = item_tap[k], c0 = item_chunk[k] * 32;
           const int rows = min(32, cnt[t][0] + cnt[t][1] - c0);
+          float *at = atile[u & 1];
           const bool live = g_row < rows;
           const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4 *>(atile + g_row * SP_ALD + g_q * 4) = live ? g[u][0] : zero4;
-          *reinterpret_cast<f32x4 *>(atile + g_row * SP_ALD + g_q * 4 + 4) = live ? g[u][1] : zero4;
+          *reinterpret_cast<f32x4 *>(at + g_row * SP_ALD + g_q * 4) = live ? g[u][0] : zero4;
+          *reinterpret_cast<f32x4 *>(at + g_row * SP_ALD + g_q * 4 + 4) = live ? g[u][1] : zero4;
           __builtin_amdgcn_sched_barrier(0);
           gather(k + DEPTH, g[u]);
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();
-          f32x16 a16, b16;                                                  // two independent chains: half the dependent-MFMA latency
+          // [16 rows x 64] x [64 x 32] on v_mfma_f32_16x16x4_f32; MFMA (j, kk) multiplies k = 16 j + 4 q4 + kk
+          typedef float f32x4c __attribute__((ext_vector_type(4)));
+          f32x4c c0v = {0.f, 0.f, 0.f, 0.f}, c1v = {0.f, 0.f, 0.f, 0.f};
+          const float *xa = at + (rh * 16 + m16) * SP_ALD + 4 * q4;
 #pragma unroll
-          for (int e = 0; e < 16; e++) { a16[e] = 0.f; b16[e] = 0.f; }
-          const float *xa = atile + r * SP_ALD + kh * 32 + 4 * h;
-          f32x4 af[4];
+          for (int j = 0; j < 4; j++) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + 16 * j);
 #pragma unroll
-          for (int j = 0; j < 4; j++) af[j] = *reinterpret_cast<const f32x4 *>(xa + 8 * j);
-          auto multiply = [&](const f32x4 (&wf)[4]) {
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-              a16 = mfma32s(af[j].x, wf[j].x, a16);
-              b16 = mfma32s(af[j + 1].x, wf[j + 1].x, b16);
-              a16 = mfma32s(af[j].y, wf[j].y, a16);
-              b16 = mfma32s(af[j + 1].y, wf[j + 1].y, b16);
-              a16 = mfma32s(af[j].z, wf[j].z, a16);
-              b16 = mfma32s(af[j + 1].z, wf[j + 1].z, b16);
-              a16 = mfma32s(af[j].w, wf[j].w, a16);
-              b16 = mfma32s(af[j + 1].w, wf[j + 1].w, b16);
+            for (int kk = 0; kk < 4; kk++) {
+              c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wq[u & 1][0][j][kk], c0v, 0, 0, 0);
+              c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wq[u & 1][1][j][kk], c1v, 0, 0, 0);
             }
-          };
-          switch (t) {                                                      // workgroup-uniform; keeps `wall` statically indexed
-            case 0: multiply(wall[0]); break;
-            case 1: multiply(wall[1]); break;
-            case 2: multiply(wall[2]); break;
-            case 3: multiply(wall[3]); break;
-            case 4: multiply(wall[4]); break;
-            case 5: multiply(wall[5]); break;
-            case 6: multiply(wall[6]); break;
-            case 7: multiply(wall[7]); break;
-            default: multiply(wall[8]); break;
+          }
+          // pixels of this lane's four rows (16 rh + 4 q4 + i); accumulator columns 32 nh + 16 s + m16
+          int pixs[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int row = rh * 16 + q4 * 4 + i;
+            pixs[i] = row < rows ? (int)row_pix[t][c0 + row] : -1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          wload(k + 2, wq[u & 1]);                       // this slot's fragments are consumed: refill it for the item after next
+          __builtin_amdgcn_sched_barrier(0);
+          float old0[4], old1[4];
+          const int col = nh * 32 + m16;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int pa = pixs[i] >= 0 ? pixs[i] : 0;
+            old0[i] = acc[pa * 64 + col];
+            old1[i] = acc[pa * 64 + col + 16];
           }
 #pragma unroll
-          for (int e = 0; e < 16; e++) res[kh][((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + nt * 32 + r] = a16[e] + b16[e];
-          __syncthreads();
-          // scatter-add: thread = (row, 16-byte column) x 2; the rows of one chunk belong to DISTINCT pixels, so all reads are issued
-          // before any write (as a read-modify-write loop the compiler must assume aliasing and serialises the LDS round trips;
-          // in-kernel stamps: 1 450 of the 4 300 cycles of an item in the 4-byte form)
-          {
-            const int q = (tid & 15) * 4;
-            int pixs[2];
-            f32x4 sum[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-              const int row = (tid >> 4) + 16 * i;
-              pixs[i] = row < rows ? (int)row_pix[t][c0 + row] : -1;
+          for (int i = 0; i < 4; i++)
+            if (pixs[i] >= 0) {
+              acc[pixs[i] * 64 + col] = old0[i] + c0v[i];
+              acc[pixs[i] * 64 + col + 16] = old1[i] + c1v[i];
             }
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-              const int row = (tid >> 4) + 16 * i;
-              const int pa = pixs[i] >= 0 ? pixs[i] : 0;
-              sum[i] = *reinterpret_cast<const f32x4 *>(acc + pa * 64 + q) +
-                       (*reinterpret_cast<const f32x4 *>(&res[0][row * 64 + q]) + *reinterpret_cast<const f32x4 *>(&res[1][row * 64 + q]));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-              if (pixs[i] >= 0) *reinterpret_cast<f32x4 *>(acc + pixs[i] * 64 + q) = sum[i];
-          }
         }
       }
     }
