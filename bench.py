@@ -403,6 +403,10 @@ def main():
                        'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
+                       'pipeline_mode': 'no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
+                                        ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
+                                         'from the pillar list when points <= 0.35 x cells (no dense canvas), dense otherwise') +
+                                        '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*)',
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
                          'achieved': round(cs['tflops'], 3), 'peak': timer.peak, 'unit': 'TFLOP/s',
