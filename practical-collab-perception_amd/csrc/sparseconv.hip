@@ -137,62 +137,70 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
       gather(u, g[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    for (int k0 = 0; k0 < n_items; k0 += DEPTH) {
-#pragma unroll
-      for (int u = 0; u < DEPTH; u++) {
-        const int k = k0 + u;
-        if (k < n_items) {                                                  // workgroup-uniform
+    // one pipeline stage = one item; ring slots are indexed by the compile-time stage number u
+    auto stage = [&](int k, f32x4 (&gu)[2], f32x4 (&wu)[2][4], float *at) {
           const int t = item_tap[k], c0 = item_chunk[k] * 32;
-          const int rows = min(32, cnt[t][0] + cnt[t][1] - c0);
-          float *at = atile[u & 1];
-          const bool live = g_row < rows;
-          const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4 *>(at + g_row * SP_ALD + g_q * 4) = live ? g[u][0] : zero4;
-          *reinterpret_cast<f32x4 *>(at + g_row * SP_ALD + g_q * 4 + 4) = live ? g[u][1] : zero4;
-          __builtin_amdgcn_sched_barrier(0);
-          gather(k + DEPTH, g[u]);
-          __builtin_amdgcn_sched_barrier(0);
-          __syncthreads();
-          // [16 rows x 64] x [64 x 32] on v_mfma_f32_16x16x4_f32; MFMA (j, kk) multiplies k = 16 j + 4 q4 + kk
-          typedef float f32x4c __attribute__((ext_vector_type(4)));
-          f32x4c c0v = {0.f, 0.f, 0.f, 0.f}, c1v = {0.f, 0.f, 0.f, 0.f};
-          const float *xa = at + (rh * 16 + m16) * SP_ALD + 4 * q4;
+      const int rows = min(32, cnt[t][0] + cnt[t][1] - c0);
+      const bool live = g_row < rows;
+      const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4 *>(at + g_row * SP_ALD + g_q * 4) = live ? gu[0] : zero4;
+      *reinterpret_cast<f32x4 *>(at + g_row * SP_ALD + g_q * 4 + 4) = live ? gu[1] : zero4;
+      __builtin_amdgcn_sched_barrier(0);
+      gather(k + DEPTH, gu);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      // [16 rows x 64] x [64 x 32] on v_mfma_f32_16x16x4_f32; MFMA (j, kk) multiplies k = 16 j + 4 q4 + kk
+      typedef float f32x4c __attribute__((ext_vector_type(4)));
+      f32x4c c0v = {0.f, 0.f, 0.f, 0.f}, c1v = {0.f, 0.f, 0.f, 0.f};
+      const float *xa = at + (rh * 16 + m16) * SP_ALD + 4 * q4;
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + 16 * j);
+      for (int j = 0; j < 4; j++) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(xa + 16 * j);
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-              c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wq[u & 1][0][j][kk], c0v, 0, 0, 0);
-              c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wq[u & 1][1][j][kk], c1v, 0, 0, 0);
-            }
-          }
-          // pixels of this lane's four rows (16 rh + 4 q4 + i); accumulator columns 32 nh + 16 s + m16
-          int pixs[4];
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int row = rh * 16 + q4 * 4 + i;
-            pixs[i] = row < rows ? (int)row_pix[t][c0 + row] : -1;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          wload(k + 2, wq[u & 1]);                       // this slot's fragments are consumed: refill it for the item after next
-          __builtin_amdgcn_sched_barrier(0);
-          float old0[4], old1[4];
-          const int col = nh * 32 + m16;
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int pa = pixs[i] >= 0 ? pixs[i] : 0;
-            old0[i] = acc[pa * 64 + col];
-            old1[i] = acc[pa * 64 + col + 16];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (pixs[i] >= 0) {
-              acc[pixs[i] * 64 + col] = old0[i] + c0v[i];
-              acc[pixs[i] * 64 + col + 16] = old1[i] + c1v[i];
-            }
+        for (int kk = 0; kk < 4; kk++) {
+          c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wu[0][j][kk], c0v, 0, 0, 0);
+          c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wu[1][j][kk], c1v, 0, 0, 0);
         }
       }
+      // pixels of this lane's four rows (16 rh + 4 q4 + i); accumulator columns 32 nh + 16 s + m16
+      int pixs[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int row = rh * 16 + q4 * 4 + i;
+        pixs[i] = row < rows ? (int)row_pix[t][c0 + row] : -1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wload(k + 2, wu);                       // this slot's fragments are consumed: refill it for the item after next
+      __builtin_amdgcn_sched_barrier(0);
+      float old0[4], old1[4];
+      const int col = nh * 32 + m16;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int pa = pixs[i] >= 0 ? pixs[i] : 0;
+        old0[i] = acc[pa * 64 + col];
+        old1[i] = acc[pa * 64 + col + 16];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (pixs[i] >= 0) {
+          acc[pixs[i] * 64 + col] = old0[i] + c0v[i];
+          acc[pixs[i] * 64 + col + 16] = old1[i] + c1v[i];
+        }
+    };
+    // Main loop: groups of DEPTH items with NO conditional stage, so the number of loads in flight at every wait is static (a guard
+    // around a stage makes it path dependent and hipcc falls back to s_waitcnt vmcnt(0): every item then waits for the gather it has
+    // just issued -- the reason prefetch depth, resident weights and occupancy all measured the same 127-133 us).
+    int k0 = 0;
+    for (; k0 + DEPTH <= n_items; k0 += DEPTH) {
+      stage(k0 + 0, g[0], wq[0], atile[0]);
+      stage(k0 + 1, g[1], wq[1], atile[1]);
+      stage(k0 + 2, g[2], wq[0], atile[0]);
+      stage(k0 + 3, g[3], wq[1], atile[1]);
     }
+    // tail: the remaining (< DEPTH) items already sit in ring slots 0 ..
+    if (k0 + 0 < n_items) stage(k0 + 0, g[0], wq[0], atile[0]);
+    if (k0 + 1 < n_items) stage(k0 + 1, g[1], wq[1], atile[1]);
+    if (k0 + 2 < n_items) stage(k0 + 2, g[2], wq[0], atile[0]);
     __syncthreads();
   }
 
