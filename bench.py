@@ -407,6 +407,7 @@ def main():
                                         ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
                                          'from the pillar list when points <= 0.35 x cells (no dense canvas), dense otherwise') +
                                         '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*)',
+                       'peak_device_memory_mb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
                          'achieved': round(cs['tflops'], 3), 'peak': timer.peak, 'unit': 'TFLOP/s',
