@@ -66,6 +66,26 @@ def test_product_path_fails_loudly_without_gpu():
         car({'points': torch.from_numpy(gc['points']), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.zeros(2, 1, 8)})
 
 
+def test_product_never_touches_the_oracle_or_the_reference():
+    """the oracle is test infrastructure: nothing under the product package (nor bench.py outside its cpu_baseline leg) may import it,
+    and nothing shipped may read /root/reference at run time"""
+    import re
+    pkg = os.path.join(REPO, 'practical-collab-perception_amd')
+    offenders = []
+    for root, _dirs, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(('.py', '.hip', '.h', '.sh')) and f != 'Makefile':
+                continue
+            text = open(os.path.join(root, f), errors='ignore').read()
+            if re.search(r'^\s*(from|import)\s+oracle\b', text, re.M) or '/root/reference' in text:
+                offenders.append(os.path.join(root, f))
+    assert offenders == [], offenders
+    bench = open(os.path.join(REPO, 'bench.py')).read()
+    uses = [m.start() for m in re.finditer(r'from oracle|import oracle', bench)]
+    assert len(uses) == 1 and bench.rfind('def cpu_baseline', 0, uses[0]) > bench.rfind('\ndef ', 0, bench.rfind('def cpu_baseline', 0, uses[0]))
+    assert '/root/reference' not in bench           # (__graft_entry__.build() only probes for it to rebuild oracle/_ref in this container)
+
+
 def test_bn_folding_and_conv3x3_packing_roundtrip():
     cin, cout = 32, 40
     w = torch.from_numpy(synth.uniform(1, 1, cout * cin * 9, -0.1, 0.1).reshape(cout, cin, 3, 3))
