@@ -193,13 +193,14 @@ def test_single_model_train_step_matches_reference():
                 np.testing.assert_allclose(d, g['it0_bn_digest'][i], rtol=2e-4, atol=1e-6, err_msg=k)
 
 
-def test_train_py_runs_and_loss_decreases(tmp_path):
+@pytest.mark.parametrize('yaml_name', ['v2x_pointpillar_disco.yaml', 'v2x_pointpillar_basic_ego_early.yaml', 'v2x_pointpillar_basic_ego.yaml'])
+def test_train_py_runs_and_loss_decreases(tmp_path, yaml_name):
     """tools/train.py (reference command line) on a small synthetic set: 2 epochs x 4 iterations, checkpoint written and loadable,
-    loss of the last iteration below the first (same frames every epoch)."""
+    loss of the last iteration below the first (same frames every epoch).  DiscoNet (config 5) and the two fusion-free configs."""
     import re
     import subprocess
     tools = os.path.join(REPO, 'practical-collab-perception_amd', 'tools')
-    cmd = [sys.executable, 'train.py', '--cfg_file', 'cfgs/v2x_sim_models/v2x_pointpillar_disco.yaml', '--batch_size', '2', '--epochs', '2',
+    cmd = [sys.executable, 'train.py', '--cfg_file', 'cfgs/v2x_sim_models/' + yaml_name, '--batch_size', '2', '--epochs', '2',
            '--output_dir', str(tmp_path), '--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '4000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '8',
            'OPTIMIZATION.LR', '0.003']
     r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900)
