@@ -153,12 +153,12 @@ class ConvTimer:
         ops.conv3x3_winograd = timed_w
         self._orig_b3 = ops.conv3x3_bf16x3
 
-        def timed_b3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+        def timed_b3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0, plain=False):
             s = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
             r = timer._orig_b3(x, packed, bias, cin, cout, cout_pad, stride=stride, relu=relu, out=out, in_ch_off=in_ch_off,
-                               out_ch_off=out_ch_off)
+                               out_ch_off=out_ch_off, plain=plain)
             e1.record(s)
             B, H, W, _ = x.shape
             Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -246,7 +246,7 @@ def main():
     ap.add_argument('--no-optin', action='store_true', help='skip the informational opt-in (bf16x3) pass after the fp32 measurement (clean '
                     'rocprofv3 kernel statistics of the headline path)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
-    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3'],
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'],
                     help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
                          '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
     ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
@@ -258,6 +258,8 @@ def main():
     args = ap.parse_args()
 
     if args.conv_algo is not None:
+        if args.conv_algo == 'bf16' and not args.train:
+            raise SystemExit('--conv-algo bf16 (plain bf16 products) is the mixed-precision TRAINING mode: add --train')
         os.environ['PCP_CONV_ALGO'] = args.conv_algo
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -393,7 +395,9 @@ def main():
             'metric': 'frames/sec (60k-pt cloud per agent) through the PointPillars hot path', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
-            'dtype': 'f32' if os.environ.get('PCP_CONV_ALGO', 'auto') != 'bf16x3' else 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
+            'dtype': {'bf16x3': 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
+                      'bf16': 'mixed precision [opt-in, --train only]: forward / data-gradient 3x3 conv products in bf16 (8 mantissa bits), f32 accumulate, '
+                              'f32 master weights, weight gradients, BatchNorm, losses and optimizer'}.get(os.environ.get('PCP_CONV_ALGO', 'auto'), 'f32'),
             'data': 'synthetic',
             'config': {'workload': conf['name'] if not args.train else ('v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)'

@@ -143,6 +143,11 @@ int pcp_conv3x3_winograd4_timed(const pcp_conv3x3_t *desc, const float *in, cons
  * error (the reference's own GPU path, cuDNN with TF32 allowed, keeps 10 bits).  cin % 16 == 0, cout_pad % 64 == 0; weights packed by
  * pcp_amd/pack.py::pack_conv3x3_bf16x3 as bf16 [cin/16][cout_pad/64][hi|lo][9][2][64][8].  Never selected by default. */
 int pcp_conv3x3_bf16x3(const pcp_conv3x3_t *desc, const float *in, const void *w_packed, const float *bias, float *out, void *stream);
+/* Same kernel with PLAIN bf16 products (only the hi halves: 8 mantissa bits, ~3e-3 relative error, fp32 accumulation; same packed
+ * weights): the mixed-precision TRAINING arithmetic BASELINE.json names for config 5 ("training loop bf16").  Opt-in through
+ * PCP_CONV_ALGO=bf16 on the training layers' forward / data-gradient convolutions; never used where parity with the reference's
+ * fp32 results is claimed. */
+int pcp_conv3x3_bf16(const pcp_conv3x3_t *desc, const float *in, const void *w_packed, const float *bias, float *out, void *stream);
 
 /* Grouped 3x3 conv with tiny outputs (the final convs of the CenterHead branches, center_head.py:39; HunterJr's 768 -> 2
  * weight conv, hunter_jr.py:151): group g reads input channels [g cin_g, (g+1) cin_g) and produces output channels

@@ -40,7 +40,9 @@ __device__ __forceinline__ int xcd_remap_b3(int bid, int nwg) {
 
 // S: stride; TH: output rows per workgroup (8 * M-tiles per wave); DB: double-buffered LDS (one barrier per slice, one workgroup per
 // CU with a 128-pixel x 64-channel register tile per wave) or single-buffered (two workgroups per CU overlap each other)
-template <int S, int TH, bool DB>
+// TERMS: 3 = split products hi*hi + hi*lo + lo*hi ("bf16x3", ~1e-5); 1 = plain bf16 products hi*hi (8 mantissa bits, ~3e-3: the
+// mixed-precision TRAINING mode named by BASELINE.json's config 5; never used for inference parity)
+template <int S, int TH, bool DB, int TERMS>
 __global__ __launch_bounds__(B3_THREADS, DB ? 1 : 2) void k_conv3x3_bf16x3(B3Params p) {
   constexpr int PH = (TH - 1) * S + 3, PW = (B3_TW - 1) * S + 3;
   constexpr int NPIX = PH * PW;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(B3_THREADS, DB ? 1 : 2) void k_conv3x3_bf16x3(B3Par
       if (pdst[u] >= 0) {
         const int o = pdst[u] & ~(1 << 30);
         *reinterpret_cast<bf16x4 *>(ph + o) = hi;
-        *reinterpret_cast<bf16x4 *>(pl + o) = lo;
+        if (TERMS == 3) *reinterpret_cast<bf16x4 *>(pl + o) = lo;
       }
     }
     f32x4 *wd = reinterpret_cast<f32x4 *>(&wts[buf][0]);
@@ -158,8 +160,10 @@ __global__ __launch_bounds__(B3_THREADS, DB ? 1 : 2) void k_conv3x3_bf16x3(B3Par
       }
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ca], bh[cb][n], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca], bl[cb][n], acc[m][n], 0, 0, 0);
+        if (TERMS == 3) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ca], bh[cb][n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca], bl[cb][n], acc[m][n], 0, 0, 0);
+        }
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ca], bh[cb][n], acc[m][n], 0, 0, 0);
       }
     }
@@ -216,8 +220,8 @@ __global__ __launch_bounds__(B3_THREADS, DB ? 1 : 2) void k_conv3x3_bf16x3(B3Par
 
 }  // namespace
 
-extern "C" int pcp_conv3x3_bf16x3(const pcp_conv3x3_t *d, const float *in, const void *w_packed, const float *bias, float *out,
-                                  void *stream) {
+template <int TERMS>
+static int launch_b3(const pcp_conv3x3_t *d, const float *in, const void *w_packed, const float *bias, float *out, void *stream) {
   if (!d || !in || !w_packed || !bias || !out) return PCP_ERR_ARG;
   if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->cin <= 0 || (d->cin % B3_CK) || d->cout <= 0 || d->cout_pad < d->cout ||
       (d->cout_pad % B3_BN) || (d->ld_in & 3) || (d->stride != 1 && d->stride != 2))
@@ -243,11 +247,21 @@ extern "C" int pcp_conv3x3_bf16x3(const pcp_conv3x3_t *d, const float *in, const
   if (blocks >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (d->stride == 1 && th == 32)
-    hipLaunchKernelGGL((k_conv3x3_bf16x3<1, 32, true>), dim3((unsigned)blocks), dim3(B3_THREADS), 0, s, p);
+    hipLaunchKernelGGL((k_conv3x3_bf16x3<1, 32, true, TERMS>), dim3((unsigned)blocks), dim3(B3_THREADS), 0, s, p);
   else if (d->stride == 1)
-    hipLaunchKernelGGL((k_conv3x3_bf16x3<1, 16, false>), dim3((unsigned)blocks), dim3(B3_THREADS), 0, s, p);
+    hipLaunchKernelGGL((k_conv3x3_bf16x3<1, 16, false, TERMS>), dim3((unsigned)blocks), dim3(B3_THREADS), 0, s, p);
   else
-    hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8, false>), dim3((unsigned)blocks), dim3(B3_THREADS), 0, s, p);
+    hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8, false, TERMS>), dim3((unsigned)blocks), dim3(B3_THREADS), 0, s, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+extern "C" int pcp_conv3x3_bf16x3(const pcp_conv3x3_t *d, const float *in, const void *w_packed, const float *bias, float *out,
+                                  void *stream) {
+  return launch_b3<3>(d, in, w_packed, bias, out, stream);
+}
+
+extern "C" int pcp_conv3x3_bf16(const pcp_conv3x3_t *d, const float *in, const void *w_packed, const float *bias, float *out,
+                                void *stream) {
+  return launch_b3<1>(d, in, w_packed, bias, out, stream);
 }

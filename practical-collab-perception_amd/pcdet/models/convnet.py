@@ -14,13 +14,21 @@ WINOGRAD_MIN_WORKGROUPS = 256
 # F(4x4,3x3) through memory (three launches, csrc/wino4.hip) wins on the wide layers once its batched GEMM fills the chip twice over
 # (tools/bench_conv.py on MI355X, 4 frames: 768->768 @128 x1.50, 384->384 @128 x1.26, 128->384 @128 x1.20, 256->256 @64 x1.16 over the fused
 # F(2x2) kernel; narrower outputs or fewer tiles lose)
+B3_MIN_WORKGROUPS = 256
 WINOGRAD4_MIN_COUT = 256
 WINOGRAD4_MIN_WORKGROUPS = 512
 CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | bf16x3 (opt-in: split-bf16 products)
 
 
 def conv_algo():
+    """'bf16' (plain bf16 products) is the mixed-precision TRAINING mode (bench.py refuses it without --train): like autocast it also
+    covers the frozen teachers' forward passes inside a training iteration; in this module it selects the same launches as 'bf16x3'
+    with single products"""
     return os.environ.get('PCP_CONV_ALGO', CONV_ALGO)
+
+
+def _plain_bf16():
+    return os.environ.get('PCP_CONV_ALGO', CONV_ALGO) == 'bf16'
 
 
 class PackedConv:
@@ -29,7 +37,7 @@ class PackedConv:
 
     def _use_winograd4(self, x):
         algo = conv_algo()
-        if self.kind != '3x3' or getattr(self, 'w4', None) is None or algo in ('direct', 'winograd', 'bf16x3'):
+        if self.kind != '3x3' or getattr(self, 'w4', None) is None or algo in ('direct', 'winograd', 'bf16x3', 'bf16'):
             return False
         if algo == 'winograd4':
             return True
@@ -49,18 +57,18 @@ class PackedConv:
 
     def _use_bf16x3(self, x):
         """opt-in only (PCP_CONV_ALGO=bf16x3), and only where the launch fills the chip (>= 256 workgroups of 16x16 px x 64 ch)"""
-        if self.kind != '3x3' or getattr(self, 'b3', None) is None or conv_algo() != 'bf16x3':
+        if self.kind != '3x3' or getattr(self, 'b3', None) is None or conv_algo() not in ('bf16x3', 'bf16'):
             return False
         B, H, W, _ = x.shape
         Ho, Wo = (H - 1) // self.stride + 1, (W - 1) // self.stride + 1
         th = 16 if self.stride == 1 else 8
-        return B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (self.b3[2] // 64) >= 256
+        return B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (self.b3[2] // 64) >= B3_MIN_WORKGROUPS
 
     def run(self, x, out=None, in_ch_off=0, out_ch_off=0):
         if self._use_bf16x3(x):
             w3, b3, cp3 = self.b3
             return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
-                                      in_ch_off=in_ch_off, out_ch_off=out_ch_off)
+                                      in_ch_off=in_ch_off, out_ch_off=out_ch_off, plain=_plain_bf16())
         if self._use_winograd4(x):
             u, ub, ucp = self.w4
             return ops.conv3x3_winograd4(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
@@ -79,7 +87,7 @@ class PackedConv:
 
 def _winograd4_shape(cin, cout, stride):
     return (stride == 1 and cin % pack.WINO4_CK == 0 and cin >= 128 and cout % 4 == 0 and cout >= WINOGRAD4_MIN_COUT
-            and conv_algo() not in ('direct', 'winograd', 'bf16x3'))
+            and conv_algo() not in ('direct', 'winograd', 'bf16x3', 'bf16'))
 
 
 def _fold(conv, bn, out_axis):
@@ -122,7 +130,7 @@ def pack_conv_module(conv, bn=None, relu=True):
         pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
         if s == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48:
             pc.wino = pack.pack_conv3x3_winograd(w, b)
-        if conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48:
+        if conv_algo() in ('bf16x3', 'bf16') and pc.cin % pack.CK == 0 and pc.cout >= 48:
             pc.b3 = pack.pack_conv3x3_bf16x3(w, b)
         if _winograd4_shape(pc.cin, pc.cout, s):
             pc.w4 = pack.pack_conv3x3_winograd4(w, b)
@@ -146,6 +154,6 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.cin, pc.cout = w.shape[1], w.shape[0]
     pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
     pc.wino = pack.pack_conv3x3_winograd(w, b) if (stride == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48) else None
-    pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
+    pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() in ('bf16x3', 'bf16') and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
     pc.w4 = pack.pack_conv3x3_winograd4(w, b) if _winograd4_shape(pc.cin, pc.cout, stride) else None
     return pc

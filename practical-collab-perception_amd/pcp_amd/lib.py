@@ -84,6 +84,7 @@ SYMBOLS = {
     'pcp_conv3x3_winograd4_timed': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float),
                                             ctypes.POINTER(ctypes.c_double)]),
     'pcp_conv3x3_bf16x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_conv3x3_bf16': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
     'pcp_conv3x3_grouped_small': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), vp, vp, vp, c_i32, vp]),
     'pcp_pointwise': (c_i32, [ctypes.POINTER(Pointwise), vp, vp, vp, vp, vp]),
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),

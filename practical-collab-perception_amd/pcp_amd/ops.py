@@ -217,8 +217,9 @@ def conv3x3_winograd4(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=Non
     return out
 
 
-def conv3x3_bf16x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
-    """opt-in split-bf16 arithmetic (see include/pcp_hip.h); same tensor contract as conv3x3"""
+def conv3x3_bf16x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0, plain=False):
+    """opt-in split-bf16 arithmetic (see include/pcp_hip.h); same tensor contract as conv3x3.  plain=True: single bf16 products
+    (pcp_conv3x3_bf16, the mixed-precision training mode)"""
     _need_cuda(x, packed, bias, out)
     L = _lib.load()
     B, H, W, ld_in = x.shape
@@ -228,8 +229,9 @@ def conv3x3_bf16x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, ou
     assert out.shape[:3] == (B, Ho, Wo) and x.is_contiguous() and out.is_contiguous()
     assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3]
     d = Conv3x3(B, H, W, cin, cout, cout_pad, stride, ld_in, out.shape[3], 1 if relu else 0)
-    check(L.pcp_conv3x3_bf16x3(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
-          'pcp_conv3x3_bf16x3')
+    fn = L.pcp_conv3x3_bf16 if plain else L.pcp_conv3x3_bf16x3
+    check(fn(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
+          'pcp_conv3x3_bf16' if plain else 'pcp_conv3x3_bf16x3')
     return out
 
 

@@ -21,6 +21,9 @@ from . import lib, ops, pack
 from . import train_ops as tops
 
 
+B3_MIN_WORKGROUPS = 256        # the bf16 / bf16x3 conv kernels are used where a launch fills the chip (tests lower it)
+
+
 class StepClock:
     """Packed weights are rebuilt when the optimizer has stepped (weights change through raw pointers, torch cannot tell)."""
     step = 0
@@ -108,7 +111,7 @@ class ConvBNAct:
                     bufs['fw_w'] = torch.empty((self.cin // 8, 16, pack.round_up(self.cout, 64), 8), dtype=torch.float32, device=dev)
                 if self.cout % pack.WINO_CK == 0 and self.cin >= 48:
                     bufs['bw_w'] = torch.empty((self.cout // 8, 16, pack.round_up(self.cin, 64), 8), dtype=torch.float32, device=dev)
-                if os.environ.get('PCP_CONV_ALGO', 'auto') == 'bf16x3':            # opt-in split-bf16 arithmetic (conv_bf16x3.hip)
+                if os.environ.get('PCP_CONV_ALGO', 'auto') in ('bf16x3', 'bf16'):  # opt-in split / plain bf16 arithmetic (conv_bf16x3.hip)
                     if self.cin % 16 == 0 and self.cout >= 48:
                         bufs['fw_3'] = torch.empty((self.cin // 16) * pack.round_up(self.cout, 64) * 9 * 16 * 2, dtype=torch.int16, device=dev)
                     if self.cout % 16 == 0 and self.cin >= 48:
@@ -155,13 +158,14 @@ class ConvBNAct:
     @staticmethod
     def _run3x3(forms, x, cin, cout, stride, out, in_off, out_off):
         B, H, W, _ = x.shape
-        algo = os.environ.get('PCP_CONV_ALGO', 'auto')                  # auto | direct | winograd | bf16x3 (same switch as inference)
-        if algo == 'bf16x3' and 'b3' in forms:
+        algo = os.environ.get('PCP_CONV_ALGO', 'auto')                  # auto | direct | winograd | bf16x3 | bf16 (same switch as inference)
+        if algo in ('bf16x3', 'bf16') and 'b3' in forms:
             Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
             th = 16 if stride == 1 else 8
-            if B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (forms['b3'][2] // 64) >= 256:
+            if B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (forms['b3'][2] // 64) >= B3_MIN_WORKGROUPS:
                 w3, b3, cp3 = forms['b3']
-                return ops.conv3x3_bf16x3(x, w3, b3, cin, cout, cp3, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
+                return ops.conv3x3_bf16x3(x, w3, b3, cin, cout, cp3, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off,
+                                          plain=(algo == 'bf16'))
         big = B * ((H + 7) // 8) * ((W + 15) // 16) * (forms['wino'][2] // 64) >= 256 if 'wino' in forms else False
         if stride == 1 and 'wino' in forms and algo != 'direct' and (big or algo == 'winograd'):
             u, ub, ucp = forms['wino']

@@ -134,6 +134,45 @@ def test_disco_train_step_matches_reference_and_oracle():
     assert len(pred) == 2 and all(torch.isfinite(p['pred_boxes']).all() for p in pred)
 
 
+def test_mixed_precision_bf16_training_step_tracks_the_fp32_reference(monkeypatch):
+    """PCP_CONV_ALGO=bf16 (BASELINE.json config 5: "training loop bf16"): forward / data-gradient 3x3 convs -- the frozen teachers' too --
+    with plain bf16 products (8 mantissa bits), everything else fp32.  Not a parity mode: the first-iteration loss of the reference's
+    train loop (golden g7) must be reproduced to 1 %, its clipped-gradient norm to 5 %, and two optimizer steps must stay finite."""
+    monkeypatch.setenv('PCP_CONV_ALGO', 'bf16')
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from pcdet.config import EasyDict
+    from pcp_amd import ops, train_layers
+    from pcdet.models import convnet
+    monkeypatch.setattr(train_layers, 'B3_MIN_WORKGROUPS', 0)      # the mini geometry never fills the chip: force the bf16 launches
+    monkeypatch.setattr(convnet, 'B3_MIN_WORKGROUPS', 0)
+    calls = []
+    orig = ops.conv3x3_bf16x3
+    monkeypatch.setattr(ops, 'conv3x3_bf16x3', lambda *a, **k: (calls.append(k.get('plain', False)), orig(*a, **k))[1])
+    g = load_golden('g7_train.npz')
+    meta = g['meta']
+    model = _build(g)
+    ocfg = EasyDict(meta['optimization'])
+    opt = build_optimizer(model, ocfg)
+    sched, _ = build_scheduler(opt, meta['total_it_each_epoch'], ocfg.NUM_EPOCHS, -1, ocfg)
+    for it in range(2):
+        sched.step(it)
+        model.train()
+        opt.zero_grad()
+        batch, _ = _batch(g)
+        ret, tb, _disp = model(batch)
+        model.update_global_step()
+        ret['loss'].backward()
+        lv, ref = float(ret['loss'].detach()), float(g['it%d_loss' % it])
+        assert np.isfinite(lv) and abs(lv - ref) <= (1e-2 if it == 0 else 5e-2) * abs(ref), (it, lv, ref)
+        opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+        opt.step()
+        if it == 0:
+            assert abs(opt.grad_norm() - float(g['it0_grad_norm'])) <= 5e-2 * float(g['it0_grad_norm']), opt.grad_norm()
+    assert calls and all(calls)                      # the bf16 launches ran, all with single products
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
 def test_single_model_train_step_matches_reference():
     """configs 3 / 4 (no fusion): VFE (11 raw features -> 17-d rows, padded to 32 floats) -> scatter -> backbone 64/128/256 -> CenterHead,
     two iterations of the reference's train loop (tests/golden/g7b_train_ego.npz).  Loss / lr / momentum as the reference; gradients

@@ -430,6 +430,28 @@ def test_fused_adam_step_matches_torch_adam_with_clipping():
         _close(p, ref, 2e-6, 'param after step %d' % step)
 
 
+def test_plain_bf16_conv_is_within_the_bf16_error_band():
+    """pcp_conv3x3_bf16 (single bf16 products, the mixed-precision training mode): error vs float64 between the split-bf16 kernel's
+    and 2^-8 relative to the output scale, stride 1 and 2"""
+    from pcp_amd import ops, pack
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    for stride in (1, 2):
+        x = (torch.rand((2, 64, 40, 48), generator=g) - 0.3)
+        w = (torch.rand((128, 64, 3, 3), generator=g) - 0.5) * 0.1
+        b = (torch.rand(128, generator=g) - 0.5) * 0.2
+        want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+        p3, b3, cp3 = pack.pack_conv3x3_bf16x3(w, b)
+        xd = ops.as_nhwc(x.to(DEV))
+        got1 = ops.conv3x3_bf16x3(xd, p3.to(DEV), b3.to(DEV), 64, 128, cp3, stride=stride, relu=False, plain=True)
+        got3 = ops.conv3x3_bf16x3(xd, p3.to(DEV), b3.to(DEV), 64, 128, cp3, stride=stride, relu=False)
+        torch.cuda.synchronize()
+        scale = float(want.abs().max())
+        e1 = float((got1.permute(0, 3, 1, 2).cpu().double() - want).abs().max()) / scale
+        e3 = float((got3.permute(0, 3, 1, 2).cpu().double() - want).abs().max()) / scale
+        assert e3 < 5e-5 and e3 < e1 < 2 ** -8, (stride, e1, e3)
+
+
 def test_conv_bn_act_layer_with_optin_bf16x3(monkeypatch):
     """training layer forward + data gradient through the opt-in split-bf16 conv kernel (weights re-split on the device every step by
     pcp_pack_conv3x3); same 3e-4 bar as the fp32 kernels.  No ReLU here: a 1e-5 forward difference flips the mask of the few
