@@ -444,8 +444,11 @@ def test_pointpillar_anchor_yaml_full_scale_against_oracle():
 @pytest.mark.parametrize('tag,yaml_name,layout,n_agents', [('car', 'v2x_pointpillar_basic_car.yaml', 'car', 1),
                                                            ('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', 1),
                                                            ('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', 6)])
-def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents):
-    """BASELINE.json's full sizes (60 000 points per agent, 512 x 512 grid, 128 x 128 maps) against digests the REFERENCE produced
+@pytest.mark.parametrize('pipeline', [False, True])
+def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents, pipeline):
+    """(pipeline = True: the mode bench.py measures -- no per-pillar tensors, reused buffers, first backbone layer from the pillar list where
+    the cloud is sparse -- against the same reference digests of the maps and detections)
+    BASELINE.json's full sizes (60 000 points per agent, 512 x 512 grid, 128 x 128 maps) against digests the REFERENCE produced
     (tests/golden/g2_full.npz): pillar count, SHA-256 of voxel_coords and of unq_inv (bit exact), per-channel sums / maxima of
     pillar_features and spatial_features_2d, probes of the maps, final boxes and scores."""
     import hashlib
@@ -461,6 +464,8 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents):
     st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
     model = model.cuda().eval()
+    if pipeline:
+        model.vfe.materialize_pillars, model.vfe.reuse_buffers, model.vfe.sparse_first_layer = False, True, True
     cloud = np.concatenate([synth.agent_cloud(agent=a, n_points=60000, layout=layout) for a in range(n_agents)], axis=0)
     pts = synth.collate([cloud])
     assert pts.shape[0] == int(g[tag + '_N'])
@@ -468,15 +473,20 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents):
     with torch.no_grad():
         pred, _ = model(batch)
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
-    vc = batch['voxel_coords'].cpu().numpy()
-    assert vc.shape[0] == int(g[tag + '_P'])
-    assert sha(vc.astype(np.int32)) == str(g[tag + '_coords_sha'])                       # bit exact at full size
     vox = batch['_pcp_vfe']['vox']
-    assert sha(vox.unq_inv[:int(vox.counters[1])].cpu().numpy().astype(np.int64)) == str(g[tag + '_inv_sha'])
-    pf = batch['pillar_features'].cpu().numpy().astype(np.float64)
-    np.testing.assert_allclose(pf.sum(0), g[tag + '_pf_sum'], rtol=1e-5, atol=1e-2)
-    np.testing.assert_allclose(np.abs(pf).sum(0), g[tag + '_pf_abs'], rtol=1e-5, atol=1e-2)
-    np.testing.assert_allclose(pf.max(0), g[tag + '_pf_max'], rtol=0, atol=1e-4)
+    assert int(vox.counters[0]) == int(g[tag + '_P'])
+    if pipeline:
+        # 60 k points on 262 k cells takes the sparse first layer; the merged 360 k-point cloud stays on the dense canvas
+        assert (batch['spatial_features'] is None) == (n_agents == 1)
+    else:
+        vc = batch['voxel_coords'].cpu().numpy()
+        assert vc.shape[0] == int(g[tag + '_P'])
+        assert sha(vc.astype(np.int32)) == str(g[tag + '_coords_sha'])                       # bit exact at full size
+        assert sha(vox.unq_inv[:int(vox.counters[1])].cpu().numpy().astype(np.int64)) == str(g[tag + '_inv_sha'])
+        pf = batch['pillar_features'].cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(pf.sum(0), g[tag + '_pf_sum'], rtol=1e-5, atol=1e-2)
+        np.testing.assert_allclose(np.abs(pf).sum(0), g[tag + '_pf_abs'], rtol=1e-5, atol=1e-2)
+        np.testing.assert_allclose(pf.max(0), g[tag + '_pf_max'], rtol=0, atol=1e-4)
     sf = batch['spatial_features_2d'].cpu().numpy()
     np.testing.assert_allclose(sf[0, :, ::16, ::16], g[tag + '_sf2d_probe'], rtol=0, atol=1e-3)
     np.testing.assert_allclose(sf.max(axis=(0, 2, 3)), g[tag + '_sf2d_max'], rtol=0, atol=1e-3)
