@@ -224,6 +224,47 @@ def g2_full():
     np.savez_compressed(os.path.join(HERE, 'g2_full.npz'), **out)
 
 
+def g2_disco_full():
+    """Config 5 at BASELINE's full size: 6 agents x 60 000 points, 512 x 512 grid, one frame, the poses of SURVEY 8(d); digests of what
+    the reference's DiscoNet forward produces (per-agent BEV maps, fused map, detections)."""
+    tmp = tempfile.mkdtemp()
+    empty = os.path.join(tmp, 'empty.pth')
+    torch.save({'model_state': {}}, empty)
+    ov = {'MODEL.BEV_MAKER_RSU.CKPT': empty, 'MODEL.BEV_MAKER_CAR.CKPT': empty, 'MODEL.BEV_MAKER_EARLY.CKPT': empty}
+    cfg = rh.load_cfg('v2x_pointpillar_disco.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    fill_weights(model)
+    agents = (0, 1, 2, 3, 4, 5)
+    poses = {a: synth.agent_pose(a) for a in agents if a != 1}
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}]}
+    with torch.no_grad():
+        bd, snaps = run_modules(model, bd)
+    out = {'N': np.array(pts.shape[0])}
+    for a in poses:
+        out['pose_%d' % a] = poses[a]
+    for aid, m in bd['bev_img'].items():
+        a = m.numpy()
+        out['bev_%d_probe' % aid] = a[0, ::8, ::8, ::8].copy()
+        out['bev_%d_sum' % aid] = a.astype(np.float64).sum((0, 2, 3))
+        out['bev_%d_max' % aid] = a.max(axis=(0, 2, 3))
+    sf = bd['spatial_features_2d'].numpy()
+    out['sf2d_probe'] = sf[0, :, ::16, ::16].copy()
+    out['sf2d_sum'] = sf.astype(np.float64).sum((0, 2, 3))
+    out['sf2d_max'] = sf.max(axis=(0, 2, 3))
+    out['voxel_P'] = np.array(bd['voxel_coords'].shape[0])
+    out['coords_sha'] = np.array(sha(bd['voxel_coords'].numpy().astype(np.int32)))
+    out['boxes'] = bd['final_box_dicts'][0]['pred_boxes'].numpy()
+    out['scores'] = bd['final_box_dicts'][0]['pred_scores'].numpy()
+    print('g2 disco full: N', pts.shape[0], 'P', int(out['voxel_P']), 'agents', sorted(bd['bev_img'].keys()), 'final', out['boxes'].shape[0])
+    np.savez_compressed(os.path.join(HERE, 'g2_disco_full.npz'), **out)
+
+
 def g3_nms():
     rh.install()
     nmsmod = sys.modules['pcdet.ops.iou3d_nms.iou3d_nms_cuda']
@@ -591,6 +632,8 @@ if __name__ == '__main__':
         g1_disco()
     if 'g2' in todo:
         g2_full()
+    if 'g2d' in todo:
+        g2_disco_full()
     if 'g7' in todo:
         g7_train()
     if 'g7b' in todo:

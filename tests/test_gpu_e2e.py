@@ -499,3 +499,65 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents, p
     if gb.shape[0]:
         n, worst = match_boxes(gb, gs, pb, ps, tol=1e-3)
         assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+
+
+@pytest.mark.parametrize('pipeline', [False, True])
+def test_disco_full_size_against_reference_digests(pipeline):
+    """Config 5 at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid, one frame) against digests of the REFERENCE's own
+    DiscoNet forward (tests/golden/g2_disco_full.npz): per-agent BEV maps, fused map, detections.  The ego->agent transform runs in
+    fp32 on the device (the reference: float64 numpy on the host), so a point within an ulp of a cell edge may change pillar: a small
+    fraction of probe pixels may differ, everything else agrees to 1e-3.  pipeline = True is the mode bench.py measures (stacked
+    agent pass, sparse first layer for the remote agents' 60 k-point clouds, F(4x4) wide layers)."""
+    import hashlib
+    import os
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import DatasetInfo, build_network
+    g = load_golden('g2_disco_full.npz')
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = cfg_from_yaml_file(os.path.join(here, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_disco.yaml'),
+                             EasyDict())
+    for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
+        cfg.MODEL[key].CKPT = None
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(cfg.DATA_CONFIG.POINT_FEATURE_ENCODING.used_feature_list))
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.cuda().eval()
+    if pipeline:
+        for m in model.modules():
+            if hasattr(m, 'sparse_first_layer'):
+                m.materialize_pillars, m.reuse_buffers, m.sparse_first_layer = False, True, True
+    agents = (0, 1, 2, 3, 4, 5)
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    assert pts.shape[0] == int(g['N'])
+    poses = {a: g['pose_%d' % a] for a in agents if a != 1}
+    batch = {'points': torch.from_numpy(pts).cuda(), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}]}
+    with torch.no_grad():
+        pred, _ = model(batch)
+    torch.cuda.synchronize()
+    assert sorted(batch['bev_img'].keys()) == [0, 2, 3, 4, 5]
+    if not pipeline:
+        vc = batch['voxel_coords'].cpu().numpy()
+        assert vc.shape[0] == int(g['voxel_P'])
+        assert hashlib.sha256(np.ascontiguousarray(vc.astype(np.int32)).tobytes()).hexdigest() == str(g['coords_sha'])
+    for aid in (0, 2, 3, 4, 5):
+        a = batch['bev_img'][aid].cpu().numpy()
+        diff = np.abs(a[0, ::8, ::8, ::8] - g['bev_%d_probe' % aid])
+        assert (diff > 1e-3).mean() < 2e-3, (aid, float((diff > 1e-3).mean()))
+        np.testing.assert_allclose(a.astype(np.float64).sum((0, 2, 3)), g['bev_%d_sum' % aid], rtol=2e-3, atol=2.0)
+    sf = batch['spatial_features_2d'].cpu().numpy()
+    diff = np.abs(sf[0, :, ::16, ::16] - g['sf2d_probe'])
+    assert (diff > 1e-3).mean() < 5e-3, float((diff > 1e-3).mean())
+    np.testing.assert_allclose(sf.astype(np.float64).sum((0, 2, 3)), g['sf2d_sum'], rtol=2e-3, atol=2.0)
+    gb, gs = g['boxes'], g['scores']
+    pb, ps = pred[0]['pred_boxes'].cpu().numpy(), pred[0]['pred_scores'].cpu().numpy()
+    assert abs(pb.shape[0] - gb.shape[0]) <= 2
+    if gb.shape[0]:
+        n, worst = match_boxes(gb, gs, pb, ps, tol=2e-3)
+        assert n >= gb.shape[0] - 4, (n, gb.shape[0], worst)
