@@ -448,6 +448,62 @@ def g7_train():
     print('g7 saved', os.path.getsize(os.path.join(HERE, 'g7_train.npz')) // 1024, 'KiB')
 
 
+def g7_train_full():
+    """Config 5 training at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid, one frame, 12 GT boxes): ONE iteration of the
+    reference's train step; loss terms, gradient norm and per-tensor gradient digests."""
+    tmp = tempfile.mkdtemp()
+    empty = os.path.join(tmp, 'empty.pth')
+    torch.save({'model_state': {}}, empty)
+    ov = {'MODEL.BEV_MAKER_RSU.CKPT': empty, 'MODEL.BEV_MAKER_CAR.CKPT': empty, 'MODEL.BEV_MAKER_EARLY.CKPT': empty}
+    cfg = rh.load_cfg('v2x_pointpillar_disco.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    fill_weights(model)
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    agents = (0, 1, 2, 3, 4, 5)
+    poses = {a: synth.agent_pose(a) for a in agents if a != 1}
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    s0 = synth.SEED_BASE + 950
+    n = 12
+    gt = np.zeros((1, n, 8), dtype=np.float32)
+    gt[0, :, 0] = synth.uniform(s0, 1, n, -48.0, 48.0)
+    gt[0, :, 1] = synth.uniform(s0, 2, n, -48.0, 48.0)
+    gt[0, :, 2] = synth.uniform(s0, 3, n, -3.0, -1.0)
+    gt[0, :, 3] = synth.uniform(s0, 4, n, 3.0, 5.5)
+    gt[0, :, 4] = synth.uniform(s0, 5, n, 1.5, 2.5)
+    gt[0, :, 5] = synth.uniform(s0, 6, n, 1.4, 2.0)
+    gt[0, :, 6] = synth.uniform(s0, 7, n, -3.14159, 3.14159)
+    gt[0, :, 7] = 1.0
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=5, total_epochs=cfg.OPTIMIZATION.NUM_EPOCHS, last_epoch=-1,
+                                      optim_cfg=cfg.OPTIMIZATION)
+    names = [n_ for n_, p_ in model.named_parameters() if p_.requires_grad]
+    lr_scheduler.step(0)
+    model.train()
+    optimizer.zero_grad()
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}], 'gt_boxes': torch.from_numpy(gt.copy())}
+    ret, tb, _disp = model(bd)
+    loss = ret['loss']
+    loss.backward()
+    params = dict(model.named_parameters())
+    out = {'gt_boxes': gt, 'N': np.array(pts.shape[0]), 'trainable': np.array(names), 'loss': np.array(float(loss)),
+           'tb_json': np.array(json.dumps({k: float(v) for k, v in tb.items()})),
+           'grad_digest': np.stack([_digest(params[n_].grad) for n_ in names])}
+    for a in poses:
+        out['pose_%d' % a] = poses[a]
+    norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+    out['grad_norm'] = np.array(float(norm))
+    out['optimization_json'] = np.array(json.dumps(rh.to_plain(cfg.OPTIMIZATION)))
+    print('g7 full: loss', float(loss), 'norm', float(norm), tb)
+    np.savez_compressed(os.path.join(HERE, 'g7_train_full.npz'), **out)
+
+
 def g7b_train_single(tag, yaml_name, layout):
     """Training contract of a single-model config (VFE -> scatter -> backbone -> CenterHead, no fusion: configs 3 / 4) on the mini
     geometry: two iterations of the reference's own train step with its own optimizer / scheduler builders."""
@@ -636,6 +692,8 @@ if __name__ == '__main__':
         g2_disco_full()
     if 'g7' in todo:
         g7_train()
+    if 'g7f' in todo:
+        g7_train_full()
     if 'g7b' in todo:
         g7b_train_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately')
     if 'g8' in todo:

@@ -282,3 +282,58 @@ def test_training_step_degenerate_batches():
         opt.clip_grad_norm(10.0)
         opt.step()
         assert bool(torch.isfinite(opt.flat_p).all())
+
+
+def test_disco_full_size_training_iteration_matches_the_reference():
+    """Config 5 at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid): one iteration of the reference's own train step
+    (tests/golden/g7_train_full.npz) -- loss terms to 5e-4 (fp32 summation order over 16 384 heat-map cells and train-mode BatchNorm
+    statistics over one frame: the CPU reference itself is no more reproducible than that), clipped-gradient norm to 5e-3, per-tensor
+    gradient norms to 3e-2 of the largest (the per-element comparison against the float64 oracle lives on the mini fixture)."""
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import DatasetInfo, build_network
+    g = load_golden('g7_train_full.npz')
+    cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_disco.yaml'),
+                             EasyDict())
+    for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
+        cfg.MODEL[key].CKPT = None
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(cfg.DATA_CONFIG.POINT_FEATURE_ENCODING.used_feature_list))
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.to(DEV)
+    ocfg = EasyDict(json.loads(str(g['optimization_json'])))
+    opt = build_optimizer(model, ocfg)
+    sched, _ = build_scheduler(opt, 5, ocfg.NUM_EPOCHS, -1, ocfg)
+    agents = (0, 1, 2, 3, 4, 5)
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    assert pts.shape[0] == int(g['N'])
+    poses = {a: g['pose_%d' % a] for a in agents if a != 1}
+    sched.step(0)
+    model.train()
+    opt.zero_grad()
+    batch = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}],
+             'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}
+    ret, tb, _disp = model(batch)
+    ret['loss'].backward()
+    lv = float(ret['loss'].detach())
+    assert abs(lv - float(g['loss'])) <= 5e-4 * abs(float(g['loss'])), (lv, float(g['loss']))
+    for k, v in json.loads(str(g['tb_json'])).items():
+        assert abs(tb[k] - v) <= 1e-3 * abs(v) + 2e-6, (k, tb[k], v)
+    names = [str(n) for n in g['trainable']]
+    params = dict(model.named_parameters())
+    ref = g['grad_digest']                                   # per tensor: [L2 norm, sum, max |.|]
+    biggest = float(ref[:, 0].max())
+    for i, n in enumerate(names):
+        mine = float(params[n].grad.detach().double().norm())
+        assert abs(mine - ref[i, 0]) <= 3e-2 * max(ref[i, 0], 1e-3 * biggest), (n, mine, ref[i, 0])
+    opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+    opt.step()
+    assert abs(opt.grad_norm() - float(g['grad_norm'])) <= 5e-3 * float(g['grad_norm']), (opt.grad_norm(), float(g['grad_norm']))
