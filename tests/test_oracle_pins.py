@@ -217,3 +217,44 @@ def test_g9_anchor_head_pointpillar():
         n, worst = match_boxes(gb, gs, r['boxes'], r['scores'], tol=1e-3)
         assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
         assert set(np.unique(r['labels'])) <= {1, 2, 3}
+
+
+def test_g2_disco_full_size_forward():
+    """the oracle's DiscoNet forward at BASELINE's full size (6 x 60 000 points, 512 x 512 grid) -- exactly what bench.py's cpu_baseline
+    leg times for `--config disco` -- against digests of the reference's own forward (tests/golden/g2_disco_full.npz)"""
+    import hashlib
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    g = load_golden('g2_disco_full.npz')
+    cfg = bench.load_cfg('v2x_pointpillar_disco.yaml')
+    _model, state, _ds = bench.build_model(cfg)
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    arch = omodel.arch_from_cfg(plain(cfg.MODEL), list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), list(vs))
+    clouds = []
+    for a in range(6):
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    poses = {a: g['pose_%d' % a] for a in (0, 2, 3, 4, 5)}
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = omodel.forward(pts, state, arch, metadata=[{'se3_from_ego': poses}])
+    assert out['voxel_coords'].shape[0] == int(g['voxel_P'])
+    assert hashlib.sha256(np.ascontiguousarray(out['voxel_coords'].astype(np.int32)).tobytes()).hexdigest() == str(g['coords_sha'])
+    for aid in (0, 2, 3, 4, 5):
+        a = out['bev_img'][aid].numpy()
+        np.testing.assert_allclose(a[0, ::8, ::8, ::8], g['bev_%d_probe' % aid], rtol=0, atol=2e-4)
+    sf = np.asarray(out['spatial_features_2d'])
+    np.testing.assert_allclose(sf[0, :, ::16, ::16], g['sf2d_probe'], rtol=0, atol=5e-4)
+    fb = out['final_box_dicts'][0]
+    n, worst = match_boxes(g['boxes'], g['scores'], np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
+    assert n >= g['boxes'].shape[0] - 2, (n, g['boxes'].shape[0], worst)
