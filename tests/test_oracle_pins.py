@@ -258,3 +258,44 @@ def test_g2_disco_full_size_forward():
     fb = out['final_box_dicts'][0]
     n, worst = match_boxes(g['boxes'], g['scores'], np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
     assert n >= g['boxes'].shape[0] - 2, (n, g['boxes'].shape[0], worst)
+
+
+@pytest.mark.parametrize('tag,yaml_name,layout,n_agents', [('car', 'v2x_pointpillar_basic_car.yaml', 'car', 1),
+                                                           ('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', 1),
+                                                           ('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', 6)])
+def test_g2_full_size_forward(tag, yaml_name, layout, n_agents):
+    """the oracle's complete forward at BASELINE's full size (the workload of bench.py's cpu_baseline leg) against the reference's
+    digests: pillar features, map probes, heat-map probe, final boxes and scores"""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    g = load_golden('g2_full.npz')
+    cfg = bench.load_cfg(yaml_name)
+    _model, state, _ds = bench.build_model(cfg)
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    arch = omodel.arch_from_cfg(plain(cfg.MODEL), list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), list(vs))
+    cloud = np.concatenate([synth.agent_cloud(agent=a, n_points=60000, layout=layout) for a in range(n_agents)], axis=0)
+    pts = synth.collate([cloud])
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = omodel.forward(pts, state, arch, metadata=[{}])
+    assert out['voxel_coords'].shape[0] == int(g[tag + '_P'])
+    pf = np.asarray(out['pillar_features']).astype(np.float64)
+    np.testing.assert_allclose(pf.sum(0), g[tag + '_pf_sum'], rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(pf.max(0), g[tag + '_pf_max'], rtol=0, atol=1e-5)
+    sf = np.asarray(out['spatial_features_2d'])
+    np.testing.assert_allclose(sf[0, :, ::16, ::16], g[tag + '_sf2d_probe'], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(np.asarray(out['head_maps']['hm'])[0, 0, ::4, ::4], g[tag + '_hm_probe'], rtol=0, atol=3e-4)
+    fb = out['final_box_dicts'][0]
+    gb, gs = g[tag + '_boxes'], g[tag + '_scores']
+    assert abs(np.asarray(fb['pred_boxes']).shape[0] - gb.shape[0]) <= 1
+    if gb.shape[0]:
+        n, worst = match_boxes(gb, gs, np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
+        assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
