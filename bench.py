@@ -1,20 +1,29 @@
 """bench.py -- frames/s of the PointPillars collaborative-perception hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config car|ego|early|disco] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config disco|car|ego|early|lately6] [--batch B] [--dist uniform|ring]
 
-A "step" is one pass of the hot path (points resident in HBM -> final boxes) over one batch of B synthetic 60k-point clouds
-per GPU.  Default workload = BASELINE.json configs[1]: v2x_pointpillar_basic_car.yaml, single-agent inference (VFE -> scatter ->
-BEV backbone -> HunterJr -> CenterHead -> decode -> rotated NMS), B = BATCH_SIZE_PER_GPU = 4.
-N > 1: launched by torch.distributed.run, one rank per GPU; frames are independent so ranks are replicas on different frames
-(weak scaling, no data-path collective); value = all ranks' frames / max-over-ranks time.
+A "step" is one pass of the hot path (points resident in HBM -> final boxes) over one batch of B synthetic frames per GPU.
+Default workload = the one BASELINE.json's metric is quoted on ("60k-pt cloud, 6 agents"): v2x_pointpillar_disco.yaml, mid fusion of
+6 agents x 60 000 points per frame (3 BEV makers -> ego VFE/backbone -> compress / warp / fuse -> CenterHead -> decode -> rotated NMS),
+B = BATCH_SIZE_PER_GPU = 4 frames.  It fits one GPU (5.7 GB).  The other BASELINE configs are --config car | ego | early | lately6.
+
+--gpus N > 1: bench.py starts N ranks ITSELF (a `python -m torch.distributed.run` child, spawned before this process touches the GPU)
+unless it already runs under a launcher (WORLD_SIZE set; it then insists on WORLD_SIZE == N).  One rank per GPU, backend nccl (= RCCL).
+Frames are independent, so ranks are replicas on different frames (weak scaling, no data-path collective); value = all ranks' frames /
+max-over-ranks time.  --shard agent / --train add the collectives those modes need.
 
 Rank 0 prints ONE JSON line with the contract keys plus
-  roofline     : the dominant kernel (3x3 conv, fp32 MFMA implicit GEMM) timed live with HIP events on its stream
+  roofline     : the kernel with the LARGEST measured share of the step (HIP events around every C-ABI launch of an instrumented pass),
+                 `achieved` = the flops that kernel EXECUTES on the matrix pipe / its measured time (never above the peak); the
+                 direct-convolution-equivalent ("algorithmic") rate is a separate key; `traffic` from the committed rocprofv3 --pmc pass
+  kernel_ms_per_step : the measured time of every kernel family of the step (the table `roofline.kernel` is picked from)
   cpu_baseline : the oracle (CPU restatement of the reference modules) timed on this box's host cores, bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,21 +33,70 @@ for _p in (REPO, PKG, os.path.join(REPO, 'tests')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 CONFIGS = {
     'car': dict(yaml='v2x_pointpillar_basic_car.yaml', layout='car', agents_in_cloud=1,
-                name='v2x_pointpillar_basic_car single-agent inference (VFE+scatter+backbone+HunterJr+CenterHead+NMS)'),
+                name='v2x_pointpillar_basic_car single-agent inference (VFE+scatter+backbone+HunterJr+CenterHead+NMS), 1 x 60k points per frame'),
     'ego': dict(yaml='v2x_pointpillar_basic_ego.yaml', layout='lately', agents_in_cloud=1,
-                name='v2x_pointpillar_basic_ego lately-fusion ego pass (60k points incl. 300 MoDAR rows)'),
+                name='v2x_pointpillar_basic_ego lately-fusion ego pass only (60k points incl. 300 synthetic MoDAR rows)'),
     'early': dict(yaml='v2x_pointpillar_basic_ego_early.yaml', layout='early', agents_in_cloud=6,
-                  name='v2x_pointpillar_basic_ego_early early fusion (6 x 60k points merged)'),
+                  name='v2x_pointpillar_basic_ego_early early fusion (6 agents x 60k points merged per frame)'),
     'disco': dict(yaml='v2x_pointpillar_disco.yaml', layout='disco', agents_in_cloud=6,
-                  name='v2x_pointpillar_disco mid fusion (3 BEV makers + warp/fuse, 6 x 60k points)'),
+                  name='v2x_pointpillar_disco mid fusion, 6 agents x 60k points per frame (3 BEV makers + ego branch + compress/warp/fuse + '
+                       'CenterHead + NMS)'),
+    'lately6': dict(yaml='v2x_pointpillar_basic_ego.yaml', layout='lately6', agents_in_cloud=6,
+                    name='lately fusion end to end, 6 agents x 60k points per frame on one GPU: 5 remote basic_car passes -> MoDAR + foreground '
+                         'rows -> device-side ingestion -> basic_ego pass'),
 }
-MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='disco', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
+    ap.add_argument('--dist', default='uniform', choices=['uniform', 'ring'], help='synthetic cloud distribution (SURVEY 8(d)): uniform in x, y '
+                    '(about 53.6k pillars per 60k points) or the LiDAR-like ring (r = 70 u^2; 20-30k pillars)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dense-first-layer', action='store_true', help='A/B switch: always write the dense canvas and run the first backbone '
+                    'layer as the dense stride-2 conv (default in pipeline mode: from the pillar list when the cloud is sparse)')
+    ap.add_argument('--plugin-default', action='store_true', help='measure the mode tools/test.py gets WITHOUT --fast: per-pillar API tensors '
+                    'materialised (one host sync per VFE), dense canvas, no buffer reuse')
+    ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
+    ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'],
+                    help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
+                         '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
+    ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
+                    "agent: configs early / disco only -- each rank holds the points of ITS agents, one all-gather of raw points (early) or "
+                    "of compressed BEV maps (disco) per step, then the frames of the batch are dealt to the ranks (pcdet/models/sharded.py; "
+                    "strong scaling: the group processes ONE batch per step)")
+    ap.add_argument('--train', action='store_true', help='configs ego / early / disco: time full training iterations (forward + backward + '
+                    'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """--gpus N outside a launcher: start N ranks as a torch.distributed.run CHILD process and return its exit code.  This parent has not
+    touched the GPU (no torch.cuda call yet), and it does not exec: it waits for the child and hands its output through."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
 
 
 def load_cfg(yaml_name):
@@ -51,6 +109,7 @@ def load_cfg(yaml_name):
 
 
 def build_model(cfg):
+    import torch
     from pcdet.models import DatasetInfo, build_network
     from pcp_amd import synth
     enc = cfg.DATA_CONFIG.POINT_FEATURE_ENCODING
@@ -63,15 +122,17 @@ def build_model(cfg):
     return model, state, ds
 
 
-def make_points(conf, batch, rank):
-    """B frames per rank; frame f of rank r uses agent streams 100*r + 10*f + a (distinct data on every rank)."""
+def make_points(conf, batch, rank, dist='uniform'):
+    """B frames per rank; frame f of rank r uses agent streams 1000*r + 10*f + a (distinct data on every rank)."""
+    import numpy as np
     from pcp_amd import synth
     clouds, metas = [], []
+    layout = 'car' if conf['layout'] == 'lately6' else conf['layout']
     for f in range(batch):
         parts = []
         for a in range(conf['agents_in_cloud']):
-            c = synth.agent_cloud(agent=1000 * rank + 10 * f + a, n_points=60000, layout=conf['layout'])
-            if conf['layout'] == 'disco':
+            c = synth.agent_cloud(agent=1000 * rank + 10 * f + a, n_points=60000, layout=layout, dist=dist)
+            if layout == 'disco':
                 c[:, -1] = float(a)
             parts.append(c)
         clouds.append(np.concatenate(parts, 0))
@@ -81,8 +142,9 @@ def make_points(conf, batch, rank):
 
 def cpu_baseline(conf, cfg, state, batch_points, metas, budget_s=25.0):
     """oracle forward on the host cores: 1 frame per run (B=1), as many runs as fit the budget (at least 1)."""
+    import torch
     from oracle import model as omodel
-    from pcdet.config import EasyDict
+    from pcdet.config import EasyDict  # noqa: F401
 
     def plain(d):
         if isinstance(d, dict):
@@ -114,181 +176,237 @@ def cpu_baseline(conf, cfg, state, batch_points, metas, budget_s=25.0):
                 sample='%d x 1 frame (%d points), oracle/model.py forward incl. decode+NMS, torch CPU threads=%d' % (runs, pts.shape[0], cores))
 
 
-class ConvTimer:
-    """HIP events around every pcp_conv3x3 launch on the launch stream (instrumented pass, outside the timed region)."""
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# instrumented pass: HIP events around EVERY C-ABI launch on the launch stream (torch's current stream is the stream pcp_amd.ops passes)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+
+class AbiTimer:
+    """Wraps the ctypes library object so that each pcp_* launch is bracketed by two HIP events on the stream it is enqueued on.  A
+    C-ABI entry is one kernel for all the heavy families (the multi-launch entries -- voxelize, NMS -- are latency work reported as a
+    group); the three launches of the F(4x4) path are split by the library's own measurement entry point."""
+
+    SKIP = ('_bytes', '_plan', 'pcp_abi_version', 'pcp_status_string', '_timed')
 
     def __init__(self):
-        self.records = []
+        self.records = []           # (label, e0, e1, exec_flops, alg_flops, bound, peak)
+        self.w4 = []                # (in_ms, gemm_ms, out_ms, gemm_flops, alg_flops)
 
     def install(self):
-        from pcp_amd import ops
-        self._orig = ops.conv3x3
+        import ctypes
+        import torch
+        from pcp_amd import lib
+        self._lib = lib
+        real = lib.load()
+        self._real = real
         timer = self
 
-        def timed(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
-            s = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            r = timer._orig(x, packed, bias, cin, cout, cout_pad, stride=stride, relu=relu, out=out, in_ch_off=in_ch_off,
-                            out_ch_off=out_ch_off)
-            e1.record(s)
-            B, H, W, _ = x.shape
-            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-            timer.records.append((e0, e1, 2.0 * B * Ho * Wo * cout * 9 * cin, stride, cout_pad))
-            return r
-        ops.conv3x3 = timed
-        self._orig_w = ops.conv3x3_winograd
+        def describe(name, a):
+            if name in ('pcp_conv3x3', 'pcp_conv3x3_winograd', 'pcp_conv3x3_bf16x3', 'pcp_conv3x3_bf16'):
+                d = a[0]._obj
+                s = d.stride
+                ho, wo = (d.in_h - 1) // s + 1, (d.in_w - 1) // s + 1
+                alg = 2.0 * d.batch * ho * wo * d.cout * 9 * d.cin
+                if name == 'pcp_conv3x3_winograd':
+                    v, fl = ctypes.c_int32(0), ctypes.c_double(0.0)
+                    real.pcp_conv3x3_winograd_plan(ctypes.byref(d), ctypes.byref(v), ctypes.byref(fl))
+                    names = {1: 'k_conv3x3_wino<1> (3x3 s1 fused Winograd F(2x2,3x3), 32-tile workgroups, v_mfma_f32_32x32x2_f32)',
+                             2: 'k_conv3x3_wino<2> (3x3 s1 fused Winograd F(2x2,3x3), 64-tile workgroups, v_mfma_f32_32x32x2_f32)'}
+                    return names.get(v.value, 'k_conv3x3_wino<%d> (3x3 s1 fused Winograd, fp32 MFMA)' % v.value), fl.value, alg, 'mfma', MFMA_F32_PEAK_TFLOPS
+                if name == 'pcp_conv3x3':
+                    return ('k_conv3x3_direct<s%d> (3x3 direct implicit GEMM, v_mfma_f32_32x32x2_f32)' % s,
+                            2.0 * d.batch * ho * wo * d.cout_pad * 9 * d.cin, alg, 'mfma', MFMA_F32_PEAK_TFLOPS)
+                mult = 3.0 if name == 'pcp_conv3x3_bf16x3' else 1.0
+                return ('k_%s<s%d> [opt-in arithmetic]' % (name[4:], s), mult * 2.0 * d.batch * ho * wo * d.cout_pad * 9 * d.cin, alg,
+                        'mfma', MFMA_BF16_PEAK_TFLOPS)
+            if name == 'pcp_pointwise':
+                d = a[0]._obj
+                if d.mode == 0:
+                    fl, tag = 2.0 * d.rows * d.cin * d.cout_pad, 'plain'
+                elif d.mode == 1:
+                    fl, tag = 2.0 * d.batch * (d.in_h // 2) * (d.in_w // 2) * 4 * d.cin * d.cout_pad, 'conv_k2s2'
+                else:
+                    fl, tag = 2.0 * d.batch * d.in_h * d.in_w * d.cin * 4 * d.cout_pad, 'convT_k2s2'
+                return 'k_pointwise<%s> (fp32 MFMA GEMM)' % tag, fl, fl * d.cout / max(d.cout_pad, 1), 'mfma', MFMA_F32_PEAK_TFLOPS
+            label = {'pcp_pfn_scatter': 'k_pfn (fused PFN + scatter)', 'pcp_sparse_conv3x3_s2': 'k_sparse_conv_s2 (first backbone layer from the pillar list)',
+                     'pcp_voxelize': 'pcp_voxelize (all its launches)', 'pcp_nms_rotated': 'pcp_nms_rotated (all its launches)',
+                     'pcp_hunter_point_head_ex': 'k_point_head', 'pcp_hunter_point_head': 'k_point_head',
+                     'pcp_conv3x3_grouped_small': 'k_head_grouped'}.get(name, name)
+            return label, None, None, 'latency', None
 
-        def timed_w(x, packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
-            s = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            r = timer._orig_w(x, packed, bias, cin, cout, cout_pad, relu=relu, out=out, in_ch_off=in_ch_off, out_ch_off=out_ch_off)
-            e1.record(s)
-            B, H, W, _ = x.shape
-            # same dispatch rule as pcp_conv3x3_winograd (csrc/wino.hip): 64-tile instantiation <2> for the long-K layers
-            big = cin >= 256 and B * ((H + 15) // 16) * ((W + 15) // 16) * (cout_pad // 64) >= 256
-            timer.records.append((e0, e1, 2.0 * B * H * W * cout * 9 * cin, 1, -2 if big else -1))
-            return r
-        ops.conv3x3_winograd = timed_w
-        self._orig_b3 = ops.conv3x3_bf16x3
+        class Proxy:
+            def __getattr__(self, name):
+                fn = getattr(real, name)
+                if not name.startswith('pcp_') or any(t in name for t in AbiTimer.SKIP):
+                    return fn
+                if name == 'pcp_conv3x3_winograd4':
+                    def w4(d, x, u, bias, out, ws, stream):
+                        ms = (ctypes.c_float * 3)()
+                        fl = ctypes.c_double(0.0)
+                        r = real.pcp_conv3x3_winograd4_timed(d, x, u, bias, out, ws, stream, ms, ctypes.byref(fl))
+                        dd = d._obj
+                        timer.w4.append((ms[0], ms[1], ms[2], fl.value, 2.0 * dd.batch * dd.in_h * dd.in_w * dd.cout * 9 * dd.cin))
+                        return r
+                    return w4
 
-        def timed_b3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0, plain=False):
-            s = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            r = timer._orig_b3(x, packed, bias, cin, cout, cout_pad, stride=stride, relu=relu, out=out, in_ch_off=in_ch_off,
-                               out_ch_off=out_ch_off, plain=plain)
-            e1.record(s)
-            B, H, W, _ = x.shape
-            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-            timer.records.append((e0, e1, 2.0 * B * Ho * Wo * cout * 9 * cin, stride, -3))
-            return r
-        ops.conv3x3_bf16x3 = timed_b3
-        self._orig_w4 = ops.conv3x3_winograd4
-        self.w4 = []
-
-        def timed_w4(x, packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
-            # three launches (input transform, batched GEMM, output transform): the library's measurement entry point brackets each with
-            # HIP events on the launch stream (pcp_conv3x3_winograd4_timed)
-            st = []
-            r = timer._orig_w4(x, packed, bias, cin, cout, cout_pad, relu=relu, out=out, in_ch_off=in_ch_off, out_ch_off=out_ch_off,
-                               stage_times=st)
-            B, H, W, _ = x.shape
-            timer.w4.append(st[0] + (2.0 * B * H * W * cout * 9 * cin,))
-            return r
-        ops.conv3x3_winograd4 = timed_w4
+                def wrapped(*a):
+                    s = torch.cuda.current_stream()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s)
+                    r = fn(*a)
+                    e1.record(s)
+                    timer.records.append((e0, e1) + describe(name, a))
+                    return r
+                return wrapped
+        lib._LIB = Proxy()
 
     def remove(self):
-        from pcp_amd import ops
-        ops.conv3x3 = self._orig
-        ops.conv3x3_winograd = self._orig_w
-        ops.conv3x3_bf16x3 = self._orig_b3
-        ops.conv3x3_winograd4 = self._orig_w4
+        self._lib._LIB = self._real
 
-    def summary(self):
+    def families(self, steps):
+        """-> list of dicts sorted by time: label, ms_per_step, launches_per_step, executed/algorithmic flops per step, bound, peak"""
+        import torch
         torch.cuda.synchronize()
-        # dominant kernel = the fused Winograd 3x3 kernel (k_conv3x3_wino); falls back to the direct stride-1 instantiation
-        self.peak, self.exec_mult = MFMA_F32_PEAK_TFLOPS, 4.0 / 9.0
-        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -3 and st == 1]
-        self.dominant = 'k_conv3x3_bf16x3 (3x3 implicit GEMM, split-bf16 operands, 3 x v_mfma_f32_32x32x16_bf16 per product) [opt-in mode]'
-        if sel:
-            self.peak, self.exec_mult = 2500.0, 3.0                     # dense bf16 MFMA peak; three MFMAs per algorithmic product
-        else:
-            sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if cp == -2]
-            self.dominant = 'k_conv3x3_wino<2> (3x3 s1 fused Winograd F(2x2,3x3), 64-tile workgroups, v_mfma_f32_32x32x2_f32)'
-        if not sel:
-            sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records if st == 1 and cp % 64 == 0]
-            self.dominant = 'k_conv3x3<1,8,16,64,2,2> (3x3 s1 implicit GEMM, v_mfma_f32_32x32x2_f32)'
-            self.exec_mult = 1.0
-        allc = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, st, cp) in self.records]
-        allc += [((a + b + c) * 1e-3, alg) for (a, b, c, _gf, alg) in self.w4]
-        extra = {}
-        if self.w4 and self.peak == MFMA_F32_PEAK_TFLOPS:
-            # dominant kernel = the batched GEMM of the F(4x4,3x3) path: its executed flops ARE its algorithmic work
-            sel = [(b * 1e-3, gf) for (_a, b, _c, gf, _alg) in self.w4]
-            self.dominant = ('k_w4_gemm (36 batched GEMMs [tiles x cin] x [cin x cout] of the Winograd F(4x4,3x3) wide-layer convolutions, '
-                             '128x128x32 LDS tiles, v_mfma_f32_32x32x2_f32)')
-            self.exec_mult = 1.0
-            n = len(self.w4)
-            extra = {'winograd4_avg_us': {'input_transform': round(1e3 * sum(r[0] for r in self.w4) / n, 2),
-                                          'gemm': round(1e3 * sum(r[1] for r in self.w4) / n, 2),
-                                          'output_transform': round(1e3 * sum(r[2] for r in self.w4) / n, 2)},
-                     'winograd4_conv_algorithmic_tflops': round(sum(r[4] for r in self.w4) / sum(r[0] + r[1] + r[2] for r in self.w4) / 1e9, 3)}
-        t, f = sum(a for a, _ in sel), sum(b for _, b in sel)
-        ta, fa = sum(a for a, _ in allc), sum(b for _, b in allc)
-        return dict(launches=len(sel), avg_us=1e6 * t / max(len(sel), 1), tflops=f / t / 1e12 if t > 0 else 0.0,
-                    all_conv_launches=len(allc), all_conv_tflops=fa / ta / 1e12 if ta > 0 else 0.0, all_conv_ms=1e3 * ta, extra=extra)
+        fam = {}
+
+        def add(label, ms, ex, alg, bound, peak):
+            f = fam.setdefault(label, dict(kernel=label, ms=0.0, launches=0, exec_flops=0.0, alg_flops=0.0, bound=bound, peak=peak))
+            f['ms'] += ms
+            f['launches'] += 1
+            f['exec_flops'] += ex or 0.0
+            f['alg_flops'] += alg or 0.0
+        for (e0, e1, label, ex, alg, bound, peak) in self.records:
+            add(label, e0.elapsed_time(e1), ex, alg, bound, peak)
+        for (a, b, c, gf, alg) in self.w4:
+            add('k_w4_input (F(4x4,3x3) input transform)', a, None, None, 'hbm', None)
+            add('k_w4_gemm (36 batched GEMMs of the Winograd F(4x4,3x3) wide layers, 128x128x32 LDS tiles, v_mfma_f32_32x32x2_f32)', b, gf, alg,
+                'mfma', MFMA_F32_PEAK_TFLOPS)
+            add('k_w4_output (F(4x4,3x3) output transform + bias + ReLU)', c, None, None, 'hbm', None)
+        out = sorted(fam.values(), key=lambda f: -f['ms'])
+        for f in out:
+            f['ms_per_step'] = f['ms'] / steps
+            f['launches_per_step'] = f['launches'] / steps
+        return out
 
 
-def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
-    WRITE_SIZE runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streaming reads)."""
-    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+def pmc_traffic(config, kernel_label):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command (separate FETCH_SIZE and
+    WRITE_SIZE runs, --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streaming reads) -- profiles/
+    r02_pmc_traffic.json, written by tools/pmc_summary.py."""
+    path = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
     if not os.path.isfile(path):
         return None
     with open(path) as f:
-        d = json.load(f)
-    e = d.get(kernel_key)
+        d = json.load(f).get(config, {})
+    short = kernel_label.split(' ')[0]
+    e = d.get(short)
     return None if e is None else e['bytes_per_launch']
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', default='car', choices=sorted(CONFIGS))
-    ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (0 = BATCH_SIZE_PER_GPU of the YAML)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--dense-first-layer', action='store_true', help='A/B switch: always write the dense canvas and run the first backbone '
-                    'layer as the dense stride-2 conv (default in pipeline mode: from the pillar list when the cloud is sparse)')
-    ap.add_argument('--no-optin', action='store_true', help='skip the informational opt-in (bf16x3) pass after the fp32 measurement (clean '
-                    'rocprofv3 kernel statistics of the headline path)')
-    ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
-    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'],
-                    help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
-                         '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
-    ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
-                    "agent: configs early / disco only -- each rank holds the points of ITS agents, one all-gather of raw points (early) or "
-                    "of compressed BEV maps (disco) per step, then the frames of the batch are dealt to the ranks (pcdet/models/sharded.py; "
-                    "strong scaling: the group processes ONE batch per step)")
-    ap.add_argument('--train', action='store_true', help='configs ego / early / disco: time full training iterations (forward + backward + '
-                    'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
-    args = ap.parse_args()
+def dry_run(args, world, rank):
+    """PCP_BENCH_DRY_RUN=1 (tests/test_dist_cpu.py only): the launcher, rendezvous, barrier and max-over-ranks aggregation of this script
+    with a sleep in place of the kernels -- no GPU, no library, backend gloo.  The line says so in `data`; it is never a measurement."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo')
+    batch = args.batch or 4
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    seen = 1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(c)
+        seen = int(c.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'frames/sec', 'value': round(world * batch * args.steps / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,
+                          'ranks_seen_by_collective': seen, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'f32', 'data': 'DRY RUN: no kernels executed (launcher / aggregation self-test)',
+                          'config': {'workload': 'dry run'}, 'roofline': None, 'cpu_baseline': None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))            # nothing in this process has initialised the GPU
+    world = int(env_world or '1')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus, or let bench.py start the ranks)'
+                         % (args.gpus, world))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('PCP_BENCH_DRY_RUN') == '1':
+        return dry_run(args, world, rank)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     if args.conv_algo is not None:
         if args.conv_algo == 'bf16' and not args.train:
             raise SystemExit('--conv-algo bf16 (plain bf16 products) is the mixed-precision TRAINING mode: add --train')
         os.environ['PCP_CONV_ALGO'] = args.conv_algo
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (the hot path has no CPU fallback)'
     # one rank per GPU; PCP_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
-    # (ranks then share devices round-robin -- a functional check, not a measurement)
-    dev_index = local_rank % torch.cuda.device_count() if world > 1 else 0
+    # (ranks then share devices round-robin -- a functional check, not a measurement, and the line says so)
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get('PCP_BENCH_BACKEND', 'nccl')
+    if world > n_dev and backend == 'nccl':
+        raise SystemExit('bench.py: %d ranks but %d GPUs visible (one rank per GPU; PCP_BENCH_BACKEND=gloo shares devices for a functional check)'
+                         % (world, n_dev))
+    dev_index = local_rank % n_dev if world > 1 else 0
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(dev_index)
-        dist.init_process_group(backend=os.environ.get('PCP_BENCH_BACKEND', 'nccl'))
+        dist.init_process_group(backend=backend)
     dev = torch.device('cuda', dev_index)
+    if world > 1:
+        c = torch.ones(1, dtype=torch.int64, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(c)                         # the world size as the collective library itself observes it
+        ranks_seen = int(c.item())
 
     conf = CONFIGS[args.config]
     cfg = load_cfg(conf['yaml'])
     batch = args.batch or int(cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU)
     model, state, ds = build_model(cfg)
-    if args.train and args.config == 'car':
-        raise SystemExit('--train: HunterJr (basic_car) has no training kernels; use --config ego | early | disco')
+    if args.train and args.config in ('car', 'lately6'):
+        raise SystemExit('--train: use --config ego | early | disco')
     model = model.to(dev).eval()
-    for m in model.modules():
-        if hasattr(m, 'materialize_pillars'):
-            m.materialize_pillars = False       # per-pillar API tensors are not consumed downstream (SURVEY 8(d))
-            m.reuse_buffers = True
-            m.sparse_first_layer = not args.dense_first_layer   # sparse clouds: first backbone layer from the pillar list, no dense canvas
-    pts_np, metas = make_points(conf, batch, rank)
+    if not args.plugin_default:
+        for m in model.modules():
+            if hasattr(m, 'materialize_pillars'):
+                m.materialize_pillars = False       # per-pillar API tensors are not consumed downstream (SURVEY 8(d))
+                m.reuse_buffers = True
+                m.sparse_first_layer = not args.dense_first_layer   # sparse clouds: first backbone layer from the pillar list, no dense canvas
+    pts_np, metas = make_points(conf, batch, rank, args.dist)
     pristine = torch.from_numpy(pts_np).to(dev)
     work = torch.empty_like(pristine)
+
+    lately = None
+    if args.config == 'lately6':
+        from pcdet.models.lately_chain import LatelyFusionChain
+        car_cfg = load_cfg(CONFIGS['car']['yaml'])
+        car_model, _car_state, _ = build_model(car_cfg)
+        car_model = car_model.to(dev).eval()
+        lately = LatelyFusionChain(car_model, model, pipeline=not args.plugin_default)
 
     graphed = None
     if args.graph:
@@ -338,7 +456,7 @@ def main():
         from pcdet.models import sharded
         sharded_runner = (sharded.AgentShardedEarlyFusion if args.config == 'early' else sharded.AgentShardedMidFusion)(model)
         # every rank generated the SAME batch (rank 0's streams); it keeps only the rows of its agents (round-robin over agents)
-        pts_np, metas = make_points(conf, batch, 0)
+        pts_np, metas = make_points(conf, batch, 0, args.dist)
         agent_of_row = pts_np[:, -1] if conf['layout'] == 'disco' else np.repeat(np.arange(conf['agents_in_cloud']), 60000)[None].repeat(batch, 0).reshape(-1)
         mine = pts_np[(agent_of_row.astype(np.int64) % world) == rank]
         pristine = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
@@ -352,6 +470,8 @@ def main():
         if graphed is not None:
             return graphed(pristine)            # copy-in + every kernel of the path = one graph replay
         work.copy_(pristine)                    # HunterJr corrects xyz in place: every step starts from the same bits
+        if lately is not None:
+            return lately(work, batch, metas)
         bd = {'points': work, 'batch_size': batch, 'metadata': metas}
         with torch.no_grad():
             pred_dicts, _ = model(bd)
@@ -372,60 +492,79 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_boxes = int(sum(p['pred_boxes'].shape[0] for p in preds))
 
-    # instrumented pass (HIP events around the conv launches).  Training and agent-sharded steps contain collectives, so in those modes
-    # every rank has to take part in the three extra steps; only rank 0 records.
+    # instrumented pass (HIP events around every C-ABI launch).  Training and agent-sharded steps contain collectives, so in those modes
+    # every rank has to take part in the extra steps; only rank 0 records.
+    INSTR_STEPS = 3
     timer = None
     if rank == 0:
         graphed = None                          # the instrumented pass runs eagerly (events around individual launches)
-        timer = ConvTimer()
+        timer = AbiTimer()
         timer.install()
     if rank == 0 or ((args.train or args.shard == 'agent') and world > 1):
-        for _ in range(3):
+        for _ in range(INSTR_STEPS):
             step()
     if rank == 0:
-        cs = timer.summary()
+        fams = timer.families(INSTR_STEPS)
         timer.remove()
+        dom = fams[0]
         frames = (world if args.shard == 'frame' else 1) * batch * args.steps
+        algo = os.environ.get('PCP_CONV_ALGO', 'auto')
+        if dom['bound'] == 'mfma' and dom['ms'] > 0:
+            ach = dom['exec_flops'] / (dom['ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(ach, 3), 'peak': dom['peak'], 'unit': 'TFLOP/s',
+                    'frac': round(ach / dom['peak'], 4),
+                    'note': 'achieved = flops this kernel EXECUTES on the matrix pipe (Winograd: 16 products per 2x2 tile, padding included) / '
+                            'its HIP-event time; algorithmic_tflops = flops of the equivalent direct convolution / the same time',
+                    'algorithmic_tflops': round(dom['alg_flops'] / (dom['ms'] * 1e-3) / 1e12, 3)}
+        else:
+            roof = {'bound': 'hbm' if dom['bound'] == 'hbm' else 'latency', 'kernel': dom['kernel'], 'achieved': None, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': None}
+        roof.update({'traffic': pmc_traffic(args.config, dom['kernel']) if (algo == 'auto' and not args.train) else None,
+                     'avg_launch_us': round(1e3 * dom['ms'] / max(dom['launches'], 1), 2),
+                     'launches_per_step': round(dom['launches_per_step'], 2),
+                     'share_of_kernel_time': round(dom['ms'] / max(sum(f['ms'] for f in fams), 1e-9), 4)})
+        mf = [f for f in fams if f['bound'] == 'mfma']
+        roof['all_mfma_kernels'] = {'executed_tflops': round(sum(f['exec_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
+                                    'algorithmic_tflops': round(sum(f['alg_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
+                                    'ms_per_step': round(sum(f['ms_per_step'] for f in mf), 3)}
         line = {
-            'metric': 'frames/sec (60k-pt cloud per agent) through the PointPillars hot path', 'value': round(frames / elapsed, 3),
+            'metric': 'frames/sec (60k-pt cloud, 6 agents)' if conf['agents_in_cloud'] == 6 else 'frames/sec (60k-pt cloud, 1 agent)',
+            'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
             'dtype': {'bf16x3': 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
                       'bf16': 'mixed precision [opt-in, --train only]: forward / data-gradient 3x3 conv products in bf16 (8 mantissa bits), f32 accumulate, '
-                              'f32 master weights, weight gradients, BatchNorm, losses and optimizer'}.get(os.environ.get('PCP_CONV_ALGO', 'auto'), 'f32'),
-            'data': 'synthetic',
+                              'f32 master weights, weight gradients, BatchNorm, losses and optimizer'}.get(algo, 'f32'),
+            'data': 'synthetic' + (' (ring distribution)' if args.dist == 'ring' else ''),
             'config': {'workload': conf['name'] if not args.train else ('v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)'
                        if args.config == 'disco' else conf['name'] + ' -- TRAINING iteration (VFE/backbone/head forward+backward, CenterNet '
                        'losses, clip, Adam one-cycle)'),
-                       'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch,
-                       'points_per_frame': int(pts_np.shape[0] // batch), 'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))
+                       'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch, 'agents_per_frame': conf['agents_in_cloud'],
+                       'points_per_frame': int(pts_np.shape[0] // batch), 'point_distribution': args.dist,
+                       'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
-                       'pipeline_mode': 'no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
-                                        ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
-                                         'from the pillar list when points <= 0.35 x cells (no dense canvas), dense otherwise') +
-                                        '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*)',
+                       'ranks_seen_by_collective': ranks_seen, 'backend': backend if world > 1 else None,
+                       'mode': ('plugin default (per-pillar API tensors materialised: one host sync per VFE; dense canvas)' if args.plugin_default else
+                                'pipeline: no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
+                                ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
+                                 'from the pillar list when points <= 0.35 x cells (no dense canvas), dense otherwise') +
+                                '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*)'),
                        'peak_device_memory_mb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
-            'roofline': {'bound': 'mfma', 'kernel': timer.dominant,
-                         'achieved': round(cs['tflops'], 3), 'peak': timer.peak, 'unit': 'TFLOP/s',
-                         'frac': round(cs['tflops'] / timer.peak, 4),
-                         'traffic': (pmc_traffic('k_w4_gemm' if 'k_w4_gemm' in timer.dominant else 'k_conv3x3_wino<2>')
-                                     if (args.config == 'car' and ('wino' in timer.dominant or 'k_w4_gemm' in timer.dominant)) else None),
-                         # the fused Winograd F(2x2) kernel executes 16/36 of the direct convolution's multiply-adds: fraction of the MFMA
-                         # peak in EXECUTED flops (what the matrix pipe actually sustains); 1:1 for the GEMM kernel
-                         'executed_frac': round(cs['tflops'] * timer.exec_mult / timer.peak, 4), **cs['extra'],
-                         'avg_launch_us': round(cs['avg_us'], 2), 'launches_per_step': cs['launches'] // 3,
-                         'all_conv3x3_tflops': round(cs['all_conv_tflops'], 3), 'all_conv3x3_ms_per_step': round(cs['all_conv_ms'] / 3, 3)},
+            'roofline': roof,
+            'kernel_ms_per_step': {f['kernel'].split(' ')[0]: round(f['ms_per_step'], 4) for f in fams[:14]},
+            'kernel_ms_per_step_total': round(sum(f['ms_per_step'] for f in fams), 3),
         }
-        if (world == 1 and not args.train and not args.graph and args.shard == 'frame' and os.environ.get('PCP_CONV_ALGO', 'auto') == 'auto'
-                and not args.no_optin):
+        if world > 1 and backend != 'nccl':
+            line['data'] += ' -- FUNCTIONAL CHECK ONLY: backend %s, %d ranks on %d device(s)' % (backend, world, n_dev)
+        if world == 1 and not args.train and not args.graph and args.shard == 'frame' and algo == 'auto' and args.optin:
             # informational: the same workload with the OPT-IN split-bf16 convolution arithmetic (never part of `value`)
             os.environ['PCP_CONV_ALGO'] = 'bf16x3'
             for m in model.modules():
@@ -447,7 +586,7 @@ def main():
                                     'note': 'NOT the headline: 3x3 conv products as split bf16 (hi + lo, 16 mantissa bits; 3 bf16 MFMAs per '
                                             'product, f32 accumulate), ~1e-5 relative error, all parity tests pass at unchanged tolerances; '
                                             'enable with --conv-algo bf16x3 / PCP_CONV_ALGO=bf16x3'}
-        if not args.no_cpu_baseline and world == 1:                    # rank 0 at N = 1 only (the contract); N > 1 lines carry null
+        if not args.no_cpu_baseline and world == 1 and args.config != 'lately6':   # rank 0 at N = 1 only (the contract); N > 1 lines carry null
             line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
         else:
             line['cpu_baseline'] = None

@@ -123,6 +123,24 @@ int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, 
 int pcp_conv3x3_winograd(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
                          void *stream);
 
+/* Same operation, same arithmetic (fused Winograd F(2x2,3x3), fp32 MFMA), "wave-stationary" decomposition for the short-K layers
+ * (base_bev_backbone.py:30-69 blocks at 64 / 128 channels, center_head.py:24-29 branches, v2x_fusion_disco.py:51-58 compressor): a wave
+ * keeps 32 tiles x 32 output channels x 8 Winograd positions in registers for the whole contraction and transforms its own A operand in
+ * registers (no V round trip through LDS, no per-slice barrier).  cin % 32 == 0, cout_pad % 64 == 0, ld_in % 4 == 0, `in` and `u_packed`
+ * 16-byte aligned; weights packed by pcp_amd/pack.py::pack_conv3x3_winograd_ws as U = G g G^T:
+ * [cin/2][cout_pad/32][2 (position rows {0,1} | {2,3})][2 (row)][64 (channel parity, cout)][4 (position column)].
+ * _supported: 1 if `desc` meets those shape rules; _plan: the kernel variant (tile groups per workgroup: 1 = 8x16 px x 128 ch,
+ * 2 = 16x16 px x 64 ch) and the flops the launch executes on the matrix pipe (padding included); either output may be NULL. */
+int pcp_conv3x3_winograd_ws_supported(const pcp_conv3x3_t *desc);
+int pcp_conv3x3_winograd_ws(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                            void *stream);
+int pcp_conv3x3_winograd_ws_plan(const pcp_conv3x3_t *desc, int32_t *variant, double *executed_flops);
+
+/* Measurement query (bench.py's roofline line): which instantiation pcp_conv3x3_winograd launches for `desc` (variant = 1: 32-tile
+ * workgroups k_conv3x3_wino<1>, 2: 64-tile workgroups k_conv3x3_wino<2>) and the flops that launch EXECUTES on the matrix pipe
+ * (16 products per 2x2 output tile and (cin, cout) pair, padding tiles and channels included).  Either output may be NULL. */
+int pcp_conv3x3_winograd_plan(const pcp_conv3x3_t *desc, int32_t *variant, double *executed_flops);
+
 /* Same operation for the wide stride-1 layers (cin >= 256) as Winograd F(4x4,3x3) in three launches through a caller-owned
  * workspace: input transform -> 36 batched fp32-MFMA GEMMs [tiles x cin] x [cin x cout] -> output transform + bias + ReLU.  4x fewer
  * multiplies than the direct form, fp32 arithmetic and accumulation throughout; transform rounding ~2e-5 of the output scale.

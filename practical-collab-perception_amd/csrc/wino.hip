@@ -356,6 +356,12 @@ extern "C" int pcp_debug_read(void *dst, size_t bytes) {
 }
 #endif
 
+// long-K layers: 64-tile workgroups (half the weight traffic per output); short-K layers: 32-tile workgroups, two per CU
+static int wino_variant(const pcp_conv3x3_t *d) {
+  const long long wg64 = (long long)d->batch * ((d->in_w + 15) / 16) * ((d->in_h + 15) / 16) * (d->cout_pad / WBN);
+  return (d->cin >= 256 && wg64 >= 256) ? 2 : 1;
+}
+
 extern "C" int pcp_conv3x3_winograd(const pcp_conv3x3_t *d, const float *in, const float *u_packed, const float *bias, float *out,
                                     void *stream_) {
   if (!d || !in || !u_packed || !bias || !out) return PCP_ERR_ARG;
@@ -364,8 +370,19 @@ extern "C" int pcp_conv3x3_winograd(const pcp_conv3x3_t *d, const float *in, con
   if (d->ld_in % 4 != 0 || (((uintptr_t)in) & 15) || (((uintptr_t)u_packed) & 15)) return PCP_ERR_ARG;
   if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0) return PCP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
-  // long-K layers: 64-tile workgroups (half the weight traffic per output); short-K layers: 32-tile workgroups, two per CU
-  const long long wg64 = (long long)d->batch * ((d->in_w + 15) / 16) * ((d->in_h + 15) / 16) * (d->cout_pad / WBN);
-  if (d->cin >= 256 && wg64 >= 256) return launch_wino<2>(d, in, u_packed, bias, out, st);
+  if (wino_variant(d) == 2) return launch_wino<2>(d, in, u_packed, bias, out, st);
   return launch_wino<1>(d, in, u_packed, bias, out, st);
+}
+
+extern "C" int pcp_conv3x3_winograd_plan(const pcp_conv3x3_t *d, int32_t *variant, double *executed_flops) {
+  if (!d || d->stride != 1 || d->cin <= 0 || d->cin % WCK != 0 || d->cout_pad % WBN != 0) return PCP_ERR_ARG;
+  const int rt = wino_variant(d);
+  if (variant) *variant = rt;
+  if (executed_flops) {
+    // every workgroup multiplies [32 * rt tiles x cin] x [cin x 64] at each of the 16 Winograd positions (padding tiles included)
+    const long long tiles_y = (d->in_h + 8 * rt - 1) / (8 * rt), tiles_x = (d->in_w + 15) / 16;
+    const double wgs = (double)d->batch * tiles_x * tiles_y * (d->cout_pad / WBN);
+    *executed_flops = wgs * 2.0 * 16.0 * (32.0 * rt) * d->cin * WBN;
+  }
+  return PCP_OK;
 }

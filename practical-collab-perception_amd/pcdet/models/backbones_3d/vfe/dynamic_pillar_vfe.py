@@ -107,6 +107,11 @@ class DynamicPillarVFE(VFETemplate):
         n_eff = batch_dict.get('_pcp_valid_points_hint', points.shape[0])
         if (self.sparse_first_layer and not self.materialize_pillars and self.num_filters[-1] == 64
                 and n_eff <= SPARSE_MAX_FILL * batch_size * nx * ny):
+            if self.reuse_buffers and self._prev_vox is not None and self._canvas is not None:
+                # a dense frame came before this sparse one: its pillars are still on the persistent canvas and its pillar list lives in the
+                # workspace pcp_voxelize is about to overwrite -- clear now, or the next dense frame would inherit them
+                ops.canvas_clear(self._prev_vox, self._canvas)
+            self._prev_vox = None
             vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=self._workspace if self.reuse_buffers else None)
             rows = max(points.shape[0], 1)
             if self._pf_buf is None or self._pf_buf.shape[0] < rows or self._pf_buf.device != dev or not self.reuse_buffers:

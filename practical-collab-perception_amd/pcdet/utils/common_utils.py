@@ -87,12 +87,9 @@ def merge_results_dist(result_part, size, tmpdir=None):
     dist.all_gather_object(parts, result_part)
     if rank != 0:
         return None
-    ordered = []
-    for res in zip(*parts):
-        ordered.extend(list(res))
-    longest = max(len(p) for p in parts)
-    for p in parts:                     # ragged tail (zip stops at the shortest)
-        ordered.extend(p[min(len(q) for q in parts):longest] if len(p) > min(len(q) for q in parts) else [])
+    # rank-interleaved = dataset order when frames are dealt round-robin (DistributedSampler pads every rank to equal length and the
+    # [:size] cut drops its repeats; an unpadded dealing leaves the last ranks one item short, which the index guard covers)
+    ordered = [p[i] for i in range(max(len(p) for p in parts)) for p in parts if i < len(p)]
     return ordered[:size]
 
 

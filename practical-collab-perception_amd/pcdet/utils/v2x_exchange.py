@@ -56,14 +56,16 @@ def gather_maps_to(local_map, dst, group=None):
     world, rank = _world(group)
     if world == 1:
         return [local_map]
+    # `dst` and the loop index are ranks INSIDE `group`; torch.distributed's point-to-point calls take GLOBAL ranks
+    glob = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank == dst:
         out = [torch.empty_like(local_map) for _ in range(world)]
         out[rank] = local_map
-        reqs = [dist.irecv(out[r], src=r, group=group) for r in range(world) if r != dst]
+        reqs = [dist.irecv(out[r], src=glob(r), group=group) for r in range(world) if r != dst]
         for q in reqs:
             q.wait()
         return out
-    dist.send(local_map.contiguous(), dst=dst, group=group)
+    dist.send(local_map.contiguous(), dst=glob(dst), group=group)
     return None
 
 

@@ -79,6 +79,10 @@ SYMBOLS = {
     'pcp_conv3x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
     'pcp_sparse_conv3x3_s2': (c_i32, [vp, ctypes.POINTER(Grid), vp, c_i64, vp, vp, c_i32, c_i32, vp, c_i32, vp]),
     'pcp_conv3x3_winograd': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_conv3x3_winograd_plan': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
+    'pcp_conv3x3_winograd_ws_supported': (c_i32, [ctypes.POINTER(Conv3x3)]),
+    'pcp_conv3x3_winograd_ws': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_conv3x3_winograd_ws_plan': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
     'pcp_conv3x3_winograd4_workspace_bytes': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(c_sz)]),
     'pcp_conv3x3_winograd4': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp, vp]),
     'pcp_conv3x3_winograd4_timed': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float),

@@ -80,6 +80,31 @@ def pack_conv3x3_winograd(w, bias):
     return packed, pad_bias(bias, cout_pad), cout_pad
 
 
+def pack_conv3x3_winograd_ws(w, bias):
+    """w: [cout, cin, 3, 3] (BN-folded) -> U = G g G^T in float64, rounded once, in the fragment order of csrc/wino_ws.hip:
+    [cin/2 (channel pair)][cout_pad/32 (block)][2 (position half: rows {0,1} | {2,3})][2 (row of the half)][64 lanes = (channel parity h,
+    cout r)][4 (position column)] -- a wave's B operand of one channel pair is two contiguous 1-KiB runs."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % 2 == 0
+    cout_pad = round_up(cout, 64)
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum('ia,ncab,jb->ncij', G, w.double(), G).float()              # [cout, cin, 4 (i), 4 (j)]
+    up = u.new_zeros((cout_pad, cin, 4, 4))
+    up[:cout] = u
+    x = up.view(cout_pad // 32, 32, cin // 2, 2, 2, 2, 4)                        # (blk, r, kp, h, ph, row, j)
+    x = x.permute(2, 0, 4, 5, 3, 1, 6)                                           # (kp, blk, ph, row, h, r, j)
+    packed = x.new_zeros((cin // 2 + 2,) + tuple(x.shape[1:]))                   # two zero channel pairs: the kernel's B prefetch overruns
+    packed[:cin // 2] = x
+    return packed.contiguous(), pad_bias(bias, cout_pad), cout_pad
+
+
+def unpack_winograd_ws(packed, cout):
+    """inverse of pack_conv3x3_winograd_ws -> U [cout, cin, 4, 4] (CPU layout check)"""
+    nkp, nblk = packed.shape[0] - 2, packed.shape[1]
+    u = packed[:nkp].permute(1, 5, 0, 4, 2, 3, 6).reshape(nblk * 32, nkp * 2, 4, 4)     # (blk, r, kp, h, ph, row, j)
+    return u[:cout]
+
+
 _WINO4_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
 WINO4_CK = 32          # K slice of the batched GEMM
 WINO4_BN = 128         # its N tile

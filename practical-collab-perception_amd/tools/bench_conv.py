@@ -50,8 +50,18 @@ def main():
         td = timeit(lambda: ops.conv3x3(x, pd, bd, cin, cout, cpd, out=out))
         tw = timeit(lambda: ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=out))
         t3 = timeit(lambda: ops.conv3x3_bf16x3(x, p3, b3, cin, cout, cp3, out=out))
+        tws = None
+        if cin % 32 == 0:
+            pws, bws, cpws = pack.pack_conv3x3_winograd_ws(w, b)
+            pws, bws = pws.to(d), bws.to(d)
+            ref = torch.empty_like(out)
+            ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=ref)
+            tws = timeit(lambda: ops.conv3x3_winograd_ws(x, pws, bws, cin, cout, cpws, out=out))
+            errws = float((out - ref).abs().max() / ref.abs().max())
         line = ('%-36s direct %8.1f us %6.1f TF | winograd %8.1f us %6.1f TF (algorithmic) | x%.2f | bf16x3 (opt-in) %8.1f us %6.1f TF' %
                 (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw, t3 * 1e6, flops / t3 / 1e12))
+        if tws is not None:
+            line += ' | WS %8.1f us %6.1f TF (x%.2f vs winograd, diff %.1e)' % (tws * 1e6, flops / tws / 1e12, tw / tws, errws)
         if cin % pack.WINO4_CK == 0 and cout % 4 == 0 and cin >= 128:
             ref = out.clone()                                    # bf16x3 result ran last; recompute the fp32 Winograd result as the yardstick
             ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=ref)

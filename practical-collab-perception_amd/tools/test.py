@@ -48,8 +48,9 @@ def parse_config():
 def main():
     args, cfg = parse_config()
     dist_test = args.launcher != 'none'
-    if dist_test:
-        common_utils.init_dist_pytorch(args.tcp_port, int(os.environ.get('LOCAL_RANK', args.local_rank)), backend='nccl')
+    if dist_test:                                           # the rank gates logging and the merged-result report (reference :148 drops it: Q3)
+        _, cfg.LOCAL_RANK = getattr(common_utils, 'init_dist_%s' % args.launcher)(
+            args.tcp_port, int(os.environ.get('LOCAL_RANK', args.local_rank)), backend=os.environ.get('PCP_DIST_BACKEND', 'nccl'))
     if args.batch_size is None:
         args.batch_size = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU
     logger = common_utils.create_logger(None, rank=cfg.LOCAL_RANK)

@@ -7,6 +7,11 @@ Config 5 (DiscoNet) is the configuration with training kernels (SURVEY appendix 
 `torchrun --nproc-per-node N train.py --launcher pytorch ...` -- one process per GPU, frames sharded by DistributedSampler, ONE
 RCCL all-reduce of the flat fp32 gradient buffer per iteration inside optimizer.step() (no DistributedDataParallel wrapper: the
 backward pass is hand written, there are no autograd hooks to bucket on).  Without V2X-Sim on disk the loader is the synthetic one.
+
+Checkpoints: output/<cfg group>/<cfg name>/<extra_tag>/ckpt/checkpoint_epoch_N.pth, written by rank 0 only (temp file + rename).
+`model_state` is interchangeable with the reference (same keys / shapes).  `optimizer_state` is this build's flat-buffer Adam state; a
+reference checkpoint's torch-Adam state is mapped into it by parameter order when every shape matches, otherwise skipped with a warning;
+the reference cannot read this build's optimizer state (its OptimWrapper expects torch.optim.Adam's dict).
 """
 import argparse
 import os
@@ -46,26 +51,41 @@ def parse_config():
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem
+    cfg.EXP_GROUP_PATH = '/'.join(args.cfg_file.split('/')[1:-1])      # reference tools/train.py:61: drop 'cfgs' and the file name
     if args.set_cfgs is not None:
         cfg_from_list(args.set_cfgs, cfg)
     return args, cfg
 
 
+def init_distributed(args, cfg):
+    """reference tools/train.py:69-78: `total_gpus, cfg.LOCAL_RANK = init_dist_<launcher>(tcp_port, local_rank, backend)` -- the rank every
+    later rank-0-only action (logging, checkpoint save / prune) is gated on.  PCP_DIST_BACKEND=gloo is for the CPU tests."""
+    if args.launcher == 'none':
+        return False, 1
+    init = getattr(common_utils, 'init_dist_%s' % args.launcher)
+    local_rank = int(os.environ.get('LOCAL_RANK', args.local_rank))
+    total_gpus, cfg.LOCAL_RANK = init(args.tcp_port, local_rank, backend=os.environ.get('PCP_DIST_BACKEND', 'nccl'))
+    return True, total_gpus
+
+
 def main():
     args, cfg = parse_config()
-    dist_train = args.launcher != 'none'
-    if dist_train:
-        common_utils.init_dist_pytorch(args.tcp_port, int(os.environ.get('LOCAL_RANK', args.local_rank)), backend='nccl')
+    dist_train, total_gpus = init_distributed(args, cfg)
     if args.batch_size is None:
         args.batch_size = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU
+    else:
+        assert args.batch_size % total_gpus == 0, 'Batch size should match the number of gpus'
+        args.batch_size = args.batch_size // total_gpus
     args.epochs = cfg.OPTIMIZATION.NUM_EPOCHS if args.epochs is None else args.epochs
-    logger = common_utils.create_logger(None, rank=cfg.LOCAL_RANK)
-    log_config_to_file(cfg, logger=logger)
-    out_dir = Path(args.output_dir) if args.output_dir else None
-    ckpt_dir = None
-    if out_dir is not None:
-        ckpt_dir = out_dir / 'ckpt'
+    # reference tools/train.py:93-96: output/<cfg group>/<cfg name>/<extra_tag>/ckpt is ALWAYS written (--output_dir overrides the root)
+    out_dir = Path(args.output_dir) if args.output_dir else cfg.ROOT_DIR / 'output' / cfg.EXP_GROUP_PATH / cfg.TAG / args.extra_tag
+    ckpt_dir = out_dir / 'ckpt'
+    if cfg.LOCAL_RANK == 0:
         ckpt_dir.mkdir(parents=True, exist_ok=True)
+    logger = common_utils.create_logger(None, rank=cfg.LOCAL_RANK)
+    if dist_train:
+        logger.info('total_batch_size: %d' % (total_gpus * args.batch_size))
+    log_config_to_file(cfg, logger=logger)
     train_set, train_loader, train_sampler = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, args.batch_size, dist_train,
                                                               workers=args.workers, logger=logger, training=True, total_epochs=args.epochs)
     for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
@@ -83,11 +103,18 @@ def main():
     model.cuda()
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     if args.ckpt is not None:
-        disk = torch.load(args.ckpt, map_location='cpu', weights_only=False)
-        model.load_state_dict(disk['model_state'])
-        if disk.get('optimizer_state') is not None:
-            optimizer.load_state_dict(disk['optimizer_state'])
-        start_epoch, it = int(disk.get('epoch', 0)), int(disk.get('it', 0))
+        it, start_epoch = model.load_params_with_optimizer(args.ckpt, to_cpu=True, optimizer=optimizer, logger=logger)
+    else:                                                   # resume from the newest loadable checkpoint (reference tools/train.py:143-156)
+        import glob
+        ckpt_list = sorted(glob.glob(str(ckpt_dir / '*.pth')), key=os.path.getmtime)
+        while ckpt_list:
+            try:
+                it, start_epoch = model.load_params_with_optimizer(ckpt_list[-1], to_cpu=True, optimizer=optimizer, logger=logger)
+                break
+            except Exception as e:                          # noqa: BLE001 -- a torn file from a killed run: try the one before
+                logger.info('could not resume from %s (%s)' % (ckpt_list[-1], e))
+                ckpt_list = ckpt_list[:-1]
+    it, start_epoch = int(it), max(int(start_epoch), 0)
     lr_scheduler, lr_warmup = build_scheduler(optimizer, total_iters_each_epoch=len(train_loader), total_epochs=args.epochs,
                                               last_epoch=start_epoch - 1, optim_cfg=cfg.OPTIMIZATION)
     logger.info('**********************Start training %s (%d trainable tensors, %.2f M parameters)**********************'

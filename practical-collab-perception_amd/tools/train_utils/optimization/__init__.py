@@ -63,6 +63,7 @@ class FlatAdamOneCycle:
         self.process_group = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and
                                                                           torch.distributed.is_initialized()) else 1
+        self.ref_order = reference_param_order(model, self.params)
 
     def zero_grad(self):
         off = 0
@@ -95,10 +96,65 @@ class FlatAdamOneCycle:
         return {'t': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr, 'mom': self.mom}
 
     def load_state_dict(self, sd):
+        if 'state' in sd and 'param_groups' in sd:              # a reference checkpoint: torch.optim.Adam's dict under fastai's OptimWrapper
+            return self._load_reference_state(sd)
         self.t = int(sd['t'])
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         self.lr, self.mom = float(sd['lr']), float(sd['mom'])
+        return True
+
+    def _load_reference_state(self, sd):
+        """maps the reference optimizer's per-parameter moments into the flat buffers.  Its parameter numbering (fastai_optim.py:16-27,
+        104-122): leaf modules in registration order, non-BatchNorm leaves first, BatchNorm leaves second, trainable tensors only.  Any
+        count or shape mismatch leaves the moments at zero and says so (the model weights are unaffected)."""
+        import logging
+        log = logging.getLogger(__name__)
+        ids = [i for g in sd['param_groups'] for i in g['params']]
+        order = self.ref_order
+        ok = len(ids) == len(order)
+        if ok:
+            for k, pi in zip(ids, order):
+                st = sd['state'].get(k)
+                if st is not None and tuple(st['exp_avg'].shape) != tuple(self.params[pi].shape):
+                    ok = False
+                    break
+        if not ok:
+            log.warning('optimizer_state of this checkpoint does not line up with the model (reference torch-Adam format, %d tensors vs %d): '
+                        'moments start from zero', len(ids), len(order))
+            return False
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        t = 0
+        for k, pi in zip(ids, order):
+            st = sd['state'].get(k)
+            if st is None:
+                continue
+            n = self.params[pi].numel()
+            self.exp_avg[offs[pi]:offs[pi] + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[offs[pi]:offs[pi] + n].copy_(st['exp_avg_sq'].reshape(-1))
+            t = max(t, int(st['step'].item() if torch.is_tensor(st['step']) else st['step']))
+        self.t = t
+        return True
+
+
+def reference_param_order(model, params):
+    """indices into `params` in the order the reference's optimizer numbers its tensors (see _load_reference_state)"""
+    def leaves(m):
+        ch = list(m.children())
+        return sum((leaves(c) for c in ch), []) if ch else [m]
+    bn = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)
+    index = {id(p): i for i, p in enumerate(params)}
+    groups = ([], [])
+    for leaf in leaves(model):
+        for p in leaf.parameters():
+            if id(p) in index:
+                groups[1 if isinstance(leaf, bn) else 0].append(index[id(p)])
+    return groups[0] + groups[1]
 
 
 def tops_zero(t):

@@ -62,7 +62,19 @@ def checkpoint_state(model=None, optimizer=None, epoch=None, it=None):
 
 
 def save_checkpoint(state, filename='checkpoint'):
-    torch.save(state, '%s.pth' % filename)
+    """write to a temporary name, then rename: a reader (resume, repeat_eval) never sees a half-written file"""
+    final = '%s.pth' % filename
+    tmp = '%s.tmp.%d' % (final, os.getpid())
+    torch.save(state, tmp)
+    os.replace(tmp, final)
+
+
+def _is_main_process(rank):
+    """the caller's rank argument AND the process group's own rank must both say 0 (a caller that forgot to set cfg.LOCAL_RANK would
+    otherwise make every rank prune and write the same files at once)"""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return rank == 0 and torch.distributed.get_rank() == 0
+    return rank == 0
 
 
 def train_model(model, optimizer, train_loader, model_func, lr_scheduler, optim_cfg, start_epoch, total_epochs, start_iter, rank,
@@ -77,10 +89,14 @@ def train_model(model, optimizer, train_loader, model_func, lr_scheduler, optim_
                                            accumulated_iter=accumulated_iter, optim_cfg=optim_cfg, rank=rank, tb_log=tb_log,
                                            total_it_each_epoch=total_it_each_epoch, logger=logger)
         trained_epoch = cur_epoch + 1
-        if trained_epoch % ckpt_save_interval == 0 and rank == 0 and ckpt_save_dir is not None:
+        if trained_epoch % ckpt_save_interval == 0 and ckpt_save_dir is not None and _is_main_process(rank):
+            os.makedirs(str(ckpt_save_dir), exist_ok=True)
             ckpts = sorted(glob.glob(os.path.join(str(ckpt_save_dir), 'checkpoint_epoch_*.pth')), key=os.path.getmtime)
             for old in ckpts[:max(0, len(ckpts) - max_ckpt_save_num + 1)]:
-                os.remove(old)
+                try:
+                    os.remove(old)
+                except FileNotFoundError:
+                    pass
             save_checkpoint(checkpoint_state(model, optimizer, trained_epoch, accumulated_iter),
                             filename=os.path.join(str(ckpt_save_dir), 'checkpoint_epoch_%d' % trained_epoch))
     return accumulated_iter

@@ -144,3 +144,156 @@ def test_flat_gradient_allreduce_gives_identical_replicas():
     assert out[0][1] == 0.5 and out[1][1] == 0.5
     assert out[0][0] < 1e-7 and out[1][0] < 1e-7
     assert out[0][2] == out[1][2]
+
+
+# ---- bench.py --gpus N: the launcher itself ------------------------------------------------------------------------------
+
+def _bench(args, env_extra, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` outside any launcher must start two ranks (the flag was parsed and ignored).  Dry-run mode
+    keeps the launcher / rendezvous / barrier / max-over-ranks aggregation and swaps the kernels for a sleep (gloo, no GPU)."""
+    r, line = _bench(['--gpus', '2', '--steps', '3', '--warmup', '1'], {'PCP_BENCH_DRY_RUN': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['ranks_seen_by_collective'] == 2
+    assert line['steps'] == 3 and line['warmup'] == 1 and 'DRY RUN' in line['data']
+    # rank 1 sleeps twice as long per step: the reported time is the MAX over ranks (>= 3 x 4 ms)
+    assert line['ms_per_step'] >= 3.9
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r, line = _bench(['--gpus', '4', '--steps', '1', '--warmup', '0'],
+                     {'PCP_BENCH_DRY_RUN': '1', 'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and line is None and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_bench_under_an_external_launcher_uses_its_world():
+    """the driver's own form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2"""
+    import json
+    import subprocess
+    env = dict(os.environ, PCP_BENCH_DRY_RUN='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                         # rank 0 only
+    assert json.loads(lines[0])['n_gpus'] == 2
+
+
+# ---- ADVICE r1: rank-0-only checkpointing, cfg.LOCAL_RANK from the launcher, group-relative ranks -------------------------------
+
+class _StubOpt:
+    lr = 1e-3
+
+    def __init__(self, model):
+        self.opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+
+    def zero_grad(self):
+        self.opt.zero_grad()
+
+    def clip_grad_norm(self, max_norm):
+        pass
+
+    def step(self):
+        self.opt.step()
+
+    def state_dict(self):
+        return {'t': 1}
+
+
+class _StubSched:
+    def step(self, it):
+        pass
+
+
+def _body_train_model_ckpt_plain(rank, world):
+    import argparse
+    sys.path.insert(0, os.path.join(PKG, 'tools'))
+    import train as train_tool
+    from pcdet.config import EasyDict, cfg
+    from train_utils.train_utils import train_model
+    os.environ['LOCAL_RANK'] = str(rank)
+    os.environ['PCP_DIST_BACKEND'] = 'gloo'
+    args = argparse.Namespace(launcher='pytorch', tcp_port=int(os.environ['MASTER_PORT']), local_rank=0)
+    dist_train, total = train_tool.init_distributed(args, cfg)
+    assert dist_train and total == world and cfg.LOCAL_RANK == rank
+    ckpt_dir = os.environ['PCP_TEST_CKPT_DIR']
+    model = torch.nn.Linear(4, 2)
+    loader = [torch.ones(3, 4) for _ in range(2)]
+
+    def model_func(m, batch):
+        loss = m(batch).sum()
+        return loss, {'loss_total': float(loss)}, {}
+    train_model(model, _StubOpt(model), loader, model_func, _StubSched(), EasyDict(GRAD_NORM_CLIP=10), start_epoch=0, total_epochs=4,
+                start_iter=0, rank=cfg.LOCAL_RANK, tb_log=None, ckpt_save_dir=ckpt_dir, max_ckpt_save_num=2)
+    dist.barrier()
+    cfg.LOCAL_RANK = 0
+    return sorted(os.listdir(ckpt_dir))
+
+
+def test_train_model_saves_checkpoints_on_rank_0_only(tmp_path):
+    os.environ['PCP_TEST_CKPT_DIR'] = str(tmp_path / 'ckpt')
+    try:
+        out = _run('_body_train_model_ckpt_plain')
+    finally:
+        os.environ.pop('PCP_TEST_CKPT_DIR')
+    # 4 epochs, keep 2: the two newest files, complete (loadable), no temp leftovers
+    assert out[0] == out[1] == ['checkpoint_epoch_3.pth', 'checkpoint_epoch_4.pth']
+    ck = torch.load(str(tmp_path / 'ckpt' / 'checkpoint_epoch_4.pth'), weights_only=False)
+    assert ck['epoch'] == 4 and ck['it'] == 8 and set(ck['model_state']) == {'weight', 'bias'}
+
+
+def test_save_is_skipped_when_a_caller_passes_rank_0_on_every_rank(tmp_path):
+    """the round-1 bug shape: rank argument 0 everywhere.  The process group's own rank gates the write as well."""
+    os.environ['PCP_TEST_CKPT_DIR'] = str(tmp_path / 'ckpt')
+    try:
+        out = _run('_body_rank_arg_zero')
+    finally:
+        os.environ.pop('PCP_TEST_CKPT_DIR')
+    assert out == [True, False]
+
+
+def _body_rank_arg_zero(rank, world):
+    sys.path.insert(0, os.path.join(PKG, 'tools'))
+    from train_utils.train_utils import _is_main_process
+    return _is_main_process(0)
+
+
+def _body_subgroup_gather(rank, world):
+    from pcdet.utils import v2x_exchange as ex
+    sub = dist.new_group([1, 2])                                  # group rank 0 = global rank 1
+    if rank == 0:
+        return None
+    m = torch.full((2, 2), float(rank))
+    got = ex.gather_maps_to(m, dst=0, group=sub)                  # dst is a rank INSIDE the group
+    return None if got is None else [float(g[0, 0]) for g in got]
+
+
+def test_gather_maps_to_translates_group_ranks():
+    out = _run('_body_subgroup_gather', world=3)
+    assert out[0] is None and out[1] == [1.0, 2.0] and out[2] is None
+
+
+def test_reference_optimizer_parameter_order():
+    """fastai's OptimWrapper numbers tensors leaf module by leaf module, non-BatchNorm leaves first (fastai_optim.py:16-27,104-122)"""
+    sys.path.insert(0, os.path.join(PKG, 'tools'))
+    from train_utils.optimization import reference_param_order
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 1), torch.nn.BatchNorm2d(3), torch.nn.Sequential(torch.nn.Linear(3, 1), torch.nn.BatchNorm1d(1)))
+    net[2][0].bias.requires_grad_(False)
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    order = reference_param_order(net, params)
+    assert [names[i] for i in order] == ['0.weight', '0.bias', '2.0.weight', '1.weight', '1.bias', '2.1.weight', '2.1.bias']

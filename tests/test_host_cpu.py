@@ -213,3 +213,24 @@ def test_training_dataset_and_onecycle_schedule():
     for it in range(2):
         sched.step(it)
         assert abs(Opt.lr - float(g['it%d_lr' % it])) < 1e-15 and abs(Opt.mom - float(g['it%d_mom' % it])) < 1e-15
+
+
+def test_winograd_ws_packing_holds_the_same_transformed_weights():
+    """pack_conv3x3_winograd_ws is a re-ordering of the same U = G g G^T the fused kernel's packing holds (layout check on the CPU; the
+    packed form evaluated in plain torch reproduces conv2d)"""
+    import torch
+    import torch.nn.functional as F
+    from pcp_amd import pack
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((100, 64, 3, 3), generator=g) * 0.05
+    b = torch.randn((100,), generator=g)
+    pws, bws, cpad = pack.pack_conv3x3_winograd_ws(w, b)
+    assert tuple(pws.shape) == (64 // 2 + 2, cpad // 32, 2, 2, 2, 32, 4) and cpad == 128
+    assert float(pws[-2:].abs().max()) == 0.0                                     # the prefetch overrun pad
+    u = pack.unpack_winograd_ws(pws, 100)                                         # [cout, cin, 4, 4]
+    pold, _, cpo = pack.pack_conv3x3_winograd(w, b)
+    u_old = pold.permute(2, 0, 3, 1).reshape(cpo, 64, 4, 4)[:100]
+    assert torch.equal(u, u_old)
+    x = torch.randn((1, 64, 8, 8), generator=g)
+    got = pack.winograd_reference(x, pold, bws, 100)
+    assert float((got - F.conv2d(x, w, b, padding=1)).abs().max()) < 1e-4
