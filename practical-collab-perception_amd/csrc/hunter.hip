@@ -250,14 +250,17 @@ __global__ void k_select_transform(const float *__restrict__ points, long long n
   const float *T = pt.m[b];
   float x = row[1], y = row[2], z = row[3];
   o[0] = row[0] + batch_offset;
-  o[1] = x * T[0] + y * T[1] + z * T[2] + T[3];
-  o[2] = x * T[4] + y * T[5] + z * T[6] + T[7];
-  o[3] = x * T[8] + y * T[9] + z * T[10] + T[11];
+  // bev_maker.py:179 `p @ R^T + t` on the reference's CPU path (torch -> BLAS sgemm, K = 3) is, bit for bit, the FMA chain
+  // fma(z, r2, fma(y, r1, x * r0)) followed by a separately rounded + t (pinned on 60 k-row clouds: tests/golden/g2_disco_full.npz
+  // holds the SHA-256 of the transformed rows).  Spelled with explicit roundings so no contraction setting can reorder it.
+  o[1] = __fadd_rn(__fmaf_rn(z, T[2], __fmaf_rn(y, T[1], __fmul_rn(x, T[0]))), T[3]);
+  o[2] = __fadd_rn(__fmaf_rn(z, T[6], __fmaf_rn(y, T[5], __fmul_rn(x, T[4]))), T[7]);
+  o[3] = __fadd_rn(__fmaf_rn(z, T[10], __fmaf_rn(y, T[9], __fmul_rn(x, T[8]))), T[11]);
 }
 
 
-// ---- a13: which agent ids occur in a column (bev_maker.py:156 torch.unique(points[:, -1])): 64-bit presence mask of the integer
-//      values 0..63; out[1] counts rows whose value is not such an integer (the caller then falls back to a sort) ----------------
+// ---- a13: which agent ids occur in a column (bev_maker.py:156 torch.unique(points[:, -1])): 64-bit presence mask of the ids
+//      0..63 (values truncated like .long()); out[1] counts rows outside that range (the caller raises: there is no fallback) ----------------
 __global__ __launch_bounds__(256) void k_column_id_mask(const float *__restrict__ points, long long n, int stride, int col,
                                                         unsigned long long *__restrict__ out) {
   __shared__ unsigned long long s_mask, s_bad;
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(256) void k_column_id_mask(const float *__restrict_
   unsigned long long m = 0ULL, bad = 0ULL;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float v = points[i * stride + col];
-    const int iv = (int)v;
-    if (v >= 0.f && v < 64.f && (float)iv == v) m |= 1ULL << iv; else bad++;
+    const int iv = (int)v;                                  // truncation toward zero = the reference's points[:, -1].long()
+    if (v > -1.f && v < 64.f) m |= 1ULL << iv; else bad++;
   }
   if (m) atomicOr(&s_mask, m);
   if (bad) atomicAdd(&s_bad, bad);

@@ -14,11 +14,13 @@
 //     pair, prefetched two channel pairs ahead (the host packs it in exactly that fragment order);
 //   * the raw input patch is staged global -> registers -> LDS in chunks of CHUNK channels, double buffered: ONE workgroup barrier per
 //     CHUNK / 2 channel pairs (= 8 or 16 K steps of 8 MFMAs per wave) instead of one per 8 channels;
-//   * 8 waves per workgroup, 2 per SIMD (256-VGPR budget): the partner's MFMAs fill the matrix pipe while a wave reads and transforms;
+//   * 4 waves per workgroup (one per SIMD), TWO workgroups per CU (256-VGPR budget, 62 KB of LDS each): the two waves of a SIMD belong
+//     to different workgroups, so one workgroup's prologue (patch fetch) and epilogue (transform, exchange, stores) run under the
+//     other's MFMAs -- measured: with one 8-wave workgroup per CU those serial phases were 10 % (K = 128) to 30 % (K = 64) of the kernel;
 //   * epilogue in registers: each wave applies A^T (.) A to its position half (linear, so the halves just add), exchanges ONE 2x2-tile
 //     row with its partner through LDS, adds bias, ReLU, and stores 128-byte rows.
 //
-// Workgroup = TG tile groups x CB = 4 / TG cout blocks of 32 (TG = 1: 8 x 16 pixels x 128 channels; TG = 2: 16 x 16 pixels x 64 channels).
+// Workgroup = 32 tiles (8 x 16 output pixels) x 64 output channels = {2 cout blocks of 32} x {2 position halves}.
 #include "pcp_common.h"
 
 namespace {
@@ -26,7 +28,7 @@ namespace {
 constexpr int RP = 24;            // row pitch of a channel plane in floats: 2 * RP * ty mod 64 = {0, 48, 32, 16} -> the 32 tiles of a
                                   // ds_read_b64 lane group hit 64 distinct banks
 constexpr int RAW_W = 18;
-constexpr int WS_THREADS = 512;
+constexpr int WS_THREADS = 256;
 
 struct WsParams {
   const float *in;
@@ -45,11 +47,11 @@ __device__ __forceinline__ int xcd_remap_ws(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int TG, int CHUNK>
+template <int CHUNK>
 struct WsCfg {
-  static constexpr int CB = 4 / TG;
+  static constexpr int CB = 2;                      // 32-channel output blocks per workgroup
   static constexpr int WBN = 32 * CB;
-  static constexpr int OUT_H = 8 * TG;
+  static constexpr int OUT_H = 8;
   static constexpr int RAW_H = OUT_H + 2;
   static constexpr int RAW_PIX = RAW_H * RAW_W;
   static constexpr int PLANE = RAW_H * RP + 2;      // +2: consecutive channel quads of one pixel land 8 banks apart when staged
@@ -58,22 +60,21 @@ struct WsCfg {
   static constexpr int ITEMS = RAW_PIX * Q;         // float4 items per stage
   static constexpr int PER = (ITEMS + WS_THREADS - 1) / WS_THREADS;
   static constexpr int KP = CHUNK / 2;              // channel pairs (MFMA K steps) per stage
-  static constexpr int XCH = 4 * 2 * 32 * 64;       // epilogue exchange: 4 wave pairs x 2 writers x 32 values x 64 lanes
+  static constexpr int XCH = 2 * 2 * 32 * 64;       // epilogue exchange: 2 wave pairs x 2 writers x 32 values x 64 lanes
   static constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
 };
 
-template <int TG, int CHUNK>
+template <int CHUNK>
 __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
-  using C = WsCfg<TG, CHUNK>;
+  using C = WsCfg<CHUNK>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int ph = wave >> 2;                     // position half: Winograd position rows {0,1} or {2,3}
-  const int tg = (wave & 3) / C::CB;            // tile group (8 output rows each)
-  const int cb = (wave & 3) % C::CB;            // 32-channel output block inside the workgroup's N tile
+  const int ph = wave >> 1;                     // position half: Winograd position rows {0,1} or {2,3}
+  const int cb = wave & 1;                      // 32-channel output block inside the workgroup's 64-channel N tile
 
   const int lid = xcd_remap_ws(blockIdx.x, gridDim.x);
   const int nt = lid / p.n_spatial;             // N tile is the slow index (its weights stay in the XCD's L2)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
   //      half 1 needs V rows 2, 3 = (d2 - d1, d1 - d3) B: with (P, Q, S) = raw rows (0, 2, 1) resp. (2, 1, 3) both are
   //      (P - Q, Q + sgn * S), sgn = +1 / -1 -- one instruction stream for both halves. ------------------------------------------------
   const int ty = r >> 3, tx = r & 7;
-  const int row0 = tg * 8 + 2 * ty;
+  const int row0 = 2 * ty;
   const int lane_base = h * C::PLANE + 2 * tx;
   const int offP = lane_base + (row0 + (ph ? 2 : 0)) * RP;
   const int offQ = lane_base + (row0 + (ph ? 1 : 2)) * RP;
@@ -143,6 +144,10 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
   auto raw_read = [&](const float *buf, int kp) {
     const float *src = buf + 2 * kp * C::PLANE;
     Raw d;
+#ifdef WS_DIAG_NO_LDSREAD
+    d.p0 = d.p1 = d.q0 = d.q1 = d.s0 = d.s1 = float2{sgn * (float)kp, (float)lane};   // timing-only build: no LDS reads in the loop
+    return d;
+#endif
     d.p0 = *reinterpret_cast<const float2 *>(src + offP);
     d.p1 = *reinterpret_cast<const float2 *>(src + offP + 2);
     d.q0 = *reinterpret_cast<const float2 *>(src + offQ);
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
     return d;
   };
   auto transform = [&](const Raw &d, float (&a)[8]) {
+#ifdef WS_DIAG_NO_XFORM
+    a[0] = d.p0.x; a[1] = d.p0.y; a[2] = d.p1.x; a[3] = d.p1.y; a[4] = d.q0.x; a[5] = d.q0.y; a[6] = d.s0.x; a[7] = d.s1.y;   // timing only
+    return;
+#endif
     const float ta0 = d.p0.x - d.q0.x, ta1 = d.p0.y - d.q0.y, ta2 = d.p1.x - d.q1.x, ta3 = d.p1.y - d.q1.y;
     const float tb0 = fmaf(sgn, d.s0.x, d.q0.x), tb1 = fmaf(sgn, d.s0.y, d.q0.y), tb2 = fmaf(sgn, d.s1.x, d.q1.x),
                 tb3 = fmaf(sgn, d.s1.y, d.q1.y);
@@ -172,6 +181,9 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
   const unsigned u_lane = (unsigned)lane * 16u;
   f32x4 bq[4][2];
   auto b_load = [&](int kpg, f32x4 (&dst)[2]) {
+#ifdef WS_DIAG_NO_BLOAD
+    if (kpg > 1) return;                                                             // timing-only build: B stays in registers
+#endif
     const char *s = ubase + kpg * u_kp_bytes;                                        // wave-uniform
     dst[0] = *reinterpret_cast<const f32x4 *>(s + u_lane);
     dst[1] = *reinterpret_cast<const f32x4 *>(s + 1024 + u_lane);
@@ -206,7 +218,9 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
       if (kp + 1 < C::KP) dn = raw_read(buf, kp + 1);
       b_load(kp0 + kp + 2, bq[(kp + 2) & 3]);
       // the next stage's raw patch is requested late in this stage so that the in-order vmcnt of the B fragments never waits on it
+#ifndef WS_DIAG_NO_STAGE
       if (kp == C::KP - 3) raw_load(min(s + 1, n_stages - 1));
+#endif
       __builtin_amdgcn_sched_barrier(0);          // every request above stays ahead of this step's MFMAs in program order
       const f32x4 b0 = bq[kp & 3][0], b1 = bq[kp & 3][1];
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b0.x, acc[0], 0, 0, 0);
@@ -233,9 +247,14 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
         for (int i = 0; i < 8; i++) a_cur[i] = a_nxt[i];
       }
     }
+#ifndef WS_DIAG_NO_STAGE
     if (s + 1 < n_stages) raw_store((s + 1) & 1);
     __syncthreads();
+#endif
   }
+#ifdef WS_DIAG_NO_STAGE
+  __syncthreads();
+#endif
 
   // ---- epilogue: Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]], split over the two position halves.
   //      half 0 holds M rows 0, 1:  u0 = M0 + M1, u1 = M1;  half 1 holds M rows 2, 3:  u0 = M2, u1 = -(M2 + M3).
@@ -259,8 +278,8 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
     theirs[0][e] = ph ? y00 : y10;
     theirs[1][e] = ph ? y01 : y11;
   }
-  float *xw = lds + (((wave & 3) * 2 + ph) * 32) * 64 + lane;
-  const float *xr = lds + (((wave & 3) * 2 + (ph ^ 1)) * 32) * 64 + lane;
+  float *xw = lds + ((cb * 2 + ph) * 32) * 64 + lane;
+  const float *xr = lds + ((cb * 2 + (ph ^ 1)) * 32) * 64 + lane;
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     xw[e * 64] = theirs[0][e];
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
     const float bias = p.bias[n];
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-      const int oy = oy0 + tg * 8 + 2 * (e >> 2) + ph;
+      const int oy = oy0 + 2 * (e >> 2) + ph;
       const int ox = ox0 + 2 * ((e & 3) + 4 * h);
       float v0 = mine[0][e] + xr[e * 64] + bias;
       float v1 = mine[1][e] + xr[(16 + e) * 64] + bias;
@@ -289,9 +308,9 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_wino_ws(WsParams p) {
   }
 }
 
-template <int TG, int CHUNK>
+template <int CHUNK>
 int launch_ws(const pcp_conv3x3_t *d, const float *in, const float *u, const float *bias, float *out, hipStream_t st) {
-  using C = WsCfg<TG, CHUNK>;
+  using C = WsCfg<CHUNK>;
   WsParams p;
   p.in = in; p.u = u; p.bias = bias; p.out = out;
   p.batch = d->batch; p.h = d->in_h; p.w = d->in_w;
@@ -302,13 +321,10 @@ int launch_ws(const pcp_conv3x3_t *d, const float *in, const float *u, const flo
   p.n_spatial = d->batch * p.tiles_x * p.tiles_y;
   long long blocks = (long long)p.n_spatial * (d->cout_pad / C::WBN);
   if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
-  hipLaunchKernelGGL((k_wino_ws<TG, CHUNK>), dim3((unsigned)blocks), dim3(WS_THREADS), 0, st, p);
+  hipLaunchKernelGGL((k_wino_ws<CHUNK>), dim3((unsigned)blocks), dim3(WS_THREADS), 0, st, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
-
-// tile-group count: 128-channel N tiles (TG = 1) when the output width allows it, 64-channel N tiles on 16 x 16 pixels otherwise
-int ws_variant(const pcp_conv3x3_t *d) { return (d->cout_pad % 128 == 0) ? 1 : 2; }
 
 }  // namespace
 
@@ -325,19 +341,16 @@ extern "C" int pcp_conv3x3_winograd_ws(const pcp_conv3x3_t *d, const float *in, 
   if (d->stride != 1) return PCP_ERR_UNSUPPORTED;
   if (!pcp_conv3x3_winograd_ws_supported(d)) return PCP_ERR_ARG;
   if ((((uintptr_t)in) & 15) || (((uintptr_t)u_packed) & 15)) return PCP_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream_;
-  if (ws_variant(d) == 1) return launch_ws<1, 32>(d, in, u_packed, bias, out, st);
-  return launch_ws<2, 32>(d, in, u_packed, bias, out, st);
+  return launch_ws<32>(d, in, u_packed, bias, out, (hipStream_t)stream_);
 }
 
 extern "C" int pcp_conv3x3_winograd_ws_plan(const pcp_conv3x3_t *d, int32_t *variant, double *executed_flops) {
   if (!pcp_conv3x3_winograd_ws_supported(d)) return PCP_ERR_ARG;
-  const int tg = ws_variant(d);
-  if (variant) *variant = tg;
+  if (variant) *variant = 1;
   if (executed_flops) {
-    const long long tiles_y = (d->in_h + 8 * tg - 1) / (8 * tg), tiles_x = (d->in_w + 15) / 16;
-    const double wgs = (double)d->batch * tiles_x * tiles_y * (d->cout_pad / (128 / tg));
-    *executed_flops = wgs * 2.0 * 16.0 * (32.0 * tg) * d->cin * (128.0 / tg);
+    // every workgroup multiplies [32 tiles x cin] x [cin x 64] at each of the 16 Winograd positions (padding tiles included)
+    const double wgs = (double)d->batch * ((d->in_w + 15) / 16) * ((d->in_h + 7) / 8) * (d->cout_pad / 64);
+    *executed_flops = wgs * 2.0 * 16.0 * 32.0 * d->cin * 64.0;
   }
   return PCP_OK;
 }

@@ -449,8 +449,9 @@ def hunter_apply_flow(points, head, thresh):
 
 
 def column_ids(points, col):
-    """sorted distinct values of an id column (torch.unique(points[:, col]) of bev_maker.py:156) as a numpy int64 array: one
-    presence-mask launch + one 16-byte read-back when every value is an integer in 0..63, the sort otherwise."""
+    """sorted distinct values of an id column (torch.unique(points[:, col].long()) of bev_maker.py:153-156) as a numpy int64 array: one
+    presence-mask launch + one 16-byte read-back.  Ids must lie in 0..63 (V2X-Sim has six agents); anything else raises -- there is no
+    torch fallback on the product path."""
     import numpy as np
     _need_cuda(points)
     L = _lib.load()
@@ -459,7 +460,7 @@ def column_ids(points, col):
     check(L.pcp_column_id_mask(_p(points), n, stride, col % stride, _p(out), _stream()), 'pcp_column_id_mask')
     mask, bad = [int(v) for v in out.cpu().tolist()]
     if bad:
-        return torch.unique(points[:, col]).cpu().numpy().astype(np.int64)
+        raise _lib.PcpError('column %d holds %d agent ids outside 0..63: the BEV maker supports up to 64 agents' % (col, bad))
     mask &= (1 << 64) - 1
     return np.asarray([i for i in range(64) if (mask >> i) & 1], dtype=np.int64)
 

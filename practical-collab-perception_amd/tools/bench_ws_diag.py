@@ -1,0 +1,60 @@
+"""Interleaved A/B timing of csrc/wino_ws.hip builds in ONE process (cdna_hip_programming.md rule 24): the shipped library and the
+timing-only diagnostic variants under lib/variants (phase-skipping builds: outputs are wrong by construction, only the time matters).
+usage: bench_ws_diag.py [B]"""
+import ctypes
+import glob
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from pcp_amd import lib as plib, pack  # noqa: E402
+
+HERE = Path(__file__).resolve().parent.parent
+
+
+def load(path):
+    L = ctypes.CDLL(str(path))
+    L.pcp_conv3x3_winograd_ws.restype = ctypes.c_int32
+    L.pcp_conv3x3_winograd_ws.argtypes = [ctypes.POINTER(plib.Conv3x3)] + [ctypes.c_void_p] * 5
+    return L
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    d = torch.device('cuda:0')
+    libs = {'shipped': load(HERE / 'lib' / 'libpcp_hip.so')}
+    for p in sorted(glob.glob(str(HERE / 'lib' / 'variants' / 'libpcp_hip_*.so'))):
+        libs[os.path.basename(p)[len('libpcp_hip_'):-3]] = load(p)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (cin, cout, H, W) in [(128, 128, 128, 128), (64, 64, 256, 256), (128, 128, 64, 64)]:
+        x = torch.randn((B, H, W, cin), device=d)
+        w = torch.randn((cout, cin, 3, 3)) * 0.05
+        pw, bw, cp = pack.pack_conv3x3_winograd_ws(w, torch.zeros(cout))
+        pw, bw = pw.to(d), bw.to(d)
+        out = torch.empty((B, H, W, cout), device=d)
+        desc = plib.Conv3x3(B, H, W, cin, cout, cp, 1, cin, cout, 1)
+        flops_exec = 2.0 * 16 * (B * H * W / 4) * cin * cp
+        times = {k: [] for k in libs}
+        for rnd in range(7):
+            for k, L in libs.items():
+                for _ in range(2):
+                    L.pcp_conv3x3_winograd_ws(ctypes.byref(desc), x.data_ptr(), pw.data_ptr(), bw.data_ptr(), out.data_ptr(), st)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    L.pcp_conv3x3_winograd_ws(ctypes.byref(desc), x.data_ptr(), pw.data_ptr(), bw.data_ptr(), out.data_ptr(), st)
+                e1.record()
+                torch.cuda.synchronize()
+                times[k].append(e0.elapsed_time(e1) / 10 * 1e3)
+        print('%d->%d @%dx%d B=%d   (executed %.2f GFLOP)' % (cin, cout, H, W, B, flops_exec / 1e9))
+        for k, v in times.items():
+            v = sorted(v)
+            print('   %-12s median %8.1f us  min %8.1f us   executed %6.1f TFLOP/s (median)' % (k, v[len(v) // 2], v[0], flops_exec / v[len(v) // 2] / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -61,6 +61,78 @@ def mini_points(layout, batch, n_per, seed_shift=0, xy_half=13.1):
     return clouds
 
 
+class PostCapture:
+    """Records, while the reference's CenterHead post-processing runs, what decides the FINAL box set and how close each decision was:
+      * per frame the candidates handed to class_agnostic_nms (boxes, scores in the reference's order),
+      * `near_score`: decoded top-K candidates whose score is within 1e-5 of SCORE_THRESH,
+      * `topk_gap`: score[K-1] - score[K] of the heat map (the K cut; Q7: tie order is implementation defined),
+      * `tie_gap`: smallest gap between consecutive candidate scores,
+      * `near_iou`: candidate index pairs whose rotated BEV IoU (reference iou3d_cpu.cpp) is within 1e-4 of NMS_THRESH.
+    tests/test_gpu_e2e.py demands an EXACT final set (count and one-to-one match at 1e-3) whenever these lists are empty and the gaps
+    are above float noise, and only otherwise falls back to a tolerance sized by the listed cases."""
+
+    def __init__(self, model):
+        self.model = model
+        self.frames = {}
+
+    def __enter__(self):
+        from pcdet.models.model_utils import centernet_utils, model_nms_utils
+        from pcdet.ops.iou3d_nms import iou3d_nms_cuda
+        self._cu, self._mu = centernet_utils, model_nms_utils
+        self._dec, self._nms = centernet_utils.decode_bbox_from_heatmap, model_nms_utils.class_agnostic_nms
+        cap = self
+        cap._next = 0
+
+        def decode(heatmap, *a, **kw):
+            K, thr = kw['K'], kw['score_thresh']
+            B = heatmap.shape[0]
+            cap._base = cap._next
+            for k in range(B):
+                flat = heatmap[k].reshape(-1)
+                top = torch.topk(flat, min(K + 1, flat.numel()))[0]
+                f = cap.frames.setdefault(cap._base + k, {})
+                f['topk_gap'] = float(top[K - 1] - top[K]) if flat.numel() > K else float('inf')
+                sc = top[:K]
+                f['near_score'] = sc[(sc - thr).abs() < 1e-5].numpy() if thr is not None else np.zeros(0, np.float32)
+                f['score_thresh'] = float(thr) if thr is not None else -1.0
+            cap._k = 0
+            return cap._dec(heatmap, *a, **kw)
+
+        def nms(box_scores, box_preds, nms_config, score_thresh=None):
+            f = cap.frames.setdefault(cap._base + cap._k, {})
+            cap._k += 1
+            cap._next = max(cap._next, cap._base + cap._k)
+            n = box_scores.shape[0]
+            f['nms_scores'] = box_scores.numpy().copy()
+            f['nms_boxes'] = box_preds.numpy().copy()
+            f['nms_thresh'] = float(nms_config.NMS_THRESH)
+            if n > 1:
+                srt = torch.sort(box_scores, descending=True)[0]
+                f['tie_gap'] = float((srt[:-1] - srt[1:]).min())
+                iou = torch.zeros(n, n)
+                iou3d_nms_cuda.boxes_iou_bev_cpu(box_preds[:, :7].contiguous(), box_preds[:, :7].contiguous(), iou)
+                near = ((iou - nms_config.NMS_THRESH).abs() < 1e-4) & torch.triu(torch.ones(n, n, dtype=torch.bool), 1)
+                f['near_iou'] = near.nonzero().numpy().astype(np.int32).reshape(-1, 2)
+            else:
+                f['tie_gap'] = float('inf')
+                f['near_iou'] = np.zeros((0, 2), np.int32)
+            return cap._nms(box_scores, box_preds, nms_config, score_thresh)
+        centernet_utils.decode_bbox_from_heatmap = decode
+        model_nms_utils.class_agnostic_nms = nms
+        return self
+
+    def __exit__(self, *exc):
+        self._cu.decode_bbox_from_heatmap = self._dec
+        self._mu.class_agnostic_nms = self._nms
+
+    def dump(self, out, prefix='post'):
+        for b, f in sorted(self.frames.items()):
+            for k in ('nms_scores', 'nms_boxes', 'near_score', 'near_iou'):
+                out['%s_%d_%s' % (prefix, b, k)] = np.asarray(f.get(k, np.zeros(0, np.float32)))
+            out['%s_%d_gaps' % (prefix, b)] = np.array([f.get('topk_gap', np.inf), f.get('tie_gap', np.inf), f.get('score_thresh', -1.0),
+                                                        f.get('nms_thresh', -1.0)], dtype=np.float64)     # topk, tie, SCORE_THRESH, NMS_THRESH
+
+
 def capture_common(model, bd, out):
     out['voxel_coords'] = bd['voxel_coords'].numpy()
     out['pillar_features'] = bd['pillar_features'].numpy()
@@ -97,12 +169,13 @@ def g1_single(tag, yaml_name, layout, extra_points=None, score_thresh=None):
         return orig_mean(src, index, dim, dim_size)
     torch_scatter.scatter_mean = spy_mean
     try:
-        with torch.no_grad():
+        with torch.no_grad(), PostCapture(model) as post:
             bd, snaps = run_modules(model, bd)
     finally:
         torch_scatter.scatter_mean = orig_mean
     out = {'points': pts, 'unq_inv': unq_inv_holder['inv'].numpy()}
     capture_common(model, bd, out)
+    post.dump(out)
     if 'backbone_2d' in snaps and cfg.MODEL.get('CORRECTOR', None) is not None:
         out['backbone_out'] = snaps['backbone_2d']['spatial_features_2d'].numpy()
     if cfg.MODEL.get('CORRECTOR', None) is not None:
@@ -158,10 +231,11 @@ def g1_disco():
         clouds.append(np.concatenate(per_agent, axis=0))
     pts = synth.collate(clouds)
     bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': metadata}
-    with torch.no_grad():
+    with torch.no_grad(), PostCapture(model) as post:
         bd, snaps = run_modules(model, bd)
     out = {'points': pts}
     capture_common(model, bd, out)
+    post.dump(out)
     out['backbone_out'] = snaps['backbone_2d']['spatial_features_2d'].numpy()
     for aid, m in bd['bev_img'].items():
         out['bev_img_%d' % aid] = m.numpy()
@@ -175,12 +249,18 @@ def g1_disco():
     print('g1 disco', {k: v.shape for k, v in out.items() if k.startswith('bev_img')})
 
 
+G2_SCORE_THRESH = {'ego': 0.02, 'early': 0.02}
+
+
 def g2_full():
     out = {}
-    for tag, yaml_name, layout, n_agents in (('car', 'v2x_pointpillar_basic_car.yaml', 'car', 1),
-                                             ('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', 1),
-                                             ('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', 6)):
-        cfg = rh.load_cfg(yaml_name)
+    # with the synthetic weights the ego / early models score below the YAML's SCORE_THRESH 0.1 everywhere (0 final boxes: decode + NMS
+    # would be vacuous at full size), so those two run with the threshold the mini fixtures use; the test builds its model with the same
+    # override, recorded here as <tag>_score_thresh
+    for tag, yaml_name, layout, n_agents, thr in (('car', 'v2x_pointpillar_basic_car.yaml', 'car', 1, None),
+                                                  ('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', 1, G2_SCORE_THRESH['ego']),
+                                                  ('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', 6, G2_SCORE_THRESH['early'])):
+        cfg = rh.load_cfg(yaml_name, {} if thr is None else {'MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH': thr})
         model, ds = rh.build_model(cfg)
         fill_weights(model)
         cloud = np.concatenate([synth.agent_cloud(agent=a, n_points=60000, layout=layout) for a in range(n_agents)], axis=0)
@@ -196,10 +276,13 @@ def g2_full():
             return orig_mean(src, index, dim, dim_size)
         torch_scatter.scatter_mean = spy_mean
         try:
-            with torch.no_grad():
+            with torch.no_grad(), PostCapture(model) as post:
                 bd, snaps = run_modules(model, bd)
         finally:
             torch_scatter.scatter_mean = orig_mean
+        post.dump(out, prefix=tag + '_post')
+        out[tag + '_score_thresh'] = np.array(float(cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH))
+        out[tag + '_hm_max'] = np.array(float(model.dense_head.forward_ret_dict['pred_dicts'][0]['hm'].sigmoid().max()))
         vc = bd['voxel_coords'].numpy()
         pf = bd['pillar_features'].numpy()
         sf = bd['spatial_features_2d'].numpy()
@@ -218,6 +301,8 @@ def g2_full():
         out[tag + '_sf2d_probe'] = sf[0, :, ::16, ::16].copy()
         pd = model.dense_head.forward_ret_dict['pred_dicts'][0]
         out[tag + '_hm_probe'] = pd['hm'].numpy()[0, 0, ::4, ::4].copy()
+        for name in ('center', 'center_z', 'dim', 'rot', 'hm'):          # the complete head maps: decode + NMS are pinned EXACTLY on them
+            out[tag + '_head_' + name] = pd[name].numpy().copy()
         out[tag + '_boxes'] = bd['final_box_dicts'][0]['pred_boxes'].numpy()
         out[tag + '_scores'] = bd['final_box_dicts'][0]['pred_scores'].numpy()
         print('g2', tag, 'N', pts.shape[0], 'P', vc.shape[0], 'final', out[tag + '_boxes'].shape[0])
@@ -243,9 +328,25 @@ def g2_disco_full():
         clouds.append(c)
     pts = synth.collate([np.concatenate(clouds, axis=0)])
     bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}]}
-    with torch.no_grad():
+    # the ego -> agent point transform of bev_maker.py:172-179 as the frozen chain receives it: per agent, in call order
+    seen = []
+    hook = model.bev_maker_car.module_list[0].register_forward_pre_hook(lambda m, args: seen.append(args[0]['points'].detach().clone()))
+    with torch.no_grad(), PostCapture(model) as post:
         bd, snaps = run_modules(model, bd)
+    hook.remove()
     out = {'N': np.array(pts.shape[0])}
+    post.dump(out)
+    car_agents = [a for a in agents if a != 1]
+    assert len(seen) == len(car_agents)
+    for a, ap in zip(car_agents, seen):
+        ap = ap.numpy()
+        assert np.all(ap[:, -1] == a)
+        out['car_agent_%d_rows' % a] = np.array(ap.shape[0])
+        out['car_agent_%d_xyz_sha' % a] = np.array(sha(ap[:, 1:4].astype(np.float32)))
+        out['car_agent_%d_xyz_head' % a] = ap[:8, 1:4].copy()
+    pd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        out['head_' + name] = pd[name].numpy().copy()
     for a in poses:
         out['pose_%d' % a] = poses[a]
     for aid, m in bd['bev_img'].items():

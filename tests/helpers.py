@@ -40,3 +40,33 @@ def match_boxes(a_boxes, a_scores, b_boxes, b_scores, tol=1e-3):
             n += 1
             worst = max(worst, e)
     return n, worst
+
+
+def assert_same_final_set(ref_boxes, ref_scores, got_boxes, got_scores, tol=1e-5):
+    """the two detection lists hold the SAME boxes: equal count and a one-to-one match of every box (7 parameters and score) within
+    `tol` -- the order among exactly tied scores is implementation defined (torch.topk), so lists are compared as sets"""
+    assert got_boxes.shape[0] == ref_boxes.shape[0], (got_boxes.shape[0], ref_boxes.shape[0])
+    n, worst = match_boxes(ref_boxes, ref_scores, got_boxes, got_scores, tol=tol)
+    assert n == ref_boxes.shape[0], (n, ref_boxes.shape[0], worst)
+
+
+def assert_subset_of_candidates(got_boxes, got_scores, cand_boxes, cand_scores, tol=1e-3):
+    """every detection is (within tol) one of the reference's own NMS-input candidates"""
+    n, worst = match_boxes(got_boxes, got_scores, cand_boxes, cand_scores, tol=tol)
+    assert n == got_boxes.shape[0], (n, got_boxes.shape[0], worst)
+
+
+def postprocess_reference_maps(model, maps):
+    """decode + rotated NMS + gather of the product's CenterHead run on GIVEN head maps ({name: (B, k, H, W) numpy}, e.g. the
+    reference's own): isolates the integer / selection stage of the path from the float noise of the conv stack in front of it"""
+    import torch
+    head = model.dense_head
+    pk = head.packed()
+    entry = pk['heads'][0]
+    B, _, H, W = maps['hm'].shape
+    ld = int(entry['offs'][-1])
+    ld_pad = (ld + 3) // 4 * 4
+    buf = torch.zeros((B, H, W, ld_pad), dtype=torch.float32, device='cuda')
+    for i, name in enumerate(entry['names']):
+        buf[..., int(entry['offs'][i]):int(entry['offs'][i + 1])] = torch.from_numpy(maps[name]).cuda().permute(0, 2, 3, 1)
+    return head.generate_predicted_boxes(B, [buf.contiguous()], pk)

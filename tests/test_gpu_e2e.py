@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, match_boxes
+from helpers import assert_same_final_set, assert_subset_of_candidates, load_golden, match_boxes, postprocess_reference_maps
 from pcp_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -25,13 +25,45 @@ def _check_common(g, batch, pred_dicts, atol_map=1e-3):
     sf = batch['spatial_features_2d']
     assert tuple(sf.shape) == g['spatial_features_2d'].shape                                   # NCHW-shaped view
     np.testing.assert_allclose(sf.cpu().numpy(), g['spatial_features_2d'], rtol=0, atol=atol_map)
+    _check_detections(g, pred_dicts, ['final_boxes_%d', 'final_scores_%d', 'post_%d_nms_boxes', 'post_%d_nms_scores'])
+
+
+def _k(key, b):
+    return key % b if '%' in key else key
+
+
+def _check_detections(g, pred_dicts, keys, slack=2, tol=1e-3):
+    """End-to-end detections vs the reference's.  With the synthetic weights every candidate scores within 5e-4 of sigmoid(-2.19): the
+    500 candidates of a frame are spaced ~1e-6 apart, so a 1e-6 difference in a heat-map value can reorder two overlapping candidates
+    and greedy NMS then keeps the other one -- an exact end-to-end set cannot be demanded of ANY fp32 implementation on this data.  What
+    is demanded: (1) the head maps agree to 1e-3 everywhere (callers), (2) decode + NMS are EXACT on the reference's own head maps
+    (_check_postprocessing_is_exact), (3) every detection here is one of the reference's NMS-input candidates to 1e-3, and (4) at most
+    `slack` of the reference's final boxes are missing."""
     for b, pd in enumerate(pred_dicts):
-        gb, gs = g['final_boxes_%d' % b], g['final_scores_%d' % b]
+        gb, gs = g[_k(keys[0], b)], g[_k(keys[1], b)]
         pb, ps = pd['pred_boxes'].cpu().numpy(), pd['pred_scores'].cpu().numpy()
         assert pd['pred_labels'].dtype == torch.int64 and bool((pd['pred_labels'] == 1).all())
         assert abs(pb.shape[0] - gb.shape[0]) <= 1
-        n, worst = match_boxes(gb, gs, pb, ps, tol=1e-3)
-        assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+        assert_subset_of_candidates(pb, ps, g[_k(keys[2], b)], g[_k(keys[3], b)], tol=tol)
+        n, worst = match_boxes(gb, gs, pb, ps, tol=tol)
+        assert n >= gb.shape[0] - slack, (n, gb.shape[0], worst)
+
+
+def _check_postprocessing_is_exact(model, g, head_key, frames, keys):
+    """decode + rotated NMS + gather on the REFERENCE'S head maps give the reference's final boxes exactly (same count, every box and
+    score to 1e-5: expf / atan2f ulps), at whatever size the fixture was made (mini goldens and BASELINE's full size)"""
+    maps = {k: g[head_key + k] for k in ('center', 'center_z', 'dim', 'rot', 'hm')}
+    got = postprocess_reference_maps(model, maps)
+    for b in range(frames):
+        # on IDENTICAL head maps the only float noise is the ulp of sigmoid / exp / atan2 (~1e-8): a candidate counts as near-threshold
+        # here when its score is within 2e-7 of SCORE_THRESH or a pair's IoU within 1e-4 of NMS_THRESH (fixture lists, margin 1e-5 / 1e-4)
+        gaps_key = _k(keys[3], b).replace('near_score', 'gaps')
+        thr = float(g[gaps_key][2])
+        near_s = g[_k(keys[3], b)]
+        assert g[_k(keys[2], b)].shape[0] == 0 and int((np.abs(near_s - thr) < 2e-7).sum()) == 0, \
+            'fixture holds a near-threshold case: exclude the listed candidates here'
+        assert_same_final_set(g[_k(keys[0], b)], g[_k(keys[1], b)], got[b]['pred_boxes'].cpu().numpy(), got[b]['pred_scores'].cpu().numpy())
+        assert g[_k(keys[0], b)].shape[0] > 0
 
 
 @pytest.mark.parametrize('tag', ['ego', 'early', 'car'])
@@ -44,6 +76,7 @@ def test_single_agent_configs_match_reference_outputs(tag):
         pred_dicts, recall = model(batch)
     torch.cuda.synchronize()
     _check_common(g, batch, pred_dicts)
+    _check_postprocessing_is_exact(model, g, 'head_', 2, ['final_boxes_%d', 'final_scores_%d', 'post_%d_near_iou', 'post_%d_near_score'])
     hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
     for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
         np.testing.assert_allclose(hd[name].cpu().numpy(), g['head_' + name], rtol=0, atol=1e-3)
@@ -63,16 +96,18 @@ def test_disco_mid_fusion_matches_reference_outputs():
     torch.cuda.synchronize()
     assert sorted(batch['bev_img'].keys()) == [0, 2]
     assert tuple(batch['bev_img'][2].shape) == g['bev_img_2'].shape         # agent 2 absent from the last frame -> batch 1
-    # the ego->agent transform runs in fp32 on the device; a point within an ulp of a cell edge may change pillar: allow a
-    # handful of pixels to differ, the rest must agree to 1e-3
+    # the ego -> agent point transform reproduces the reference's rounding order bit for bit (pcp_select_transform_points:
+    # test_select_transform_points_bit_equal_to_the_reference), so no pillar changes cell: EVERY pixel of every map agrees to 1e-3
     for aid in (0, 2):
-        diff = np.abs(batch['bev_img'][aid].cpu().numpy() - g['bev_img_%d' % aid])
-        assert (diff > 1e-3).mean() < 2e-3, (aid, float((diff > 1e-3).mean()))
-    diff = np.abs(batch['bev_img_early'].cpu().numpy()[:, ::4] - g['bev_img_early_probe'])
-    assert float(diff.max()) < 1e-3
-    diff = np.abs(batch['spatial_features_2d'].cpu().numpy() - g['spatial_features_2d'])
-    assert (diff > 1e-3).mean() < 5e-3, float((diff > 1e-3).mean())
+        np.testing.assert_allclose(batch['bev_img'][aid].cpu().numpy(), g['bev_img_%d' % aid], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(batch['bev_img_early'].cpu().numpy()[:, ::4], g['bev_img_early_probe'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(batch['spatial_features_2d'].cpu().numpy(), g['spatial_features_2d'], rtol=0, atol=1e-3)
     assert np.array_equal(batch['voxel_coords'].cpu().numpy(), g['voxel_coords'])
+    hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        np.testing.assert_allclose(hd[name].cpu().numpy(), g['head_' + name], rtol=0, atol=1e-3)
+    _check_detections(g, pred_dicts, ['final_boxes_%d', 'final_scores_%d', 'post_%d_nms_boxes', 'post_%d_nms_scores'])
+    _check_postprocessing_is_exact(model, g, 'head_', 2, ['final_boxes_%d', 'final_scores_%d', 'post_%d_near_iou', 'post_%d_near_score'])
 
 
 @pytest.mark.parametrize('tag', ['car', 'disco'])
@@ -460,6 +495,8 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents, p
     cfg = cfg_from_yaml_file(os.path.join(here, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', yaml_name), EasyDict())
     vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
     ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(cfg.DATA_CONFIG.POINT_FEATURE_ENCODING.used_feature_list))
+    # ego / early: the YAML's SCORE_THRESH 0.1 leaves no box with the synthetic weights; the fixture was made with the value it records
+    cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = float(g[tag + '_score_thresh'])
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
@@ -491,22 +528,21 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents, p
     np.testing.assert_allclose(sf[0, :, ::16, ::16], g[tag + '_sf2d_probe'], rtol=0, atol=1e-3)
     np.testing.assert_allclose(sf.max(axis=(0, 2, 3)), g[tag + '_sf2d_max'], rtol=0, atol=1e-3)
     np.testing.assert_allclose(sf.astype(np.float64).sum((0, 2, 3)), g[tag + '_sf2d_sum'], rtol=1e-4, atol=0.5)
-    hm = model.dense_head.forward_ret_dict['pred_dicts'][0]['hm'].cpu().numpy()
-    np.testing.assert_allclose(hm[0, 0, ::4, ::4], g[tag + '_hm_probe'], rtol=0, atol=1e-3)
-    gb, gs = g[tag + '_boxes'], g[tag + '_scores']
-    pb, ps = pred[0]['pred_boxes'].cpu().numpy(), pred[0]['pred_scores'].cpu().numpy()
-    assert abs(pb.shape[0] - gb.shape[0]) <= 1
-    if gb.shape[0]:
-        n, worst = match_boxes(gb, gs, pb, ps, tol=1e-3)
-        assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+    hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):                      # all five head maps, every pixel, at full size
+        np.testing.assert_allclose(hd[name].cpu().numpy(), g[tag + '_head_' + name], rtol=0, atol=1e-3)
+    assert g[tag + '_boxes'].shape[0] == 83                                      # decode + NMS are NOT vacuous at full size
+    keys = [tag + '_boxes', tag + '_scores', tag + '_post_%d_nms_boxes', tag + '_post_%d_nms_scores']
+    _check_detections(g, pred, keys, slack=2)
+    _check_postprocessing_is_exact(model, g, tag + '_head_', 1, [tag + '_boxes', tag + '_scores', tag + '_post_%d_near_iou',
+                                                                 tag + '_post_%d_near_score'])
 
 
 @pytest.mark.parametrize('pipeline', [False, True])
 def test_disco_full_size_against_reference_digests(pipeline):
     """Config 5 at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid, one frame) against digests of the REFERENCE's own
-    DiscoNet forward (tests/golden/g2_disco_full.npz): per-agent BEV maps, fused map, detections.  The ego->agent transform runs in
-    fp32 on the device (the reference: float64 numpy on the host), so a point within an ulp of a cell edge may change pillar: a small
-    fraction of probe pixels may differ, everything else agrees to 1e-3.  pipeline = True is the mode bench.py measures (stacked
+    DiscoNet forward (tests/golden/g2_disco_full.npz): per-agent BEV maps, fused map, head maps, detections -- every value to 1e-3 (the
+    ego -> agent point transform is bit-equal to the reference's, so no pillar moves).  pipeline = True is the mode bench.py measures (stacked
     agent pass, sparse first layer for the remote agents' 60 k-point clouds, F(4x4) wide layers)."""
     import hashlib
     import os
@@ -546,21 +582,23 @@ def test_disco_full_size_against_reference_digests(pipeline):
         vc = batch['voxel_coords'].cpu().numpy()
         assert vc.shape[0] == int(g['voxel_P'])
         assert hashlib.sha256(np.ascontiguousarray(vc.astype(np.int32)).tobytes()).hexdigest() == str(g['coords_sha'])
-    for aid in (0, 2, 3, 4, 5):
+    for aid in (0, 2, 3, 4, 5):                                                  # every probe pixel of every agent's map: 1e-3
         a = batch['bev_img'][aid].cpu().numpy()
-        diff = np.abs(a[0, ::8, ::8, ::8] - g['bev_%d_probe' % aid])
-        assert (diff > 1e-3).mean() < 2e-3, (aid, float((diff > 1e-3).mean()))
-        np.testing.assert_allclose(a.astype(np.float64).sum((0, 2, 3)), g['bev_%d_sum' % aid], rtol=2e-3, atol=2.0)
+        np.testing.assert_allclose(a[0, ::8, ::8, ::8], g['bev_%d_probe' % aid], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(a.max(axis=(0, 2, 3)), g['bev_%d_max' % aid], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(a.astype(np.float64).sum((0, 2, 3)), g['bev_%d_sum' % aid], rtol=1e-4, atol=0.5)
     sf = batch['spatial_features_2d'].cpu().numpy()
-    diff = np.abs(sf[0, :, ::16, ::16] - g['sf2d_probe'])
-    assert (diff > 1e-3).mean() < 5e-3, float((diff > 1e-3).mean())
-    np.testing.assert_allclose(sf.astype(np.float64).sum((0, 2, 3)), g['sf2d_sum'], rtol=2e-3, atol=2.0)
-    gb, gs = g['boxes'], g['scores']
-    pb, ps = pred[0]['pred_boxes'].cpu().numpy(), pred[0]['pred_scores'].cpu().numpy()
-    assert abs(pb.shape[0] - gb.shape[0]) <= 2
-    if gb.shape[0]:
-        n, worst = match_boxes(gb, gs, pb, ps, tol=2e-3)
-        assert n >= gb.shape[0] - 4, (n, gb.shape[0], worst)
+    np.testing.assert_allclose(sf[0, :, ::16, ::16], g['sf2d_probe'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(sf.max(axis=(0, 2, 3)), g['sf2d_max'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(sf.astype(np.float64).sum((0, 2, 3)), g['sf2d_sum'], rtol=1e-4, atol=0.5)
+    hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        np.testing.assert_allclose(hd[name].cpu().numpy(), g['head_' + name], rtol=0, atol=1e-3)
+    assert g['boxes'].shape[0] == 83
+    g2 = dict(g)
+    g2['boxes_0'], g2['scores_0'] = g['boxes'], g['scores']
+    _check_detections(g2, pred, ['boxes_%d', 'scores_%d', 'post_%d_nms_boxes', 'post_%d_nms_scores'], slack=2)
+    _check_postprocessing_is_exact(model, g2, 'head_', 1, ['boxes_%d', 'scores_%d', 'post_%d_near_iou', 'post_%d_near_score'])
 
 
 @pytest.mark.gpu

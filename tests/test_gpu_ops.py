@@ -579,17 +579,24 @@ def test_conv3x3_winograd4_channel_windows_and_bad_arguments():
 
 
 def test_column_ids_equals_torch_unique():
-    """agent ids present in the cloud (bev_maker.py:156): presence-mask kernel == torch.unique, incl. the fallback for values that are
-    not integers in 0..63 and the empty cloud"""
+    """agent ids present in the cloud (bev_maker.py:153-156: torch.unique(points[:, -1].long())): presence-mask kernel == torch.unique
+    of the truncated column; ids outside 0..63 raise (no torch fallback on the product path); the empty cloud gives no ids"""
+    from pcp_amd import lib
     ops = _ops()
     d = dev()
     g = torch.Generator().manual_seed(3)
     pts = torch.rand((5000, 7), generator=g)
     pts[:, -1] = torch.tensor([0, 2, 5, 63])[torch.randint(0, 4, (5000,), generator=g)].float()
     assert ops.column_ids(pts.to(d), -1).tolist() == [0, 2, 5, 63]
-    pts[17, -1] = 2.5
+    pts[17, -1] = 3.5                                           # .long() truncates: 3
+    pts[18, -1] = -0.25                                         # -> 0
+    assert ops.column_ids(pts.to(d), -1).tolist() == torch.unique(pts[:, -1].long()).tolist() == [0, 2, 3, 5, 63]
     pts[99, -1] = -1.0
-    assert ops.column_ids(pts.to(d), -1).tolist() == torch.unique(pts[:, -1]).numpy().astype(np.int64).tolist()
+    with pytest.raises(lib.PcpError):
+        ops.column_ids(pts.to(d), -1)
+    pts[99, -1] = 64.0
+    with pytest.raises(lib.PcpError):
+        ops.column_ids(pts.to(d), -1)
     assert ops.column_ids(torch.zeros((0, 7), device=d), -1).tolist() == []
 
 
@@ -836,3 +843,33 @@ def test_conv3x3_bf16x3_optin_matches_torch_cpu(cin, cout, h, w, stride, relu, b
     got = out.permute(0, 3, 1, 2).cpu()
     err = float((got - want).abs().max()) / float(want.abs().max())
     assert err < 1e-4, err
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a13: ego -> agent point transform, bit for bit the reference's (bev_maker.py:172-179) at BASELINE's full size
+# ---------------------------------------------------------------------------------------------------------------------
+def test_select_transform_points_bit_equal_to_the_reference():
+    """tests/golden/g2_disco_full.npz holds, per remote agent, the SHA-256 of the xyz the reference's frozen chain received after
+    `agent_points[mask, 1:4] @ R^T + t` (torch CPU: an FMA chain then a rounded add).  pcp_select_transform_points must produce the
+    same bits for all 60 000 rows of every agent -- which is what lets the DiscoNet map tests demand 1e-3 on every pixel."""
+    import hashlib
+    from pcp_amd import synth
+    ops = _ops()
+    g = load_golden('g2_disco_full.npz')
+    agents = (0, 1, 2, 3, 4, 5)
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = torch.from_numpy(synth.collate([np.concatenate(clouds, axis=0)])).to(dev())
+    for a in agents:
+        if a == 1:
+            continue
+        T = torch.from_numpy(g['pose_%d' % a]).float().numpy()                  # the reference casts the float64 pose to float32 first
+        pose = np.concatenate([T[:3, :3], T[:3, 3:4]], axis=1).reshape(1, 12)
+        out = ops.select_transform_points(pts, -1, a, pose, np.array([True]))
+        rows = out[out[:, 0] >= 0].cpu().numpy()
+        assert rows.shape[0] == int(g['car_agent_%d_rows' % a]) == 60000
+        assert np.array_equal(rows[:8, 1:4], g['car_agent_%d_xyz_head' % a])
+        assert hashlib.sha256(np.ascontiguousarray(rows[:, 1:4]).tobytes()).hexdigest() == str(g['car_agent_%d_xyz_sha' % a])

@@ -272,6 +272,7 @@ def test_g2_full_size_forward(tag, yaml_name, layout, n_agents):
     import bench
     g = load_golden('g2_full.npz')
     cfg = bench.load_cfg(yaml_name)
+    cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = float(g[tag + '_score_thresh'])     # ego / early: see make_golden.G2_SCORE_THRESH
     _model, state, _ds = bench.build_model(cfg)
 
     def plain(d):
@@ -293,9 +294,17 @@ def test_g2_full_size_forward(tag, yaml_name, layout, n_agents):
     sf = np.asarray(out['spatial_features_2d'])
     np.testing.assert_allclose(sf[0, :, ::16, ::16], g[tag + '_sf2d_probe'], rtol=0, atol=3e-4)
     np.testing.assert_allclose(np.asarray(out['head_maps']['hm'])[0, 0, ::4, ::4], g[tag + '_hm_probe'], rtol=0, atol=3e-4)
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):                                 # every pixel of every head map
+        np.testing.assert_allclose(np.asarray(out['head_maps'][name]), g[tag + '_head_' + name], rtol=0, atol=3e-4)
     fb = out['final_box_dicts'][0]
     gb, gs = g[tag + '_boxes'], g[tag + '_scores']
-    assert abs(np.asarray(fb['pred_boxes']).shape[0] - gb.shape[0]) <= 1
-    if gb.shape[0]:
-        n, worst = match_boxes(gb, gs, np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
-        assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+    assert gb.shape[0] == 83 and abs(np.asarray(fb['pred_boxes']).shape[0] - gb.shape[0]) <= 1
+    n, worst = match_boxes(gb, gs, np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
+    assert n >= gb.shape[0] - 2, (n, gb.shape[0], worst)
+    # decode + NMS of the oracle on the REFERENCE'S head maps: the reference's final set, exactly (lists compared as sets: the order among
+    # exactly tied scores is torch.topk's)
+    from oracle import bev as obev
+    from helpers import assert_same_final_set
+    assert g[tag + '_post_0_near_iou'].shape[0] == 0 and g[tag + '_post_0_near_score'].shape[0] == 0
+    fin = obev.head_postprocess({k: torch.from_numpy(g[tag + '_head_' + k]) for k in ('center', 'center_z', 'dim', 'rot', 'hm')}, arch)[0]
+    assert_same_final_set(gb, gs, np.asarray(fin['pred_boxes']), np.asarray(fin['pred_scores']))
