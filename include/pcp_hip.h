@@ -136,6 +136,16 @@ int pcp_conv3x3_winograd_ws(const pcp_conv3x3_t *desc, const float *in, const fl
                             void *stream);
 int pcp_conv3x3_winograd_ws_plan(const pcp_conv3x3_t *desc, int32_t *variant, double *executed_flops);
 
+/* Same operation as ONE fused Winograd F(4x4,3x3) launch (csrc/wino4f.hip): 36 products per 4x4 output tile (1.78x fewer matrix flops
+ * than F(2x2), 4x fewer than the direct form), fp32 MFMA with fp32 accumulation, transform rounding ~1e-5 of the output scale; nothing
+ * goes through HBM between the transforms and the products (no workspace).  Built for the 64 / 128-channel layers of
+ * base_bev_backbone.py:30-69, center_head.py:24-29,75-82 and v2x_fusion_disco.py:51-58.  cin % 8 == 0, cout % 4 == 0, cout_pad % 64 == 0,
+ * ld_in % 4 == 0, ld_out % 4 == 0, `in`, `out`, `bias` and `u_packed` 16-byte aligned; weights packed by pcp_amd/pack.py::pack_conv3x3_winograd4f as U = G g G^T:
+ * [cin/8][36 (i*6+j)][cout_pad][8].  _plan: the flops the launch executes on the matrix pipe (padding tiles / channels included). */
+int pcp_conv3x3_winograd4f(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                           void *stream);
+int pcp_conv3x3_winograd4f_plan(const pcp_conv3x3_t *desc, double *executed_flops);
+
 /* Measurement query (bench.py's roofline line): which instantiation pcp_conv3x3_winograd launches for `desc` (variant = 1: 32-tile
  * workgroups k_conv3x3_wino<1>, 2: 64-tile workgroups k_conv3x3_wino<2>) and the flops that launch EXECUTES on the matrix pipe
  * (16 products per 2x2 output tile and (cin, cout) pair, padding tiles and channels included).  Either output may be NULL. */

@@ -123,6 +123,20 @@ def pack_conv3x3_winograd4(w, bias):
     return up.contiguous(), pad_bias(bias, cout_pad), cout_pad
 
 
+def pack_conv3x3_winograd4f(w, bias):
+    """w: [cout, cin, 3, 3] (BN-folded) -> F(4x4,3x3) filter transform U = G g G^T in float64, rounded once, in the fragment order of the
+    FUSED kernel csrc/wino4f.hip: [cin/8][36 (i*6+j)][cout_pad][8] (a wave's B operand of one position and slice = one 1-KiB run)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % 8 == 0
+    cout_pad = round_up(cout, 64)
+    G = torch.tensor(_WINO4_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum('ia,ncab,jb->ncij', G, w.double(), G).float()              # [cout, cin, 6, 6]
+    up = u.new_zeros((cout_pad, cin, 36))
+    up[:cout] = u.reshape(cout, cin, 36)
+    packed = up.view(cout_pad, cin // 8, 8, 36).permute(1, 3, 0, 2).contiguous()
+    return packed, pad_bias(bias, cout_pad), cout_pad
+
+
 def winograd4_reference(x, packed, bias, cout):
     """Plain-torch evaluation of the packed F(4x4,3x3) form with the transforms of csrc/wino4.hip (validates matrices + layout on the
     CPU): x (B, cin, H, W), H, W multiples of 4."""

@@ -62,6 +62,13 @@ def main():
                 (name, td * 1e6, flops / td / 1e12, tw * 1e6, flops / tw / 1e12, td / tw, t3 * 1e6, flops / t3 / 1e12))
         if tws is not None:
             line += ' | WS %8.1f us %6.1f TF (x%.2f vs winograd, diff %.1e)' % (tws * 1e6, flops / tws / 1e12, tw / tws, errws)
+        p4f, b4f, cp4f = pack.pack_conv3x3_winograd4f(w, b)
+        p4f, b4f = p4f.to(d), b4f.to(d)
+        ref = torch.empty_like(out)
+        ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=ref)
+        t4f = timeit(lambda: ops.conv3x3_winograd4f(x, p4f, b4f, cin, cout, cp4f, out=out))
+        err4f = float((out - ref).abs().max() / ref.abs().max())
+        line += ' | F(4x4) FUSED %8.1f us %6.1f TF (x%.2f vs winograd, diff %.1e)' % (t4f * 1e6, flops / t4f / 1e12, tw / t4f, err4f)
         if cin % pack.WINO4_CK == 0 and cout % 4 == 0 and cin >= 128:
             ref = out.clone()                                    # bf16x3 result ran last; recompute the fp32 Winograd result as the yardstick
             ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=ref)

@@ -15,10 +15,15 @@ from pcp_amd import lib as plib, pack  # noqa: E402
 HERE = Path(__file__).resolve().parent.parent
 
 
+ENTRY = os.environ.get('PCP_DIAG_ENTRY', 'pcp_conv3x3_winograd_ws')       # or pcp_conv3x3_winograd4f
+
+
 def load(path):
     L = ctypes.CDLL(str(path))
-    L.pcp_conv3x3_winograd_ws.restype = ctypes.c_int32
-    L.pcp_conv3x3_winograd_ws.argtypes = [ctypes.POINTER(plib.Conv3x3)] + [ctypes.c_void_p] * 5
+    fn = getattr(L, ENTRY)
+    fn.restype = ctypes.c_int32
+    fn.argtypes = [ctypes.POINTER(plib.Conv3x3)] + [ctypes.c_void_p] * 5
+    L.entry = fn
     return L
 
 
@@ -29,24 +34,27 @@ def main():
     for p in sorted(glob.glob(str(HERE / 'lib' / 'variants' / 'libpcp_hip_*.so'))):
         libs[os.path.basename(p)[len('libpcp_hip_'):-3]] = load(p)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for (cin, cout, H, W) in [(128, 128, 128, 128), (64, 64, 256, 256), (128, 128, 64, 64)]:
+    pat = os.environ.get('PCP_DIAG_VARIANTS', '')
+    libs = {k: v for k, v in libs.items() if k == 'shipped' or k.startswith(pat)}
+    for (cin, cout, H, W) in [(128, 128, 128, 128), (64, 64, 256, 256), (384, 128, 128, 128)]:
         x = torch.randn((B, H, W, cin), device=d)
         w = torch.randn((cout, cin, 3, 3)) * 0.05
-        pw, bw, cp = pack.pack_conv3x3_winograd_ws(w, torch.zeros(cout))
+        f4 = ENTRY.endswith('4f')
+        pw, bw, cp = (pack.pack_conv3x3_winograd4f if f4 else pack.pack_conv3x3_winograd_ws)(w, torch.zeros(cout))
         pw, bw = pw.to(d), bw.to(d)
         out = torch.empty((B, H, W, cout), device=d)
         desc = plib.Conv3x3(B, H, W, cin, cout, cp, 1, cin, cout, 1)
-        flops_exec = 2.0 * 16 * (B * H * W / 4) * cin * cp
+        flops_exec = 2.0 * (36 * (B * H * W / 16) if f4 else 16 * (B * H * W / 4)) * cin * cp
         times = {k: [] for k in libs}
         for rnd in range(7):
             for k, L in libs.items():
                 for _ in range(2):
-                    L.pcp_conv3x3_winograd_ws(ctypes.byref(desc), x.data_ptr(), pw.data_ptr(), bw.data_ptr(), out.data_ptr(), st)
+                    L.entry(ctypes.byref(desc), x.data_ptr(), pw.data_ptr(), bw.data_ptr(), out.data_ptr(), st)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10):
-                    L.pcp_conv3x3_winograd_ws(ctypes.byref(desc), x.data_ptr(), pw.data_ptr(), bw.data_ptr(), out.data_ptr(), st)
+                    L.entry(ctypes.byref(desc), x.data_ptr(), pw.data_ptr(), bw.data_ptr(), out.data_ptr(), st)
                 e1.record()
                 torch.cuda.synchronize()
                 times[k].append(e0.elapsed_time(e1) / 10 * 1e3)

@@ -526,6 +526,53 @@ def test_conv3x3_winograd_ws_channel_windows_and_bad_arguments():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# FUSED Winograd F(4x4, 3x3) (csrc/wino4f.hip): ragged image edges (H, W not multiples of the 16 x 32 workgroup tile nor of 4), padded
+# cout, odd slice counts, channel windows
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,h,w,relu,batch', [(64, 64, 32, 32, True, 1), (128, 128, 16, 64, True, 2), (8, 64, 16, 32, False, 1),
+                                                      (384, 64, 16, 32, True, 1), (64, 320, 32, 32, True, 1), (64, 100, 20, 36, False, 2),
+                                                      (24, 128, 7, 9, True, 1), (128, 384, 24, 40, True, 1), (128, 128, 64, 64, True, 3),
+                                                      (256, 256, 64, 64, True, 1)])
+def test_conv3x3_winograd4f_matches_torch_cpu(cin, cout, h, w, relu, batch):
+    ops = _ops()
+    from pcp_amd import pack
+    x = torch.from_numpy(_rand(271, (batch, cin, h, w)))
+    wt = torch.from_numpy(_rand(272, (cout, cin, 3, 3), -0.05, 0.05))
+    b = torch.from_numpy(_rand(273, (cout,), -0.2, 0.2))
+    want = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        want = F.relu(want)
+    packed, bp, cpad = pack.pack_conv3x3_winograd4f(wt, b)
+    d = dev()
+    got = ops.conv3x3_winograd4f(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
+    torch.cuda.synchronize()
+    # F(4x4) transforms round at ~1e-5 of the output scale (same bar as the through-memory F(4x4) path)
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * max(1.0, float(want.abs().max())))
+    got2 = ops.conv3x3_winograd4f(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
+    assert torch.equal(got, got2)                                            # deterministic
+
+
+def test_conv3x3_winograd4f_channel_windows_and_bad_arguments():
+    ops = _ops()
+    from pcp_amd import lib, pack
+    d = dev()
+    cin, cout = 64, 128
+    wt = torch.from_numpy(_rand(277, (cout, cin, 3, 3), -0.05, 0.05))
+    packed, bp, cpad = pack.pack_conv3x3_winograd4f(wt, torch.zeros(cout))
+    x = torch.from_numpy(_rand(278, (1, 48, 40, 96))).to(d)
+    out = torch.full((1, 48, 40, 384), 7.0, device=d)
+    ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=16, out_ch_off=128)
+    torch.cuda.synchronize()
+    assert float((out[..., :128] - 7.0).abs().max()) == 0.0 and float((out[..., 256:] - 7.0).abs().max()) == 0.0
+    want = F.conv2d(x[..., 16:80].permute(0, 3, 1, 2).cpu(), wt, None, padding=1)
+    np.testing.assert_allclose(out[..., 128:256].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
+    with pytest.raises(lib.PcpError):
+        ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), 36, cout, cpad, relu=False, out=out)
+    with pytest.raises(lib.PcpError):
+        ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Winograd F(4x4, 3x3) through memory (input transform, 36 batched MFMA GEMMs, output transform): the wide layers
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cin,cout,h,w,relu,batch', [(128, 256, 16, 16, True, 1), (384, 384, 32, 32, True, 2), (768, 768, 16, 16, True, 1),
