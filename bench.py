@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     'materialised (one host sync per VFE), dense canvas, no buffer reuse')
     ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
-    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'],
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'bf16x3', 'bf16'],
                     help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
                          '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
     ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
@@ -218,6 +218,12 @@ class AbiTimer:
                 mult = 3.0 if name == 'pcp_conv3x3_bf16x3' else 1.0
                 return ('k_%s<s%d> [opt-in arithmetic]' % (name[4:], s), mult * 2.0 * d.batch * ho * wo * d.cout_pad * 9 * d.cin, alg,
                         'mfma', MFMA_BF16_PEAK_TFLOPS)
+            if name == 'pcp_conv3x3_winograd4f':
+                d = a[0]._obj
+                fl = ctypes.c_double(0.0)
+                real.pcp_conv3x3_winograd4f_plan(ctypes.byref(d), ctypes.byref(fl))
+                return ('k_wino4f (3x3 s1 fused Winograd F(4x4,3x3), one 8-wave workgroup per CU, v_mfma_f32_32x32x2_f32)', fl.value,
+                        2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
             if name == 'pcp_pointwise':
                 d = a[0]._obj
                 if d.mode == 0:
@@ -518,7 +524,7 @@ def main(argv=None):
             ach = dom['exec_flops'] / (dom['ms'] * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(ach, 3), 'peak': dom['peak'], 'unit': 'TFLOP/s',
                     'frac': round(ach / dom['peak'], 4),
-                    'note': 'achieved = flops this kernel EXECUTES on the matrix pipe (Winograd: 16 products per 2x2 tile, padding included) / '
+                    'note': 'achieved = flops this kernel EXECUTES on the matrix pipe (Winograd F(2x2): 16 products per 2x2 tile, F(4x4): 36 per 4x4 tile, padding included) / '
                             'its HIP-event time; algorithmic_tflops = flops of the equivalent direct convolution / the same time',
                     'algorithmic_tflops': round(dom['alg_flops'] / (dom['ms'] * 1e-3) / 1e12, 3)}
         else:

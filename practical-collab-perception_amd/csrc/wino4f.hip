@@ -47,7 +47,7 @@ constexpr int F4_CK = 8;                                  // input channels per 
 constexpr int F4_RP = 40;                                 // raw plane row pitch (floats): 4 * RP mod 64 = 32
 constexpr int F4_RAW_H = 18, F4_RAW_W = 34;               // 16 x 32 output pixels + halo
 constexpr int F4_RAW_PIX = F4_RAW_H * F4_RAW_W;
-constexpr int F4_PLANE = F4_RAW_H * F4_RP + 8;            // channel planes 8 banks apart
+constexpr int F4_PLANE = F4_RAW_H * F4_RP;                // 720 = 16 (mod 64): the 16-lane groups of the transform's ds_read_b128 hit 64 distinct banks
 constexpr int F4_RAW_FLOATS = F4_CK * F4_PLANE;           // 5824
 constexpr int F4_V_FLOATS = 36 * 32 * F4_CK;              // 9216: V[pos][tile][8 channels]
 constexpr int F4_MAIN_FLOATS = 2 * F4_RAW_FLOATS + 2 * F4_V_FLOATS;
@@ -138,11 +138,12 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   bool rin[F4_RAW_PER];
 #pragma unroll
   for (int i = 0; i < F4_RAW_PER; i++) {
-    const int idx = tid + i * F4_THREADS;
-    roff[i] = 0u;
+    int idx = tid + i * F4_THREADS;
+    if (idx >= F4_RAW_ITEMS) idx -= F4_RAW_ITEMS;          // surplus threads repeat an item (same value to the same address): the staging
+    roff[i] = 0u;                                          // code stays free of divergent branches
     rdst[i] = -1;
     rin[i] = false;
-    if (idx < F4_RAW_ITEMS) {
+    {
       const int q = idx & 1, pix = idx >> 1;
       const int py = pix / F4_RAW_W, px = pix % F4_RAW_W;
       const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
@@ -162,55 +163,56 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   auto raw_store = [&](int buf) {
     float *dst = rawb + buf * F4_RAW_FLOATS;
 #pragma unroll
-    for (int i = 0; i < F4_RAW_PER; i++)
-      if (rdst[i] >= 0) {
-        f32x4 v = rreg[i];
-        if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        dst[rdst[i]] = v.x;
-        dst[rdst[i] + F4_PLANE] = v.y;
-        dst[rdst[i] + 2 * F4_PLANE] = v.z;
-        dst[rdst[i] + 3 * F4_PLANE] = v.w;
-      }
+    for (int i = 0; i < F4_RAW_PER; i++) {
+      f32x4 v = rreg[i];
+      if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      dst[rdst[i]] = v.x;
+      dst[rdst[i] + F4_PLANE] = v.y;
+      dst[rdst[i] + 2 * F4_PLANE] = v.z;
+      dst[rdst[i] + 3 * F4_PLANE] = v.w;
+    }
   };
 
-  // ---- input transform V = B^T d B, LDS -> LDS.  Item = (tile, channel); the two SIMD partners of a wave pair (w, w + 4) split an item by
-  //      output column triple: waves 0-3 produce V[i][0..2], waves 4-7 V[i][3..5] (row pass: 3 of the 6 outputs per raw row; column pass:
-  //      the full 6-point transform of their 3 columns).  Lane = (tile column, channel): a wave's 18 stores per position row cover 64
-  //      consecutive floats of V. ---------------------------------------------------------------------------------------------------------
-  const int t_half = wave >> 2;
-  const int t_ty = wave & 3, t_tx = lane >> 3, t_ch = lane & 7;
-  const int t_src = t_ch * F4_PLANE + (4 * t_ty) * F4_RP + 4 * t_tx;
-  const int t_dst = ((t_ty * 8 + t_tx) * F4_CK + t_ch) + (3 * t_half) * (32 * F4_CK);
+  // ---- input transform V = B^T d B, LDS -> LDS.  Item = (tile, channel), one per lane PAIR (l, l + 32) of a wave, ONE instruction stream
+  //      for all lanes (no wave-uniform branches: the step below is a single scheduling region):
+  //        row pass:    lane half h transforms raw rows 3h .. 3h+2 of the 6 x 6 patch (full 6-point B^T: 13 operations per row)
+  //        exchange:    9 v_permlane32_swap: half 0 hands columns 3..5 of its rows to half 1 and receives columns 0..2 of rows 3..5
+  //        column pass: half h transforms columns 3h .. 3h+2 (6-point B^T down the column) -> V[i][3h + c], i = 0..5
+  //      87 VALU + 9 swaps, 6 LDS reads (16 + 8 bytes per raw row), 18 LDS stores per lane and slice. ----------------------------------------
+  const int t_li = lane & 31;
+  const int t_ty = wave >> 1, t_tx = (wave & 1) * 4 + (t_li >> 3), t_ch = t_li & 7;
+  const int t_src = t_ch * F4_PLANE + (4 * t_ty + 3 * h) * F4_RP + 4 * t_tx;
+  const int t_dst = ((t_ty * 8 + t_tx) * F4_CK + t_ch) + (3 * h) * (32 * F4_CK);
   auto transform = [&](int rbuf, int vbuf) {
 #ifdef F4_DIAG_NO_XFORM
     return;                                                  // timing-only build
 #endif
     const float *src = rawb + rbuf * F4_RAW_FLOATS + t_src;
     float *dst = vb + vbuf * F4_V_FLOATS + t_dst;
-    float wv[6][3];
+    float wr[3][6];
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(src + a * F4_RP);
-      const float2 hi = *reinterpret_cast<const float2 *>(src + a * F4_RP + 4);
-      const float d0 = lo.x, d1 = lo.y, d2 = lo.z, d3 = lo.w, d4 = hi.x, d5 = hi.y;
-      if (t_half == 0) {
-        const float pp = d4 - 4.f * d2, qq = d3 - 4.f * d1;
-        wv[a][0] = 4.f * d0 - 5.f * d2 + d4;
-        wv[a][1] = pp + qq;
-        wv[a][2] = pp - qq;
-      } else {
-        const float rr = d4 - d2, ss = 2.f * (d3 - d1);
-        wv[a][0] = rr + ss;
-        wv[a][1] = rr - ss;
-        wv[a][2] = 4.f * d1 - 5.f * d3 + d5;
-      }
+    for (int rr = 0; rr < 3; rr++) {
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(src + rr * F4_RP);
+      const float2 hi = *reinterpret_cast<const float2 *>(src + rr * F4_RP + 4);
+      f4_bt6(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, wr[rr]);
     }
+    float top[3][3], bot[3][3];                               // after the swap: column 3h + c, rows rr (top) and 3 + rr (bot)
 #pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
+    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        // X = columns 0..2 (kept by half 0, given by half 1), Y = columns 3..5 (given by half 0, kept by half 1):
+        // v_permlane32_swap: X[32..63] <-> Y[0..31]
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(wr[rr][c]), __float_as_uint(wr[rr][3 + c]), false, false);
+        top[rr][c] = __uint_as_float(sw[0]);
+        bot[rr][c] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
       float o[6];
-      f4_bt6(wv[0][jj], wv[1][jj], wv[2][jj], wv[3][jj], wv[4][jj], wv[5][jj], o);
+      f4_bt6(top[0][c], top[1][c], top[2][c], bot[0][c], bot[1][c], bot[2][c], o);
 #pragma unroll
-      for (int i = 0; i < 6; i++) dst[(i * 6 + jj) * (32 * F4_CK)] = o[i];
+      for (int i = 0; i < 6; i++) dst[(i * 6 + c) * (32 * F4_CK)] = o[i];
     }
   };
 
@@ -219,12 +221,14 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   const unsigned u_lane = (unsigned)((r * F4_CK + 4 * h) * 4);                                    // bytes
   const long long u_pos = (long long)p.cout_pad * F4_CK;                                          // floats between positions
   const long long u_slice = 36 * u_pos;
+  const int n_slices = p.cin / F4_CK;
+  const int last = n_slices - 1;
   f32x4 bq[9];
   auto b_load_one = [&](int slice, int pi) {
 #ifdef F4_DIAG_NO_BLOAD
     if (slice > 0) return;                                   // timing-only build: B stays in registers
 #endif
-    const float *s = ubase + slice * u_slice + pi * u_pos;
+    const float *s = ubase + min(slice, last) * u_slice + pi * u_pos;
     bq[pi] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(s) + u_lane);
   };
 
@@ -234,8 +238,6 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
 
-  const int n_slices = p.cin / F4_CK;
-  const int last = n_slices - 1;
   const int a_off = ((9 * pg) * 32 + r) * F4_CK + 4 * h;
   // multiply slice s (V[vbuf] x bq) and, position by position, request the NEXT slice's B fragment right after its last use
   auto multiply = [&](int vbuf, int next_slice) {
@@ -262,33 +264,36 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
       if (pi + 3 < 9) aq[pi % 3] = *reinterpret_cast<const f32x4 *>(vsrc + (pi + 3) * (32 * F4_CK));
 #endif
       b_load_one(next_slice, pi);
-      __builtin_amdgcn_sched_barrier(0);               // keep this order (the scheduler would sink the reads back to their uses)
     }
   };
 
-  const bool xf_first = wave < 4;
+  // One pipeline step as ONE scheduling region (straight-line code): the next slice's input transform, the raw staging and this slice's
+  // 36 MFMAs are interleaved instruction by instruction inside every wave (an MFMA holds the matrix pipe for 64 cycles but the issue port
+  // for a fraction of that), so a wave keeps the pipe fed by itself instead of relying on its SIMD partner being in the opposite phase
+  // (stamps of the phase-separated version: 7.5 k cycles per slice against 4.6 k of MFMA time; a lone multiplying wave reached ~60 % of
+  // the pipe).  Nothing in it is conditional: the staging of the last steps re-fetches the last slice (clamped) into a dead buffer.
   auto step = [&](int s) {
     const int cur = s & 1, nxt = cur ^ 1;
-    const bool has1 = s + 1 < n_slices, has2 = s + 2 < n_slices;
 #ifdef F4_STAMP
     if (s == 4) F4_STAMP_AT(10);
 #endif
-    if (has1 && xf_first) transform(nxt, nxt);
-#ifdef F4_STAMP
-    if (s == 4) F4_STAMP_AT(11);
-#endif
-    multiply(cur, min(s + 1, last));
-#ifdef F4_STAMP
-    if (s == 4) F4_STAMP_AT(12);
-#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // source order = dependence order the compiler must assume: the A reads of V[cur] come BEFORE the transform's stores to V[nxt] (it
+    // cannot prove the two LDS windows distinct), so the transform's reads and arithmetic are free to move up between the MFMAs
+    multiply(cur, s + 1);
+    transform(nxt, nxt);
 #ifndef F4_DIAG_NO_STAGE
-    if (has2) raw_store(cur);            // raw[cur] was consumed by transform(s) one step ago; rreg holds raw(s + 2)
+    raw_store(cur);                      // raw[cur] was consumed by transform(s) one step ago; rreg holds raw(s + 2)
     raw_load(min(s + 3, last));
 #endif
-#ifdef F4_STAMP
-    if (s == 4) F4_STAMP_AT(13);
+#ifndef F4_NO_PIPELINE_SPEC
+#pragma unroll
+    for (int g = 0; g < 36; g++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // 3 VALU
+    }
 #endif
-    if (has1 && !xf_first) transform(nxt, nxt);
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef F4_STAMP
     if (s == 4) F4_STAMP_AT(14);
 #endif
@@ -311,15 +316,14 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
     for (int pi = 0; pi < 9; pi++) b_load_one(0, pi);
     float *dst = rawb;
 #pragma unroll
-    for (int i = 0; i < F4_RAW_PER; i++)
-      if (rdst[i] >= 0) {
-        f32x4 v = r0[i];
-        if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        dst[rdst[i]] = v.x;
-        dst[rdst[i] + F4_PLANE] = v.y;
-        dst[rdst[i] + 2 * F4_PLANE] = v.z;
-        dst[rdst[i] + 3 * F4_PLANE] = v.w;
-      }
+    for (int i = 0; i < F4_RAW_PER; i++) {
+      f32x4 v = r0[i];
+      if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      dst[rdst[i]] = v.x;
+      dst[rdst[i] + F4_PLANE] = v.y;
+      dst[rdst[i] + 2 * F4_PLANE] = v.z;
+      dst[rdst[i] + 3 * F4_PLANE] = v.w;
+    }
     if (n_slices > 1) raw_store(1);
     raw_load(min(2, last));
   }
@@ -328,7 +332,9 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   __syncthreads();
 
   F4_STAMP_AT(0);
-  for (int s = 0; s < n_slices; s++) step(s);
+  for (int s = 0; s < last; s++) step(s);
+  multiply(last & 1, last);              // the last slice: nothing left to transform or stage (the B reload is a harmless re-read)
+  __syncthreads();                       // every wave is done reading V before the epilogue reuses the LDS
   F4_STAMP_AT(1);
 
   // ---- epilogue: one 32-channel half at a time through LDS: M[pos][tile][channel] -> Y = A^T M A + bias (ReLU).

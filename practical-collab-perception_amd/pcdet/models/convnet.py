@@ -17,7 +17,7 @@ WINOGRAD_MIN_WORKGROUPS = 256
 B3_MIN_WORKGROUPS = 256
 WINOGRAD4_MIN_COUT = 256
 WINOGRAD4_MIN_WORKGROUPS = 512
-CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | bf16x3 (opt-in: split-bf16 products)
+CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | winograd4f | bf16x3 (opt-in: split-bf16 products)
 
 
 def conv_algo():
@@ -31,9 +31,31 @@ def _plain_bf16():
     return os.environ.get('PCP_CONV_ALGO', CONV_ALGO) == 'bf16'
 
 
+# fused F(4x4,3x3) (csrc/wino4f.hip: one workgroup per CU = 16 x 32 pixels x 64 channels): measured against the fused F(2x2) kernel on MI355X
+# (tools/bench_conv.py, 4 / 20 frames): 64->64 @256 x1.21 / x1.12, 128->128 @128 x1.34 / x1.36, 384->64 @128 - / x1.41, 384->128 @128 x1.41 /
+# x1.46, 128->384 x1.37 / x1.47; it loses when its grid does not fill the chip (128->128 @64 at 4 frames: 64 workgroups) or covers it unevenly
+# (320 workgroups on 256 CUs), and the through-memory F(4x4) path keeps the very wide layers (768 -> 768: x0.84)
+WINOGRAD4F_MIN_WORKGROUPS = 256
+WINOGRAD4F_MAX_CIN = 448
+
+
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f')
+
+    def _use_winograd4f(self, x, out, out_ch_off):
+        algo = conv_algo()
+        if self.kind != '3x3' or getattr(self, 'w4f', None) is None or algo in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'):
+            return False
+        if out is not None and (out.shape[-1] % 4 != 0 or out_ch_off % 4 != 0):
+            return False                                   # 16-byte output stores
+        if algo == 'winograd4f':
+            return True
+        B, H, W, _ = x.shape
+        wgs = B * ((H + 15) // 16) * ((W + 31) // 32) * (self.w4f[2] // 64)
+        if self.cin > WINOGRAD4F_MAX_CIN and getattr(self, 'w4', None) is not None:
+            return False
+        return wgs >= WINOGRAD4F_MIN_WORKGROUPS and (wgs % 256 == 0 or wgs >= 512)
 
     def _use_winograd4(self, x):
         algo = conv_algo()
@@ -69,6 +91,10 @@ class PackedConv:
             w3, b3, cp3 = self.b3
             return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
                                       in_ch_off=in_ch_off, out_ch_off=out_ch_off, plain=_plain_bf16())
+        if self._use_winograd4f(x, out, out_ch_off):
+            u, ub, ucp = self.w4f
+            return ops.conv3x3_winograd4f(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                          out_ch_off=out_ch_off)
         if self._use_winograd4(x):
             u, ub, ucp = self.w4
             return ops.conv3x3_winograd4(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
@@ -90,6 +116,10 @@ def _winograd4_shape(cin, cout, stride):
             and conv_algo() not in ('direct', 'winograd', 'bf16x3', 'bf16'))
 
 
+def _winograd4f_shape(cin, cout, stride):
+    return (stride == 1 and cin % 8 == 0 and cout % 4 == 0 and cout >= 48 and conv_algo() not in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'))
+
+
 def _fold(conv, bn, out_axis):
     w = conv.weight.detach().float()
     cb = conv.bias.detach().float() if conv.bias is not None else None
@@ -108,6 +138,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc.wino = None
     pc.b3 = None
     pc.w4 = None
+    pc.w4f = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -134,6 +165,8 @@ def pack_conv_module(conv, bn=None, relu=True):
             pc.b3 = pack.pack_conv3x3_bf16x3(w, b)
         if _winograd4_shape(pc.cin, pc.cout, s):
             pc.w4 = pack.pack_conv3x3_winograd4(w, b)
+        if _winograd4f_shape(pc.cin, pc.cout, s):
+            pc.w4f = pack.pack_conv3x3_winograd4f(w, b)
     elif k == 1 and s == 1:
         pc.kind = 'plain'
         pc.w, pc.b, pc.cout_pad = pack.pack_plain(w, b)
@@ -156,4 +189,5 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.wino = pack.pack_conv3x3_winograd(w, b) if (stride == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48) else None
     pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() in ('bf16x3', 'bf16') and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
     pc.w4 = pack.pack_conv3x3_winograd4(w, b) if _winograd4_shape(pc.cin, pc.cout, stride) else None
+    pc.w4f = pack.pack_conv3x3_winograd4f(w, b) if _winograd4f_shape(pc.cin, pc.cout, stride) else None
     return pc

@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 # substring of the rocprof kernel name -> bench.py label key
-KEYS = [('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_conv3x3_wino<2>', 'k_conv3x3_wino<2>'), ('k_wino_mid', 'k_wino_mid'),
+KEYS = [('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_conv3x3_wino<2>', 'k_conv3x3_wino<2>'), ('k_wino4f', 'k_wino4f'), ('k_wino_ws', 'k_wino_ws'),
         ('k_w4_gemm', 'k_w4_gemm'), ('k_w4_input', 'k_w4_input'), ('k_w4_output', 'k_w4_output'),
         ('k_conv3x3<1,', 'k_conv3x3_direct<s1>'), ('k_conv3x3<2,', 'k_conv3x3_direct<s2>'),
         ('k_pointwise<0', 'k_pointwise<plain>'), ('k_pointwise<1', 'k_pointwise<conv_k2s2>'), ('k_pointwise<2', 'k_pointwise<convT_k2s2>'),
