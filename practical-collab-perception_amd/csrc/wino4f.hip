@@ -68,6 +68,7 @@ struct F4Params {
   int ld_in, ld_out;
   int relu;
   int tiles_x, tiles_y, n_spatial;
+  unsigned in_bytes, u_bytes;     // extents for the buffer descriptors (range-checked loads)
 };
 
 __device__ __forceinline__ int xcd_remap_f4(int bid, int nwg) {
@@ -133,39 +134,35 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
 
   // ---- raw patch staging: item = (pixel, channel quad).  Unconditional loads with clamped addresses (static VMEM counts); pixels
   //      outside the image are zeroed by a select.  LDS image is channel-planar: [8 channels][18 rows][pitch 40]. ------------------------
+  // Loads go through a buffer descriptor: the per-lane byte offset sits in one VGPR, the slice offset in an SGPR (no vector address
+  // arithmetic in the loop -- VALU work displaces fp32 MFMAs on gfx950), and pixels outside the image carry an offset past the end of
+  // the buffer, for which the range check returns zeros (no select either).  The load count per step is static (counted vmcnt waits).
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
   unsigned roff[F4_RAW_PER];
   int rdst[F4_RAW_PER];
-  bool rin[F4_RAW_PER];
 #pragma unroll
   for (int i = 0; i < F4_RAW_PER; i++) {
     int idx = tid + i * F4_THREADS;
     if (idx >= F4_RAW_ITEMS) idx -= F4_RAW_ITEMS;          // surplus threads repeat an item (same value to the same address): the staging
-    roff[i] = 0u;                                          // code stays free of divergent branches
-    rdst[i] = -1;
-    rin[i] = false;
-    {
-      const int q = idx & 1, pix = idx >> 1;
-      const int py = pix / F4_RAW_W, px = pix % F4_RAW_W;
-      const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-      rdst[i] = (4 * q) * F4_PLANE + py * F4_RP + px;
-      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
-        rin[i] = true;
-        roff[i] = (unsigned)((((long long)(b * p.h + iy) * p.w + ix) * p.ld_in + q * 4) * 4);
-      }
-    }
+    const int q = idx & 1, pix = idx >> 1;                 // code stays free of divergent branches
+    const int py = pix / F4_RAW_W, px = pix % F4_RAW_W;
+    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+    rdst[i] = (4 * q) * F4_PLANE + py * F4_RP + px;
+    roff[i] = 0x80000000u;                                 // out of range -> 0
+    if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) roff[i] = (unsigned)((((long long)(b * p.h + iy) * p.w + ix) * p.ld_in + q * 4) * 4);
   }
   f32x4 rreg[F4_RAW_PER];
   auto raw_load = [&](int slice) {
-    const char *base = reinterpret_cast<const char *>(p.in + slice * F4_CK);       // wave-uniform
+    const int soff = slice * (F4_CK * 4);                  // wave-uniform byte offset of the slice's first channel
 #pragma unroll
-    for (int i = 0; i < F4_RAW_PER; i++) rreg[i] = *reinterpret_cast<const f32x4 *>(base + roff[i]);
+    for (int i = 0; i < F4_RAW_PER; i++)
+      rreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)roff[i], soff, 0));
   };
   auto raw_store = [&](int buf) {
     float *dst = rawb + buf * F4_RAW_FLOATS;
 #pragma unroll
     for (int i = 0; i < F4_RAW_PER; i++) {
-      f32x4 v = rreg[i];
-      if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = rreg[i];
       dst[rdst[i]] = v.x;
       dst[rdst[i] + F4_PLANE] = v.y;
       dst[rdst[i] + 2 * F4_PLANE] = v.z;
@@ -217,10 +214,11 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   };
 
   // ---- B fragments (transformed weights) from global / L2: one f32x4 per position = channels 4h .. 4h+3 of output channel r ------------
-  const float *ubase = p.u + ((long long)(9 * pg) * p.cout_pad + n0 + cb * 32) * F4_CK;         // wave-uniform
-  const unsigned u_lane = (unsigned)((r * F4_CK + 4 * h) * 4);                                    // bytes
-  const long long u_pos = (long long)p.cout_pad * F4_CK;                                          // floats between positions
-  const long long u_slice = 36 * u_pos;
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, p.u_bytes, 0x00020000);
+  const int u_lane = (r * F4_CK + 4 * h) * 4;                                         // bytes, per lane
+  const int u_pos = p.cout_pad * (F4_CK * 4);                                         // bytes between positions
+  const int u_slice = 36 * u_pos;
+  const int u_base = (9 * pg) * u_pos + (n0 + cb * 32) * (F4_CK * 4);                 // wave-uniform
   const int n_slices = p.cin / F4_CK;
   const int last = n_slices - 1;
   f32x4 bq[9];
@@ -228,8 +226,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
 #ifdef F4_DIAG_NO_BLOAD
     if (slice > 0) return;                                   // timing-only build: B stays in registers
 #endif
-    const float *s = ubase + min(slice, last) * u_slice + pi * u_pos;
-    bq[pi] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(s) + u_lane);
+    bq[pi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, u_base + min(slice, last) * u_slice + pi * u_pos, 0));
   };
 
   f32x16 acc[9];
@@ -317,8 +314,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
     float *dst = rawb;
 #pragma unroll
     for (int i = 0; i < F4_RAW_PER; i++) {
-      f32x4 v = r0[i];
-      if (!rin[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = r0[i];
       dst[rdst[i]] = v.x;
       dst[rdst[i] + F4_PLANE] = v.y;
       dst[rdst[i] + 2 * F4_PLANE] = v.z;
@@ -449,6 +445,12 @@ int f4_geom(const pcp_conv3x3_t *d, F4Params *p) {
   p->tiles_x = (d->in_w + 31) / 32;
   p->tiles_y = (d->in_h + 15) / 16;
   p->n_spatial = d->batch * p->tiles_x * p->tiles_y;
+  // buffer-descriptor addressing: 32-bit byte offsets (2 GiB of activations per launch, far above any BEV map here)
+  const long long in_bytes = (long long)d->batch * d->in_h * d->in_w * d->ld_in * 4;
+  const long long u_bytes = (long long)(d->cin / F4_CK) * 36 * d->cout_pad * F4_CK * 4;
+  if (in_bytes > 0x7fffffffLL || u_bytes > 0x7fffffffLL) return PCP_ERR_UNSUPPORTED;
+  p->in_bytes = (unsigned)in_bytes;
+  p->u_bytes = (unsigned)u_bytes;
   return PCP_OK;
 }
 
