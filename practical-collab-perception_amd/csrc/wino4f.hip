@@ -49,7 +49,8 @@ constexpr int F4_RAW_H = 18, F4_RAW_W = 34;               // 16 x 32 output pixe
 constexpr int F4_RAW_PIX = F4_RAW_H * F4_RAW_W;
 constexpr int F4_PLANE = F4_RAW_H * F4_RP;                // 720 = 16 (mod 64): the 16-lane groups of the transform's ds_read_b128 hit 64 distinct banks
 constexpr int F4_RAW_FLOATS = F4_CK * F4_PLANE;           // 5824
-constexpr int F4_V_FLOATS = 36 * 32 * F4_CK;              // 9216: V[pos][tile][8 channels]
+constexpr int F4_VLD = 12;                                // padded V row (floats): the 16 lanes of a ds_read_b128 group hit 64 distinct banks
+constexpr int F4_V_FLOATS = 36 * 32 * F4_VLD;             // 13824: V[pos][tile][8 channels + 4 pad]
 constexpr int F4_MAIN_FLOATS = 2 * F4_RAW_FLOATS + 2 * F4_V_FLOATS;
 constexpr int F4_MS_LD = 32;
 constexpr int F4_MS_FLOATS = 36 * 32 * F4_MS_LD;          // 36864 floats = 147 KB: M[pos][tile][32 channels]
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   const int t_li = lane & 31;
   const int t_ty = wave >> 1, t_tx = (wave & 1) * 4 + (t_li >> 3), t_ch = t_li & 7;
   const int t_src = t_ch * F4_PLANE + (4 * t_ty + 3 * h) * F4_RP + 4 * t_tx;
-  const int t_dst = ((t_ty * 8 + t_tx) * F4_CK + t_ch) + (3 * h) * (32 * F4_CK);
+  const int t_dst = ((t_ty * 8 + t_tx) * F4_VLD + t_ch) + (3 * h) * (32 * F4_VLD);
   auto transform = [&](int rbuf, int vbuf) {
 #ifdef F4_DIAG_NO_XFORM
     return;                                                  // timing-only build
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
       float o[6];
       f4_bt6(top[0][c], top[1][c], top[2][c], bot[0][c], bot[1][c], bot[2][c], o);
 #pragma unroll
-      for (int i = 0; i < 6; i++) dst[(i * 6 + c) * (32 * F4_CK)] = o[i];
+      for (int i = 0; i < 6; i++) dst[(i * 6 + c) * (32 * F4_VLD)] = o[i];
     }
   };
 
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
 
-  const int a_off = ((9 * pg) * 32 + r) * F4_CK + 4 * h;
+  const int a_off = ((9 * pg) * 32 + r) * F4_VLD + 4 * h;
   // multiply slice s (V[vbuf] x bq) and, position by position, request the NEXT slice's B fragment right after its last use
   auto multiply = [&](int vbuf, int next_slice) {
     const float *vsrc = vb + vbuf * F4_V_FLOATS + a_off;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
     f32x4 aq[3];
 #ifndef F4_DIAG_NO_AREAD
 #pragma unroll
-    for (int i = 0; i < 3; i++) aq[i] = *reinterpret_cast<const f32x4 *>(vsrc + i * (32 * F4_CK));
+    for (int i = 0; i < 3; i++) aq[i] = *reinterpret_cast<const f32x4 *>(vsrc + i * (32 * F4_VLD));
 #endif
 #pragma unroll
     for (int pi = 0; pi < 9; pi++) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
       acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[pi].z, acc[pi], 0, 0, 0);
       acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[pi].w, acc[pi], 0, 0, 0);
 #ifndef F4_DIAG_NO_AREAD
-      if (pi + 3 < 9) aq[pi % 3] = *reinterpret_cast<const f32x4 *>(vsrc + (pi + 3) * (32 * F4_CK));
+      if (pi + 3 < 9) aq[pi % 3] = *reinterpret_cast<const f32x4 *>(vsrc + (pi + 3) * (32 * F4_VLD));
 #endif
       b_load_one(next_slice, pi);
     }
