@@ -176,6 +176,62 @@ def cpu_baseline(conf, cfg, state, batch_points, metas, budget_s=25.0):
                 sample='%d x 1 frame (%d points), oracle/model.py forward incl. decode+NMS, torch CPU threads=%d' % (runs, pts.shape[0], cores))
 
 
+def cpu_baseline_lately(car_cfg, car_state, ego_cfg, ego_state, frame, budget_s=30.0):
+    """config 3 on the host cores: the oracle's basic_car forward for each of the 5 remote agents, its ingestion, its basic_ego forward
+    -- one frame per run, as many runs as fit the budget (at least 1)."""
+    import numpy as np
+    import torch
+    from oracle import exchange as oex
+    from oracle import model as omodel
+    from pcp_amd import synth
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+
+    def arch_of(cfg):
+        vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+        return omodel.arch_from_cfg(plain(cfg.MODEL), list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), list(vs))
+    car_arch, ego_arch = arch_of(car_cfg), arch_of(ego_cfg)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
+    torch.set_num_threads(cores)
+
+    def one():
+        e = frame['ego']
+        ego_rows = np.zeros((e.shape[0], 13), np.float32)
+        ego_rows[:, :5], ego_rows[:, 11:13] = e[:, :5], e[:, 5:7]
+        parts = [ego_rows]
+        for cloud, T in zip(frame['remote'], frame['target_se3_lidar']):
+            out = omodel.forward(synth.collate([cloud]), car_state, car_arch, metadata=[{}])
+            fb = out['final_box_dicts'][0]
+            modar = np.concatenate([np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores'])[:, None],
+                                    np.asarray(fb['pred_labels'], dtype=np.float32)[:, None]], 1).astype(np.float32)
+            hj = out['hunter']
+            fg, _ = oex.foreground_rows(np.asarray(hj['points']), np.asarray(hj['cls_logit']), np.asarray(hj['flow']))
+            if modar.shape[0]:
+                parts.append(oex.modar_ingest(modar, fg, T, frame['max_sweep_idx']))
+        omodel.forward(synth.collate([np.concatenate(parts, 0)]), ego_state, ego_arch, metadata=[{}])
+    t0 = time.time()
+    one()
+    warm = time.time() - t0
+    runs, spent = 0, 0.0
+    while runs < 1 or (spent + spent / max(runs, 1) < budget_s - warm and runs < 10):
+        t1 = time.time()
+        one()
+        spent += time.time() - t1
+        runs += 1
+    return dict(value=round(runs / spent, 4), unit='frames/s', cores=cores, kind='port',
+                sample='%d x 1 frame (6 agents x 60000 points: 5 oracle basic_car forwards + ingestion + 1 basic_ego forward), torch CPU threads=%d'
+                       % (runs, cores))
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # instrumented pass: HIP events around EVERY C-ABI launch on the launch stream (torch's current stream is the stream pcp_amd.ops passes)
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -408,11 +464,21 @@ def main(argv=None):
 
     lately = None
     if args.config == 'lately6':
+        # config 3 end to end: 5 remote agents run the basic_car detector on their own clouds (one stacked pass), their MoDAR + foreground
+        # rows are ingested on the device into the ego cloud, the basic_ego detector runs on the result (pcdet/models/lately_chain.py)
         from pcdet.models.lately_chain import LatelyFusionChain
+        from pcp_amd import synth
         car_cfg = load_cfg(CONFIGS['car']['yaml'])
-        car_model, _car_state, _ = build_model(car_cfg)
+        car_model, car_state, _ = build_model(car_cfg)
         car_model = car_model.to(dev).eval()
         lately = LatelyFusionChain(car_model, model, pipeline=not args.plugin_default)
+        lately_frames = []
+        for f in range(batch):
+            cl = lambda a: synth.agent_cloud(agent=1000 * rank + 10 * f + a, n_points=60000, layout='car', dist=args.dist)
+            lately_frames.append(dict(ego=cl(1), remote=[cl(a) for a in (0, 2, 3, 4, 5)],
+                               target_se3_lidar=[np.linalg.inv(synth.agent_pose(a)) for a in (0, 2, 3, 4, 5)], max_sweep_idx=10.0))
+        lately_inputs = LatelyFusionChain.build_inputs(lately_frames, dev)
+        lately_pristine = lately_inputs['remote_points'].clone()
 
     graphed = None
     if args.graph:
@@ -475,9 +541,10 @@ def main(argv=None):
             return train_step()
         if graphed is not None:
             return graphed(pristine)            # copy-in + every kernel of the path = one graph replay
-        work.copy_(pristine)                    # HunterJr corrects xyz in place: every step starts from the same bits
         if lately is not None:
-            return lately(work, batch, metas)
+            lately_inputs['remote_points'].copy_(lately_pristine)     # HunterJr corrects xyz in place: every step starts from the same bits
+            return lately(lately_inputs)
+        work.copy_(pristine)                    # HunterJr corrects xyz in place: every step starts from the same bits
         bd = {'points': work, 'batch_size': batch, 'metadata': metas}
         with torch.no_grad():
             pred_dicts, _ = model(bd)
@@ -592,8 +659,11 @@ def main(argv=None):
                                     'note': 'NOT the headline: 3x3 conv products as split bf16 (hi + lo, 16 mantissa bits; 3 bf16 MFMAs per '
                                             'product, f32 accumulate), ~1e-5 relative error, all parity tests pass at unchanged tolerances; '
                                             'enable with --conv-algo bf16x3 / PCP_CONV_ALGO=bf16x3'}
-        if not args.no_cpu_baseline and world == 1 and args.config != 'lately6':   # rank 0 at N = 1 only (the contract); N > 1 lines carry null
-            line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
+        if not args.no_cpu_baseline and world == 1:                    # rank 0 at N = 1 only (the contract); N > 1 lines carry null
+            if args.config == 'lately6':
+                line['cpu_baseline'] = cpu_baseline_lately(car_cfg, car_state, cfg, state, lately_frames[0])
+            else:
+                line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))

@@ -355,6 +355,23 @@ int pcp_hunter_foreground_rows(const float *points, int64_t n, int32_t row_strid
 int pcp_modar_ingest(const float *modar, int32_t n_modar, const float *foreground, int32_t n_foreground, int32_t foreground_cols,
                      const double *target_se3_lidar_host, float max_sweep_idx, float *rows, void *stream);
 
+/* The same ingestion for ALL remote agents of ALL frames at once, driven by device-resident counts (no host synchronisation; config 3 of
+ * BASELINE.json on one GPU: pcdet/models/lately_chain.py).  Group g = one (frame, remote agent) pair.
+ * det_*: (groups, det_max, 7) / (groups, det_max) float32 / (groups, det_max) int64 (1-based labels) / (groups,) int32 -- exactly what
+ *        pcp_gather_detections leaves for the stacked remote pass;
+ * foreground: (>= *foreground_count, cols) rows of pcp_hunter_foreground_rows over the stacked pass, foreground_group their frame-slot
+ *        index (ascending: the rows keep the original point order), foreground_count a device int32, max_foreground the row capacity;
+ * poses: device (groups, 12) float64 row-major 3x4 target_se3_lidar; max_sweep_idx: device (groups,) float32; frame_of_group: device
+ *        (groups,) int32 = the ego frame whose cloud receives the rows;
+ * rows:  (groups * det_max, 14) = [frame index | the 13 columns of pcp_modar_ingest]; padding slots carry frame index -1 (pcp_voxelize
+ *        drops them).  Same arithmetic as pcp_modar_ingest (first containing box wins a point, float32 mean * 2, float64 pose). */
+size_t pcp_modar_ingest_batched_workspace_bytes(int32_t groups, int64_t max_foreground);
+int pcp_modar_ingest_batched(const float *det_boxes, const float *det_scores, const int64_t *det_labels, const int32_t *det_count,
+                             int32_t groups, int32_t det_max, const float *foreground, int32_t foreground_cols,
+                             const int32_t *foreground_group, const int32_t *foreground_count, int64_t max_foreground,
+                             const double *poses, const float *max_sweep_idx, const int32_t *frame_of_group, void *workspace,
+                             size_t workspace_bytes, float *rows, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * SURVEY 8(f) row 3  AnchorHeadSingle: box decoding + class-agnostic candidate selection.
  * Replaces pcdet/models/dense_heads/anchor_head_template.py:225-272 (generate_predicted_boxes), pcdet/utils/box_coder_utils.py:46-78

@@ -161,9 +161,133 @@ __global__ __launch_bounds__(256) void k_modar_ingest(const float *__restrict__ 
   o[12] = -1.f;
 }
 
+// ---- batched, device-driven ingestion (config 3 on one GPU: all remote agents of all frames in three launches, no host sync) ----------
+//      group g = one (frame, remote agent) pair; detections as pcp_gather_detections leaves them (padded to det_max per group).
+
+__global__ void k_fg_box_index(const float *__restrict__ det_boxes, const int *__restrict__ det_count, int det_max, const float *__restrict__ fg,
+                               int fg_cols, const int *__restrict__ fg_group, const int *__restrict__ fg_count, int groups,
+                               int *__restrict__ box_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *fg_count) return;
+  const int g = fg_group[i];
+  int idx = -1;
+  if (g >= 0 && g < groups) {
+    const float *bx = det_boxes + (long long)g * det_max * 7;
+    const int nb = min(det_count[g], det_max);
+    const float *p = fg + (long long)i * fg_cols;
+    for (int k = 0; k < nb; ++k)
+      if (pt_in_box(p, bx + k * 7)) { idx = k; break; }       // points_in_boxes_gpu: the FIRST box that contains the point
+  }
+  box_idx[i] = idx;
+}
+
+// start[g] = first foreground row of group g (rows are in the original point order, i.e. ascending group), start[groups] = count
+__global__ void k_fg_group_starts(const int *__restrict__ fg_group, const int *__restrict__ fg_count, int groups, int *__restrict__ start) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > groups) return;
+  const int n = *fg_count;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (fg_group[mid] < g) lo = mid + 1; else hi = mid;
+  }
+  start[g] = lo;
+}
+
+struct PoseTableD {
+  const double *poses;          // device: [groups][12]
+  const float *max_sweep;       // device: [groups]
+  const int *frame;             // device: [groups] frame index written to column 0 of the emitted rows
+};
+
+__global__ __launch_bounds__(256) void k_modar_ingest_batched(const float *__restrict__ det_boxes, const float *__restrict__ det_scores,
+                                                             const long long *__restrict__ det_labels, const int *__restrict__ det_count,
+                                                             int det_max, const float *__restrict__ fg, int fg_cols,
+                                                             const int *__restrict__ box_idx, const int *__restrict__ start, PoseTableD pt,
+                                                             float *__restrict__ rows) {
+  __shared__ float red[4][4];
+  const int k = blockIdx.x, g = blockIdx.y;
+  float *o = rows + ((long long)g * det_max + k) * 14;
+  if (k >= det_count[g]) {                                   // padding slot: a row the pillariser drops (frame index -1)
+    if (threadIdx.x < 14) o[threadIdx.x] = threadIdx.x == 0 ? -1.f : 0.f;
+    return;
+  }
+  const float *bx = det_boxes + ((long long)g * det_max + k) * 7;
+  float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
+  for (int i = start[g] + threadIdx.x; i < start[g + 1]; i += blockDim.x) {
+    if (box_idx[i] != k) continue;
+    const float *p = fg + (long long)i * fg_cols;
+    sx += p[fg_cols - 3]; sy += p[fg_cols - 2]; sz += p[fg_cols - 1];
+    cnt += 1.f;
+  }
+  float v[4] = {sx, sy, sz, cnt};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int of = 32; of > 0; of >>= 1) v[q] += __shfl_down(v[q], of);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float tot[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tot[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+  float c[3] = {bx[0], bx[1], bx[2]};
+  if (tot[3] > 0.f) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = c[a] + (tot[a] / tot[3]) * 2.f;
+  }
+  const double *T = pt.poses + (long long)g * 12;
+  o[0] = (float)pt.frame[g];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    o[1 + a] = (float)((double)c[0] * T[4 * a] + (double)c[1] * T[4 * a + 1] + (double)c[2] * T[4 * a + 2] + T[4 * a + 3]);
+  o[4] = 0.f;
+  o[5] = 0.f;
+  o[6] = bx[3]; o[7] = bx[4]; o[8] = bx[5];
+  const float yaw = (float)((double)bx[6] + atan2(T[4], T[0]));
+  o[9] = atan2f(sinf(yaw), cosf(yaw));
+  o[10] = det_scores[(long long)g * det_max + k];
+  o[11] = (float)det_labels[(long long)g * det_max + k];
+  o[12] = pt.max_sweep[g];
+  o[13] = -1.f;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t pcp_modar_ingest_batched_workspace_bytes(int32_t groups, int64_t max_foreground) {
+  return pcp_align_up((size_t)(max_foreground > 0 ? max_foreground : 1) * 4, 256) + pcp_align_up((size_t)(groups + 2) * 4, 256);
+}
+
+int pcp_modar_ingest_batched(const float *det_boxes, const float *det_scores, const int64_t *det_labels, const int32_t *det_count,
+                             int32_t groups, int32_t det_max, const float *foreground, int32_t foreground_cols,
+                             const int32_t *foreground_group, const int32_t *foreground_count, int64_t max_foreground,
+                             const double *poses, const float *max_sweep_idx, const int32_t *frame_of_group, void *workspace,
+                             size_t workspace_bytes, float *rows, void *stream) {
+  if (groups <= 0 || det_max <= 0) return PCP_OK;
+  if (!det_boxes || !det_scores || !det_labels || !det_count || !poses || !max_sweep_idx || !frame_of_group || !workspace || !rows ||
+      !foreground_count || max_foreground < 0)
+    return PCP_ERR_ARG;
+  if (max_foreground > 0 && (!foreground || !foreground_group || foreground_cols < 6)) return PCP_ERR_ARG;
+  if (workspace_bytes < pcp_modar_ingest_batched_workspace_bytes(groups, max_foreground)) return PCP_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int *box_idx = (int *)workspace;
+  int *start = (int *)((char *)workspace + pcp_align_up((size_t)(max_foreground > 0 ? max_foreground : 1) * 4, 256));
+  if (max_foreground > 0) {
+    hipLaunchKernelGGL(k_fg_box_index, dim3((unsigned)((max_foreground + 255) / 256)), dim3(256), 0, s, det_boxes, det_count, det_max, foreground,
+                       foreground_cols, foreground_group, foreground_count, groups, box_idx);
+    PCP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_fg_group_starts, dim3((groups + 1 + 63) / 64), dim3(64), 0, s, foreground_group, foreground_count, groups, start);
+  PCP_CHECK_LAUNCH();
+  PoseTableD pt;
+  pt.poses = poses; pt.max_sweep = max_sweep_idx; pt.frame = frame_of_group;
+  hipLaunchKernelGGL(k_modar_ingest_batched, dim3(det_max, groups), dim3(256), 0, s, det_boxes, det_scores, (const long long *)det_labels,
+                     det_count, det_max, foreground, foreground_cols, box_idx, start, pt, rows);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
 
 int pcp_points_in_boxes(const float *boxes, int32_t batch, int32_t n_boxes, int32_t box_stride, const float *points, int32_t n_points,
                         int32_t point_stride, int32_t *box_idx, void *stream) {

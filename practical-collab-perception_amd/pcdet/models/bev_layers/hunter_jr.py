@@ -172,6 +172,8 @@ class HunterJr(PackedModule):
         ops.softmax_fuse_raw([cat.data_ptr(), cat.data_ptr() + 4 * C], lbuf, C, 2 * C, fused)
         batch_dict.pop('spatial_features_2d')
         batch_dict['spatial_features_2d'] = ops.nchw_view(fused)
+        if getattr(self, 'keep_point_heads', False):
+            batch_dict['hunter_point_heads'] = head8                                  # (N, 8): consumers that stay on the device
         if self.model_cfg.get('GENERATING_EXCHANGE_DATA', False) or self.model_cfg.get('RETURN_SCENE_FLOW', False):
             self._emit_foreground(batch_dict, points, head8)
         return batch_dict

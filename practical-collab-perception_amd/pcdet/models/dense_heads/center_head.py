@@ -169,6 +169,14 @@ class CenterHead(PackedModule):
     def finalize(self, per_head, batch_size):
         """one gather launch for all frames and heads (boxes[keep], scores[keep], class_id_mapping[labels[keep]] + 1, concatenated over
         heads: reference :335-357), then the one host sync of the path: how many boxes survive per frame -> exact-shape views."""
+        ob, os_, ol, cnt = self.gather_pending(per_head, batch_size)
+        counts = cnt.cpu().numpy()
+        return [dict(pred_boxes=ob[b, :int(counts[b])], pred_scores=os_[b, :int(counts[b])], pred_labels=ol[b, :int(counts[b])])
+                for b in range(batch_size)]
+
+    def gather_pending(self, per_head, batch_size):
+        """the gather launch of finalize() WITHOUT its host read: padded (B, M, 7) boxes, (B, M) scores, (B, M) int64 1-based labels and the
+        (B,) int32 counts, all on the device (consumers that stay on the device: pcdet/models/lately_chain.py)"""
         heads = []
         for boxes, scores, labels, keep, kcnt, idx in per_head:
             cmap = self._class_maps.get(idx) if hasattr(self, '_class_maps') else None
@@ -178,10 +186,7 @@ class CenterHead(PackedModule):
                 cmap = self.class_id_mapping_each_head[idx].to(device=boxes.device, dtype=torch.int32).contiguous()
                 self._class_maps[idx] = cmap
             heads.append(dict(boxes=boxes, scores=scores, labels=labels, keep=keep, keep_count=kcnt, class_map=cmap))
-        ob, os_, ol, cnt = ops.gather_detections(heads, batch_size)
-        counts = cnt.cpu().numpy()
-        return [dict(pred_boxes=ob[b, :int(counts[b])], pred_scores=os_[b, :int(counts[b])], pred_labels=ol[b, :int(counts[b])])
-                for b in range(batch_size)]
+        return ops.gather_detections(heads, batch_size)
 
     def generate_predicted_boxes(self, batch_size, head_bufs, pk):
         return self.finalize(self.device_postprocess(head_bufs, pk), batch_size)

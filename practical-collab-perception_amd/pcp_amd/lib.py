@@ -120,6 +120,8 @@ SYMBOLS = {
     'pcp_points_in_boxes': (c_i32, [vp, c_i32, c_i32, c_i32, vp, c_i32, c_i32, vp, vp]),
     'pcp_hunter_foreground_workspace_bytes': (c_sz, [c_i64]),
     'pcp_hunter_foreground_rows': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_f, vp, c_sz, vp, vp, vp, vp]),
+    'pcp_modar_ingest_batched_workspace_bytes': (c_sz, [c_i32, c_i64]),
+    'pcp_modar_ingest_batched': (c_i32, [vp, vp, vp, vp, c_i32, c_i32, vp, c_i32, vp, vp, c_i64, vp, vp, vp, vp, c_sz, vp, vp]),
     'pcp_modar_ingest': (c_i32, [vp, c_i32, vp, c_i32, c_i32, ctypes.POINTER(ctypes.c_double), c_f, vp, vp]),
 }
 

@@ -562,9 +562,10 @@ def points_in_boxes(points, boxes):
     return out
 
 
-def hunter_foreground_rows(points, head, thresh_bg=0.3):
+def hunter_foreground_rows(points, head, thresh_bg=0.3, sync=True):
     """points (N, 1+F) with the frame index in column 0, head (N, >=6) = [cls logits(3), flow(3), ...].
-    Returns (rows (n_send, F+6), row_batch (n_send,) int32) in the original row order; one host sync for n_send."""
+    Returns (rows (n_send, F+6), row_batch (n_send,) int32) in the original row order; one host sync for n_send.
+    sync=False: no host sync -- returns the full-capacity buffers and the device count: (rows (N, F+6), row_batch (N,), count (1,) int32)."""
     _need_cuda(points, head)
     L = _lib.load()
     n, stride = points.shape
@@ -575,8 +576,37 @@ def hunter_foreground_rows(points, head, thresh_bg=0.3):
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     check(L.pcp_hunter_foreground_rows(_p(points), n, stride, _p(head), head.shape[1], float(thresh_bg), _p(ws), ws.numel(), _p(rows), _p(rb),
                                        _p(cnt), _stream()), 'pcp_hunter_foreground_rows')
+    if not sync:
+        return rows, rb, cnt
     k = int(cnt.item())
     return rows[:k], rb[:k]
+
+
+def modar_ingest_batched(det, foreground, fg_group, fg_count, poses, max_sweep_idx, frame_of_group, out=None):
+    """Device-driven ingestion of every (frame, remote agent) group at once (include/pcp_hip.h: pcp_modar_ingest_batched).
+    det = (boxes (G, M, 7), scores (G, M), labels (G, M) int64, count (G,) int32) as ops.gather_detections returns them;
+    foreground (cap, cols), fg_group (cap,) int32, fg_count (1,) int32 as hunter_foreground_rows(sync=False) returns them (or None);
+    poses (G, 12) float64 / max_sweep_idx (G,) float32 / frame_of_group (G,) int32 DEVICE tensors.  Returns (G * M, 14) rows."""
+    boxes, scores, labels, count = det
+    _need_cuda(boxes, scores, labels, count, foreground, fg_group, fg_count, poses, max_sweep_idx, frame_of_group, out)
+    L = _lib.load()
+    G, M = int(boxes.shape[0]), int(boxes.shape[1])
+    dev = boxes.device
+    assert boxes.is_contiguous() and scores.is_contiguous() and labels.is_contiguous() and labels.dtype == torch.int64
+    assert poses.dtype == torch.float64 and poses.is_contiguous() and tuple(poses.shape) == (G, 12)
+    assert max_sweep_idx.dtype == torch.float32 and frame_of_group.dtype == torch.int32
+    cap, cols = (0, 0) if foreground is None else (int(foreground.shape[0]), int(foreground.shape[1]))
+    if foreground is None:
+        fg_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    need = L.pcp_modar_ingest_batched_workspace_bytes(G, cap)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty((G * M, 14), dtype=torch.float32, device=dev)
+    assert out.is_contiguous() and tuple(out.shape) == (G * M, 14)
+    check(L.pcp_modar_ingest_batched(_p(boxes), _p(scores), _p(labels), _p(count), G, M, _p(foreground), cols, _p(fg_group), _p(fg_count), cap,
+                                     _p(poses), _p(max_sweep_idx), _p(frame_of_group), _p(ws), ws.numel(), _p(out), _stream()),
+          'pcp_modar_ingest_batched')
+    return out
 
 
 def modar_ingest(modar, foreground, target_se3_lidar, max_sweep_idx):

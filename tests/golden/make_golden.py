@@ -775,6 +775,102 @@ def g9_anchor(tag, multi_class):
           'labels', [np.bincount(out['final_labels_%d' % b], minlength=4).tolist() for b in range(2)])
 
 
+G10_SEG_BIAS_SHIFT = 1.0
+
+
+def g10_lately_chain():
+    """BASELINE config 3 end to end on the mini geometry, produced by chaining the REFERENCE'S OWN pieces: for every (frame, remote agent)
+    pair the reference's basic_car model with RETURN_MODAR_POINTS / RETURN_SCENE_FLOW (center_head.py:409-427, hunter_jr.py:377-397), the
+    ego-side ingestion lines of v2x_sim_dataset_ego.py:196-232 (torch.unique + scatter(mean) through the shim, its own apply_se3_;
+    points_in_boxes_gpu is CUDA-only: indices from oracle/exchange.py, stored as data), then the reference's basic_ego model on the
+    augmented cloud.  2 frames x 5 remote agents, 2 000 points per cloud."""
+    rh.install()
+    sys.path.insert(0, REPO)
+    from oracle import exchange as oex
+    from pcdet.datasets.nuscenes.nuscenes_temporal_utils import apply_se3_
+    from torch_scatter import scatter
+    car_cfg = rh.load_cfg('v2x_pointpillar_basic_car.yaml', {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE})
+    car_cfg.MODEL.DENSE_HEAD.RETURN_MODAR_POINTS = True
+    car_cfg.MODEL.CORRECTOR.RETURN_SCENE_FLOW = True
+    car, _ = rh.build_model(car_cfg)
+    car_shapes = fill_weights(car)
+    # with the synthetic fill no point is ever foreground (P(background) ~ 0.5 everywhere) and the flow propagation would go untested:
+    # lower the background logit's bias (the test applies the same shift, recorded in the meta)
+    with torch.no_grad():
+        car.corrector.point_head.seg[0].bias[0] -= G10_SEG_BIAS_SHIFT
+    ego_cfg = rh.load_cfg('v2x_pointpillar_basic_ego.yaml', {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE,
+                                                             'MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH': 0.02})
+    ego, _ = rh.build_model(ego_cfg)
+    ego_shapes = fill_weights(ego)
+    B, remote_agents, n_pts = 2, (0, 2, 3, 4, 5), 2000
+    out = {}
+    ego_rows = []
+    for f in range(B):
+        ego_cloud = synth.agent_cloud(agent=200 + 10 * f + 1, n_points=n_pts, layout='car', xy_half=13.1)
+        out['ego_cloud_%d' % f] = ego_cloud
+        max_sweep_idx = float(ego_cloud[:, -2].max())
+        out['max_sweep_idx_%d' % f] = np.array(max_sweep_idx)
+        pts13 = np.zeros((ego_cloud.shape[0], 13))
+        pts13[:, :5] = ego_cloud[:, :5]
+        pts13[:, -2:] = ego_cloud[:, -2:]
+        for slot, a in enumerate(remote_agents):
+            cloud = synth.agent_cloud(agent=200 + 10 * f + a, n_points=n_pts, layout='car', xy_half=13.1)
+            pose = np.linalg.inv(synth.agent_pose(a))                       # remote lidar -> ego frame
+            pose[:3, 3] *= 0.25                                             # keep the mapped boxes inside the mini range
+            key = '%d_%d' % (f, slot)
+            out['remote_cloud_' + key] = cloud
+            out['target_se3_lidar_' + key] = pose
+            bd = {'points': torch.from_numpy(synth.collate([cloud]).copy()), 'batch_size': 1,
+                  'metadata': [{'sample_token': 'f%d' % f, 'lidar_id': a}]}
+            with torch.no_grad():
+                for mod in car.module_list:
+                    bd = mod(bd)
+            modar = bd['mo_pts'].numpy().copy() if 'mo_pts' in bd else np.zeros((0, 9), np.float32)
+            fg = bd['scene_flow'].numpy().copy() if 'scene_flow' in bd else np.zeros((0, 13), np.float32)
+            out['modar_' + key], out['foreground_' + key] = modar, fg
+            # ---- the reference's ingestion lines (v2x_sim_dataset_ego.py:203-232) ----
+            modar_t = torch.from_numpy(modar.copy())
+            if fg.shape[0] > 0 and modar.shape[0] > 0:
+                foregr = torch.from_numpy(fg.copy())
+                box_idx = torch.from_numpy(oex.points_in_boxes(fg[:, :3], modar[:, :7])).long()
+                out['box_idx_' + key] = box_idx.numpy().astype(np.int32)
+                mask_valid = box_idx > -1
+                foregr, bi = foregr[mask_valid], box_idx[mask_valid]
+                if bi.numel() > 0:
+                    unq_box_idx, inv = torch.unique(bi, return_inverse=True)
+                    boxes_offset = scatter(foregr[:, -3:], inv, dim=0, reduce='mean') * 2.
+                    modar_t[unq_box_idx, :3] += boxes_offset
+            m = modar_t.numpy()
+            if m.shape[0] > 0:
+                m[:, :7] = apply_se3_(pose, boxes_=m[:, :7], return_transformed=True)
+            modar_ = np.zeros((m.shape[0], 13))
+            modar_[:, :3] = m[:, :3]
+            modar_[:, 4] = 0.
+            modar_[:, 5:11] = m[:, 3:]
+            modar_[:, -2] = max_sweep_idx
+            modar_[:, -1] = -1
+            out['ingest_rows_' + key] = modar_.astype(np.float32)
+            pts13 = np.concatenate((pts13, modar_))
+        ego_rows.append(pts13.astype(np.float32))
+        print('g10 frame', f, 'modar', [out['modar_%d_%d' % (f, s)].shape[0] for s in range(5)], 'foreground',
+              [out['foreground_%d_%d' % (f, s)].shape[0] for s in range(5)])
+    ego_pts = synth.collate(ego_rows)
+    out['ego_points'] = ego_pts
+    bd = {'points': torch.from_numpy(ego_pts.copy()), 'batch_size': B, 'metadata': [{} for _ in range(B)]}
+    with torch.no_grad(), PostCapture(ego) as post:
+        bd, _ = run_modules(ego, bd)
+    capture_common(ego, bd, out)
+    post.dump(out)
+    out['meta_json'] = np.array(json.dumps(dict(
+        car=dict(model=rh.to_plain(car_cfg.MODEL), pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(car_cfg.CLASS_NAMES),
+                 yaml='v2x_pointpillar_basic_car.yaml', layout='car', state_shapes=car_shapes),
+        ego=dict(model=rh.to_plain(ego_cfg.MODEL), pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(ego_cfg.CLASS_NAMES),
+                 yaml='v2x_pointpillar_basic_ego.yaml', layout='lately', state_shapes=ego_shapes),
+        frames=B, remote_agents=list(remote_agents), car_seg_bias_shift=G10_SEG_BIAS_SHIFT)))
+    np.savez_compressed(os.path.join(HERE, 'g10_lately_chain.npz'), **out)
+    print('g10 ego P', out['voxel_coords'].shape[0], 'final', [out['final_boxes_%d' % b].shape[0] for b in range(B)])
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
@@ -799,6 +895,8 @@ if __name__ == '__main__':
         g7b_train_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately')
     if 'g8' in todo:
         g8_exchange()
+    if 'g10' in todo:
+        g10_lately_chain()
     if 'g9' in todo:
         g9_anchor('agnostic', False)     # MULTI_CLASSES_NMS with a single (non multi-head) AnchorHeadSingle trips the reference's own
                                          # assertion (detector3d_template.py:283,295: arange(1, num_class) has num_class - 1 entries)

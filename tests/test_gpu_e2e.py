@@ -661,3 +661,90 @@ def test_pipeline_mode_survives_dense_sparse_dense_switches():
         want = run(fresh(), pts)
         for g, w in zip(got, want):
             assert g.shape == w.shape and torch.equal(g, w), 'frame %d differs from a fresh model (stale canvas)' % i
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3: lately fusion end to end on one GPU (pcdet/models/lately_chain.py) vs the chained reference (g10)
+# ---------------------------------------------------------------------------------------------------------------------
+def _g10_models(g):
+    from pcdet.models import build_network_from_meta
+    meta = g['meta']
+    car = build_network_from_meta(meta['car'])
+    st = synth.fill_state_dict(meta['car']['state_shapes'])
+    st['corrector.point_head.seg.0.bias'] = st['corrector.point_head.seg.0.bias'].copy()
+    st['corrector.point_head.seg.0.bias'][0] -= np.float32(meta['car_seg_bias_shift'])
+    car.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    ego = build_network_from_meta(meta['ego'])
+    ste = synth.fill_state_dict(meta['ego']['state_shapes'])
+    ego.load_state_dict({k: torch.from_numpy(v) for k, v in ste.items()})
+    return car.cuda().eval(), ego.cuda().eval()
+
+
+def _g10_frames(g):
+    meta = g['meta']
+    frames = []
+    for f in range(meta['frames']):
+        n = len(meta['remote_agents'])
+        frames.append(dict(ego=g['ego_cloud_%d' % f], remote=[g['remote_cloud_%d_%d' % (f, s)] for s in range(n)],
+                           target_se3_lidar=[g['target_se3_lidar_%d_%d' % (f, s)] for s in range(n)],
+                           max_sweep_idx=float(g['max_sweep_idx_%d' % f])))
+    return frames
+
+
+@pytest.mark.parametrize('pipeline', [False, True])
+def test_lately_fusion_chain_matches_the_chained_reference(pipeline):
+    """remote detector (all 10 (frame, agent) pairs stacked) -> foreground rows + padded detections -> batched device-side ingestion ->
+    ego detector, no host sync in between; every stage against what the REFERENCE produced at that stage (g10), then the final boxes"""
+    from oracle import exchange as oex
+    from pcdet.models.lately_chain import LatelyFusionChain
+    g = load_golden('g10_lately_chain.npz')
+    meta = g['meta']
+    car, ego = _g10_models(g)
+    chain = LatelyFusionChain(car, ego, pipeline=pipeline)
+    inputs = LatelyFusionChain.build_inputs(_g10_frames(g), torch.device('cuda', 0))
+    preds = chain(inputs)
+    torch.cuda.synchronize()
+    B, n_rem = meta['frames'], len(meta['remote_agents'])
+    ob, os_, ol, cnt = [t.cpu().numpy() for t in chain.last['detections']]
+    rows, row_group, n_rows = chain.last['foreground']
+    n_rows = int(n_rows.item())
+    rows, row_group = rows[:n_rows].cpu().numpy(), row_group[:n_rows].cpu().numpy()
+    modar_rows = chain.last['modar_rows'].cpu().numpy().reshape(B * n_rem, -1, 14)
+    for f in range(B):
+        for s in range(n_rem):
+            grp, key = f * n_rem + s, '%d_%d' % (f, s)
+            want = g['modar_' + key]
+            # stage 1a: the remote detections (as sets: see _check_detections on why a couple may differ)
+            k = int(cnt[grp])
+            assert abs(k - want.shape[0]) <= 1 and bool((ol[grp, :k] == 1).all())
+            n, worst = match_boxes(want[:, :7], want[:, 7], ob[grp, :k], os_[grp, :k], tol=1e-3)
+            assert n >= want.shape[0] - 2, (key, n, worst)
+            # stage 1b: the foreground rows (every point is foreground in this fixture), xyz already flow-corrected in place
+            fg = rows[row_group == grp]
+            assert fg.shape == g['foreground_' + key].shape
+            np.testing.assert_allclose(fg, g['foreground_' + key], rtol=0, atol=2e-4)
+            # stage 2 inside the chain: rows written for this group = the ingestion of ITS OWN detections and foreground rows (oracle)
+            mine = np.concatenate([ob[grp, :k], os_[grp, :k, None], ol[grp, :k, None].astype(np.float32)], 1)
+            ref_rows = oex.modar_ingest(mine, fg, g['target_se3_lidar_' + key], float(g['max_sweep_idx_%d' % f]))
+            got = modar_rows[grp]
+            assert bool((got[:k, 0] == f).all()) and bool((got[k:, 0] == -1).all())
+            np.testing.assert_allclose(got[:k, 1:], ref_rows, rtol=0, atol=2e-5)
+    # stage 3 + the whole chain: final boxes of the ego pass vs the reference's (tolerant: two fp32 detectors in series)
+    for b in range(B):
+        gb, gs = g['final_boxes_%d' % b], g['final_scores_%d' % b]
+        pb, ps = preds[b]['pred_boxes'].cpu().numpy(), preds[b]['pred_scores'].cpu().numpy()
+        assert abs(pb.shape[0] - gb.shape[0]) <= 2
+        n, worst = match_boxes(gb, gs, pb, ps, tol=2e-3)
+        assert n >= gb.shape[0] - 8, (b, n, gb.shape[0], worst)
+
+
+def test_lately_fusion_ego_stage_on_the_reference_rows():
+    """the ego detector on EXACTLY the augmented cloud the reference built (ego points + its ingested MoDAR rows): pillars bit exact, maps
+    1e-3, decode + NMS exact on the reference's head maps"""
+    g = load_golden('g10_lately_chain.npz')
+    _car, ego = _g10_models(g)
+    batch = {'points': torch.from_numpy(g['ego_points']).cuda(), 'batch_size': 2, 'metadata': [{}, {}]}
+    with torch.no_grad():
+        pred_dicts, _ = ego(batch)
+    _check_common(g, batch, pred_dicts)
+    _check_postprocessing_is_exact(ego, g, 'head_', 2, ['final_boxes_%d', 'final_scores_%d', 'post_%d_near_iou', 'post_%d_near_score'])

@@ -920,3 +920,56 @@ def test_select_transform_points_bit_equal_to_the_reference():
         assert rows.shape[0] == int(g['car_agent_%d_rows' % a]) == 60000
         assert np.array_equal(rows[:8, 1:4], g['car_agent_%d_xyz_head' % a])
         assert hashlib.sha256(np.ascontiguousarray(rows[:, 1:4]).tobytes()).hexdigest() == str(g['car_agent_%d_xyz_sha' % a])
+
+
+def test_modar_ingest_batched_equals_the_per_pair_ingestion():
+    """pcp_modar_ingest_batched (all (frame, remote agent) groups in one device-driven call, padded detections, device counts) against
+    the per-pair oracle on the reference's MoDAR + foreground rows of tests/golden/g10_lately_chain.npz; ragged groups, an empty group and
+    a group without foreground rows included"""
+    ops = _ops()
+    from oracle import exchange as oex
+    g = load_golden('g10_lately_chain.npz')
+    meta = g['meta']
+    keys = ['%d_%d' % (f, s) for f in range(meta['frames']) for s in range(len(meta['remote_agents']))]
+    G, M = len(keys), 83
+    counts = [g['modar_' + k].shape[0] for k in keys]
+    counts[2], counts[5] = 40, 0                                  # ragged + empty group
+    fg_keep = [True] * G
+    fg_keep[7] = False                                            # a group that sent no foreground rows
+    boxes = np.zeros((G, M, 7), np.float32)
+    scores = np.zeros((G, M), np.float32)
+    labels = np.zeros((G, M), np.int64)
+    fg_rows, fg_group = [], []
+    for i, k in enumerate(keys):
+        m = g['modar_' + k][:counts[i]]
+        boxes[i, :counts[i]], scores[i, :counts[i]], labels[i, :counts[i]] = m[:, :7], m[:, 7], m[:, 8].astype(np.int64)
+        if fg_keep[i]:
+            fg_rows.append(g['foreground_' + k])
+            fg_group.append(np.full(g['foreground_' + k].shape[0], i, np.int32))
+    fg_rows, fg_group = np.concatenate(fg_rows, 0), np.concatenate(fg_group, 0)
+    cap = fg_rows.shape[0] + 100                                  # capacity beyond the count: the tail must be ignored
+    fg_buf = np.full((cap, fg_rows.shape[1]), 1e9, np.float32)
+    fg_buf[:fg_rows.shape[0]] = fg_rows
+    grp_buf = np.full(cap, 3, np.int32)
+    grp_buf[:fg_group.shape[0]] = fg_group
+    poses = np.stack([np.asarray(g['target_se3_lidar_' + k], np.float64)[:3, :4].reshape(-1) for k in keys], 0)
+    sweeps = np.array([float(g['max_sweep_idx_%d' % int(k[0])]) for k in keys], np.float32)
+    frames = np.array([int(k[0]) for k in keys], np.int32)
+    d = dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    out = ops.modar_ingest_batched((t(boxes), t(scores), t(labels), t(np.array(counts, np.int32))), t(fg_buf), t(grp_buf),
+                                   t(np.array([fg_rows.shape[0]], np.int32)), t(poses), t(sweeps), t(frames)).cpu().numpy().reshape(G, M, 14)
+    for i, k in enumerate(keys):
+        n = counts[i]
+        assert bool((out[i, n:, 0] == -1).all()) and bool((out[i, :n, 0] == frames[i]).all())
+        if n == 0:
+            continue
+        want = oex.modar_ingest(g['modar_' + k][:n], g['foreground_' + k] if fg_keep[i] else None, g['target_se3_lidar_' + k], float(sweeps[i]))
+        np.testing.assert_allclose(out[i, :n, 1:], want, rtol=0, atol=5e-6)
+        if n == g['modar_' + k].shape[0] and fg_keep[i]:
+            np.testing.assert_allclose(out[i, :n, 1:], g['ingest_rows_' + k], rtol=0, atol=5e-6)      # = the reference's own rows
+    # no foreground at all
+    out2 = ops.modar_ingest_batched((t(boxes), t(scores), t(labels), t(np.array(counts, np.int32))), None, None, None, t(poses), t(sweeps),
+                                    t(frames)).cpu().numpy().reshape(G, M, 14)
+    want = oex.modar_ingest(g['modar_' + keys[0]], None, g['target_se3_lidar_' + keys[0]], float(sweeps[0]))
+    np.testing.assert_allclose(out2[0, :counts[0], 1:], want, rtol=0, atol=5e-6)

@@ -308,3 +308,45 @@ def test_g2_full_size_forward(tag, yaml_name, layout, n_agents):
     assert g[tag + '_post_0_near_iou'].shape[0] == 0 and g[tag + '_post_0_near_score'].shape[0] == 0
     fin = obev.head_postprocess({k: torch.from_numpy(g[tag + '_head_' + k]) for k in ('center', 'center_z', 'dim', 'rot', 'hm')}, arch)[0]
     assert_same_final_set(gb, gs, np.asarray(fin['pred_boxes']), np.asarray(fin['pred_scores']))
+
+
+def test_g10_lately_fusion_chain():
+    """BASELINE config 3 end to end (tests/golden/g10_lately_chain.npz: the reference's basic_car model per remote agent -> its ingestion
+    lines -> its basic_ego model).  The oracle restates every stage; each is pinned on the REFERENCE'S inputs to that stage:
+    remote detector (detections, foreground rows), ingestion (rows, tight), ego detector (maps, detections)."""
+    from helpers import assert_same_final_set
+    from oracle import bev as obev
+    from oracle import exchange as oex
+    g = load_golden('g10_lately_chain.npz')
+    meta = g['meta']
+    car_arch, ego_arch = arch_of(meta['car']), arch_of(meta['ego'])
+    car_state = _filled_state(meta['car']['state_shapes'])
+    car_state['corrector.point_head.seg.0.bias'] = car_state['corrector.point_head.seg.0.bias'].copy()
+    car_state['corrector.point_head.seg.0.bias'][0] -= np.float32(meta['car_seg_bias_shift'])
+    ego_state = _filled_state(meta['ego']['state_shapes'])
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    for f in range(meta['frames']):
+        for slot in range(len(meta['remote_agents'])):
+            key = '%d_%d' % (f, slot)
+            # ---- ingestion on the reference's own MoDAR + foreground rows: tight
+            rows = oex.modar_ingest(g['modar_' + key], g['foreground_' + key], g['target_se3_lidar_' + key], float(g['max_sweep_idx_%d' % f]))
+            np.testing.assert_allclose(rows, g['ingest_rows_' + key], rtol=0, atol=3e-6)
+            if (f, slot) not in ((0, 0), (1, 3)):
+                continue                                            # two of the ten remote passes keep the CPU suite short
+            out = omodel.forward(synth.collate([g['remote_cloud_' + key]]), car_state, car_arch, metadata=[{}])
+            fb = out['final_box_dicts'][0]
+            modar = g['modar_' + key]
+            n, worst = match_boxes(modar[:, :7], modar[:, 7], np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
+            assert n >= modar.shape[0] - 2, (key, n, worst)
+            hj = out['hunter']
+            # hunter_jr.py:265 corrects the xyz of predicted-dynamic points in place BEFORE the rows are cut (:377-397)
+            fg_rows, _ = oex.foreground_rows(np.asarray(hj['points']), np.asarray(hj['cls_logit']), np.asarray(hj['flow']))
+            assert fg_rows.shape == g['foreground_' + key].shape
+            np.testing.assert_allclose(fg_rows, g['foreground_' + key], rtol=0, atol=2e-4)
+    out = omodel.forward(g['ego_points'], ego_state, ego_arch, metadata=[{}, {}])
+    assert np.array_equal(out['voxel_coords'], g['voxel_coords'])
+    np.testing.assert_allclose(np.asarray(out['pillar_features']), g['pillar_features'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(np.asarray(out['spatial_features_2d']), g['spatial_features_2d'], rtol=0, atol=3e-4)
+    for b in range(meta['frames']):
+        fin = obev.head_postprocess({k: torch.from_numpy(g['head_' + k]) for k in ('center', 'center_z', 'dim', 'rot', 'hm')}, ego_arch)[b]
+        assert_same_final_set(g['final_boxes_%d' % b], g['final_scores_%d' % b], np.asarray(fin['pred_boxes']), np.asarray(fin['pred_scores']))
