@@ -153,6 +153,52 @@ int pcp_disco_fuse_backward(const float *const *maps_host, int32_t n_agents, int
                             int32_t accumulate, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a16  AnchorHeadSingle training (MODEL.NAME PointPillar): target assignment, the three losses and dL/d(head maps).
+ * Replaces: pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:37-210 (assign_targets: python loop over frames x
+ *           anchor classes, an anchors x boxes IoU matrix and .nonzero() host syncs per pair), pcdet/utils/box_utils.py:291-340
+ *           (boxes3d_nearest_bev_iou), pcdet/utils/box_coder_utils.py:13-44 (ResidualCoder.encode_torch),
+ *           pcdet/models/dense_heads/anchor_head_template.py:99-216 (get_cls_layer_loss, add_sin_difference, get_direction_target,
+ *           get_box_reg_layer_loss, get_loss), pcdet/utils/loss_utils.py:9-148,180-208 (SigmoidFocalClassificationLoss,
+ *           WeightedSmoothL1Loss, WeightedCrossEntropyLoss) and their autograd.
+ * Covers POS_FRACTION < 0, MATCH_HEIGHT False, NORM_BY_NUM_EXAMPLES False, ResidualCoder without sin/cos (every anchor YAML of the
+ * reference).  Anchors are flat in the order of torch.cat(anchors, dim=-3).view(-1, 7): index = (y * W + x) * A + slot.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define PCP_ANCHOR_MAX_SLOTS 32
+#define PCP_ANCHOR_MAX_GROUPS 8
+typedef struct {
+  int32_t batch, h, w;                          /* feature map */
+  int32_t anchors_per_loc;                      /* A */
+  int32_t num_class;                            /* len(CLASS_NAMES); box class c names CLASS_NAMES[c - 1] (0 wraps to the last, like numpy) */
+  int32_t num_groups;                           /* ANCHOR_GENERATOR_CONFIG entries (anchor classes) */
+  int32_t slot_group[PCP_ANCHOR_MAX_SLOTS];     /* anchor class of each per-location slot */
+  int32_t group_class[PCP_ANCHOR_MAX_GROUPS];   /* 0-based index of the anchor class's class_name in CLASS_NAMES (-1: not a detected class) */
+  float matched[PCP_ANCHOR_MAX_GROUPS], unmatched[PCP_ANCHOR_MAX_GROUPS];
+} pcp_anchor_assign_t;
+
+size_t pcp_anchor_assign_workspace_bytes(const pcp_anchor_assign_t *desc, int32_t max_boxes);
+/* anchors (H*W*A, 7); gt_boxes (B, max_boxes, 8) [x,y,z,dx,dy,dz,heading,class], max_boxes <= 1024 (0: no boxes at all).
+ * Outputs: labels (B, N) int32 (-1 ignored, 0 background, > 0 class), reg_targets (B, N, 7), reg_weights (B, N). */
+int pcp_anchor_assign_targets(const pcp_anchor_assign_t *desc, const float *anchors, const float *gt_boxes, int32_t max_boxes,
+                              void *workspace, size_t workspace_bytes, int32_t *labels, float *reg_targets, float *reg_weights,
+                              void *stream);
+
+typedef struct {
+  int32_t batch, h, w;
+  int32_t ld, ld_d;                             /* pixel stride of the head buffer / of the gradient buffer (same channel numbering) */
+  int32_t anchors_per_loc, num_class, num_dir_bins;     /* num_dir_bins 0: no direction classifier */
+  int32_t ch_cls, ch_box, ch_dir;               /* first channel of conv_cls / conv_box / conv_dir_cls outputs */
+  float dir_offset, dir_period;                 /* DIR_OFFSET, 2 pi / NUM_DIR_BINS */
+  float cls_weight, loc_weight, dir_weight, code_weights[7];
+} pcp_anchor_loss_t;
+
+size_t pcp_anchor_loss_workspace_bytes(int32_t batch);
+/* losses (5,) float32 device: [rpn_loss_cls, rpn_loss_loc, rpn_loss_dir, rpn_loss, positives].  dhead (B, H, W, ld_d) or NULL: every
+ * channel written (padding channels zero), scaled by grad_scale. */
+int pcp_anchor_loss(const pcp_anchor_loss_t *desc, const float *head, const float *anchors, const int32_t *labels,
+                    const float *reg_targets, float grad_scale, void *workspace, size_t workspace_bytes, float *losses, float *dhead,
+                    void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers: global-norm clipping + Adam with decoupled weight decay.
  * Replaces tools/train_utils/train_utils.py:57-58 (clip_grad_norm_ + optimizer.step()) and
  *          tools/train_utils/optimization/fastai_optim.py:104-122 (p.mul_(1 - wd * lr); torch.optim.Adam.step, betas (mom, 0.99)).

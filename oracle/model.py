@@ -27,14 +27,17 @@ def arch_from_cfg(model_cfg, pc_range, voxel_size):
                 grid_size=[int(v) for v in grid])
     arch.update(vfe_bb(model_cfg))
     hd = model_cfg['DENSE_HEAD']
-    pp = hd['POST_PROCESSING']
-    heads = [(n, hd['SEPARATE_HEAD_CFG']['HEAD_DICT'][n]['out_channels']) for n in hd['SEPARATE_HEAD_CFG']['HEAD_ORDER']]
-    heads.append(('hm', len(hd['CLASS_NAMES_EACH_HEAD'][0])))
-    arch['head'] = dict(shared=hd['SHARED_CONV_CHANNEL'], heads=heads, num_conv=hd['NUM_HM_CONV'],
-                        stride=hd['TARGET_ASSIGNER_CONFIG']['FEATURE_MAP_STRIDE'], max_obj=pp['MAX_OBJ_PER_SAMPLE'],
-                        score_thresh=pp['SCORE_THRESH'], limit_range=list(pp['POST_CENTER_LIMIT_RANGE']),
-                        nms_thresh=pp['NMS_CONFIG']['NMS_THRESH'], nms_pre=pp['NMS_CONFIG']['NMS_PRE_MAXSIZE'],
-                        nms_post=pp['NMS_CONFIG']['NMS_POST_MAXSIZE'])
+    if hd['NAME'] == 'AnchorHeadSingle':                   # MODEL.NAME PointPillar: oracle/anchor.py reads the head block itself
+        arch['head'] = dict(kind='anchor', cfg=hd)
+    else:
+        pp = hd['POST_PROCESSING']
+        heads = [(n, hd['SEPARATE_HEAD_CFG']['HEAD_DICT'][n]['out_channels']) for n in hd['SEPARATE_HEAD_CFG']['HEAD_ORDER']]
+        heads.append(('hm', len(hd['CLASS_NAMES_EACH_HEAD'][0])))
+        arch['head'] = dict(shared=hd['SHARED_CONV_CHANNEL'], heads=heads, num_conv=hd['NUM_HM_CONV'],
+                            stride=hd['TARGET_ASSIGNER_CONFIG']['FEATURE_MAP_STRIDE'], max_obj=pp['MAX_OBJ_PER_SAMPLE'],
+                            score_thresh=pp['SCORE_THRESH'], limit_range=list(pp['POST_CENTER_LIMIT_RANGE']),
+                            nms_thresh=pp['NMS_CONFIG']['NMS_THRESH'], nms_pre=pp['NMS_CONFIG']['NMS_PRE_MAXSIZE'],
+                            nms_post=pp['NMS_CONFIG']['NMS_POST_MAXSIZE'])
     co = g(model_cfg, 'CORRECTOR')
     arch['corrector'] = None if co is None else dict(
         bev_stride=co['BEV_IMAGE_STRIDE'], point_hidden=list(co['POINT_HEAD_HIDDEN_CHANNELS']),

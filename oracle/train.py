@@ -260,8 +260,11 @@ def head_train(x, st, arch, prefix='dense_head'):
     return out
 
 
-def add_train_arch(arch, model_cfg):
+def add_train_arch(arch, model_cfg, class_names=None):
     hd = model_cfg['DENSE_HEAD']
+    if arch['head'].get('kind') == 'anchor':
+        arch['head']['class_names'] = list(class_names)
+        return arch
     ta = hd['TARGET_ASSIGNER_CONFIG']
     lw = hd['LOSS_CONFIG']['LOSS_WEIGHTS']
     arch['head'].update(num_max_objs=ta['NUM_MAX_OBJS'], gaussian_overlap=ta['GAUSSIAN_OVERLAP'], min_radius=ta['MIN_RADIUS'],
@@ -321,6 +324,19 @@ def train_forward(points, gt_boxes, metadata, st, arch, probe=None):
             aux['backbone_out'].retain_grad()
         loss_distill = distill_loss(m, bev_early.to(dt))
         aux['fused'] = m
+    if arch['head'].get('kind') == 'anchor':               # MODEL.NAME PointPillar (pointpillar.py:20-33): loss = dense_head.get_loss()
+        from . import anchor as oan
+        hc, names = arch['head']['cfg'], arch['head']['class_names']
+        cls, box, dirp = oan.head_train_forward(m, st, hc)
+        anchor_list = [oan.generate_anchors([c], arch['grid_size'], arch['pc_range']) for c in hc['ANCHOR_GENERATOR_CONFIG']]
+        labels, reg_t, reg_w = oan.assign_targets(anchor_list, gt_boxes, hc, names)
+        anchors = torch.cat(anchor_list, dim=-3).view(-1, 7)
+        loss, terms = oan.losses(cls, box, dirp, anchors, labels, reg_t, hc, len(names))
+        tb = {k: float(v.detach()) for k, v in terms.items()}
+        tb.update(rpn_loss=float(loss.detach()), loss_rpn=float(loss.detach()))
+        aux.update(cls_preds=cls, box_preds=box, dir_cls_preds=dirp, box_cls_labels=labels, box_reg_targets=reg_t, reg_weights=reg_w,
+                   pillar_features=pf)
+        return loss, tb, aux
     maps = head_train(m, st, arch)
     targets = assign_targets(gt_boxes, arch, (m.shape[2], m.shape[3]))
     loss_rpn, hm_loss, loc_loss = head_loss(maps, targets, arch)

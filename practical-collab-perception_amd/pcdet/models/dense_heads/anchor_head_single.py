@@ -7,7 +7,10 @@ Same parameter tree (conv_cls, conv_box, conv_dir_cls: 1x1 convs) so checkpoints
   torch.topk(NMS_PRE_MAXSIZE) + gather                                       -> pcp_topk_boxes (radix select, one workgroup / frame)
   rotated NMS                                                                -> pcp_nms_rotated (candidates arrive sorted)
 The anchors are generated once on the host with the reference's own arithmetic (torch.arange / meshgrid in float32).
-Training (AxisAlignedTargetAssigner + focal / smooth-L1 / direction losses) is not built: no V2X-Sim config uses this head.
+Training forward (reference: anchor_head_template.py:89-216, target_assigner/axis_aligned_target_assigner.py:37-210):
+  the three 1x1 convs            -> the same pointwise launch with the raw weights (train_path.AnchorHeadTrain keeps what backward needs)
+  AxisAlignedTargetAssigner      -> pcp_anchor_assign_targets (no host loop over frames x anchor classes, no IoU matrix, no .nonzero())
+  focal + smooth-L1(sin diff) + direction losses AND dL/d(head maps) -> pcp_anchor_loss (one pass)
 """
 import numpy as np
 import torch
@@ -15,7 +18,7 @@ import torch.nn as nn
 
 from pcp_amd import lib, ops, pack
 
-from ..packed import PackedModule, require_eval_hip
+from ..packed import PackedModule, require_eval_hip, train_tape
 
 
 class ResidualCoder:
@@ -102,6 +105,8 @@ class AnchorHeadSingle(PackedModule):
         return self._anchors_flat
 
     def forward(self, data_dict):
+        if self.training:
+            return self._forward_train(data_dict)
         require_eval_hip(self, 'AnchorHeadSingle')
         pk = self.packed()
         x = ops.as_nhwc(data_dict['spatial_features_2d'])
@@ -133,5 +138,93 @@ class AnchorHeadSingle(PackedModule):
         data_dict['_pcp_anchor'] = dict(keys=keys, labels=labels)
         return data_dict
 
+    # ---- training (reference anchor_head_single.py:39-75, anchor_head_template.py:89-216) ---------------------------------------
+    def _assign_desc(self, B, H, W):
+        gcfg = self.model_cfg.ANCHOR_GENERATOR_CONFIG
+        tcfg = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        if tcfg.NAME != 'AxisAlignedTargetAssigner':
+            raise NotImplementedError('target assigner %s (the anchor YAMLs of the reference use AxisAlignedTargetAssigner)' % tcfg.NAME)
+        if tcfg.POS_FRACTION >= 0 or tcfg.get('MATCH_HEIGHT', False) or tcfg.get('NORM_BY_NUM_EXAMPLES', False):
+            raise NotImplementedError('POS_FRACTION >= 0 (random sampling), MATCH_HEIGHT and NORM_BY_NUM_EXAMPLES are not used by any '
+                                      'anchor YAML of the reference and have no kernel')
+        d = lib.AnchorAssign()
+        d.batch, d.h, d.w = B, H, W
+        d.anchors_per_loc, d.num_class, d.num_groups = self.num_anchors_per_location, len(self.class_names), len(gcfg)
+        if d.anchors_per_loc > 32 or d.num_groups > 8:
+            raise NotImplementedError('more than 32 anchors per location / 8 anchor classes')
+        slot = 0
+        names = list(self.class_names)
+        for g, cfg in enumerate(gcfg):
+            per = len(cfg['anchor_rotations']) * len(cfg['anchor_sizes']) * len(cfg['anchor_bottom_heights'])
+            for _ in range(per):
+                d.slot_group[slot] = g
+                slot += 1
+            d.group_class[g] = names.index(cfg['class_name']) if cfg['class_name'] in names else -1
+            d.matched[g], d.unmatched[g] = float(cfg['matched_threshold']), float(cfg['unmatched_threshold'])
+        assert slot == d.anchors_per_loc
+        return d
+
+    def _forward_train(self, data_dict):
+        from pcp_amd import train_ops as tops
+        from pcp_amd.train_layers import Act
+        from ..train_path import AnchorHeadTrain
+        if self.predict_boxes_when_training:
+            raise NotImplementedError('predict_boxes_when_training needs a RoI head (not on the PointPillars path)')
+        if getattr(self, '_pcp_train', None) is None:
+            self._pcp_train = AnchorHeadTrain(self)
+        self.invalidate_packed()
+        x = ops.as_nhwc(data_dict['spatial_features_2d'])
+        buf = self._pcp_train.forward(Act(x))
+        B, H, W, ld = buf.shape
+        a, ncls = self.num_anchors_per_location, self.num_class
+        nbins = int(self.model_cfg.NUM_DIR_BINS) if self.conv_dir_cls is not None else 0
+        view = ops.nchw_view(buf)
+        self.forward_ret_dict['cls_preds'] = view[:, :a * ncls].permute(0, 2, 3, 1)
+        self.forward_ret_dict['box_preds'] = view[:, a * ncls:a * ncls + a * 7].permute(0, 2, 3, 1)
+        if nbins:
+            self.forward_ret_dict['dir_cls_preds'] = view[:, a * ncls + a * 7:a * ncls + a * 7 + a * nbins].permute(0, 2, 3, 1)
+        gt = data_dict['gt_boxes']
+        if gt.dtype != torch.float32 or not gt.is_contiguous():
+            gt = gt.float().contiguous()
+        if gt.shape[-1] != 8:
+            raise NotImplementedError('gt_boxes with velocity columns are not used by the V2X-Sim configs')
+        anchors = self.flat_anchors(x.device)
+        labels, reg_t, reg_w = tops.anchor_assign_targets(anchors, gt, self._assign_desc(B, H, W))
+        self.forward_ret_dict.update(box_cls_labels=labels, box_reg_targets=reg_t, reg_weights=reg_w)
+        self._train_state = dict(buf=buf, labels=labels, reg_t=reg_t, anchors=anchors, nbins=nbins)
+        train_tape(data_dict).append(('dense_head', self._backward_from_loss))
+        return data_dict
+
     def get_loss(self):
-        raise NotImplementedError('AnchorHeadSingle training is not built (no V2X-Sim config uses this head)')
+        """the three loss terms AND dL/d(head maps) in one pass (the gradient is consumed by loss.backward())"""
+        from pcp_amd import train_ops as tops
+        st = self._train_state
+        buf = st['buf']
+        B, H, W, ld = buf.shape
+        a, ncls, nbins = self.num_anchors_per_location, self.num_class, st['nbins']
+        lcfg = self.model_cfg.LOSS_CONFIG
+        if lcfg.get('REG_LOSS_TYPE', None) not in (None, 'WeightedSmoothL1Loss'):
+            raise NotImplementedError('REG_LOSS_TYPE %s' % lcfg.REG_LOSS_TYPE)
+        lw = lcfg.LOSS_WEIGHTS
+        d = lib.AnchorLoss()
+        d.batch, d.h, d.w, d.ld, d.ld_d = B, H, W, ld, ld
+        d.anchors_per_loc, d.num_class, d.num_dir_bins = a, ncls, nbins
+        d.ch_cls, d.ch_box, d.ch_dir = 0, a * ncls, a * ncls + a * 7
+        if nbins:
+            d.dir_offset, d.dir_period = float(self.model_cfg.DIR_OFFSET), float(2 * np.pi / nbins)
+            d.dir_weight = float(lw['dir_weight'])
+        d.cls_weight, d.loc_weight = float(lw['cls_weight']), float(lw['loc_weight'])
+        for j in range(7):
+            d.code_weights[j] = float(lw['code_weights'][j])
+        dhead = torch.empty_like(buf)
+        losses = tops.anchor_loss(buf, st['anchors'], st['labels'], st['reg_t'], d, dhead=dhead)
+        st['dhead'] = dhead
+        vals = losses.tolist()
+        tb_dict = {'rpn_loss_cls': vals[0], 'rpn_loss_loc': vals[1]}
+        if nbins:
+            tb_dict['rpn_loss_dir'] = vals[2]
+        tb_dict['rpn_loss'] = vals[3]
+        return losses[3], tb_dict
+
+    def _backward_from_loss(self, _unused):
+        return self._pcp_train.backward(self._train_state['dhead'])

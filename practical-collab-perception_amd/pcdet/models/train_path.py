@@ -340,3 +340,60 @@ class HeadTrain:
         ds = _empty(tuple(sv['s'].t.shape), dev)
         ConvBNAct._run3x3(f['bw1'], dmid, n * c, c, 1, ds, 0, 0)
         return self.shared.backward(Act(ds))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AnchorHeadSingle (MODEL.NAME PointPillar)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class AnchorHeadTrain:
+    """conv_cls / conv_box / conv_dir_cls (1x1 convs with bias, anchor_head_single.py:17-37) as ONE pointwise GEMM over the concatenated
+    output channels; the data gradient is the same kernel on the transposed matrix, the weight gradient one pixel-contraction GEMM."""
+
+    def __init__(self, head):
+        self.m = head
+        self.convs = [head.conv_cls, head.conv_box] + ([head.conv_dir_cls] if head.conv_dir_cls is not None else [])
+        self.outs = [c.weight.shape[0] for c in self.convs]
+        self.offs = [int(v) for v in np.concatenate([[0], np.cumsum(self.outs)])]
+        self.cin = self.convs[0].weight.shape[1]
+        self.cout = self.offs[-1]
+        self.ld = pack.round_up(self.cout, 16)              # the gradient buffer is a contraction operand of the data-gradient GEMM
+        self._step = -1
+        self.saved = None
+
+    def _forms(self):
+        if self._step == tl.StepClock.step:
+            return self._f
+        w = torch.cat([c.weight.detach().float().reshape(c.weight.shape[0], -1) for c in self.convs], 0)      # (cout, cin)
+        b = torch.cat([c.bias.detach().float() for c in self.convs], 0)
+        wt = w.new_zeros((self.cin, self.ld))
+        wt[:, :self.cout] = w.t()
+        self._f = dict(fw=pack.pack_plain(w, b), bw=pack.pack_plain(wt, w.new_zeros(self.cin)))
+        self._step = tl.StepClock.step
+        return self._f
+
+    def forward(self, x):
+        """x: Act (B, H, W, cin).  Returns the raw head buffer (B, H, W, ld); channels past cout are zero."""
+        f = self._forms()
+        B, H, W, _ = x.t.shape
+        buf = torch.zeros((B, H, W, self.ld), dtype=torch.float32, device=x.t.device)
+        w, b, cp = f['fw']
+        ops.pointwise(x.t, w, b, lib.PW_PLAIN, self.cin, self.cout, cp, relu=False, out=buf, in_ch_off=x.off)
+        self.saved = x
+        return buf
+
+    def backward(self, dhead):
+        """dhead: (B, H, W, ld), padding channels zero.  Returns Act gradient of the head input."""
+        x = self.saved
+        dev = dhead.device
+        dw = _empty((self.ld, self.cin), dev)
+        tops.pointwise_wgrad(tops.rowmap(dhead, self.ld), tops.rowmap(x.t, self.cin, x.off), x.rows, dw)
+        db = _empty((self.ld,), dev)
+        tops.colsum(dhead, self.ld, db)
+        for i, c in enumerate(self.convs):
+            ensure_grad(c.weight).view(self.outs[i], self.cin).copy_(dw[self.offs[i]:self.offs[i + 1]])
+            ensure_grad(c.bias).copy_(db[self.offs[i]:self.offs[i + 1]])
+        w, b, cp = self._forms()['bw']
+        dx = _empty(tuple(x.t.shape[:-1]) + (self.cin,), dev)
+        ops.pointwise(dhead, w, b, lib.PW_PLAIN, self.ld, self.cin, cp, relu=False, out=dx)
+        return Act(dx)

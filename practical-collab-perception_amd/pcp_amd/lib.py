@@ -65,6 +65,18 @@ class HeadLoss(ctypes.Structure):
                 ('reg_ch', c_i32 * 8), ('k', c_i32), ('cls_weight', c_f), ('loc_weight', c_f), ('code_weights', c_f * 8)]
 
 
+class AnchorAssign(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('anchors_per_loc', c_i32), ('num_class', c_i32), ('num_groups', c_i32),
+                ('slot_group', c_i32 * 32), ('group_class', c_i32 * 8), ('matched', c_f * 8), ('unmatched', c_f * 8)]
+
+
+class AnchorLoss(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('ld', c_i32), ('ld_d', c_i32), ('anchors_per_loc', c_i32),
+                ('num_class', c_i32), ('num_dir_bins', c_i32), ('ch_cls', c_i32), ('ch_box', c_i32), ('ch_dir', c_i32),
+                ('dir_offset', c_f), ('dir_period', c_f), ('cls_weight', c_f), ('loc_weight', c_f), ('dir_weight', c_f),
+                ('code_weights', c_f * 7)]
+
+
 PW_PLAIN, PW_SPACE2DEPTH, PW_DEPTH2SPACE = 0, 1, 2
 
 # every symbol include/pcp_hip.h declares: name -> (restype, argtypes)
@@ -141,6 +153,10 @@ SYMBOLS.update({
     'pcp_centerhead_targets': (c_i32, [ctypes.POINTER(Target), vp, c_i32, vp, vp, vp, vp, vp]),
     'pcp_loss_workspace_bytes': (c_sz, []),
     'pcp_centerhead_loss': (c_i32, [ctypes.POINTER(HeadLoss), vp, vp, vp, vp, vp, c_f, vp, vp, vp, vp]),
+    'pcp_anchor_assign_workspace_bytes': (c_sz, [ctypes.POINTER(AnchorAssign), c_i32]),
+    'pcp_anchor_assign_targets': (c_i32, [ctypes.POINTER(AnchorAssign), vp, vp, c_i32, vp, c_sz, vp, vp, vp, vp]),
+    'pcp_anchor_loss_workspace_bytes': (c_sz, [c_i32]),
+    'pcp_anchor_loss': (c_i32, [ctypes.POINTER(AnchorLoss), vp, vp, vp, vp, c_f, vp, c_sz, vp, vp, vp]),
     'pcp_distill_loss': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, c_f, vp, vp, vp, c_i32, c_i32, vp]),
     'pcp_pfn_train_features': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, vp, vp, vp]),
     'pcp_pfn_train_mid': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp]),

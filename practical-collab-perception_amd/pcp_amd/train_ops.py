@@ -185,6 +185,50 @@ def centerhead_loss(head, desc, heat, tb, inds, mask, dhead=None, grad_scale=1.0
     return losses
 
 
+_ANCHOR_WS = {}
+
+
+def _anchor_ws(device, nbytes):
+    ws = _ANCHOR_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 4096), dtype=torch.uint8, device=device)
+        _ANCHOR_WS[device] = ws
+    return ws
+
+
+def anchor_assign_targets(anchors, gt_boxes, desc):
+    """anchors (N, 7) flat in torch.cat(anchors, dim=-3) order, gt_boxes (B, M, 8) float32 device.
+    Returns labels (B, N) int32, reg_targets (B, N, 7), reg_weights (B, N)  (axis_aligned_target_assigner.py:37-132)."""
+    _need_cuda(anchors, gt_boxes)
+    L = _lib.load()
+    B, M = gt_boxes.shape[0], gt_boxes.shape[1]
+    N = anchors.shape[0]
+    assert anchors.is_contiguous() and gt_boxes.is_contiguous() and gt_boxes.shape[-1] == 8 and desc.batch == B
+    assert N == desc.h * desc.w * desc.anchors_per_loc
+    dev = anchors.device
+    labels = torch.empty((B, N), dtype=torch.int32, device=dev)
+    reg_t = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
+    reg_w = torch.empty((B, N), dtype=torch.float32, device=dev)
+    need = L.pcp_anchor_assign_workspace_bytes(ctypes.byref(desc), M)
+    ws = _anchor_ws(dev, need)
+    check(L.pcp_anchor_assign_targets(ctypes.byref(desc), _p(anchors), _p(gt_boxes), M, _p(ws), ws.numel(), _p(labels), _p(reg_t), _p(reg_w),
+                                      _stream()), 'pcp_anchor_assign_targets')
+    return labels, reg_t, reg_w
+
+
+def anchor_loss(head, anchors, labels, reg_targets, desc, dhead=None, grad_scale=1.0):
+    """head (B, H, W, ld).  Returns losses (5,) float32 device [cls, loc, dir, total, positives]  (anchor_head_template.py:99-216)."""
+    _need_cuda(head, anchors, labels, reg_targets, dhead)
+    L = _lib.load()
+    losses = torch.empty(5, dtype=torch.float32, device=head.device)
+    need = L.pcp_anchor_loss_workspace_bytes(desc.batch)
+    ws = _anchor_ws(head.device, need)
+    assert labels.dtype == torch.int32 and labels.is_contiguous() and reg_targets.is_contiguous()
+    check(L.pcp_anchor_loss(ctypes.byref(desc), _p(head), _p(anchors), _p(labels), _p(reg_targets), float(grad_scale), _p(ws), ws.numel(),
+                            _p(losses), _p(dhead), _stream()), 'pcp_anchor_loss')
+    return losses
+
+
 def distill_loss(fused, early, c, weight=10.0, dfused=None, accumulate=False, grad_scale=1.0):
     """fused, early: (B,H,W,ld) NHWC.  Returns loss (1,) float32 device."""
     _need_cuda(fused, early, dfused)

@@ -775,6 +775,112 @@ def g9_anchor(tag, multi_class):
           'labels', [np.bincount(out['final_labels_%d' % b], minlength=4).tolist() for b in range(2)])
 
 
+def anchor_train_gt_boxes():
+    """(2, 10, 8) boxes of three classes for the anchor-head training fixture: cars near / on anchor centres with axis-aligned headings (IoU
+    over the matched threshold), cars and small objects that only get their best anchor (forced positives), an all-zero row in the MIDDLE
+    of frame 1 (class 0 indexes CLASS_NAMES[-1] in axis_aligned_target_assigner.py:62-66) and zero padding at the end."""
+    s = synth.SEED_BASE + 1100
+    step = 25.6 / 31
+    gt = np.zeros((2, 10, 8), dtype=np.float32)
+    for b in range(2):
+        n = 10 - 3 * b
+        gt[b, :n, 0] = synth.uniform(s, 10 * b + 1, n, -11.0, 11.0)
+        gt[b, :n, 1] = synth.uniform(s, 10 * b + 2, n, -11.0, 11.0)
+        gt[b, :n, 2] = synth.uniform(s, 10 * b + 3, n, -2.0, -0.5)
+        gt[b, :n, 6] = synth.uniform(s, 10 * b + 7, n, -3.14159, 3.14159)
+        cls = np.array([1, 1, 1, 1, 2, 2, 2, 3, 3, 1])[:n]
+        gt[b, :n, 7] = cls
+        base = {1: (3.9, 1.6, 1.56), 2: (0.8, 0.6, 1.73), 3: (1.76, 0.6, 1.73)}
+        jit = synth.uniform(s, 10 * b + 4, n * 3, 0.85, 1.2).reshape(n, 3)
+        for i in range(n):
+            gt[b, i, 3:6] = np.array(base[int(cls[i])], dtype=np.float32) * jit[i]
+    # cars on / near anchor centres, headings near 0 and pi / 2: matched by threshold
+    gt[0, 0, [0, 1, 6]] = [-12.8 + 9 * step, -12.8 + 20 * step, 0.0]
+    gt[0, 0, 3:6] = [3.9, 1.6, 1.56]
+    gt[0, 1, [0, 1, 6]] = [-12.8 + 22 * step + 0.1, -12.8 + 7 * step - 0.08, 1.55]
+    gt[0, 1, 3:6] = [4.1, 1.7, 1.5]
+    gt[1, 0, [0, 1, 6]] = [-12.8 + 15 * step + 0.15, -12.8 + 15 * step + 0.1, 3.1]
+    gt[1, 0, 3:6] = [4.2, 1.65, 1.6]
+    gt[0, 5, [0, 1]] = [-12.8 + 4 * step, -12.8 + 27 * step]          # a pedestrian exactly on an anchor centre
+    gt[0, 5, 3:6] = [0.8, 0.6, 1.73]
+    gt[0, 5, 6] = 0.0
+    gt[1, 2] = 0.0                                                        # the zero row in the middle
+    return gt
+
+
+def g11_anchor_train():
+    """Training contract of MODEL.NAME PointPillar + AnchorHeadSingle (three anchor classes, direction classifier) on the mini geometry:
+    AxisAlignedTargetAssigner targets, focal / smooth-L1(sin difference) / direction losses and two iterations of the reference's own train
+    step (anchor_head_template.py:89-216, axis_aligned_target_assigner.py:37-210, tools/train_utils/train_utils.py:39-65)."""
+    post = {'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'SCORE_THRESH': 0.5, 'OUTPUT_RAW_SCORE': False, 'EVAL_METRIC': 'kitti',
+            'NMS_CONFIG': {'MULTI_CLASSES_NMS': False, 'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.1, 'NMS_PRE_MAXSIZE': 1024,
+                           'NMS_POST_MAXSIZE': 100}}
+    ov = {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE, 'CLASS_NAMES': ['car', 'pedestrian', 'cyclist'], 'MODEL.NAME': 'PointPillar',
+          'MODEL.DENSE_HEAD': rh.AttrDict(ANCHOR_HEAD), 'MODEL.POST_PROCESSING': rh.AttrDict(post)}
+    cfg = rh.load_cfg('v2x_pointpillar_basic_ego.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    pts = synth.collate(mini_points('lately', 2, 2500))
+    gt = anchor_train_gt_boxes()
+    total_it_each_epoch, epochs = 5, cfg.OPTIMIZATION.NUM_EPOCHS
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=total_it_each_epoch, total_epochs=epochs,
+                                      last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
+    out = {'points': pts, 'gt_boxes': gt, 'anchors': torch.cat(model.dense_head.anchors, dim=-3).numpy()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out['trainable'] = np.array(names)
+    for it in range(2):
+        lr_scheduler.step(it)
+        out['it%d_lr' % it] = np.array(float(optimizer.lr))
+        out['it%d_mom' % it] = np.array(float(optimizer.mom))
+        model.train()
+        optimizer.zero_grad()
+        bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.from_numpy(gt.copy())}
+        ret, tb, _disp = model(bd)
+        loss = ret['loss']
+        model.update_global_step()
+        loss.backward()
+        out['it%d_loss' % it] = np.array(float(loss))
+        out['it%d_tb_json' % it] = np.array(json.dumps({k: float(v) for k, v in tb.items()}))
+        params = dict(model.named_parameters())
+        out['it%d_grad_digest' % it] = np.stack([_digest(params[n].grad) for n in names])
+        if it == 0:
+            fr = model.dense_head.forward_ret_dict
+            out['box_cls_labels'] = fr['box_cls_labels'].numpy().copy()
+            out['box_reg_targets'] = fr['box_reg_targets'].numpy().copy()
+            out['reg_weights'] = fr['reg_weights'].numpy().copy()
+            out['cls_preds'] = fr['cls_preds'].detach().numpy().copy()
+            out['box_preds'] = fr['box_preds'].detach().numpy().copy()
+            out['dir_cls_preds'] = fr['dir_cls_preds'].detach().numpy().copy()
+            out['map_probe'] = bd['spatial_features_2d'].detach().numpy()[:, ::8].copy()
+            for n in names:
+                out['g0/' + n] = _sample(params[n].grad)
+        norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        out['it%d_grad_norm' % it] = np.array(float(norm))
+        optimizer.step()
+        if it == 0:
+            for n in names:
+                out['p1/' + n] = _sample(params[n])
+            sd = model.state_dict()
+            bn_keys = [k for k in sd if 'running_' in k]
+            out['bn_keys'] = np.array(bn_keys)
+            out['it0_bn_digest'] = np.stack([_digest(sd[k]) for k in bn_keys])
+        print('g11 it', it, 'loss', float(loss), 'norm', float(norm), tb)
+    lab = out['box_cls_labels']
+    print('g11 labels', [np.bincount(lab[b] + 1, minlength=5).tolist() for b in range(2)])
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), optimization=rh.to_plain(cfg.OPTIMIZATION),
+                                                 pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(cfg.CLASS_NAMES),
+                                                 layout='lately', state_shapes=shapes,
+                                                 num_point_features=int(ds.point_feature_encoder.num_point_features),
+                                                 total_it_each_epoch=total_it_each_epoch)))
+    path = os.path.join(HERE, 'g11_anchor_train.npz')
+    np.savez_compressed(path, **out)
+    print('g11 saved', os.path.getsize(path) // 1024, 'KiB')
+
+
 G10_SEG_BIAS_SHIFT = 1.0
 
 
@@ -897,6 +1003,8 @@ if __name__ == '__main__':
         g8_exchange()
     if 'g10' in todo:
         g10_lately_chain()
+    if 'g11' in todo:
+        g11_anchor_train()
     if 'g9' in todo:
         g9_anchor('agnostic', False)     # MULTI_CLASSES_NMS with a single (non multi-head) AnchorHeadSingle trips the reference's own
                                          # assertion (detector3d_template.py:283,295: arange(1, num_class) has num_class - 1 entries)

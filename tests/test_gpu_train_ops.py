@@ -465,3 +465,153 @@ def test_conv_bn_act_layer_with_optin_bf16x3(monkeypatch):
     pairs = _layer_case(conv, bn, False, x, seed)
     for k, (mine, ref) in pairs.items():
         _close(mine, ref, 3e-4, 'bf16x3/' + k)
+
+
+# ---- a16: AnchorHeadSingle training ------------------------------------------------------------------------------------------
+
+def _anchor_setup(head_cfg, class_names, grid_size, pc_range):
+    from oracle import anchor as oan
+    from pcp_amd import lib
+    gcfg = head_cfg['ANCHOR_GENERATOR_CONFIG']
+    anchor_list = [oan.generate_anchors([c], grid_size, pc_range) for c in gcfg]
+    flat = torch.cat(anchor_list, dim=-3).reshape(-1, 7).contiguous()
+    ny, nx = anchor_list[0].shape[1], anchor_list[0].shape[2]
+    d = lib.AnchorAssign()
+    d.h, d.w = ny, nx
+    d.num_class, d.num_groups = len(class_names), len(gcfg)
+    slot = 0
+    for g, c in enumerate(gcfg):
+        for _ in range(len(c['anchor_rotations']) * len(c['anchor_sizes']) * len(c['anchor_bottom_heights'])):
+            d.slot_group[slot] = g
+            slot += 1
+        d.group_class[g] = class_names.index(c['class_name'])
+        d.matched[g], d.unmatched[g] = c['matched_threshold'], c['unmatched_threshold']
+    d.anchors_per_loc = slot
+    return anchor_list, flat, d
+
+
+def test_anchor_target_assignment_is_the_references():
+    """pcp_anchor_assign_targets on the reference's own fixture (tests/golden/g11_anchor_train.npz: three anchor classes, threshold and
+    forced positives, ignored anchors, an all-zero row in the middle of a frame, trailing padding): labels and weights bit exact,
+    regression targets to 1e-6 (device logf)"""
+    from helpers import load_golden
+    from pcp_amd import train_ops as tops
+    g = load_golden('g11_anchor_train.npz')
+    meta = g['meta']
+    hc = meta['model']['DENSE_HEAD']
+    _al, flat, d = _anchor_setup(hc, meta['class_names'], [128, 128, 1], meta['pc_range'])
+    assert np.array_equal(flat.numpy(), g['anchors'].reshape(-1, 7))
+    d.batch = 2
+    labels, reg_t, reg_w = tops.anchor_assign_targets(flat.to(DEV), torch.from_numpy(g['gt_boxes']).to(DEV), d)
+    assert np.array_equal(labels.cpu().numpy(), g['box_cls_labels'])
+    assert np.array_equal(reg_w.cpu().numpy(), g['reg_weights'])
+    np.testing.assert_allclose(reg_t.cpu().numpy(), g['box_reg_targets'], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', ['full_single_class', 'three_classes_many_boxes', 'no_boxes', 'all_zero_rows'])
+def test_anchor_target_assignment_matches_the_oracle(case):
+    """full-size map (128 x 128 x 2 anchors = the shipped v2x_pointpillar_anchor.yaml), 60 boxes per frame; 6 anchors x 200 boxes with
+    many ties (boxes ON anchor centres); frames without boxes (M = 0 and all-zero rows): labels bit exact against oracle/anchor.py"""
+    from oracle import anchor as oan
+    from pcp_amd import train_ops as tops
+    rng = np.random.RandomState(11)
+    if case == 'full_single_class':
+        names = ['car']
+        hc = {'ANCHOR_GENERATOR_CONFIG': [{'class_name': 'car', 'anchor_sizes': [[4.7, 2.1, 1.7]], 'anchor_rotations': [0, 1.57],
+                                           'anchor_bottom_heights': [-3.0], 'align_center': False, 'feature_map_stride': 4,
+                                           'matched_threshold': 0.6, 'unmatched_threshold': 0.45}]}
+        grid, rngp, B, M = [512, 512, 1], [-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], 3, 60
+    else:
+        names = ['car', 'pedestrian', 'cyclist']
+        mk = lambda n, s, hi, lo: {'class_name': n, 'anchor_sizes': [s], 'anchor_rotations': [0, 1.57], 'anchor_bottom_heights': [-1.0],
+                                   'align_center': False, 'feature_map_stride': 4, 'matched_threshold': hi, 'unmatched_threshold': lo}
+        hc = {'ANCHOR_GENERATOR_CONFIG': [mk('car', [3.9, 1.6, 1.56], 0.6, 0.45), mk('pedestrian', [0.8, 0.6, 1.73], 0.5, 0.35),
+                                           mk('cyclist', [1.76, 0.6, 1.73], 0.5, 0.35)]}
+        grid, rngp, B, M = [256, 192, 1], [-25.6, -19.2, -8.0, 25.6, 19.2, 0.0], 2, 200
+    hc['TARGET_ASSIGNER_CONFIG'] = {'POS_FRACTION': -1.0, 'MATCH_HEIGHT': False, 'NORM_BY_NUM_EXAMPLES': False}
+    al, flat, d = _anchor_setup(hc, names, grid, rngp)
+    d.batch = B
+    gt = np.zeros((B, M, 8), dtype=np.float32)
+    if case in ('full_single_class', 'three_classes_many_boxes'):
+        for b in range(B):
+            n = M - 7 * b
+            gt[b, :n, 0] = rng.uniform(rngp[0], rngp[3], n)
+            gt[b, :n, 1] = rng.uniform(rngp[1], rngp[4], n)
+            gt[b, :n, 2] = rng.uniform(-3, -1, n)
+            cls = rng.randint(1, len(names) + 1, n)
+            base = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]] if len(names) == 3 else [[4.7, 2.1, 1.7]], dtype=np.float32)
+            gt[b, :n, 3:6] = base[cls - 1] * rng.uniform(0.8, 1.25, (n, 3))
+            gt[b, :n, 6] = rng.uniform(-3.2, 3.2, n)
+            gt[b, :n, 7] = cls
+            # a third of the boxes sit exactly on anchor centres with anchor headings: equal overlaps between neighbours (ties)
+            a7 = flat.numpy()
+            pick = rng.randint(0, a7.shape[0], n // 3)
+            gt[b, :n // 3, 0:2] = a7[pick, 0:2]
+            gt[b, :n // 3, 6] = a7[pick, 6]
+    if case == 'no_boxes':
+        gt = np.zeros((B, 0, 8), dtype=np.float32)
+    ref_l, ref_t, ref_w = oan.assign_targets(al, gt if gt.shape[1] else np.zeros((B, 1, 8), np.float32), hc, names)
+    labels, reg_t, reg_w = tops.anchor_assign_targets(flat.to(DEV), torch.from_numpy(gt).to(DEV), d)
+    assert np.array_equal(labels.cpu().numpy(), ref_l.numpy())
+    assert np.array_equal(reg_w.cpu().numpy(), ref_w.numpy())
+    np.testing.assert_allclose(reg_t.cpu().numpy(), ref_t.numpy(), rtol=0, atol=2e-6)
+    if case in ('full_single_class', 'three_classes_many_boxes'):
+        assert (ref_l.numpy() > 0).sum() > B * 20 and (ref_l.numpy() == -1).any()
+
+
+def test_anchor_losses_and_head_gradient():
+    """pcp_anchor_loss on the reference's own head outputs and targets (g11): the three weighted terms against the reference's tb_dict
+    (1e-5 relative), dL/d(head maps) against torch autograd of oracle/anchor.py (1e-5 of the largest entry), padding channels zero"""
+    import json
+    from helpers import load_golden
+    from oracle import anchor as oan
+    from pcp_amd import lib
+    from pcp_amd import train_ops as tops
+    g = load_golden('g11_anchor_train.npz')
+    meta = g['meta']
+    hc = meta['model']['DENSE_HEAD']
+    ncls, A, nb = 3, 6, 2
+    cls, box, dirp = (torch.from_numpy(g[k].copy()).requires_grad_(True) for k in ('cls_preds', 'box_preds', 'dir_cls_preds'))
+    anchors = torch.from_numpy(g['anchors']).reshape(-1, 7).contiguous()
+    labels, reg_t = torch.from_numpy(g['box_cls_labels']), torch.from_numpy(g['box_reg_targets'])
+    total, terms = oan.losses(cls, box, dirp, anchors, labels, reg_t, hc, ncls)
+    total.backward()
+    B, H, W = cls.shape[0], cls.shape[1], cls.shape[2]
+    used = A * (ncls + 7 + nb)
+    ld = 80
+    head = torch.zeros((B, H, W, ld))
+    head[..., :A * ncls] = cls.detach()
+    head[..., A * ncls:A * ncls + A * 7] = box.detach()
+    head[..., A * ncls + A * 7:used] = dirp.detach()
+    d = lib.AnchorLoss()
+    d.batch, d.h, d.w, d.ld, d.ld_d = B, H, W, ld, ld
+    d.anchors_per_loc, d.num_class, d.num_dir_bins = A, ncls, nb
+    d.ch_cls, d.ch_box, d.ch_dir = 0, A * ncls, A * ncls + A * 7
+    d.dir_offset, d.dir_period = hc['DIR_OFFSET'], float(2 * np.pi / nb)
+    lw = hc['LOSS_CONFIG']['LOSS_WEIGHTS']
+    d.cls_weight, d.loc_weight, d.dir_weight = lw['cls_weight'], lw['loc_weight'], lw['dir_weight']
+    for j in range(7):
+        d.code_weights[j] = lw['code_weights'][j]
+    dhead = torch.full((B, H, W, ld), 7.0, device=DEV)
+    losses = tops.anchor_loss(head.to(DEV), anchors.to(DEV), labels.to(DEV), reg_t.to(DEV), d, dhead=dhead).cpu().numpy()
+    ref_tb = json.loads(str(g['it0_tb_json']))
+    for i, k in enumerate(('rpn_loss_cls', 'rpn_loss_loc', 'rpn_loss_dir', 'rpn_loss')):
+        assert abs(losses[i] - ref_tb[k]) <= 1e-5 * abs(ref_tb[k]), (k, losses[i], ref_tb[k])
+    assert losses[4] == float((g['box_cls_labels'] > 0).sum())
+    dh = dhead.cpu()
+    assert float(dh[..., used:].abs().max()) == 0.0
+    ref = torch.cat([cls.grad, box.grad, dirp.grad], dim=-1)
+    _close(dh[..., :used], ref, 1e-5, 'dhead')
+    for lo, hi, name in ((0, A * ncls, 'cls'), (A * ncls, A * ncls + A * 7, 'box'), (A * ncls + A * 7, used, 'dir')):
+        _close(dh[..., lo:hi], ref[..., lo:hi], 2e-5, 'dhead ' + name)
+    # class-agnostic head (num_class 1): every positive trains logit 0; and grad_scale scales the gradient only
+    d.num_class = 1
+    d.ch_box, d.ch_dir = A, A + A * 7
+    cls1 = cls.detach()[..., ::3].contiguous().requires_grad_(True)
+    head1 = torch.zeros((B, H, W, ld))
+    head1[..., :A], head1[..., A:A + A * 7], head1[..., A + A * 7:A + A * 9] = cls1.detach(), box.detach(), dirp.detach()
+    t1, _ = oan.losses(cls1, box.detach(), dirp.detach(), anchors, labels, reg_t, hc, 1)
+    t1.backward()
+    l1 = tops.anchor_loss(head1.to(DEV), anchors.to(DEV), labels.to(DEV), reg_t.to(DEV), d, dhead=dhead, grad_scale=0.5).cpu().numpy()
+    assert abs(l1[3] - float(t1)) <= 1e-5 * float(t1)
+    _close(dhead.cpu()[..., :A] * 2.0, cls1.grad, 2e-5, 'class-agnostic dcls')

@@ -350,3 +350,75 @@ def test_g10_lately_fusion_chain():
     for b in range(meta['frames']):
         fin = obev.head_postprocess({k: torch.from_numpy(g['head_' + k]) for k in ('center', 'center_z', 'dim', 'rot', 'hm')}, ego_arch)[b]
         assert_same_final_set(g['final_boxes_%d' % b], g['final_scores_%d' % b], np.asarray(fin['pred_boxes']), np.asarray(fin['pred_scores']))
+
+
+def test_g11_anchor_head_training_step():
+    """oracle/anchor.py (AxisAlignedTargetAssigner + focal / smooth-L1 with sin difference / direction losses) and oracle/train.py on the
+    PointPillar + AnchorHeadSingle trunk against two iterations of the reference's own train step (tests/golden/g11_anchor_train.npz):
+    labels bit exact, regression targets to 1 ulp-level, loss terms, gradients, the Adam step."""
+    import json
+    from oracle import anchor as oan
+    from oracle import train as otr
+    g = load_golden('g11_anchor_train.npz')
+    meta = g['meta']
+    arch = otr.add_train_arch(arch_of(meta), meta['model'], meta['class_names'])
+    hc = meta['model']['DENSE_HEAD']
+    anchor_list = [oan.generate_anchors([c], arch['grid_size'], arch['pc_range']) for c in hc['ANCHOR_GENERATOR_CONFIG']]
+    assert np.array_equal(torch.cat(anchor_list, dim=-3).numpy(), g['anchors'])
+    labels, reg_t, reg_w = oan.assign_targets(anchor_list, g['gt_boxes'], hc, meta['class_names'])
+    assert np.array_equal(labels.numpy(), g['box_cls_labels'])
+    assert np.array_equal(reg_w.numpy(), g['reg_weights'])
+    np.testing.assert_allclose(reg_t.numpy(), g['box_reg_targets'], rtol=0, atol=1e-6)
+    # every branch of the assigner is exercised by the fixture: ignored (-1), background, threshold positives and forced positives
+    assert (g['box_cls_labels'] == -1).any() and set(np.unique(g['box_cls_labels'])) == {-1, 0, 1, 2, 3}
+    # the loss terms on the REFERENCE's own head outputs and targets
+    t = lambda k: torch.from_numpy(g[k].copy())
+    total, terms = oan.losses(t('cls_preds'), t('box_preds'), t('dir_cls_preds'), torch.from_numpy(g['anchors']).view(-1, 7),
+                              t('box_cls_labels'), t('box_reg_targets'), hc, len(meta['class_names']))
+    ref_tb = json.loads(str(g['it0_tb_json']))
+    for k, v in terms.items():
+        assert abs(float(v) - ref_tb[k]) <= 2e-6 * abs(ref_tb[k]), (k, float(v), ref_tb[k])
+    assert abs(float(total) - ref_tb['rpn_loss']) <= 2e-6 * ref_tb['rpn_loss']
+    # two whole train steps
+    st = otr.make_state(synth.fill_state_dict(meta['state_shapes']))
+    names = [str(n) for n in g['trainable']]
+    assert set(names) == set(k for k in st if st[k].requires_grad)
+    opt = otr.AdamOneCycle(names, wd=meta['optimization']['WEIGHT_DECAY'])
+    total_it = meta['total_it_each_epoch'] * meta['optimization']['NUM_EPOCHS']
+    for it in range(2):
+        r = otr.train_step(g['points'], g['gt_boxes'], [{}, {}], st, arch, opt, it, total_it, meta['optimization'])
+        assert abs(r['lr'] - float(g['it%d_lr' % it])) < 1e-12 and abs(r['mom'] - float(g['it%d_mom' % it])) < 1e-12
+        ref_tb = json.loads(str(g['it%d_tb_json' % it]))
+        tol = 5e-6 if it == 0 else 2e-3
+        assert abs(r['loss'] - float(g['it%d_loss' % it])) <= tol * abs(float(g['it%d_loss' % it])), (it, r['loss'])
+        for k, v in ref_tb.items():
+            assert abs(r['tb'][k] - v) <= max(tol, 1e-4) * abs(v) + 1e-9, (k, r['tb'][k], v)
+        if it == 0:
+            np.testing.assert_allclose(r['aux']['cls_preds'].detach().numpy(), g['cls_preds'], rtol=1e-4, atol=5e-5)
+            assert abs(r['grad_norm'] - float(g['it0_grad_norm'])) < 2e-4 * float(g['it0_grad_norm'])
+            gmax = max(float(r['grads'][n].abs().max()) for n in names)
+            num = den = 0.0
+            for n in names:
+                a = r['grads'][n]
+                ref = g['g0/' + n]
+                mine = a.reshape(-1).numpy() if a.numel() <= 4096 else a.reshape(-1)[::a.numel() // 1024][:1024].numpy()
+                scale = max(float(np.abs(ref).max()), 1e-4 * gmax)
+                assert np.abs(mine - ref).max() <= 1e-1 * scale, (n, np.abs(mine - ref).max(), scale)   # fp32 noise band of the 8 x 8 block (see below)
+                num += float(((mine - ref).astype(np.float64) ** 2).sum())
+                den += float((ref.astype(np.float64) ** 2).sum())
+                p = st[n].detach()
+                pm = p.reshape(-1).numpy() if p.numel() <= 4096 else p.reshape(-1)[::p.numel() // 1024][:1024].numpy()
+                assert np.abs(pm - g['p1/' + n]).max() <= 2.1 * r['lr'], n
+            assert num <= (5e-3 ** 2) * den, (num / den) ** 0.5
+    # the float64 run of the same oracle is the noise-free gradient: the reference's float32 gradients sit within 3e-2 of it per tensor
+    # (the oracle's own float32 run is up to 6e-2 away in backbone block 2: 8 x 8 maps, batch-statistics BatchNorm over 128 values)
+    st64 = otr.make_state(synth.fill_state_dict(meta['state_shapes']))
+    st64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.dtype == torch.float32 else v) for k, v in st64.items()}
+    loss64, _tb, _aux = otr.train_forward(g['points'], g['gt_boxes'], [{}, {}], st64, arch)
+    loss64.backward()
+    assert abs(float(loss64.detach()) - float(g['it0_loss'])) <= 2e-6 * float(g['it0_loss'])
+    for n in names:
+        a = st64[n].grad.detach().reshape(-1)
+        mine = a.numpy() if a.numel() <= 4096 else a[::a.numel() // 1024][:1024].numpy()
+        ref = g['g0/' + n].astype(np.float64)
+        assert np.abs(mine - ref).max() <= 3e-2 * max(float(np.abs(ref).max()), 1e-4 * gmax), n
