@@ -262,6 +262,8 @@ def head_train(x, st, arch, prefix='dense_head'):
 
 def add_train_arch(arch, model_cfg, class_names=None):
     hd = model_cfg['DENSE_HEAD']
+    if model_cfg.get('CORRECTOR') is not None:
+        arch['corrector_cfg'] = model_cfg['CORRECTOR']
     if arch['head'].get('kind') == 'anchor':
         arch['head']['class_names'] = list(class_names)
         return arch
@@ -287,7 +289,7 @@ def make_state(state):
     return st
 
 
-def train_forward(points, gt_boxes, metadata, st, arch, probe=None):
+def train_forward(points, gt_boxes, metadata, st, arch, probe=None, instances_tf=None):
     """One train-mode forward.  st: make_state() output (running stats are updated in place).  Returns (loss, tb, aux)."""
     pts = np.ascontiguousarray(points, dtype=F32)
     st_np = {k: v.detach().numpy() for k, v in st.items()}
@@ -316,6 +318,14 @@ def train_forward(points, gt_boxes, metadata, st, arch, probe=None):
     m = backbone_train(canvas, st, arch)
     aux = dict(backbone_out=m)
     loss_distill = None
+    loss_corrector = None
+    if arch.get('corrector') is not None:                  # configs 1 / 2: HunterJr between backbone and head (centerpoint.py:9-62)
+        from . import hunter_train as oht
+        gtt = torch.as_tensor(gt_boxes, dtype=torch.float32)
+        m, loss_corrector, cterms, caux = oht.hunter_train(m, torch.from_numpy(pts), gtt, torch.as_tensor(instances_tf, dtype=torch.float32),
+                                                            st, arch, arch['corrector_cfg'])
+        gt_boxes = oht.filter_gt_boxes(gtt, arch['pc_range']).numpy()
+        aux.update(hunter=caux, hunter_terms=cterms, gt_boxes_after=gt_boxes)
     if arch.get('fusion') is not None:
         se3 = [md['se3_from_ego'] for md in metadata]
         m = fusion_train(m, {a: t.to(dt) for a, t in bev_img.items()}, se3, st, arch, probe=probe)
@@ -343,6 +353,10 @@ def train_forward(points, gt_boxes, metadata, st, arch, probe=None):
     loss = loss_rpn
     tb = dict(loss_rpn=float(loss_rpn.detach()), hm_loss_head_0=float(hm_loss.detach()), loc_loss_head_0=float(loc_loss.detach()),
               rpn_loss=float(loss_rpn.detach()))
+    if loss_corrector is not None:
+        loss = loss + loss_corrector
+        tb.update({k: float(v.detach()) for k, v in cterms.items()})
+        tb['loss_corrector'] = float(loss_corrector.detach())
     if loss_distill is not None:
         loss = loss + loss_distill
         tb['loss_mid_fusion_distill'] = float(loss_distill.detach())
@@ -405,14 +419,14 @@ class AdamOneCycle:
                 p.addcdiv_(self.m[n], denom, value=-lr / bc1)
 
 
-def train_step(points, gt_boxes, metadata, st, arch, opt, it, total_steps, ocfg):
+def train_step(points, gt_boxes, metadata, st, arch, opt, it, total_steps, ocfg, instances_tf=None):
     """lr_scheduler.step(it); zero_grad; forward; backward; clip; step  (train_utils.py:39-65).
     Returns dict(loss, tb, grads, grad_norm, lr, mom)."""
     lr, mom = onecycle(it, total_steps, ocfg['LR'], list(ocfg['MOMS']), ocfg['DIV_FACTOR'], ocfg['PCT_START'])
     names = opt.names
     for n in names:
         st[n].grad = None
-    loss, tb, aux = train_forward(points, gt_boxes, metadata, st, arch)
+    loss, tb, aux = train_forward(points, gt_boxes, metadata, st, arch, instances_tf=instances_tf)
     loss.backward()
     grads = {n: (st[n].grad.detach().clone() if st[n].grad is not None else torch.zeros_like(st[n])) for n in names}
     norm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))

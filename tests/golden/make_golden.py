@@ -881,6 +881,150 @@ def g11_anchor_train():
     print('g11 saved', os.path.getsize(path) // 1024, 'KiB')
 
 
+G12_SEG_BIAS_SHIFT = 0.0
+
+
+def hunter_train_inputs():
+    """basic_car training batch on the mini geometry: 2 frames x 2500 background points plus foreground points of 6 / 5 instances
+    (instance index in the last column, sweep index before it), `instances_tf` (B, N_inst_max, 11, 3, 4) = the rigid motion that takes a
+    sweep-s point of the instance to the newest sweep (identity for static instances; |t(sweep 0)| > 0.5 marks a moving one,
+    hunter_jr.py:222), and gt_boxes with one centre outside the range (dropped by remove_gt_boxes_outside_range)."""
+    s = synth.SEED_BASE + 1200
+    gt = train_gt_boxes(2, 6, 3)
+    gt[1, 4:] = 0.0                                     # frame 1: four instances, two padding rows
+    B, M, S = 2, 6, 11
+    tf = np.zeros((B, M, S, 3, 4), dtype=np.float32)
+    tf[..., :3, :3] = np.eye(3, dtype=np.float32)
+    clouds = mini_points('car', 2, 2500)
+    out_clouds = []
+    for b in range(B):
+        rows = [clouds[b]]
+        for i in range(M):
+            if gt[b, i, 7] == 0 or (b == 0 and i == 0):    # padding rows; the out-of-range box has no points
+                continue
+            c, dims, yaw = gt[b, i, 0:3].astype(np.float64), gt[b, i, 3:6].astype(np.float64), float(gt[b, i, 6])
+            moving = (i % 2 == 1)
+            speed = 2.0 + 1.5 * i
+            omega = 0.15 * (i - 2)
+            sweeps = [10, 9, 7, 4, 0][:(3 + (i + b) % 3)]
+            for k, sw in enumerate(sweeps):
+                dt = (10 - sw) * 0.1
+                n = 6 + 3 * ((i + k + b) % 4)
+                u = synth.uniform(s, 100 * b + 10 * i + k, n * 3, -0.5, 0.5).reshape(n, 3).astype(np.float64)
+                local = u * dims
+                if moving:
+                    yaw_s = yaw - omega * dt
+                    c_s = c - speed * dt * np.array([np.cos(yaw), np.sin(yaw), 0.0])
+                else:
+                    yaw_s, c_s = yaw, c
+                Rs = np.array([[np.cos(yaw_s), -np.sin(yaw_s), 0], [np.sin(yaw_s), np.cos(yaw_s), 0], [0, 0, 1]])
+                p = local @ Rs.T + c_s
+                if moving:
+                    d = omega * dt
+                    R = np.array([[np.cos(d), -np.sin(d), 0], [np.sin(d), np.cos(d), 0], [0, 0, 1]])
+                    tf[b, i, sw, :3, :3] = R
+                    tf[b, i, sw, :3, 3] = c - R @ c_s
+                r = np.zeros((n, 7), dtype=np.float32)
+                r[:, 0:3] = p
+                r[:, 3] = 0.5
+                r[:, 4] = dt
+                r[:, 5] = sw
+                r[:, 6] = i
+                rows.append(r)
+        if moving is not None:
+            pass
+        out_clouds.append(np.concatenate(rows, axis=0))
+    # the motion flag is read from sweep 0 (hunter_jr.py:222) whether or not the instance has points there
+    for b in range(B):
+        for i in range(M):
+            if gt[b, i, 7] != 0 and i % 2 == 1 and not (b == 0 and i == 0):
+                c, yaw = gt[b, i, 0:3].astype(np.float64), float(gt[b, i, 6])
+                speed, omega, dt = 2.0 + 1.5 * i, 0.15 * (i - 2), 1.0
+                c_s = c - speed * dt * np.array([np.cos(yaw), np.sin(yaw), 0.0])
+                d = omega * dt
+                R = np.array([[np.cos(d), -np.sin(d), 0], [np.sin(d), np.cos(d), 0], [0, 0, 1]])
+                tf[b, i, 0, :3, :3] = R
+                tf[b, i, 0, :3, 3] = c - R @ c_s
+    return synth.collate(out_clouds), gt, tf
+
+
+def g12_hunter_train():
+    """Training contract of configs 1 / 2 (VFE -> scatter -> backbone -> HunterJr -> CenterHead) on the mini geometry: two iterations of the
+    reference's own train step; HunterJr's meta / targets / predictions / seven loss terms of iteration 0 are stored one by one."""
+    cfg = rh.load_cfg('v2x_pointpillar_basic_car.yaml', {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE})
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    if G12_SEG_BIAS_SHIFT:
+        with torch.no_grad():
+            model.corrector.point_head.seg[0].bias[2] += G12_SEG_BIAS_SHIFT
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    pts, gt, tf = hunter_train_inputs()
+    total_it_each_epoch, epochs = 5, cfg.OPTIMIZATION.NUM_EPOCHS
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=total_it_each_epoch, total_epochs=epochs,
+                                      last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
+    out = {'points': pts, 'gt_boxes': gt, 'instances_tf': tf}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out['trainable'] = np.array(names)
+    for it in range(2):
+        lr_scheduler.step(it)
+        out['it%d_lr' % it] = np.array(float(optimizer.lr))
+        out['it%d_mom' % it] = np.array(float(optimizer.mom))
+        model.train()
+        optimizer.zero_grad()
+        bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.from_numpy(gt.copy()),
+              'instances_tf': torch.from_numpy(tf.copy())}
+        ret, tb, _disp = model(bd)
+        loss = ret['loss']
+        model.update_global_step()
+        loss.backward()
+        out['it%d_loss' % it] = np.array(float(loss))
+        out['it%d_tb_json' % it] = np.array(json.dumps({k: float(v) for k, v in tb.items()}))
+        params = dict(model.named_parameters())
+        out['it%d_grad_digest' % it] = np.stack([_digest(params[n].grad) if params[n].grad is not None else np.zeros(3) for n in names])
+        if it == 0:
+            fr = model.corrector.forward_return_dict
+            meta, pred, tgt = fr['meta'], fr['prediction'], fr['target']
+            for k in ('locals2fg', 'inst2locals', 'indices_locals_max_sweep', 'indices_locals_min_sweep', 'locals_bis', 'instance_bi',
+                      'mask_fg'):
+                out['meta/' + k] = meta[k].numpy().copy()
+            for k in ('points_cls_logit', 'points_flow3d', 'points_embedding', 'locals_tf'):
+                out['pred/' + k] = pred[k].detach().numpy().copy()
+            for k in ('locals_tf', 'points_cls', 'fg_embedding', 'fg_offset'):
+                out['tgt/' + k] = tgt[k].numpy().copy()
+            out['tgt/mask_locals_mos'] = tgt['meta']['mask_locals_mos'].numpy().copy()
+            out['points_after'] = bd['points'].detach().numpy().copy()
+            out['gt_boxes_after'] = bd['gt_boxes'].numpy().copy()
+            out['map_probe'] = bd['spatial_features_2d'].detach().numpy()[:, ::8].copy()
+            out['no_grad'] = np.array([n for n in names if params[n].grad is None])
+            for n in names:
+                if params[n].grad is not None:
+                    out['g0/' + n] = _sample(params[n].grad)
+        norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        out['it%d_grad_norm' % it] = np.array(float(norm))
+        optimizer.step()
+        if it == 0:
+            for n in names:
+                out['p1/' + n] = _sample(params[n])
+            sd = model.state_dict()
+            bn_keys = [k for k in sd if 'running_' in k]
+            out['bn_keys'] = np.array(bn_keys)
+            out['it0_bn_digest'] = np.stack([_digest(sd[k]) for k in bn_keys])
+        print('g12 it', it, 'loss', float(loss), 'norm', float(norm), tb)
+    print('g12 fg', int(out['meta/mask_fg'].sum()), 'locals', out['meta/locals_bis'].shape[0], 'inst', out['meta/instance_bi'].shape[0],
+          'dyn points moved', int((np.abs(out['points_after'] - pts).max(1) > 0).sum()), 'moving locals', int(out['tgt/mask_locals_mos'].sum()),
+          'no grad', list(out['no_grad']))
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), optimization=rh.to_plain(cfg.OPTIMIZATION),
+                                                 pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(cfg.CLASS_NAMES),
+                                                 yaml='v2x_pointpillar_basic_car.yaml', layout='car', state_shapes=shapes,
+                                                 seg_bias_shift=G12_SEG_BIAS_SHIFT, total_it_each_epoch=total_it_each_epoch)))
+    path = os.path.join(HERE, 'g12_hunter_train.npz')
+    np.savez_compressed(path, **out)
+    print('g12 saved', os.path.getsize(path) // 1024, 'KiB')
+
+
 G10_SEG_BIAS_SHIFT = 1.0
 
 
@@ -1005,6 +1149,8 @@ if __name__ == '__main__':
         g10_lately_chain()
     if 'g11' in todo:
         g11_anchor_train()
+    if 'g12' in todo:
+        g12_hunter_train()
     if 'g9' in todo:
         g9_anchor('agnostic', False)     # MULTI_CLASSES_NMS with a single (non multi-head) AnchorHeadSingle trips the reference's own
                                          # assertion (detector3d_template.py:283,295: arange(1, num_class) has num_class - 1 entries)

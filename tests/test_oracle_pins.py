@@ -422,3 +422,50 @@ def test_g11_anchor_head_training_step():
         mine = a.numpy() if a.numel() <= 4096 else a[::a.numel() // 1024][:1024].numpy()
         ref = g['g0/' + n].astype(np.float64)
         assert np.abs(mine - ref).max() <= 3e-2 * max(float(np.abs(ref).max()), 1e-4 * gmax), n
+
+
+def test_g12_hunter_jr_training_step():
+    """oracle/hunter_train.py (locals / instances, object head, targets, CE + Lovasz, hard-mining regression losses, feature distillation,
+    the differentiable BEV correction) inside oracle/train.py against two iterations of the reference's own train step on
+    v2x_pointpillar_basic_car.yaml (tests/golden/g12_hunter_train.npz)."""
+    import json
+    from oracle import train as otr
+    g = load_golden('g12_hunter_train.npz')
+    meta = g['meta']
+    arch = otr.add_train_arch(arch_of(meta), meta['model'])
+    st = otr.make_state(synth.fill_state_dict(meta['state_shapes']))
+    names = [str(n) for n in g['trainable']]
+    assert set(names) == set(k for k in st if st[k].requires_grad) and len(g['no_grad']) == 0
+    opt = otr.AdamOneCycle(names, wd=meta['optimization']['WEIGHT_DECAY'])
+    total_it = meta['total_it_each_epoch'] * meta['optimization']['NUM_EPOCHS']
+    for it in range(2):
+        r = otr.train_step(g['points'], g['gt_boxes'], [{}, {}], st, arch, opt, it, total_it, meta['optimization'], instances_tf=g['instances_tf'])
+        ref_tb = json.loads(str(g['it%d_tb_json' % it]))
+        tol = 1e-5 if it == 0 else 5e-3
+        for k, v in ref_tb.items():
+            assert abs(r['tb'][k] - v) <= max(tol, 1e-4) * abs(v) + 1e-9, (it, k, r['tb'][k], v)
+        assert abs(r['loss'] - float(g['it%d_loss' % it])) <= tol * abs(float(g['it%d_loss' % it])), (it, r['loss'])
+        if it == 0:
+            h = r['aux']['hunter']
+            for k in ('locals2fg', 'inst2locals', 'indices_locals_max_sweep', 'indices_locals_min_sweep', 'locals_bis', 'instance_bi', 'mask_fg'):
+                assert np.array_equal(h['meta'][k].numpy(), g['meta/' + k]), k
+            assert np.array_equal(h['target']['points_cls'].numpy(), g['tgt/points_cls'])
+            assert np.array_equal(h['target']['mask_locals_mos'].numpy(), g['tgt/mask_locals_mos'])
+            for k in ('locals_tf', 'fg_embedding', 'fg_offset'):
+                np.testing.assert_allclose(h['target'][k].numpy(), g['tgt/' + k], rtol=0, atol=2e-6, err_msg=k)
+            for mine, ref in (('cls_logit', 'points_cls_logit'), ('flow', 'points_flow3d'), ('embed', 'points_embedding'), ('locals_tf', 'locals_tf')):
+                np.testing.assert_allclose(h[mine].detach().numpy(), g['pred/' + ref], rtol=1e-4, atol=1e-4, err_msg=ref)
+            np.testing.assert_allclose(h['points'].numpy(), g['points_after'], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(r['aux']['gt_boxes_after'], g['gt_boxes_after'], rtol=0, atol=0)
+            assert abs(r['grad_norm'] - float(g['it0_grad_norm'])) < 2e-3 * float(g['it0_grad_norm'])
+            gmax = max(float(r['grads'][n].abs().max()) for n in names)
+            num = den = 0.0
+            for n in names:
+                a = r['grads'][n]
+                ref = g['g0/' + n]
+                mine = a.reshape(-1).numpy() if a.numel() <= 4096 else a.reshape(-1)[::a.numel() // 1024][:1024].numpy()
+                scale = max(float(np.abs(ref).max()), 1e-4 * gmax)
+                assert np.abs(mine - ref).max() <= 1e-1 * scale, (n, np.abs(mine - ref).max(), scale)
+                num += float(((mine - ref).astype(np.float64) ** 2).sum())
+                den += float((ref.astype(np.float64) ** 2).sum())
+            assert num <= (1e-2 ** 2) * den, (num / den) ** 0.5
