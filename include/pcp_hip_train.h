@@ -199,6 +199,99 @@ int pcp_anchor_loss(const pcp_anchor_loss_t *desc, const float *head, const floa
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a17  HunterJr training branch (configs 1 / 2).
+ * Replaces: pcdet/models/bev_layers/hunter_jr.py:165-196 (_build_meta: two torch.unique + scatter_max / scatter_min), :42-76
+ *           (HunterObjectHead: scatter_mean, three scatter_max, cat), :198-260 (assign_target), :106-113 (get_loss_distill), :401-495
+ *           (get_training_loss), pcdet/models/loss_fnc/pcaccum_ce_lovasz_loss.py:20-71, lovasz_softmax.py:56-95,
+ *           hunter_toolbox.py:42-62 (quat2mat), :161-184 (remove_gt_boxes_outside_range), :187-219 (hard_mining_regression_loss), and the
+ *           autograd of hunter_toolbox.py:8-39 (bilinear sampling incl. its position gradient), :65-91 (bev_scatter), hunter_jr.py:281-285.
+ * Rows of `points` are [frame, x, y, z, ..., sweep, instance]; foreground = instance > -1 (hunter_jr.py:323).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t batch, max_inst, num_sweeps;          /* key = (frame * max_inst + instance) * num_sweeps + sweep; max_inst = gt_boxes.shape[1] */
+  int32_t sweep_col, inst_col;                  /* columns of the point rows */
+} pcp_hunter_meta_t;
+
+size_t pcp_hunter_meta_workspace_bytes(const pcp_hunter_meta_t *desc, int64_t n);
+/* fg_idx / fg_local (n): rows of the foreground points in ascending order and their local index (locals2fg);
+ * local_key / local_inst (batch*max_inst*num_sweeps): locals_bis / inst2locals; inst_key / inst_first / inst_last (batch*max_inst):
+ * instance_bi / indices_locals_min_sweep / indices_locals_max_sweep; counts (4) int32 = [n_fg, n_local, n_inst, rows with a key outside
+ * the table (treated as background)]. */
+int pcp_hunter_meta(const pcp_hunter_meta_t *desc, const float *points, int64_t n, int32_t row_stride, void *workspace, size_t workspace_bytes,
+                    int32_t *fg_idx, int32_t *fg_local, int32_t *local_key, int32_t *local_inst, int32_t *inst_key, int32_t *inst_first,
+                    int32_t *inst_last, int32_t *counts, void *stream);
+
+/* torch_scatter.scatter_max(src[row_index], seg): out (n_seg, c) and the arg-max row (first maximal row) per (segment, channel);
+ * backward: dsrc[row_index[arg[s, ch]], ch] += dout[s, ch]. */
+int pcp_segment_max(const float *src, int32_t ld_src, const int32_t *row_index, int64_t rows, const int32_t *seg, int64_t n_seg, int32_t c,
+                    float *out, int32_t ld_out, int32_t *arg, void *stream);
+int pcp_segment_max_backward(const float *dout, int32_t ld_dout, const int32_t *arg, int64_t n_seg, int32_t c, const int32_t *row_index,
+                             float *dsrc, int32_t ld_dsrc, void *stream);
+/* dst[row_index[r], :c] += src[r, :c]  (row_index injective) */
+int pcp_rows_scatter_add(const float *src, int32_t ld_src, const int32_t *row_index, int64_t rows, int32_t c, float *dst, int32_t ld_dst,
+                         void *stream);
+/* centroid (n_local, 3) = scatter_mean(fg xyz); centered (n_fg, ld) = [xyz - centroid[local], 0 ...]; workspace >= 32 * n_local bytes */
+int pcp_hunter_local_centroids(const float *points, int32_t row_stride, const int32_t *fg_idx, const int32_t *fg_local, int32_t n_fg,
+                               int32_t n_local, void *workspace, size_t workspace_bytes, float *centroid, float *centered, int32_t ld_centered,
+                               void *stream);
+/* out (n_local, ld) = [lf0 | gf[inst] | centroid | centroid[last local of inst] | 0 ...]   (hunter_jr.py:64-69) and its backward */
+int pcp_hunter_object_cat(const float *lf0, const float *gf, const float *centroid, const int32_t *local_inst, const int32_t *inst_last,
+                          int32_t n_local, int32_t c, float *out, int32_t ld_out, void *stream);
+int pcp_hunter_object_cat_backward(const float *dcat, int32_t ld, const int32_t *inst_first, const int32_t *inst_last, int32_t n_local,
+                                   int32_t n_inst, int32_t c, float *dlf0, float *dgf, void *stream);
+
+typedef struct {
+  int64_t n;
+  int32_t stride, n_fg, n_local, n_inst, c;
+  int32_t batch, max_inst, num_sweeps;
+  const float *points;                          /* rows BEFORE the in-place correction */
+  const float *gt_boxes;                        /* (batch, max_inst, 8) */
+  const float *instances_tf;                    /* (batch, max_inst, num_sweeps, 3, 4) */
+  const int32_t *fg_idx, *fg_local, *local_key, *local_inst, *inst_key;
+  const float *head;                            /* (n, ld_head): [cls(3) | flow(3) | embedding(2)] */
+  int32_t ld_head;
+  const float *local_feat;                      /* (n, ld): point head's local feature */
+  int32_t ld_local_feat;
+  const float *locals_feat;                     /* (n_local, ld): object head's local feature */
+  int32_t ld_locals_feat;
+  const float *locals_tf;                       /* (n_local, ld): [t(3) | quaternion xyzw(4)] */
+  int32_t ld_locals_tf;
+  float coef_fg, coef_locals;                   /* LOSS_HARD_MINING_STATIC_FG_COEF / _LOCALS_COEF */
+  float grad_scale;
+  float *dhead;                                 /* (n, ld_dhead), every channel written */
+  int32_t ld_dhead;
+  float *dlocal_feat_fg;                        /* (n_fg, c): gradient of local_feat at the foreground rows */
+  float *dlocals_feat;                          /* (n_local, c) */
+  float *dlocals_tf;                            /* (n_local, ld_dlocals_tf), every channel written */
+  int32_t ld_dlocals_tf;
+  float *losses;                                /* (8): l_points_cls, l_points_embed, l_fg_offset, l_locals_transl, l_locals_rot, l_recon,
+                                                   l_dtl_locals_feat, their sum */
+  int32_t *labels;                              /* (n): point class targets 0 background / 1 static / 2 moving foreground */
+  float *tgt_embedding, *tgt_offset;            /* optional (n_fg, 2) / (n_fg, 3) */
+} pcp_hunter_loss_t;
+
+size_t pcp_hunter_loss_workspace_bytes(int64_t n, int32_t n_fg, int32_t n_local, int32_t c);
+int pcp_hunter_losses(const pcp_hunter_loss_t *desc, void *workspace, size_t workspace_bytes, void *stream);
+
+/* fused = map0 * w0 + map1 * w1, (w0, w1) = softmax(logits[:, 0:2]); cat rows hold [map0 (c) | map1 (c)].  dcat (pixels, ld_dcat) and
+ * dlogits (pixels, ld_dlogits; channels >= 2 zeroed) are overwritten. */
+int pcp_softmax_fuse2_backward(const float *dfused, int32_t ld_df, const float *cat, int32_t ld_cat, const float *logits, int32_t ld_logits,
+                               int64_t pixels, int32_t c, float *dcat, int32_t ld_dcat, float *dlogits, int32_t ld_dlogits, void *stream);
+/* backward of pcp_bev_scatter_mean through the workspace its forward left: rows with dyn_mask go to dfeat_dyn (overwritten), the others are
+ * ADDED to dfeat_acc */
+int pcp_bev_scatter_mean_backward(const void *scatter_workspace, int32_t batch, int32_t h, int32_t w, int64_t n, const float *dmap,
+                                  int32_t ld_dmap, int32_t c, const uint8_t *dyn_mask, float *dfeat_acc, int32_t ld_acc, float *dfeat_dyn,
+                                  int32_t ld_dyn, void *stream);
+/* backward of pcp_bev_sample_bilinear: dbev += (atomic); with bev != NULL also dxyz[i, 0..1] += d loss / d (x, y) of point i */
+int pcp_bev_sample_bilinear_backward(const float *dfeat, int32_t ld_dfeat, const uint8_t *row_mask, const float *points, int64_t n,
+                                     int32_t row_stride, const float *bev, int32_t ld_bev, int32_t batch, int32_t h, int32_t w, int32_t c,
+                                     float min_x, float min_y, float pix_x, float pix_y, float *dbev, int32_t ld_dbev, float *dxyz,
+                                     int32_t ld_dxyz, void *stream);
+/* remove_gt_boxes_outside_range: rows whose centre lies in [range[0:3], range[3:6]) keep their order, the rest of (batch, max_boxes, 8) is
+ * zero (the reference additionally shrinks max_boxes to the largest kept count; zero rows are padding to every consumer) */
+int pcp_filter_gt_boxes(const float *gt_boxes, int32_t batch, int32_t max_boxes, const float *range6_host, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Optimizer step on flat buffers: global-norm clipping + Adam with decoupled weight decay.
  * Replaces tools/train_utils/train_utils.py:57-58 (clip_grad_norm_ + optimizer.step()) and
  *          tools/train_utils/optimization/fastai_optim.py:104-122 (p.mul_(1 - wd * lr); torch.optim.Adam.step, betas (mom, 0.99)).

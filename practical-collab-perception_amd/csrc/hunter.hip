@@ -228,6 +228,20 @@ __global__ void k_apply_flow(float *__restrict__ points, long long n, int stride
   row_mask[i] = dyn ? 1 : 0;
 }
 
+// bev_scatter backward: every kept point receives d map[cell] / count[cell]; rows of `dyn` points go to dfeat_dyn (overwritten), the
+// others are ADDED to dfeat_acc (they carry the first sampling's features)
+__global__ void k_sc_mean_backward(const int *__restrict__ cell_count, const int *__restrict__ point_cell, long long n, const float *__restrict__ dmap,
+                                   int ld_dmap, int c, const unsigned char *__restrict__ dyn, float *__restrict__ dfeat_acc, int ld_acc,
+                                   float *__restrict__ dfeat_dyn, int ld_dyn) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  const long long i = t / c;
+  const int ch = (int)(t % c);
+  const int cell = point_cell[i];
+  const float v = cell >= 0 ? dmap[(long long)cell * ld_dmap + ch] / (float)cell_count[cell] : 0.f;
+  if (dyn[i]) dfeat_dyn[i * ld_dyn + ch] = v; else dfeat_acc[i * ld_acc + ch] += v;
+}
+
 constexpr int MAX_POSE_BATCH = 16;
 struct PoseTable {
   float m[MAX_POSE_BATCH][12];
@@ -361,6 +375,22 @@ extern "C" int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_
   }
   hipLaunchKernelGGL(k_sc_mean, dim3((unsigned)cells), dim3(SC_THREADS), 0, st, cell_start, bucket, feat, ld_feat, c / 4, out,
                      ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+
+// backward of pcp_bev_scatter_mean (training, include/pcp_hip_train.h): reads the cell counts and the per-point cell list the forward left
+// in ITS workspace (same batch / h / w / n)
+extern "C" int pcp_bev_scatter_mean_backward(const void *scatter_workspace, int32_t batch, int32_t h, int32_t w, int64_t n, const float *dmap,
+                                             int32_t ld_dmap, int32_t c, const uint8_t *dyn_mask, float *dfeat_acc, int32_t ld_acc,
+                                             float *dfeat_dyn, int32_t ld_dyn, void *stream_) {
+  if (!scatter_workspace || !dmap || !dyn_mask || !dfeat_acc || !dfeat_dyn || n <= 0 || c <= 0 || batch <= 0 || h <= 0 || w <= 0) return PCP_ERR_ARG;
+  ScLayout L = sc_layout((long long)batch * h * w, n);
+  const char *ws = (const char *)scatter_workspace;
+  const int *cell_count = (const int *)(ws + L.cell_count), *point_cell = (const int *)(ws + L.point_cell);
+  hipLaunchKernelGGL(k_sc_mean_backward, dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, cell_count, point_cell,
+                     (long long)n, dmap, ld_dmap, c, dyn_mask, dfeat_acc, ld_acc, dfeat_dyn, ld_dyn);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

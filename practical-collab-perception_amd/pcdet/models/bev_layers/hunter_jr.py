@@ -1,6 +1,7 @@
-"""HunterJr "aligner" corrector on gfx950, inference branch (reference: pcdet/models/bev_layers/hunter_jr.py:115-399 and
-hunter_toolbox.py).  Parameter tree identical to the reference, including the training-only object_head (it exists in
-published checkpoints because the reference constructs it whenever the module is built in training mode).
+"""HunterJr "aligner" corrector on gfx950 (reference: pcdet/models/bev_layers/hunter_jr.py:115-495 and hunter_toolbox.py).  Parameter tree
+identical to the reference, including the training-only object_head (it exists in published checkpoints because the reference constructs
+it whenever the module is built in training mode).  Training (object head, targets, the seven loss terms and the whole backward) runs in
+pcdet/models/hunter_train_path.py on the kernels of csrc/hunter_train.hip; this file holds the module and the inference branch.
 
 Forward: conv_input (MFMA 3x3, written into the first half of a 768-channel NHWC buffer) -> bilinear point sampling ->
 point MLP (two fused Linear+BN+ReLU launches, residual add fused into the second) -> the three point heads as ONE
@@ -17,7 +18,7 @@ import torch.nn as nn
 from pcp_amd import lib, ops, pack
 
 from ..convnet import PackedConv, pack_conv_module
-from ..packed import PackedModule, require_eval_hip
+from ..packed import PackedModule, require_eval_hip, train_tape
 
 
 def conv_bn_relu(in_channels, out_channels, kernel_size=3, stride=1, padding=0, norm_layer=nn.BatchNorm2d):
@@ -93,6 +94,8 @@ class HunterJr(PackedModule):
         # always creates it too (hunter_jr.py:139-142) and checkpoints contain its weights
         self.object_head = HunterObjectHead(num_bev_features, list(model_cfg.get('OBJ_HEAD_HIDDEN_CHANNELS')), use_drop_out=False)
         self.thresh_point_cls_prob = model_cfg.get('THRESHOLD_POINT_CLS_PROB', 0.3)
+        self.meta_sweep_col = model_cfg.get('META_POINTS_FEAT_LOCATION_SWEEP_IDX', -2)
+        self.meta_inst_col = model_cfg.get('META_POINTS_FEAT_LOCATION_INSTANCE_IDX', -1)
         self.sorted_gather = True          # MI355X knob: point-head gathers in spatially sorted order (output unchanged)
         self.conv_weightor = nn.Sequential(
             conv_bn_relu(2 * num_bev_features, 2 * num_bev_features, padding=1, norm_layer=norm),
@@ -127,7 +130,20 @@ class HunterJr(PackedModule):
                     w0=pack_conv_module(self.conv_weightor[0][0], self.conv_weightor[0][1], relu=True),
                     w1=pack_conv_module(self.conv_weightor[1], None, relu=False))
 
+    def _forward_train(self, batch_dict):
+        from ..hunter_train_path import HunterTrain
+        if getattr(self, '_pcp_train', None) is None:
+            self._pcp_train = HunterTrain(self)
+        self.invalidate_packed()
+        fused = self._pcp_train.forward(batch_dict)
+        batch_dict.pop('spatial_features_2d')
+        batch_dict['spatial_features_2d'] = ops.nchw_view(fused)
+        train_tape(batch_dict).append(('corrector', self._pcp_train.backward))
+        return batch_dict
+
     def forward(self, batch_dict):
+        if self.training:
+            return self._forward_train(batch_dict)
         require_eval_hip(self, 'HunterJr')
         pk = self.packed()
         points = batch_dict['points']
@@ -198,4 +214,14 @@ class HunterJr(PackedModule):
                 batch_dict['scene_flow'] = sample_points
 
     def get_training_loss(self, tb_dict=None):
-        raise NotImplementedError('HunterJr training losses are outside round 1 (inference path only)')
+        """the seven loss terms of hunter_jr.py:401-495 AND their gradients w.r.t. the head outputs (consumed by loss.backward())"""
+        tb_dict = {} if tb_dict is None else tb_dict
+        out = self._pcp_train.losses()
+        vals = out['losses'].tolist()
+        for k, v in zip(('l_points_cls', 'l_points_embed', 'l_fg_offset', 'l_locals_transl', 'l_locals_rot', 'l_recon', 'l_dtl_locals_feat'), vals):
+            tb_dict[k] = v
+        st = self._pcp_train.s
+        self.forward_return_dict.update(points_cls_target=out['labels'], meta=st['meta'], prediction={
+            'points_cls_logit': st['head'][:, 0:3], 'points_flow3d': st['head'][:, 3:6], 'points_embedding': st['head'][:, 6:8],
+            'locals_tf': st['locals_tf'][:, :7] if 'locals_tf' in st else None})
+        return out['losses'][7], tb_dict

@@ -77,6 +77,21 @@ class AnchorLoss(ctypes.Structure):
                 ('code_weights', c_f * 7)]
 
 
+class HunterMeta(ctypes.Structure):
+    _fields_ = [('batch', c_i32), ('max_inst', c_i32), ('num_sweeps', c_i32), ('sweep_col', c_i32), ('inst_col', c_i32)]
+
+
+class HunterLoss(ctypes.Structure):
+    _fields_ = [('n', c_i64), ('stride', c_i32), ('n_fg', c_i32), ('n_local', c_i32), ('n_inst', c_i32), ('c', c_i32),
+                ('batch', c_i32), ('max_inst', c_i32), ('num_sweeps', c_i32),
+                ('points', vp), ('gt_boxes', vp), ('instances_tf', vp),
+                ('fg_idx', vp), ('fg_local', vp), ('local_key', vp), ('local_inst', vp), ('inst_key', vp),
+                ('head', vp), ('ld_head', c_i32), ('local_feat', vp), ('ld_local_feat', c_i32), ('locals_feat', vp), ('ld_locals_feat', c_i32),
+                ('locals_tf', vp), ('ld_locals_tf', c_i32), ('coef_fg', c_f), ('coef_locals', c_f), ('grad_scale', c_f),
+                ('dhead', vp), ('ld_dhead', c_i32), ('dlocal_feat_fg', vp), ('dlocals_feat', vp), ('dlocals_tf', vp), ('ld_dlocals_tf', c_i32),
+                ('losses', vp), ('labels', vp), ('tgt_embedding', vp), ('tgt_offset', vp)]
+
+
 PW_PLAIN, PW_SPACE2DEPTH, PW_DEPTH2SPACE = 0, 1, 2
 
 # every symbol include/pcp_hip.h declares: name -> (restype, argtypes)
@@ -157,6 +172,21 @@ SYMBOLS.update({
     'pcp_anchor_assign_targets': (c_i32, [ctypes.POINTER(AnchorAssign), vp, vp, c_i32, vp, c_sz, vp, vp, vp, vp]),
     'pcp_anchor_loss_workspace_bytes': (c_sz, [c_i32]),
     'pcp_anchor_loss': (c_i32, [ctypes.POINTER(AnchorLoss), vp, vp, vp, vp, c_f, vp, c_sz, vp, vp, vp]),
+    'pcp_hunter_meta_workspace_bytes': (c_sz, [ctypes.POINTER(HunterMeta), c_i64]),
+    'pcp_hunter_meta': (c_i32, [ctypes.POINTER(HunterMeta), vp, c_i64, c_i32, vp, c_sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_segment_max': (c_i32, [vp, c_i32, vp, c_i64, vp, c_i64, c_i32, vp, c_i32, vp, vp]),
+    'pcp_segment_max_backward': (c_i32, [vp, c_i32, vp, c_i64, c_i32, vp, vp, c_i32, vp]),
+    'pcp_rows_scatter_add': (c_i32, [vp, c_i32, vp, c_i64, c_i32, vp, c_i32, vp]),
+    'pcp_hunter_local_centroids': (c_i32, [vp, c_i32, vp, vp, c_i32, c_i32, vp, c_sz, vp, vp, c_i32, vp]),
+    'pcp_hunter_object_cat': (c_i32, [vp, vp, vp, vp, vp, c_i32, c_i32, vp, c_i32, vp]),
+    'pcp_hunter_object_cat_backward': (c_i32, [vp, c_i32, vp, vp, c_i32, c_i32, c_i32, vp, vp, vp]),
+    'pcp_hunter_loss_workspace_bytes': (c_sz, [c_i64, c_i32, c_i32, c_i32]),
+    'pcp_hunter_losses': (c_i32, [ctypes.POINTER(HunterLoss), vp, c_sz, vp]),
+    'pcp_softmax_fuse2_backward': (c_i32, [vp, c_i32, vp, c_i32, vp, c_i32, c_i64, c_i32, vp, c_i32, vp, c_i32, vp]),
+    'pcp_bev_scatter_mean_backward': (c_i32, [vp, c_i32, c_i32, c_i32, c_i64, vp, c_i32, c_i32, vp, vp, c_i32, vp, c_i32, vp]),
+    'pcp_bev_sample_bilinear_backward': (c_i32, [vp, c_i32, vp, vp, c_i64, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, vp,
+                                                 c_i32, vp, c_i32, vp]),
+    'pcp_filter_gt_boxes': (c_i32, [vp, c_i32, c_i32, ctypes.POINTER(c_f), vp, vp]),
     'pcp_distill_loss': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, c_f, vp, vp, vp, c_i32, c_i32, vp]),
     'pcp_pfn_train_features': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, vp, vp, vp]),
     'pcp_pfn_train_mid': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp]),

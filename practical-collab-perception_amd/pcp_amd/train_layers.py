@@ -275,3 +275,113 @@ class ConvBNAct:
             w, b, cp = self._bw
             ops.pointwise(dy.t, w, b, mode, self.cout, self.cin, cp, relu=False, out=dx_out.t, in_ch_off=dy.off, out_ch_off=dx_out.off)
         return dx_out
+
+
+class LinearBNAct:
+    """nn.Linear (no bias) + BatchNorm1d (batch statistics) + ReLU on rows (N, cin) -- the blocks of hunter_toolbox.py:130-158 (nn_make_mlp).
+    cin is padded to a multiple of 16 with zero weight columns (the 3-d and 774-d inputs of the object head)."""
+
+    def __init__(self, linear, bn, relu=True, name=''):
+        self.lin, self.bn, self.relu, self.name = linear, bn, relu, name
+        self.cout, self.cin = linear.weight.shape
+        self.cin_pad = pack.round_up(self.cin, 16)
+        assert linear.bias is None and bn is not None
+        self._step = -1
+        self.vec = None
+        self.saved = None
+
+    def _forms(self):
+        if self._step == StepClock.step:
+            return self._f
+        w = self.lin.weight.detach().float()
+        dev = w.device
+        wp = w.new_zeros((self.cout, self.cin_pad))
+        wp[:, :self.cin] = w
+        self._f = dict(fw=pack.pack_plain(wp, w.new_zeros(self.cout)), bw=pack.pack_plain(wp.t().contiguous(), w.new_zeros(self.cin_pad)))
+        self._step = StepClock.step
+        return self._f
+
+    def forward(self, x):
+        """x: (rows, ld >= cin_pad) contiguous, columns [cin, cin_pad) zero.  Returns (rows, cout)."""
+        f = self._forms()
+        rows = x.shape[0]
+        w, b, cp = f['fw']
+        y = torch.empty((rows, self.cout), dtype=torch.float32, device=x.device)
+        ops.pointwise(x, w, b, lib.PW_PLAIN, self.cin_pad, self.cout, cp, relu=False, out=y)
+        bn = self.bn
+        self.vec = tops.bn_train_stats(y, self.cout, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                       vec=self.vec)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        out = torch.empty_like(y)
+        tops.scale_shift_act(y, self.cout, self.vec, self.relu, out)
+        self.saved = (x, y)
+        return out
+
+    def backward(self, dout, need_dx=True):
+        """dout: (rows, cout), overwritten.  Returns (rows, cin_pad) or None."""
+        x, y = self.saved
+        tops.bn_act_backward(dout, y, self.cout, self.vec, self.relu, ensure_grad(self.bn.weight), ensure_grad(self.bn.bias))
+        rows = x.shape[0]
+        dw = torch.empty((self.cout, self.cin_pad), dtype=torch.float32, device=x.device)
+        tops.pointwise_wgrad(tops.rowmap(dout, self.cout), tops.rowmap(x, self.cin_pad), rows, dw)
+        ensure_grad(self.lin.weight).copy_(dw[:, :self.cin])
+        if not need_dx:
+            return None
+        w, b, cp = self._forms()['bw']
+        dx = torch.empty((rows, self.cin_pad), dtype=torch.float32, device=x.device)
+        ops.pointwise(dout, w, b, lib.PW_PLAIN, self.cout, self.cin_pad, cp, relu=False, out=dx)
+        return dx
+
+
+class MultiLinear:
+    """several nn.Linear (with bias) reading the same rows, as ONE pointwise GEMM over the concatenated outputs (the three point heads
+    seg / reg_flow3d / instance_embedding of hunter_jr.py:93-96, the local_tf_decoder of :40).  The output / gradient buffers are 16 columns
+    wide per 16 outputs so that the gradient is a legal contraction operand of the data-gradient GEMM."""
+
+    def __init__(self, linears, name=''):
+        self.lins, self.name = list(linears), name
+        self.outs = [l.weight.shape[0] for l in self.lins]
+        self.offs = [0]
+        for o in self.outs:
+            self.offs.append(self.offs[-1] + o)
+        self.cin = self.lins[0].weight.shape[1]
+        self.cout = self.offs[-1]
+        self.ld = pack.round_up(self.cout, 16)
+        self._step = -1
+        self.saved = None
+
+    def _forms(self):
+        if self._step == StepClock.step:
+            return self._f
+        w = torch.cat([l.weight.detach().float() for l in self.lins], 0)
+        b = torch.cat([l.bias.detach().float() for l in self.lins], 0)
+        wt = w.new_zeros((self.cin, self.ld))
+        wt[:, :self.cout] = w.t()
+        self._f = dict(fw=pack.pack_plain(w, b), bw=pack.pack_plain(wt, w.new_zeros(self.cin)))
+        self._step = StepClock.step
+        return self._f
+
+    def forward(self, x):
+        """x: (rows, cin) contiguous.  Returns (rows, ld); columns past cout are zero."""
+        w, b, cp = self._forms()['fw']
+        out = torch.zeros((x.shape[0], self.ld), dtype=torch.float32, device=x.device)
+        ops.pointwise(x, w, b, lib.PW_PLAIN, self.cin, self.cout, cp, relu=False, out=out)
+        self.saved = x
+        return out
+
+    def backward(self, dout):
+        """dout: (rows, ld) with zero padding columns.  Returns (rows, cin)."""
+        x = self.saved
+        rows = x.shape[0]
+        dw = torch.empty((self.ld, self.cin), dtype=torch.float32, device=x.device)
+        tops.pointwise_wgrad(tops.rowmap(dout, self.ld), tops.rowmap(x, self.cin), rows, dw)
+        db = torch.empty((self.ld,), dtype=torch.float32, device=x.device)
+        tops.colsum(dout, self.ld, db)
+        for i, l in enumerate(self.lins):
+            ensure_grad(l.weight).copy_(dw[self.offs[i]:self.offs[i + 1]])
+            ensure_grad(l.bias).copy_(db[self.offs[i]:self.offs[i + 1]])
+        w, b, cp = self._forms()['bw']
+        dx = torch.empty((rows, self.cin), dtype=torch.float32, device=x.device)
+        ops.pointwise(dout, w, b, lib.PW_PLAIN, self.ld, self.cin, cp, relu=False, out=dx)
+        return dx

@@ -330,3 +330,132 @@ def pack_conv3x3(w, transpose, direct=None, direct_opad=0, wino=None, wino_opad=
     assert w.is_contiguous() and w.dtype == torch.float32
     check(L.pcp_pack_conv3x3(_p(w), w.shape[0], w.shape[1], 1 if transpose else 0, _p(direct), direct_opad, _p(wino), wino_opad, _p(b3), b3_opad,
                              _stream()), 'pcp_pack_conv3x3')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a17: HunterJr training branch
+# ---------------------------------------------------------------------------------------------------------------------
+
+_HUNTER_WS = Scratch()
+
+
+class HunterMetaResult:
+    """device tensors at their capacity; n_fg / n_local / n_inst read back once (the reference syncs several times here: torch.unique,
+    .item())"""
+    __slots__ = ('fg_idx', 'fg_local', 'local_key', 'local_inst', 'inst_key', 'inst_first', 'inst_last', 'n_fg', 'n_local', 'n_inst', 'bad_rows')
+
+
+def hunter_meta(points, batch, max_inst, num_sweeps, sweep_col, inst_col):
+    """hunter_jr.py:165-196 (_build_meta) + the foreground mask of :323"""
+    _need_cuda(points)
+    L = _lib.load()
+    n, stride = points.shape
+    d = _lib.HunterMeta(batch, max_inst, num_sweeps, sweep_col % stride, inst_col % stride)
+    dev = points.device
+    T, BM = batch * max_inst * num_sweeps, batch * max_inst
+    i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)
+    r = HunterMetaResult()
+    r.fg_idx, r.fg_local, r.local_key, r.local_inst = i32(n), i32(n), i32(T), i32(T)
+    r.inst_key, r.inst_first, r.inst_last = i32(BM), i32(BM), i32(BM)
+    counts = i32(4)
+    ws = _HUNTER_WS.get(L.pcp_hunter_meta_workspace_bytes(ctypes.byref(d), n), dev)
+    check(L.pcp_hunter_meta(ctypes.byref(d), _p(points), n, stride, _p(ws), ws.numel(), _p(r.fg_idx), _p(r.fg_local), _p(r.local_key),
+                            _p(r.local_inst), _p(r.inst_key), _p(r.inst_first), _p(r.inst_last), _p(counts), _stream()), 'pcp_hunter_meta')
+    r.n_fg, r.n_local, r.n_inst, r.bad_rows = [int(v) for v in counts.tolist()]
+    return r
+
+
+def segment_max(src, seg, n_seg, c, row_index=None, rows=None):
+    """torch_scatter.scatter_max(src[row_index], seg, dim=0): returns (out (n_seg, c), arg (n_seg, c) int32)"""
+    _need_cuda(src, seg, row_index)
+    L = _lib.load()
+    rows = (row_index.shape[0] if row_index is not None else src.shape[0]) if rows is None else rows
+    out = torch.empty((n_seg, c), dtype=torch.float32, device=src.device)
+    arg = torch.empty((n_seg, c), dtype=torch.int32, device=src.device)
+    check(L.pcp_segment_max(_p(src), src.shape[-1], _p(row_index), rows, _p(seg), n_seg, c, _p(out), c, _p(arg), _stream()), 'pcp_segment_max')
+    return out, arg
+
+
+def segment_max_backward(dout, arg, dsrc, c, row_index=None):
+    L = _lib.load()
+    check(L.pcp_segment_max_backward(_p(dout), dout.shape[-1], _p(arg), arg.shape[0], c, _p(row_index), _p(dsrc), dsrc.shape[-1], _stream()),
+          'pcp_segment_max_backward')
+    return dsrc
+
+
+def rows_scatter_add(src, row_index, rows, c, dst):
+    L = _lib.load()
+    check(L.pcp_rows_scatter_add(_p(src), src.shape[-1], _p(row_index), rows, c, _p(dst), dst.shape[-1], _stream()), 'pcp_rows_scatter_add')
+    return dst
+
+
+def hunter_local_centroids(points, meta, ld_centered=16):
+    L = _lib.load()
+    dev = points.device
+    centroid = torch.empty((meta.n_local, 3), dtype=torch.float32, device=dev)
+    centered = torch.empty((meta.n_fg, ld_centered), dtype=torch.float32, device=dev)
+    ws = _HUNTER_WS.get(32 * meta.n_local, dev)
+    check(L.pcp_hunter_local_centroids(_p(points), points.shape[1], _p(meta.fg_idx), _p(meta.fg_local), meta.n_fg, meta.n_local, _p(ws),
+                                       ws.numel(), _p(centroid), _p(centered), ld_centered, _stream()), 'pcp_hunter_local_centroids')
+    return centroid, centered
+
+
+def hunter_object_cat(lf0, gf, centroid, meta, c, ld_out):
+    L = _lib.load()
+    out = torch.empty((meta.n_local, ld_out), dtype=torch.float32, device=lf0.device)
+    check(L.pcp_hunter_object_cat(_p(lf0), _p(gf), _p(centroid), _p(meta.local_inst), _p(meta.inst_last), meta.n_local, c, _p(out), ld_out,
+                                  _stream()), 'pcp_hunter_object_cat')
+    return out
+
+
+def hunter_object_cat_backward(dcat, meta, c):
+    L = _lib.load()
+    dlf0 = torch.empty((meta.n_local, c), dtype=torch.float32, device=dcat.device)
+    dgf = torch.empty((meta.n_inst, c), dtype=torch.float32, device=dcat.device)
+    check(L.pcp_hunter_object_cat_backward(_p(dcat), dcat.shape[-1], _p(meta.inst_first), _p(meta.inst_last), meta.n_local, meta.n_inst, c,
+                                           _p(dlf0), _p(dgf), _stream()), 'pcp_hunter_object_cat_backward')
+    return dlf0, dgf
+
+
+def hunter_losses(desc, device):
+    """desc: lib.HunterLoss with every pointer set (see include/pcp_hip_train.h); runs the loss + gradient kernels"""
+    L = _lib.load()
+    need = L.pcp_hunter_loss_workspace_bytes(desc.n, desc.n_fg, desc.n_local, desc.c)
+    ws = _HUNTER_WS2.get(need, device)
+    check(L.pcp_hunter_losses(ctypes.byref(desc), _p(ws), ws.numel(), _stream()), 'pcp_hunter_losses')
+
+
+_HUNTER_WS2 = Scratch()
+
+
+def softmax_fuse2_backward(dfused, cat, logits, c, dcat, dlogits):
+    L = _lib.load()
+    pixels = dfused.numel() // dfused.shape[-1]
+    check(L.pcp_softmax_fuse2_backward(_p(dfused), dfused.shape[-1], _p(cat), cat.shape[-1], _p(logits), logits.shape[-1], pixels, c, _p(dcat),
+                                       dcat.shape[-1], _p(dlogits), dlogits.shape[-1], _stream()), 'pcp_softmax_fuse2_backward')
+
+
+def bev_scatter_mean_backward(workspace, batch, h, w, n, dmap, dmap_ch_off, c, dyn_mask, dfeat_acc, dfeat_dyn):
+    L = _lib.load()
+    check(L.pcp_bev_scatter_mean_backward(_p(workspace), batch, h, w, n, _chan_ptr(dmap, dmap_ch_off), dmap.shape[-1], c, _p(dyn_mask),
+                                          _p(dfeat_acc), dfeat_acc.shape[-1], _p(dfeat_dyn), dfeat_dyn.shape[-1], _stream()),
+          'pcp_bev_scatter_mean_backward')
+
+
+def bev_sample_bilinear_backward(dfeat, points, batch, h, w, c, min_xy, pix_xy, dbev, row_mask=None, bev=None, dxyz=None, dxyz_ch_off=0):
+    L = _lib.load()
+    n, stride = points.shape
+    check(L.pcp_bev_sample_bilinear_backward(_p(dfeat), dfeat.shape[-1], _p(row_mask), _p(points), n, stride, _p(bev),
+                                             bev.shape[-1] if bev is not None else 0, batch, h, w, c, float(min_xy[0]), float(min_xy[1]),
+                                             float(pix_xy[0]), float(pix_xy[1]), _p(dbev), dbev.shape[-1],
+                                             _chan_ptr(dxyz, dxyz_ch_off) if dxyz is not None else ctypes.c_void_p(0),
+                                             dxyz.shape[-1] if dxyz is not None else 0, _stream()), 'pcp_bev_sample_bilinear_backward')
+
+
+def filter_gt_boxes(gt_boxes, pc_range):
+    L = _lib.load()
+    B, M, _ = gt_boxes.shape
+    out = torch.empty_like(gt_boxes)
+    rng = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    check(L.pcp_filter_gt_boxes(_p(gt_boxes), B, M, rng, _p(out), _stream()), 'pcp_filter_gt_boxes')
+    return out

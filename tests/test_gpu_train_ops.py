@@ -615,3 +615,299 @@ def test_anchor_losses_and_head_gradient():
     l1 = tops.anchor_loss(head1.to(DEV), anchors.to(DEV), labels.to(DEV), reg_t.to(DEV), d, dhead=dhead, grad_scale=0.5).cpu().numpy()
     assert abs(l1[3] - float(t1)) <= 1e-5 * float(t1)
     _close(dhead.cpu()[..., :A] * 2.0, cls1.grad, 2e-5, 'class-agnostic dcls')
+
+
+# ---- a17: HunterJr training branch -------------------------------------------------------------------------------------------
+
+def _g12():
+    from helpers import load_golden
+    return load_golden('g12_hunter_train.npz')
+
+
+def test_hunter_meta_equals_the_references_unique_chain():
+    """pcp_hunter_meta against the reference's _build_meta (two torch.unique + scatter_max / scatter_min) on the g12 fixture: every index
+    list bit exact"""
+    from pcp_amd import train_ops as tops
+    g = _g12()
+    pts = torch.from_numpy(g['points']).to(DEV)
+    m = tops.hunter_meta(pts, 2, g['gt_boxes'].shape[1], 11, -2, -1)
+    mask = g['meta/mask_fg']
+    assert m.n_fg == int(mask.sum()) and m.n_local == g['meta/locals_bis'].shape[0] and m.n_inst == g['meta/instance_bi'].shape[0] and m.bad_rows == 0
+    assert np.array_equal(m.fg_idx[:m.n_fg].cpu().numpy(), np.nonzero(mask)[0])
+    assert np.array_equal(m.fg_local[:m.n_fg].cpu().numpy(), g['meta/locals2fg'])
+    assert np.array_equal(m.local_key[:m.n_local].cpu().numpy(), g['meta/locals_bis'])
+    assert np.array_equal(m.local_inst[:m.n_local].cpu().numpy(), g['meta/inst2locals'])
+    assert np.array_equal(m.inst_key[:m.n_inst].cpu().numpy(), g['meta/instance_bi'])
+    assert np.array_equal(m.inst_last[:m.n_inst].cpu().numpy(), g['meta/indices_locals_max_sweep'])
+    assert np.array_equal(m.inst_first[:m.n_inst].cpu().numpy(), g['meta/indices_locals_min_sweep'])
+    # a cloud without foreground
+    bg = pts.clone()
+    bg[:, -1] = -1.0
+    m0 = tops.hunter_meta(bg, 2, 6, 11, -2, -1)
+    assert (m0.n_fg, m0.n_local, m0.n_inst) == (0, 0, 0)
+
+
+def test_segment_max_and_its_routing():
+    from pcp_amd import train_ops as tops
+    rng = np.random.RandomState(5)
+    n, c, nseg = 3000, 48, 37
+    src = torch.from_numpy(rng.randn(n, 64).astype(np.float32))
+    src[::7, :10] = 0.0                                       # ties (ReLU zeros): the first row wins, like torch_scatter
+    rows = torch.from_numpy(np.sort(rng.choice(n, 900, replace=False)).astype(np.int32))
+    seg = torch.from_numpy(rng.randint(0, nseg, 900).astype(np.int32))
+    seg[:nseg] = torch.arange(nseg, dtype=torch.int32)        # no empty segment
+    out, arg = tops.segment_max(src.to(DEV), seg.to(DEV), nseg, c, row_index=rows.to(DEV), rows=900)
+    sel = src[rows.long(), :c]
+    ref = torch.full((nseg, c), -np.inf).scatter_reduce(0, seg.long()[:, None].expand(-1, c), sel, 'amax', include_self=True)
+    assert torch.equal(out.cpu(), ref)
+    a = arg.cpu().long()
+    assert torch.equal(sel.gather(0, a), ref)                 # arg rows hold the maxima
+    first = torch.full((nseg, c), 900, dtype=torch.long).scatter_reduce(
+        0, seg.long()[:, None].expand(-1, c), torch.where(sel == ref[seg.long()], torch.arange(900)[:, None].expand(-1, c), 900), 'amin')
+    assert torch.equal(a, first)
+    dout = torch.from_numpy(rng.randn(nseg, c).astype(np.float32))
+    dsrc = torch.zeros((n, 64), device=DEV)
+    tops.segment_max_backward(dout.to(DEV), arg, dsrc, c, row_index=rows.to(DEV))
+    ref_d = torch.zeros((n, 64))
+    for ch in range(c):
+        ref_d[rows.long()[a[:, ch]], ch] += dout[:, ch]
+    assert torch.equal(dsrc.cpu(), ref_d)
+
+
+@pytest.mark.parametrize('case', ['mixed', 'no_positive', 'all_positive', 'ties', 'large'])
+def test_hard_mining_loss_and_weights(case):
+    """pcp_hunter_losses' hard-mining kernel through the fg-offset term is covered end to end below; here the selection itself: a C-ABI
+    call is not exported for it, so the check runs the whole loss entry on a crafted batch where only l_fg_offset varies"""
+    from oracle import hunter_train as oht
+    rng = np.random.RandomState(3)
+    n = {'mixed': 500, 'no_positive': 300, 'all_positive': 50, 'ties': 400, 'large': 70000}[case]
+    vals = torch.from_numpy(rng.rand(n).astype(np.float32) * 3)
+    pos = torch.from_numpy(rng.rand(n) < {'mixed': 0.2, 'no_positive': 0.0, 'all_positive': 1.1, 'ties': 0.1, 'large': 0.3}[case])
+    if case == 'ties':
+        vals[~pos] = torch.from_numpy(rng.randint(1, 5, int((~pos).sum())).astype(np.float32)) * 0.5
+    v = vals.clone().requires_grad_(True)
+    ref = oht.hard_mining(v, pos)
+    ref.backward()
+    got, w = _hard_mining_via_offsets(vals, pos)
+    assert abs(got - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    if case == 'ties':                                        # tied values share the slots: compare the per-value totals
+        for val in torch.unique(vals[~pos]):
+            sel = (~pos) & (vals == val)
+            assert abs(float(w[sel].sum()) - float(v.grad[sel].sum())) < 1e-5
+        assert torch.allclose(w[pos], v.grad[pos], atol=1e-7)
+    else:
+        assert torch.allclose(w, v.grad, atol=1e-7)
+
+
+def _hard_mining_via_offsets(vals, pos):
+    """drive pcp_hunter_losses so that the per-point offset loss equals `vals` (flow = [val, 0, 0] against a zero offset target with
+    val < 1 -> smooth-L1 = 0.5 val^2 ... simpler: flow = val + 0.5 with val >= 0 gives |d| - 0.5 = val when |d| >= 1, so use d = val + 0.5
+    for val >= 0.5 and sqrt(2 val) below) and the motion flag equals `pos`; returns (l_fg_offset, d loss / d val)."""
+    from pcp_amd import lib
+    from pcp_amd import train_ops as tops
+    n = vals.shape[0]
+    d_abs = torch.where(vals >= 0.5, vals + 0.5, torch.sqrt(2 * vals))          # sl1(d) = vals
+    # one frame, one instance per motion class, one sweep each: instance 0 static, instance 1 moving
+    pts = torch.zeros((n, 8))
+    pts[:, 1:4] = torch.rand(n, 3)
+    pts[:, 6] = 0.0
+    pts[:, 7] = pos.float()
+    gt = torch.zeros((1, 2, 8))
+    gt[0, :, 7] = 1.0
+    itf = torch.zeros((1, 2, 1, 3, 4))
+    itf[..., :3, :3] = torch.eye(3)
+    itf[0, 1, 0, 0, 3] = 1.0                                   # instance 1 moves: |t| > 0.5
+    meta = tops.hunter_meta(pts.to(DEV), 1, 2, 1, -2, -1)
+    assert meta.n_fg == n
+    head = torch.zeros((n, 16))
+    off_t = torch.zeros((n, 3))
+    off_t[pos, 0] = 1.0                                        # offset target = R p + t - p = t
+    head[:, 3] = off_t[:, 0] + d_abs
+    C = 16
+    local_feat = torch.zeros((n, C))
+    locals_feat = torch.zeros((meta.n_local, C))
+    locals_tf = torch.zeros((meta.n_local, 16))
+    locals_tf[:, 6] = 1.0
+    dev_t = lambda t: t.to(DEV).contiguous()
+    ten = dict(pts=dev_t(pts), gt=dev_t(gt), itf=dev_t(itf), head=dev_t(head), lf=dev_t(local_feat), lsf=dev_t(locals_feat), ltf=dev_t(locals_tf),
+               dhead=torch.empty((n, 16), device=DEV), dlf=torch.empty((n, C), device=DEV), dlsf=torch.empty((meta.n_local, C), device=DEV),
+               dltf=torch.empty((meta.n_local, 16), device=DEV), losses=torch.empty(8, device=DEV), labels=torch.empty(n, dtype=torch.int32, device=DEV))
+    d = lib.HunterLoss()
+    d.n, d.stride, d.n_fg, d.n_local, d.n_inst, d.c = n, 8, meta.n_fg, meta.n_local, meta.n_inst, C
+    d.batch, d.max_inst, d.num_sweeps = 1, 2, 1
+    p = lambda t: t.data_ptr()
+    d.points, d.gt_boxes, d.instances_tf = p(ten['pts']), p(ten['gt']), p(ten['itf'])
+    d.fg_idx, d.fg_local, d.local_key, d.local_inst, d.inst_key = p(meta.fg_idx), p(meta.fg_local), p(meta.local_key), p(meta.local_inst), p(meta.inst_key)
+    d.head, d.ld_head, d.local_feat, d.ld_local_feat = p(ten['head']), 16, p(ten['lf']), C
+    d.locals_feat, d.ld_locals_feat, d.locals_tf, d.ld_locals_tf = p(ten['lsf']), C, p(ten['ltf']), 16
+    d.coef_fg, d.coef_locals, d.grad_scale = 1.0, 1.0, 1.0
+    d.dhead, d.ld_dhead, d.dlocal_feat_fg, d.dlocals_feat, d.dlocals_tf, d.ld_dlocals_tf = p(ten['dhead']), 16, p(ten['dlf']), p(ten['dlsf']), p(ten['dltf']), 16
+    d.losses, d.labels = p(ten['losses']), p(ten['labels'])
+    tops.hunter_losses(d, torch.device(DEV))
+    g = ten['dhead'].cpu()[:, 3]                               # = w * sl1'(d) ; sl1'(d) = min(d, 1)
+    w = g / torch.clamp(d_abs, max=1.0)
+    w = torch.where(d_abs > 0, w, torch.zeros_like(w))
+    return float(ten['losses'][2]), w
+
+
+def test_hunter_losses_and_gradients_on_the_references_predictions():
+    """pcp_hunter_losses fed with the reference's own predictions (g12: point logits / flow / embedding, locals_tf) and its own points,
+    boxes and instance motions: six of the seven terms against the reference's tb_dict (1e-5), targets against the reference's
+    assign_target, the distillation term and every gradient against torch autograd of oracle/hunter_train.py"""
+    import json
+    from oracle import hunter_train as oht
+    from pcp_amd import lib
+    from pcp_amd import train_ops as tops
+    g = _g12()
+    ref_tb = json.loads(str(g['it0_tb_json']))
+    pts = torch.from_numpy(g['points'])
+    gt, itf = torch.from_numpy(g['gt_boxes']), torch.from_numpy(g['instances_tf'])
+    N = pts.shape[0]
+    mask_fg = torch.from_numpy(g['meta/mask_fg'])
+    meta_ref = {k: torch.from_numpy(g['meta/' + k]) for k in ('locals2fg', 'inst2locals', 'indices_locals_max_sweep', 'locals_bis', 'instance_bi')}
+    n_local = meta_ref['locals_bis'].shape[0]
+    C = 32
+    rng = np.random.RandomState(9)
+    cls = torch.from_numpy(g['pred/points_cls_logit']).requires_grad_(True)
+    flow = torch.from_numpy(g['pred/points_flow3d']).requires_grad_(True)
+    emb = torch.from_numpy(g['pred/points_embedding']).requires_grad_(True)
+    ltf = torch.from_numpy(g['pred/locals_tf']).requires_grad_(True)
+    lf = torch.from_numpy(rng.randn(N, C).astype(np.float32)).requires_grad_(True)
+    lsf = torch.from_numpy(rng.randn(n_local, C).astype(np.float32)).requires_grad_(True)
+    # ---- oracle terms with autograd
+    tgt = oht.assign_target(pts, mask_fg, gt, itf, meta_ref)
+    terms = {}
+    terms['l_points_cls'], _ = oht.ce_lovasz(cls, torch.argmax(tgt['points_cls'], dim=1))
+    terms['l_points_embed'] = oht._sl1(emb[mask_fg], tgt['fg_embedding']).mean()
+    terms['l_fg_offset'] = oht.hard_mining(oht._sl1(flow[mask_fg], tgt['fg_offset']), tgt['points_cls'][mask_fg, 2] > 0)
+    mos = tgt['mask_locals_mos']
+    terms['l_locals_transl'] = oht.hard_mining(oht._sl1(ltf[:, :3], tgt['locals_tf'][:, :, -1]), mos)
+    rot = oht.quat2mat(ltf[:, 3:])
+    terms['l_locals_rot'] = oht.hard_mining(torch.linalg.norm(rot - tgt['locals_tf'][:, :, :3], dim=(1, 2), ord='fro'), mos)
+    fg_xyz = pts[mask_fg][:, 1:4]
+    fg_tf = tgt['locals_tf'][meta_ref['locals2fg']]
+    gt_corr = torch.matmul(fg_tf[:, :3, :3], fg_xyz.unsqueeze(-1)).squeeze(-1) + fg_tf[:, :3, -1]
+    ptf = torch.cat((rot, ltf[:, :3].unsqueeze(-1)), dim=-1)[meta_ref['locals2fg']]
+    corr = torch.matmul(ptf[:, :3, :3], fg_xyz.unsqueeze(-1)).squeeze(-1) + ptf[:, :3, -1]
+    terms['l_recon'] = oht.hard_mining(oht._sl1(corr, gt_corr), mos[meta_ref['locals2fg']]) * 0.1
+    terms['l_dtl_locals_feat'] = oht._sl1(lf[mask_fg], lsf[meta_ref['locals2fg']]).mean() * 0.1
+    for k in ('l_points_cls', 'l_points_embed', 'l_fg_offset', 'l_locals_transl', 'l_locals_rot', 'l_recon'):
+        assert abs(float(terms[k]) - ref_tb[k]) <= 1e-5 * abs(ref_tb[k]), (k, float(terms[k]), ref_tb[k])     # the oracle itself
+    sum(terms.values()).backward()
+    # ---- device
+    dev_t = lambda t: t.detach().to(DEV).contiguous()
+    meta = tops.hunter_meta(dev_t(pts), 2, gt.shape[1], 11, -2, -1)
+    head = torch.zeros((N, 16))
+    head[:, 0:3], head[:, 3:6], head[:, 6:8] = cls.detach(), flow.detach(), emb.detach()
+    ltf16 = torch.zeros((n_local, 16))
+    ltf16[:, :7] = ltf.detach()
+    ten = dict(pts=dev_t(pts), gt=dev_t(gt), itf=dev_t(itf), head=dev_t(head), lf=dev_t(lf), lsf=dev_t(lsf), ltf=dev_t(ltf16),
+               dhead=torch.full((N, 16), 3.0, device=DEV), dlf=torch.empty((meta.n_fg, C), device=DEV), dlsf=torch.empty((n_local, C), device=DEV),
+               dltf=torch.full((n_local, 16), 3.0, device=DEV), losses=torch.empty(8, device=DEV), labels=torch.empty(N, dtype=torch.int32, device=DEV),
+               te=torch.empty((meta.n_fg, 2), device=DEV), to=torch.empty((meta.n_fg, 3), device=DEV))
+    d = lib.HunterLoss()
+    d.n, d.stride, d.n_fg, d.n_local, d.n_inst, d.c = N, pts.shape[1], meta.n_fg, meta.n_local, meta.n_inst, C
+    d.batch, d.max_inst, d.num_sweeps = 2, gt.shape[1], 11
+    p = lambda t: t.data_ptr()
+    d.points, d.gt_boxes, d.instances_tf = p(ten['pts']), p(ten['gt']), p(ten['itf'])
+    d.fg_idx, d.fg_local, d.local_key, d.local_inst, d.inst_key = p(meta.fg_idx), p(meta.fg_local), p(meta.local_key), p(meta.local_inst), p(meta.inst_key)
+    d.head, d.ld_head, d.local_feat, d.ld_local_feat = p(ten['head']), 16, p(ten['lf']), C
+    d.locals_feat, d.ld_locals_feat, d.locals_tf, d.ld_locals_tf = p(ten['lsf']), C, p(ten['ltf']), 16
+    d.coef_fg, d.coef_locals, d.grad_scale = 1.0, 1.0, 1.0
+    d.dhead, d.ld_dhead, d.dlocal_feat_fg, d.dlocals_feat, d.dlocals_tf, d.ld_dlocals_tf = p(ten['dhead']), 16, p(ten['dlf']), p(ten['dlsf']), p(ten['dltf']), 16
+    d.losses, d.labels, d.tgt_embedding, d.tgt_offset = p(ten['losses']), p(ten['labels']), p(ten['te']), p(ten['to'])
+    tops.hunter_losses(d, torch.device(DEV))
+    got = ten['losses'].cpu().numpy()
+    names = ('l_points_cls', 'l_points_embed', 'l_fg_offset', 'l_locals_transl', 'l_locals_rot', 'l_recon', 'l_dtl_locals_feat')
+    for i, k in enumerate(names):
+        assert abs(got[i] - float(terms[k])) <= 1e-5 * abs(float(terms[k])), (k, got[i], float(terms[k]))
+    assert abs(got[7] - sum(float(terms[k]) for k in names)) <= 1e-5 * got[7]
+    assert np.array_equal(ten['labels'].cpu().numpy(), np.argmax(g['tgt/points_cls'], axis=1))
+    np.testing.assert_allclose(ten['te'].cpu().numpy(), g['tgt/fg_embedding'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ten['to'].cpu().numpy(), g['tgt/fg_offset'], rtol=0, atol=2e-6)
+    dh = ten['dhead'].cpu()
+    assert float(dh[:, 8:].abs().max()) == 0.0
+    _close(dh[:, 0:3], cls.grad, 2e-4, 'd cls logits')
+    _close(dh[:, 3:6], flow.grad, 1e-5, 'd flow')
+    _close(dh[:, 6:8], emb.grad, 1e-5, 'd embedding')
+    dl = ten['dltf'].cpu()
+    assert float(dl[:, 7:].abs().max()) == 0.0
+    _close(dl[:, :7], ltf.grad, 2e-5, 'd locals_tf')
+    _close(ten['dlf'].cpu(), lf.grad[mask_fg], 1e-5, 'd local_feat (foreground rows)')
+    _close(ten['dlsf'].cpu(), lsf.grad, 1e-5, 'd locals_feat')
+
+
+def test_bev_correction_backward_kernels():
+    """pcp_softmax_fuse2_backward, pcp_bev_scatter_mean_backward, pcp_bev_sample_bilinear_backward (incl. the position gradient) against
+    torch autograd of oracle/bev.py's bilinear / scatter-mean / blend on a small map"""
+    from oracle import bev as obev
+    from pcp_amd import ops
+    from pcp_amd import train_ops as tops
+    rng = np.random.RandomState(21)
+    B, H, W, C, N = 2, 12, 10, 32, 700
+    pc_min, pix = [-5.0, -6.0], [1.0, 1.0]
+    pts = np.zeros((N, 8), np.float32)
+    pts[:, 0] = rng.randint(0, B, N)
+    pts[:, 1] = rng.uniform(-5.5, 5.5, N)                       # some rows outside the map (dropped by the scatter, clamped by the sampler)
+    pts[:, 2] = rng.uniform(-6.5, 6.5, N)
+    bev = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).requires_grad_(True)
+    flow = torch.from_numpy((rng.randn(N, 2) * 0.3).astype(np.float32)).requires_grad_(True)
+    dyn = torch.from_numpy(rng.rand(N) < 0.4)
+    logits = torch.from_numpy(rng.randn(B, 2, H, W).astype(np.float32)).requires_grad_(True)
+    p0 = torch.from_numpy(pts)
+    coord0 = (p0[:, 1:3] - torch.tensor(pc_min)) / torch.tensor(pix)
+
+    def sample(coord):
+        feat = bev.new_zeros(N, C)
+        for b in range(B):
+            mb = p0[:, 0].long() == b
+            feat[mb] = obev._bilinear(bev[b].permute(1, 2, 0), coord[mb, 0], coord[mb, 1])
+        return feat
+    pf = sample(coord0)
+    moved = p0[:, 1:3] + flow * dyn[:, None].float()
+    coord1 = (moved - torch.tensor(pc_min)) / torch.tensor(pix)
+    cf = sample(coord1)
+    d = dyn.float()[:, None]
+    pf2 = pf * (1 - d) + cf * d
+    corrected = obev.bev_scatter_mean(coord1.detach(), p0[:, 0].long(), pf2, (H, W), batch_size=B)
+    wts = torch.softmax(logits, dim=1)
+    fused = bev * wts[:, [0]] + corrected * wts[:, [1]]
+    gout = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32))
+    (fused * gout).sum().backward()
+    # ---- device: forward pieces with the product kernels, then the three backward kernels
+    cat = torch.zeros((B, H, W, 2 * C), device=DEV)
+    cat[..., :C] = bev.detach().permute(0, 2, 3, 1).to(DEV)
+    pts_moved = p0.clone()
+    pts_moved[:, 1:3] = moved.detach()
+    pm = pts_moved.to(DEV).contiguous()
+    dyn_d = dyn.to(torch.uint8).to(DEV)
+    pf_d = ops.bev_sample_bilinear(cat, p0.to(DEV), pc_min, pix, channels=C)
+    pf2_d = pf_d.clone()
+    ops.bev_sample_bilinear(cat, pm, pc_min, pix, out=pf2_d, row_mask=dyn_d, channels=C)
+    ws = torch.empty(ops._lib.load().pcp_bev_scatter_mean_workspace_bytes(B, H, W, N), dtype=torch.uint8, device=DEV)
+    ops.bev_scatter_mean(pm, pf2_d, B, H, W, pc_min, pix, out=cat, out_ch_off=C, workspace=ws)
+    np.testing.assert_allclose(cat[..., C:].cpu().numpy(), corrected.detach().permute(0, 2, 3, 1).numpy(), rtol=0, atol=1e-5)
+    lg = logits.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dfused = gout.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dcat = torch.empty((B, H, W, 2 * C), device=DEV)
+    dlog = torch.empty((B, H, W, 16), device=DEV)
+    tops.softmax_fuse2_backward(dfused, cat, lg, C, dcat, dlog)
+    _close(dlog[..., :2].cpu(), logits.grad.permute(0, 2, 3, 1), 1e-5, 'd logits')
+    assert float(dlog[..., 2:].abs().max()) == 0.0
+    dpf = torch.zeros((N, C), device=DEV)
+    dcf = torch.zeros((N, C), device=DEV)
+    tops.bev_scatter_mean_backward(ws, B, H, W, N, dcat, C, C, dyn_d, dpf, dcf)
+    dxyz = torch.zeros((N, 16), device=DEV)
+    tops.bev_sample_bilinear_backward(dcf, pm, B, H, W, C, pc_min, pix, dcat, row_mask=dyn_d, bev=cat, dxyz=dxyz, dxyz_ch_off=3)
+    tops.bev_sample_bilinear_backward(dpf, p0.to(DEV), B, H, W, C, pc_min, pix, dcat)
+    _close(dxyz[:, 3:5].cpu(), flow.grad, 2e-5, 'd flow (position gradient of the re-sampling)')
+    assert float(dxyz[:, 5:].abs().max()) == 0.0 and float(dxyz[:, :3].abs().max()) == 0.0
+    _close(dcat[..., :C].cpu(), bev.grad.permute(0, 2, 3, 1), 2e-5, 'd bev')
+
+
+def test_filter_gt_boxes_keeps_in_range_rows_in_order():
+    from pcp_amd import train_ops as tops
+    g = _g12()
+    out = tops.filter_gt_boxes(torch.from_numpy(g['gt_boxes']).to(DEV), [-12.8, -12.8, -8.0, 12.8, 12.8, 0.0]).cpu().numpy()
+    ref = g['gt_boxes_after']
+    assert np.array_equal(out[:, :ref.shape[1]], ref) and not out[:, ref.shape[1]:].any()
