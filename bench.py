@@ -449,8 +449,8 @@ def main(argv=None):
     cfg = load_cfg(conf['yaml'])
     batch = args.batch or int(cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU)
     model, state, ds = build_model(cfg)
-    if args.train and args.config in ('car', 'lately6'):
-        raise SystemExit('--train: use --config ego | early | disco')
+    if args.train and args.config == 'lately6':
+        raise SystemExit('--train: use --config car | ego | early | disco')
     model = model.to(dev).eval()
     if not args.plugin_default:
         for m in model.modules():
@@ -505,6 +505,19 @@ def main(argv=None):
             gt[f, :n, 6] = synth.uniform(sd, 7, n, -3.14159, 3.14159)
             gt[f, :n, 7] = 1.0
         train_state = dict(opt=opt, sched=sched, gt=torch.from_numpy(gt).to(dev), it=0)
+        if args.config == 'car':
+            # configs 1 / 2 train HunterJr: foreground points with (sweep, instance) columns and the per-sweep motion of every instance
+            from pcdet.datasets import SyntheticV2XDataset
+            tf = np.zeros((batch, 40, 11, 3, 4), dtype=np.float32)
+            tf[..., :3, :3] = np.eye(3, dtype=np.float32)
+            extra = []
+            for f in range(batch):
+                fg, tf_f = SyntheticV2XDataset.synthetic_foreground(None, 1000 * rank + f, gt[f, :40 - 3 * f])
+                tf[f, :tf_f.shape[0]] = tf_f
+                extra.append(np.concatenate([np.full((fg.shape[0], 1), float(f), np.float32), fg], 1))
+            pristine = torch.cat([pristine, torch.from_numpy(np.concatenate(extra, 0)).to(dev)], 0).contiguous()
+            work = torch.empty_like(pristine)
+            train_state['instances_tf'] = torch.from_numpy(tf).to(dev)
 
     def train_step():
         ts = train_state
@@ -512,6 +525,9 @@ def main(argv=None):
         model.train()
         ts['opt'].zero_grad()
         bd = {'points': pristine, 'batch_size': batch, 'metadata': metas, 'gt_boxes': ts['gt']}
+        if 'instances_tf' in ts:
+            work.copy_(pristine)                    # HunterJr corrects xyz in place
+            bd.update(points=work, instances_tf=ts['instances_tf'])
         ret, tb, _ = model(bd)
         model.update_global_step()
         ret['loss'].backward()
@@ -616,8 +632,8 @@ def main(argv=None):
             'data': 'synthetic' + (' (ring distribution)' if args.dist == 'ring' else ''),
             'config': {'workload': conf['name'] if not args.train else ('v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)'
-                       if args.config == 'disco' else conf['name'] + ' -- TRAINING iteration (VFE/backbone/head forward+backward, CenterNet '
-                       'losses, clip, Adam one-cycle)'),
+                       if args.config == 'disco' else conf['name'] + ' -- TRAINING iteration (VFE/backbone/%shead forward+backward, CenterNet '
+                       'losses, clip, Adam one-cycle)' % ('HunterJr incl. object head and its seven loss terms/' if args.config == 'car' else '')),
                        'yaml': conf['yaml'], 'frames_per_gpu_per_step': batch, 'agents_per_frame': conf['agents_in_cloud'],
                        'points_per_frame': int(pts_np.shape[0] // batch), 'point_distribution': args.dist,
                        'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))

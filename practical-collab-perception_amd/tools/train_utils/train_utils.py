@@ -34,7 +34,7 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
         optimizer.clip_grad_norm(optim_cfg.GRAD_NORM_CLIP)
         optimizer.step()
         accumulated_iter += 1
-        disp = {'loss': tb_dict.get('loss_total', float('nan')), 'lr': cur_lr}
+        disp = {'loss': tb_dict.get('loss_total', tb_dict.get('loss_rpn', float('nan'))), 'lr': cur_lr}    # PointPillar reports loss_rpn only
         if tb_log is not None:
             tb_log.add_scalar('train/loss', disp['loss'], accumulated_iter)
             for key, val in tb_dict.items():
