@@ -66,6 +66,8 @@ def parse_args(argv=None):
                     'layer as the dense stride-2 conv (default in pipeline mode: from the pillar list when the cloud is sparse)')
     ap.add_argument('--plugin-default', action='store_true', help='measure the mode tools/test.py gets WITHOUT --fast: per-pillar API tensors '
                     'materialised (one host sync per VFE), dense canvas, no buffer reuse')
+    ap.add_argument('--no-overlap', action='store_true', help='run the BEV-maker passes of a DiscoNet forward one after the other on the '
+                                                                'main stream (the pipeline mode overlaps them on side streams)')
     ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
     ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'bf16x3', 'bf16'],
@@ -452,6 +454,10 @@ def main(argv=None):
     if args.train and args.config == 'lately6':
         raise SystemExit('--train: use --config car | ego | early | disco')
     model = model.to(dev).eval()
+    overlapped = False
+    if not args.plugin_default and not args.no_overlap and not args.train and not args.graph and hasattr(model, 'overlap_makers') \
+            and any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
+        overlapped = model.overlap_makers = True                 # frozen BEV-maker passes on their own HIP streams, joined in front of the fusion module
     if not args.plugin_default:
         for m in model.modules():
             if hasattr(m, 'materialize_pillars'):
@@ -592,6 +598,8 @@ def main(argv=None):
     timer = None
     if rank == 0:
         graphed = None                          # the instrumented pass runs eagerly (events around individual launches)
+        if getattr(model, 'overlap_makers', False):
+            model.overlap_makers = False        # ... and on ONE stream: an event pair must not time other streams' kernels
         timer = AbiTimer()
         timer.install()
     if rank == 0 or ((args.train or args.shard == 'agent') and world > 1):
@@ -644,7 +652,9 @@ def main(argv=None):
                                 'pipeline: no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
                                 ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
                                  'from the pillar list when points <= 0.35 x cells (no dense canvas), dense otherwise') +
-                                '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*)'),
+                                ('; the frozen BEV-maker passes run on their own HIP streams and join in front of the fusion module '
+                                 '(kernel_ms_per_step and roofline come from an extra single-stream pass)' if overlapped else '') +
+                                '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*, test_overlapped_makers_*)'),
                        'peak_device_memory_mb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': roof,

@@ -209,16 +209,17 @@ _W4_RETIRED = []
 
 
 def _w4_workspace(device, nbytes):
-    """one grow-only scratch buffer per device for the F(4x4,3x3) transforms (V and M, ~0.9 GB for 768 -> 768 at 4 frames); the three
-    launches of a call consume it in stream order, so consecutive calls on the same stream can share it (callers that run convolutions
-    on several streams at once must pass their own workspace through the C ABI).  A buffer that is outgrown stays referenced: a
-    captured hipGraph may have its address baked in."""
-    buf = _W4_WORKSPACE.get(device)
+    """one grow-only scratch buffer per (device, launch stream) for the F(4x4,3x3) transforms (V and M, ~0.9 GB for 768 -> 768 at 4
+    frames); the three launches of a call consume it in stream order, so consecutive calls on the same stream share it and concurrent
+    streams (CenterPoint.overlap_makers) each get their own.  A buffer that is outgrown stays referenced: a captured hipGraph may have
+    its address baked in."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)      # one buffer per launch stream: concurrent streams never share it
+    buf = _W4_WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
             _W4_RETIRED.append(buf)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _W4_WORKSPACE[device] = buf
+        _W4_WORKSPACE[key] = buf
     return buf
 
 

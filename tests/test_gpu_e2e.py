@@ -557,12 +557,13 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents, p
                                                                  tag + '_post_%d_near_score'])
 
 
-@pytest.mark.parametrize('pipeline', [False, True])
+@pytest.mark.parametrize('pipeline', [False, True, 'overlap'])
 def test_disco_full_size_against_reference_digests(pipeline):
     """Config 5 at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid, one frame) against digests of the REFERENCE's own
     DiscoNet forward (tests/golden/g2_disco_full.npz): per-agent BEV maps, fused map, head maps, detections -- every value to 1e-3 (the
     ego -> agent point transform is bit-equal to the reference's, so no pillar moves).  pipeline = True is the mode bench.py measures (stacked
-    agent pass, sparse first layer for the remote agents' 60 k-point clouds, F(4x4) wide layers)."""
+    agent pass, sparse first layer for the remote agents' 60 k-point clouds, F(4x4) wide layers); 'overlap' adds the BEV-maker passes on their
+    own HIP streams, exactly bench.py's default."""
     import hashlib
     import os
     from pcdet.config import EasyDict, cfg_from_yaml_file
@@ -583,6 +584,8 @@ def test_disco_full_size_against_reference_digests(pipeline):
         for m in model.modules():
             if hasattr(m, 'sparse_first_layer'):
                 m.materialize_pillars, m.reuse_buffers, m.sparse_first_layer = False, True, True
+    if pipeline == 'overlap':
+        model.overlap_makers = True
     agents = (0, 1, 2, 3, 4, 5)
     clouds = []
     for a in agents:
@@ -748,3 +751,36 @@ def test_lately_fusion_ego_stage_on_the_reference_rows():
         pred_dicts, _ = ego(batch)
     _check_common(g, batch, pred_dicts)
     _check_postprocessing_is_exact(ego, g, 'head_', 2, ['final_boxes_%d', 'final_scores_%d', 'post_%d_near_iou', 'post_%d_near_score'])
+
+
+@pytest.mark.gpu
+def test_overlapped_makers_give_the_bits_of_the_sequential_chain():
+    """CenterPoint.overlap_makers (the three frozen BEV-maker passes on their own HIP streams, joined in front of the fusion module) against
+    the sequential module chain on the DiscoNet mini fixture, ten alternating forwards with fresh clouds in between: every map, head
+    output and detection bit-identical (same kernels, same inputs -- a difference would be a cross-stream race)"""
+    g = load_golden('g1_disco.npz')
+    model = _build(g)
+    for m in model.modules():
+        if hasattr(m, 'sparse_first_layer'):
+            m.materialize_pillars, m.reuse_buffers, m.sparse_first_layer = False, True, True
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    base = torch.from_numpy(g['points']).cuda()
+
+    def run(points, overlap):
+        model.overlap_makers = overlap
+        batch = {'points': points.clone(), 'batch_size': 2, 'metadata': metadata}
+        with torch.no_grad():
+            pred, _ = model(batch)
+        torch.cuda.synchronize()
+        hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+        outs = [batch['bev_img'][0], batch['bev_img'][2], batch['bev_img_early'], batch['spatial_features_2d']] + [hd[k] for k in sorted(hd)]
+        outs += [p['pred_boxes'] for p in pred] + [p['pred_scores'] for p in pred]
+        return [o.clone() for o in outs]
+    for it in range(5):
+        pts = base.clone()
+        pts[:, 1:3] += 0.013 * it                                  # a different cloud every round
+        seq = run(pts, False)
+        ovl = run(pts, True)
+        assert len(seq) == len(ovl)
+        for a, b in zip(seq, ovl):
+            assert a.shape == b.shape and torch.equal(a, b), it
