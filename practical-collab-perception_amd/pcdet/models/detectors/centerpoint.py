@@ -39,12 +39,13 @@ class CenterPoint(Detector3DTemplate):
     # independent of each other and of the ego trunk until V2XMidFusionDisco reads their maps, so each runs on its own HIP stream and
     # the streams are joined in front of the fusion module.  Same kernels, same inputs, same launch order per stream: outputs are
     # bit-identical (tests/test_gpu_e2e.py::test_overlapped_makers_*); small launches of one pass fill the CUs another pass leaves idle.
+    # Works in train() mode too: the makers are frozen teachers evaluated under no_grad, the tape only holds the ego branch.
     overlap_makers = False
 
     def _run_modules(self, batch_dict):
         from ..bev_layers.bev_maker import BEVMaker
         makers = [m for m in self.module_list if isinstance(m, BEVMaker)]
-        if self.training or not self.overlap_makers or not makers or not batch_dict['points'].is_cuda:
+        if not self.overlap_makers or not makers or not batch_dict['points'].is_cuda:
             for cur_module in self.module_list:
                 batch_dict = cur_module(batch_dict)
             return batch_dict
