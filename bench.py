@@ -513,12 +513,11 @@ def main(argv=None):
         train_state = dict(opt=opt, sched=sched, gt=torch.from_numpy(gt).to(dev), it=0)
         if args.config == 'car':
             # configs 1 / 2 train HunterJr: foreground points with (sweep, instance) columns and the per-sweep motion of every instance
-            from pcdet.datasets import SyntheticV2XDataset
             tf = np.zeros((batch, 40, 11, 3, 4), dtype=np.float32)
             tf[..., :3, :3] = np.eye(3, dtype=np.float32)
             extra = []
             for f in range(batch):
-                fg, tf_f = SyntheticV2XDataset.synthetic_foreground(None, 1000 * rank + f, gt[f, :40 - 3 * f])
+                fg, tf_f = synth.instance_foreground(1000 * rank + f, gt[f, :40 - 3 * f])
                 tf[f, :tf_f.shape[0]] = tf_f
                 extra.append(np.concatenate([np.full((fg.shape[0], 1), float(f), np.float32), fg], 1))
             pristine = torch.cat([pristine, torch.from_numpy(np.concatenate(extra, 0)).to(dev)], 0).contiguous()

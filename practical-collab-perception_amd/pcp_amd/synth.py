@@ -186,3 +186,30 @@ def _is_last_hm_conv(name, names):
                 idxs.append(int(tok))
     tok = name[len(prefix):].split('.')[0]
     return tok.isdigit() and int(tok) == max(idxs)
+
+
+def instance_foreground(index, gt, n_sweeps=11, per_local=12, max_instances=12):
+    """Foreground points for HunterJr training: points inside the first `max_instances` boxes of gt (n, 8) at three sweeps, rows
+    [x, y, z, intensity, time, sweep, instance], and instances_tf (n, n_sweeps, 3, 4): odd instances drive along their heading (the rigid
+    motion takes a sweep-s point to the newest sweep), even instances stand still."""
+    n = gt.shape[0]
+    tf = np.zeros((n, n_sweeps, 3, 4), dtype=np.float32)
+    tf[..., :3, :3] = np.eye(3, dtype=np.float32)
+    rows = []
+    s = SEED_BASE + 6000 + index
+    for i in range(min(n, max_instances)):
+        c, dims, yaw = gt[i, 0:3].astype(np.float64), gt[i, 3:6].astype(np.float64), float(gt[i, 6])
+        moving = i % 2 == 1
+        speed = 3.0 + 0.5 * i
+        R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+        for sw in range(n_sweeps):
+            if moving:
+                tf[i, sw, :3, 3] = speed * (10 - sw) * 0.1 * np.array([np.cos(yaw), np.sin(yaw), 0.0])
+        for k, sw in enumerate((10, 7, 3)):
+            dt = (10 - sw) * 0.1
+            u = uniform(s, 20 * i + k, per_local * 3, -0.5, 0.5).reshape(per_local, 3).astype(np.float64)
+            p = (u * dims) @ R.T + c - (tf[i, sw, :3, 3].astype(np.float64) if moving else 0.0)
+            r = np.zeros((per_local, 7), dtype=np.float32)
+            r[:, 0:3], r[:, 3], r[:, 4], r[:, 5], r[:, 6] = p, 0.5, dt, sw, i
+            rows.append(r)
+    return np.concatenate(rows, 0), tf

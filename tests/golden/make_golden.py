@@ -881,6 +881,65 @@ def g11_anchor_train():
     print('g11 saved', os.path.getsize(path) // 1024, 'KiB')
 
 
+def anchor_full_gt():
+    s0 = synth.SEED_BASE + 970
+    n = 24
+    gt = np.zeros((1, n, 8), dtype=np.float32)
+    gt[0, :, 0] = synth.uniform(s0, 1, n, -48.0, 48.0)
+    gt[0, :, 1] = synth.uniform(s0, 2, n, -48.0, 48.0)
+    gt[0, :, 2] = synth.uniform(s0, 3, n, -2.0, -0.5)
+    cls = 1 + (np.arange(n) % 3)
+    base = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], dtype=np.float32)
+    gt[0, :, 3:6] = base[cls - 1] * synth.uniform(s0, 4, n * 3, 0.85, 1.2).reshape(n, 3)
+    gt[0, :, 6] = synth.uniform(s0, 7, n, -3.14159, 3.14159)
+    gt[0, :, 7] = cls
+    return gt
+
+
+def g11f_anchor_train_full():
+    """PointPillar + AnchorHeadSingle training at full geometry (60 000 points of 13-column rows, 512 x 512 grid, 128 x 128 x 6 anchors, 24
+    boxes of three classes): ONE iteration of the reference's own train step; labels digest, loss terms, gradient norm, per-tensor digests."""
+    post = {'RECALL_THRESH_LIST': [0.3, 0.5, 0.7], 'SCORE_THRESH': 0.5, 'OUTPUT_RAW_SCORE': False, 'EVAL_METRIC': 'kitti',
+            'NMS_CONFIG': {'MULTI_CLASSES_NMS': False, 'NMS_TYPE': 'nms_gpu', 'NMS_THRESH': 0.1, 'NMS_PRE_MAXSIZE': 1024,
+                           'NMS_POST_MAXSIZE': 100}}
+    ov = {'CLASS_NAMES': ['car', 'pedestrian', 'cyclist'], 'MODEL.NAME': 'PointPillar', 'MODEL.DENSE_HEAD': rh.AttrDict(ANCHOR_HEAD),
+          'MODEL.POST_PROCESSING': rh.AttrDict(post)}
+    cfg = rh.load_cfg('v2x_pointpillar_basic_ego.yaml', ov)
+    model, ds = rh.build_model(cfg)
+    shapes = fill_weights(model)
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    pts = synth.collate([synth.agent_cloud(agent=1, n_points=60000, layout='lately')])
+    gt = anchor_full_gt()
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=5, total_epochs=cfg.OPTIMIZATION.NUM_EPOCHS, last_epoch=-1,
+                                      optim_cfg=cfg.OPTIMIZATION)
+    names = [n_ for n_, p_ in model.named_parameters() if p_.requires_grad]
+    lr_scheduler.step(0)
+    model.train()
+    optimizer.zero_grad()
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{}], 'gt_boxes': torch.from_numpy(gt.copy())}
+    ret, tb, _disp = model(bd)
+    loss = ret['loss']
+    loss.backward()
+    params = dict(model.named_parameters())
+    fr = model.dense_head.forward_ret_dict
+    lab = fr['box_cls_labels'].numpy()
+    out = {'N': np.array(pts.shape[0]), 'gt_boxes': gt, 'trainable': np.array(names), 'loss': np.array(float(loss)),
+           'tb_json': np.array(json.dumps({k: float(v) for k, v in tb.items()})),
+           'grad_digest': np.stack([_digest(params[n_].grad) for n_ in names]),
+           'labels_sha': np.array(sha(lab.astype(np.int32))), 'label_hist': np.bincount(lab.reshape(-1) + 1, minlength=5),
+           'reg_targets_digest': _digest(fr['box_reg_targets'])}
+    norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+    out['grad_norm'] = np.array(float(norm))
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), optimization=rh.to_plain(cfg.OPTIMIZATION),
+                                                 pc_range=[float(v) for v in cfg.DATA_CONFIG.POINT_CLOUD_RANGE], voxel_size=[0.2, 0.2, 8.0],
+                                                 class_names=list(cfg.CLASS_NAMES), layout='lately', state_shapes=shapes)))
+    print('g11 full: loss', float(loss), 'norm', float(norm), 'labels', out['label_hist'], tb)
+    np.savez_compressed(os.path.join(HERE, 'g11_anchor_train_full.npz'), **out)
+
+
 G12_SEG_BIAS_SHIFT = 0.0
 
 
@@ -1025,6 +1084,61 @@ def g12_hunter_train():
     print('g12 saved', os.path.getsize(path) // 1024, 'KiB')
 
 
+def hunter_full_inputs():
+    """one full-size basic_car training frame: 60 000 background points (BASELINE's cloud) + the foreground of 12 instances"""
+    s0 = synth.SEED_BASE + 960
+    n = 12
+    gt = np.zeros((1, n, 8), dtype=np.float32)
+    gt[0, :, 0] = synth.uniform(s0, 1, n, -48.0, 48.0)
+    gt[0, :, 1] = synth.uniform(s0, 2, n, -48.0, 48.0)
+    gt[0, :, 2] = synth.uniform(s0, 3, n, -3.0, -1.0)
+    gt[0, :, 3] = synth.uniform(s0, 4, n, 3.0, 5.5)
+    gt[0, :, 4] = synth.uniform(s0, 5, n, 1.5, 2.5)
+    gt[0, :, 5] = synth.uniform(s0, 6, n, 1.4, 2.0)
+    gt[0, :, 6] = synth.uniform(s0, 7, n, -3.14159, 3.14159)
+    gt[0, :, 7] = 1.0
+    fg, tf = synth.instance_foreground(77, gt[0], per_local=40)
+    cloud = np.concatenate([synth.agent_cloud(agent=0, n_points=60000, layout='car'), fg], axis=0)
+    return synth.collate([cloud]), gt, tf[None]
+
+
+def g12f_hunter_train_full():
+    """Configs 1 / 2 training at BASELINE's full size (60 000 points, 512 x 512 grid, 128 x 128 BEV map, one frame): ONE iteration of the
+    reference's own train step; all loss terms, gradient norm, per-tensor gradient digests."""
+    cfg = rh.load_cfg('v2x_pointpillar_basic_car.yaml', {})
+    model, ds = rh.build_model(cfg)
+    fill_weights(model)
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from torch.nn.utils import clip_grad_norm_
+    pts, gt, tf = hunter_full_inputs()
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    lr_scheduler, _ = build_scheduler(optimizer, total_iters_each_epoch=5, total_epochs=cfg.OPTIMIZATION.NUM_EPOCHS, last_epoch=-1,
+                                      optim_cfg=cfg.OPTIMIZATION)
+    names = [n_ for n_, p_ in model.named_parameters() if p_.requires_grad]
+    lr_scheduler.step(0)
+    model.train()
+    optimizer.zero_grad()
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{}], 'gt_boxes': torch.from_numpy(gt.copy()),
+          'instances_tf': torch.from_numpy(tf.copy())}
+    ret, tb, _disp = model(bd)
+    loss = ret['loss']
+    loss.backward()
+    params = dict(model.named_parameters())
+    meta = model.corrector.forward_return_dict['meta']
+    out = {'N': np.array(pts.shape[0]), 'trainable': np.array(names), 'loss': np.array(float(loss)),
+           'tb_json': np.array(json.dumps({k: float(v) for k, v in tb.items()})),
+           'grad_digest': np.stack([_digest(params[n_].grad) for n_ in names]),
+           'counts': np.array([int(meta['mask_fg'].sum()), meta['locals_bis'].shape[0], meta['instance_bi'].shape[0]]),
+           'moved_rows': np.array(int((np.abs(bd['points'].detach().numpy() - pts).max(1) > 0).sum())),
+           'map_probe': bd['spatial_features_2d'].detach().numpy()[0, ::8, ::16, ::16].copy()}
+    norm = clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+    out['grad_norm'] = np.array(float(norm))
+    out['optimization_json'] = np.array(json.dumps(rh.to_plain(cfg.OPTIMIZATION)))
+    print('g12 full: loss', float(loss), 'norm', float(norm), 'counts', out['counts'], 'moved', int(out['moved_rows']), tb)
+    np.savez_compressed(os.path.join(HERE, 'g12_hunter_train_full.npz'), **out)
+
+
 G10_SEG_BIAS_SHIFT = 1.0
 
 
@@ -1149,8 +1263,12 @@ if __name__ == '__main__':
         g10_lately_chain()
     if 'g11' in todo:
         g11_anchor_train()
+    if 'g11f' in todo:
+        g11f_anchor_train_full()
     if 'g12' in todo:
         g12_hunter_train()
+    if 'g12f' in todo:
+        g12f_hunter_train_full()
     if 'g9' in todo:
         g9_anchor('agnostic', False)     # MULTI_CLASSES_NMS with a single (non multi-head) AnchorHeadSingle trips the reference's own
                                          # assertion (detector3d_template.py:283,295: arange(1, num_class) has num_class - 1 entries)

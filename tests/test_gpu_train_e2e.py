@@ -480,3 +480,110 @@ def test_hunter_jr_train_step_matches_reference():
                 a = sd[k].double()
                 d = np.array([float(a.norm()), float(a.sum()), float(a.abs().max())])
                 np.testing.assert_allclose(d, g['it0_bn_digest'][i], rtol=5e-4, atol=1e-6, err_msg=k)
+
+
+def _hunter_full_inputs():
+    """the inputs of tests/golden/make_golden.py::hunter_full_inputs, regenerated (closed-form streams: nothing large is committed)"""
+    s0 = synth.SEED_BASE + 960
+    n = 12
+    gt = np.zeros((1, n, 8), dtype=np.float32)
+    for col, (lo, hi) in enumerate([(-48.0, 48.0), (-48.0, 48.0), (-3.0, -1.0), (3.0, 5.5), (1.5, 2.5), (1.4, 2.0), (-3.14159, 3.14159)]):
+        gt[0, :, col] = synth.uniform(s0, col + 1, n, lo, hi)
+    gt[0, :, 7] = 1.0
+    fg, tf = synth.instance_foreground(77, gt[0], per_local=40)
+    cloud = np.concatenate([synth.agent_cloud(agent=0, n_points=60000, layout='car'), fg], axis=0)
+    return synth.collate([cloud]), gt, tf[None]
+
+
+def test_hunter_jr_full_size_training_iteration_matches_the_reference():
+    """Configs 1 / 2 at BASELINE's full size (60 000 points + 1 440 foreground rows, 512 x 512 grid, 128 x 128 x 384 BEV map): one iteration of
+    the reference's own train step (tests/golden/g12_hunter_train_full.npz) -- locals / instances counts and the number of rows the flow
+    head moved exact, all thirteen loss entries to 1e-3, clipped-gradient norm to 5e-3, per-tensor gradient norms to 3e-2 of the largest."""
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import DatasetInfo, build_network
+    g = load_golden('g12_hunter_train_full.npz')
+    cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_basic_car.yaml'),
+                             EasyDict())
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(cfg.DATA_CONFIG.POINT_FEATURE_ENCODING.used_feature_list))
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.to(DEV)
+    ocfg = EasyDict(json.loads(str(g['optimization_json'])))
+    opt = build_optimizer(model, ocfg)
+    sched, _ = build_scheduler(opt, 5, ocfg.NUM_EPOCHS, -1, ocfg)
+    pts, gt, tf = _hunter_full_inputs()
+    assert pts.shape[0] == int(g['N'])
+    sched.step(0)
+    model.train()
+    opt.zero_grad()
+    batch = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 1, 'metadata': [{}], 'gt_boxes': torch.from_numpy(gt).to(DEV),
+             'instances_tf': torch.from_numpy(tf).to(DEV)}
+    ret, tb, _disp = model(batch)
+    ret['loss'].backward()
+    m = model.corrector.forward_return_dict['meta']
+    assert [m.n_fg, m.n_local, m.n_inst] == [int(v) for v in g['counts']]
+    moved = int((np.abs(batch['points'].cpu().numpy() - pts).max(1) > 0).sum())
+    assert abs(moved - int(g['moved_rows'])) <= 3, (moved, int(g['moved_rows']))          # rows within 1e-6 of the 0.3 probability threshold
+    np.testing.assert_allclose(batch['spatial_features_2d'].detach().cpu().numpy()[0, ::8, ::16, ::16], g['map_probe'], rtol=0, atol=1e-3)
+    lv = float(ret['loss'].detach())
+    assert abs(lv - float(g['loss'])) <= 1e-3 * abs(float(g['loss'])), (lv, float(g['loss']))
+    for k, v in json.loads(str(g['tb_json'])).items():
+        assert abs(tb[k] - v) <= 1e-3 * abs(v) + 2e-6, (k, tb[k], v)
+    names = [str(n) for n in g['trainable']]
+    params = dict(model.named_parameters())
+    ref = g['grad_digest']
+    biggest = float(ref[:, 0].max())
+    for i, n in enumerate(names):
+        mine = float(params[n].grad.detach().double().norm())
+        assert abs(mine - ref[i, 0]) <= 3e-2 * max(ref[i, 0], 1e-3 * biggest), (n, mine, ref[i, 0])
+    opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+    opt.step()
+    assert abs(opt.grad_norm() - float(g['grad_norm'])) <= 5e-3 * float(g['grad_norm']), (opt.grad_norm(), float(g['grad_norm']))
+
+
+def test_pointpillar_anchor_full_size_training_iteration_matches_the_reference():
+    """PointPillar + AnchorHeadSingle at full geometry (60 000 points, 128 x 128 x 6 = 98 304 anchors, 24 boxes of three classes): one
+    iteration of the reference's own train step (tests/golden/g11_anchor_train_full.npz) -- the 98 304 labels bit exact (SHA-256), the
+    loss terms to 1e-3, clipped-gradient norm to 5e-3, per-tensor gradient norms to 3e-2 of the largest."""
+    import hashlib
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from pcdet.config import EasyDict
+    g = load_golden('g11_anchor_train_full.npz')
+    meta = g['meta']
+    model = _build(g)
+    ocfg = EasyDict(meta['optimization'])
+    opt = build_optimizer(model, ocfg)
+    sched, _ = build_scheduler(opt, 5, ocfg.NUM_EPOCHS, -1, ocfg)
+    pts = synth.collate([synth.agent_cloud(agent=1, n_points=60000, layout='lately')])
+    assert pts.shape[0] == int(g['N'])
+    sched.step(0)
+    model.train()
+    opt.zero_grad()
+    batch = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 1, 'metadata': [{}], 'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}
+    ret, tb, _disp = model(batch)
+    ret['loss'].backward()
+    fr = model.dense_head.forward_ret_dict
+    lab = fr['box_cls_labels'].cpu().numpy().astype(np.int32)
+    assert np.array_equal(np.bincount(lab.reshape(-1) + 1, minlength=5), g['label_hist'])
+    assert hashlib.sha256(np.ascontiguousarray(lab).tobytes()).hexdigest() == str(g['labels_sha'])
+    a = fr['box_reg_targets'].double()
+    np.testing.assert_allclose([float(a.norm()), float(a.sum()), float(a.abs().max())], g['reg_targets_digest'], rtol=1e-5, atol=1e-5)
+    lv = float(ret['loss'].detach())
+    assert abs(lv - float(g['loss'])) <= 1e-3 * abs(float(g['loss'])), (lv, float(g['loss']))
+    for k, v in json.loads(str(g['tb_json'])).items():
+        assert abs(tb[k] - v) <= 1e-3 * abs(v) + 2e-6, (k, tb[k], v)
+    names = [str(n) for n in g['trainable']]
+    params = dict(model.named_parameters())
+    ref = g['grad_digest']
+    biggest = float(ref[:, 0].max())
+    for i, n in enumerate(names):
+        mine = float(params[n].grad.detach().double().norm())
+        assert abs(mine - ref[i, 0]) <= 3e-2 * max(ref[i, 0], 1e-3 * biggest), (n, mine, ref[i, 0])
+    opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+    opt.step()
+    assert abs(opt.grad_norm() - float(g['grad_norm'])) <= 5e-3 * float(g['grad_norm']), (opt.grad_norm(), float(g['grad_norm']))
