@@ -55,6 +55,8 @@ class PackedConv:
         wgs = B * ((H + 15) // 16) * ((W + 31) // 32) * (self.w4f[2] // 64)
         if self.cin > WINOGRAD4F_MAX_CIN and getattr(self, 'w4', None) is not None:
             return False
+        if H * W <= 64 * 64 and self.cin <= 128:
+            return False                                   # 8 spatial tiles per frame, 16 K slices: F(2x2) wins (profiles/r02_bench_conv_b*.txt)
         return wgs >= WINOGRAD4F_MIN_WORKGROUPS and (wgs % 256 == 0 or wgs >= 512)
 
     def _use_winograd4(self, x):
@@ -65,6 +67,10 @@ class PackedConv:
             return True
         B, H, W, _ = x.shape
         tiles = B * ((H + 3) // 4) * ((W + 3) // 4)
+        # the through-memory GEMM pays two extra passes over V and M: measured a win only from 256 input channels and a full 128-wide N tile
+        # (128 -> 128 @64^2 B = 4: 46 vs 32 us fused F(2x2); 384 -> 64 @128^2: 225 vs 145 us; profiles/r02_bench_conv_b*.txt)
+        if self.cin < 256 or self.cout < 128:
+            return False
         return 36 * ((tiles + 127) // 128) * (self.w4[2] // 128) >= WINOGRAD4_MIN_WORKGROUPS
 
     def _use_winograd(self, x):
