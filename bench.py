@@ -282,6 +282,19 @@ class AbiTimer:
                 real.pcp_conv3x3_winograd4f_plan(ctypes.byref(d), ctypes.byref(fl))
                 return ('k_wino4f (3x3 s1 fused Winograd F(4x4,3x3), one 8-wave workgroup per CU, v_mfma_f32_32x32x2_f32)', fl.value,
                         2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
+            if name == 'pcp_conv3x3_wgrad':
+                # pixel-contraction GEMM of the weight gradient: 64(co) x 64(ci) x 9-tap tiles, padding channels included in `executed`
+                d = a[0]._obj
+                s = d.stride
+                ho, wo = d.in_h // s, d.in_w // s
+                r64 = lambda v: (v + 63) // 64 * 64
+                return ('pcp_conv3x3_wgrad (3x3 weight gradient, pixel-contraction GEMM, split-K, v_mfma_f32_32x32x2_f32)',
+                        2.0 * d.batch * ho * wo * r64(d.cout) * 9 * r64(d.cin), 2.0 * d.batch * ho * wo * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
+            if name == 'pcp_pointwise_wgrad':
+                ra, rb, rows = a[0]._obj, a[1]._obj, int(a[2])
+                r64 = lambda v: (v + 63) // 64 * 64
+                return ('pcp_pointwise_wgrad (1x1 / k2s2 weight gradient, pixel-contraction GEMM, fp32 MFMA)',
+                        2.0 * rows * r64(ra.channels) * r64(rb.channels), 2.0 * rows * ra.channels * rb.channels, 'mfma', MFMA_F32_PEAK_TFLOPS)
             if name == 'pcp_pointwise':
                 d = a[0]._obj
                 if d.mode == 0:
