@@ -7,7 +7,13 @@ class PackedModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._pcp_cache = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._weights_replaced())
+
+    def _weights_replaced(self):
+        """load_state_dict: the folded inference weights AND the per-step packed forms of the train-mode layers are stale"""
+        self.invalidate_packed()
+        from pcp_amd.train_layers import StepClock
+        StepClock.tick()
 
     def invalidate_packed(self):
         self._pcp_cache = None

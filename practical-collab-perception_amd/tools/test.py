@@ -36,7 +36,8 @@ def parse_config():
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
     p.add_argument('--infer_time', action='store_true', default=False)
-    p.add_argument('--fast', action='store_true', help='MI355X pipeline mode: no per-pillar API tensors, persistent buffers, first backbone layer from the pillar list')
+    p.add_argument('--fast', action='store_true', help='MI355X pipeline mode: no per-pillar API tensors, persistent buffers, first backbone layer from the pillar list, '
+                                                     'BEV-maker passes of a DiscoNet forward on their own HIP streams')
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem
@@ -74,6 +75,8 @@ def main():
             if hasattr(m, 'materialize_pillars'):
                 m.materialize_pillars, m.reuse_buffers = False, True
                 m.sparse_first_layer = True          # sparse clouds: no dense canvas, first backbone layer from the pillar list
+        if hasattr(model, 'overlap_makers'):
+            model.overlap_makers = True              # DiscoNet: frozen BEV-maker passes on their own HIP streams (bit-identical outputs)
     eval_utils.eval_one_epoch(cfg, args, model, test_loader, 'synthetic' if args.ckpt is None else Path(args.ckpt).stem, logger,
                               dist_test=dist_test)
 
