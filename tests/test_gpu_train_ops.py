@@ -911,3 +911,60 @@ def test_filter_gt_boxes_keeps_in_range_rows_in_order():
     out = tops.filter_gt_boxes(torch.from_numpy(g['gt_boxes']).to(DEV), [-12.8, -12.8, -8.0, 12.8, 12.8, 0.0]).cpu().numpy()
     ref = g['gt_boxes_after']
     assert np.array_equal(out[:, :ref.shape[1]], ref) and not out[:, ref.shape[1]:].any()
+
+
+@pytest.mark.parametrize('seed,B,M,S,n,frac', [(1, 1, 3, 11, 700, 0.3), (2, 4, 40, 11, 50000, 0.05), (3, 3, 7, 5, 9000, 0.9), (4, 2, 1, 1, 300, 0.5),
+                                               (5, 6, 25, 11, 260000, 0.02)])
+def test_hunter_meta_random_clouds_against_the_unique_chain(seed, B, M, S, n, frac):
+    """pcp_hunter_meta against oracle/hunter_train.py::build_meta (torch.unique(sorted, return_inverse) twice + arg-max / arg-min sweeps) on
+    random (frame, instance, sweep) columns: sparse and crowded key tables, a single-key table, 260 k rows (more than 1 024 scan blocks)"""
+    from oracle import hunter_train as oht
+    from pcp_amd import train_ops as tops
+    rng = np.random.RandomState(seed)
+    pts = np.zeros((n, 8), np.float32)
+    pts[:, 0] = rng.randint(0, B, n)
+    pts[:, 1:4] = rng.randn(n, 3)
+    pts[:, 6] = rng.randint(0, S, n)
+    inst = rng.randint(0, M, n).astype(np.float32)
+    inst[rng.rand(n) > frac] = -1.0
+    pts[:, 7] = inst
+    p = torch.from_numpy(pts)
+    m = tops.hunter_meta(p.to(DEV), B, M, S, -2, -1)
+    mask = p[:, -1] > -1
+    assert m.n_fg == int(mask.sum()) and m.bad_rows == 0
+    if m.n_fg == 0:
+        return
+    ref = oht.build_meta(p[mask], M, S)
+    assert m.n_local == ref['locals_bis'].shape[0] and m.n_inst == ref['instance_bi'].shape[0]
+    assert torch.equal(m.fg_idx[:m.n_fg].cpu().long(), torch.nonzero(mask)[:, 0])
+    assert torch.equal(m.fg_local[:m.n_fg].cpu().long(), ref['locals2fg'])
+    assert torch.equal(m.local_key[:m.n_local].cpu().long(), ref['locals_bis'])
+    assert torch.equal(m.local_inst[:m.n_local].cpu().long(), ref['inst2locals'])
+    assert torch.equal(m.inst_key[:m.n_inst].cpu().long(), ref['instance_bi'])
+    assert torch.equal(m.inst_last[:m.n_inst].cpu().long(), ref['indices_locals_max_sweep'])
+    assert torch.equal(m.inst_first[:m.n_inst].cpu().long(), ref['indices_locals_min_sweep'])
+
+
+def test_hunter_meta_reports_rows_outside_the_key_table():
+    from pcp_amd import train_ops as tops
+    pts = torch.zeros((10, 8))
+    pts[:, 7] = torch.tensor([0, 1, 2, 3, -1, 0, 1, 9, 0, 1.0])         # instance 9 >= max_inst 4
+    pts[:, 6] = torch.tensor([0, 1, 2, 3, 0, 11, 1, 1, 0, 1.0])         # sweep 11 >= NUM_SWEEPS 11
+    m = tops.hunter_meta(pts.to(DEV), 1, 4, 11, -2, -1)
+    assert m.bad_rows == 2 and m.n_fg == 7
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_filter_gt_boxes_random(seed):
+    from oracle import hunter_train as oht
+    from pcp_amd import train_ops as tops
+    rng = np.random.RandomState(seed)
+    B, M = 3, 300 if seed == 2 else 17
+    gt = (rng.rand(B, M, 8).astype(np.float32) - 0.5) * np.array([130, 130, 12, 5, 3, 2, 6, 0], np.float32)
+    gt[..., 2] -= 4.0
+    gt[..., 7] = 1.0
+    gt[1, M // 2:] = 0.0
+    rngp = [-51.2, -51.2, -8.0, 51.2, 51.2, 0.0]
+    ref = oht.filter_gt_boxes(torch.from_numpy(gt), rngp).numpy()
+    out = tops.filter_gt_boxes(torch.from_numpy(gt).to(DEV), rngp).cpu().numpy()
+    assert np.array_equal(out[:, :ref.shape[1]], ref) and not out[:, ref.shape[1]:].any()
