@@ -405,7 +405,16 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
 #ifdef F4_DIAG_NO_STORE
               if (v.x == 1.2345e30f)                  // timing-only build: never true, keeps the values alive
 #endif
+#ifdef F4_DIAG_CONTIG_STORE
+              // timing-only build: the same bytes to a permuted, fully contiguous place (1 KiB per store instruction, 64 KiB per half)
+              *reinterpret_cast<f32x4 *>(p.out + ((((long long)lid * 2 + half) * 16 + a * 4 + c2) * 4 + (wave & 3)) * 256 + lane * 4) = v;
+#elif defined(F4_DIAG_PLAIN_STORE)
               *reinterpret_cast<f32x4 *>(o + (long long)c2 * p.ld_out) = v;
+#else
+              // streaming (non-temporal) stores: the 131 KB a workgroup writes do not displace the weights / halo rows the running
+              // workgroups keep hitting in L2 (interleaved A/B on MI355X, 20 frames: 128->128 @128^2 315 -> 298 us, 64->64 @256^2 391 -> 376)
+              __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(o + (long long)c2 * p.ld_out));
+#endif
             }
         }
       }
