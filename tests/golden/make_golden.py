@@ -1244,9 +1244,12 @@ if __name__ == '__main__':
         g4_warp()
     if 'g1' in todo:
         g1_single('car', 'v2x_pointpillar_basic_car.yaml', 'car', extra_points=hunter_edge_points)
+        g1_single('rsu', 'v2x_pointpillar_basic_rsu.yaml', 'car', extra_points=hunter_edge_points)
         g1_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately', score_thresh=0.02)
         g1_single('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early', score_thresh=0.02)
         g1_disco()
+    if 'g1rsu' in todo:
+        g1_single('rsu', 'v2x_pointpillar_basic_rsu.yaml', 'car', extra_points=hunter_edge_points)
     if 'g2' in todo:
         g2_full()
     if 'g2d' in todo:

@@ -66,7 +66,7 @@ def _check_postprocessing_is_exact(model, g, head_key, frames, keys):
         assert g[_k(keys[0], b)].shape[0] > 0
 
 
-@pytest.mark.parametrize('tag', ['ego', 'early', 'car'])
+@pytest.mark.parametrize('tag', ['ego', 'early', 'car', 'rsu'])
 def test_single_agent_configs_match_reference_outputs(tag):
     g = load_golden('g1_%s.npz' % tag)
     model = _build(g)

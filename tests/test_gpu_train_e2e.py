@@ -233,7 +233,7 @@ def test_single_model_train_step_matches_reference():
 
 
 @pytest.mark.parametrize('yaml_name', ['v2x_pointpillar_disco.yaml', 'v2x_pointpillar_basic_ego_early.yaml', 'v2x_pointpillar_basic_ego.yaml',
-                                       'v2x_pointpillar_anchor.yaml', 'v2x_pointpillar_basic_car.yaml'])
+                                       'v2x_pointpillar_anchor.yaml', 'v2x_pointpillar_basic_car.yaml', 'v2x_pointpillar_basic_rsu.yaml'])
 def test_train_py_runs_and_loss_decreases(tmp_path, yaml_name):
     """tools/train.py (reference command line) on a small synthetic set: 2 epochs x 4 iterations, checkpoint written and loadable,
     loss of the last iteration below the first (same frames every epoch).  DiscoNet (config 5), the two fusion-free configs, the

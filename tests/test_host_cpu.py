@@ -189,6 +189,29 @@ def test_shipped_yaml_configs_build_all_five_models():
                 'dense_head.conv_dir_cls.bias', 'dense_head.conv_dir_cls.weight']
 
 
+@pytest.mark.parametrize('yaml_name,golden', [('v2x_pointpillar_basic_car.yaml', 'g1_car.npz'), ('v2x_pointpillar_basic_rsu.yaml', 'g1_rsu.npz'),
+                                              ('v2x_pointpillar_basic_ego.yaml', 'g1_ego.npz'), ('v2x_pointpillar_basic_ego_early.yaml', 'g1_early.npz'),
+                                              ('v2x_pointpillar_disco.yaml', 'g1_disco.npz')])
+def test_shipped_yaml_state_dicts_equal_the_references(yaml_name, golden):
+    """every shipped YAML builds a model whose state-dict keys and shapes are EXACTLY those of the reference model built from the
+    reference's YAML of the same name (recorded as data in the golden fixtures): reference checkpoints load with strict=True"""
+    from helpers import load_golden
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import DatasetInfo, build_network
+    cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', yaml_name), EasyDict())
+    for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
+        if cfg.MODEL.get(key, None) is not None:
+            cfg.MODEL[key].CKPT = None
+    enc = cfg.DATA_CONFIG.POINT_FEATURE_ENCODING
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(enc.used_feature_list))
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {k: tuple(v) for k, v in load_golden(golden)['meta']['state_shapes'].items()}
+    assert sorted(mine) == sorted(ref), sorted(set(mine) ^ set(ref))[:10]
+    assert all(mine[k] == ref[k] for k in ref), [k for k in ref if mine[k] != ref[k]][:10]
+
+
 def test_training_dataset_and_onecycle_schedule():
     """synthetic training items carry zero-padded gt_boxes (collate_batch contract, dataset.py:260-266); the one-cycle schedule
     reproduces the lr / beta1 values the reference's scheduler produced for the golden run"""

@@ -23,7 +23,7 @@ def _shapes(arch, meta):
     return meta['state_shapes']
 
 
-@pytest.mark.parametrize('tag', ['car', 'ego', 'early'])
+@pytest.mark.parametrize('tag', ['car', 'rsu', 'ego', 'early'])
 def test_g1_single_agent(tag):
     g = load_golden('g1_%s.npz' % tag)
     arch = arch_of(g['meta'])
