@@ -212,6 +212,43 @@ def test_shipped_yaml_state_dicts_equal_the_references(yaml_name, golden):
     assert all(mine[k] == ref[k] for k in ref), [k for k in ref if mine[k] != ref[k]][:10]
 
 
+@pytest.mark.parametrize('yaml_name,golden,opt_golden', [
+    ('v2x_pointpillar_basic_car.yaml', 'g1_car.npz', 'g12_hunter_train.npz'), ('v2x_pointpillar_basic_rsu.yaml', 'g1_rsu.npz', None),
+    ('v2x_pointpillar_basic_ego.yaml', 'g1_ego.npz', 'g7b_train_ego.npz'), ('v2x_pointpillar_basic_ego_early.yaml', 'g1_early.npz', None),
+    ('v2x_pointpillar_disco.yaml', 'g1_disco.npz', 'g7_train.npz')])
+def test_shipped_yaml_sections_equal_the_references(yaml_name, golden, opt_golden):
+    """the resolved MODEL (and OPTIMIZATION) section of every shipped YAML against the reference's resolved section of the YAML of the same
+    name (stored as data with the golden fixtures): equal key by key except the build's own include keys, keys the build adds with the
+    reference's default, and the overrides the fixture generator applied (temp checkpoints, mini-geometry range, lowered score threshold)"""
+    from helpers import load_golden
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', yaml_name), EasyDict())
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        return [plain(v) for v in d] if isinstance(d, (list, tuple)) else d
+
+    def diff(a, b, path=''):
+        if isinstance(a, dict) and isinstance(b, dict):
+            out = []
+            for k in sorted(set(a) | set(b)):
+                out += [(path + '/' + k, a.get(k, '<absent>'), b.get(k, '<absent>'))] if (k not in a or k not in b) else diff(a[k], b[k], path + '/' + k)
+            return out
+        if isinstance(a, list) and isinstance(b, list) and len(a) == len(b):
+            return [d for i, (x, y) in enumerate(zip(a, b)) for d in diff(x, y, '%s[%d]' % (path, i))]
+        same = a == b or (isinstance(a, (int, float)) and isinstance(b, (int, float)) and abs(a - b) < 1e-12)
+        return [] if same else [(path, a, b)]
+    allowed = ('_BASE_CONFIG_', '/CKPT', '/DEBUG', 'GENERATING_EXCHANGE_DATA', 'DATABASE_EXCHANGE_DATA', 'PC_RANGE_MIN', 'BACKBONE_2D/BACKBONE_2D',
+               'POST_PROCESSING/SCORE_THRESH')
+    left = [d for d in diff(plain(cfg.MODEL), load_golden(golden)['meta']['model']) if not any(a in d[0] for a in allowed)]
+    assert not left, left
+    assert cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH == 0.1                       # the reference's value (fixtures lower it to 0.02)
+    if opt_golden is not None:
+        left = [d for d in diff(plain(cfg.OPTIMIZATION), load_golden(opt_golden)['meta']['optimization']) if '_BASE_CONFIG_' not in d[0]]
+        assert not left, left
+
+
 def test_training_dataset_and_onecycle_schedule():
     """synthetic training items carry zero-padded gt_boxes (collate_batch contract, dataset.py:260-266); the one-cycle schedule
     reproduces the lr / beta1 values the reference's scheduler produced for the golden run"""
