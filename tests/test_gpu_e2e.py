@@ -784,3 +784,41 @@ def test_overlapped_makers_give_the_bits_of_the_sequential_chain():
         assert len(seq) == len(ovl)
         for a, b in zip(seq, ovl):
             assert a.shape == b.shape and torch.equal(a, b), it
+
+
+@pytest.mark.gpu
+def test_recall_record_with_ground_truth_in_eval():
+    """Detector3DTemplate.generate_recall_record (detector3d_template.py:347-389 of the reference) when eval batches carry gt_boxes: the
+    3-D IoU of every detection with every box (BEV overlap kernel x height overlap) thresholded at RECALL_THRESH_LIST, against the same
+    counts from the C oracle's overlap matrix; trailing all-zero rows are padding"""
+    from oracle import nms as onms
+    g = load_golden('g1_car.npz')
+    model = _build(g)
+    ref_boxes = [g['final_boxes_%d' % b] for b in range(2)]
+    rng = np.random.RandomState(4)
+    gt = np.zeros((2, 12, 8), np.float32)
+    for b in range(2):
+        take = ref_boxes[b][:9].copy()
+        take[:, 0:2] += rng.uniform(-0.6, 0.6, (take.shape[0], 2))          # some still overlap their detection well, some do not
+        take[:, 6] += rng.uniform(-0.3, 0.3, take.shape[0])
+        gt[b, :take.shape[0], :7] = take
+        gt[b, :take.shape[0], 7] = 1.0
+    batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': [{}, {}], 'gt_boxes': torch.from_numpy(gt).cuda()}
+    with torch.no_grad():
+        pred_dicts, recall = model(batch)
+    thr = list(model.model_cfg.POST_PROCESSING.RECALL_THRESH_LIST)
+    want = {'gt': 0, **{'rcnn_%s' % t: 0 for t in thr}, **{'roi_%s' % t: 0 for t in thr}}
+    for b in range(2):
+        pb = pred_dicts[b]['pred_boxes'].cpu().numpy().astype(np.float32)
+        gb = gt[b, :9, :7]
+        ov = onms.overlap_matrix(pb, gb)
+        zmax = np.minimum((pb[:, 2] + pb[:, 5] / 2)[:, None], (gb[:, 2] + gb[:, 5] / 2)[None])
+        zmin = np.maximum((pb[:, 2] - pb[:, 5] / 2)[:, None], (gb[:, 2] - gb[:, 5] / 2)[None])
+        o3 = ov * np.clip(zmax - zmin, 0, None)
+        va, vb = (pb[:, 3] * pb[:, 4] * pb[:, 5])[:, None], (gb[:, 3] * gb[:, 4] * gb[:, 5])[None]
+        iou = o3 / np.clip(va + vb - o3, 1e-6, None)
+        for t in thr:
+            want['rcnn_%s' % t] += int((iou.max(axis=0) > t).sum())
+        want['gt'] += 9
+    assert recall == want, (recall, want)
+    assert 0 < want['rcnn_%s' % thr[-1]] < want['gt']                      # the fixture separates the thresholds
