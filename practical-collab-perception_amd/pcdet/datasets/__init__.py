@@ -14,7 +14,7 @@ from pcp_amd import synth
 from ..models import DatasetInfo
 from ..utils import common_utils
 
-LAYOUT_OF = {'V2XSimDataset_CAR': 'car', 'V2XSimDataset_RSU': 'car', 'V2XSimDataset_EGO': 'lately',
+LAYOUT_OF = {'V2XSimDataset_CAR': 'car', 'V2XSimDataset_RSU': 'car', 'V2XSimDataset_EGO': 'lately', 'V2XSimDataset_EGO_LATE': 'lately',
              'V2XSimDataset_EGO_EARLY': 'early', 'V2XSimDataset_EGO_DISCO': 'disco'}
 AGENTS_OF = {'car': 1, 'lately': 1, 'early': 6, 'disco': 6}
 
@@ -50,6 +50,10 @@ class SyntheticV2XDataset(DatasetInfo, Dataset):
             parts.append(c)
         meta = {'sample_token': 'synthetic_%06d' % index, 'lidar_id': 1,
                 'se3_from_ego': {a: synth.agent_pose(a) for a in range(n_agents) if a != 1}}
+        if self.dataset_cfg.DATASET == 'V2XSimDataset_EGO_LATE':
+            # box-level fusion reads every agent's detections from the exchange database (v2x_sim_dataset_ego_late.py): synthetic stand-in
+            # = 40 boxes per agent, neighbouring agents reporting overlapping boxes so that the NMS has something to merge
+            meta['exchange_boxes'] = {a: self.synthetic_exchange_boxes(index, a) for a in range(6)}
         item = {'points': np.concatenate(parts, 0), 'frame_id': index, 'metadata': meta}
         if self.training:
             item['gt_boxes'] = self.synthetic_gt_boxes(index)
@@ -62,6 +66,17 @@ class SyntheticV2XDataset(DatasetInfo, Dataset):
     def synthetic_foreground(self, index, gt, n_sweeps=11, per_local=12):
         """the fields V2XSimDataset_CAR adds for HunterJr (pcdet/datasets/v2x_sim/v2x_sim_dataset_car.py): see synth.instance_foreground"""
         return synth.instance_foreground(index, gt, n_sweeps, per_local)
+
+    def synthetic_exchange_boxes(self, index, agent, n=40):
+        """(n, 9) [box7, score, label]: the boxes of synthetic_gt_boxes jittered per agent (same objects seen by several agents)"""
+        gt = self.synthetic_gt_boxes(index, n_max=n)
+        s = synth.SEED_BASE + 7000 + 10 * index + agent
+        out = np.zeros((gt.shape[0], 9), dtype=np.float32)
+        out[:, :7] = gt[:, :7]
+        out[:, 0:2] += synth.uniform(s, 1, gt.shape[0] * 2, -0.3, 0.3).reshape(-1, 2)
+        out[:, 7] = synth.uniform(s, 2, gt.shape[0], 0.05, 0.95)
+        out[:, 8] = gt[:, 7]
+        return out[agent::2].copy()                       # every agent sees a different subset
 
     def synthetic_gt_boxes(self, index, n_max=40):
         """(n, 8) [x, y, z, dx, dy, dz, heading, class] car-sized boxes inside the range, n varies with the frame"""

@@ -822,3 +822,27 @@ def test_recall_record_with_ground_truth_in_eval():
         want['gt'] += 9
     assert recall == want, (recall, want)
     assert 0 < want['rcnn_%s' % thr[-1]] < want['gt']                      # the fixture separates the thresholds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('yaml_name,fast', [('v2x_pointpillar_basic_car.yaml', False), ('v2x_pointpillar_basic_ego.yaml', True),
+                                            ('v2x_pointpillar_basic_ego_early.yaml', True), ('v2x_pointpillar_disco.yaml', True),
+                                            ('v2x_pointpillar_disco.yaml', False), ('v2x_pointpillar_anchor.yaml', False),
+                                            ('v2x_late_fusion.yaml', False)])
+def test_tools_test_py_runs_every_shipped_config(yaml_name, fast):
+    """tools/test.py (the reference's command line) on a small synthetic set for every shipped YAML, plugin-default and `--fast`
+    (pipeline mode incl. the overlapped BEV makers): exit code 0 and the evaluation report of eval_utils.eval_one_epoch"""
+    import os
+    import re
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = os.path.join(repo, 'practical-collab-perception_amd', 'tools')
+    cmd = [sys.executable, 'test.py', '--cfg_file', 'cfgs/v2x_sim_models/' + yaml_name, '--batch_size', '2'] + (['--fast'] if fast else []) + \
+          ['--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '6000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '6']
+    r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
+    out = r.stdout + r.stderr
+    assert 'Performance of EPOCH' in out
+    m = re.search(r'(\d+) detections over (\d+) frames', out)
+    assert m is not None and int(m.group(2)) == 6, out[-1500:]
