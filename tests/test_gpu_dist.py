@@ -120,3 +120,20 @@ def test_train_py_two_ranks_share_one_gpu(tmp_path, yaml_name):
     ck = torch.load(os.path.join(str(tmp_path), 'ckpt', 'checkpoint_epoch_2.pth'), map_location='cpu', weights_only=False)
     assert ck['epoch'] == 2 and ck['it'] == 8
     assert all(torch.isfinite(v).all() for v in ck['model_state'].values() if v.dtype.is_floating_point)
+
+
+def test_test_py_two_ranks_merge_results_in_dataset_order():
+    """tools/test.py --launcher pytorch with two ranks on this GPU (gloo): frames sharded by the DistributedSampler, per-rank detections
+    merged on rank 0 (common_utils.merge_results_dist) -- the report covers every frame once"""
+    import re
+    import subprocess
+    tools = os.path.join(PKG, 'tools')
+    env = dict(os.environ, PCP_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+           str(_free_port()), 'test.py', '--launcher', 'pytorch', '--fast', '--cfg_file', 'cfgs/v2x_sim_models/v2x_pointpillar_disco.yaml',
+           '--batch_size', '2', '--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '3000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '7']
+    r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
+    out = r.stdout + r.stderr
+    reports = re.findall(r'(\d+) detections over (\d+) frames', out)
+    assert len(reports) == 1 and int(reports[0][1]) == 7, (reports, out[-1500:])          # one report (rank 0), 7 frames (ragged shard 4 + 3)
