@@ -69,8 +69,16 @@ constexpr int XLD = 36;           // padded row of the x / xmax0 tiles (floats):
 
 __device__ __forceinline__ f32x16 mfma32p(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// The kernel is latency bound (a 64-pillar workgroup holds ~120 points = two chunks behind a chain of dependent global loads): ONE x tile
+// and an extra barrier per chunk keep the LDS at 39 KB, i.e. four workgroups per CU instead of three -- 267 -> 233 us on 1.44 M points.
+#ifdef PFN_DOUBLE_BUF
+constexpr int PFN_NBUF = 2, PFN_WGS = 3;
+#else
+constexpr int PFN_NBUF = 1, PFN_WGS = 4;
+#endif
+
 template <int NUM_RAW>
-__global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
+__global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
   constexpr int F = NUM_RAW + 6;
   constexpr int PL_CAP = 512;                            // points of the block with a direct point -> pillar table
   __shared__ unsigned char pl_of[PL_CAP];
@@ -81,20 +89,39 @@ __global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
   __shared__ float cell_xy[PILLARS_PER_BLOCK][2];       // cell indices of each pillar as floats
   __shared__ __attribute__((aligned(16))) float xmax0[PILLARS_PER_BLOCK * XLD];   // >= 0 after ReLU: int order == float order
   __shared__ unsigned dmax[PILLARS_PER_BLOCK][C1];      // fkey-encoded running max of the point half of layer 1
-  __shared__ __attribute__((aligned(16))) float xs[2][64 * XLD];                  // layer-0 output of the current chunk
-  __shared__ int pl_s[2][64];                           // pillar of each point of the chunk (-1: past the end)
+  __shared__ __attribute__((aligned(16))) float xs[PFN_NBUF][64 * XLD];           // layer-0 output of the current chunk
+  __shared__ int pl_s[PFN_NBUF][64];                           // pillar of each point of the chunk (-1: past the end)
 
-  const int P = p.counters[0];
   const int r0 = blockIdx.x * PILLARS_PER_BLOCK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // The workgroup's time is a chain of dependent global loads (counters -> pillar_start -> bucket_order -> point rows): everything that does
+  // not depend on the pillar count is requested BEFORE the count is waited for (the tables have n + 1 / n entries: guarded, values past the
+  // last pillar are never used), and the slot range comes from two scalar loads instead of an LDS round trip behind a barrier.
+  int ps_reg = 0, pc_reg = 0;
+  if (tid <= PILLARS_PER_BLOCK && (long long)r0 + tid <= p.n) ps_reg = p.pillar_start[r0 + tid];
+  if (tid < PILLARS_PER_BLOCK && (long long)r0 + tid < p.n) pc_reg = p.pillar_cell[r0 + tid];
+  const int s0 = (long long)r0 <= p.n ? p.pillar_start[r0] : 0;
+  const int P = p.counters[0];
   if (r0 >= P) return;
   const int np = min(PILLARS_PER_BLOCK, P - r0);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int s1 = p.pillar_start[r0 + np];
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // SGPR: keeps the weight addresses scalar
   const int r = lane & 31, h = lane >> 5;
   const int rt = wave >> 1, ct = wave & 1;
   const int plane = p.g.nx * p.g.ny;
 
-  for (int i = tid; i <= np; i += PFN_THREADS) pl_start[i] = p.pillar_start[r0 + i];
+  // rows of the first chunk and the bucket order of the second: in flight during the LDS set-up and sweep 1
+  float rawc[NUM_RAW], rawn[NUM_RAW];
+  int bo_n = 0;
+  {
+    const int sa = s0 + lane, sb = s0 + 64 + lane;
+    const int bo = sa < s1 ? p.bucket_order[sa] : 0;
+    if (sb < s1) bo_n = p.bucket_order[sb];
+    const float *row = p.points + (long long)bo * p.stride;
+#pragma unroll
+    for (int k = 0; k < NUM_RAW; k++) rawc[k] = row[1 + k];             // slot past the end: row 0, never used
+  }
+  if (tid <= np) pl_start[tid] = ps_reg;
   for (int i = tid; i < PILLARS_PER_BLOCK * 3; i += PFN_THREADS) (&sum_fx[0][0])[i] = 0;
   for (int i = tid; i < PILLARS_PER_BLOCK * XLD; i += PFN_THREADS) xmax0[i] = 0.f;
   for (int i = tid; i < PILLARS_PER_BLOCK * C1; i += PFN_THREADS) (&dmax[0][0])[i] = 0u;
@@ -102,7 +129,7 @@ __global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
     long long off = 0;
     float cxf = 0.f, cyf = 0.f;
     if (i < np) {
-      const int cell = p.pillar_cell[r0 + i];
+      const int cell = pc_reg;                             // i == tid: PILLARS_PER_BLOCK <= PFN_THREADS
       const int b = cell / plane, rem = cell % plane;
       const int cx = rem / p.g.ny, cy = rem % p.g.ny;
       off = (((long long)b * p.g.ny + cy) * p.g.nx + cx) * C1;
@@ -125,24 +152,12 @@ __global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
     }
   }
   __syncthreads();
-  const int s0 = pl_start[0], s1 = pl_start[np];
   // point -> pillar of the block's first PL_CAP points (a pillar is a run of consecutive slots); later points (crowded pillars) search
   for (int i = tid; i < np; i += PFN_THREADS) {
     const int a = pl_start[i] - s0, b = min(pl_start[i + 1] - s0, PL_CAP);
     for (int q = a; q < b; q++) pl_of[q] = (unsigned char)i;
   }
   auto pillar_of = [&](int s) { return (s - s0 < PL_CAP) ? (int)pl_of[s - s0] : find_pillar(pl_start, np, s); };
-  // rows of the first chunk and the bucket order of the second: in flight during sweep 1
-  float rawc[NUM_RAW], rawn[NUM_RAW];
-  int bo_n = 0;
-  {
-    const int sa = s0 + lane, sb = s0 + 64 + lane;
-    const int bo = sa < s1 ? p.bucket_order[sa] : 0;
-    if (sb < s1) bo_n = p.bucket_order[sb];
-    const float *row = p.points + (long long)bo * p.stride;
-#pragma unroll
-    for (int k = 0; k < NUM_RAW; k++) rawc[k] = row[1 + k];             // slot past the end: row 0, never used
-  }
   __syncthreads();
 
   // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
 
   // ---- sweep 2 -----------------------------------------------------------------------------------------------------------
   int buf = 0;
-  for (int base = s0; base < s1; base += 64, buf ^= 1) {
+  for (int base = s0; base < s1; base += 64, buf ^= (PFN_NBUF - 1)) {
     const int s = base + lane;
     // software pipeline: the next chunk's rows (their bucket order arrived during the previous iteration) and the bucket order of the
     // chunk after it are requested now and consumed one iteration later
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(PFN_THREADS, 3) void k_pfn(PfnParams p) {
 #pragma unroll
     for (int k = 0; k < NUM_RAW; k++) rawc[k] = rawn[k];
     bo_n = bo_nn;
+    if (PFN_NBUF == 1) __syncthreads();      // single buffer (four workgroups per CU): every wave is done with xs before the next chunk
     // xs / pl_s are double buffered: the next chunk writes the other buffer, and the barrier of the chunk after that orders the reuse
   }
   __syncthreads();
