@@ -77,6 +77,13 @@ constexpr int PFN_NBUF = 2, PFN_WGS = 3;
 constexpr int PFN_NBUF = 1, PFN_WGS = 4;
 #endif
 
+#ifdef PFN_STAMP
+__device__ unsigned long long pfn_dbg[32];
+#define PFN_STAMP_AT(k) do { if (blockIdx.x == PFN_STAMP && threadIdx.x == 0) pfn_dbg[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PFN_STAMP_AT(k) do {} while (0)
+#endif
+
 template <int NUM_RAW>
 __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
   constexpr int F = NUM_RAW + 6;
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
   __shared__ __attribute__((aligned(16))) float xs[PFN_NBUF][64 * XLD];           // layer-0 output of the current chunk
   __shared__ int pl_s[PFN_NBUF][64];                           // pillar of each point of the chunk (-1: past the end)
 
+  PFN_STAMP_AT(0);
   const int r0 = blockIdx.x * PILLARS_PER_BLOCK;
   const int tid = threadIdx.x, lane = tid & 63;
   // The workgroup's time is a chain of dependent global loads (counters -> pillar_start -> bucket_order -> point rows): everything that does
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
   if (r0 >= P) return;
   const int np = min(PILLARS_PER_BLOCK, P - r0);
   const int s1 = p.pillar_start[r0 + np];
+  PFN_STAMP_AT(1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // SGPR: keeps the weight addresses scalar
   const int r = lane & 31, h = lane >> 5;
   const int rt = wave >> 1, ct = wave & 1;
@@ -151,7 +160,9 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
       wm[j] = *reinterpret_cast<const f32x4 *>(wr + C0 + 8 * j);
     }
   }
+  PFN_STAMP_AT(12);
   __syncthreads();
+  PFN_STAMP_AT(13);
   // point -> pillar of the block's first PL_CAP points (a pillar is a run of consecutive slots); later points (crowded pillars) search
   for (int i = tid; i < np; i += PFN_THREADS) {
     const int a = pl_start[i] - s0, b = min(pl_start[i + 1] - s0, PL_CAP);
@@ -160,6 +171,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
   auto pillar_of = [&](int s) { return (s - s0 < PL_CAP) ? (int)pl_of[s - s0] : find_pillar(pl_start, np, s); };
   __syncthreads();
 
+  PFN_STAMP_AT(2);
   // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
   for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
     const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
@@ -178,6 +190,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
   }
   __syncthreads();
 
+  PFN_STAMP_AT(3);
   // cell-centre offsets exactly as the reference constructor rounds them (dynamic_pillar_vfe.py:80-82)
   const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
   const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
@@ -199,6 +212,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
       }
       if (sn2 < s1) bo_nn = p.bucket_order[sn2];
     }
+    if (base == s0) PFN_STAMP_AT(4);
     int pl = -1;
     float x8[8];
 #pragma unroll
@@ -227,7 +241,9 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
     *reinterpret_cast<f32x4 *>(&xs[buf][lane * XLD + wave * 8]) = f32x4{x8[0], x8[1], x8[2], x8[3]};
     *reinterpret_cast<f32x4 *>(&xs[buf][lane * XLD + wave * 8 + 4]) = f32x4{x8[4], x8[5], x8[6], x8[7]};
     if (wave == 0) pl_s[buf][lane] = pl;
+    if (base == s0) PFN_STAMP_AT(5);
     __syncthreads();
+    if (base == s0) PFN_STAMP_AT(6);
     // point half of layer 1 on the matrix pipe: rows = points rt*32 .. +31, columns = channels ct*32 .. +31
     f32x16 acc;
 #pragma unroll
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
       acc = mfma32p(a.z, wp[j].z, acc);
       acc = mfma32p(a.w, wp[j].w, acc);
     }
+    if (base == s0) PFN_STAMP_AT(7);
     const int o = ct * 32 + r;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
@@ -251,11 +268,14 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
 #pragma unroll
     for (int k = 0; k < NUM_RAW; k++) rawc[k] = rawn[k];
     bo_n = bo_nn;
-    if (PFN_NBUF == 1) __syncthreads();      // single buffer (four workgroups per CU): every wave is done with xs before the next chunk
+    if (base == s0) PFN_STAMP_AT(8);
+    if (PFN_NBUF == 1) __syncthreads();
+    if (base == s0) PFN_STAMP_AT(9);      // single buffer (four workgroups per CU): every wave is done with xs before the next chunk
     // xs / pl_s are double buffered: the next chunk writes the other buffer, and the barrier of the chunk after that orders the reuse
   }
   __syncthreads();
 
+  PFN_STAMP_AT(10);
   // ---- epilogue: out = relu(b1 + xmax0 . W1[:, 32:]^T + dmax) for rows = pillars rt2*32 .. +31 --------------------------------
   const int o = ct * 32 + r;
   const float bias = p.b1[o];
@@ -272,16 +292,22 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
       acc = mfma32p(a.z, wm[j].z, acc);
       acc = mfma32p(a.w, wm[j].w, acc);
     }
+    PFN_STAMP_AT(14);
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       const int pl = rt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       if (pl < np) {
         const float v = fmaxf((bias + acc[e]) + fkey_inv(dmax[pl][o]), 0.0f);
         if (p.pillar_features) p.pillar_features[(long long)(r0 + pl) * C1 + o] = v;
+#ifdef PFN_DIAG_NO_STORE
+        if (p.canvas && v == 1.2345e30f) p.canvas[row_off[pl] + o] = v;       // timing-only build
+#else
         if (p.canvas) p.canvas[row_off[pl] + o] = v;
+#endif
       }
     }
   }
+  PFN_STAMP_AT(11);
 }
 
 __global__ void k_canvas_clear(const int *__restrict__ pillar_cell, const int *__restrict__ counters, pcp_grid_t g,
@@ -356,3 +382,9 @@ extern "C" int pcp_fill_zero(void *ptr, size_t bytes, void *stream_) {
   if (bytes == 0) return PCP_OK;
   return pcp_zero_async(ptr, bytes, (hipStream_t)stream_);
 }
+
+#ifdef PFN_STAMP
+extern "C" int pcp_debug_read_pfn(void *dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pfn_dbg), bytes) == hipSuccess ? 0 : 3;
+}
+#endif
