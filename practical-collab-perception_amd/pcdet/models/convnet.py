@@ -37,18 +37,23 @@ def _plain_bf16():
 # (320 workgroups on 256 CUs), and the through-memory F(4x4) path keeps the very wide layers (768 -> 768: x0.84)
 WINOGRAD4F_MIN_WORKGROUPS = 256
 WINOGRAD4F_MAX_CIN = 448
+WINOGRAD4F_MAX_INPUT_BYTES = 0x7fffffff                    # buffer-descriptor addressing (tests lower it to exercise the fallback)
 
 
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
     __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f')
 
-    def _use_winograd4f(self, x, out, out_ch_off):
+    def _use_winograd4f(self, x, out, out_ch_off, in_ch_off=0):
         algo = conv_algo()
         if self.kind != '3x3' or getattr(self, 'w4f', None) is None or algo in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'):
             return False
         if out is not None and (out.shape[-1] % 4 != 0 or out_ch_off % 4 != 0):
             return False                                   # 16-byte output stores
+        # the kernel's own limits (csrc/wino4f.hip f4_geom): 16-byte input loads through a buffer descriptor with 32-bit byte offsets.
+        # Outside them the launch returns PCP_ERR_UNSUPPORTED / PCP_ERR_ARG, so the dispatch falls through to the other kernels instead
+        if x.shape[-1] % 4 != 0 or in_ch_off % 4 != 0 or x.numel() * 4 > WINOGRAD4F_MAX_INPUT_BYTES:
+            return False
         if algo == 'winograd4f':
             return True
         B, H, W, _ = x.shape
@@ -97,7 +102,7 @@ class PackedConv:
             w3, b3, cp3 = self.b3
             return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
                                       in_ch_off=in_ch_off, out_ch_off=out_ch_off, plain=_plain_bf16())
-        if self._use_winograd4f(x, out, out_ch_off):
+        if self._use_winograd4f(x, out, out_ch_off, in_ch_off):
             u, ub, ucp = self.w4f
             return ops.conv3x3_winograd4f(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
                                           out_ch_off=out_ch_off)
@@ -123,6 +128,10 @@ def _winograd4_shape(cin, cout, stride):
 
 
 def _winograd4f_shape(cin, cout, stride):
+    # layers auto dispatch never sends to the fused kernel (cin above its cap with the through-memory form available) do not get the
+    # 4x-sized fused weight form packed at all; PCP_CONV_ALGO=winograd4f packs it for every eligible layer
+    if conv_algo() != 'winograd4f' and cin > WINOGRAD4F_MAX_CIN and _winograd4_shape(cin, cout, stride):
+        return False
     return (stride == 1 and cin % 8 == 0 and cout % 4 == 0 and cout >= 48 and conv_algo() not in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'))
 
 

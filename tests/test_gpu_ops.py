@@ -572,6 +572,32 @@ def test_conv3x3_winograd4f_channel_windows_and_bad_arguments():
         ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
 
 
+def test_auto_dispatch_falls_back_when_the_fused_f4_kernel_refuses(monkeypatch):
+    """a layer the fused F(4x4) kernel cannot take (over its 2 GiB input limit -- lowered here) still runs in auto mode, on the
+    F(2x2) kernel, with the same result (every conv kernel of the library needs 16-byte aligned channel windows, so there is no fallback for
+    those: the wrappers raise)"""
+    import torch.nn as nn
+    from pcdet.models import convnet
+    ops = _ops()
+    d = dev()
+    torch.manual_seed(5)
+    conv = nn.Conv2d(64, 64, 3, padding=1, bias=False)
+    pc = convnet.pack_conv_module(conv, None, relu=True)
+    for attr in ('w', 'b', 'wino', 'w4f'):
+        v = getattr(pc, attr)
+        setattr(pc, attr, tuple(t.to(d) if torch.is_tensor(t) else t for t in v) if isinstance(v, tuple) else v.to(d))
+    x = torch.from_numpy(_rand(281, (32, 64, 64, 72))).to(d)                      # 32 x 4 x 2 = 256 workgroups: auto picks the fused kernel
+    assert pc._use_winograd4f(x, None, 0, 4)
+    want = pc.run(x, in_ch_off=4)                                                  # fused F(4x4)
+    monkeypatch.setattr(convnet, 'WINOGRAD4F_MAX_INPUT_BYTES', 1 << 20)
+    assert not pc._use_winograd4f(x, None, 0, 4)
+    got = pc.run(x, in_ch_off=4)                                                   # F(2x2): no exception
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x[..., 4:68].permute(0, 3, 1, 2).cpu(), conv.weight.detach(), None, padding=1))
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(want.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Winograd F(4x4, 3x3) through memory (input transform, 36 batched MFMA GEMMs, output transform): the wide layers
 # ---------------------------------------------------------------------------------------------------------------------

@@ -297,3 +297,25 @@ def test_winograd_ws_packing_holds_the_same_transformed_weights():
     x = torch.randn((1, 64, 8, 8), generator=g)
     got = pack.winograd_reference(x, pold, bws, 100)
     assert float((got - F.conv2d(x, w, b, padding=1)).abs().max()) < 1e-4
+
+
+def test_auto_dispatch_respects_the_fused_f4_kernels_own_limits(monkeypatch):
+    """the fused F(4x4) kernel (csrc/wino4f.hip f4_geom) takes 16-byte aligned channel windows and at most 2 GiB of input
+    (32-bit buffer-descriptor offsets); auto dispatch must fall through to the other kernels outside those limits instead of raising"""
+    import torch.nn as nn
+    from pcdet.models import convnet
+    conv = nn.Conv2d(64, 64, 3, padding=1, bias=False)
+    pc = convnet.pack_conv_module(conv, nn.BatchNorm2d(64).eval(), relu=True)
+    assert pc.w4f is not None
+    x = torch.empty((4, 256, 256, 64), device='meta')
+    assert pc._use_winograd4f(x, None, 0, 0)
+    assert not pc._use_winograd4f(x, None, 0, 2)                        # input window not 16-byte aligned
+    assert not pc._use_winograd4f(torch.empty((4, 256, 256, 66), device='meta'), None, 0, 0)
+    monkeypatch.setattr(convnet, 'WINOGRAD4F_MAX_INPUT_BYTES', x.numel() * 4 - 1)
+    assert not pc._use_winograd4f(x, None, 0, 0)                        # over the byte limit: F(2x2) / direct take the layer
+    monkeypatch.undo()
+    big = torch.empty((130, 256, 256, 64), device='meta')               # the stacked car-maker pass at B = 26 frames: > 2 GiB
+    assert big.numel() * 4 > 0x7fffffff and not pc._use_winograd4f(big, None, 0, 0)
+    # layers auto dispatch never sends to the fused kernel do not get its (4x sized) weight form packed
+    wide = convnet.pack_conv_module(nn.Conv2d(768, 768, 3, padding=1, bias=False), None, relu=False)
+    assert wide.w4 is not None and wide.w4f is None
