@@ -60,6 +60,11 @@ size_t pcp_voxelize_workspace_bytes(const pcp_grid_t *grid, int64_t max_points);
 int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid,
                  void *workspace, size_t workspace_bytes,
                  int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt, int32_t *counters, void *stream);
+/* The passes of pcp_voxelize behind its first one, for rows whose cell ids and per-cell histogram are already in the workspace
+ * (pcp_select_transform_compact with vox_grid).  No unq_inv in this mode. */
+int pcp_voxelize_cells_ready(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid,
+                             void *workspace, size_t workspace_bytes,
+                             int32_t *voxel_coords, int32_t *unq_cnt, int32_t *counters, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a2 / a3 / a5  point feature build + two PFN layers + scatter to the dense BEV canvas, one kernel.
@@ -266,6 +271,11 @@ size_t pcp_nms_workspace_bytes(int32_t n_max, int32_t batch);
 int pcp_nms_rotated(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
                     float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
                     int32_t *keep, int32_t *keep_count, void *stream);
+/* The same pipeline with the AXIS-ALIGNED IoU of nms_normal_gpu (iou3d_nms_api.cpp:16 -> iou3d_nms.cpp:139-188 +
+ * iou3d_nms_kernel.cu:314-372: x / y extents only, the heading is ignored). */
+int pcp_nms_normal(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
+                   float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+                   int32_t *keep, int32_t *keep_count, void *stream);
 /* mode 0: overlap area (boxes_overlap_bev_gpu), mode 1: IoU (boxes_iou_bev_gpu); out (na, nb) float32 */
 int pcp_boxes_bev_pairwise(const float *a, int32_t na, const float *b, int32_t nb, int32_t mode, float *out,
                            void *stream);
@@ -334,6 +344,26 @@ int pcp_select_transform_points(const float *points, int64_t n, int32_t row_stri
  * of the integer values 0..63 found in column `col`, out2[1] = number of rows holding anything else (then the caller sorts).
  * out2: 2 x uint64 on the device, 16-byte aligned; zeroed by the call. */
 int pcp_column_id_mask(const float *points, int64_t n, int32_t row_stride, int32_t col, uint64_t *out2, void *stream);
+/* The same with the number of rows per id: out66[0] = presence mask, out66[1] = rows outside 0..63, out66[2 + i] = rows whose value
+ * truncates to i.  One read-back then sizes every per-agent selection of a forward on the host (bev_maker.py:156,168-169).
+ * out66: 66 x uint64 on the device, 16-byte aligned; zeroed by the call. */
+int pcp_column_id_counts(const float *points, int64_t n, int32_t row_stride, int32_t col, uint64_t *out66, void *stream);
+
+/* a13 as a STABLE COMPACTION (round 3; replaces bev_maker.py:168-190 for all agents of one stacked pass): for slots s = 0 .. n_slots-1
+ * the rows of agent agents_host[s] whose frame b has present_host[s * batch + b] != 0 are written to `out` in input order, slot s
+ * directly behind slot s-1 (= torch.cat([points[mask_s] for s])), with frame index b + s * batch and xyz mapped by the 3x4 pose
+ * poses_host[(s * batch + b) * 12 ..] (same rounding order as pcp_select_transform_points).  Rows [total, out_rows) of `out` get frame
+ * index -1 (pcp_voxelize drops them); slot_start (n_slots + 1 int32 on the device, may be NULL) receives the first row of every slot
+ * and the total.  n_slots <= 8, n_slots * batch <= 64 (the pose table is a kernel argument).  workspace: device scratch of
+ * pcp_select_transform_compact_workspace_bytes(n, n_slots).
+ * vox_grid != NULL (batch_size = n_slots * batch): the cell id of every written row and the per-cell histogram are emitted into
+ * vox_workspace, laid out as pcp_voxelize lays it out for (vox_grid, out_rows); follow with pcp_voxelize_cells_ready on the same
+ * arguments instead of pcp_voxelize (its first pass over the rows is then already done). */
+size_t pcp_select_transform_compact_workspace_bytes(int64_t n, int32_t n_slots);
+int pcp_select_transform_compact(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
+                                 const float *agents_host, int32_t batch, const float *poses_host, const uint8_t *present_host,
+                                 float *out, int64_t out_rows, void *workspace, size_t workspace_bytes, int32_t *slot_start,
+                                 const pcp_grid_t *vox_grid, void *vox_workspace, size_t vox_workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * SURVEY 8(f) rows 1-2  lately-fusion exchange: producer rows and ego-side MoDAR ingestion.

@@ -84,6 +84,30 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None):
     return order[keep]
 
 
+def iou_normal_matrix(a, b):
+    """iou3d_nms_kernel.cu:314-325 (iou_normal: axis-aligned x / y extents, heading ignored), float32 operation for operation"""
+    a = np.ascontiguousarray(a[:, :7], dtype=np.float32)
+    b = np.ascontiguousarray(b[:, :7], dtype=np.float32)
+    two, zero = np.float32(2.0), np.float32(0.0)
+    ax, ay, adx, ady = (a[:, i][:, None] for i in (0, 1, 3, 4))
+    bx, by, bdx, bdy = (b[:, i][None, :] for i in (0, 1, 3, 4))
+    left = np.maximum(ax - adx / two, bx - bdx / two)
+    right = np.minimum(ax + adx / two, bx + bdx / two)
+    top = np.maximum(ay - ady / two, by - bdy / two)
+    bottom = np.minimum(ay + ady / two, by + bdy / two)
+    inter = np.maximum(right - left, zero) * np.maximum(bottom - top, zero)
+    sa, sb = adx * ady, bdx * bdy
+    return (inter / np.maximum(sa + sb - inter, np.float32(1e-8))).astype(np.float32)
+
+
+def nms_normal_gpu(boxes, scores, thresh):
+    """iou3d_nms_utils.py:102-117 -> iou3d_nms.cpp:139-188: stable descending score sort, axis-aligned IoU mask, greedy sweep;
+    returns indices into `boxes`."""
+    order = np.argsort(-scores.astype(np.float32), kind='stable')
+    keep = nms_from_iou(iou_normal_matrix(boxes[order], boxes[order]), thresh)
+    return order[keep]
+
+
 def class_agnostic_nms(scores, boxes, thresh, pre_max, post_max, score_thresh=None):
     """model_nms_utils.py:6-25 -> (selected indices into the inputs, selected scores)."""
     src = scores

@@ -128,6 +128,16 @@ __device__ __forceinline__ float iou_of(const Box &a, const Box &b) {
   return ov / fmaxf(sa + sb - ov, NMS_EPS);
 }
 
+// axis-aligned IoU of nms_normal_gpu (iou3d_nms_kernel.cu:314-325: the heading is ignored), operation for operation
+__device__ __forceinline__ float iou_normal_of(const Box &a, const Box &b) {
+  float left = fmaxf(a.x - a.dx / 2, b.x - b.dx / 2), right = fminf(a.x + a.dx / 2, b.x + b.dx / 2);
+  float top = fmaxf(a.y - a.dy / 2, b.y - b.dy / 2), bottom = fminf(a.y + a.dy / 2, b.y + b.dy / 2);
+  float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+  float inter = width * height;
+  float sa = a.dx * a.dy, sb = b.dx * b.dy;
+  return inter / fmaxf(sa + sb - inter, NMS_EPS);
+}
+
 __device__ __forceinline__ Box load_box(const float *p) {
   Box b;
   b.x = p[0]; b.y = p[1]; b.dx = p[3]; b.dy = p[4]; b.ang = p[6];
@@ -206,6 +216,7 @@ __global__ void k_nms_identity(const float *__restrict__ boxes, int n_max, const
 // ---- (2) suppression mask: word (row i, col block c) bit t = iou(i, 64c + t) > thresh, for columns > i ---------------------
 // One wavefront per 64-bit mask word: lane t evaluates the pair (i, 64c + t) and the word is the wave ballot.  The n^2/2
 // pair tests are spread over n * ceil(n/64) / 2 independent wavefronts instead of a serial 64-iteration loop per lane.
+template <bool NORMAL>
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sorted_boxes, const int *__restrict__ n_eff_p,
                                                  int col_blocks, float thresh, u64 *__restrict__ mask, int n_max) {
   const int fb = blockIdx.z;
@@ -223,7 +234,8 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ sorte
     float4 lo = src[0], hi = src[1];
     Box b;
     b.x = lo.x; b.y = lo.y; b.dx = lo.w; b.dy = hi.x; b.ang = hi.z;
-    if (!far_apart(a, b)) hit = iou_of(a, b) > thresh;
+    if (NORMAL) hit = iou_normal_of(a, b) > thresh;
+    else if (!far_apart(a, b)) hit = iou_of(a, b) > thresh;
   }
   u64 word = __ballot(hit);
   if (lane == 0) mask[(size_t)row * col_blocks + col_blk] = word;
@@ -315,9 +327,10 @@ extern "C" size_t pcp_nms_workspace_bytes(int32_t n_max, int32_t batch) {
   return nms_layout(n_max, batch).total;
 }
 
-extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
-                               float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
-                               int32_t *keep, int32_t *keep_count, void *stream_) {
+namespace {
+int nms_run(bool normal, const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
+            float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+            int32_t *keep, int32_t *keep_count, void *stream_) {
   if (!keep || !keep_count || n_max < 0 || batch <= 0 || post_max <= 0 || pre_max <= 0) return PCP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
   if (n_max == 0) return pcp_zero_async(keep_count, 4 * (size_t)batch, st);
@@ -339,11 +352,25 @@ extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t 
                        sorted_boxes, n_eff);
   }
   PCP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_nms_mask, dim3(cb, n_max, batch), dim3(64), 0, st, sorted_boxes, n_eff, cb, thresh, mask, n_max);
+  if (normal) hipLaunchKernelGGL(k_nms_mask<true>, dim3(cb, n_max, batch), dim3(64), 0, st, sorted_boxes, n_eff, cb, thresh, mask, n_max);
+  else hipLaunchKernelGGL(k_nms_mask<false>, dim3(cb, n_max, batch), dim3(64), 0, st, sorted_boxes, n_eff, cb, thresh, mask, n_max);
   PCP_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_nms_greedy, dim3(batch), dim3(64), 0, st, mask, n_eff, cb, order, post_max, keep, keep_count, n_max);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+}  // namespace
+
+extern "C" int pcp_nms_rotated(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
+                               float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+                               int32_t *keep, int32_t *keep_count, void *stream_) {
+  return nms_run(false, boxes, scores, batch, n_max, n_dev, thresh, pre_max, post_max, workspace, workspace_bytes, keep, keep_count, stream_);
+}
+
+extern "C" int pcp_nms_normal(const float *boxes, const float *scores, int32_t batch, int32_t n_max, const int32_t *n_dev,
+                              float thresh, int32_t pre_max, int32_t post_max, void *workspace, size_t workspace_bytes,
+                              int32_t *keep, int32_t *keep_count, void *stream_) {
+  return nms_run(true, boxes, scores, batch, n_max, n_dev, thresh, pre_max, post_max, workspace, workspace_bytes, keep, keep_count, stream_);
 }
 
 extern "C" int pcp_boxes_bev_pairwise(const float *a, int32_t na, const float *b, int32_t nb, int32_t mode, float *out,

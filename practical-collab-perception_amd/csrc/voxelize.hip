@@ -259,18 +259,22 @@ extern "C" size_t pcp_voxelize_workspace_bytes(const pcp_grid_t *grid, int64_t m
   return pcp_vox_layout(cells, max_points > 0 ? max_points : 1).total;
 }
 
-extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid, void *workspace,
-                            size_t workspace_bytes, int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt,
-                            int32_t *counters, void *stream_) {
+namespace {
+
+// the pillariser's passes behind the per-point cell ids.  cells_ready: cell_count / point_cell were filled by the caller's own pass over
+// the rows (pcp_select_transform_compact emits them while the transformed row is in registers), so the zero fill and k_point_cells are
+// skipped; the stable compaction position (unq_inv) needs k_point_cells' per-tile sums and is not available in that mode.
+int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid, void *workspace, size_t workspace_bytes,
+               int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt, int32_t *counters, hipStream_t stream, bool cells_ready) {
   if (!grid || !workspace || !voxel_coords || n < 0 || row_stride < 3) return PCP_ERR_ARG;
   if (n > 0 && !points) return PCP_ERR_ARG;
   if (grid->nx <= 0 || grid->ny <= 0 || grid->batch_size <= 0) return PCP_ERR_ARG;
+  if (cells_ready && unq_inv) return PCP_ERR_ARG;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   if (cells >= (1LL << 31) || n >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
   const int64_t n_alloc = n > 0 ? n : 1;
   VoxLayout L = pcp_vox_layout(cells, n_alloc);
   if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
   char *ws = (char *)workspace;
   int *cell_count = (int *)(ws + L.cell_count);
   int *cell_fill = (int *)(ws + L.cell_fill);
@@ -286,16 +290,18 @@ extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, 
   int *pt_bs = (int *)(ws + L.block_sums + (size_t)n_cblk * 8 + 8);
   int *counters_ws = (int *)(ws + L.counters);
 
-  // cell_count and cell_fill are adjacent (layout keeps 256-B alignment between them): one memset
-  if (pcp_zero_async(cell_count, L.cell_rank - L.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
-  if (n_pblk > 0) {
-    hipLaunchKernelGGL(k_point_cells, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
-                       *grid, cell_count, point_cell, pt_bs);
-    PCP_CHECK_LAUNCH();
+  if (!cells_ready) {
+    // cell_count and cell_fill are adjacent (layout keeps 256-B alignment between them): one memset
+    if (pcp_zero_async(cell_count, L.cell_rank - L.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+    if (n_pblk > 0) {
+      hipLaunchKernelGGL(k_point_cells, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
+                         *grid, cell_count, point_cell, pt_bs);
+      PCP_CHECK_LAUNCH();
+    }
   }
   hipLaunchKernelGGL(k_cell_tile_sums, dim3(n_cblk), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, cell_bs);
   PCP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(2), dim3(SCAN_THREADS), 0, stream, cell_bs, n_cblk, pt_bs, n_pblk, counters_ws,
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(cells_ready ? 1 : 2), dim3(SCAN_THREADS), 0, stream, cell_bs, n_cblk, pt_bs, n_pblk, counters_ws,
                      counters, pillar_start);
   PCP_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_cell_finish, dim3(n_cblk), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, *grid, cell_bs,
@@ -304,6 +310,308 @@ extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, 
   if (n_pblk > 0) {
     hipLaunchKernelGGL(k_point_finish, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, point_cell, (long long)n, pt_bs, cell_rank,
                        cell_start, cell_fill, (long long *)unq_inv, bucket_order);
+    PCP_CHECK_LAUNCH();
+  }
+  return PCP_OK;
+}
+
+}  // namespace
+
+extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid, void *workspace,
+                            size_t workspace_bytes, int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt,
+                            int32_t *counters, void *stream_) {
+  return vox_passes(points, n, row_stride, grid, workspace, workspace_bytes, voxel_coords, unq_inv, unq_cnt, counters,
+                    (hipStream_t)stream_, false);
+}
+
+extern "C" int pcp_voxelize_cells_ready(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid, void *workspace,
+                                        size_t workspace_bytes, int32_t *voxel_coords, int32_t *unq_cnt, int32_t *counters,
+                                        void *stream_) {
+  return vox_passes(points, n, row_stride, grid, workspace, workspace_bytes, voxel_coords, nullptr, unq_cnt, counters,
+                    (hipStream_t)stream_, true);
+}
+
+
+// ---- a13 (round 3): BEVMaker input preparation as a STABLE COMPACTION --------------------------------------------------------------
+// Reference: pcdet/models/bev_layers/bev_maker.py:168-190 -- per agent `points[mask]` (boolean-mask copy, input order kept), per frame
+// `p @ R^T + t`, one pass of the frozen chain per agent.  Round 2 stacked the agents into one pass by writing, per agent, a FULL copy of
+// the cloud with the foreign rows masked (frame index -1): the pillariser then scanned slots x n rows to keep n.  Here the rows of all
+// agent slots of a pass are written once, compactly: slot s's rows (input order) directly behind slot s-1's, frame index + s * batch,
+// xyz mapped by the (slot, frame) pose -- exactly cat_s(transform(points[mask_s])).  Rows [total, out_rows) are filled with frame
+// index -1 (the host sizes `out` from the per-agent row counts of pcp_column_id_counts; rows of absent frames make total smaller).
+// With a pillariser workspace the transformed row's cell id is emitted while the row is in registers (k_point_cells fused).
+//   k_stc_count   per 1024-row tile and slot: rows kept                          (reads the frame and agent columns)
+//   k_stc_scan    one workgroup: exclusive prefix over (slot-major, tile) -> tile offsets, slot starts, total
+//   k_stc_scatter rank inside the tile (ballot prefix, item-major row order), transform, write, [cell id + histogram], tail fill
+namespace {
+
+constexpr int STC_MAX_SLOTS = 8;
+constexpr int STC_MAX_POSES = 64;                    // n_slots * batch: the table travels as a kernel argument (< 4 KB)
+struct StcTable {
+  float m[STC_MAX_POSES][12];
+  unsigned char present[STC_MAX_POSES];
+  int agent[STC_MAX_SLOTS];                          // ids compared after truncation, as the reference's points[:, -1].long() (bev_maker.py:154,169)
+  int n_slots, batch;
+};
+
+__device__ __forceinline__ int stc_slot_of(const float *row, int agent_col, const StcTable &t) {
+  const float a = row[agent_col];
+  const int ai = (a > -1.f && a < 64.f) ? (int)a : -1;      // ids outside 0..63 never reach here (pcp_column_id_counts reports them)
+  const int b = (int)row[0];
+  int s = -1;
+#pragma unroll
+  for (int k = 0; k < STC_MAX_SLOTS; k++)
+    if (k < t.n_slots && ai == t.agent[k]) s = k;
+  if (s >= 0 && !(b >= 0 && b < t.batch && t.present[s * t.batch + b])) s = -1;
+  return s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_stc_count(const float *__restrict__ points, long long n, int stride, int agent_col,
+                                                            StcTable t, int n_tiles, int *__restrict__ tile_cnt) {
+  __shared__ int cnt[SCAN_ITEMS][SCAN_THREADS / 64][STC_MAX_SLOTS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * SCAN_TILE;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const long long r = base + i * SCAN_THREADS + threadIdx.x;
+    const int s = r < n ? stc_slot_of(points + r * stride, agent_col, t) : -1;
+#pragma unroll
+    for (int k = 0; k < STC_MAX_SLOTS; k++) {
+      const unsigned long long bal = __ballot(s == k);
+      if (lane == 0) cnt[i][wave][k] = __popcll(bal);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < t.n_slots) {
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+#pragma unroll
+      for (int w = 0; w < SCAN_THREADS / 64; w++) tot += cnt[i][w][threadIdx.x];
+    tile_cnt[(long long)threadIdx.x * n_tiles + blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_stc_scan(int *__restrict__ tile_cnt, int n_entries, int n_tiles, int n_slots,
+                                                           int *__restrict__ slot_start_ws, int *__restrict__ slot_start_out) {
+  __shared__ int lds32[SCAN_THREADS / 64 + 1];
+  int carry = 0;
+  for (int base = 0; base < n_entries; base += SCAN_TILE) {
+    int v[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+      const int idx = base + threadIdx.x * SCAN_ITEMS + i;
+      v[i] = idx < n_entries ? tile_cnt[idx] : 0;
+    }
+    int tot;
+    block_scan_excl<int>(v, lds32, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+      const int idx = base + threadIdx.x * SCAN_ITEMS + i;
+      if (idx < n_entries) {
+        const int e = v[i] + carry;
+        tile_cnt[idx] = e;
+        if (idx % n_tiles == 0) {
+          slot_start_ws[idx / n_tiles] = e;
+          if (slot_start_out) slot_start_out[idx / n_tiles] = e;
+        }
+      }
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    slot_start_ws[n_slots] = carry;
+    if (slot_start_out) slot_start_out[n_slots] = carry;
+  }
+  if (n_entries == 0 && (int)threadIdx.x < n_slots) {   // empty source
+    slot_start_ws[threadIdx.x] = 0;
+    if (slot_start_out) slot_start_out[threadIdx.x] = 0;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__restrict__ points, long long n, int stride, int agent_col,
+                                                              StcTable t, int n_tiles, const int *__restrict__ tile_off,
+                                                              const int *__restrict__ slot_start, float *__restrict__ out,
+                                                              long long out_rows, int emit_cells, pcp_grid_t g,
+                                                              int *__restrict__ cell_count, int *__restrict__ point_cell) {
+  __shared__ int cnt[SCAN_ITEMS][SCAN_THREADS / 64][STC_MAX_SLOTS];       // rows kept per (item, wave, slot) -> exclusive prefix
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * SCAN_TILE;
+  const unsigned long long lt = (1ULL << lane) - 1ULL;
+  int slot[SCAN_ITEMS], rank[SCAN_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const long long r = base + i * SCAN_THREADS + threadIdx.x;
+    slot[i] = r < n ? stc_slot_of(points + r * stride, agent_col, t) : -1;
+    rank[i] = 0;
+#pragma unroll
+    for (int k = 0; k < STC_MAX_SLOTS; k++) {
+      const unsigned long long bal = __ballot(slot[i] == k);
+      if (lane == 0) cnt[i][wave][k] = __popcll(bal);
+      if (slot[i] == k) rank[i] = __popcll(bal & lt);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < t.n_slots) {                       // rows of one slot keep the input order: items, then waves, then lanes
+    int run = (int)blockIdx.x < n_tiles ? tile_off[(long long)threadIdx.x * n_tiles + blockIdx.x] : 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+#pragma unroll
+      for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        const int c = cnt[i][w][threadIdx.x];
+        cnt[i][w][threadIdx.x] = run;
+        run += c;
+      }
+  }
+  __syncthreads();
+  const int total = slot_start[t.n_slots];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const long long r = base + i * SCAN_THREADS + threadIdx.x;
+    if (slot[i] >= 0) {
+      const float *row = points + r * stride;
+      const int s = slot[i];
+      const long long pos = (long long)cnt[i][wave][s] + rank[i];
+      if (pos < out_rows) {                             // the host sized `out` from the same column: always true
+        float *o = out + pos * stride;
+        const int b = (int)row[0];
+        const float *T = t.m[s * t.batch + b];
+        const float x = row[1], y = row[2], z = row[3];
+        const float fb = row[0] + (float)(s * t.batch);
+        // bev_maker.py:179 `p @ R^T + t` on the reference's CPU path (torch -> BLAS sgemm, K = 3) is, bit for bit, the FMA chain
+        // fma(z, r2, fma(y, r1, x * r0)) followed by a separately rounded + t (pinned: tests/golden/g2_disco_full.npz holds the SHA-256
+        // of the transformed rows).  Spelled with explicit roundings so no contraction setting can reorder it.
+        const float tx = __fadd_rn(__fmaf_rn(z, T[2], __fmaf_rn(y, T[1], __fmul_rn(x, T[0]))), T[3]);
+        const float ty = __fadd_rn(__fmaf_rn(z, T[6], __fmaf_rn(y, T[5], __fmul_rn(x, T[4]))), T[7]);
+        const float tz = __fadd_rn(__fmaf_rn(z, T[10], __fmaf_rn(y, T[9], __fmul_rn(x, T[8]))), T[11]);
+        o[0] = fb;
+        o[1] = tx;
+        o[2] = ty;
+        o[3] = tz;
+        for (int c = 4; c < stride; c++) o[c] = row[c];
+        if (emit_cells) {
+          const float cell_row[3] = {fb, tx, ty};
+          const int c = point_to_cell(cell_row, g);
+          point_cell[pos] = c;
+          if (c >= 0) atomicAdd(&cell_count[c], 1);
+        }
+      }
+    }
+    if (r >= total && r < out_rows) {                   // tail of the destination: rows the pillariser must drop
+      float *o = out + r * stride;
+      o[0] = -1.0f;
+      for (int c = 1; c < stride; c++) o[c] = 0.0f;
+      if (emit_cells) point_cell[r] = -1;
+    }
+  }
+}
+
+// per-id row counts of an id column (values truncated like .long()): LDS histogram per workgroup, one global add per id and workgroup
+__global__ __launch_bounds__(256) void k_column_id_counts(const float *__restrict__ points, long long n, int stride, int col,
+                                                          unsigned long long *__restrict__ out) {
+  __shared__ unsigned int s_cnt[64];
+  __shared__ unsigned int s_bad;
+  if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) s_bad = 0u;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = points[i * stride + col];
+    if (v > -1.f && v < 64.f) atomicAdd(&s_cnt[(int)v], 1u); else atomicAdd(&s_bad, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && s_cnt[threadIdx.x]) {
+    atomicAdd(&out[2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    atomicOr(&out[0], 1ULL << threadIdx.x);
+  }
+  if (threadIdx.x == 0 && s_bad) atomicAdd(&out[1], (unsigned long long)s_bad);
+}
+
+struct StcLayout { size_t tile_cnt, slot_start, total; };
+inline StcLayout stc_layout(int64_t n, int n_slots) {
+  StcLayout L;
+  const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  L.tile_cnt = 0;
+  L.slot_start = pcp_align_up((size_t)(n_tiles > 0 ? n_tiles : 1) * n_slots * 4, 256);
+  L.total = L.slot_start + 256;
+  return L;
+}
+
+}  // namespace
+
+extern "C" int pcp_column_id_counts(const float *points, int64_t n, int32_t row_stride, int32_t col, uint64_t *out66, void *stream_) {
+  if (!out66 || n < 0 || row_stride <= 0 || col < 0 || col >= row_stride || (((uintptr_t)out66) & 15)) return PCP_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (pcp_zero_async(out66, 66 * sizeof(uint64_t), stream) != PCP_OK) return PCP_ERR_LAUNCH;
+  if (n == 0) return PCP_OK;
+  if (!points) return PCP_ERR_ARG;
+  long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_column_id_counts, dim3((unsigned)blocks), dim3(256), 0, stream, points, (long long)n, (int)row_stride, (int)col,
+                     (unsigned long long *)out66);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" size_t pcp_select_transform_compact_workspace_bytes(int64_t n, int32_t n_slots) {
+  if (n < 0 || n_slots <= 0 || n_slots > STC_MAX_SLOTS) return 0;
+  return stc_layout(n, n_slots).total;
+}
+
+extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
+                                            const float *agents_host, int32_t batch, const float *poses_host,
+                                            const uint8_t *present_host, float *out, int64_t out_rows, void *workspace,
+                                            size_t workspace_bytes, int32_t *slot_start, const pcp_grid_t *vox_grid,
+                                            void *vox_workspace, size_t vox_workspace_bytes, void *stream_) {
+  if (n < 0 || row_stride < 4 || agent_col < 0 || agent_col >= row_stride || n_slots <= 0 || n_slots > STC_MAX_SLOTS || batch <= 0 ||
+      n_slots * batch > STC_MAX_POSES || out_rows < 0 || n >= (1LL << 31) || out_rows >= (1LL << 31))
+    return PCP_ERR_ARG;
+  if (!agents_host || !poses_host || !present_host || !workspace || (out_rows > 0 && !out) || (n > 0 && !points) || points == out)
+    return PCP_ERR_ARG;
+  const StcLayout L = stc_layout(n, n_slots);
+  if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  StcTable t;
+  t.n_slots = n_slots;
+  t.batch = batch;
+  for (int k = 0; k < STC_MAX_SLOTS; k++) t.agent[k] = k < n_slots ? (int)agents_host[k] : -2;
+  for (int i = 0; i < STC_MAX_POSES; i++) {
+    t.present[i] = i < n_slots * batch ? present_host[i] : 0;
+    for (int k = 0; k < 12; k++) t.m[i][k] = i < n_slots * batch ? poses_host[i * 12 + k] : 0.f;
+  }
+  pcp_grid_t g;
+  int *cell_count = nullptr, *point_cell = nullptr;
+  if (vox_grid) {
+    if (!vox_workspace || vox_grid->nx <= 0 || vox_grid->ny <= 0 || vox_grid->batch_size <= 0) return PCP_ERR_ARG;
+    const int64_t cells = (int64_t)vox_grid->batch_size * vox_grid->nx * vox_grid->ny;
+    if (cells >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
+    const VoxLayout V = pcp_vox_layout(cells, out_rows > 0 ? out_rows : 1);
+    if (vox_workspace_bytes < V.total) return PCP_ERR_WORKSPACE;
+    g = *vox_grid;
+    cell_count = (int *)((char *)vox_workspace + V.cell_count);
+    point_cell = (int *)((char *)vox_workspace + V.point_cell);
+    if (pcp_zero_async(cell_count, V.cell_rank - V.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+  } else {
+    g = pcp_grid_t{};
+  }
+  char *ws = (char *)workspace;
+  int *tile_cnt = (int *)(ws + L.tile_cnt);
+  int *slot_start_ws = (int *)(ws + L.slot_start);
+  // the grid covers the source rows and the destination (tail fill)
+  const long long span = n > out_rows ? n : out_rows;
+  const int n_tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  const int n_blocks = (int)((span + SCAN_TILE - 1) / SCAN_TILE);
+  if (n_tiles > 0) {
+    hipLaunchKernelGGL(k_stc_count, dim3(n_tiles), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, (int)agent_col, t,
+                       n_tiles, tile_cnt);
+    PCP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_stc_scan, dim3(1), dim3(SCAN_THREADS), 0, stream, tile_cnt, n_tiles * n_slots, n_tiles > 0 ? n_tiles : 1, (int)n_slots,
+                     slot_start_ws, slot_start);
+  PCP_CHECK_LAUNCH();
+  if (n_blocks > 0) {
+    hipLaunchKernelGGL(k_stc_scatter, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, (int)agent_col, t,
+                       n_tiles > 0 ? n_tiles : 1, tile_cnt, slot_start_ws, out, (long long)out_rows, vox_grid ? 1 : 0, g, cell_count,
+                       point_cell);
     PCP_CHECK_LAUNCH();
   }
   return PCP_OK;

@@ -91,6 +91,20 @@ class DynamicPillarVFE(VFETemplate):
         w1, b1 = self.pfn_layers[1].folded()
         return dict(w0=w0.contiguous(), b0=b0.contiguous(), w1=w1.contiguous(), b1=b1.contiguous())
 
+    def release_canvas_rows(self):
+        """zero the persistent canvas rows of the previous (dense) frame NOW: needed when a caller is about to write into the
+        pillariser workspace that still holds that frame's pillar list (BEVMaker's compaction emits cell ids into it)"""
+        if self.reuse_buffers and self._prev_vox is not None and self._canvas is not None:
+            ops.canvas_clear(self._prev_vox, self._canvas)
+        self._prev_vox = None
+
+    def _voxelize(self, points, grid, batch_dict, want_inverse):
+        ready = batch_dict.get('_pcp_vox_ready', None)
+        if ready is not None and not want_inverse:
+            return ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=ready['workspace'], cells_ready=True)
+        return ops.voxelize(points, grid, want_inverse=want_inverse, want_counts=False,
+                            workspace=self._workspace if self.reuse_buffers else None)
+
     def forward(self, batch_dict, **kwargs):
         if self.training:
             return self._forward_train(batch_dict)
@@ -112,7 +126,7 @@ class DynamicPillarVFE(VFETemplate):
                 # workspace pcp_voxelize is about to overwrite -- clear now, or the next dense frame would inherit them
                 ops.canvas_clear(self._prev_vox, self._canvas)
             self._prev_vox = None
-            vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=self._workspace if self.reuse_buffers else None)
+            vox = self._voxelize(points, grid, batch_dict, False)
             rows = max(points.shape[0], 1)
             if self._pf_buf is None or self._pf_buf.shape[0] < rows or self._pf_buf.device != dev or not self.reuse_buffers:
                 self._pf_buf = torch.empty((rows, 64), dtype=torch.float32, device=dev)
@@ -134,8 +148,7 @@ class DynamicPillarVFE(VFETemplate):
             canvas = torch.zeros((batch_size, ny, nx, 64), dtype=torch.float32, device=dev)
         # stream order makes one workspace enough: the clear above has consumed the previous pillar list before
         # pcp_voxelize overwrites it
-        vox = ops.voxelize(points, grid, want_inverse=self.materialize_pillars, want_counts=False,
-                           workspace=self._workspace if self.reuse_buffers else None)
+        vox = self._voxelize(points, grid, batch_dict, self.materialize_pillars)
         pf = None
         if self.materialize_pillars:
             pf = torch.empty((max(points.shape[0], 1), 64), dtype=torch.float32, device=dev)

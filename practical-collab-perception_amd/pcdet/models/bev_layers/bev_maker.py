@@ -31,6 +31,7 @@ class BEVMaker(nn.Module):
         self.maker_type = model_cfg.MAKER_TYPE
         self.only_agents = None            # agent-sharded execution (pcdet/models/sharded.py): encode just these agents on this rank
         self.max_agents_per_pass = 8       # agents stacked into one pass of the frozen chain (1 = the reference's one pass per agent)
+        self._stack_buf = None
         ckpt = model_cfg.get('CKPT', None)
         if ckpt not in (None, '', 'none', 'None'):
             self.load_params_from_file(ckpt, logger or logging.getLogger(), to_cpu=True)
@@ -67,27 +68,32 @@ class BEVMaker(nn.Module):
         self.load_state_dict(own)
         print('[TEACHER] ==> Done (loaded %d/%d)' % (len(update), len(own)))
 
-    def _run_chain(self, points, batch_size, valid_points_hint=None):
+    def _run_chain(self, points, batch_size, vox_ready=None, valid_points_hint=None):
         d = {'points': points, 'batch_size': batch_size}
-        if valid_points_hint is not None:          # rows of other agents are masked out (frame index -1): what the pillariser will keep
+        if vox_ready is not None:                  # the pillariser's first pass already ran inside the compaction (cell ids + histogram)
+            d['_pcp_vox_ready'] = vox_ready
+        if valid_points_hint is not None:          # masked-copy form: rows of other agents carry frame index -1
             d['_pcp_valid_points_hint'] = valid_points_hint
         for m in self.module_list:
             d = m(d)
         return d['spatial_features_2d']
+
+    # False (PCP_BEVMAKER_COMPACT=0): round 2's form, one full masked copy of the cloud per agent; kept for A/B runs and the equality test
+    compact = os.environ.get('PCP_BEVMAKER_COMPACT', '1') != '0'
 
     @torch.no_grad()
     def forward_rsu_car(self, batch_dict):
         self.eval()
         points = batch_dict['points']
         batch_size = batch_dict['batch_size']
-        # which agents have points: one sync, as in the reference (:156), but a presence-mask launch instead of a sort; the rsu and
-        # car makers of one forward see the same (unmodified) points, so the second one reuses the answer
+        # which agents have points, and how many rows each: one sync, as in the reference (:156), but a histogram launch instead of a
+        # sort; the rsu and car makers of one forward see the same (unmodified) points, so the second one reuses the answer
         cached = batch_dict.get('_pcp_agent_ids', None)
         if cached is not None and cached[0] is points:
-            agent_ids = cached[1]
+            agent_ids, agent_rows = cached[1], cached[2]
         else:
-            agent_ids = ops.column_ids(points, -1)
-            batch_dict['_pcp_agent_ids'] = (points, agent_ids)
+            agent_ids, agent_rows = ops.column_id_counts(points, -1)
+            batch_dict['_pcp_agent_ids'] = (points, agent_ids, agent_rows)
         batch_dict['bev_img'] = dict()
         jobs = []
         for agent_idx in agent_ids:
@@ -113,15 +119,36 @@ class BEVMaker(nn.Module):
         # The agents share this maker's frozen chain and frames are independent in it (eval-mode BatchNorm, per-frame pillars and
         # tiles), so their clouds are stacked into ONE pass: agent slot i -> frames [i * B, (i + 1) * B).  Bit-identical per frame to
         # the reference's one pass per agent (:168-190), with 1/len(jobs) of the launches and better-filled small layers.
+        # Round 3: the stacked cloud is the reference's own cat of `points[mask]` selections (a stable compaction, one call for all slots,
+        # rows = what the agents really hold) instead of one full masked copy of the cloud per agent.
         n, c = points.shape
+        use_compact = self.compact and batch_size <= 64
         group = max(1, min(len(jobs), self.max_agents_per_pass))
+        if use_compact:
+            group = max(1, min(group, 8, 64 // batch_size))
         for g0 in range(0, len(jobs), group):
             chunk = jobs[g0:g0 + group]
-            stacked = points.new_empty((len(chunk) * n, c))
-            for slot, (agent_idx, poses, present, _last) in enumerate(chunk):
-                ops.select_transform_points(points, c - 1, float(agent_idx), poses, present, out=stacked[slot * n:(slot + 1) * n],
-                                            batch_offset=slot * batch_size)
-            bev = self._run_chain(stacked, batch_size * len(chunk), valid_points_hint=len(chunk) * n / max(len(agent_ids), 1))
+            if use_compact:
+                rows = sum(int(agent_rows[a]) for a, _p, _q, _l in chunk)
+                vfe_mod = self.module_list[0]
+                grid = ops.make_grid(vfe_mod.point_cloud_range, vfe_mod.voxel_size, vfe_mod.grid_size, batch_size * len(chunk))
+                vfe_mod.release_canvas_rows()          # a dense previous frame: its pillar list is consumed before the workspace is reused
+                ws = ops.voxelize_workspace(grid, max(rows, 1), points.device, vfe_mod._workspace if vfe_mod.reuse_buffers else None)
+                if vfe_mod.reuse_buffers:
+                    vfe_mod._workspace = ws
+                if (self._stack_buf is None or self._stack_buf.shape[0] < max(rows, 1) or self._stack_buf.shape[1] != c
+                        or self._stack_buf.device != points.device or not vfe_mod.reuse_buffers):
+                    self._stack_buf = points.new_empty((max(rows, 1), c))
+                stacked = self._stack_buf[:max(rows, 1)]
+                ops.select_transform_compact(points, c - 1, [a for a, _p, _q, _l in chunk], np.stack([p_ for _a, p_, _q, _l in chunk]),
+                                             np.stack([q for _a, _p, q, _l in chunk]), rows, out=stacked, vox_grid=grid, vox_workspace=ws)
+                bev = self._run_chain(stacked[:rows], batch_size * len(chunk), vox_ready=dict(workspace=ws))
+            else:
+                stacked = points.new_empty((len(chunk) * n, c))
+                for slot, (agent_idx, poses, present, _last) in enumerate(chunk):
+                    ops.select_transform_points(points, c - 1, float(agent_idx), poses, present, out=stacked[slot * n:(slot + 1) * n],
+                                                batch_offset=slot * batch_size)
+                bev = self._run_chain(stacked, batch_size * len(chunk), valid_points_hint=len(chunk) * n / max(len(agent_ids), 1))
             for slot, (agent_idx, _poses, _present, last) in enumerate(chunk):
                 batch_dict['bev_img'][agent_idx] = bev[slot * batch_size:slot * batch_size + last]
         return batch_dict

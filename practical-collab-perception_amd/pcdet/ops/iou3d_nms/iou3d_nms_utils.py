@@ -10,8 +10,20 @@ from pcp_amd import ops
 
 
 def boxes_bev_iou_cpu(boxes_a, boxes_b):
-    raise NotImplementedError('the CPU IoU of the reference (iou3d_cpu.cpp) is not part of the GPU product path; '
-                              'use boxes_iou_bev on CUDA tensors')
+    """reference :12-29 (-> iou3d_cpu.cpp boxes_iou_bev_cpu): CPU tensors or numpy arrays in, the same kind out.  The arithmetic of the
+    reference's CPU file is, operation for operation, that of its CUDA kernel (oracle/nms_oracle.c pins both), so the pairs are evaluated by
+    pcp_boxes_bev_pairwise on the device and copied back; without the device this raises like every other entry of the product."""
+    import numpy as np
+    is_numpy = isinstance(boxes_a, np.ndarray)
+    a = torch.from_numpy(boxes_a).float() if isinstance(boxes_a, np.ndarray) else boxes_a
+    b = torch.from_numpy(boxes_b).float() if isinstance(boxes_b, np.ndarray) else boxes_b
+    assert not (a.is_cuda or b.is_cuda), 'Only support CPU tensors'
+    assert a.shape[1] == 7 and b.shape[1] == 7
+    if not torch.cuda.is_available():
+        from pcp_amd import lib as _lib
+        raise _lib.PcpError('boxes_bev_iou_cpu evaluates the pairs on the HIP device (no CPU fallback exists) and found none')
+    out = ops.boxes_bev_pairwise(a.float().cuda(), b.float().cuda(), 1).cpu()
+    return out.numpy() if is_numpy else out
 
 
 def boxes_iou_bev(boxes_a, boxes_b):
@@ -51,4 +63,10 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
 
 
 def nms_normal_gpu(boxes, scores, thresh, **kwargs):
-    raise NotImplementedError('axis-aligned nms_normal_gpu is not on the PointPillars hot path (SURVEY.md section 2.1)')
+    """reference :102-117 (-> nms_normal_gpu, iou3d_nms.cpp:139-188): score sort + axis-aligned IoU mask + greedy, all on the device"""
+    assert boxes.shape[1] == 7
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes.device), None
+    keep, cnt = ops.nms_normal(boxes.float().contiguous(), scores.float().contiguous(), thresh, n, n)
+    return keep[:int(cnt.item())].long(), None

@@ -123,9 +123,15 @@ SYMBOLS = {
     'pcp_decode_workspace_bytes': (c_sz, [ctypes.POINTER(Decode)]),
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
     'pcp_column_id_mask': (c_i32, [vp, ctypes.c_int64, c_i32, c_i32, vp, vp]),
+    'pcp_column_id_counts': (c_i32, [vp, ctypes.c_int64, c_i32, c_i32, vp, vp]),
+    'pcp_select_transform_compact_workspace_bytes': (c_sz, [c_i64, c_i32]),
+    'pcp_select_transform_compact': (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, ctypes.POINTER(c_f),
+                                             ctypes.POINTER(ctypes.c_uint8), vp, c_i64, vp, c_sz, vp, ctypes.POINTER(Grid), vp, c_sz, vp]),
+    'pcp_voxelize_cells_ready': (c_i32, [vp, c_i64, c_i32, ctypes.POINTER(Grid), vp, c_sz, vp, vp, vp, vp]),
     'pcp_gather_detections': (c_i32, [ctypes.POINTER(DetHead), c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     'pcp_nms_workspace_bytes': (c_sz, [c_i32, c_i32]),
     'pcp_nms_rotated': (c_i32, [vp, vp, c_i32, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
+    'pcp_nms_normal': (c_i32, [vp, vp, c_i32, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
     'pcp_boxes_bev_pairwise': (c_i32, [vp, c_i32, vp, c_i32, c_i32, vp, vp]),
     'pcp_warp_nearest': (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp]),
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),

@@ -73,13 +73,25 @@ class VoxelizeResult:
     __slots__ = ('workspace', 'voxel_coords', 'unq_inv', 'unq_cnt', 'counters', 'n', 'grid', 'row_stride')
 
 
-def voxelize(points, grid, want_inverse=True, want_counts=True, workspace=None):
-    """points: (N, 1+C) float32 CUDA.  Returns VoxelizeResult with max-size outputs; counters = [P, N', 0, 0] on device."""
+def voxelize_workspace(grid, n, device, workspace=None):
+    """a pillariser workspace large enough for (grid, n rows); `workspace` is returned unchanged when it already is"""
+    need = _lib.load().pcp_voxelize_workspace_bytes(ctypes.byref(grid), n)
+    if workspace is None or workspace.numel() < need or workspace.device != device:
+        workspace = torch.empty(need, dtype=torch.uint8, device=device)
+    return workspace
+
+
+def voxelize(points, grid, want_inverse=True, want_counts=True, workspace=None, cells_ready=False):
+    """points: (N, 1+C) float32 CUDA.  Returns VoxelizeResult with max-size outputs; counters = [P, N', 0, 0] on device.
+    cells_ready: `workspace` already holds the rows' cell ids and the per-cell histogram (select_transform_compact with a grid): the
+    pillariser's first pass is skipped (no unq_inv in that mode)."""
     _need_cuda(points)
     L = _lib.load()
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
     n, stride = points.shape
     need = L.pcp_voxelize_workspace_bytes(ctypes.byref(grid), n)
+    if cells_ready:
+        assert workspace is not None and workspace.numel() >= need and not want_inverse
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=points.device)
     res = VoxelizeResult()
@@ -92,6 +104,10 @@ def voxelize(points, grid, want_inverse=True, want_counts=True, workspace=None):
     res.unq_inv = torch.empty((cap,), dtype=torch.int64, device=points.device) if want_inverse else None
     res.unq_cnt = torch.empty((cap,), dtype=torch.int32, device=points.device) if want_counts else None
     res.counters = torch.zeros((4,), dtype=torch.int32, device=points.device)
+    if cells_ready:
+        check(L.pcp_voxelize_cells_ready(_p(points), n, stride, ctypes.byref(grid), _p(workspace), workspace.numel(), _p(res.voxel_coords),
+                                         _p(res.unq_cnt), _p(res.counters), _stream()), 'pcp_voxelize_cells_ready')
+        return res
     check(L.pcp_voxelize(_p(points), n, stride, ctypes.byref(grid), _p(workspace), workspace.numel(), _p(res.voxel_coords),
                          _p(res.unq_inv), _p(res.unq_cnt), _p(res.counters), _stream()), 'pcp_voxelize')
     return res
@@ -344,7 +360,12 @@ def centerhead_decode(head, desc_kwargs):
     return boxes, scores, labels, cell, count
 
 
-def nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=None):
+def nms_normal(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=None):
+    """nms_rotated with the axis-aligned IoU of the reference's nms_normal_gpu (heading ignored); same contract"""
+    return nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=n_dev, workspace=workspace, normal=True)
+
+
+def nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=None, normal=False):
     """boxes (n_max, 7) or (B, n_max, 7) float32; scores matching or None (= already sorted); n_dev (B,) int32 or None.
     Returns (keep (post_max,) | (B, post_max) int32 indices into each frame's input order, count (1,) | (B,) int32)."""
     _need_cuda(boxes, scores, n_dev)
@@ -357,8 +378,9 @@ def nms_rotated(boxes, scores, thresh, pre_max, post_max, n_dev=None, workspace=
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=boxes.device)
     keep, cnt = _zeros_views(boxes.device, [((B, post_max), torch.int32), ((B,), torch.int32)])
-    check(L.pcp_nms_rotated(_p(boxes), _p(scores), B, n_max, _p(n_dev), float(thresh), int(pre_max), int(post_max), _p(workspace),
-                            workspace.numel(), _p(keep), _p(cnt), _stream()), 'pcp_nms_rotated')
+    fn = L.pcp_nms_normal if normal else L.pcp_nms_rotated
+    check(fn(_p(boxes), _p(scores), B, n_max, _p(n_dev), float(thresh), int(pre_max), int(post_max), _p(workspace),
+             workspace.numel(), _p(keep), _p(cnt), _stream()), 'pcp_nms_normal' if normal else 'pcp_nms_rotated')
     return (keep[0], cnt) if single else (keep, cnt)
 
 
@@ -480,6 +502,61 @@ def column_ids(points, col):
         raise _lib.PcpError('column %d holds %d agent ids outside 0..63: the BEV maker supports up to 64 agents' % (col, bad))
     mask &= (1 << 64) - 1
     return np.asarray([i for i in range(64) if (mask >> i) & 1], dtype=np.int64)
+
+
+def column_id_counts(points, col):
+    """column_ids plus the number of rows per id: (ids int64 numpy, {id: rows}); one launch + one 528-byte read-back.  The counts size
+    every per-agent selection of the forward on the host (select_transform_compact)."""
+    import numpy as np
+    _need_cuda(points)
+    L = _lib.load()
+    n, stride = points.shape
+    out = torch.empty((66,), dtype=torch.int64, device=points.device)
+    check(L.pcp_column_id_counts(_p(points), n, stride, col % stride, _p(out), _stream()), 'pcp_column_id_counts')
+    vals = [int(v) for v in out.cpu().tolist()]
+    mask, bad = vals[0] & ((1 << 64) - 1), vals[1]
+    if bad:
+        raise _lib.PcpError('column %d holds %d agent ids outside 0..63: the BEV maker supports up to 64 agents' % (col, bad))
+    ids = [i for i in range(64) if (mask >> i) & 1]
+    return np.asarray(ids, dtype=np.int64), {i: vals[2 + i] for i in ids}
+
+
+_STC_SCRATCH = {}
+
+
+def select_transform_compact(points, agent_col, agents, poses, present, out_rows, out=None, vox_grid=None, vox_workspace=None,
+                             slot_start=None):
+    """Stable compaction of the rows of `agents` (list of ids, <= 8 slots) into one stacked cloud (include/pcp_hip.h:
+    pcp_select_transform_compact).  poses: (slots, B, 12) float32 numpy; present: (slots, B) uint8; out_rows: capacity of `out`
+    (>= the rows that will be kept: the sum of the agents' row counts).  Returns out (out_rows, C): slot s's rows behind slot s-1's,
+    frame index + s * B; rows past the total carry frame index -1.  vox_grid (+ vox_workspace sized for (vox_grid, out_rows)): also emit
+    the pillariser's cell ids / histogram, to be followed by voxelize(..., cells_ready=True)."""
+    import numpy as np
+    _need_cuda(points, out, vox_workspace, slot_start)
+    L = _lib.load()
+    n, stride = points.shape
+    assert points.dtype == torch.float32 and points.is_contiguous()
+    S = len(agents)
+    poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(S, -1, 12)
+    B = poses.shape[1]
+    pres = np.ascontiguousarray(present, dtype=np.uint8).reshape(S, B)
+    ag = np.ascontiguousarray(np.asarray(agents, dtype=np.float32))
+    if out is None:
+        out = torch.empty((max(int(out_rows), 1), stride), dtype=torch.float32, device=points.device)
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[1] == stride and out.shape[0] >= out_rows
+    need = L.pcp_select_transform_compact_workspace_bytes(n, S)
+    key = (points.device, torch.cuda.current_stream(points.device).cuda_stream)      # one scratch per launch stream (overlapped makers)
+    ws = _STC_SCRATCH.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
+        _STC_SCRATCH[key] = ws
+    gref = ctypes.byref(vox_grid) if vox_grid is not None else None
+    check(L.pcp_select_transform_compact(_p(points), n, stride, agent_col % stride, S, ag.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), B,
+                                         poses.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                         pres.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _p(out), int(out_rows), _p(ws), ws.numel(),
+                                         _p(slot_start), gref, _p(vox_workspace), vox_workspace.numel() if vox_workspace is not None else 0,
+                                         _stream()), 'pcp_select_transform_compact')
+    return out
 
 
 def select_transform_points(points, agent_col, agent, poses, present, out=None, batch_offset=0):

@@ -172,6 +172,38 @@ def test_stacked_agent_pass_is_bitwise_the_per_agent_passes():
         assert torch.equal(a['pred_boxes'], b['pred_boxes']) and torch.equal(a['pred_scores'], b['pred_scores'])
 
 
+@pytest.mark.parametrize('pipeline', [False, True])
+def test_compacted_agent_clouds_give_the_bits_of_the_masked_copies(pipeline):
+    """round 3: BEVMaker hands its frozen chain the cat of the agents' `points[mask]` selections (stable compaction + fused cell ids)
+    instead of one masked full copy of the cloud per agent; every agent map, the fused map and the detections keep their bits"""
+    g = load_golden('g1_disco.npz')
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    outs = []
+    for compact in (False, True):
+        model = _build(g)
+        for m in model.modules():
+            if hasattr(m, 'compact'):
+                m.compact = compact
+            if pipeline and hasattr(m, 'reuse_buffers'):
+                m.reuse_buffers = True
+                m.materialize_pillars = False
+        res = []
+        for _rep in range(2):                      # twice: the persistent buffers of the second frame hold the first frame's state
+            batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+            with torch.no_grad():
+                pred_dicts, _ = model(batch)
+            torch.cuda.synchronize()
+            res.append((batch, pred_dicts))
+        outs.append(res)
+    for (b0, p0), (b1, p1) in zip(*outs):
+        assert sorted(b0['bev_img'].keys()) == sorted(b1['bev_img'].keys()) == [0, 2]
+        for aid in (0, 2):
+            assert torch.equal(b0['bev_img'][aid], b1['bev_img'][aid])
+        assert torch.equal(b0['spatial_features_2d'], b1['spatial_features_2d'])
+        for a, b in zip(p0, p1):
+            assert torch.equal(a['pred_boxes'], b['pred_boxes']) and torch.equal(a['pred_scores'], b['pred_scores'])
+
+
 def test_fast_mode_skips_pillar_materialisation_and_matches():
     g = load_golden('g1_ego.npz')
     model = _build(g)

@@ -2,6 +2,8 @@
 Integer / index outputs must be bit exact; floating point within the tolerance written next to each assert
 (north_star: 1e-3 on boxes / scores).  Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -586,7 +588,7 @@ def test_auto_dispatch_falls_back_when_the_fused_f4_kernel_refuses(monkeypatch):
     for attr in ('w', 'b', 'wino', 'w4f'):
         v = getattr(pc, attr)
         setattr(pc, attr, tuple(t.to(d) if torch.is_tensor(t) else t for t in v) if isinstance(v, tuple) else v.to(d))
-    x = torch.from_numpy(_rand(281, (32, 64, 64, 72))).to(d)                      # 32 x 4 x 2 = 256 workgroups: auto picks the fused kernel
+    x = torch.from_numpy(_rand(281, (8, 128, 128, 72))).to(d)                     # 8 x 8 x 4 = 256 workgroups: auto picks the fused kernel
     assert pc._use_winograd4f(x, None, 0, 4)
     want = pc.run(x, in_ch_off=4)                                                  # fused F(4x4)
     monkeypatch.setattr(convnet, 'WINOGRAD4F_MAX_INPUT_BYTES', 1 << 20)
@@ -649,6 +651,78 @@ def test_conv3x3_winograd4_channel_windows_and_bad_arguments():
         ops.conv3x3_winograd4(x, packed.to(d), bp.to(d), 100, cout, cpad, relu=False, out=out)
     with pytest.raises(RuntimeError):       # window offset that breaks 16-byte alignment
         ops.conv3x3_winograd4(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
+
+
+def _random_boxes(n, seed, spread=12.0):
+    rng = np.random.default_rng(seed)
+    b = np.zeros((n, 7), np.float32)
+    b[:, 0:2] = rng.uniform(-spread, spread, (n, 2))
+    b[:, 2] = rng.uniform(-1, 1, n)
+    b[:, 3:6] = rng.uniform(0.8, 5.0, (n, 3))
+    b[:, 6] = rng.uniform(-3.14, 3.14, n)
+    return b, rng.uniform(0.0, 1.0, n).astype(np.float32)
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 64, 65, 700, 4096])
+def test_nms_normal_gpu_matches_oracle(n):
+    """iou3d_nms_utils.nms_normal_gpu (reference :102-117, nms_normal_kernel iou3d_nms_kernel.cu:314-372: axis-aligned IoU, heading
+    ignored) against the oracle's float32 restatement: the keep list is bit exact"""
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    boxes, scores = _random_boxes(n, 900 + n)
+    keep, _ = U.nms_normal_gpu(torch.from_numpy(boxes).to(dev()), torch.from_numpy(scores).to(dev()), 0.25)
+    want = onms.nms_normal_gpu(boxes, scores, 0.25) if n else np.zeros(0, np.int64)
+    assert keep.dtype == torch.int64 and keep.cpu().numpy().tolist() == want.tolist()
+    if n >= 63:
+        assert 0 < want.shape[0] < n                                                  # the threshold bites
+
+
+def test_boxes_bev_iou_cpu_takes_cpu_tensors_and_numpy():
+    """iou3d_nms_utils.boxes_bev_iou_cpu (reference :12-29): CPU tensors / numpy in, the same kind out, values = the C oracle's (which is
+    pinned bit for bit on the reference's own iou3d_cpu.cpp, tests/test_oracle_pins.py)"""
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils as U
+    a, _ = _random_boxes(37, 5, spread=4.0)
+    b, _ = _random_boxes(91, 6, spread=4.0)
+    want = onms.iou_matrix(a, b)
+    got_t = U.boxes_bev_iou_cpu(torch.from_numpy(a), torch.from_numpy(b))
+    got_n = U.boxes_bev_iou_cpu(a, b)
+    assert isinstance(got_t, torch.Tensor) and not got_t.is_cuda and isinstance(got_n, np.ndarray)
+    np.testing.assert_allclose(got_t.numpy(), want, rtol=0, atol=2e-6)               # sinf / cosf / atan2f ulps (ocml vs glibc)
+    assert np.array_equal(got_n, got_t.numpy())
+    with pytest.raises(AssertionError):
+        U.boxes_bev_iou_cpu(torch.from_numpy(a).to(dev()), torch.from_numpy(b))      # 'Only support CPU tensors', as the reference
+
+
+def test_integration_b1_stub_runs_verbatim():
+    """INTEGRATION.md B1 shows the ctypes module a maintainer drops in as pcdet/ops/iou3d_nms/iou3d_nms_cuda.py.  This test executes
+    that block as written (only the library path is pointed at the in-tree build) under the REFERENCE's calling convention
+    (iou3d_nms_utils.py:84-117: boxes sorted by the caller, `keep` a LongTensor on the CPU, the count returned) and checks the results
+    against the oracle"""
+    import re
+    import types
+    from pcp_amd import lib
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'INTEGRATION.md')).read()
+    sec = text[text.index('### B1.'):]
+    block = re.search(r'```python\n(.*?)```', sec, re.S).group(1)
+    assert 'ctypes.CDLL("libpcp_hip.so")' in block
+    mod = types.ModuleType('iou3d_nms_cuda')
+    exec(compile(block.replace('ctypes.CDLL("libpcp_hip.so")', 'ctypes.CDLL(%r)' % lib.LIB_PATH), 'INTEGRATION.md#B1', 'exec'), mod.__dict__)
+    boxes, scores = _random_boxes(500, 77)
+    order = np.argsort(-scores, kind='stable')
+    sb = torch.from_numpy(boxes[order]).to(dev()).contiguous()
+    for fn, oracle_keep in ((mod.nms_gpu, onms.nms_sorted(boxes[order], 0.2)),
+                            (mod.nms_normal_gpu, onms.nms_from_iou(onms.iou_normal_matrix(boxes[order], boxes[order]), 0.2))):
+        keep = torch.LongTensor(sb.size(0))
+        num_out = fn(sb, keep, 0.2)
+        assert not keep.is_cuda and num_out == oracle_keep.shape[0] and keep[:num_out].numpy().tolist() == oracle_keep.tolist()
+    a, b = torch.from_numpy(boxes[:40]).to(dev()), torch.from_numpy(boxes[40:140]).to(dev())
+    for fn, want in ((mod.boxes_iou_bev_gpu, onms.iou_matrix(boxes[:40], boxes[40:140])),
+                     (mod.boxes_overlap_bev_gpu, onms.overlap_matrix(boxes[:40], boxes[40:140]))):
+        out = torch.cuda.FloatTensor(torch.Size((40, 100))).zero_()
+        fn(a.contiguous(), b.contiguous(), out)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-5)
+    out = torch.zeros((40, 100))
+    mod.boxes_iou_bev_cpu(torch.from_numpy(boxes[:40]), torch.from_numpy(boxes[40:140]), out)
+    np.testing.assert_allclose(out.numpy(), onms.iou_matrix(boxes[:40], boxes[40:140]), rtol=0, atol=2e-6)
 
 
 def test_column_ids_equals_torch_unique():
@@ -946,6 +1020,110 @@ def test_select_transform_points_bit_equal_to_the_reference():
         assert rows.shape[0] == int(g['car_agent_%d_rows' % a]) == 60000
         assert np.array_equal(rows[:8, 1:4], g['car_agent_%d_xyz_head' % a])
         assert hashlib.sha256(np.ascontiguousarray(rows[:, 1:4]).tobytes()).hexdigest() == str(g['car_agent_%d_xyz_sha' % a])
+
+
+def _compact_case(n, stride=7, batch=3, agents_in_cloud=(0, 1, 2, 4, 5), seed=11):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand((n, stride), generator=g) * 80.0 - 40.0)
+    if n:
+        pts[:, 0] = torch.randint(0, batch, (n,), generator=g).float()
+        pts[:, -1] = torch.tensor(agents_in_cloud)[torch.randint(0, len(agents_in_cloud), (n,), generator=g)].float()
+    return pts
+
+
+@pytest.mark.parametrize('n', [0, 1, 1000, 1024, 5000, 262144 + 77])
+def test_select_transform_compact_is_the_cat_of_the_masked_selections(n):
+    """pcp_select_transform_compact against the round-2 kernel it replaces (pcp_select_transform_points, itself bit-equal to the
+    reference's `points[mask] @ R^T + t`): slot s's segment == the kept rows of the per-agent masked copy, same order, same bits; the tail
+    carries frame index -1; slot_start / total are the exact counts; an agent absent from a frame loses that frame's rows (bev_maker.py:172-179);
+    the row counts of pcp_column_id_counts equal torch's"""
+    ops = _ops()
+    d = dev()
+    batch = 3
+    pts = _compact_case(n, batch=batch)
+    agents = [0, 2, 4, 5, 3]                                               # 3 has no rows; 1 (the ego) is not selected
+    rng = np.random.default_rng(5)
+    poses = rng.standard_normal((len(agents), batch, 12)).astype(np.float32)
+    present = np.ones((len(agents), batch), np.uint8)
+    present[1, 2] = 0                                                      # agent 2 absent from frame 2
+    present[3, 0] = 0
+    dp = pts.to(d)
+    ids, rows = ops.column_id_counts(dp, -1)
+    want_ids = torch.unique(pts[:, -1].long()).tolist() if n else []
+    assert ids.tolist() == want_ids
+    for a in want_ids:
+        assert rows[a] == int((pts[:, -1].long() == a).sum())
+    cap = sum(rows.get(a, 0) for a in agents)
+    slot_start = torch.full((len(agents) + 1,), -7, dtype=torch.int32, device=d)
+    out = ops.select_transform_compact(dp, -1, agents, poses, present, cap, slot_start=slot_start)
+    torch.cuda.synchronize()
+    out = out[:cap].cpu().numpy()
+    starts = slot_start.cpu().numpy()
+    off = 0
+    for s, a in enumerate(agents):
+        ref = ops.select_transform_points(dp, -1, float(a), poses[s], present[s], batch_offset=s * batch).cpu().numpy() if n else np.zeros((0, 7), np.float32)
+        ref = ref[ref[:, 0] >= 0]
+        assert starts[s] == off
+        assert np.array_equal(out[off:off + ref.shape[0]], ref), (s, a)
+        off += ref.shape[0]
+    assert starts[-1] == off <= cap
+    assert np.all(out[off:, 0] == -1.0) and np.all(out[off:, 1:] == 0.0)
+
+
+def test_select_transform_compact_rejects_bad_arguments():
+    from pcp_amd import lib
+    ops = _ops()
+    d = dev()
+    pts = _compact_case(100).to(d)
+    with pytest.raises(lib.PcpError):                                      # more than 8 slots
+        ops.select_transform_compact(pts, -1, list(range(9)), np.zeros((9, 3, 12), np.float32), np.ones((9, 3), np.uint8), 100)
+    with pytest.raises(lib.PcpError):                                      # pose table beyond the kernel-argument budget (slots x frames > 64)
+        ops.select_transform_compact(pts, -1, list(range(8)), np.zeros((8, 9, 12), np.float32), np.ones((8, 9), np.uint8), 100)
+
+
+@pytest.mark.parametrize('n', [3000, 200000])
+def test_voxelize_cells_ready_equals_the_full_pillariser(n):
+    """the compaction emits the cell id + histogram of every row it writes; pcp_voxelize_cells_ready (the pillariser minus its first pass)
+    must then leave the same pillar list as pcp_voxelize on the compacted cloud: voxel_coords, counters, and the per-pillar features the PFN
+    computes from the buckets (order inside a bucket is free: means are fixed point, maxima commute), bit for bit"""
+    ops = _ops()
+    d = dev()
+    batch = 2
+    pts = _compact_case(n, batch=batch, seed=23)
+    pts[:, 1:3] = pts[:, 1:3] * 0.2                                       # inside an 80 x 80 cell grid around the origin (+ some rows outside)
+    agents = [0, 2, 5]
+    rng = np.random.default_rng(9)
+    poses = np.zeros((len(agents), batch, 12), np.float32)
+    for s in range(len(agents)):
+        for b in range(batch):
+            yaw = rng.uniform(-1, 1)
+            R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]], np.float32)
+            poses[s, b] = np.concatenate([R, rng.uniform(-3, 3, (3, 1)).astype(np.float32)], 1).reshape(-1)
+    present = np.ones((len(agents), batch), np.uint8)
+    dp = pts.to(d)
+    _ids, rows = ops.column_id_counts(dp, -1)
+    cap = sum(rows[a] for a in agents)
+    grid = ops.make_grid([-8.0, -8.0, -3.0, 8.0, 8.0, 1.0], [0.2, 0.2, 4.0], [80, 80, 1], batch * len(agents))
+    ws = ops.voxelize_workspace(grid, cap, d)
+    out = ops.select_transform_compact(dp, -1, agents, poses, present, cap, vox_grid=grid, vox_workspace=ws)
+    fast = ops.voxelize(out[:cap], grid, want_inverse=False, want_counts=True, workspace=ws, cells_ready=True)
+    full = ops.voxelize(out[:cap].clone(), grid, want_inverse=False, want_counts=True)
+    torch.cuda.synchronize()
+    cf, cu = fast.counters.cpu().numpy(), full.counters.cpu().numpy()
+    assert np.array_equal(cf, cu) and cf[0] > 0
+    P = int(cf[0])
+    assert torch.equal(fast.voxel_coords[:P], full.voxel_coords[:P]) and torch.equal(fast.unq_cnt[:P], full.unq_cnt[:P])
+    w0 = torch.from_numpy(_rand(31, (32, 11), -0.3, 0.3)).to(d)
+    b0 = torch.from_numpy(_rand(32, (32,), -0.1, 0.1)).to(d)
+    w1 = torch.from_numpy(_rand(33, (64, 64), -0.2, 0.2)).to(d)
+    b1 = torch.from_numpy(_rand(34, (64,), -0.1, 0.1)).to(d)
+    pf = []
+    for vox in (fast, full):
+        f = torch.zeros((cap, 64), device=d)
+        ops.pfn_scatter(out[:cap], vox, 5, w0, b0, w1, b1, canvas=None, pillar_features=f)
+        pf.append(f[:P])
+    torch.cuda.synchronize()
+    assert torch.equal(pf[0], pf[1])
 
 
 def test_modar_ingest_batched_equals_the_per_pair_ingestion():
