@@ -54,7 +54,7 @@ constexpr int F4_V_FLOATS = 36 * 32 * F4_VLD;             // 13824: V[pos][tile]
 constexpr int F4_MAIN_FLOATS = 2 * F4_RAW_FLOATS + 2 * F4_V_FLOATS;
 constexpr int F4_MS_LD = 32;
 constexpr int F4_MS_FLOATS = 36 * 32 * F4_MS_LD;          // 36864 floats = 147 KB: M[pos][tile][32 channels]
-constexpr int F4_LDS_FLOATS = F4_MS_FLOATS > F4_MAIN_FLOATS ? F4_MS_FLOATS : F4_MAIN_FLOATS;
+constexpr int F4_LDS_FLOATS = (F4_MS_FLOATS > F4_MAIN_FLOATS ? F4_MS_FLOATS : F4_MAIN_FLOATS) + 4;   // + the half-1 barrier counter of the epilogue
 constexpr int F4_RAW_ITEMS = F4_RAW_PIX * 2;              // float4 items per slice
 constexpr int F4_RAW_PER = (F4_RAW_ITEMS + F4_THREADS - 1) / F4_THREADS;
 constexpr int F4_WBN = 64;
@@ -362,12 +362,14 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
       }
     }
   };
-  auto finish = [&](int half) {
+  // The output transform in two steps with the barrier BETWEEN them: stage 1 pulls the unit's 36 M values out of the LDS (first A^T pass on
+  // the fly: 24 f32x4 stay in registers); after it the LDS is free for the other half's dump while this half computes and stores.
+  f32x4 u[4][6];                                     // u[a][j] = sum_i AT[a][i] M[i][j]
+  auto finish_read = [&]() {
 #ifdef F4_DIAG_NO_FINISH
     return;                                            // timing-only build
 #endif
     const float *src = ms + e_tt * F4_MS_LD + 4 * e_q;
-    f32x4 u[4][6];                                   // u[a][j] = sum_i AT[a][i] M[i][j]
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       f32x4 m[6];
@@ -381,6 +383,11 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
         asm volatile("" : "+v"(u[a][j]));            // materialise here: one column at a time (the compiler otherwise hoists all 36
       }                                              // 16-byte reads -- 144 registers -- above the arithmetic and spills)
     }
+  };
+  auto finish_store = [&](int half) {
+#ifdef F4_DIAG_NO_FINISH
+    return;                                            // timing-only build
+#endif
     F4_STAMP_AT(6 + half * 2);
     const int n = n0 + half * 32 + 4 * e_q;
     if (n < p.cout) {
@@ -420,29 +427,61 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
       }
     }
   };
+  // A barrier of the four waves of channel half 1 only (the hardware barrier counts all eight waves): a counter in the LDS words the M
+  // image leaves free, polled with s_sleep.  Lets half 1 go from its dump to its reads without waiting for half 0 to finish issuing stores.
+  auto half1_barrier = [&]() {
+    volatile int *cnt = reinterpret_cast<volatile int *>(lds + F4_MS_FLOATS);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(const_cast<int *>(cnt), 1);
+    while (*cnt < 4) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
   // two explicit paths with matching barrier counts: on each path the accumulators are dead once dumped (a loop over the halves would
-  // keep them live through the other half's transform and spill)
+  // keep them live through the other half's transform and spill).
+  //   half 0: dump | B1 | read M            | B2 | compute + stores
+  //   half 1:      | B1 | (zero the counter) | B2 | dump | half-1 barrier | read M, compute + stores
+  // so half 1's dump and reads run under half 0's store tail (the stores of a workgroup leave at ~10 B/clk: 2 x 6 600 cycles)
+#ifdef F4_EPI_SERIAL
+  if (cb == 0) {
+    dump();
+    __syncthreads();
+    finish_read();
+    finish_store(0);
+    __syncthreads();
+    __syncthreads();
+  } else {
+    __syncthreads();
+    __syncthreads();
+    dump();
+    __syncthreads();
+    finish_read();
+    finish_store(1);
+  }
+#else
   if (cb == 0) {
     dump();
     F4_STAMP_AT(2);
     __syncthreads();
     F4_STAMP_AT(3);
-    finish(0);
+    finish_read();
     F4_STAMP_AT(4);
     __syncthreads();
-    __syncthreads();
+    finish_store(0);
     F4_STAMP_AT(5);
   } else {
     __syncthreads();
+    if (tid == 256) lds[F4_MS_FLOATS] = 0.f;           // the counter word (bit pattern 0), ordered before its use by B2
     __syncthreads();
     F4_STAMP_AT(2);
     dump();
     F4_STAMP_AT(3);
-    __syncthreads();
+    half1_barrier();
     F4_STAMP_AT(4);
-    finish(1);
+    finish_read();
+    finish_store(1);
     F4_STAMP_AT(5);
   }
+#endif
 }
 
 int f4_geom(const pcp_conv3x3_t *d, F4Params *p) {
