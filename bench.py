@@ -68,6 +68,9 @@ def parse_args(argv=None):
                     'materialised (one host sync per VFE), dense canvas, no buffer reuse')
     ap.add_argument('--no-overlap', action='store_true', help='run the BEV-maker passes of a DiscoNet forward one after the other on the '
                                                                 'main stream (the pipeline mode overlaps them on side streams)')
+    ap.add_argument('--elide-dead-makers', action='store_true', help='DiscoNet inference: skip the BEV-maker passes whose output nothing reads '
+                    '(reference quirk F3: the rsu map is overwritten by the car maker, bev_img_early feeds only the training loss); pred_dicts are '
+                    'bit-identical; reported under its own metric name, never the headline')
     ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
     ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'bf16x3', 'bf16'],
@@ -365,18 +368,42 @@ class AbiTimer:
         return out
 
 
+PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
+
+
 def pmc_traffic(config, kernel_label):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command (separate FETCH_SIZE and
-    WRITE_SIZE runs, --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streaming reads) -- profiles/
-    r02_pmc_traffic.json, written by tools/pmc_summary.py."""
-    path = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
-    if not os.path.isfile(path):
-        return None
-    with open(path) as f:
+    WRITE_SIZE runs, --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streaming reads), written by
+    tools/pmc_summary.py together with the SHA-256 of the kernel's source file.  A kernel edited after its PMC pass gets `traffic` null and a
+    note instead of stale bytes.  Returns (bytes_per_launch | None, note | None)."""
+    import hashlib
+    if not os.path.isfile(PMC_TRAFFIC_JSON):
+        return None, 'no PMC pass committed for this round'
+    with open(PMC_TRAFFIC_JSON) as f:
         d = json.load(f).get(config, {})
     short = kernel_label.split(' ')[0]
     e = d.get(short)
-    return None if e is None else e['bytes_per_launch']
+    if e is None:
+        return None, 'no PMC entry for %s / %s' % (config, short)
+    src = e.get('source')
+    path = os.path.join(PKG, 'csrc', src) if src else None
+    if not path or not os.path.isfile(path) or not e.get('source_sha256'):
+        return None, 'PMC entry carries no source hash'
+    with open(path, 'rb') as f:
+        if hashlib.sha256(f.read()).hexdigest() != e['source_sha256']:
+            return None, 'stale: csrc/%s changed after the PMC pass in %s' % (src, os.path.basename(PMC_TRAFFIC_JSON))
+    return e['bytes_per_launch'], None
+
+
+def hip_current_device():
+    """the device the HIP runtime of THIS process launches on (what every C-ABI call of libpcp_hip.so uses), asked of the runtime itself"""
+    import ctypes
+    import torch
+    rt = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    d = ctypes.c_int(-1)
+    if rt.hipGetDevice(ctypes.byref(d)) != 0:
+        return -1
+    return int(d.value)
 
 
 def dry_run(args, world, rank):
@@ -471,6 +498,10 @@ def main(argv=None):
     if not args.plugin_default and not args.no_overlap and not args.graph and hasattr(model, 'overlap_makers') \
             and any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
         overlapped = model.overlap_makers = True                 # frozen BEV-maker passes on their own HIP streams, joined in front of the fusion module
+    if args.elide_dead_makers:
+        if args.train or not hasattr(model, 'elide_dead_makers'):
+            raise SystemExit('--elide-dead-makers: DiscoNet inference only')
+        model.elide_dead_makers = True
     if not args.plugin_default:
         for m in model.modules():
             if hasattr(m, 'materialize_pillars'):
@@ -598,10 +629,20 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms, rank_devices = [round(1e3 * elapsed / args.steps, 4)], [hip_current_device()]
     if world > 1:
+        # every rank's own time and the device its HIP runtime launches on (a straggler or two ranks on one device must be visible in the
+        # line); `value` uses the MAX over ranks, as the contract says
+        info = torch.tensor([elapsed, float(hip_current_device())], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        gathered = [torch.zeros_like(info) for _ in range(world)]
+        dist.all_gather(gathered, info)
+        per_rank_ms = [round(1e3 * float(g[0]) / args.steps, 4) for g in gathered]
+        rank_devices = [int(g[1]) for g in gathered]
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if backend == 'nccl' and sorted(rank_devices) != list(range(world)):
+            raise SystemExit('bench.py: ranks do not sit on distinct devices: %s' % rank_devices)
     n_boxes = int(sum(p['pred_boxes'].shape[0] for p in preds))
 
     # instrumented pass (HIP events around every C-ABI launch).  Training and agent-sharded steps contain collectives, so in those modes
@@ -633,7 +674,8 @@ def main(argv=None):
         else:
             roof = {'bound': 'hbm' if dom['bound'] == 'hbm' else 'latency', 'kernel': dom['kernel'], 'achieved': None, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': None}
-        roof.update({'traffic': pmc_traffic(args.config, dom['kernel']) if (algo == 'auto' and not args.train) else None,
+        traffic, traffic_note = pmc_traffic(args.config, dom['kernel']) if (algo == 'auto' and not args.train) else (None, 'not collected for this mode')
+        roof.update({'traffic': traffic, **({'traffic_note': traffic_note} if traffic_note else {}),
                      'avg_launch_us': round(1e3 * dom['ms'] / max(dom['launches'], 1), 2),
                      'launches_per_step': round(dom['launches_per_step'], 2),
                      'share_of_kernel_time': round(dom['ms'] / max(sum(f['ms'] for f in fams), 1e-9), 4)})
@@ -642,7 +684,8 @@ def main(argv=None):
                                     'algorithmic_tflops': round(sum(f['alg_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
                                     'ms_per_step': round(sum(f['ms_per_step'] for f in mf), 3)}
         line = {
-            'metric': 'frames/sec (60k-pt cloud, 6 agents)' if conf['agents_in_cloud'] == 6 else 'frames/sec (60k-pt cloud, 1 agent)',
+            'metric': ('frames/sec (60k-pt cloud, 6 agents)' if conf['agents_in_cloud'] == 6 else 'frames/sec (60k-pt cloud, 1 agent)') +
+                      (' [dead BEV-maker passes elided: NOT the headline]' if args.elide_dead_makers else ''),
             'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
@@ -660,6 +703,7 @@ def main(argv=None):
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
                        'ranks_seen_by_collective': ranks_seen, 'backend': backend if world > 1 else None,
+                       'per_rank_ms_per_step': per_rank_ms, 'rank_devices': rank_devices,
                        'mode': ('plugin default (per-pillar API tensors materialised: one host sync per VFE; dense canvas)' if args.plugin_default else
                                 'pipeline: no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
                                 ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
@@ -668,6 +712,7 @@ def main(argv=None):
                                  '(kernel_ms_per_step and roofline come from an extra single-stream pass)' if overlapped else '') +
                                 '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*, test_overlapped_makers_*)'),
                        'peak_device_memory_mb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
+                       **({'elided': 'rsu BEV maker (overwritten by the car maker) and early BEV maker (training-only output): reference quirk F3'} if args.elide_dead_makers else {}),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': roof,
             'kernel_ms_per_step': {f['kernel'].split(' ')[0]: round(f['ms_per_step'], 4) for f in fams[:14]},

@@ -231,6 +231,8 @@ typedef struct {
   float limit[6];                 /* POST_CENTER_LIMIT_RANGE (inclusive both ends) */
   int32_t use_score_thresh;       /* SCORE_THRESH is not None */
   float score_thresh;             /* strict > */
+  int32_t activated;              /* 0: hm holds logits and dim log-sizes (the head's raw maps); 1: hm holds sigmoid scores and dim exp'ed
+                                   * sizes -- the call convention of centernet_utils.decode_bbox_from_heatmap (center_head.py:312-333) */
 } pcp_decode_t;
 
 size_t pcp_decode_workspace_bytes(const pcp_decode_t *desc);
@@ -292,6 +294,15 @@ int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t w, int32_t
  * column per agent; out[p, :] = sum_a softmax_a(weights[p, :])[a] * maps[a][p, :] */
 int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const float *weights, int32_t ld_w, int64_t pixels,
                      int32_t c, int32_t ld_map, int32_t ld_out, float *out, void *stream);
+/* a12 (round 3): pixel weightor + softmax over the maps + weighted sum in ONE launch (v2x_fusion_disco.py:8-26,85,104,107-115).
+ * maps_host: host array of n_maps device pointers (map 0 = the compressed ego map, the others the warped agent maps), each (pixels, ld_map)
+ * with c = 128 channels.  For every map a: l_a = relu(w3 . relu(w2 . relu(w1 . [map_0 | map_a] + b1) + b2) + b3) with BatchNorm folded
+ * by the host (w1 (64, 2c) row-major, w2 (16, 64), w3 (16), b3 (1)); out[p] = sum_a softmax_a(l)[p] * map_a[p]  (pixels, ld_out).
+ * logits (optional, (pixels, ld_w)): the pre-softmax weights l_a.  n_maps <= 16; c != 128 -> PCP_ERR_UNSUPPORTED. */
+int pcp_disco_weight_fuse(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
+                          const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                          float *out, int32_t ld_out, float *logits, int32_t ld_w, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a14  HunterJr point <-> BEV ops.

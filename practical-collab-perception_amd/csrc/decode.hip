@@ -79,7 +79,8 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecParams p) {
     if (idx < total) {
       int cls = idx / HW, cellid = idx % HW;
       float hm = hb[(long long)cellid * d.ld + d.ch_hm + cls];
-      float s = 1.0f / (1.0f + expf(-hm));
+      // activated = 1: the caller already applied sigmoid (centernet_utils.decode_bbox_from_heatmap's convention): the value IS the score
+      float s = d.activated ? fminf(fmaxf(hm, 0.0f), 1.0f) : 1.0f / (1.0f + expf(-hm));
       key[i] = __float_as_uint(s) + 1u;        // s in [0,1]: bits are monotone; +1 keeps 0 for "absent"
     }
   }
@@ -190,9 +191,9 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecParams p) {
     box[0] = xs * d.stride * d.voxel_x + d.min_x;
     box[1] = ys * d.stride * d.voxel_y + d.min_y;
     box[2] = px[d.ch_z];
-    box[3] = expf(px[d.ch_dim]);
-    box[4] = expf(px[d.ch_dim + 1]);
-    box[5] = expf(px[d.ch_dim + 2]);
+    box[3] = d.activated ? px[d.ch_dim] : expf(px[d.ch_dim]);
+    box[4] = d.activated ? px[d.ch_dim + 1] : expf(px[d.ch_dim + 1]);
+    box[5] = d.activated ? px[d.ch_dim + 2] : expf(px[d.ch_dim + 2]);
     box[6] = atan2f(px[d.ch_rot + 1], px[d.ch_rot]);
     ok = box[0] >= d.limit[0] && box[1] >= d.limit[1] && box[2] >= d.limit[2] && box[0] <= d.limit[3] &&
          box[1] <= d.limit[4] && box[2] <= d.limit[5];

@@ -114,3 +114,178 @@ extern "C" int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents,
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
+
+
+// ---- a12 (round 3): the whole pixel weightor + softmax over agents + weighted sum in ONE launch -----------------------------------------
+// Reference: pcdet/models/bev_layers/v2x_fusion_disco.py:8-26 (PixelWeightedFusionSoftmax: Conv1x1 2C -> 64 + BN + ReLU, Conv1x1 64 -> 16 +
+// BN + ReLU, Conv1x1 16 -> 1 + ReLU on cat[ego, map_a]) applied once per map (:85,:104) and :107-115 (softmax over the maps, weighted sum).
+// Round 2 ran it as 3 pointwise launches per map + k_softmax_fuse: 19 launches and two (pixels, 64) / (pixels, 16) round trips per map.
+// Here a workgroup owns 64 pixels: the ego half of the first layer (W1[:, :C] . ego) is computed ONCE per tile and reused for every map
+// (7 instead of 12 K = 128 products for six maps), the map half runs on the matrix pipe with the W1 fragments resident in registers, the
+// two small layers and the softmax stay on the VALU through LDS, and the weighted sum re-reads the map rows (L2-hot) exactly as
+// k_softmax_fuse does (same operation order: acc += m * s, a = 0 .. n-1).
+namespace {
+
+constexpr int WF_PX = 64;
+constexpr int WF_C = 128;            // compressed channels (COMPRESSED_CHANNELS of the shipped YAML)
+constexpr int WF_H1 = 64, WF_H2 = 16;
+constexpr int WF_H1_LD = 68;         // padded h1 row: conflict-free ds_read_b128 groups
+
+struct WfParams {
+  MapPtrs maps;
+  int n_maps, ld_map, ld_out, ld_w;
+  long long pixels;
+  const float *w1, *b1, *w2, *b2, *w3, *b3;     // BN folded: w1 (64, 2C) row-major, w2 (16, 64), w3 (16)
+  float *out, *logits;                          // logits: optional (pixels, ld_w) copy of the pre-softmax weights
+};
+
+}  // namespace
+
+#pragma clang fp contract(on)
+namespace {
+__device__ __forceinline__ f32x16 wf_mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+}
+
+namespace {
+
+__global__ __launch_bounds__(256, 2) void k_weight_fuse(WfParams p) {
+  __shared__ __attribute__((aligned(16))) float h1[WF_PX * WF_H1_LD];
+  __shared__ float h2[WF_PX][WF_H2 + 1];
+  __shared__ float lg[MAX_AGENTS][WF_PX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 1, ct = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  // W1 fragments of this wave's 32 hidden channels, k permuted as the 16-byte A loads deliver it: MFMA (j, i) multiplies k = 8j + 4h + i
+  // (the map half stays in registers for every map of every tile; the ego half is used once per tile and re-read from L1 / L2)
+  f32x4 wb[16];
+  const float *w1_row = p.w1 + (long long)(ct * 32 + r) * (2 * WF_C) + 4 * h;
+#pragma unroll
+  for (int j = 0; j < 16; j++) wb[j] = *reinterpret_cast<const f32x4 *>(w1_row + WF_C + 8 * j);
+  const float bias1 = p.b1[ct * 32 + r];
+  const long long n_tiles = (p.pixels + WF_PX - 1) / WF_PX;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long px0 = tile * WF_PX;
+    long long prow = px0 + rt * 32 + r;                       // the pixel whose row this lane feeds into the matrix pipe
+    if (prow >= p.pixels) prow = p.pixels - 1;                // clamped: rows past the end are computed and never stored
+    f32x16 acc_e;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc_e[e] = 0.f;
+    {
+      const float *src = p.maps.p[0] + prow * p.ld_map + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(src + 8 * j);
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(w1_row + 8 * j);
+        acc_e = wf_mfma(a.x, w.x, acc_e);
+        acc_e = wf_mfma(a.y, w.y, acc_e);
+        acc_e = wf_mfma(a.z, w.z, acc_e);
+        acc_e = wf_mfma(a.w, w.w, acc_e);
+      }
+    }
+    for (int a_i = 0; a_i < p.n_maps; a_i++) {
+      f32x16 acc = acc_e;
+      const float *src = p.maps.p[a_i] + prow * p.ld_map + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(src + 8 * j);
+        acc = wf_mfma(a.x, wb[j].x, acc);
+        acc = wf_mfma(a.y, wb[j].y, acc);
+        acc = wf_mfma(a.z, wb[j].z, acc);
+        acc = wf_mfma(a.w, wb[j].w, acc);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        h1[row * WF_H1_LD + ct * 32 + r] = fmaxf(acc[e] + bias1, 0.f);
+      }
+      __syncthreads();
+      {   // layer 2 (64 -> 16): thread = (pixel, 4 outputs); the wave's four W2 rows are wave-uniform (scalar loads)
+        const int px = lane, og = wave;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = p.b2[og * 4 + i];
+        const float *xr = &h1[px * WF_H1_LD];
+#pragma unroll
+        for (int k4 = 0; k4 < WF_H1 / 4; k4++) {
+          const f32x4 x = *reinterpret_cast<const f32x4 *>(xr + 4 * k4);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float *wr = p.w2 + (og * 4 + i) * WF_H1 + 4 * k4;
+            o[i] = fmaf(wr[0], x.x, o[i]);
+            o[i] = fmaf(wr[1], x.y, o[i]);
+            o[i] = fmaf(wr[2], x.z, o[i]);
+            o[i] = fmaf(wr[3], x.w, o[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) h2[px][og * 4 + i] = fmaxf(o[i], 0.f);
+      }
+      __syncthreads();
+      if (tid < WF_PX) {   // layer 3 (16 -> 1) + ReLU
+        float l = p.b3[0];
+#pragma unroll
+        for (int k = 0; k < WF_H2; k++) l = fmaf(p.w3[k], h2[tid][k], l);
+        l = fmaxf(l, 0.f);
+        lg[a_i][tid] = l;
+        if (p.logits && px0 + tid < p.pixels) p.logits[(px0 + tid) * p.ld_w + a_i] = l;
+      }
+      // the next map's h1 stores come after its 64 MFMAs and are ordered behind this map's layer-2 reads by the barrier above; its h2
+      // stores are ordered behind this layer-3 read by the barrier that follows its h1 stores
+    }
+    __syncthreads();
+    if (tid < WF_PX) {     // softmax over the maps, as k_softmax_fuse: max, expf, sum, divide
+      float mx = -INFINITY;
+      for (int a_i = 0; a_i < p.n_maps; a_i++) mx = fmaxf(mx, lg[a_i][tid]);
+      float den = 0.f;
+      for (int a_i = 0; a_i < p.n_maps; a_i++) {
+        const float e = expf(lg[a_i][tid] - mx);
+        lg[a_i][tid] = e;
+        den += e;
+      }
+      for (int a_i = 0; a_i < p.n_maps; a_i++) lg[a_i][tid] = lg[a_i][tid] / den;
+    }
+    __syncthreads();
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int i = 0; i < WF_PX * (WF_C / 4) / 256; i++) {
+        const int idx = i * 256 + tid;
+        const int px = idx >> 5, q = idx & 31;
+        if (px0 + px < p.pixels) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int a_i = 0; a_i < p.n_maps; a_i++) {
+            const float s = lg[a_i][px];
+            const float4 m = *reinterpret_cast<const float4 *>(p.maps.p[a_i] + (px0 + px) * p.ld_map + q * 4);
+            acc.x += m.x * s; acc.y += m.y * s; acc.z += m.z * s; acc.w += m.w * s;
+          }
+          *reinterpret_cast<float4 *>(p.out + (px0 + px) * p.ld_out + q * 4) = acc;
+        }
+      }
+    }
+    __syncthreads();          // lg / h1 / h2 are reused by the next tile
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_disco_weight_fuse(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
+                                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                     float *out, int32_t ld_out, float *logits, int32_t ld_w, void *stream_) {
+  if (!maps_host || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || n_maps <= 0 || n_maps > MAX_AGENTS || pixels <= 0) return PCP_ERR_ARG;
+  if (c != WF_C) return PCP_ERR_UNSUPPORTED;
+  if ((ld_map & 3) || (ld_out & 3) || ld_map < c || ld_out < c || (logits && ld_w < n_maps)) return PCP_ERR_ARG;
+  if ((((uintptr_t)w1) & 15) || (((uintptr_t)out) & 15)) return PCP_ERR_ARG;
+  WfParams p;
+  for (int a = 0; a < MAX_AGENTS; a++) {
+    p.maps.p[a] = a < n_maps ? maps_host[a] : nullptr;
+    if (a < n_maps && (!maps_host[a] || (((uintptr_t)maps_host[a]) & 15))) return PCP_ERR_ARG;
+  }
+  p.n_maps = n_maps; p.ld_map = ld_map; p.ld_out = ld_out; p.ld_w = ld_w; p.pixels = pixels;
+  p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.out = out; p.logits = logits;
+  const long long n_tiles = (pixels + WF_PX - 1) / WF_PX;
+  const unsigned blocks = (unsigned)(n_tiles < 512 ? n_tiles : 512);
+  hipLaunchKernelGGL(k_weight_fuse, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

@@ -6,6 +6,8 @@ Per frame batch: compress ego + each agent map (MFMA convs), warp each compresse
 pixel weightor on [ego | agent] WITHOUT materialising the concat (dual-source 1x1 conv), softmax over agents + weighted
 sum in one kernel, decompress.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -67,7 +69,22 @@ class V2XMidFusionDisco(PackedModule):
                     w1=pack_conv_module(pw.conv1_1, pw.bn1_1, relu=True), w2=pack_conv_module(pw.conv1_2, pw.bn1_2, relu=True),
                     w3=pack_conv_module(pw.conv1_4, None, relu=True),
                     d0=pack_conv_module(self.decompressor[0], self.decompressor[1], relu=True),
-                    d1=pack_conv_module(self.decompressor[3], None, relu=False))
+                    d1=pack_conv_module(self.decompressor[3], None, relu=False),
+                    wf=self._fold_weightor())
+
+    # one launch for the whole weightor + softmax + weighted sum (pcp_disco_weight_fuse) instead of three pointwise launches per map and
+    # k_softmax_fuse; False (PCP_DISCO_FUSED_WEIGHTOR=0): the launch-per-stage form, kept for A/B runs and the equality test
+    fused_weightor = os.environ.get('PCP_DISCO_FUSED_WEIGHTOR', '1') != '0'
+
+    def _fold_weightor(self):
+        from ..convnet import _fold
+        pw = self.pixel_weightor
+        w1, b1 = _fold(pw.conv1_1, pw.bn1_1, 0)
+        w2, b2 = _fold(pw.conv1_2, pw.bn1_2, 0)
+        w3, b3 = _fold(pw.conv1_4, None, 0)
+        f = lambda t: t.reshape(t.shape[0], -1).float().contiguous()
+        return dict(w1=f(w1), b1=b1.float().contiguous(), w2=f(w2), b2=b2.float().contiguous(), w3=f(w3).reshape(-1).contiguous(),
+                    b3=b3.float().reshape(1).contiguous())
 
     def _compress(self, pk, x_nhwc, out=None):
         return pk['c1'].run(pk['c0'].run(x_nhwc), out=out)
@@ -108,8 +125,12 @@ class V2XMidFusionDisco(PackedModule):
         dev = ego_in.device
         stack = torch.zeros((n_maps, B, H, W, self.cc), dtype=torch.float32, device=dev)   # ego + warped agents (zeros = absent)
         self._compress(pk, ego_in, out=stack[0])
-        wbuf = torch.zeros((B, H, W, max(4, (n_maps + 3) // 4 * 4)), dtype=torch.float32, device=dev)
-        self._weight(pk, stack[0], stack[0], wbuf, 0)
+        fuse_now = self.fused_weightor and self.cc == 128 and n_maps <= 16 and pk['wf']['w1'].shape == (64, 2 * self.cc) \
+            and pk['wf']['w2'].shape == (16, 64)
+        wbuf = None
+        if not fuse_now:
+            wbuf = torch.zeros((B, H, W, max(4, (n_maps + 3) // 4 * 4)), dtype=torch.float32, device=dev)
+            self._weight(pk, stack[0], stack[0], wbuf, 0)
         pre = batch_dict.get('bev_img_compressed', None)      # agent-sharded execution: maps compressed on the agent's own GPU
         for a, (agent_idx, bev_img) in enumerate(agents, start=1):
             comp = pre[agent_idx] if pre is not None else self._compress(pk, ops.as_nhwc(bev_img))
@@ -119,9 +140,14 @@ class V2XMidFusionDisco(PackedModule):
                 T = fusion_host.ego_se3_agent(meta['se3_from_ego'][agent_idx])
                 theta = fusion_host.warp_theta(T, H, W, self.pc_min, self.pix_size)
                 ops.warp_nearest(comp[b_idx], stack[a, b_idx], theta, self.cc)
-            self._weight(pk, stack[0], stack[a], wbuf, a)
+            if not fuse_now:
+                self._weight(pk, stack[0], stack[a], wbuf, a)
         fused = torch.empty((B, H, W, self.cc), dtype=torch.float32, device=dev)
-        ops.softmax_fuse([stack[a] for a in range(n_maps)], wbuf, self.cc, fused)
+        if fuse_now:
+            wf = pk['wf']
+            ops.disco_weight_fuse([stack[a] for a in range(n_maps)], wf['w1'], wf['b1'], wf['w2'], wf['b2'], wf['w3'], wf['b3'], self.cc, fused)
+        else:
+            ops.softmax_fuse([stack[a] for a in range(n_maps)], wbuf, self.cc, fused)
         out = pk['d1'].run(pk['d0'].run(fused))
         batch_dict['spatial_features_2d'] = ops.nchw_view(out)
         return batch_dict

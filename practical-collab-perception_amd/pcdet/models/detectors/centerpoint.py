@@ -41,12 +41,34 @@ class CenterPoint(Detector3DTemplate):
     # bit-identical (tests/test_gpu_e2e.py::test_overlapped_makers_*); small launches of one pass fill the CUs another pass leaves idle.
     # Works in train() mode too: the makers are frozen teachers evaluated under no_grad, the tape only holds the ego branch.
     overlap_makers = False
+    # MI355X knob (off by default, never part of a headline number): skip BEV-maker passes whose output no later module reads -- reference
+    # quirk F3 (bev_maker.py:157,212-230): every rsu / car maker REPLACES batch_dict['bev_img'], so an rsu maker followed by a car maker
+    # is overwritten (the car maker re-encodes agent 0 with its own weights), and 'bev_img_early' feeds only the training distillation
+    # loss (v2x_fusion_disco.py:119).  pred_dicts are bit-identical (tests/test_gpu_e2e.py::test_eliding_dead_makers_*); bench.py
+    # --elide-dead-makers reports what the quirk costs.
+    elide_dead_makers = False
+
+    def _dead_makers(self, makers):
+        dead = set()
+        if not self.elide_dead_makers:
+            return dead
+        for i, m in enumerate(makers):
+            if m.maker_type == 'early' and not self.training:
+                dead.add(id(m))
+            if m.maker_type == 'rsu' and any(n.maker_type in ('rsu', 'car') for n in makers[i + 1:]):
+                dead.add(id(m))
+        return dead
 
     def _run_modules(self, batch_dict):
         from ..bev_layers.bev_maker import BEVMaker
         makers = [m for m in self.module_list if isinstance(m, BEVMaker)]
-        if not self.overlap_makers or not makers or not batch_dict['points'].is_cuda:
+        dead = self._dead_makers(makers)
+        # a module in front of the fusion that corrects the points IN PLACE (HunterJr's k_apply_flow) would race with makers still
+        # reading them on their own streams: such models run the sequential chain
+        if not self.overlap_makers or not makers or not batch_dict['points'].is_cuda or getattr(self, 'corrector', None) is not None:
             for cur_module in self.module_list:
+                if id(cur_module) in dead:
+                    continue
                 batch_dict = cur_module(batch_dict)
             return batch_dict
         main = torch.cuda.current_stream()
@@ -54,24 +76,32 @@ class CenterPoint(Detector3DTemplate):
             self._maker_streams = [torch.cuda.Stream() for _ in makers]
         ready = main.record_event()
         joins = []
+
+        def join_all():
+            for ev in joins:
+                main.wait_event(ev)
+            for t in list(batch_dict.get('bev_img', {}).values()) + [batch_dict.get('bev_img_early', None)]:
+                if t is not None:
+                    t.record_stream(main)               # allocated on a side stream, consumed on the main one
+            del joins[:]
+        mi = 0
         for cur_module in self.module_list:
             if isinstance(cur_module, BEVMaker):
-                s = self._maker_streams[len(joins)]
+                s = self._maker_streams[mi]
+                mi += 1
+                if id(cur_module) in dead:
+                    continue
                 s.wait_event(ready)
+                batch_dict['points'].record_stream(s)             # main-stream allocation read on the side stream
                 with torch.cuda.stream(s):
                     batch_dict = cur_module(batch_dict)            # dict updates happen in program order (car replaces rsu)
                     joins.append(s.record_event())
                 continue
             if joins and cur_module is self.v2x_mid_fusion:
-                for ev in joins:
-                    main.wait_event(ev)
-                for t in list(batch_dict.get('bev_img', {}).values()) + [batch_dict.get('bev_img_early', None)]:
-                    if t is not None:
-                        t.record_stream(main)
-                joins = []
+                join_all()
             batch_dict = cur_module(batch_dict)
-        for ev in joins:                                           # no fusion module consumed the maps: still leave with everything joined
-            main.wait_event(ev)
+        if joins:                                                  # no fusion module consumed the maps: still leave with everything joined
+            join_all()
         return batch_dict
 
     def forward(self, batch_dict):

@@ -12,19 +12,18 @@ def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, p
     center_head.py:312-333).  Returns a list of dicts(pred_boxes, pred_scores, pred_labels) per frame."""
     assert not circle_nms and vel is None, 'circle_nms / vel are not used by the five configs'
     B, C, H, W = heatmap.shape
-    # the device kernel consumes raw logits / log-sizes: invert the caller's activations exactly where possible
-    head = torch.zeros((B, H, W, 16), dtype=torch.float32, device=heatmap.device)
-    hm = heatmap.clamp(1e-38, 1.0)
+    # the device kernel reads the caller's ACTIVATED maps as they are (descriptor flag `activated`): no inverse sigmoid / log round trip
+    head = torch.zeros((B, H, W, (8 + C + 3) // 4 * 4), dtype=torch.float32, device=heatmap.device)
     head[..., 0:2] = center.permute(0, 2, 3, 1)
     head[..., 2:3] = center_z.permute(0, 2, 3, 1)
-    head[..., 3:6] = torch.log(dim).permute(0, 2, 3, 1)
+    head[..., 3:6] = dim.permute(0, 2, 3, 1)
     head[..., 6:7] = rot_cos.permute(0, 2, 3, 1)
     head[..., 7:8] = rot_sin.permute(0, 2, 3, 1)
-    head[..., 8:8 + C] = torch.log(hm / (1 - hm).clamp_min(1e-38)).permute(0, 2, 3, 1)
+    head[..., 8:8 + C] = heatmap.permute(0, 2, 3, 1)
     lim = [float(v) for v in post_center_limit_range]
     kw = dict(k=K, num_class=C, ch_center=0, ch_z=2, ch_dim=3, ch_rot=6, ch_hm=8, stride=feature_map_stride,
               voxel_x=float(voxel_size[0]), voxel_y=float(voxel_size[1]), min_x=float(point_cloud_range[0]),
-              min_y=float(point_cloud_range[1]), limit=lim, score_thresh=score_thresh)
+              min_y=float(point_cloud_range[1]), limit=lim, score_thresh=score_thresh, activated=True)
     boxes, scores, labels, _cell, count = ops.centerhead_decode(head, kw)
     counts = count.cpu().tolist()
     return [dict(pred_boxes=boxes[b, :counts[b]], pred_scores=scores[b, :counts[b]], pred_labels=labels[b, :counts[b]])

@@ -41,7 +41,7 @@ class Decode(ctypes.Structure):
     _fields_ = [('batch', c_i32), ('h', c_i32), ('w', c_i32), ('ld', c_i32), ('num_class', c_i32), ('ch_center', c_i32),
                 ('ch_z', c_i32), ('ch_dim', c_i32), ('ch_rot', c_i32), ('ch_hm', c_i32), ('k', c_i32), ('stride', c_f),
                 ('voxel_x', c_f), ('voxel_y', c_f), ('min_x', c_f), ('min_y', c_f), ('limit', c_f * 6),
-                ('use_score_thresh', c_i32), ('score_thresh', c_f)]
+                ('use_score_thresh', c_i32), ('score_thresh', c_f), ('activated', c_i32)]
 
 
 class Anchor(ctypes.Structure):
@@ -135,6 +135,7 @@ SYMBOLS = {
     'pcp_boxes_bev_pairwise': (c_i32, [vp, c_i32, vp, c_i32, c_i32, vp, vp]),
     'pcp_warp_nearest': (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp]),
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
+    'pcp_disco_weight_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, c_i32, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i32, vp, c_i32, vp]),
     'pcp_bev_sample_bilinear': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp,
                                         c_i32, vp]),
     'pcp_hunter_point_head': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp, vp, vp, vp,

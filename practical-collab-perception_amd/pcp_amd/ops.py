@@ -352,6 +352,7 @@ def centerhead_decode(head, desc_kwargs):
     st = desc_kwargs.get('score_thresh', None)
     d.use_score_thresh = 0 if st is None else 1
     d.score_thresh = 0.0 if st is None else float(st)
+    d.activated = 1 if desc_kwargs.get('activated', False) else 0
     dev = head.device
     boxes, scores, labels, cell, count = _zeros_views(dev, [((B, k, 7), torch.float32), ((B, k), torch.float32), ((B, k), torch.int32),
                                                             ((B, k), torch.int32), ((B,), torch.int32)])
@@ -439,6 +440,25 @@ def softmax_fuse(maps, weights, channels, out):
     pixels = weights.numel() // weights.shape[-1]
     check(L.pcp_softmax_fuse(arr, n, _p(weights), weights.shape[-1], pixels, channels, maps[0].shape[-1], out.shape[-1], _p(out),
                              _stream()), 'pcp_softmax_fuse')
+    return out
+
+
+def disco_weight_fuse(maps, w1, b1, w2, b2, w3, b3, channels, out, logits=None):
+    """the DiscoNet pixel weightor + softmax over the maps + weighted sum as one launch (include/pcp_hip.h: pcp_disco_weight_fuse).
+    maps: list of (..., ld_map) tensors sharing one pixel stride, maps[0] = ego; BN-folded float32 weights; out (..., ld_out)."""
+    _need_cuda(w1, b1, w2, b2, w3, b3, out, logits, *maps)
+    L = _lib.load()
+    n = len(maps)
+    arr = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
+    ld_map = maps[0].shape[-1]
+    pixels = maps[0].numel() // ld_map
+    for m in maps:
+        assert m.is_contiguous() and m.shape[-1] == ld_map and m.numel() // ld_map == pixels
+    for t in (w1, b1, w2, b2, w3, b3):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert tuple(w1.shape) == (64, 2 * channels) and tuple(w2.shape) == (16, 64) and w3.numel() == 16 and b3.numel() == 1
+    check(L.pcp_disco_weight_fuse(arr, n, channels, ld_map, pixels, _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(out), out.shape[-1],
+                                  _p(logits), logits.shape[-1] if logits is not None else 0, _stream()), 'pcp_disco_weight_fuse')
     return out
 
 

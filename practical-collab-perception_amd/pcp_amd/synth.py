@@ -174,10 +174,20 @@ def fill_state_dict(shapes, seed=SEED_BASE + 7, scheme='survey'):
                     v = np.full(n, -2.19, dtype=np.float32)
         else:                                               # conv / linear / deconv weight
             fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
-            k = (math.sqrt(6.0) if scheme == 'he' else 1.0) / math.sqrt(max(fan_in, 1))
+            k = _weight_gain(scheme) / math.sqrt(max(fan_in, 1))
             v = uniform(seed, st, n, -k, k)
         out[name] = v.reshape(shape).astype(np.float32)
     return out
+
+
+def _weight_gain(scheme):
+    if scheme == 'survey':
+        return 1.0
+    if scheme == 'he':
+        return math.sqrt(6.0)
+    if scheme.startswith('gain:'):
+        return float(scheme[5:])
+    raise ValueError('unknown weight scheme %r' % (scheme,))
 
 
 def _is_last_hm_conv(name, names):

@@ -8,6 +8,26 @@ import os
 import sys
 from collections import defaultdict
 
+# kernel label -> the source file whose SHA-256 is recorded next to the counters: bench.py reports `traffic` only while that file is
+# unchanged (a kernel edited after the PMC pass would otherwise keep quoting stale bytes)
+SOURCES = {'k_wino4f': 'wino4f.hip', 'k_conv3x3_wino<1>': 'wino.hip', 'k_conv3x3_wino<2>': 'wino.hip', 'k_wino_ws': 'wino_ws.hip',
+           'k_w4_gemm': 'wino4.hip', 'k_w4_input': 'wino4.hip', 'k_w4_output': 'wino4.hip', 'k_conv3x3_direct<s1>': 'conv.hip',
+           'k_conv3x3_direct<s2>': 'conv.hip', 'k_pointwise<plain>': 'conv.hip', 'k_pointwise<conv_k2s2>': 'conv.hip',
+           'k_pointwise<convT_k2s2>': 'conv.hip', 'k_pfn': 'pfn.hip', 'k_sparse_conv_s2': 'sparseconv.hip', 'k_point_head': 'pointhead.hip',
+           'k_head_grouped': 'headconv.hip'}
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc')
+
+
+def source_sha(label):
+    import hashlib
+    name = SOURCES.get(label)
+    path = os.path.join(CSRC, name) if name else None
+    if not path or not os.path.isfile(path):
+        return None
+    with open(path, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 # substring of the rocprof kernel name -> bench.py label key
 KEYS = [('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_conv3x3_wino<2>', 'k_conv3x3_wino<2>'), ('k_wino4f', 'k_wino4f'), ('k_wino_ws', 'k_wino_ws'),
         ('k_w4_gemm', 'k_w4_gemm'), ('k_w4_input', 'k_w4_input'), ('k_w4_output', 'k_w4_output'),
@@ -46,7 +66,7 @@ def main():
         fa = sum(fv) / max(len(fv), 1)
         wa = sum(wv) / max(len(wv), 1)
         sec[label] = {'launches': len(fv), 'fetch_size_kb_avg': round(fa, 2), 'write_size_kb_avg': round(wa, 2),
-                      'bytes_per_launch': round((2.0 * fa + wa) * 1024.0, 2)}
+                      'bytes_per_launch': round((2.0 * fa + wa) * 1024.0, 2), 'source': SOURCES.get(label), 'source_sha256': source_sha(label)}
     doc[config] = sec
     with open(out_path, 'w') as f:
         json.dump(doc, f, indent=1)

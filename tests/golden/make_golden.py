@@ -25,10 +25,13 @@ from pcp_amd import synth  # noqa: E402
 MINI_RANGE = [-12.8, -12.8, -8.0, 12.8, 12.8, 0.0]
 
 
+WEIGHT_SCHEME = 'survey'          # 'he' while the well-conditioned fixtures (g13) are generated
+
+
 def fill_weights(model):
     sd = model.state_dict()
     shapes = {k: [int(x) for x in v.shape] for k, v in sd.items()}
-    filled = synth.fill_state_dict(shapes)
+    filled = synth.fill_state_dict(shapes, scheme=WEIGHT_SCHEME)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     return shapes
 
@@ -1235,9 +1238,210 @@ def g10_lately_chain():
     print('g10 ego P', out['voxel_coords'].shape[0], 'final', [out['final_boxes_%d' % b].shape[0] for b in range(B)])
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# g13: WELL-CONDITIONED end-to-end fixtures ("what's weak" 1).  With the SURVEY 8(d) weight bound every candidate of a frame
+# scores within 5e-4 of sigmoid(-2.19) and the final box SET is a function of float noise; these fixtures use He-scaled weights (an O(1)
+# spatial signal survives the conv stack) and a SCORE_THRESH picked so that the reference's final set is INVARIANT under random
+# perturbations of all five head maps 10x larger than any fp32 implementation's noise (certificate: `trials` perturbed runs of the
+# reference's own generate_predicted_boxes give the same set).  The GPU tests then demand the exact final set (count + one-to-one match at
+# 1e-3) through the whole HIP path, at mini size, at BASELINE's full sizes and for the config-3 chain.
+# ---------------------------------------------------------------------------------------------------------------------
+G13_NOISE = 1e-4
+G13_TRIALS = 12
+G13_COUNTS = [120, 100, 150, 80, 180, 60, 200, 240, 40, 300]      # candidates above SCORE_THRESH in frame 0 (tried in this order)
+G13_GAINS = [1.6, 1.7, 1.8, 1.9, 2.0, 2.1, 2.2, 2.3, 2.4, 2.5, 2.6]   # conv / linear weights U(-k, k), k = gain / sqrt(fan_in).  The gain at which the signal
+# neither dies nor explodes over the ~20 layers depends on the model and on the map size (zero padding damps small maps), so it is tuned per
+# case: the smallest gain whose hm logits have a standard deviation in [0.15, 0.9] with box-size logits inside +-3.5 (metric boxes)
+
+
+def _same_set(a_boxes, a_scores, b_boxes, b_scores, tol):
+    """same detections (count + one-to-one match of centre, size and score within tol).  The heading is matched loosely (0.2 rad): it is
+    atan2 of two head values that may both be small, so under the certificate's 1e-4 perturbation it moves by 1e-4 / |(cos, sin)| without
+    any change of WHICH boxes survive -- the question this certificate answers"""
+    if a_boxes.shape[0] != b_boxes.shape[0]:
+        return False
+    used = np.zeros(b_boxes.shape[0], bool)
+    for i in range(a_boxes.shape[0]):
+        d = np.abs(b_boxes - a_boxes[i])
+        d[:, 6] = np.minimum(d[:, 6], np.abs(d[:, 6] - 2 * np.pi)) * (tol / 0.2)
+        e = np.maximum(d.max(1), np.abs(b_scores - a_scores[i])) + used * 1e9
+        j = int(np.argmin(e))
+        if e[j] > tol:
+            return False
+        used[j] = True
+    return True
+
+
+def robust_threshold(head, batch_size, pred_dicts, what):
+    """picks SCORE_THRESH for `head` (the reference's CenterHead, its raw head maps in pred_dicts) such that the final sets of all frames
+    are invariant under G13_TRIALS random perturbations (uniform +-G13_NOISE on every value of the five maps); returns (thr, finals)"""
+    cfg = head.model_cfg.POST_PROCESSING
+    keep = cfg.SCORE_THRESH
+    gen = torch.Generator().manual_seed(1234)
+    K = int(cfg.MAX_OBJ_PER_SAMPLE)
+    tops = [torch.topk(pred_dicts[0]['hm'][b].sigmoid().reshape(-1), K)[0].double().numpy() for b in range(batch_size)]
+    # candidate thresholds: the middles of the WIDEST score gaps (over all frames together) among those that leave 30 .. 300 candidates in
+    # every frame -- widest first, so the SCORE_THRESH cut has the largest margin the data offers
+    lo = max(t[min(300, K - 1)] for t in tops)
+    hi = min(t[30] for t in tops)
+    union = np.sort(np.concatenate([t[(t >= lo) & (t <= hi)] for t in tops]))
+    gaps = union[1:] - union[:-1]
+    order = np.argsort(-gaps)[:24]
+    try:
+        for gi in order:
+            thr = round(float(union[gi] + union[gi + 1]) / 2.0, 7)
+            c = int((tops[0] > thr).sum())
+            if gaps[gi] < 5e-5:
+                break
+            cfg.SCORE_THRESH = thr
+            with torch.no_grad():
+                base = head.generate_predicted_boxes(batch_size, pred_dicts)
+            counts = [int(d['pred_boxes'].shape[0]) for d in base]
+            if min(counts) < 8:
+                continue
+            ok = True
+            for _t in range(G13_TRIALS):
+                noisy = [{k: v + (torch.rand(v.shape, generator=gen) * 2 - 1) * G13_NOISE for k, v in pd.items()} for pd in pred_dicts]
+                with torch.no_grad():
+                    got = head.generate_predicted_boxes(batch_size, noisy)
+                for a, b in zip(base, got):
+                    if not _same_set(a['pred_boxes'].numpy(), a['pred_scores'].numpy(), b['pred_boxes'].numpy(), b['pred_scores'].numpy(), 1e-3):
+                        ok = False
+                        break
+                if not ok:
+                    break
+            print('   g13 %-12s thr %.6f (%d candidates in frame 0) finals %s -> %s' % (what, thr, c, counts, 'robust' if ok else 'order-sensitive'))
+            if ok:
+                return thr, base
+    finally:
+        cfg.SCORE_THRESH = keep
+    raise RuntimeError('g13 %s: no threshold gives a perturbation-invariant final set' % what)
+
+
+def _g13_store(out, tag, finals, thr):
+    out[tag + '_score_thresh'] = np.array(float(thr))
+    out[tag + '_frames'] = np.array(len(finals))
+    for b, d in enumerate(finals):
+        out['%s_boxes_%d' % (tag, b)] = d['pred_boxes'].numpy().copy()
+        out['%s_scores_%d' % (tag, b)] = d['pred_scores'].numpy().copy()
+        out['%s_labels_%d' % (tag, b)] = d['pred_labels'].numpy().copy()
+
+
+def _g13_meta(cfg, yaml_name, layout, shapes, pc_range, extra=None):
+    m = dict(model=rh.to_plain(cfg.MODEL), pc_range=pc_range, voxel_size=[0.2, 0.2, 8.0], class_names=list(cfg.CLASS_NAMES), yaml=yaml_name,
+             layout=layout, state_shapes=shapes, weight_scheme=WEIGHT_SCHEME)
+    m.update(extra or {})
+    return m
+
+
+def _g13_run(build, make_bd, tag, out):
+    """build() -> (cfg, model) with WEIGHT_SCHEME applied; make_bd() -> a fresh batch dict.  Tunes the weight gain, runs the reference
+    forward, picks the robust threshold on its own head maps and stores the final sets under that threshold."""
+    global WEIGHT_SCHEME
+    chosen = None
+    for gain in G13_GAINS:
+        WEIGHT_SCHEME = 'gain:%g' % gain
+        cfg, model, shapes = build()
+        bd = make_bd()
+        with torch.no_grad():
+            for mod in model.module_list:
+                bd = mod(bd)
+        pd0 = model.dense_head.forward_ret_dict['pred_dicts'][0]
+        sd, dmax = float(pd0['hm'].std()), float(pd0['dim'].abs().max())
+        print('   g13 %-12s gain %.1f: hm logits %.2f .. %.2f (std %.3f), |dim logits| <= %.2f' % (tag, gain, float(pd0['hm'].min()), float(pd0['hm'].max()), sd, dmax))
+        if 0.15 <= sd <= 0.9 and dmax <= 3.5:
+            chosen = gain
+            break
+    if chosen is None:
+        raise RuntimeError('g13 %s: no gain gives a usable head map' % tag)
+    head = model.dense_head
+    pred_dicts = [{k: v.detach().clone() for k, v in pd.items()} for pd in head.forward_ret_dict['pred_dicts']]
+    thr, finals = robust_threshold(head, bd['batch_size'], pred_dicts, tag)
+    _g13_store(out, tag, finals, thr)
+    out[tag + '_weight_scheme'] = np.array(WEIGHT_SCHEME)
+    out[tag + '_hm_range'] = np.array([float(pred_dicts[0]['hm'].min()), float(pred_dicts[0]['hm'].max())])
+    return thr, cfg, shapes
+
+
+def g13_conditioned():
+    global WEIGHT_SCHEME
+    out, metas = {}, {}
+    tmp = tempfile.mkdtemp()
+    empty = os.path.join(tmp, 'empty.pth')
+    torch.save({'model_state': {}}, empty)
+
+    def builder(yaml_name, ov):
+        def build():
+            cfg = rh.load_cfg(yaml_name, ov)
+            model, _ds = rh.build_model(cfg)
+            shapes = fill_weights(model)
+            return cfg, model, shapes
+        return build
+    try:
+        # ---- mini geometry: the three single-model configs (car incl. HunterJr), 2 frames x 3 000 points -----------------------------
+        for tag, yaml_name, layout in (('car', 'v2x_pointpillar_basic_car.yaml', 'car'), ('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately'),
+                                       ('early', 'v2x_pointpillar_basic_ego_early.yaml', 'early')):
+            pts = synth.collate(mini_points(layout, 2, 3000))
+            thr, cfg, shapes = _g13_run(builder(yaml_name, {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE}),
+                                        lambda: {'points': torch.from_numpy(pts.copy()), 'batch_size': 2, 'metadata': [{}, {}]}, tag, out)
+            cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = thr
+            metas[tag] = _g13_meta(cfg, yaml_name, layout, shapes, MINI_RANGE)
+        # ---- mini DiscoNet (the g1_disco scene: 3 agents, agent 2 absent from frame 1, half-pixel poses) ---------------------------------
+        ov = {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE, 'MODEL.BEV_MAKER_RSU.CKPT': empty, 'MODEL.BEV_MAKER_CAR.CKPT': empty,
+              'MODEL.BEV_MAKER_EARLY.CKPT': empty, 'MODEL.V2X_MID_FUSION.PC_RANGE_MIN': MINI_RANGE[0]}
+        poses = {0: synth.agent_pose(0), 2: synth.agent_pose(2)}
+        poses[0][:3, 3] = [0.8, -0.4, 0.0]
+        poses[0][:3, :3] = synth.agent_pose(1)[:3, :3]
+        poses[2][:3, 3] = [-1.6, 2.4, 0.0]
+        metadata = [{'se3_from_ego': {0: poses[0], 2: poses[2]}}, {'se3_from_ego': {0: poses[0]}}]
+        clouds = []
+        for b in range(2):
+            per_agent = []
+            for a in (0, 1, 2):
+                if b == 1 and a == 2:
+                    continue
+                c = synth.agent_cloud(agent=20 + 3 * b + a, n_points=1500, layout='disco', xy_half=13.1)
+                c[:, -1] = float(a)
+                per_agent.append(c)
+            clouds.append(np.concatenate(per_agent, axis=0))
+        dpts = synth.collate(clouds)
+        thr, cfg, shapes = _g13_run(builder('v2x_pointpillar_disco.yaml', ov),
+                                    lambda: {'points': torch.from_numpy(dpts.copy()), 'batch_size': 2, 'metadata': metadata}, 'disco', out)
+        cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = thr
+        metas['disco'] = _g13_meta(cfg, 'v2x_pointpillar_disco.yaml', 'disco', shapes, MINI_RANGE, dict(absent=[[], [2]]))
+        out['disco_pose_0'], out['disco_pose_2'] = poses[0], poses[2]
+        # ---- BASELINE's full sizes: 60 000 points per agent, 512 x 512 grid, one frame -----------------------------------------------------
+        for tag, yaml_name, layout, n_agents in (('car_full', 'v2x_pointpillar_basic_car.yaml', 'car', 1),
+                                                 ('ego_full', 'v2x_pointpillar_basic_ego.yaml', 'lately', 1),
+                                                 ('early_full', 'v2x_pointpillar_basic_ego_early.yaml', 'early', 6)):
+            cloud = np.concatenate([synth.agent_cloud(agent=a, n_points=60000, layout=layout) for a in range(n_agents)], axis=0)
+            fpts = synth.collate([cloud])
+            _g13_run(builder(yaml_name, {}), lambda: {'points': torch.from_numpy(fpts.copy()), 'batch_size': 1, 'metadata': [{}]}, tag, out)
+        agents = (0, 1, 2, 3, 4, 5)
+        fposes = {a: synth.agent_pose(a) for a in agents if a != 1}
+        fclouds = []
+        for a in agents:
+            c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+            c[:, -1] = float(a)
+            fclouds.append(c)
+        dfpts = synth.collate([np.concatenate(fclouds, axis=0)])
+        _g13_run(builder('v2x_pointpillar_disco.yaml', {'MODEL.BEV_MAKER_RSU.CKPT': empty, 'MODEL.BEV_MAKER_CAR.CKPT': empty,
+                                                        'MODEL.BEV_MAKER_EARLY.CKPT': empty}),
+                 lambda: {'points': torch.from_numpy(dfpts.copy()), 'batch_size': 1, 'metadata': [{'se3_from_ego': fposes}]}, 'disco_full', out)
+        for a in fposes:
+            out['disco_full_pose_%d' % a] = fposes[a]
+        out['meta_json'] = np.array(json.dumps(dict(cases=metas, noise=G13_NOISE, trials=G13_TRIALS)))
+        np.savez_compressed(os.path.join(HERE, 'g13_conditioned.npz'), **out)
+        print('g13:', {k: (str(out[k]) if out[k].ndim == 0 else out[k].shape) for k in sorted(out) if k.endswith('_score_thresh') or k.endswith('_scheme') or '_boxes_' in k})
+    finally:
+        WEIGHT_SCHEME = 'survey'
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
+    if 'g13' in todo:
+        g13_conditioned()
     if 'g3' in todo:
         g3_nms()
     if 'g4' in todo:

@@ -137,3 +137,51 @@ def test_test_py_two_ranks_merge_results_in_dataset_order():
     out = r.stdout + r.stderr
     reports = re.findall(r'(\d+) detections over (\d+) frames', out)
     assert len(reports) == 1 and int(reports[0][1]) == 7, (reports, out[-1500:])          # one report (rank 0), 7 frames (ragged shard 4 + 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus 2 through the REAL kernels: two ranks share this box's one MI355X (PCP_BENCH_BACKEND=gloo), so the
+# line is a functional check of the N > 1 path -- launcher, rendezvous, device binding, collectives, max-over-ranks timing, JSON contract
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ, **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, cwd=REPO, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+_BENCH_N1 = {}
+
+
+def _bench_n1(extra):
+    key = tuple(extra)
+    if key not in _BENCH_N1:
+        _BENCH_N1[key] = _bench(['--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'] + list(extra))
+    return _BENCH_N1[key]
+
+
+@pytest.mark.parametrize('extra', [[], ['--train'], ['--shard', 'agent'], ['--shard', 'agent', '--config', 'early']],
+                         ids=['replicas', 'train', 'agent_disco', 'agent_early'])
+def test_bench_two_ranks_through_the_real_kernels(extra):
+    line = _bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'] + extra, {'PCP_BENCH_BACKEND': 'gloo'})
+    cfg = line['config']
+    assert line['n_gpus'] == 2 and cfg['ranks_seen_by_collective'] == 2 and cfg['backend'] == 'gloo'
+    assert line['steps'] == 3 and line['warmup'] == 1 and line['cpu_baseline'] is None
+    assert 'FUNCTIONAL CHECK ONLY' in line['data']
+    assert len(cfg['per_rank_ms_per_step']) == 2 and cfg['rank_devices'] == [0, 0]          # both ranks on this box's one device
+    assert max(cfg['per_rank_ms_per_step']) <= line['ms_per_step'] * 1.001 + 1e-3           # the line carries the MAX over ranks
+    assert line['scaling'] == ('strong' if '--shard' in extra else 'weak')
+    if '--shard' in extra:
+        return
+    # two replicas time-share one GPU: the aggregate stays near the single-rank rate (a rank that silently did nothing, or did its work
+    # twice, would double or halve it)
+    one = _bench_n1([e for e in extra])
+    assert one['n_gpus'] == 1 and one['config']['rank_devices'] == [0]
+    ratio = line['value'] / one['value']
+    assert 0.55 < ratio < 1.6, (line['value'], one['value'])
+    if '--train' not in extra:
+        assert cfg['final_boxes_last_step'] > 0

@@ -725,6 +725,72 @@ def test_integration_b1_stub_runs_verbatim():
     np.testing.assert_allclose(out.numpy(), onms.iou_matrix(boxes[:40], boxes[40:140]), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize('fixture', ['g1_ego.npz', 'g1_car.npz'])
+def test_decode_bbox_from_heatmap_adapter_equals_the_reference(fixture):
+    """pcdet.models.model_utils.centernet_utils.decode_bbox_from_heatmap called the way center_head.py:312-333 calls it (heatmap =
+    sigmoid scores, dim = exp'ed sizes, (B, C, H, W) tensors) on the reference's own head maps: the candidates it returns are the ones
+    the reference handed to its NMS (fixture keys post_<b>_nms_*), bit for bit on the scores (the kernel reads the activated maps as they
+    are: no inverse sigmoid) and to 1e-5 on the boxes (atan2f ulps)"""
+    from helpers import assert_same_final_set
+    from pcdet.models.model_utils import centernet_utils
+    g = load_golden(fixture)
+    pp = g['meta']['model']['DENSE_HEAD']['POST_PROCESSING']
+    d = dev()
+    hm = torch.from_numpy(g['head_hm']).to(d).sigmoid()
+    dim = torch.from_numpy(g['head_dim']).to(d).exp()
+    rot = torch.from_numpy(g['head_rot']).to(d)
+    out = centernet_utils.decode_bbox_from_heatmap(
+        heatmap=hm, rot_cos=rot[:, 0:1], rot_sin=rot[:, 1:2], center=torch.from_numpy(g['head_center']).to(d),
+        center_z=torch.from_numpy(g['head_center_z']).to(d), dim=dim, point_cloud_range=g['meta']['pc_range'], voxel_size=g['meta']['voxel_size'],
+        feature_map_stride=g['meta']['model']['DENSE_HEAD']['TARGET_ASSIGNER_CONFIG']['FEATURE_MAP_STRIDE'], K=pp['MAX_OBJ_PER_SAMPLE'],
+        circle_nms=False, score_thresh=pp['SCORE_THRESH'], post_center_limit_range=torch.tensor(pp['POST_CENTER_LIMIT_RANGE']))
+    for b in range(2):
+        rb, rs = g['post_%d_nms_boxes' % b], g['post_%d_nms_scores' % b]
+        gb, gs = out[b]['pred_boxes'].cpu().numpy(), out[b]['pred_scores'].cpu().numpy()
+        assert rb.shape[0] > 100 and gb.shape == rb.shape
+        # the adapter adds nothing to the caller's scores: every returned score is, bit for bit, one of the heat-map values passed in
+        assert bool(np.isin(gs, hm[b].reshape(-1).cpu().numpy()).all())
+        assert_same_final_set(rb, rs, gb, gs, tol=1e-5)
+        assert bool((out[b]['pred_labels'] == 0).all())
+
+
+@pytest.mark.parametrize('pixels,n_maps', [(64, 1), (1000, 3), (4096 + 17, 6), (200, 8)])
+def test_disco_weight_fuse_matches_torch_cpu(pixels, n_maps):
+    """pcp_disco_weight_fuse (pixel weightor on cat[ego, map_a] for every map, softmax over the maps, weighted sum: one launch) against a
+    plain torch fp32 CPU evaluation of v2x_fusion_disco.py:8-26,107-115 with BatchNorm already folded; ragged pixel counts (tiles of 64),
+    1 .. 8 maps, a padded pixel stride.  fp32 MFMA products, fp32 accumulation: 2e-5 of the scale"""
+    ops = _ops()
+    d = dev()
+    C, ld = 128, 132
+    maps = [torch.from_numpy(_rand(300 + a, (pixels, ld), -1.0, 1.0)) for a in range(n_maps)]
+    w1 = torch.from_numpy(_rand(311, (64, 2 * C), -0.2, 0.2))
+    b1 = torch.from_numpy(_rand(312, (64,), -0.2, 0.2))
+    w2 = torch.from_numpy(_rand(313, (16, 64), -0.3, 0.3))
+    b2 = torch.from_numpy(_rand(314, (16,), -0.2, 0.2))
+    w3 = torch.from_numpy(_rand(315, (16,), -0.5, 0.5))
+    b3 = torch.from_numpy(_rand(316, (1,), 0.0, 0.3))
+    logits = []
+    for a in range(n_maps):
+        x = torch.cat([maps[0][:, :C], maps[a][:, :C]], dim=1)
+        h1 = F.relu(x @ w1.t() + b1)
+        h2 = F.relu(h1 @ w2.t() + b2)
+        logits.append(F.relu(h2 @ w3 + b3))
+    logits = torch.stack(logits, dim=1)                                   # (pixels, n_maps)
+    sm = torch.softmax(logits, dim=1)
+    want = sum(sm[:, a:a + 1] * maps[a][:, :C] for a in range(n_maps))
+    out = torch.full((pixels, C + 4), 7.0, device=d)
+    lg = torch.full((pixels, 8), -1.0, device=d)
+    ops.disco_weight_fuse([m.to(d) for m in maps], w1.to(d), b1.to(d), w2.to(d), b2.to(d), w3.to(d), b3.to(d), C, out, logits=lg)
+    torch.cuda.synchronize()
+    assert float((out[:, C:] - 7.0).abs().max()) == 0.0 and float((lg[:, n_maps:] + 1.0).abs().max()) == 0.0     # windows respected
+    assert float(logits.max()) > 0.05                                      # the ReLU'd logits are not all clamped
+    np.testing.assert_allclose(lg[:, :n_maps].cpu().numpy(), logits.numpy(), rtol=0, atol=2e-5 * max(1.0, float(logits.abs().max())))
+    np.testing.assert_allclose(out[:, :C].cpu().numpy(), want.numpy(), rtol=0, atol=2e-5)
+    out2 = torch.empty_like(out)
+    ops.disco_weight_fuse([m.to(d) for m in maps], w1.to(d), b1.to(d), w2.to(d), b2.to(d), w3.to(d), b3.to(d), C, out2)
+    assert torch.equal(out2[:, :C], out[:, :C])                            # deterministic, logits output optional
+
+
 def test_column_ids_equals_torch_unique():
     """agent ids present in the cloud (bev_maker.py:153-156: torch.unique(points[:, -1].long())): presence-mask kernel == torch.unique
     of the truncated column; ids outside 0..63 raise (no torch fallback on the product path); the empty cloud gives no ids"""

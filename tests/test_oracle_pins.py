@@ -66,6 +66,42 @@ def test_g1_disco():
         np.testing.assert_allclose(out['head_maps'][name], g['head_' + name], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize('case', ['car', 'ego', 'early', 'disco'])
+def test_g13_well_conditioned_final_sets(case):
+    """tests/golden/g13_conditioned.npz (weights that keep an O(1) spatial signal, SCORE_THRESH under which the reference's own final set is
+    invariant to 1e-4 perturbations of its head maps): the oracle's complete forward returns EXACTLY the reference's detections -- same
+    count, one-to-one match at 1e-3 -- which the slack-free GPU test then demands of the HIP path"""
+    from helpers import assert_same_final_set
+    g = load_golden('g13_conditioned.npz')
+    meta = g['meta']['cases'][case]
+    arch = arch_of(meta)
+    st = synth.fill_state_dict(meta['state_shapes'], scheme=str(g[case + '_weight_scheme']))
+    assert abs(float(meta['model']['DENSE_HEAD']['POST_PROCESSING']['SCORE_THRESH']) - float(g[case + '_score_thresh'])) < 1e-9
+    if case == 'disco':
+        clouds = []
+        for b in range(2):
+            per_agent = []
+            for a in (0, 1, 2):
+                if b == 1 and a == 2:
+                    continue
+                c = synth.agent_cloud(agent=20 + 3 * b + a, n_points=1500, layout='disco', xy_half=13.1)
+                c[:, -1] = float(a)
+                per_agent.append(c)
+            clouds.append(np.concatenate(per_agent, axis=0))
+        pts = synth.collate(clouds)
+        metadata = [{'se3_from_ego': {0: g['disco_pose_0'], 2: g['disco_pose_2']}}, {'se3_from_ego': {0: g['disco_pose_0']}}]
+        out = omodel.forward(pts, st, arch, metadata=metadata)
+    else:
+        layout = {'car': 'car', 'ego': 'lately', 'early': 'early'}[case]
+        pts = synth.collate([synth.agent_cloud(agent=10 + b, n_points=3000, layout=layout, seed=synth.SEED_BASE, xy_half=13.1) for b in range(2)])
+        out = omodel.forward(pts, st, arch)
+    for b in range(2):
+        fb = out['final_box_dicts'][b]
+        assert g['%s_boxes_%d' % (case, b)].shape[0] >= 8
+        assert_same_final_set(g['%s_boxes_%d' % (case, b)], g['%s_scores_%d' % (case, b)], fb['pred_boxes'], fb['pred_scores'], tol=1e-3)
+        assert np.array_equal(np.sort(fb['pred_labels']), np.sort(g['%s_labels_%d' % (case, b)]))
+
+
 def test_g3_nms_known_answer():
     g = load_golden('g3_nms.npz')
     boxes, scores = g['boxes'], g['scores']
