@@ -308,7 +308,9 @@ class AbiTimer:
                     fl, tag = 2.0 * d.batch * d.in_h * d.in_w * d.cin * 4 * d.cout_pad, 'convT_k2s2'
                 return 'k_pointwise<%s> (fp32 MFMA GEMM)' % tag, fl, fl * d.cout / max(d.cout_pad, 1), 'mfma', MFMA_F32_PEAK_TFLOPS
             label = {'pcp_pfn_scatter': 'k_pfn (fused PFN + scatter)', 'pcp_sparse_conv3x3_s2': 'k_sparse_conv_s2 (first backbone layer from the pillar list)',
-                     'pcp_voxelize': 'pcp_voxelize (all its launches)', 'pcp_nms_rotated': 'pcp_nms_rotated (all its launches)',
+                     'pcp_voxelize': 'pcp_voxelize (all its launches)', 'pcp_voxelize_cells_ready': 'pcp_voxelize (all its launches)',
+                     'pcp_select_transform_compact': 'pcp_select_transform_compact (agent selection + pose + compaction + cell ids, all its launches)',
+                     'pcp_disco_weight_fuse': 'k_weight_fuse (DiscoNet pixel weightor + softmax + weighted sum, one launch)', 'pcp_nms_rotated': 'pcp_nms_rotated (all its launches)',
                      'pcp_hunter_point_head_ex': 'k_point_head', 'pcp_hunter_point_head': 'k_point_head',
                      'pcp_conv3x3_grouped_small': 'k_head_grouped'}.get(name, name)
             return label, None, None, 'latency', None

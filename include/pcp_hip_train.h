@@ -38,6 +38,20 @@ int pcp_scale_shift_act(const float *x, int64_t rows, int32_t c, int32_t ld_x, c
 int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
                         const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, float *dgamma,
                         float *dbeta, int32_t accumulate, float *dx, int32_t ld_dx, void *stream);
+/* Cross-rank BatchNorm (nn.SyncBatchNorm: reference tools/train.py:37,128-129 `--sync_bn`): the two calls above split where the ranks
+ * exchange.  sums = 2 * c float64 on the device ([sum x | sum x^2] forward, [sum dz | sum dz * xhat] backward); the host all-reduces them
+ * (and the row count) over the ranks between the two halves.  Forward statistics then come from the global sums; backward dgamma / dbeta
+ * from the LOCAL sums (the gradient all-reduce combines them, as DDP does) and the mean terms of dx from the global ones. */
+int pcp_bn_train_sums(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, double *sums, void *stream);
+int pcp_bn_train_stats_from_sums(const double *sums, int64_t total_rows, int32_t c, const float *gamma, const float *beta, float eps,
+                                 float momentum, float *running_mean, float *running_var, float *scale, float *shift, float *mean,
+                                 float *invstd, void *stream);
+int pcp_bn_bwd_sums(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
+                    const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, double *sums, void *stream);
+int pcp_bn_bwd_apply_from_sums(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
+                               const float *shift, const float *mean, const float *invstd, int32_t relu, const double *local_sums,
+                               const double *global_sums, int64_t total_rows, void *workspace, float *dgamma, float *dbeta,
+                               int32_t accumulate, float *dx, int32_t ld_dx, void *stream);
 /* out[c] (+)= sum over rows (bias gradients); workspace as above */
 int pcp_colsum(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, float *out, int32_t accumulate, void *stream);
 /* dst[r, :c] += alpha * src[r, :c] (gradient fan-in) */

@@ -166,6 +166,29 @@ __global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_bnbwd_finalize(const dou
   coef[c + i] = (float)(s1 / n);
 }
 
+// block partials -> the two per-channel float64 sums themselves (sums[0][c], sums[1][c]): the hand-off point of cross-rank BatchNorm
+__global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_sums_finalize(const double *acc, int nb, int c, double *sums) {
+  const int lc = threadIdx.x / FIN_PARTS, part = threadIdx.x % FIN_PARTS;
+  const int i = blockIdx.x * FIN_CH + lc;
+  double s0, s1;
+  reduce_partials(acc, nb, c, i, part, lc, s0, s1);
+  if (part != 0 || i >= c) return;
+  sums[i] = s0;
+  sums[c + i] = s1;
+}
+
+// dgamma / dbeta from THIS rank's sums (the optimizer's gradient all-reduce combines them, as DDP does for nn.SyncBatchNorm); the mean
+// terms of dx from the sums over ALL ranks
+__global__ void k_bnbwd_finalize_sync(const double *local, const double *global, double n_total, int c, float *dgamma, float *dbeta,
+                                      int accumulate, float *coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float db = (float)local[i], dg = (float)local[c + i];
+  if (accumulate) { dbeta[i] += db; dgamma[i] += dg; } else { dbeta[i] = db; dgamma[i] = dg; }
+  coef[i] = (float)(global[i] / n_total);
+  coef[c + i] = (float)(global[c + i] / n_total);
+}
+
 __global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_colsum_finalize(const double *acc, int nb, int c, float *out, int accumulate) {
   const int lc = threadIdx.x / FIN_PARTS, part = threadIdx.x % FIN_PARTS;
   const int i = blockIdx.x * FIN_CH + lc;
@@ -305,6 +328,67 @@ int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int3
   hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(nb), dim3(RED_THREADS), 0, s, p);
   hipLaunchKernelGGL(k_bnbwd_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, (long long)rows, c, dgamma,
                      dbeta, accumulate, coef);
+  const long long total = (long long)rows * (c >> 2);
+  hipLaunchKernelGGL(k_bnbwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, ld_dout, x, ld_x, (long long)rows,
+                     c >> 2, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+// ---- cross-rank BatchNorm (nn.SyncBatchNorm, tools/train.py --sync_bn): the two calls above split at their reduction ------------------
+int pcp_bn_train_sums(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, double *sums, void *stream) {
+  if (!x || !workspace || !sums || !red_shape_ok(rows, c, ld) || !al16(x)) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  RedParams p{};
+  p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
+  const int nb = red_grid(rows, c);
+  hipLaunchKernelGGL(k_col_reduce<RED_STATS>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_sums_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, sums);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_bn_train_stats_from_sums(const double *sums, int64_t total_rows, int32_t c, const float *gamma, const float *beta, float eps,
+                                 float momentum, float *running_mean, float *running_var, float *scale, float *shift, float *mean,
+                                 float *invstd, void *stream) {
+  if (!sums || !gamma || !beta || !scale || !shift || !mean || !invstd || total_rows <= 0 || c <= 0) return PCP_ERR_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return PCP_ERR_ARG;
+  // sums is laid out like ONE block partial ([2][c]): the finalize kernel of the single-rank path reads it with nb = 1
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, (hipStream_t)stream, sums, 1,
+                     (long long)total_rows, c, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_bn_bwd_sums(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
+                    const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, double *sums, void *stream) {
+  if (!dout || !x || !scale || !shift || !mean || !invstd || !workspace || !sums || !red_shape_ok(rows, c, ld_x) || (ld_dout & 3) ||
+      !al16(dout) || !al16(x))
+    return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  RedParams p{};
+  p.x = x; p.dout = dout; p.rows = rows; p.c = c; p.ld_x = ld_x; p.ld_d = ld_dout;
+  p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.relu = relu; p.acc = acc;
+  const int nb = red_grid(rows, c);
+  hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_sums_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, sums);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_bn_bwd_apply_from_sums(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
+                               const float *shift, const float *mean, const float *invstd, int32_t relu, const double *local_sums,
+                               const double *global_sums, int64_t total_rows, void *workspace, float *dgamma, float *dbeta,
+                               int32_t accumulate, float *dx, int32_t ld_dx, void *stream) {
+  if (!dout || !x || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !workspace || !dgamma || !dbeta || !dx ||
+      !red_shape_ok(rows, c, ld_x) || (ld_dout & 3) || (ld_dx & 3) || !al16(dout) || !al16(x) || !al16(dx) || total_rows < rows)
+    return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float *coef = (float *)((double *)workspace + 2 * (size_t)c * RED_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_bnbwd_finalize_sync, dim3((c + 255) / 256), dim3(256), 0, s, local_sums, global_sums, (double)total_rows, c, dgamma, dbeta,
+                     accumulate, coef);
   const long long total = (long long)rows * (c >> 2);
   hipLaunchKernelGGL(k_bnbwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, ld_dout, x, ld_x, (long long)rows,
                      c >> 2, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx);

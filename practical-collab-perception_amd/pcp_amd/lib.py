@@ -166,6 +166,10 @@ SYMBOLS.update({
     'pcp_scale_shift_act': (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp, c_i32, vp, c_i32, vp]),
     'pcp_bn_act_backward': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, vp, c_i32, vp, c_i32, vp]),
     'pcp_colsum': (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp, c_i32, vp]),
+    'pcp_bn_train_sums': (c_i32, [vp, c_i64, c_i32, c_i32, vp, vp, vp]),
+    'pcp_bn_train_stats_from_sums': (c_i32, [vp, c_i64, c_i32, vp, vp, c_f, c_f, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_bn_bwd_sums': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, vp]),
+    'pcp_bn_bwd_apply_from_sums': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, c_i64, vp, vp, vp, c_i32, vp, c_i32, vp]),
     'pcp_accumulate': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, vp]),
     'pcp_dilate2x': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp]),
     'pcp_conv3x3_wgrad_workspace_bytes': (c_sz, [ctypes.POINTER(Conv3x3)]),

@@ -39,6 +39,29 @@ class BNVectors:
         self.scale, self.shift, self.mean, self.invstd = buf[0], buf[1], buf[2], buf[3]
 
 
+# Cross-rank BatchNorm (tools/train.py --sync_bn == nn.SyncBatchNorm.convert_sync_batchnorm of the reference, tools/train.py:128-129):
+# when SYNC_BN is set and a process group with more than one rank exists, every training-mode BatchNorm all-reduces its per-channel
+# float64 sums (+ the row count) in the forward and its two gradient sums in the backward.
+SYNC_BN = False
+
+
+def _sync_group():
+    import torch.distributed as dist
+    if SYNC_BN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def _all_reduce_sums(dist, sums_and_count):
+    """sum over the ranks of a float64 device vector; gloo (the CPU-test / shared-device backend) reduces a host copy"""
+    if dist.get_backend() == 'nccl':
+        dist.all_reduce(sums_and_count)
+        return sums_and_count
+    host = sums_and_count.cpu()
+    dist.all_reduce(host)
+    return host.to(sums_and_count.device)
+
+
 def bn_train_stats(x, c, gamma, beta, eps, momentum, running_mean, running_var, vec=None, ch_off=0):
     """x: (..., ld) NHWC / row-major.  Returns BNVectors; running stats are updated in place (pass None to skip)."""
     _need_cuda(x, gamma, beta)
@@ -47,6 +70,17 @@ def bn_train_stats(x, c, gamma, beta, eps, momentum, running_mean, running_var, 
     if vec is None:
         vec = BNVectors(c, x.device)
     ws = _BN_WS.get(L.pcp_bn_workspace_bytes(c), x.device)
+    dist = _sync_group()
+    if dist is not None:
+        buf = torch.empty((2 * c + 1,), dtype=torch.float64, device=x.device)
+        buf[2 * c:].fill_(float(rows))
+        check(L.pcp_bn_train_sums(_chan_ptr(x, ch_off), rows, c, ld, _p(ws), _p(buf), _stream()), 'pcp_bn_train_sums')
+        buf = _all_reduce_sums(dist, buf)
+        total = int(round(float(buf[2 * c].item())))
+        check(L.pcp_bn_train_stats_from_sums(_p(buf), total, c, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                                             _p(running_var), _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), _stream()),
+              'pcp_bn_train_stats_from_sums')
+        return vec
     check(L.pcp_bn_train_stats(_chan_ptr(x, ch_off), rows, c, ld, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
                                _p(running_var), _p(ws), _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), _stream()),
           'pcp_bn_train_stats')
@@ -75,6 +109,19 @@ def bn_act_backward(dout, x, c, vec, relu, dgamma, dbeta, accumulate=False, dx=N
         dx, dx_ch_off = dout, dout_ch_off
     ld_dx = dx.shape[-1]
     ws = _BN_WS.get(L.pcp_bn_workspace_bytes(c), x.device)
+    dist = _sync_group()
+    if dist is not None:
+        local = torch.empty((2 * c + 1,), dtype=torch.float64, device=x.device)
+        local[2 * c:].fill_(float(rows))
+        check(L.pcp_bn_bwd_sums(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale), _p(vec.shift),
+                                _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(local), _stream()), 'pcp_bn_bwd_sums')
+        glob = _all_reduce_sums(dist, local.clone())
+        total = int(round(float(glob[2 * c].item())))
+        check(L.pcp_bn_bwd_apply_from_sums(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale),
+                                           _p(vec.shift), _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(local), _p(glob), total, _p(ws),
+                                           _p(dgamma), _p(dbeta), 1 if accumulate else 0, _chan_ptr(dx, dx_ch_off), ld_dx, _stream()),
+              'pcp_bn_bwd_apply_from_sums')
+        return dx
     check(L.pcp_bn_act_backward(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale), _p(vec.shift),
                                 _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(dgamma), _p(dbeta), 1 if accumulate else 0,
                                 _chan_ptr(dx, dx_ch_off), ld_dx, _stream()), 'pcp_bn_act_backward')

@@ -47,6 +47,7 @@ def parse_config():
     p.add_argument('--ckpt_save_interval', type=int, default=1)
     p.add_argument('--max_ckpt_save_num', type=int, default=30)
     p.add_argument('--output_dir', type=str, default=None)
+    p.add_argument('--sync_bn', action='store_true', default=False, help='whether to use sync bn')
     p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
@@ -93,6 +94,12 @@ def main():
             logger.info('%s.CKPT %s not found: synthetic teacher weights' % (key, cfg.MODEL[key].CKPT))
             cfg.MODEL[key].CKPT = None
     model = build_network(model_cfg=cfg.MODEL, num_class=len(cfg.CLASS_NAMES), dataset=train_set)
+    if args.sync_bn and dist_train:
+        # reference tools/train.py:128-129 (nn.SyncBatchNorm.convert_sync_batchnorm): every training-mode BatchNorm of the hand-written
+        # path all-reduces its per-channel sums over the ranks (pcp_amd/train_ops.py; csrc/bn_train.hip pcp_bn_*_sums)
+        from pcp_amd import train_ops
+        train_ops.SYNC_BN = True
+        logger.info('cross-rank BatchNorm statistics: on (%d ranks)' % total_gpus)
     start_epoch = it = 0
     if args.pretrained_model is not None:
         model.load_params_from_file(filename=args.pretrained_model, logger=logger, to_cpu=True)

@@ -108,9 +108,13 @@ def test_train_py_two_ranks_share_one_gpu(tmp_path, yaml_name):
            str(_free_port()), 'train.py', '--launcher', 'pytorch', '--cfg_file', 'cfgs/v2x_sim_models/' + yaml_name, '--batch_size', '2',
            '--epochs', '2', '--output_dir', str(tmp_path), '--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '3000',
            'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '8', 'OPTIMIZATION.LR', '0.003']
+    sync_bn = 'disco' in yaml_name                        # the DiscoNet run also exercises --sync_bn (reference tools/train.py:37,128-129)
+    if sync_bn:
+        cmd.insert(cmd.index('--set'), '--sync_bn')
     r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
     out = r.stdout + r.stderr
+    assert ('cross-rank BatchNorm statistics: on (2 ranks)' in out) == sync_bn
     losses = [float(m) for m in re.findall(r'loss ([0-9.]+)  lr', out)]
     # --batch_size is the TOTAL batch (reference tools/train.py:86-88): 1 frame per rank and iteration, 4 iterations per epoch, first and
     # last of each epoch logged -- by rank 0 only
@@ -137,6 +141,70 @@ def test_test_py_two_ranks_merge_results_in_dataset_order():
     out = r.stdout + r.stderr
     reports = re.findall(r'(\d+) detections over (\d+) frames', out)
     assert len(reports) == 1 and int(reports[0][1]) == 7, (reports, out[-1500:])          # one report (rank 0), 7 frames (ragged shard 4 + 3)
+
+
+def _sync_bn_worker(rank, world, port, ret):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pcp_amd import train_ops as tops
+        tops.SYNC_BN = True
+        x, dy, gamma, beta = _sync_bn_case()
+        rows = [slice(0, 700), slice(700, 1800)][rank]                           # ragged split of the rows over the two ranks
+        xs, dys = x[rows].cuda().contiguous(), dy[rows].cuda().contiguous()
+        rm, rv = torch.zeros(32).cuda(), torch.ones(32).cuda()
+        vec = tops.bn_train_stats(xs, 32, gamma.cuda(), beta.cuda(), 1e-3, 0.01, rm, rv)
+        out = torch.empty_like(xs)
+        tops.scale_shift_act(xs, 32, vec, True, out)
+        dg, db = torch.zeros(32).cuda(), torch.zeros(32).cuda()
+        dx = tops.bn_act_backward(dys.clone(), xs, 32, vec, True, dg, db)
+        torch.cuda.synchronize()
+        ret[rank] = dict(out=out.cpu().numpy(), dx=dx.cpu().numpy(), dg=dg.cpu().numpy(), db=db.cpu().numpy(), rm=rm.cpu().numpy(),
+                         rv=rv.cpu().numpy(), mean=vec.mean.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _sync_bn_case():
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn((1800, 32), generator=g) * 2.0 + 0.5
+    x[:700] += 1.5                                                                # the two shards have DIFFERENT statistics
+    dy = torch.randn((1800, 32), generator=g)
+    return x, dy, torch.rand(32, generator=g) + 0.5, torch.rand(32, generator=g) - 0.5
+
+
+def test_sync_bn_two_ranks_equal_one_rank_on_the_union():
+    """tools/train.py --sync_bn (reference tools/train.py:128-129, nn.SyncBatchNorm): training-mode BatchNorm + ReLU, forward and backward,
+    on two ranks holding a ragged split of the rows (all-reduce of the per-channel float64 sums, pcp_bn_*_sums) against ONE rank on all
+    rows: activations, running statistics and dx agree to float rounding; the ranks' dgamma / dbeta add up to the single-rank ones"""
+    _setup_paths()
+    from pcp_amd import train_ops as tops
+    assert tops.SYNC_BN is False
+    x, dy, gamma, beta = _sync_bn_case()
+    xs, dys = x.cuda().contiguous(), dy.cuda().contiguous()
+    rm, rv = torch.zeros(32).cuda(), torch.ones(32).cuda()
+    vec = tops.bn_train_stats(xs, 32, gamma.cuda(), beta.cuda(), 1e-3, 0.01, rm, rv)
+    out = torch.empty_like(xs)
+    tops.scale_shift_act(xs, 32, vec, True, out)
+    dg, db = torch.zeros(32).cuda(), torch.zeros(32).cuda()
+    dx = tops.bn_act_backward(dys.clone(), xs, 32, vec, True, dg, db)
+    torch.cuda.synchronize()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sync_bn_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    got_out = np.concatenate([ret[0]['out'], ret[1]['out']], 0)
+    got_dx = np.concatenate([ret[0]['dx'], ret[1]['dx']], 0)
+    np.testing.assert_allclose(ret[0]['mean'], vec.mean.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got_out, out.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got_dx, dx.cpu().numpy(), rtol=0, atol=2e-6)
+    for r in (0, 1):                                                              # both ranks track the GLOBAL running statistics
+        np.testing.assert_allclose(ret[r]['rm'], rm.cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(ret[r]['rv'], rv.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ret[0]['dg'] + ret[1]['dg'], dg.cpu().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ret[0]['db'] + ret[1]['db'], db.cpu().numpy(), rtol=0, atol=2e-4)
+    # and the shards' OWN statistics differ: without the exchange the result would not match
+    assert float(np.abs(x[:700].mean(0).numpy() - x.mean(0).numpy()).max()) > 0.5
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -779,7 +779,7 @@ def test_disco_weight_fuse_matches_torch_cpu(pixels, n_maps):
     sm = torch.softmax(logits, dim=1)
     want = sum(sm[:, a:a + 1] * maps[a][:, :C] for a in range(n_maps))
     out = torch.full((pixels, C + 4), 7.0, device=d)
-    lg = torch.full((pixels, 8), -1.0, device=d)
+    lg = torch.full((pixels, 12), -1.0, device=d)
     ops.disco_weight_fuse([m.to(d) for m in maps], w1.to(d), b1.to(d), w2.to(d), b2.to(d), w3.to(d), b3.to(d), C, out, logits=lg)
     torch.cuda.synchronize()
     assert float((out[:, C:] - 7.0).abs().max()) == 0.0 and float((lg[:, n_maps:] + 1.0).abs().max()) == 0.0     # windows respected
