@@ -125,6 +125,12 @@ int pcp_centerhead_loss(const pcp_headloss_t *desc, const float *head, const flo
  * c <= 512.  Shares the workspace of pcp_centerhead_loss. */
 int pcp_distill_loss(const float *fused, int32_t ld_f, const float *early, int32_t ld_e, int64_t pixels, int32_t c, float weight,
                      float grad_scale, void *workspace, float *loss, float *dfused, int32_t ld_d, int32_t accumulate, void *stream);
+/* HunterJr teacher-BEV term (hunter_jr.py:352-365): loss (1,) = mean over the pixels with ||teacher[p, :]||_2 > thresh of
+ * sum_c smooth_l1(fused[p, c] - teacher[p, c]) (nan when no pixel qualifies, as torch's mean of an empty selection).  Value only: the
+ * reference keeps it in forward_return_dict['loss_dtl_bev_img'] and never adds it to the training loss (hunter_jr.py:490-494).
+ * workspace: pcp_loss_workspace_bytes() bytes. */
+int pcp_masked_smooth_l1_rows(const float *fused, int32_t ld_f, const float *teacher, int32_t ld_t, int64_t pixels, int32_t c, float thresh,
+                              void *workspace, float *loss, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training-mode PillarFeatureNet (BatchNorm1d with batch statistics splits the fused inference kernel at its two global

@@ -332,6 +332,50 @@ __global__ void k_distill_finalize(const double *acc, long long pixels, int c, f
 
 }  // namespace
 
+namespace {
+constexpr int MSL_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void k_masked_sl1(const float *__restrict__ fused, int ld_f, const float *__restrict__ teacher, int ld_t,
+                                                   long long pixels, int c, float thresh, double *__restrict__ acc) {
+  __shared__ double red[4][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long wave0 = (long long)blockIdx.x * 4 + wv, nw = (long long)gridDim.x * 4;
+  double sum = 0.0, cnt = 0.0;
+  for (long long pix = wave0; pix < pixels; pix += nw) {
+    float n2 = 0.f, l = 0.f;
+    for (int ch = lane; ch < c; ch += 64) {
+      const float t = teacher[pix * ld_t + ch], d = fused[pix * ld_f + ch] - t, a = fabsf(d);
+      n2 = fmaf(t, t, n2);
+      l += a < 1.0f ? 0.5f * d * d : a - 0.5f;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      n2 += __shfl_xor(n2, o);
+      l += __shfl_xor(l, o);
+    }
+    if (sqrtf(n2) > thresh) {
+      sum += (double)l;
+      cnt += 1.0;
+    }
+  }
+  if (lane == 0) { red[wv][0] = sum; red[wv][1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    acc[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  }
+}
+
+__global__ void k_masked_sl1_finalize(const double *__restrict__ acc, int nb, float *__restrict__ loss) {
+  double s = 0.0, n = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) { s += acc[2 * i]; n += acc[2 * i + 1]; }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    n += __shfl_xor(n, o);
+  }
+  if (threadIdx.x == 0) loss[0] = n > 0.0 ? (float)(s / n) : __builtin_nanf("");      // torch: the mean of an empty selection is nan
+}
+}  // namespace
+
 extern "C" {
 
 int pcp_centerhead_targets(const pcp_target_t *d, const float *gt_boxes, int32_t max_boxes, float *heatmap, float *target_boxes,
@@ -346,7 +390,7 @@ int pcp_centerhead_targets(const pcp_target_t *d, const float *gt_boxes, int32_t
   return PCP_OK;
 }
 
-size_t pcp_loss_workspace_bytes(void) { return ACC_N * sizeof(double); }
+size_t pcp_loss_workspace_bytes(void) { return (size_t)(ACC_N > 2 * MSL_BLOCKS ? ACC_N : 2 * MSL_BLOCKS) * sizeof(double); }
 
 int pcp_centerhead_loss(const pcp_headloss_t *d, const float *head, const float *heatmap, const float *target_boxes,
                         const int32_t *inds, const int32_t *mask, float grad_scale, void *workspace, float *losses, float *dhead,
@@ -370,6 +414,23 @@ int pcp_centerhead_loss(const pcp_headloss_t *d, const float *head, const float 
     hipLaunchKernelGGL(k_focal_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *d, head, heatmap, acc, grad_scale, dhead);
     hipLaunchKernelGGL(k_reg_grad, dim3((nk + 255) / 256), dim3(256), 0, s, *d, head, target_boxes, inds, mask, acc, grad_scale, dhead);
   }
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+// HunterJr's teacher-BEV term (hunter_jr.py:352-365): mean over the pixels whose teacher row has an L2 norm > thresh of the per-pixel SUM
+// of smooth_l1(fused - teacher) (beta = 1).  The reference stores the value in forward_return_dict['loss_dtl_bev_img'] and never adds it
+// to the training loss (hunter_jr.py:490-494), so no gradient is formed.  One wavefront per pixel, block partials in float64 reduced in a
+// fixed order by one wave (deterministic).
+int pcp_masked_smooth_l1_rows(const float *fused, int32_t ld_f, const float *teacher, int32_t ld_t, int64_t pixels, int32_t c, float thresh,
+                              void *workspace, float *loss, void *stream) {
+  if (!fused || !teacher || !workspace || !loss || pixels <= 0 || c <= 0) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;                         // [MSL_BLOCKS][2]: sum, count
+  long long blocks = (pixels + 3) / 4;
+  if (blocks > MSL_BLOCKS) blocks = MSL_BLOCKS;
+  hipLaunchKernelGGL(k_masked_sl1, dim3((unsigned)blocks), dim3(256), 0, s, fused, ld_f, teacher, ld_t, (long long)pixels, c, thresh, acc);
+  hipLaunchKernelGGL(k_masked_sl1_finalize, dim3(1), dim3(64), 0, s, acc, (int)blocks, loss);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -75,8 +75,6 @@ class HunterTrain:
         M, S = gt.shape[1], int(m.num_sweeps)
         if tuple(itf.shape) != (B, M, S, 3, 4):
             raise ValueError('instances_tf must be (batch, gt_boxes.shape[1], NUM_SWEEPS, 3, 4), got %s' % (tuple(itf.shape),))
-        if 'teacher_spatial_features_2d' in batch_dict:
-            raise NotImplementedError('teacher BEV distillation (hunter_jr.py:349-363) is not used by the V2X-Sim configs')
         min_xy = m.point_cloud_range[:2]
         pix = [np.float32(m.voxel_size[0]) * m.bev_image_stride, np.float32(m.voxel_size[1]) * m.bev_image_stride]
         cat = torch.empty((B, H, W, 2 * C), dtype=torch.float32, device=dev)         # [bev | corrected]
@@ -126,6 +124,11 @@ class HunterTrain:
         fused = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
         ops.softmax_fuse_raw([cat.data_ptr(), cat.data_ptr() + 4 * C], logits, C, 2 * C, fused)
         s.update(dyn=dyn, hid=hid, logits=logits, points=points)
+        if 'teacher_spatial_features_2d' in batch_dict:
+            # hunter_jr.py:352-365: smooth-L1 between the corrected map and a teacher's, over the pixels the teacher covers.  The reference
+            # stores the value and never adds it to the training loss (:490-494), so it is a reported quantity without a gradient
+            teacher = ops.as_nhwc(batch_dict['teacher_spatial_features_2d'].float())
+            m.forward_return_dict['loss_dtl_bev_img'] = tops.masked_smooth_l1_rows(fused, teacher, C)[0]
         self.s = s
         batch_dict['gt_boxes'] = tops.filter_gt_boxes(gt, m.point_cloud_range)
         return fused

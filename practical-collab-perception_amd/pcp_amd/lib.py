@@ -199,6 +199,7 @@ SYMBOLS.update({
                                                  c_i32, vp, c_i32, vp]),
     'pcp_filter_gt_boxes': (c_i32, [vp, c_i32, c_i32, ctypes.POINTER(c_f), vp, vp]),
     'pcp_distill_loss': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, c_f, vp, vp, vp, c_i32, c_i32, vp]),
+    'pcp_masked_smooth_l1_rows': (c_i32, [vp, c_i32, vp, c_i32, c_i64, c_i32, c_f, vp, vp, vp]),
     'pcp_pfn_train_features': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, vp, vp, vp]),
     'pcp_pfn_train_mid': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp]),
     'pcp_pfn_train_out': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp, vp]),

@@ -288,6 +288,18 @@ def distill_loss(fused, early, c, weight=10.0, dfused=None, accumulate=False, gr
     return loss
 
 
+def masked_smooth_l1_rows(fused, teacher, c, thresh=1e-3):
+    """HunterJr's teacher-BEV term (hunter_jr.py:352-365), value only.  fused, teacher: (B,H,W,ld) NHWC.  Returns loss (1,) device."""
+    _need_cuda(fused, teacher)
+    L = _lib.load()
+    pixels = fused.numel() // fused.shape[-1]
+    assert fused.is_contiguous() and teacher.is_contiguous() and teacher.numel() // teacher.shape[-1] == pixels
+    loss = torch.empty(1, dtype=torch.float32, device=fused.device)
+    check(L.pcp_masked_smooth_l1_rows(_p(fused), fused.shape[-1], _p(teacher), teacher.shape[-1], pixels, c, float(thresh),
+                                      _p(_loss_ws(fused.device)), _p(loss), _stream()), 'pcp_masked_smooth_l1_rows')
+    return loss
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # PFN (train mode)
 # ---------------------------------------------------------------------------------------------------------------------

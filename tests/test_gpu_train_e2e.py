@@ -482,6 +482,43 @@ def test_hunter_jr_train_step_matches_reference():
                 np.testing.assert_allclose(d, g['it0_bn_digest'][i], rtol=5e-4, atol=1e-6, err_msg=k)
 
 
+def test_hunter_jr_teacher_bev_term_is_a_reported_value_without_a_gradient():
+    """hunter_jr.py:352-365: with batch_dict['teacher_spatial_features_2d'] the corrector records loss_dtl_bev_img = mean over the pixels the
+    teacher covers (row norm > 1e-3) of the per-pixel sum of smooth_l1(corrected map - teacher).  The reference never adds it to the training
+    loss (hunter_jr.py:490-494): the loss and every gradient must be the bits of the run without a teacher, and the value must equal a torch
+    fp32 CPU evaluation of the reference's expression on the map the model produced"""
+    import torch.nn.functional as F
+    g = load_golden('g12_hunter_train.npz')
+    outs = []
+    for with_teacher in (False, True):
+        model = _build(g)
+        model.train()
+        batch = {'points': torch.from_numpy(g['points']).to(DEV), 'batch_size': 2, 'metadata': [{}, {}],
+                 'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV), 'instances_tf': torch.from_numpy(g['instances_tf']).to(DEV)}
+        if with_teacher:
+            C, H, W = model.corrector.num_points_feat, g['map_probe'].shape[2], g['map_probe'].shape[3]
+            gen = torch.Generator().manual_seed(3)
+            teacher = torch.randn((2, C, H, W), generator=gen) * 0.5
+            teacher[:, :, : H // 3] = 0.0                                     # a region the teacher does not cover: masked out
+            teacher[0, :, H // 2, :] *= 1e-6                                  # row norms below the 1e-3 threshold
+            batch['teacher_spatial_features_2d'] = teacher.to(DEV)
+        ret, tb, _ = model(batch)
+        ret['loss'].backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        outs.append((model, batch, float(ret['loss'].detach()), grads))
+    (m0, b0, l0, g0), (m1, b1, l1, g1) = outs
+    assert l0 == l1 and set(g0) == set(g1) and all(torch.equal(g0[n], g1[n]) for n in g0)
+    assert 'loss_dtl_bev_img' not in m0.corrector.forward_return_dict
+    got = float(m1.corrector.forward_return_dict['loss_dtl_bev_img'])
+    fused = b1['spatial_features_2d'].detach().cpu().float()
+    t = b1['teacher_spatial_features_2d'].cpu()
+    f2, t2 = fused.permute(0, 2, 3, 1).reshape(-1, fused.shape[1]), t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    mask = torch.linalg.norm(t2, dim=1) > 1e-3
+    want = float(F.smooth_l1_loss(f2[mask], t2[mask], reduction='none').sum(dim=1).mean())
+    assert 0 < int(mask.sum()) < mask.numel()
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)
+
+
 def _hunter_full_inputs():
     """the inputs of tests/golden/make_golden.py::hunter_full_inputs, regenerated (closed-form streams: nothing large is committed)"""
     s0 = synth.SEED_BASE + 960
