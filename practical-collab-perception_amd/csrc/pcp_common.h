@@ -16,7 +16,7 @@
 static inline size_t pcp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Zero fill as a KERNEL node (hipMemsetAsync nodes replayed incorrectly inside captured hipGraphs on this stack: the second
-// replay of a graph containing them faulted, tools/dbg_graph.py): 16-byte stores, grid-stride.
+// replay of a graph containing them faulted, profiles/scripts/debug/dbg_graph.py): 16-byte stores, grid-stride.
 __global__ static void pcp_k_zero(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, size_t ntail) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -95,7 +95,7 @@ def test_disco_train_step_matches_reference_and_oracle():
             # conv) must agree to 1e-4.  Further upstream the comparison is bounded by the fixture, not the kernels: a forward
             # difference of 1e-5 flips the ReLU mask of the few pre-activations that sit within 1e-5 of zero, and with only
             # 2 x 32 x 32 samples per channel one flipped element moves a BatchNorm bias gradient by ~1 %; the float32 CPU oracle
-            # shows the same effect (tests/dbg_train_grad_bisect.py prints both columns).  There: 3e-2 per tensor, 5e-3 global relative L2.
+            # shows the same effect (profiles/scripts/debug/dbg_train_grad_bisect.py prints both columns).  There: 3e-2 per tensor, 5e-3 global relative L2.
             num = den = 0.0
             gmax = max(float(v.abs().max()) for v in g64.values())
             for n in names:
