@@ -485,7 +485,7 @@ def test_hunter_jr_train_step_matches_reference():
 def test_hunter_jr_teacher_bev_term_is_a_reported_value_without_a_gradient():
     """hunter_jr.py:352-365: with batch_dict['teacher_spatial_features_2d'] the corrector records loss_dtl_bev_img = mean over the pixels the
     teacher covers (row norm > 1e-3) of the per-pixel sum of smooth_l1(corrected map - teacher).  The reference never adds it to the training
-    loss (hunter_jr.py:490-494): the loss and every gradient must be the bits of the run without a teacher, and the value must equal a torch
+    loss (hunter_jr.py:490-494): the loss and every gradient must be those of the run without a teacher, and the value must equal a torch
     fp32 CPU evaluation of the reference's expression on the map the model produced"""
     import torch.nn.functional as F
     g = load_golden('g12_hunter_train.npz')
@@ -507,7 +507,11 @@ def test_hunter_jr_teacher_bev_term_is_a_reported_value_without_a_gradient():
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         outs.append((model, batch, float(ret['loss'].detach()), grads))
     (m0, b0, l0, g0), (m1, b1, l1, g1) = outs
-    assert l0 == l1 and set(g0) == set(g1) and all(torch.equal(g0[n], g1[n]) for n in g0)
+    # no gradient comes from the term: the two runs agree to the run-to-run noise of the float atomics in the point <-> BEV backward kernels
+    assert abs(l0 - l1) <= 1e-6 * abs(l0) and set(g0) == set(g1)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-4 * max(float(g0[n].abs().max()), 1e-3 * gmax), n
     assert 'loss_dtl_bev_img' not in m0.corrector.forward_return_dict
     got = float(m1.corrector.forward_return_dict['loss_dtl_bev_img'])
     fused = b1['spatial_features_2d'].detach().cpu().float()
