@@ -35,7 +35,11 @@ struct SpParams {
 
 __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
   __shared__ __attribute__((aligned(16))) float acc[SP_PIX * 64];          // per-pixel accumulators
+#ifdef SP_ROW_SPLIT
   __shared__ __attribute__((aligned(16))) float atile[2][32 * SP_ALD];      // gathered pillar rows of the chunk (double buffered)
+#else
+  __shared__ __attribute__((aligned(16))) float atile[4][32 * SP_ALD];      // gathered pillar rows of two stages x two items
+#endif
   __shared__ int row_rank[9][SP_PIX];                                       // compacted (tap-wise) pillar ranks ...
   __shared__ unsigned char row_pix[9][SP_PIX];                              // ... and the output pixel each row belongs to
   __shared__ int cnt[9][2];
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
   }
   __syncthreads();
 
+#ifdef SP_ROW_SPLIT
   if (total > 0) {
     // wave = (16-row half of the chunk, 32-channel half of the outputs): its product block [16 x 32] over the whole K = 64 is final, so
     // it is added straight into the accumulators of its rows' pixels -- no partial sums, no result tile in LDS, ONE barrier per item
@@ -204,6 +209,125 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
     if (k0 + 2 < n_items) stage(k0 + 2, g[2], wq[0], atile[0]);
     __syncthreads();
   }
+
+#else
+  if (total > 0) {
+    // Round 3: wave w owns output channels [16 w, 16 w + 16) for ALL rows of an item, so an accumulator word (pixel, channel) is only ever
+    // touched by one wave: the read-modify-write of the per-pixel accumulators needs no cross-wave ordering and TWO items (taps) share one
+    // barrier -- 64 instead of 32 MFMAs per wave between barriers, half the barriers (the row-split form sat at 22 - 25 % matrix-pipe busy:
+    // ~4 300 cycles per item around 1 024 cycles of MFMA).  Same products in the same order per (row, channel): results are bit-identical.
+    const int m16 = lane & 15, q4 = lane >> 4;
+    const int g_row = tid >> 3, g_q = (tid & 7) * 2;                       // gather: row, first of two 16-byte columns
+    __shared__ unsigned char item_tap[36], item_chunk[36];
+    __shared__ int n_items_s;
+    if (tid == 0) {
+      int k = 0;
+      for (int t = 0; t < 9; t++)
+        for (int c0 = 0; c0 < cnt[t][0] + cnt[t][1]; c0 += 32) { item_tap[k] = (unsigned char)t; item_chunk[k] = (unsigned char)(c0 >> 5); k++; }
+      n_items_s = k;
+    }
+    __syncthreads();
+    const int n_items = n_items_s;
+    // register rings over FOUR items (two stages of two): gathered pillar rows and this wave's 16-channel weight fragments.  All loads are
+    // unconditional with clamped indices (static count of outstanding loads: counted s_waitcnt).
+    f32x4 g[4][2];
+    f32x4 wq[4][4];                                      // [ring slot][k group j]: W[t][16 wave + m16][16 j + 4 q4 ..]
+    auto gather = [&](int k, f32x4 (&dst)[2]) {
+      const int kc = min(k, n_items - 1);
+      const int t = item_tap[kc], c0 = item_chunk[kc] * 32;
+      const int row = min(c0 + g_row, cnt[t][0] + cnt[t][1] - 1);
+      const float *src = p.pf + (long long)row_rank[t][row] * SP_CIN + g_q * 4;
+      dst[0] = *reinterpret_cast<const f32x4 *>(src);
+      dst[1] = *reinterpret_cast<const f32x4 *>(src + 4);
+    };
+    auto wload = [&](int k, f32x4 (&dst)[4]) {
+      const int t = item_tap[min(k, n_items - 1)];
+      const float *wr = p.w + ((long long)(t * 64 + wave * 16 + m16)) * SP_CIN + 4 * q4;
+#pragma unroll
+      for (int j = 0; j < 4; j++) dst[j] = *reinterpret_cast<const f32x4 *>(wr + 16 * j);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      wload(u, wq[u]);
+      gather(u, g[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    typedef float f32x4c __attribute__((ext_vector_type(4)));
+    const int col = wave * 16 + m16;
+    // one stage = items k and k + 1 (k + 1 may lie past the end: its rows are stored as zeros and its updates masked off)
+    auto stage = [&](int k, f32x4 (&g0)[2], f32x4 (&g1)[2], f32x4 (&w0)[4], f32x4 (&w1)[4], float *at0, float *at1) {
+      const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      int rows_i[2], tap_i[2], c0_i[2];
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int kk = min(k + it, n_items - 1);
+        tap_i[it] = item_tap[kk];
+        c0_i[it] = item_chunk[kk] * 32;
+        rows_i[it] = (k + it < n_items) ? min(32, cnt[tap_i[it]][0] + cnt[tap_i[it]][1] - c0_i[it]) : 0;
+      }
+      *reinterpret_cast<f32x4 *>(at0 + g_row * SP_ALD + g_q * 4) = g_row < rows_i[0] ? g0[0] : zero4;
+      *reinterpret_cast<f32x4 *>(at0 + g_row * SP_ALD + g_q * 4 + 4) = g_row < rows_i[0] ? g0[1] : zero4;
+      *reinterpret_cast<f32x4 *>(at1 + g_row * SP_ALD + g_q * 4) = g_row < rows_i[1] ? g1[0] : zero4;
+      *reinterpret_cast<f32x4 *>(at1 + g_row * SP_ALD + g_q * 4 + 4) = g_row < rows_i[1] ? g1[1] : zero4;
+      __builtin_amdgcn_sched_barrier(0);
+      gather(k + 4, g0);
+      gather(k + 5, g1);
+      __builtin_amdgcn_sched_barrier(0);
+      // pixels of this lane's rows (16 rtile + 4 q4 + i): four consecutive bytes of the compaction table per row tile
+      unsigned pix4[2][2];
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int rtile = 0; rtile < 2; rtile++)
+          pix4[it][rtile] = *reinterpret_cast<const unsigned *>(&row_pix[tap_i[it]][min(c0_i[it] + rtile * 16 + q4 * 4, SP_PIX - 4)]);
+      __syncthreads();
+      f32x4c cv[2][2];
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const float *at = it == 0 ? at0 : at1;
+        f32x4 a[2][4];
+#pragma unroll
+        for (int rtile = 0; rtile < 2; rtile++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) a[rtile][j] = *reinterpret_cast<const f32x4 *>(at + (rtile * 16 + m16) * SP_ALD + 16 * j + 4 * q4);
+#pragma unroll
+        for (int rtile = 0; rtile < 2; rtile++) {
+          f32x4c c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rtile][j][kk], (it == 0 ? w0 : w1)[j][kk], c, 0, 0, 0);
+          cv[it][rtile] = c;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wload(k + 4, w0);                          // both slots' fragments are consumed: refill them for the stage after next
+      wload(k + 5, w1);
+      __builtin_amdgcn_sched_barrier(0);
+      // accumulate, item k first (a pixel may receive both taps: in-order LDS operations of one wave keep the order)
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int rtile = 0; rtile < 2; rtile++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int row = rtile * 16 + q4 * 4 + i;
+            if (row < rows_i[it]) {
+              const int pix = (int)((pix4[it][rtile] >> (8 * i)) & 255u);
+              acc[pix * 64 + col] += cv[it][rtile][i];
+            }
+          }
+    };
+    int k0 = 0;
+    for (; k0 + 4 <= n_items; k0 += 4) {
+      stage(k0 + 0, g[0], g[1], wq[0], wq[1], atile[0], atile[1]);
+      stage(k0 + 2, g[2], g[3], wq[2], wq[3], atile[2], atile[3]);
+    }
+    if (k0 + 0 < n_items) stage(k0 + 0, g[0], g[1], wq[0], wq[1], atile[0], atile[1]);
+    if (k0 + 2 < n_items) stage(k0 + 2, g[2], g[3], wq[2], wq[3], atile[2], atile[3]);
+    __syncthreads();
+  }
+#endif
 
   // ---- epilogue: bias + ReLU, one 256-byte row per pixel --------------------------------------------------------------------------
   {
