@@ -130,6 +130,20 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
 #pragma unroll
     for (int k = 0; k < NUM_RAW; k++) rawc[k] = row[1 + k];             // slot past the end: row 0, never used
   }
+#ifndef PFN_OLD_SWEEP1
+  // xyz of slot s0 + tid for the mean sweep: requested now, with everything else that does not depend on the LDS set-up (the sweep used to
+  // start its own bucket_order -> row chain behind two barriers: one more dependent global round trip on the workgroup's critical path)
+  float xyz1[3] = {0.f, 0.f, 0.f};
+  {
+    const int s = s0 + tid;
+    if (s < s1) {
+      const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+      xyz1[0] = row[1];
+      xyz1[1] = row[2];
+      xyz1[2] = row[3];
+    }
+  }
+#endif
   if (tid <= np) pl_start[tid] = ps_reg;
   for (int i = tid; i < PILLARS_PER_BLOCK * 3; i += PFN_THREADS) (&sum_fx[0][0])[i] = 0;
   for (int i = tid; i < PILLARS_PER_BLOCK * XLD; i += PFN_THREADS) xmax0[i] = 0.f;
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
 
   PFN_STAMP_AT(2);
   // ---- sweep 1: per-pillar xyz sums in 2^-24 fixed point (integer adds commute -> deterministic) ---------------------------
+#ifdef PFN_OLD_SWEEP1
   for (int s = s0 + tid; s < s1; s += PFN_THREADS) {
     const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
     int pl = pillar_of(s);
@@ -182,6 +197,25 @@ __global__ __launch_bounds__(PFN_THREADS, PFN_WGS) void k_pfn(PfnParams p) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
     }
   }
+#else
+  if (s0 + tid < s1) {
+    const int pl = pillar_of(s0 + tid);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      long long q = __double2ll_rn((double)xyz1[a] * 16777216.0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
+    }
+  }
+  for (int s = s0 + PFN_THREADS + tid; s < s1; s += PFN_THREADS) {          // crowded blocks: more than 256 points in 64 pillars
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+    int pl = pillar_of(s);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      long long q = __double2ll_rn((double)row[1 + a] * 16777216.0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)q);
+    }
+  }
+#endif
   __syncthreads();
   for (int i = tid; i < np * 3; i += PFN_THREADS) {
     int pl = i / 3, a = i % 3;

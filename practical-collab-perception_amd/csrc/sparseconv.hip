@@ -281,6 +281,22 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
         for (int rtile = 0; rtile < 2; rtile++)
           pix4[it][rtile] = *reinterpret_cast<const unsigned *>(&row_pix[tap_i[it]][min(c0_i[it] + rtile * 16 + q4 * 4, SP_PIX - 4)]);
       __syncthreads();
+      // this lane's accumulator words of both items: pixel (or 0 for a row past the chunk: read, never written) and the old values of item
+      // k, requested BEFORE the MFMAs so that their LDS round trip runs under the matrix work (a `+=` per word would serialise 16 dependent
+      // round trips: the compiler cannot prove the words distinct)
+      int pixs[2][2][4];
+      float old0[2][4];
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int rtile = 0; rtile < 2; rtile++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            pixs[it][rtile][i] = (rtile * 16 + q4 * 4 + i < rows_i[it]) ? (int)((pix4[it][rtile] >> (8 * i)) & 255u) : -1;
+#pragma unroll
+      for (int rtile = 0; rtile < 2; rtile++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) old0[rtile][i] = acc[max(pixs[0][rtile][i], 0) * 64 + col];
       f32x4c cv[2][2];
 #pragma unroll
       for (int it = 0; it < 2; it++) {
@@ -304,19 +320,22 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
       wload(k + 4, w0);                          // both slots' fragments are consumed: refill them for the stage after next
       wload(k + 5, w1);
       __builtin_amdgcn_sched_barrier(0);
-      // accumulate, item k first (a pixel may receive both taps: in-order LDS operations of one wave keep the order)
+      // accumulate, item k first (a pixel may receive both taps: the in-order LDS operations of one wave keep the order)
 #pragma unroll
-      for (int it = 0; it < 2; it++)
+      for (int rtile = 0; rtile < 2; rtile++)
 #pragma unroll
-        for (int rtile = 0; rtile < 2; rtile++)
+        for (int i = 0; i < 4; i++)
+          if (pixs[0][rtile][i] >= 0) acc[pixs[0][rtile][i] * 64 + col] = old0[rtile][i] + cv[0][rtile][i];
+      float old1[2][4];
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int row = rtile * 16 + q4 * 4 + i;
-            if (row < rows_i[it]) {
-              const int pix = (int)((pix4[it][rtile] >> (8 * i)) & 255u);
-              acc[pix * 64 + col] += cv[it][rtile][i];
-            }
-          }
+      for (int rtile = 0; rtile < 2; rtile++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) old1[rtile][i] = acc[max(pixs[1][rtile][i], 0) * 64 + col];
+#pragma unroll
+      for (int rtile = 0; rtile < 2; rtile++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (pixs[1][rtile][i] >= 0) acc[pixs[1][rtile][i] * 64 + col] = old1[rtile][i] + cv[1][rtile][i];
     };
     int k0 = 0;
     for (; k0 + 4 <= n_items; k0 += 4) {
