@@ -41,10 +41,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---- workspace layout of pcp_voxelize / pcp_pfn_scatter (offsets in bytes, all 256-B aligned) -----------------------
 struct VoxLayout {
   size_t cell_count;    // int32 [cells]   points per cell (zeroed every call)
-  size_t cell_fill;     // int32 [cells]   bucket cursor   (zeroed every call; contiguous with cell_count)
+  size_t cell_fill;     // int32 [cells]   (round 1-2: bucket cursor of a second atomic pass; unused since round 3, kept in the layout)
   size_t cell_rank;     // int32 [cells]   pillar rank, -1 if empty
   size_t cell_start;    // int32 [cells]   first slot of the cell in bucket order
   size_t point_cell;    // int32 [n]       merged cell id or -1
+  size_t point_rank;    // int32 [n]       arrival rank of the row inside its cell (the value the histogram atomic returned)
   size_t bucket_order;  // int32 [n]       point rows grouped by pillar (ascending merged id)
   size_t pillar_cell;   // int32 [n]       merged id of pillar r
   size_t pillar_start;  // int32 [n + 1]   first slot of pillar r (pillar_start[P] = N')
@@ -62,6 +63,7 @@ static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
   L.cell_rank = take((size_t)cells * 4);
   L.cell_start = take((size_t)cells * 4);
   L.point_cell = take((size_t)n * 4);
+  L.point_rank = take((size_t)n * 4);
   L.bucket_order = take((size_t)n * 4);
   L.pillar_cell = take((size_t)n * 4);
   L.pillar_start = take((size_t)(n + 1) * 4);

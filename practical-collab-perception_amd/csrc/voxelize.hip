@@ -69,7 +69,8 @@ __device__ __forceinline__ void block_scan_excl(T (&v)[SCAN_ITEMS], T *lds_wave 
 // pass 1 over points: cell id per row, per-cell histogram, valid rows per 1024-row tile
 __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__restrict__ points, long long n, int stride,
                                                               pcp_grid_t g, int *__restrict__ cell_count,
-                                                              int *__restrict__ point_cell, int *__restrict__ pt_block_sums) {
+                                                              int *__restrict__ point_cell, int *__restrict__ point_rank,
+                                                              int *__restrict__ pt_block_sums) {
   __shared__ int wave_tot[SCAN_THREADS / 64];
   long long base = (long long)blockIdx.x * SCAN_TILE;
   int valid = 0;
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__res
       int c = point_to_cell(points + r * stride, g);
       point_cell[r] = c;
       if (c >= 0) {
-        atomicAdd(&cell_count[c], 1);
+        // the histogram atomic's return value IS the row's slot inside its cell: k_point_finish needs no second atomic pass (and no
+        // second zeroed table); the order inside a cell is arrival order either way
+        point_rank[r] = atomicAdd(&cell_count[c], 1);
         valid++;
       }
     }
@@ -227,15 +230,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cell_finish(const int *__restr
 __global__ __launch_bounds__(SCAN_THREADS) void k_point_finish(const int *__restrict__ point_cell, long long n,
                                                                const int *__restrict__ pt_block_sums,
                                                                const int *__restrict__ cell_rank, const int *__restrict__ cell_start,
-                                                               int *__restrict__ cell_fill, long long *__restrict__ unq_inv,
+                                                               const int *__restrict__ point_rank, long long *__restrict__ unq_inv,
                                                                int *__restrict__ bucket_order) {
   __shared__ int lds32[SCAN_THREADS / 64 + 1];
   // items of one thread must be consecutive rows for a stable compaction
   long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  int cell[SCAN_ITEMS], v[SCAN_ITEMS];
+  int cell[SCAN_ITEMS], v[SCAN_ITEMS], prank[SCAN_ITEMS];
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
     cell[i] = (base + i < n) ? point_cell[base + i] : -1;
+    prank[i] = cell[i] >= 0 ? point_rank[base + i] : 0;
     v[i] = cell[i] >= 0 ? 1 : 0;
   }
   int tot;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_finish(const int *__rest
     if (cell[i] < 0) continue;
     int pos = v[i] + blk;
     if (unq_inv) unq_inv[pos] = (long long)cell_rank[cell[i]];
-    int slot = cell_start[cell[i]] + atomicAdd(&cell_fill[cell[i]], 1);
+    int slot = cell_start[cell[i]] + prank[i];
     bucket_order[slot] = (int)(base + i);
   }
 }
@@ -277,7 +281,7 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
   char *ws = (char *)workspace;
   int *cell_count = (int *)(ws + L.cell_count);
-  int *cell_fill = (int *)(ws + L.cell_fill);
+  int *point_rank = (int *)(ws + L.point_rank);
   int *cell_rank = (int *)(ws + L.cell_rank);
   int *cell_start = (int *)(ws + L.cell_start);
   int *point_cell = (int *)(ws + L.point_cell);
@@ -291,11 +295,10 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   int *counters_ws = (int *)(ws + L.counters);
 
   if (!cells_ready) {
-    // cell_count and cell_fill are adjacent (layout keeps 256-B alignment between them): one memset
-    if (pcp_zero_async(cell_count, L.cell_rank - L.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+    if (pcp_zero_async(cell_count, L.cell_fill - L.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
     if (n_pblk > 0) {
       hipLaunchKernelGGL(k_point_cells, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
-                         *grid, cell_count, point_cell, pt_bs);
+                         *grid, cell_count, point_cell, point_rank, pt_bs);
       PCP_CHECK_LAUNCH();
     }
   }
@@ -309,7 +312,7 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   PCP_CHECK_LAUNCH();
   if (n_pblk > 0) {
     hipLaunchKernelGGL(k_point_finish, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, point_cell, (long long)n, pt_bs, cell_rank,
-                       cell_start, cell_fill, (long long *)unq_inv, bucket_order);
+                       cell_start, point_rank, (long long *)unq_inv, bucket_order);
     PCP_CHECK_LAUNCH();
   }
   return PCP_OK;
@@ -433,7 +436,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
                                                               StcTable t, int n_tiles, const int *__restrict__ tile_off,
                                                               const int *__restrict__ slot_start, float *__restrict__ out,
                                                               long long out_rows, int emit_cells, pcp_grid_t g,
-                                                              int *__restrict__ cell_count, int *__restrict__ point_cell) {
+                                                              int *__restrict__ cell_count, int *__restrict__ point_cell,
+                                                              int *__restrict__ point_rank) {
   __shared__ int cnt[SCAN_ITEMS][SCAN_THREADS / 64][STC_MAX_SLOTS];       // rows kept per (item, wave, slot) -> exclusive prefix
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)blockIdx.x * SCAN_TILE;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
           const float cell_row[3] = {fb, tx, ty};
           const int c = point_to_cell(cell_row, g);
           point_cell[pos] = c;
-          if (c >= 0) atomicAdd(&cell_count[c], 1);
+          if (c >= 0) point_rank[pos] = atomicAdd(&cell_count[c], 1);
         }
       }
     }
@@ -579,7 +583,7 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
     for (int k = 0; k < 12; k++) t.m[i][k] = i < n_slots * batch ? poses_host[i * 12 + k] : 0.f;
   }
   pcp_grid_t g;
-  int *cell_count = nullptr, *point_cell = nullptr;
+  int *cell_count = nullptr, *point_cell = nullptr, *point_rank = nullptr;
   if (vox_grid) {
     if (!vox_workspace || vox_grid->nx <= 0 || vox_grid->ny <= 0 || vox_grid->batch_size <= 0) return PCP_ERR_ARG;
     const int64_t cells = (int64_t)vox_grid->batch_size * vox_grid->nx * vox_grid->ny;
@@ -589,7 +593,8 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
     g = *vox_grid;
     cell_count = (int *)((char *)vox_workspace + V.cell_count);
     point_cell = (int *)((char *)vox_workspace + V.point_cell);
-    if (pcp_zero_async(cell_count, V.cell_rank - V.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+    point_rank = (int *)((char *)vox_workspace + V.point_rank);
+    if (pcp_zero_async(cell_count, V.cell_fill - V.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
   } else {
     g = pcp_grid_t{};
   }
@@ -611,7 +616,7 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
   if (n_blocks > 0) {
     hipLaunchKernelGGL(k_stc_scatter, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, (int)agent_col, t,
                        n_tiles > 0 ? n_tiles : 1, tile_cnt, slot_start_ws, out, (long long)out_rows, vox_grid ? 1 : 0, g, cell_count,
-                       point_cell);
+                       point_cell, point_rank);
     PCP_CHECK_LAUNCH();
   }
   return PCP_OK;

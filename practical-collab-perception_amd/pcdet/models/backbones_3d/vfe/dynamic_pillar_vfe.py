@@ -102,8 +102,28 @@ class DynamicPillarVFE(VFETemplate):
         ready = batch_dict.get('_pcp_vox_ready', None)
         if ready is not None and not want_inverse:
             return ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=ready['workspace'], cells_ready=True)
-        return ops.voxelize(points, grid, want_inverse=want_inverse, want_counts=False,
-                            workspace=self._workspace if self.reuse_buffers else None)
+        share = batch_dict.get('_pcp_vox_share', None)
+        if share is None or want_inverse or not self.reuse_buffers:
+            return ops.voxelize(points, grid, want_inverse=want_inverse, want_counts=False,
+                                workspace=self._workspace if self.reuse_buffers else None)
+        # Two VFEs of one forward that pillarise the SAME cloud on the SAME grid (DiscoNet: the early-fusion BEV maker and the ego branch
+        # both see all points, bev_maker.py:212-230 / SURVEY F4) share one pillar list: the first to arrive builds it, the other waits for
+        # its event and only runs its own PFN.  The producer alternates between two workspaces so that the list of the previous forward is
+        # still intact when the consumer clears its persistent canvas from it.
+        key = (points.data_ptr(), int(points.shape[0]), int(points.shape[1]), grid.nx, grid.ny, grid.batch_size, grid.min_x, grid.min_y, grid.min_z,
+               grid.voxel_x, grid.voxel_y, grid.voxel_z)
+        cur = torch.cuda.current_stream()
+        ent = share.get(key)
+        if ent is not None:
+            vox, ev = ent
+            cur.wait_event(ev)
+            for t in (vox.workspace, vox.voxel_coords, vox.counters):
+                t.record_stream(cur)
+            return vox
+        self._workspace, self._workspace_alt = getattr(self, '_workspace_alt', None), self._workspace
+        vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=self._workspace)
+        share[key] = (vox, cur.record_event())
+        return vox
 
     def forward(self, batch_dict, **kwargs):
         if self.training:

@@ -68,8 +68,10 @@ class BEVMaker(nn.Module):
         self.load_state_dict(own)
         print('[TEACHER] ==> Done (loaded %d/%d)' % (len(update), len(own)))
 
-    def _run_chain(self, points, batch_size, vox_ready=None, valid_points_hint=None):
+    def _run_chain(self, points, batch_size, vox_ready=None, valid_points_hint=None, vox_share=None):
         d = {'points': points, 'batch_size': batch_size}
+        if vox_share is not None:                  # the ego branch pillarises the same cloud on the same grid: one pillar list for both
+            d['_pcp_vox_share'] = vox_share
         if vox_ready is not None:                  # the pillariser's first pass already ran inside the compaction (cell ids + histogram)
             d['_pcp_vox_ready'] = vox_ready
         if valid_points_hint is not None:          # masked-copy form: rows of other agents carry frame index -1
@@ -156,7 +158,7 @@ class BEVMaker(nn.Module):
     @torch.no_grad()
     def forward_early(self, batch_dict):
         self.eval()
-        batch_dict['bev_img_early'] = self._run_chain(batch_dict['points'], batch_dict['batch_size'])
+        batch_dict['bev_img_early'] = self._run_chain(batch_dict['points'], batch_dict['batch_size'], vox_share=batch_dict.get('_pcp_vox_share'))
         return batch_dict
 
     def forward(self, batch_dict):

@@ -59,10 +59,17 @@ class CenterPoint(Detector3DTemplate):
                 dead.add(id(m))
         return dead
 
+    # MI355X knob (pipeline mode only: needs the VFEs' persistent buffers): the early-fusion BEV maker and the ego branch pillarise the same
+    # cloud on the same grid -- share the pillar list (DynamicPillarVFE._voxelize).  Off when a corrector moves the points in place.
+    share_voxelization = True
+
     def _run_modules(self, batch_dict):
         from ..bev_layers.bev_maker import BEVMaker
         makers = [m for m in self.module_list if isinstance(m, BEVMaker)]
         dead = self._dead_makers(makers)
+        if (self.share_voxelization and getattr(self, 'corrector', None) is None and batch_dict['points'].is_cuda
+                and any(m.maker_type == 'early' and id(m) not in dead for m in makers) and getattr(self, 'vfe', None) is not None):
+            batch_dict['_pcp_vox_share'] = {}
         # a module in front of the fusion that corrects the points IN PLACE (HunterJr's k_apply_flow) would race with makers still
         # reading them on their own streams: such models run the sequential chain
         if not self.overlap_makers or not makers or not batch_dict['points'].is_cuda or getattr(self, 'corrector', None) is not None:

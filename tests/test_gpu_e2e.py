@@ -905,6 +905,43 @@ def test_fused_weightor_equals_the_launch_per_stage_form():
         assert n >= a['pred_boxes'].shape[0] - 2, (n, worst)
 
 
+@pytest.mark.parametrize('dense', [True, False])
+@pytest.mark.parametrize('overlap', [False, True])
+def test_shared_pillar_list_of_the_early_maker_and_the_ego_branch(overlap, dense):
+    """CenterPoint.share_voxelization: the early-fusion BEV maker and the ego VFE pillarise the same cloud on the same grid (bev_maker.py:212-230,
+    SURVEY F4); in pipeline mode the second one reuses the first one's pillar list (event-ordered across the maker streams, the producer
+    alternating between two workspaces so the previous forward's list survives until the consumer has cleared its persistent canvas from it).
+    Six forwards over alternating clouds of different sizes: every map and detection keeps the bits of the unshared run"""
+    g = load_golden('g1_disco.npz')
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    pts_a = g['points']
+    keep = np.ones(pts_a.shape[0], bool)
+    keep[::3] = False                                    # a second, smaller cloud: other pillars, other counts
+    clouds = [pts_a, pts_a[keep], pts_a, pts_a[keep][::-1].copy(), pts_a[keep], pts_a]
+    runs = []
+    for share in (False, True):
+        model = _build(g)
+        model.share_voxelization = share
+        model.overlap_makers = overlap
+        for m in model.modules():
+            if hasattr(m, 'materialize_pillars'):
+                # dense: persistent canvases cleared from the previous forward's pillar list (what the 360 k-point clouds of the benchmark take)
+                m.materialize_pillars, m.reuse_buffers, m.sparse_first_layer = False, True, not dense
+        outs = []
+        for pts in clouds:
+            batch = {'points': torch.from_numpy(pts).cuda(), 'batch_size': 2, 'metadata': metadata}
+            with torch.no_grad():
+                pred, _ = model(batch)
+            torch.cuda.synchronize()
+            assert ('_pcp_vox_share' in batch and len(batch['_pcp_vox_share']) == 1) == share
+            outs.append((batch['bev_img_early'].clone(), batch['spatial_features_2d'].clone(), [(p['pred_boxes'].clone(), p['pred_scores'].clone()) for p in pred]))
+        runs.append(outs)
+    for (e0, s0, p0), (e1, s1, p1) in zip(*runs):
+        assert torch.equal(e0, e1) and torch.equal(s0, s1)
+        for (b0, c0), (b1, c1) in zip(p0, p1):
+            assert torch.equal(b0, b1) and torch.equal(c0, c1)
+
+
 @pytest.mark.parametrize('overlap', [False, True])
 def test_eliding_dead_makers_keeps_every_output_bit(overlap):
     """CenterPoint.elide_dead_makers skips the BEV-maker passes nothing reads in eval (reference quirk F3, bev_maker.py:157,212-230: the rsu
