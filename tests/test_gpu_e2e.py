@@ -773,6 +773,43 @@ def test_lately_fusion_chain_matches_the_chained_reference(pipeline):
         assert n >= gb.shape[0] - 8, (b, n, gb.shape[0], worst)
 
 
+@pytest.mark.parametrize('pipeline', [False, True])
+def test_lately_fusion_chain_exact_final_set_on_well_conditioned_weights(pipeline):
+    """config 3 end to end at 1e-3: tests/golden/g13_chain.npz is the g10 scene on weights and thresholds under which the
+    reference's final sets -- of all ten remote passes and of the ego pass -- are invariant to 1e-4 perturbations of the head maps
+    (tests/golden/make_golden.py g13c).  The device-side chain (stacked remote pass -> foreground rows -> batched MoDAR ingestion -> ego
+    pass, no host sync) must return EXACTLY the reference's detections: every remote pass's MoDAR boxes and the ego pass's final boxes,
+    same count, one-to-one at 1e-3"""
+    from pcdet.models import build_network_from_meta
+    from pcdet.models.lately_chain import LatelyFusionChain
+    g = load_golden('g13_chain.npz')
+    meta = g['meta']
+    car = build_network_from_meta(meta['car'])
+    st = synth.fill_state_dict(meta['car']['state_shapes'], scheme=str(g['car_weight_scheme']))
+    st['corrector.point_head.seg.0.bias'] = st['corrector.point_head.seg.0.bias'].copy()
+    st['corrector.point_head.seg.0.bias'][0] -= np.float32(meta['car_seg_bias_shift'])
+    car.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    ego = build_network_from_meta(meta['ego'])
+    ego.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(meta['ego']['state_shapes'], scheme=str(g['ego_weight_scheme'])).items()})
+    assert abs(float(meta['car']['model']['DENSE_HEAD']['POST_PROCESSING']['SCORE_THRESH']) - float(g['car_score_thresh'])) < 1e-9
+    chain = LatelyFusionChain(car.cuda().eval(), ego.cuda().eval(), pipeline=pipeline)
+    preds = chain(LatelyFusionChain.build_inputs(_g10_frames(g), torch.device('cuda', 0)))
+    torch.cuda.synchronize()
+    B, n_rem = meta['frames'], len(meta['remote_agents'])
+    ob, os_, ol, cnt = [t.cpu().numpy() for t in chain.last['detections']]
+    for f in range(B):
+        for s_ in range(n_rem):
+            grp, want = f * n_rem + s_, g['modar_%d_%d' % (f, s_)]
+            k = int(cnt[grp])
+            assert want.shape[0] >= 8
+            assert_same_final_set(want[:, :7], want[:, 7], ob[grp, :k], os_[grp, :k], tol=1e-3)
+    for b in range(B):
+        rb, rs = g['ego_boxes_%d' % b], g['ego_scores_%d' % b]
+        assert rb.shape[0] >= 8
+        assert_same_final_set(rb, rs, preds[b]['pred_boxes'].cpu().numpy(), preds[b]['pred_scores'].cpu().numpy(), tol=1e-3)
+        assert np.array_equal(np.sort(preds[b]['pred_labels'].cpu().numpy()), np.sort(g['ego_labels_%d' % b]))
+
+
 def test_lately_fusion_ego_stage_on_the_reference_rows():
     """the ego detector on EXACTLY the augmented cloud the reference built (ego points + its ingested MoDAR rows): pillars bit exact, maps
     1e-3, decode + NMS exact on the reference's head maps"""
