@@ -23,6 +23,7 @@
 //   epilogue: accumulators -> LDS ([36][32 tiles][32 channels], one cout half at a time: 147 KB) -> Y = A^T M A + bias (ReLU) by all 512
 //             threads (unit = tile x channel quad x output row pair) -> 16-byte stores.
 #include "pcp_common.h"
+#include <type_traits>
 
 #ifdef F4_STAMP
 __device__ unsigned long long f4_dbg[8 * 16];                 // [wave][stamp] of workgroup F4_STAMP (diagnostic build only)
@@ -285,11 +286,29 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
     raw_load(min(s + 3, last));
 #endif
 #ifndef F4_NO_PIPELINE_SPEC
+#ifdef F4_PIPE_V2
+    // full pipeline: LDS reads (the A ring's first three fragments + the transform's six raw reads) up front; per MFMA three VALU and one
+    // LDS store (raw stores first -- their data is two slices old --, V stores as the column pass produces them) so that the 61 KB a slice
+    // writes to LDS drain UNDER the matrix work instead of in one burst in front of the barrier; per position the A read three positions
+    // ahead and the next slice's B fragment
+    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+    for (int g = 0; g < 36; g++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // 3 VALU
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 1 LDS store
+      if ((g & 3) == 3) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // A fragment of position + 3
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // B fragment of the next slice
+      }
+    }
+#else
 #pragma unroll
     for (int g = 0; g < 36; g++) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // 3 VALU
     }
+#endif
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #ifdef F4_STAMP
@@ -302,6 +321,107 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
     if (s == 4) F4_STAMP_AT(15);
 #endif
   };
+
+#ifndef F4_STEP_COMPILER
+  // Round 3: the same step as NINE fenced blocks, one per Winograd position of the wave: block pi = the position's four MFMAs + the A read
+  // three positions ahead + the next slice's B fragment + one ninth of the step's other work (raw reads / raw stores / row pass / swaps /
+  // column pass with its V stores).  hipcc's own order put every LDS store of the step (61 KB per workgroup) into one burst in front of the
+  // barrier and sank the A reads to just before their MFMAs (s_waitcnt lgkmcnt(0) nine times a slice); sched_barrier(0) between the blocks
+  // pins the hand order, inside a block the compiler still interleaves freely.
+  auto step_blocks = [&](int s, auto mfma_first_tag) {
+    constexpr bool MF = decltype(mfma_first_tag)::value;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const float *vsrc = vb + cur * F4_V_FLOATS + a_off;
+    const float *tsrc = rawb + nxt * F4_RAW_FLOATS + t_src;
+    float *tdst = vb + nxt * F4_V_FLOATS + t_dst;
+    float *rdstb = rawb + cur * F4_RAW_FLOATS;
+#ifndef F4_RING
+#define F4_RING 3
+#endif
+    f32x4 aq[F4_RING];
+#pragma unroll
+    for (int i = 0; i < F4_RING; i++) aq[i] = *reinterpret_cast<const f32x4 *>(vsrc + i * (32 * F4_VLD));
+    auto mm = [&](int pi) {
+      const f32x4 a = aq[pi % F4_RING];
+      acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[pi].x, acc[pi], 0, 0, 0);
+      acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[pi].y, acc[pi], 0, 0, 0);
+      acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[pi].z, acc[pi], 0, 0, 0);
+      acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[pi].w, acc[pi], 0, 0, 0);
+      if (pi + F4_RING < 9) aq[pi % F4_RING] = *reinterpret_cast<const f32x4 *>(vsrc + (pi + F4_RING) * (32 * F4_VLD));
+      b_load_one(s + 1, pi);
+    };
+    auto rstore = [&](int i) {
+      const f32x4 v = rreg[i];
+      rdstb[rdst[i]] = v.x;
+      rdstb[rdst[i] + F4_PLANE] = v.y;
+      rdstb[rdst[i] + 2 * F4_PLANE] = v.z;
+      rdstb[rdst[i] + 3 * F4_PLANE] = v.w;
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 lo[3];
+    float2 hi[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+      lo[rr] = *reinterpret_cast<const f32x4 *>(tsrc + rr * F4_RP);
+      hi[rr] = *reinterpret_cast<const float2 *>(tsrc + rr * F4_RP + 4);
+    }
+    // SIMD partners (waves w and w + 4) run the two halves of every block in OPPOSITE order: one issues its four MFMAs while the other does
+    // its share of the transform / staging, then they swap -- in lockstep both would queue on the matrix pipe and then both leave it idle
+    // (MI355X_MICROARCH.md "two waves per SIMD", item 9)
+    const auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+    float wr[3][6];
+    float top[3][3], bot[3][3];
+    auto other = [&](int blk) {
+      if (blk == 0) rstore(0);
+      if (blk == 1) { f4_bt6(lo[0].x, lo[0].y, lo[0].z, lo[0].w, hi[0].x, hi[0].y, wr[0]); if (F4_RAW_PER > 1) rstore(1); }
+      if (blk == 2) { f4_bt6(lo[1].x, lo[1].y, lo[1].z, lo[1].w, hi[1].x, hi[1].y, wr[1]); if (F4_RAW_PER > 2) rstore(2); }
+      if (blk == 3) { f4_bt6(lo[2].x, lo[2].y, lo[2].z, lo[2].w, hi[2].x, hi[2].y, wr[2]); raw_load(min(s + 3, last)); }
+      if (blk == 4) {
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(wr[rr][c]), __float_as_uint(wr[rr][3 + c]), false, false);
+            top[rr][c] = __uint_as_float(sw[0]);
+            bot[rr][c] = __uint_as_float(sw[1]);
+          }
+      }
+      if (blk >= 5 && blk <= 7) {
+        const int c = blk - 5;
+        float o[6];
+        f4_bt6(top[0][c], top[1][c], top[2][c], bot[0][c], bot[1][c], bot[2][c], o);
+#pragma unroll
+        for (int i = 0; i < 6; i++) tdst[(i * 6 + c) * (32 * F4_VLD)] = o[i];
+      }
+    };
+#pragma unroll
+    for (int blk = 0; blk < 9; blk++) {
+#ifdef F4_BLOCK_INTERLEAVE
+      if (MF) {                                   // one region per block: let a local pipeline spec weave the block's VALU between its MFMAs
+        mm(blk);
+        other(blk);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+      } else {
+#else
+      if (MF) {
+        mm(blk);
+        fence();
+        other(blk);
+      } else {
+#endif
+        other(blk);
+        fence();
+        mm(blk);
+      }
+      fence();
+    }
+    __syncthreads();
+  };
+#endif
 
   // ---- prologue: raw(0), raw(1) -> LDS; V(0); rreg <- raw(2); B(0) ------------------------------------------------------------------------
   {
@@ -329,7 +449,23 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
   __syncthreads();
 
   F4_STAMP_AT(0);
+#ifndef F4_STEP_COMPILER
+#ifdef F4_STEP_DEPHASE
+  if (cb == 0) {
+    for (int s = 0; s < last; s++) step_blocks(s, std::true_type{});
+  } else {
+    for (int s = 0; s < last; s++) step_blocks(s, std::false_type{});
+  }
+#else
+#ifdef F4_OTHER_FIRST
+  for (int s = 0; s < last; s++) step_blocks(s, std::false_type{});
+#else
+  for (int s = 0; s < last; s++) step_blocks(s, std::true_type{});
+#endif
+#endif
+#else
   for (int s = 0; s < last; s++) step(s);
+#endif
   multiply(last & 1, last);              // the last slice: nothing left to transform or stage (the B reload is a harmless re-read)
   __syncthreads();                       // every wave is done reading V before the epilogue reuses the LDS
   F4_STAMP_AT(1);
