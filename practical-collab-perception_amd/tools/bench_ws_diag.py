@@ -36,15 +36,23 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     pat = os.environ.get('PCP_DIAG_VARIANTS', '')
     libs = {k: v for k, v in libs.items() if k == 'shipped' or k.startswith(pat)}
-    for (cin, cout, H, W) in [(128, 128, 128, 128), (64, 64, 256, 256), (384, 128, 128, 128)]:
+    direct = ENTRY == 'pcp_conv3x3'                 # the direct implicit-GEMM kernel on the backbone's three stride-2 layers
+    shapes = [(64, 64, 512, 512), (64, 128, 256, 256), (128, 256, 128, 128)] if direct else [(128, 128, 128, 128), (64, 64, 256, 256), (384, 128, 128, 128)]
+    for (cin, cout, H, W) in shapes:
         x = torch.randn((B, H, W, cin), device=d)
         w = torch.randn((cout, cin, 3, 3)) * 0.05
         f4 = ENTRY.endswith('4f')
-        pw, bw, cp = (pack.pack_conv3x3_winograd4f if f4 else pack.pack_conv3x3_winograd_ws)(w, torch.zeros(cout))
+        if direct:
+            pw, bw, cp = pack.pack_conv3x3(w, torch.zeros(cout))
+            out = torch.empty((B, H // 2, W // 2, cout), device=d)
+            desc = plib.Conv3x3(B, H, W, cin, cout, cp, 2, cin, cout, 1)
+            flops_exec = 2.0 * B * (H // 2) * (W // 2) * cp * 9 * cin
+        else:
+            pw, bw, cp = (pack.pack_conv3x3_winograd4f if f4 else pack.pack_conv3x3_winograd_ws)(w, torch.zeros(cout))
+            out = torch.empty((B, H, W, cout), device=d)
+            desc = plib.Conv3x3(B, H, W, cin, cout, cp, 1, cin, cout, 1)
+            flops_exec = 2.0 * (36 * (B * H * W / 16) if f4 else 16 * (B * H * W / 4)) * cin * cp
         pw, bw = pw.to(d), bw.to(d)
-        out = torch.empty((B, H, W, cout), device=d)
-        desc = plib.Conv3x3(B, H, W, cin, cout, cp, 1, cin, cout, 1)
-        flops_exec = 2.0 * (36 * (B * H * W / 16) if f4 else 16 * (B * H * W / 4)) * cin * cp
         times = {k: [] for k in libs}
         for rnd in range(7):
             for k, L in libs.items():
