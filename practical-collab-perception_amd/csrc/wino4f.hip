@@ -26,14 +26,14 @@
 #include <type_traits>
 
 #ifdef F4_STAMP
-__device__ unsigned long long f4_dbg[8 * 16];                 // [wave][stamp] of workgroup F4_STAMP (diagnostic build only)
+__device__ unsigned long long f4_dbg[8 * 32];                 // [wave][stamp] of workgroup F4_STAMP (diagnostic build only)
 #define F4_STAMP_AT(slot)                                                                        \
   do {                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if (blockIdx.x == F4_STAMP && lane == 0) {                                                   \
       unsigned long long t_;                                                                     \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
-      f4_dbg[wave * 16 + (slot)] = t_;                                                           \
+      f4_dbg[wave * 32 + (slot)] = t_;                                                           \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
@@ -381,9 +381,14 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
         for (int rr = 0; rr < 3; rr++)
 #pragma unroll
           for (int c = 0; c < 3; c++) {
+#ifdef F4_DIAG_NO_SWAP
+            top[rr][c] = wr[rr][c];                 // timing-only build: wrong values, no cross-lane exchange
+            bot[rr][c] = wr[rr][3 + c];
+#else
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(wr[rr][c]), __float_as_uint(wr[rr][3 + c]), false, false);
             top[rr][c] = __uint_as_float(sw[0]);
             bot[rr][c] = __uint_as_float(sw[1]);
+#endif
           }
       }
       if (blk >= 5 && blk <= 7) {
@@ -394,32 +399,29 @@ __global__ __launch_bounds__(F4_THREADS, 2) void k_wino4f(F4Params p) {
         for (int i = 0; i < 6; i++) tdst[(i * 6 + c) * (32 * F4_VLD)] = o[i];
       }
     };
+#ifdef F4_STAMP
+    if (s == 4) F4_STAMP_AT(16);
+#endif
 #pragma unroll
     for (int blk = 0; blk < 9; blk++) {
-#ifdef F4_BLOCK_INTERLEAVE
-      if (MF) {                                   // one region per block: let a local pipeline spec weave the block's VALU between its MFMAs
-        mm(blk);
-        other(blk);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-      } else {
-#else
       if (MF) {
         mm(blk);
         fence();
         other(blk);
       } else {
-#endif
         other(blk);
         fence();
         mm(blk);
       }
       fence();
+#ifdef F4_STAMP
+      if (s == 4) F4_STAMP_AT(17 + blk);
+#endif
     }
     __syncthreads();
+#ifdef F4_STAMP
+    if (s == 4) F4_STAMP_AT(26);
+#endif
   };
 #endif
 

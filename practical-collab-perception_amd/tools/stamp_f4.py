@@ -21,9 +21,9 @@ for _ in range(3):
 torch.cuda.synchronize()
 L = lib.load()
 L.pcp_debug_read_f4.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-buf = np.zeros(8 * 16, dtype=np.uint64)
+buf = np.zeros(8 * 32, dtype=np.uint64)
 print('rc', L.pcp_debug_read_f4(buf.ctypes.data, buf.nbytes))
-t = buf.reshape(8, 16).astype(np.int64)
+t = buf.reshape(8, 32).astype(np.int64)
 t0 = t[:, 0].min()
 for wv in range(8):
     r = t[wv] - t0
@@ -34,8 +34,8 @@ for wv in range(8):
     else:
         print('wave %d: loop %6d | wait for half 0 %5d | dump %5d | barrier %5d | finish: stage1 %5d stage2+stores %5d' %
               (wv, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[8] - r[4], r[5] - r[8]))
-print('slice 4 of the main loop:')
+print('slice 4 of the main loop (nine fenced blocks; cycles from the slice start to the END of each block, then the barrier):')
 for wv in range(8):
-    r = t[wv] - t[:, 10].min()
-    print('  wave %d: start %5d | transform-first %5d | multiply %5d | stage %5d | transform-last %5d | barrier %5d   (slice %5d)' %
-          (wv, r[10], r[11] - r[10], r[12] - r[11], r[13] - r[12], r[14] - r[13], r[15] - r[14], r[15] - r[10]))
+    r = t[wv] - t[:, 16].min()
+    ends = [int(r[17 + k]) for k in range(9)]
+    print('  wave %d: start %5d | block ends %s | barrier done %5d' % (wv, r[16], ' '.join('%5d' % e for e in ends), r[26]))
