@@ -71,9 +71,11 @@ def parse_args(argv=None):
     ap.add_argument('--elide-dead-makers', action='store_true', help='DiscoNet inference: skip the BEV-maker passes whose output nothing reads '
                     '(reference quirk F3: the rsu map is overwritten by the car maker, bev_img_early feeds only the training loss); pred_dicts are '
                     'bit-identical; reported under its own metric name, never the headline')
+    ap.add_argument('--layer-table', default=None, help='write the per-shape table of the instrumented pass (kernel, shape, launches per step, '
+                    'us per launch, executed TFLOP/s) to this file')
     ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
-    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'bf16x3', 'bf16'],
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'winograd4h', 'bf16x3', 'bf16'],
                     help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
                          '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
     ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
@@ -285,6 +287,12 @@ class AbiTimer:
                 real.pcp_conv3x3_winograd4f_plan(ctypes.byref(d), ctypes.byref(fl))
                 return ('k_wino4f (3x3 s1 fused Winograd F(4x4,3x3), one 8-wave workgroup per CU, v_mfma_f32_32x32x2_f32)', fl.value,
                         2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
+            if name == 'pcp_conv3x3_winograd4h':
+                d = a[0]._obj
+                fl = ctypes.c_double(0.0)
+                real.pcp_conv3x3_winograd4h_plan(ctypes.byref(d), ctypes.byref(fl))
+                return ('k_wino4h (3x3 s1 fused Winograd F(4x4,3x3), two 4-wave workgroups per CU, v_mfma_f32_16x16x4_f32)', fl.value,
+                        2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
             if name == 'pcp_conv3x3_wgrad':
                 # pixel-contraction GEMM of the weight gradient: 64(co) x 64(ci) x 9-tap tiles, padding channels included in `executed`
                 d = a[0]._obj
@@ -315,6 +323,16 @@ class AbiTimer:
                      'pcp_conv3x3_grouped_small': 'k_head_grouped'}.get(name, name)
             return label, None, None, 'latency', None
 
+        def shape_of(name, a):
+            d = getattr(a[0], '_obj', None) if a else None
+            if d is None:
+                return ''
+            if name.startswith('pcp_conv3x3'):
+                return 'B%d %dx%d %d->%d s%d' % (d.batch, d.in_h, d.in_w, d.cin, d.cout, getattr(d, 'stride', 1) or 1)
+            if name == 'pcp_pointwise':
+                return 'mode%d rows %d B%d %dx%d %d->%d' % (d.mode, d.rows, d.batch, d.in_h, d.in_w, d.cin, d.cout)
+            return ''
+
         class Proxy:
             def __getattr__(self, name):
                 fn = getattr(real, name)
@@ -336,7 +354,7 @@ class AbiTimer:
                     e0.record(s)
                     r = fn(*a)
                     e1.record(s)
-                    timer.records.append((e0, e1) + describe(name, a))
+                    timer.records.append((e0, e1) + describe(name, a) + (shape_of(name, a),))
                     return r
                 return wrapped
         lib._LIB = Proxy()
@@ -356,8 +374,16 @@ class AbiTimer:
             f['launches'] += 1
             f['exec_flops'] += ex or 0.0
             f['alg_flops'] += alg or 0.0
-        for (e0, e1, label, ex, alg, bound, peak) in self.records:
-            add(label, e0.elapsed_time(e1), ex, alg, bound, peak)
+        self.layers = {}
+        for (e0, e1, label, ex, alg, bound, peak, shape) in self.records:
+            ms = e0.elapsed_time(e1)
+            add(label, ms, ex, alg, bound, peak)
+            if shape:
+                L = self.layers.setdefault((label.split(' ')[0], shape), [0.0, 0, 0.0, 0.0])
+                L[0] += ms
+                L[1] += 1
+                L[2] += ex or 0.0
+                L[3] += alg or 0.0
         for (a, b, c, gf, alg) in self.w4:
             add('k_w4_input (F(4x4,3x3) input transform)', a, None, None, 'hbm', None)
             add('k_w4_gemm (36 batched GEMMs of the Winograd F(4x4,3x3) wide layers, 128x128x32 LDS tiles, v_mfma_f32_32x32x2_f32)', b, gf, alg,
@@ -663,6 +689,12 @@ def main(argv=None):
     if rank == 0:
         fams = timer.families(INSTR_STEPS)
         timer.remove()
+        if args.layer_table and rank == 0:
+            with open(args.layer_table, 'w') as f:
+                f.write('%-28s %-44s %9s %10s %9s %9s\n' % ('kernel', 'shape', 'per step', 'us/launch', 'exec TF', 'ms/step'))
+                for (lab, shape), (ms, n, ex, alg) in sorted(timer.layers.items(), key=lambda kv: -kv[1][0]):
+                    f.write('%-28s %-44s %9.2f %10.1f %9.1f %9.3f\n' % (lab, shape, n / INSTR_STEPS, ms / n * 1e3, ex / ms / 1e9 if ms else 0.0,
+                                                                     ms / INSTR_STEPS))
         dom = fams[0]
         frames = (world if args.shard == 'frame' else 1) * batch * args.steps
         algo = os.environ.get('PCP_CONV_ALGO', 'auto')
@@ -682,6 +714,10 @@ def main(argv=None):
                      'launches_per_step': round(dom['launches_per_step'], 2),
                      'share_of_kernel_time': round(dom['ms'] / max(sum(f['ms'] for f in fams), 1e-9), 4)})
         mf = [f for f in fams if f['bound'] == 'mfma']
+        # the next matrix-pipe kernels of the step beside the dominant one (the two fused F(4x4) kernels share the 3x3 stride-1 layers)
+        roof['next_mfma_kernels'] = [{'kernel': f['kernel'].split(' ')[0], 'ms_per_step': round(f['ms_per_step'], 4),
+                                      'achieved': round(f['exec_flops'] / max(f['ms'], 1e-9) / 1e9, 3),
+                                      'frac': round(f['exec_flops'] / max(f['ms'], 1e-9) / 1e9 / f['peak'], 4)} for f in mf if f is not dom][:3]
         roof['all_mfma_kernels'] = {'executed_tflops': round(sum(f['exec_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
                                     'algorithmic_tflops': round(sum(f['alg_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
                                     'ms_per_step': round(sum(f['ms_per_step'] for f in mf), 3)}

@@ -151,6 +151,14 @@ int pcp_conv3x3_winograd4f(const pcp_conv3x3_t *desc, const float *in, const flo
                            void *stream);
 int pcp_conv3x3_winograd4f_plan(const pcp_conv3x3_t *desc, double *executed_flops);
 
+/* The same fused F(4x4,3x3) convolution with TWO four-wave workgroups per CU (csrc/wino4h.hip): an item is 16 x 16 output pixels x 64
+ * channels on v_mfma_f32_16x16x4_f32, so one workgroup's prologue / epilogue runs under the other one's MFMAs.  Same descriptor rules as
+ * pcp_conv3x3_winograd4f; weights packed by pcp_amd/pack.py::pack_conv3x3_winograd4h: [cin/8][36 (i*6+j)][cout_pad/64][64 lanes][8], lane
+ * l = 16 kq + c, value 2 nb + ks = U[i][j][input channel 8 s + 4 ks + kq][output channel 64 n + 16 nb + c]. */
+int pcp_conv3x3_winograd4h(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                           void *stream);
+int pcp_conv3x3_winograd4h_plan(const pcp_conv3x3_t *desc, double *executed_flops);
+
 /* Measurement query (bench.py's roofline line): which instantiation pcp_conv3x3_winograd launches for `desc` (variant = 1: 32-tile
  * workgroups k_conv3x3_wino<1>, 2: 64-tile workgroups k_conv3x3_wino<2>) and the flops that launch EXECUTES on the matrix pipe
  * (16 products per 2x2 output tile and (cin, cout) pair, padding tiles and channels included).  Either output may be NULL. */

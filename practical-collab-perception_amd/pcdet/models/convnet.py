@@ -17,7 +17,7 @@ WINOGRAD_MIN_WORKGROUPS = 256
 B3_MIN_WORKGROUPS = 256
 WINOGRAD4_MIN_COUT = 256
 WINOGRAD4_MIN_WORKGROUPS = 512
-CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | winograd4f | bf16x3 (opt-in: split-bf16 products)
+CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | winograd4f | winograd4h | bf16x3 (opt-in: split-bf16 products)
 
 
 def conv_algo():
@@ -37,12 +37,15 @@ def _plain_bf16():
 # (320 workgroups on 256 CUs), and the through-memory F(4x4) path keeps the very wide layers (768 -> 768: x0.84)
 WINOGRAD4F_MIN_WORKGROUPS = 256
 WINOGRAD4F_MAX_CIN = 448
+WINOGRAD4H = os.environ.get('PCP_WINO4H', 'auto')          # auto | 0 (never dispatch k_wino4h)
+WINOGRAD4H_MAX_CIN = 128
+WINOGRAD4H_MIN_WORKGROUPS = 256
 WINOGRAD4F_MAX_INPUT_BYTES = 0x7fffffff                    # buffer-descriptor addressing (tests lower it to exercise the fallback)
 
 
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f', 'w4h')
 
     def _use_winograd4f(self, x, out, out_ch_off, in_ch_off=0):
         algo = conv_algo()
@@ -54,15 +57,41 @@ class PackedConv:
         # Outside them the launch returns PCP_ERR_UNSUPPORTED / PCP_ERR_ARG, so the dispatch falls through to the other kernels instead
         if x.shape[-1] % 4 != 0 or in_ch_off % 4 != 0 or x.numel() * 4 > WINOGRAD4F_MAX_INPUT_BYTES:
             return False
-        if algo == 'winograd4f':
+        if algo in ('winograd4f', 'winograd4h'):
             return True
         B, H, W, _ = x.shape
         wgs = B * ((H + 15) // 16) * ((W + 31) // 32) * (self.w4f[2] // 64)
         if self.cin > WINOGRAD4F_MAX_CIN and getattr(self, 'w4', None) is not None:
             return False
+        if self._prefer_winograd4h(x):
+            return True                                    # the half-size items of k_wino4h also cover grids k_wino4f fills unevenly
         if H * W <= 64 * 64 and self.cin <= 128:
             return False                                   # 8 spatial tiles per frame, 16 K slices: F(2x2) wins (profiles/r02_bench_conv_b*.txt)
         return wgs >= WINOGRAD4F_MIN_WORKGROUPS and (wgs % 256 == 0 or wgs >= 512)
+
+    def _prefer_winograd4h(self, x):
+        """which fused F(4x4) kernel: k_wino4h (two four-wave workgroups per CU, 16 x 16-pixel items: one workgroup's prologue / epilogue
+        under the other's MFMAs) or k_wino4f (one eight-wave workgroup, 16 x 32-pixel items: half the weight traffic per product).
+        Interleaved A/B on MI355X (tools/bench_w4h.py, profiles/r03_wino4h_ab.txt): 4h wins up to 128 input channels wherever its
+        grid covers the chip (>= 256 workgroups), by 3-4 % on full grids and 20-40 % on the grids 4f fills unevenly; 4f keeps cin >= 256."""
+        algo = conv_algo()
+        if algo == 'winograd4h':
+            return True
+        if algo == 'winograd4f' or WINOGRAD4H == '0':
+            return False
+        B, H, W, _ = x.shape
+        nb = self.w4f[2] // 64
+        wgs = B * ((H + 15) // 16) * ((W + 15) // 16) * nb
+        if wgs < WINOGRAD4H_MIN_WORKGROUPS:
+            return False
+        # wider layers only where the eight-wave kernel's 16 x 32-pixel items leave CUs idle (CenterHead's 384 -> 64 conv at 4 frames: 128
+        # items; k_wino4h 95 us against 145 us on the fused F(2x2) kernel that used to take it, tools/bench_conv.py)
+        return self.cin <= WINOGRAD4H_MAX_CIN or B * ((H + 15) // 16) * ((W + 31) // 32) * nb < WINOGRAD4F_MIN_WORKGROUPS
+
+    def _w4h(self):
+        if getattr(self, 'w4h', None) is None:
+            self.w4h = (pack.repack_winograd4f_to_4h(self.w4f[0]), self.w4f[1], self.w4f[2])
+        return self.w4h
 
     def _use_winograd4(self, x):
         algo = conv_algo()
@@ -103,6 +132,10 @@ class PackedConv:
             return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
                                       in_ch_off=in_ch_off, out_ch_off=out_ch_off, plain=_plain_bf16())
         if self._use_winograd4f(x, out, out_ch_off, in_ch_off):
+            if self._prefer_winograd4h(x):
+                u, ub, ucp = self._w4h()
+                return ops.conv3x3_winograd4h(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                              out_ch_off=out_ch_off)
             u, ub, ucp = self.w4f
             return ops.conv3x3_winograd4f(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
                                           out_ch_off=out_ch_off)
@@ -130,7 +163,7 @@ def _winograd4_shape(cin, cout, stride):
 def _winograd4f_shape(cin, cout, stride):
     # layers auto dispatch never sends to the fused kernel (cin above its cap with the through-memory form available) do not get the
     # 4x-sized fused weight form packed at all; PCP_CONV_ALGO=winograd4f packs it for every eligible layer
-    if conv_algo() != 'winograd4f' and cin > WINOGRAD4F_MAX_CIN and _winograd4_shape(cin, cout, stride):
+    if conv_algo() not in ('winograd4f', 'winograd4h') and cin > WINOGRAD4F_MAX_CIN and _winograd4_shape(cin, cout, stride):
         return False
     return (stride == 1 and cin % 8 == 0 and cout % 4 == 0 and cout >= 48 and conv_algo() not in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'))
 
@@ -154,6 +187,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc.b3 = None
     pc.w4 = None
     pc.w4f = None
+    pc.w4h = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -205,4 +239,5 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() in ('bf16x3', 'bf16') and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
     pc.w4 = pack.pack_conv3x3_winograd4(w, b) if _winograd4_shape(pc.cin, pc.cout, stride) else None
     pc.w4f = pack.pack_conv3x3_winograd4f(w, b) if _winograd4f_shape(pc.cin, pc.cout, stride) else None
+    pc.w4h = None
     return pc

@@ -137,6 +137,21 @@ def pack_conv3x3_winograd4f(w, bias):
     return packed, pad_bias(bias, cout_pad), cout_pad
 
 
+def pack_conv3x3_winograd4h(w, bias):
+    """the F(4x4,3x3) filter transform in the fragment order of csrc/wino4h.hip: [cin/8][36][cout_pad/64][64 lanes][8]; lane l = 16 kq + c
+    holds, at index 2 nb + ks, U[position][input channel 8 s + 4 ks + kq][output channel 64 n + 16 nb + c] (the A operand of
+    v_mfma_f32_16x16x4_f32 for the four 16-channel blocks and the two k steps of a slice: two 16-byte loads per lane)"""
+    packed, b, cout_pad = pack_conv3x3_winograd4f(w, bias)                      # [S, 36, cout_pad, 8]
+    return repack_winograd4f_to_4h(packed), b, cout_pad
+
+
+def repack_winograd4f_to_4h(packed):
+    """[cin/8][36][cout_pad][8] (k_wino4f's order) -> k_wino4h's lane order (a pure permutation)"""
+    S, _p, cout_pad, _k = packed.shape
+    v = packed.view(S, 36, cout_pad // 64, 4, 16, 2, 4)                         # [s, pos, n, nb, c, ks, kq]
+    return v.permute(0, 1, 2, 6, 4, 3, 5).contiguous().view(S, 36, cout_pad // 64, 64, 8)
+
+
 def winograd4_reference(x, packed, bias, cout):
     """Plain-torch evaluation of the packed F(4x4,3x3) form with the transforms of csrc/wino4.hip (validates matrices + layout on the
     CPU): x (B, cin, H, W), H, W multiples of 4."""

@@ -69,6 +69,10 @@ def main():
         t4f = timeit(lambda: ops.conv3x3_winograd4f(x, p4f, b4f, cin, cout, cp4f, out=out))
         err4f = float((out - ref).abs().max() / ref.abs().max())
         line += ' | F(4x4) FUSED %8.1f us %6.1f TF (x%.2f vs winograd, diff %.1e)' % (t4f * 1e6, flops / t4f / 1e12, tw / t4f, err4f)
+        p4h = pack.repack_winograd4f_to_4h(p4f)
+        t4h = timeit(lambda: ops.conv3x3_winograd4h(x, p4h, b4f, cin, cout, cp4f, out=out))
+        err4h = float((out - ref).abs().max() / ref.abs().max())
+        line += ' | F(4x4) FUSED 2 WG/CU %8.1f us %6.1f TF (x%.2f vs the 8-wave kernel, diff %.1e)' % (t4h * 1e6, flops / t4h / 1e12, t4f / t4h, err4h)
         if cin % pack.WINO4_CK == 0 and cout % 4 == 0 and cin >= 128:
             ref = out.clone()                                    # bf16x3 result ran last; recompute the fp32 Winograd result as the yardstick
             ops.conv3x3_winograd(x, pw, bw, cin, cout, cpw, out=ref)

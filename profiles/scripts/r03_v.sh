@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3v; mkdir -p $O
+for B in 20 4; do
+PCP_DIAG_VARIANTS=h4_ PCP_DIAG_ENTRY=pcp_conv3x3_winograd4h timeout 900 python practical-collab-perception_amd/tools/bench_ws_diag.py $B 2>&1 | grep -v amdgpu.ids | tee -a $O/h4_variants.txt
+done

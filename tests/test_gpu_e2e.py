@@ -128,16 +128,17 @@ def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monke
         assert (128, 384) in calls and (384, 384) in calls
 
 
+@pytest.mark.parametrize('algo', ['winograd4f', 'winograd4h'])
 @pytest.mark.parametrize('tag', ['car', 'ego', 'disco'])
-def test_reference_outputs_with_every_eligible_layer_forced_onto_fused_winograd4(tag, monkeypatch):
+def test_reference_outputs_with_every_eligible_layer_forced_onto_fused_winograd4(tag, algo, monkeypatch):
     """the mini geometry never reaches the workgroup count at which `auto` picks the FUSED F(4x4,3x3) kernel (csrc/wino4f.hip); force it on
     every stride-1 3x3 layer it supports (backbone blocks, CenterHead, HunterJr, DiscoNet compressor / decompressor) and hold the same
     reference goldens at the same tolerances"""
-    monkeypatch.setenv('PCP_CONV_ALGO', 'winograd4f')
+    monkeypatch.setenv('PCP_CONV_ALGO', algo)                     # winograd4h: the two-workgroups-per-CU kernel (csrc/wino4h.hip) on the same layers
     from pcp_amd import ops
     calls = []
-    orig = ops.conv3x3_winograd4f
-    monkeypatch.setattr(ops, 'conv3x3_winograd4f', lambda *a, **k: (calls.append(a[3:5]), orig(*a, **k))[1])
+    orig = getattr(ops, 'conv3x3_' + algo)
+    monkeypatch.setattr(ops, 'conv3x3_' + algo, lambda *a, **k: (calls.append(a[3:5]), orig(*a, **k))[1])
     if tag == 'disco':
         test_disco_mid_fusion_matches_reference_outputs()
         assert (384, 128) in calls and (128, 384) in calls and (128, 128) in calls and (64, 64) in calls

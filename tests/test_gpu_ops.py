@@ -535,7 +535,10 @@ def test_conv3x3_winograd_ws_channel_windows_and_bad_arguments():
                                                       (384, 64, 16, 32, True, 1), (64, 320, 32, 32, True, 1), (64, 100, 20, 36, False, 2),
                                                       (24, 128, 7, 9, True, 1), (128, 384, 24, 40, True, 1), (128, 128, 64, 64, True, 3),
                                                       (256, 256, 64, 64, True, 1)])
-def test_conv3x3_winograd4f_matches_torch_cpu(cin, cout, h, w, relu, batch):
+@pytest.mark.parametrize('kernel', ['winograd4f', 'winograd4h'])
+def test_conv3x3_winograd4f_matches_torch_cpu(cin, cout, h, w, relu, batch, kernel):
+    """both fused F(4x4) kernels: k_wino4f (eight-wave workgroup, 16 x 32-pixel items) and k_wino4h (two four-wave workgroups per CU,
+    16 x 16-pixel items, csrc/wino4h.hip)"""
     ops = _ops()
     from pcp_amd import pack
     x = torch.from_numpy(_rand(271, (batch, cin, h, w)))
@@ -544,34 +547,37 @@ def test_conv3x3_winograd4f_matches_torch_cpu(cin, cout, h, w, relu, batch):
     want = F.conv2d(x, wt, b, padding=1)
     if relu:
         want = F.relu(want)
-    packed, bp, cpad = pack.pack_conv3x3_winograd4f(wt, b)
+    packed, bp, cpad = getattr(pack, 'pack_conv3x3_' + kernel)(wt, b)
     d = dev()
-    got = ops.conv3x3_winograd4f(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
+    run = getattr(ops, 'conv3x3_' + kernel)
+    got = run(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
     torch.cuda.synchronize()
     # F(4x4) transforms round at ~1e-5 of the output scale (same bar as the through-memory F(4x4) path)
     np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * max(1.0, float(want.abs().max())))
-    got2 = ops.conv3x3_winograd4f(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
+    got2 = run(ops.as_nhwc(x.to(d)), packed.to(d), bp.to(d), cin, cout, cpad, relu=relu)
     assert torch.equal(got, got2)                                            # deterministic
 
 
-def test_conv3x3_winograd4f_channel_windows_and_bad_arguments():
+@pytest.mark.parametrize('kernel', ['winograd4f', 'winograd4h'])
+def test_conv3x3_winograd4f_channel_windows_and_bad_arguments(kernel):
     ops = _ops()
     from pcp_amd import lib, pack
     d = dev()
     cin, cout = 64, 128
     wt = torch.from_numpy(_rand(277, (cout, cin, 3, 3), -0.05, 0.05))
-    packed, bp, cpad = pack.pack_conv3x3_winograd4f(wt, torch.zeros(cout))
+    packed, bp, cpad = getattr(pack, 'pack_conv3x3_' + kernel)(wt, torch.zeros(cout))
+    run = getattr(ops, 'conv3x3_' + kernel)
     x = torch.from_numpy(_rand(278, (1, 48, 40, 96))).to(d)
     out = torch.full((1, 48, 40, 384), 7.0, device=d)
-    ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=16, out_ch_off=128)
+    run(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=16, out_ch_off=128)
     torch.cuda.synchronize()
     assert float((out[..., :128] - 7.0).abs().max()) == 0.0 and float((out[..., 256:] - 7.0).abs().max()) == 0.0
     want = F.conv2d(x[..., 16:80].permute(0, 3, 1, 2).cpu(), wt, None, padding=1)
     np.testing.assert_allclose(out[..., 128:256].permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4)
     with pytest.raises(lib.PcpError):
-        ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), 36, cout, cpad, relu=False, out=out)
+        run(x, packed.to(d), bp.to(d), 36, cout, cpad, relu=False, out=out)
     with pytest.raises(lib.PcpError):
-        ops.conv3x3_winograd4f(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
+        run(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
 
 
 def test_auto_dispatch_falls_back_when_the_fused_f4_kernel_refuses(monkeypatch):
@@ -590,7 +596,13 @@ def test_auto_dispatch_falls_back_when_the_fused_f4_kernel_refuses(monkeypatch):
         setattr(pc, attr, tuple(t.to(d) if torch.is_tensor(t) else t for t in v) if isinstance(v, tuple) else v.to(d))
     x = torch.from_numpy(_rand(281, (8, 128, 128, 72))).to(d)                     # 8 x 8 x 4 = 256 workgroups: auto picks the fused kernel
     assert pc._use_winograd4f(x, None, 0, 4)
-    want = pc.run(x, in_ch_off=4)                                                  # fused F(4x4)
+    assert pc._prefer_winograd4h(x)                                                # 64 input channels, 512 half-size items: k_wino4h
+    want = pc.run(x, in_ch_off=4)                                                  # fused F(4x4), two workgroups per CU
+    monkeypatch.setattr(convnet, 'WINOGRAD4H', '0')
+    assert pc._use_winograd4f(x, None, 0, 4) and not pc._prefer_winograd4h(x)
+    want8 = pc.run(x, in_ch_off=4)                                                 # fused F(4x4), one eight-wave workgroup per CU
+    np.testing.assert_allclose(want8.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-4)
+    monkeypatch.setattr(convnet, 'WINOGRAD4H', 'auto')
     monkeypatch.setattr(convnet, 'WINOGRAD4F_MAX_INPUT_BYTES', 1 << 20)
     assert not pc._use_winograd4f(x, None, 0, 4)
     got = pc.run(x, in_ch_off=4)                                                   # F(2x2): no exception

@@ -299,6 +299,33 @@ def test_winograd_ws_packing_holds_the_same_transformed_weights():
     assert float((got - F.conv2d(x, w, b, padding=1)).abs().max()) < 1e-4
 
 
+def test_winograd4h_weight_order_is_the_documented_permutation_and_dispatch_rule(monkeypatch):
+    """include/pcp_hip.h: k_wino4h's weights are [cin/8][36][cout_pad/64][64 lanes][8] with lane l = 16 kq + c holding, at index 2 nb + ks,
+    U[position][input channel 8 s + 4 ks + kq][output channel 64 n + 16 nb + c]; auto dispatch sends a layer to it up to 128 input channels
+    once its 16 x 16-pixel items cover the chip"""
+    import torch.nn as nn
+    from pcdet.models import convnet
+    from pcp_amd import pack
+    torch.manual_seed(3)
+    w, b = torch.randn(72, 16, 3, 3), torch.randn(72)
+    pf, _bf, cp = pack.pack_conv3x3_winograd4f(w, b)                          # [2, 36, 128, 8]: U[s][pos][cout][k]
+    ph, bh, cph = pack.pack_conv3x3_winograd4h(w, b)
+    assert cph == cp == 128 and tuple(ph.shape) == (2, 36, 2, 64, 8) and torch.equal(bh, _bf)
+    for (s, pos, n, lane, j) in [(0, 0, 0, 0, 0), (1, 35, 1, 63, 7), (0, 17, 1, 37, 5), (1, 4, 0, 22, 2)]:
+        kq, c, nb, ks = lane >> 4, lane & 15, j >> 1, j & 1
+        assert ph[s, pos, n, lane, j] == pf[s, pos, 64 * n + 16 * nb + c, 4 * ks + kq]
+    pc = convnet.pack_conv_module(nn.Conv2d(128, 128, 3, padding=1, bias=False), None, relu=True)
+    assert pc._prefer_winograd4h(torch.empty((20, 64, 64, 128), device='meta'))          # 640 items: the layer F(2x2) used to keep
+    assert pc._use_winograd4f(torch.empty((20, 64, 64, 128), device='meta'), None, 0, 0)
+    assert not pc._prefer_winograd4h(torch.empty((4, 64, 64, 128), device='meta'))       # 128 items: does not cover the chip
+    wide = convnet.pack_conv_module(nn.Conv2d(384, 128, 3, padding=1, bias=False), None, relu=True)
+    assert not wide._prefer_winograd4h(torch.empty((4, 128, 128, 384), device='meta'))   # cin > 128: the eight-wave kernel
+    monkeypatch.setenv('PCP_CONV_ALGO', 'winograd4h')
+    assert wide._prefer_winograd4h(torch.empty((4, 128, 128, 384), device='meta'))
+    monkeypatch.setenv('PCP_CONV_ALGO', 'winograd4f')
+    assert not pc._prefer_winograd4h(torch.empty((20, 64, 64, 128), device='meta'))
+
+
 def test_auto_dispatch_respects_the_fused_f4_kernels_own_limits(monkeypatch):
     """the fused F(4x4) kernel (csrc/wino4f.hip f4_geom) takes 16-byte aligned channel windows and at most 2 GiB of input
     (32-bit buffer-descriptor offsets); auto dispatch must fall through to the other kernels outside those limits instead of raising"""
