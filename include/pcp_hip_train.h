@@ -334,6 +334,12 @@ int pcp_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *direct, int32_t direct_cout_pad,
                      float *winograd, int32_t winograd_cout_pad, void *split_bf16, int32_t split_cout_pad, void *stream);
 
+/* The same per-step repacking into the weight forms of the two fused Winograd F(4x4,3x3) kernels: U = G g G^T (float64, one rounding --
+ * the arithmetic of pcp_amd/pack.py::pack_conv3x3_winograd4f) as u4f [I/8][36][cout_pad][8] (pcp_conv3x3_winograd4f) and / or u4h
+ * [I/8][36][cout_pad/64][64][8] (pcp_conv3x3_winograd4h); either may be NULL.  I % 8 == 0, cout_pad % 64 == 0, cout_pad >= O. */
+int pcp_pack_conv3x3_winograd4(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *u4f, float *u4h, int32_t cout_pad,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,7 +91,63 @@ __global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
   }
 }
 
+// U = G g G^T of Winograd F(4x4,3x3) (float64, one rounding; G as in pcp_amd/pack.py) in the fragment orders of the two fused kernels:
+//   u4f [I/8][36][O_pad][8]                      (csrc/wino4f.hip)
+//   u4h [I/8][36][O_pad/64][64 lanes][8]         (csrc/wino4h.hip: lane = 16 kq + c, index 2 nb + ks <-> channel 4 ks + kq, output 16 nb + c)
+// one thread per (slice, output channel, channel of the slice): 36 stores to each layout.
+struct Pack4Params {
+  const float *w;
+  int cout, cin, transpose;
+  float *u4f, *u4h;
+  int opad;
+};
+
+__global__ __launch_bounds__(256) void k_pack3x3_wino4(Pack4Params q) {
+  const int O = q.transpose ? q.cin : q.cout, I = q.transpose ? q.cout : q.cin;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)(I / 8) * q.opad * 8) return;
+  const int k = (int)(t & 7);
+  long long r = t >> 3;
+  const int o = (int)(r % q.opad);
+  const int s = (int)(r / q.opad);
+  PackParams p{};
+  p.w = q.w; p.cout = q.cout; p.cin = q.cin; p.transpose = q.transpose;
+  double g[3][3];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) g[a / 3][a % 3] = o < O ? (double)eff(p, o, s * 8 + k, a) : 0.0;
+  const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  double gg[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gg[i][j] = G[i][0] * g[0][j] + G[i][1] * g[1][j] + G[i][2] * g[2][j];
+  const int nblk = o >> 6, ol = o & 63;
+  const int lane = 16 * (k & 3) + (ol & 15), idx = 2 * (ol >> 4) + (k >> 2);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float u = (float)(gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2]);
+      const long long pos = (long long)s * 36 + i * 6 + j;
+      if (q.u4f) q.u4f[(pos * q.opad + o) * 8 + k] = u;
+      if (q.u4h) q.u4h[((pos * (q.opad >> 6) + nblk) * 64 + lane) * 8 + idx] = u;
+    }
+}
+
 }  // namespace
+
+extern "C" int pcp_pack_conv3x3_winograd4(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *u4f, float *u4h,
+                                          int32_t cout_pad, void *stream) {
+  if (!w || cout <= 0 || cin <= 0 || (!u4f && !u4h)) return PCP_ERR_ARG;
+  const int O = transpose ? cin : cout, I = transpose ? cout : cin;
+  if ((I & 7) || cout_pad < O || (cout_pad & 63)) return PCP_ERR_ARG;
+  Pack4Params q{w, cout, cin, transpose, u4f, u4h, cout_pad};
+  const long long n = (long long)(I / 8) * cout_pad * 8;
+  hipLaunchKernelGGL(k_pack3x3_wino4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
 
 extern "C" int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *direct, int32_t direct_cout_pad,
                                 float *winograd, int32_t winograd_cout_pad, void *split_bf16, int32_t split_cout_pad, void *stream) {

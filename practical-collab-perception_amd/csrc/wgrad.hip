@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int WG_THREADS = 256;
+constexpr int WG8_THREADS = 512;        // the 3x3 kernel: eight waves, one workgroup per CU
 constexpr int TILE_C = 64;
 
 struct Wg3Params {
@@ -23,20 +24,28 @@ struct Wg3Params {
   int tiles_y, tiles_x, n_tiles, nsplit, ci_tiles, cout_r, cin_r;
 };
 
+// Round 3 form: ONE eight-wave workgroup per CU.  Wave = (quadrant of the 64 x 64 tile, row parity of the pixel tile): two waves per SIMD
+// accumulate the same quadrant over alternate tile rows and are summed through LDS once, at the end of the workgroup.  The pixel tiles are
+// double buffered in LDS: the global loads of tile t+1 are requested (into registers) before the MFMAs of tile t and stored after them, one
+// barrier per tile (the round-2 form staged a tile, waited, multiplied, and relied on the second workgroup of the CU to cover the wait; it
+// also wrote twice as many partial tiles: 2 workgroups x 147 KB per CU).
 template <int S, int TH, int TW>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad3x3(Wg3Params p) {
+__global__ __launch_bounds__(WG8_THREADS, 2) void k_wgrad3x3(Wg3Params p) {
   constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-  constexpr int NPIX = TH * TW;
-  __shared__ __attribute__((aligned(16))) float lds[(NPIX + PH * PW) * TILE_C];
-  float *dyT = lds;                       // [NPIX][64]
-  float *xP = lds + NPIX * TILE_C;        // [PH*PW][64]
+  constexpr int NPIX = TH * TW, NPATCH = PH * PW;
+  constexpr int STAGE = (NPIX + NPATCH) * TILE_C;                       // floats per pipeline stage
+  constexpr int RED = 4 * 9 * 16 * 64;                                  // the end-of-workgroup exchange: [quadrant][tap][register][lane]
+  constexpr int LDS_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
+  constexpr int DY_PER = (NPIX * 16 + WG8_THREADS - 1) / WG8_THREADS, X_PER = (NPATCH * 16 + WG8_THREADS - 1) / WG8_THREADS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int hl = lane >> 5, l32 = lane & 31;
+  const int quad = wave & 3, par = wave >> 2;
   const int co_tile = blockIdx.x / p.ci_tiles, ci_tile = blockIdx.x % p.ci_tiles;
   const int co0 = co_tile * TILE_C, ci0 = ci_tile * TILE_C;
-  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const int wco = (quad >> 1) * 32, wci = (quad & 1) * 32;
 
   f32x16 acc[9];
 #pragma unroll
@@ -44,37 +53,65 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad3x3(Wg3Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int tile = blockIdx.y; tile < p.n_tiles; tile += p.nsplit) {
+  float4 rdy[DY_PER], rx[X_PER];
+  auto gload = [&](int tile) {
     const int tx = tile % p.tiles_x;
     const int ty = (tile / p.tiles_x) % p.tiles_y;
     const int b = tile / (p.tiles_x * p.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
-    __syncthreads();                       // previous tile's MFMA reads are done
-    // dy tile
-    for (int i = tid; i < NPIX * 16; i += WG_THREADS) {
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+#pragma unroll
+    for (int k = 0; k < DY_PER; ++k) {
+      const int i = tid + k * WG8_THREADS;
       const int pix = i >> 4, q = i & 15;
       const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
       const int co = co0 + q * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < p.out_h && ox < p.out_w && co < p.cout)
-        v = *reinterpret_cast<const float4 *>(p.dy + (((long long)b * p.out_h + oy) * p.out_w + ox) * p.ld_dy + co);
-      *reinterpret_cast<float4 *>(dyT + pix * TILE_C + q * 4) = v;
+      rdy[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NPIX * 16 && oy < p.out_h && ox < p.out_w && co < p.cout)
+        rdy[k] = *reinterpret_cast<const float4 *>(p.dy + (((long long)b * p.out_h + oy) * p.out_w + ox) * p.ld_dy + co);
     }
-    // input patch with halo (padding 1)
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    for (int i = tid; i < PH * PW * 16; i += WG_THREADS) {
+#pragma unroll
+    for (int k = 0; k < X_PER; ++k) {
+      const int i = tid + k * WG8_THREADS;
       const int pp = i >> 4, q = i & 15;
       const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
       const int ci = ci0 + q * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w && ci < p.cin)
-        v = *reinterpret_cast<const float4 *>(p.x + (((long long)b * p.in_h + iy) * p.in_w + ix) * p.ld_x + ci);
-      *reinterpret_cast<float4 *>(xP + pp * TILE_C + q * 4) = v;
+      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NPATCH * 16 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w && ci < p.cin)
+        rx[k] = *reinterpret_cast<const float4 *>(p.x + (((long long)b * p.in_h + iy) * p.in_w + ix) * p.ld_x + ci);
     }
-    __syncthreads();
-    // one tile row per trip, the TW/2 pixel pairs fully unrolled: every LDS address is a loop-invariant base + an immediate, so the
-    // body is ds_read_b32 + MFMA only (fp32 MFMA and VALU do not overlap on a gfx950 SIMD: address arithmetic is lost matrix time)
-    for (int py = 0; py < TH; ++py) {
+  };
+  auto lstore = [&](int buf) {
+    float *dyT = lds + buf * STAGE;                 // [NPIX][64]
+    float *xP = dyT + NPIX * TILE_C;                // [PH * PW][64]
+#pragma unroll
+    for (int k = 0; k < DY_PER; ++k) {
+      const int i = tid + k * WG8_THREADS;
+      if (i < NPIX * 16) *reinterpret_cast<float4 *>(dyT + i * 4) = rdy[k];
+    }
+#pragma unroll
+    for (int k = 0; k < X_PER; ++k) {
+      const int i = tid + k * WG8_THREADS;
+      if (i < NPATCH * 16) *reinterpret_cast<float4 *>(xP + i * 4) = rx[k];
+    }
+  };
+
+  int tile = blockIdx.y;
+  if (tile < p.n_tiles) {
+    gload(tile);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < p.n_tiles; tile += p.nsplit) {
+    const int next = tile + p.nsplit;
+    const bool has_next = next < p.n_tiles;
+    if (has_next) gload(next);                       // in flight under this tile's MFMAs
+    const float *dyT = lds + buf * STAGE;
+    const float *xP = dyT + NPIX * TILE_C;
+    // tile rows of this wave's parity, TW/2 pixel pairs per row fully unrolled: every LDS address is a loop-invariant base + an immediate
+#pragma unroll 1
+    for (int py = par; py < TH; py += 2) {
       const float *ab = dyT + (py * TW + hl) * TILE_C + wco + l32;
       const float *xb = xP + ((py * S) * PW + hl * S) * TILE_C + wci + l32;
 #pragma unroll
@@ -89,16 +126,29 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad3x3(Wg3Params p) {
           }
       }
     }
+    if (has_next) lstore(buf ^ 1);                   // the other stage was last read before the previous barrier
+    __syncthreads();
+    buf ^= 1;
   }
-  // partial tile -> workspace [split][tap][co][ci]
-  float *out = p.part + (long long)blockIdx.y * 9 * p.cout_r * p.cin_r;
+  // the two row-parity waves of a quadrant exchange the taps they do not write: parity 0 keeps taps 0..4, parity 1 taps 5..8
+  {
+    float *red = lds + quad * (9 * 16 * 64) + lane;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
+      if ((t < 5) == (par == 1))
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wco + (r >> 2) * 8 + hl * 4 + (r & 3);
-      out[((long long)t * p.cout_r + co) * p.cin_r + ci0 + wci + l32] = acc[t][r];
-    }
+        for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64] = acc[t][r];
+    __syncthreads();
+    float *out = p.part + (long long)blockIdx.y * 9 * p.cout_r * p.cin_r;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      if ((t < 5) == (par == 0))
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wco + (r >> 2) * 8 + hl * 4 + (r & 3);
+          out[((long long)t * p.cout_r + co) * p.cin_r + ci0 + wci + l32] = acc[t][r] + red[(t * 16 + r) * 64];
+        }
+  }
 }
 
 // dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci].  Block = 64 consecutive outputs x 4 split lanes (coalesced 256-B reads per
@@ -233,7 +283,7 @@ inline Wg3Plan plan3(const pcp_conv3x3_t *d) {
   pl.cout_r = round64(d->cout);
   pl.cin_r = round64(d->cin);
   const int pairs = (pl.cout_r / 64) * (pl.cin_r / 64);
-  int ns = 512 / pairs;          // <= 512 blocks: one full wave of 2 workgroups per CU, no second partial wave
+  int ns = 256 / pairs;          // <= 256 blocks: one eight-wave workgroup per CU, no second partial wave
   if (ns > 256) ns = 256;
   if (ns > pl.n_tiles) ns = pl.n_tiles;
   if (ns < 1) ns = 1;
@@ -282,9 +332,9 @@ int pcp_conv3x3_wgrad(const pcp_conv3x3_t *d, const float *x, const float *dy, v
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((pl.cout_r / 64) * (pl.cin_r / 64), pl.nsplit);
   if (d->stride == 1) {
-    hipLaunchKernelGGL((k_wgrad3x3<1, 8, 16>), grid, dim3(WG_THREADS), 0, s, p);
+    hipLaunchKernelGGL((k_wgrad3x3<1, 8, 16>), grid, dim3(WG8_THREADS), 0, s, p);
   } else {
-    hipLaunchKernelGGL((k_wgrad3x3<2, 4, 8>), grid, dim3(WG_THREADS), 0, s, p);
+    hipLaunchKernelGGL((k_wgrad3x3<2, 4, 8>), grid, dim3(WG8_THREADS), 0, s, p);
   }
   const long long total = (long long)9 * d->cout * d->cin;
   hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float *)workspace, pl.nsplit,

@@ -213,6 +213,7 @@ SYMBOLS.update({
                                         c_i64, vp, c_i32, ctypes.POINTER(vp), vp, vp, vp, c_i32, vp]),
     'pcp_grad_sqnorm': (c_i32, [vp, c_i64, vp, c_i32, vp]),
     'pcp_pack_conv3x3': (c_i32, [vp, c_i32, c_i32, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp]),
+    'pcp_pack_conv3x3_winograd4': (c_i32, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
     'pcp_adam_step': (c_i32, [vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, vp, c_f, vp]),
 })
 

@@ -24,6 +24,28 @@ from . import train_ops as tops
 B3_MIN_WORKGROUPS = 256        # the bf16 / bf16x3 conv kernels are used where a launch fills the chip (tests lower it)
 
 
+def fused_f4_choice(B, H, W, cin, cout):
+    """which fused Winograd F(4x4,3x3) kernel a stride-1 3x3 conv cin -> cout on a (B, H, W) map goes to in the training step: None | '4f' |
+    '4h'.  The rule of the inference dispatch (pcdet/models/convnet.py::PackedConv._use_winograd4f / _prefer_winograd4h): k_wino4h up to 128
+    input channels or where k_wino4f's 16 x 32-pixel items leave CUs idle, k_wino4f for the wider layers, neither below one item per CU
+    slot.  PCP_CONV_ALGO = winograd4f | winograd4h forces a kernel (tests), direct | winograd | bf16* switch both off."""
+    algo = os.environ.get('PCP_CONV_ALGO', 'auto')
+    if cin % 8 or cout % 4 or cout < 48 or algo in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'):
+        return None
+    if algo == 'winograd4f':
+        return '4f'
+    if algo == 'winograd4h':
+        return '4h'
+    nb = pack.round_up(cout, 64) // 64
+    w4h = B * ((H + 15) // 16) * ((W + 15) // 16) * nb
+    w4f = B * ((H + 15) // 16) * ((W + 31) // 32) * nb
+    if w4h >= 256 and (cin <= 128 or w4f < 256):
+        return '4h'
+    if cin <= 448 and w4f >= 256 and (w4f % 256 == 0 or w4f >= 512) and not (H * W <= 64 * 64 and cin <= 128):
+        return '4f'
+    return None
+
+
 class StepClock:
     """Packed weights are rebuilt when the optimizer has stepped (weights change through raw pointers, torch cannot tell)."""
     step = 0
@@ -85,10 +107,16 @@ class ConvBNAct:
     # ---- weight forms ----------------------------------------------------------------------------------------------------
     # cached ON THE CONV MODULE (several layer instances may share one module: the weightor runs once per agent) and rebuilt
     # once per optimizer step; 3x3 layouts are written by pcp_pack_conv3x3 into persistent buffers (one launch per direction)
-    def _repack(self):
+    def _repack(self, bhw=None):
+        """bhw: (B, H, W) of the layer input -- decides, once, whether the fused F(4x4) forms are packed (forward: the conv on that map;
+        backward: the data-gradient conv on the same map, for stride 2 on the zero-dilated gradient)"""
         cache = getattr(self.conv, '_pcp_train_pack', None)
         if cache is None:
             cache = self.conv._pcp_train_pack = dict(step=-1)
+        if bhw is not None and self.kind == '3x3' and cache.get('f4_key') != (tuple(bhw), os.environ.get('PCP_CONV_ALGO', 'auto')):
+            cache['f4_key'] = (tuple(bhw), os.environ.get('PCP_CONV_ALGO', 'auto'))
+            cache['f4'] = (fused_f4_choice(*bhw, self.cin, self.cout) if self.stride == 1 else None, fused_f4_choice(*bhw, self.cout, self.cin))
+            cache['step'] = -1
         if cache['step'] == StepClock.step:
             self._fw, self._bw = cache['fw'], cache['bw']
             return
@@ -124,12 +152,32 @@ class ConvBNAct:
             f3, b3 = bufs.get('fw_3'), bufs.get('bw_3')
             tops.pack_conv3x3(wc, False, bufs['fw_d'], fo, fww, fww.shape[2] if fww is not None else 0, f3, pack.round_up(self.cout, 64))
             tops.pack_conv3x3(wc, True, bufs['bw_d'], bo, bww, bww.shape[2] if bww is not None else 0, b3, pack.round_up(self.cin, 64))
+            f4 = cache.get('f4', (None, None))
+            f4fw = f4bw = None
+            for tag, kind, transpose, o in (('fw_4', f4[0], False, self.cout), ('bw_4', f4[1], True, self.cin)):
+                if kind is None:
+                    continue
+                i_ch = self.cin if not transpose else self.cout
+                op4 = pack.round_up(o, 64)
+                key = tag + kind
+                if key not in bufs:
+                    bufs[key] = torch.empty((i_ch // 8) * 36 * op4 * 8, dtype=torch.float32, device=dev)
+                tops.pack_conv3x3_winograd4(wc, transpose, bufs[key] if kind == '4f' else None, bufs[key] if kind == '4h' else None, op4)
+                form = (kind, bufs[key], bias_for(op4, self.cout) if not transpose else zeros, op4)
+                if transpose:
+                    f4bw = form
+                else:
+                    f4fw = form
             fw = dict(direct=(bufs['fw_d'], bias_for(fo, self.cout), fo))
             if fww is not None:
                 fw['wino'] = (fww, bias_for(fww.shape[2], self.cout), fww.shape[2])
             if f3 is not None:
                 fw['b3'] = (f3, bias_for(pack.round_up(self.cout, 64), self.cout), pack.round_up(self.cout, 64))
+            if f4fw is not None:
+                fw['f4'] = f4fw
             bw = dict(direct=(bufs['bw_d'], zeros, bo))
+            if f4bw is not None:
+                bw['f4'] = f4bw
             if bww is not None:
                 bw['wino'] = (bww, zeros, bww.shape[2])
             if b3 is not None:
@@ -166,6 +214,10 @@ class ConvBNAct:
                 w3, b3, cp3 = forms['b3']
                 return ops.conv3x3_bf16x3(x, w3, b3, cin, cout, cp3, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off,
                                           plain=(algo == 'bf16'))
+        if stride == 1 and 'f4' in forms and x.shape[-1] % 4 == 0 and in_off % 4 == 0 and out.shape[-1] % 4 == 0 and out_off % 4 == 0:
+            kind, u, ub, ucp = forms['f4']
+            run = ops.conv3x3_winograd4h if kind == '4h' else ops.conv3x3_winograd4f
+            return run(x, u, ub, cin, cout, ucp, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
         big = B * ((H + 7) // 8) * ((W + 15) // 16) * (forms['wino'][2] // 64) >= 256 if 'wino' in forms else False
         if stride == 1 and 'wino' in forms and algo != 'direct' and (big or algo == 'winograd'):
             u, ub, ucp = forms['wino']
@@ -185,7 +237,7 @@ class ConvBNAct:
 
     def forward(self, x, out=None):
         """x: Act.  out: Act to write the activation into (a channel window of a wider buffer) or None.  Returns Act."""
-        self._repack()
+        self._repack(tuple(x.t.shape[:3]))
         dev = x.t.device
         shp = self.out_shape(x)
         need_post = self.bn is not None or self.relu
@@ -262,7 +314,7 @@ class ConvBNAct:
             gw.add_(g) if accumulate else gw.copy_(g)
         if not need_dx:
             return None
-        self._repack()
+        self._repack(tuple(x.t.shape[:3]))
         if dx_out is None:
             dx_out = Act(torch.empty(tuple(x.t.shape[:-1]) + (self.cin,), dtype=torch.float32, device=dev), 0, self.cin)
         if k == '3x3':

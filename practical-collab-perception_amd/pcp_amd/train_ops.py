@@ -391,6 +391,16 @@ def pack_conv3x3(w, transpose, direct=None, direct_opad=0, wino=None, wino_opad=
                              _stream()), 'pcp_pack_conv3x3')
 
 
+def pack_conv3x3_winograd4(w, transpose, u4f=None, u4h=None, opad=0):
+    """per-step repack of a 3x3 weight into the forms of the fused F(4x4,3x3) kernels (pcp_pack_conv3x3_winograd4); u4f / u4h: persistent
+    float32 buffers of (I/8) * 36 * opad * 8 elements or None"""
+    L = _lib.load()
+    _need_cuda(w, u4f, u4h)
+    assert w.is_contiguous() and w.dtype == torch.float32
+    check(L.pcp_pack_conv3x3_winograd4(_p(w), w.shape[0], w.shape[1], 1 if transpose else 0, _p(u4f), _p(u4h), opad, _stream()),
+          'pcp_pack_conv3x3_winograd4')
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # a17: HunterJr training branch
 # ---------------------------------------------------------------------------------------------------------------------

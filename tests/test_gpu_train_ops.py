@@ -195,7 +195,9 @@ def test_conv_bn_act_layer_forward_backward(kind, cin, cout, bias, with_bn, relu
     conv = _mk_conv(kind, cin, cout, bias, seed)
     bn = _mk_bn(cout, seed) if with_bn else None
     x = _u(seed, 5, (B, cin, H, W))
-    for algo in (('direct', 'winograd') if kind == 'c3s1' else ('auto',)):
+    # c3s1: every forward / data-gradient kernel family (the fused F(4x4) kernels take the layer in `auto` only at full-size maps: forced
+    # here); c3s2: the data gradient (a stride-1 conv on the zero-dilated gradient) through the fused F(4x4) kernel as well
+    for algo in (('direct', 'winograd', 'winograd4f', 'winograd4h') if kind == 'c3s1' else ('auto', 'winograd4h') if kind == 'c3s2' else ('auto',)):
         monkeypatch.setenv('PCP_CONV_ALGO', algo)
         conv.zero_grad()
         if bn is not None:
