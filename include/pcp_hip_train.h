@@ -340,6 +340,27 @@ int pcp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpos
 int pcp_pack_conv3x3_winograd4(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *u4f, float *u4h, int32_t cout_pad,
                                void *stream);
 
+/* All 3x3 layers of a training step repacked by ONE launch.  A job is one (layer, direction): the arguments of pcp_pack_conv3x3 (without the
+ * split-bf16 form) and of pcp_pack_conv3x3_winograd4; any destination may be NULL.  block_start = first block of the job in the grouped
+ * launch (jobs in ascending order: job i covers blocks [block_start_i, block_start_i + pcp_pack_conv3x3_group_blocks(job_i))), total_blocks
+ * their sum.  `jobs_device` is the table in DEVICE memory (it holds device pointers; the caller keeps it and the buffers alive).
+ * _group_blocks: blocks of 256 threads the job needs, -1 for an invalid job (host-side helper, no launch). */
+typedef struct pcp_pack_job {
+  const float *w;              /* (cout, cin, 3, 3) */
+  int32_t cout, cin, transpose;
+  int32_t direct_cout_pad;
+  float *direct;
+  float *winograd;
+  int32_t winograd_cout_pad;
+  int32_t f4_cout_pad;
+  float *u4f;
+  float *u4h;
+  int32_t block_start;
+  int32_t reserved;
+} pcp_pack_job_t;
+int pcp_pack_conv3x3_group_blocks(const pcp_pack_job_t *job);
+int pcp_pack_conv3x3_group(const pcp_pack_job_t *jobs_device, int32_t n_jobs, int32_t total_blocks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,9 +23,8 @@ __device__ __forceinline__ float eff(const PackParams &p, int o, int i, int tap)
   return p.w[((long long)i * p.cin + o) * 9 + (8 - tap)];
 }
 
-__global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
+__device__ __forceinline__ void pack3x3_body(const PackParams &p, const long long t) {
   const int O = p.transpose ? p.cin : p.cout, I = p.transpose ? p.cout : p.cin;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p.direct) {
     const long long total = (long long)(I / 16) * 9 * p.direct_opad * 16;
     if (t < total) {
@@ -91,6 +90,10 @@ __global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_pack3x3(PackParams p) {
+  pack3x3_body(p, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // U = G g G^T of Winograd F(4x4,3x3) (float64, one rounding; G as in pcp_amd/pack.py) in the fragment orders of the two fused kernels:
 //   u4f [I/8][36][O_pad][8]                      (csrc/wino4f.hip)
 //   u4h [I/8][36][O_pad/64][64 lanes][8]         (csrc/wino4h.hip: lane = 16 kq + c, index 2 nb + ks <-> channel 4 ks + kq, output 16 nb + c)
@@ -102,9 +105,8 @@ struct Pack4Params {
   int opad;
 };
 
-__global__ __launch_bounds__(256) void k_pack3x3_wino4(Pack4Params q) {
+__device__ __forceinline__ void pack3x3_wino4_body(const Pack4Params &q, const long long t) {
   const int O = q.transpose ? q.cin : q.cout, I = q.transpose ? q.cout : q.cin;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)(I / 8) * q.opad * 8) return;
   const int k = (int)(t & 7);
   long long r = t >> 3;
@@ -135,7 +137,53 @@ __global__ __launch_bounds__(256) void k_pack3x3_wino4(Pack4Params q) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_pack3x3_wino4(Pack4Params q) {
+  pack3x3_wino4_body(q, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every 3x3 layer of the training step in ONE launch: block -> job by binary search over the jobs' first blocks
+__global__ __launch_bounds__(256) void k_pack3x3_group(const pcp_pack_job_t *__restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pcp_pack_job_t j = jobs[lo];
+  const long long t = (long long)((int)blockIdx.x - j.block_start) * blockDim.x + threadIdx.x;
+  if (j.direct || j.winograd) {
+    PackParams p{};
+    p.w = j.w; p.cout = j.cout; p.cin = j.cin; p.transpose = j.transpose;
+    p.direct = j.direct; p.direct_opad = j.direct_cout_pad; p.wino = j.winograd; p.wino_opad = j.winograd_cout_pad;
+    pack3x3_body(p, t);
+  }
+  if (j.u4f || j.u4h) {
+    Pack4Params q{j.w, j.cout, j.cin, j.transpose, j.u4f, j.u4h, j.f4_cout_pad};
+    pack3x3_wino4_body(q, t);
+  }
+}
+
 }  // namespace
+
+extern "C" int pcp_pack_conv3x3_group_blocks(const pcp_pack_job_t *job) {
+  if (!job || !job->w || job->cout <= 0 || job->cin <= 0) return -1;
+  const int O = job->transpose ? job->cin : job->cout, I = job->transpose ? job->cout : job->cin;
+  if ((job->direct && ((I & 15) || job->direct_cout_pad < O)) || (job->winograd && ((I & 7) || job->winograd_cout_pad < O)) ||
+      ((job->u4f || job->u4h) && ((I & 7) || job->f4_cout_pad < O || (job->f4_cout_pad & 63))))
+    return -1;
+  long long n = 0;
+  if (job->direct) n = (long long)(I / 16) * 9 * job->direct_cout_pad * 16;
+  if (job->winograd) { const long long m = (long long)(I / 8) * job->winograd_cout_pad * 8; if (m > n) n = m; }
+  if (job->u4f || job->u4h) { const long long m = (long long)(I / 8) * job->f4_cout_pad * 8; if (m > n) n = m; }
+  if (n <= 0 || n > 0x7fffffffLL) return -1;
+  return (int)((n + 255) / 256);
+}
+
+extern "C" int pcp_pack_conv3x3_group(const pcp_pack_job_t *jobs_device, int32_t n_jobs, int32_t total_blocks, void *stream) {
+  if (!jobs_device || n_jobs <= 0 || total_blocks <= 0) return PCP_ERR_ARG;
+  hipLaunchKernelGGL(k_pack3x3_group, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
 
 extern "C" int pcp_pack_conv3x3_winograd4(const float *w, int32_t cout, int32_t cin, int32_t transpose, float *u4f, float *u4h,
                                           int32_t cout_pad, void *stream) {

@@ -21,6 +21,14 @@ class Grid(ctypes.Structure):
                 ('nx', c_i32), ('ny', c_i32), ('batch_size', c_i32)]
 
 
+class PackJob(ctypes.Structure):
+    """pcp_pack_job_t (include/pcp_hip_train.h)"""
+    _fields_ = [('w', ctypes.c_void_p), ('cout', ctypes.c_int32), ('cin', ctypes.c_int32), ('transpose', ctypes.c_int32),
+                ('direct_cout_pad', ctypes.c_int32), ('direct', ctypes.c_void_p), ('winograd', ctypes.c_void_p),
+                ('winograd_cout_pad', ctypes.c_int32), ('f4_cout_pad', ctypes.c_int32), ('u4f', ctypes.c_void_p), ('u4h', ctypes.c_void_p),
+                ('block_start', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 class Conv3x3(ctypes.Structure):
     _fields_ = [('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32), ('cout', c_i32), ('cout_pad', c_i32),
                 ('stride', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32)]
@@ -214,6 +222,8 @@ SYMBOLS.update({
     'pcp_grad_sqnorm': (c_i32, [vp, c_i64, vp, c_i32, vp]),
     'pcp_pack_conv3x3': (c_i32, [vp, c_i32, c_i32, c_i32, vp, c_i32, vp, c_i32, vp, c_i32, vp]),
     'pcp_pack_conv3x3_winograd4': (c_i32, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
+    'pcp_pack_conv3x3_group_blocks': (c_i32, [vp]),
+    'pcp_pack_conv3x3_group': (c_i32, [vp, c_i32, c_i32, vp]),
     'pcp_adam_step': (c_i32, [vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, vp, c_f, vp]),
 })
 

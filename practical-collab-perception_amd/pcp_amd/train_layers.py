@@ -46,6 +46,10 @@ def fused_f4_choice(B, H, W, cin, cout):
     return None
 
 
+PACK_GROUP = tops.PackGroup()
+PACK_GROUPING = os.environ.get('PCP_PACK_GROUP', '1') != '0'
+
+
 class StepClock:
     """Packed weights are rebuilt when the optimizer has stepped (weights change through raw pointers, torch cannot tell)."""
     step = 0
@@ -120,6 +124,15 @@ class ConvBNAct:
         if cache['step'] == StepClock.step:
             self._fw, self._bw = cache['fw'], cache['bw']
             return
+        if (self.kind == '3x3' and cache.get('grouped') and PACK_GROUP.has((id(self.conv), False))
+                and cache.get('w_ptr') == self.conv.weight.data_ptr()):
+            # steps after the first: ONE launch repacks every registered 3x3 layer, issued by whichever layer asks first in a step
+            if PACK_GROUP.step != StepClock.step:
+                PACK_GROUP.run(self.conv.weight.device)
+                PACK_GROUP.step = StepClock.step
+            cache['step'] = StepClock.step
+            self._fw, self._bw = cache['fw'], cache['bw']
+            return
         w = self.conv.weight.detach()
         dev = w.device
         zeros = _zeros_like_cache(_ZERO_BIAS, dev, 2048, dev)
@@ -173,6 +186,16 @@ class ConvBNAct:
                 fw['wino'] = (fww, bias_for(fww.shape[2], self.cout), fww.shape[2])
             if f3 is not None:
                 fw['b3'] = (f3, bias_for(pack.round_up(self.cout, 64), self.cout), pack.round_up(self.cout, 64))
+            cache['grouped'] = False
+            if f3 is None and b3 is None and b is None and wc.data_ptr() == w.data_ptr() and PACK_GROUPING:      # (a padded bias is a per-step copy)
+                # the buffers are persistent and the weight tensor is the parameter's own storage: later steps repack through the group launch
+                k4 = lambda form, kind: form[1] if (form is not None and form[0] == kind) else None
+                PACK_GROUP.add((id(self.conv), False), self.conv, wc, False, bufs['fw_d'], fo, fww, fww.shape[2] if fww is not None else 0,
+                               k4(f4fw, '4f'), k4(f4fw, '4h'), f4fw[3] if f4fw is not None else 0)
+                PACK_GROUP.add((id(self.conv), True), self.conv, wc, True, bufs['bw_d'], bo, bww, bww.shape[2] if bww is not None else 0,
+                               k4(f4bw, '4f'), k4(f4bw, '4h'), f4bw[3] if f4bw is not None else 0)
+                cache['grouped'] = True
+                cache['w_ptr'] = wc.data_ptr()
             if f4fw is not None:
                 fw['f4'] = f4fw
             bw = dict(direct=(bufs['bw_d'], zeros, bo))

@@ -401,6 +401,53 @@ def pack_conv3x3_winograd4(w, transpose, u4f=None, u4h=None, opad=0):
           'pcp_pack_conv3x3_winograd4')
 
 
+class PackGroup:
+    """every 3x3 layer of the trainable branch repacked by ONE launch per optimizer step (pcp_pack_conv3x3_group).  A job = (weight, direction)
+    with its persistent destination buffers; `owner` is weakly referenced (the conv module that caches the buffers): jobs of collected
+    modules are dropped before the next launch."""
+
+    def __init__(self):
+        self.jobs = {}              # key -> (weakref to owner, PackJob, tensors kept alive)
+        self.dirty = True
+        self.table = None
+        self.total = 0
+        self.step = -1
+
+    def add(self, key, owner, w, transpose, direct=None, direct_opad=0, wino=None, wino_opad=0, u4f=None, u4h=None, f4_opad=0):
+        import weakref
+        j = _lib.PackJob(_p(w), w.shape[0], w.shape[1], 1 if transpose else 0, direct_opad, _p(direct), _p(wino), wino_opad, f4_opad,
+                         _p(u4f), _p(u4h), 0, 0)
+        if _lib.load().pcp_pack_conv3x3_group_blocks(ctypes.byref(j)) <= 0:
+            raise _lib.PcpError('pcp_pack_conv3x3_group: invalid job')
+        self.jobs[key] = (weakref.ref(owner), j, (w, direct, wino, u4f, u4h))
+        self.dirty = True
+
+    def has(self, key):
+        e = self.jobs.get(key)
+        return e is not None and e[0]() is not None
+
+    def run(self, device):
+        L = _lib.load()
+        dead = [k for k, e in self.jobs.items() if e[0]() is None]
+        for k in dead:
+            del self.jobs[k]
+            self.dirty = True
+        if not self.jobs:
+            return
+        if self.dirty or self.table is None or self.table.device != device:
+            arr = (_lib.PackJob * len(self.jobs))()
+            start = 0
+            for i, (_o, j, _t) in enumerate(self.jobs.values()):
+                j.block_start = start
+                start += L.pcp_pack_conv3x3_group_blocks(ctypes.byref(j))
+                arr[i] = j
+            self.total = start
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = host.to(device)
+            self.dirty = False
+        check(L.pcp_pack_conv3x3_group(_p(self.table), len(self.jobs), self.total, _stream()), 'pcp_pack_conv3x3_group')
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # a17: HunterJr training branch
 # ---------------------------------------------------------------------------------------------------------------------

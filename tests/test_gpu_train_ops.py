@@ -211,6 +211,36 @@ def test_conv_bn_act_layer_forward_backward(kind, cin, cout, bias, with_bn, relu
             _close(mine, ref, 3e-4, '%s/%s/%s' % (kind, algo, k), floor=floor)
 
 
+def test_grouped_weight_repack_equals_the_per_layer_repack_over_several_steps(monkeypatch):
+    """from the second optimizer step on every bias-free 3x3 layer is repacked by ONE launch (pcp_pack_conv3x3_group); three steps of a two-layer
+    stack with an in-place SGD update give bit-identical activations and gradients with the group switched off"""
+    from pcp_amd import train_layers as tl
+
+    def run(grouping):
+        monkeypatch.setattr(tl, 'PACK_GROUPING', grouping)
+        monkeypatch.setattr(tl, 'PACK_GROUP', tl.tops.PackGroup())
+        c1, c2 = _mk_conv('c3s1', 64, 64, False, 91).to(DEV), _mk_conv('c3s2', 64, 128, False, 92).to(DEV)
+        b1, b2 = _mk_bn(64, 93).to(DEV), _mk_bn(128, 94).to(DEV)
+        l1, l2 = tl.ConvBNAct(c1, b1, True, name='g1'), tl.ConvBNAct(c2, b2, True, name='g2')
+        x = _nhwc(_u(95, 1, (2, 64, 32, 48)).to(DEV))
+        outs = []
+        for step in range(3):
+            tl.StepClock.tick()
+            y = l2.forward(l1.forward(tl.Act(x)))
+            g = l1.backward(l2.backward(tl.Act(torch.ones_like(y.t) * 0.01)))
+            outs += [y.t.clone(), g.t.clone(), c1.weight.grad.clone(), c2.weight.grad.clone()]
+            with torch.no_grad():
+                for c in (c1, c2):
+                    c.weight.add_(c.weight.grad, alpha=-0.05)               # in place: the packed forms are stale until the next repack
+        return outs, len(tl.PACK_GROUP.jobs)
+    a, n_a = run(True)
+    b, n_b = run(False)
+    assert n_a == 4 and n_b == 0                                         # two layers x (forward, data gradient) registered
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), i
+    assert not torch.equal(a[0], a[4])                                   # the weights did move between the steps
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # a15: targets, losses
 # ---------------------------------------------------------------------------------------------------------------------
