@@ -39,6 +39,7 @@ def main():
         step()
         torch.cuda.synchronize()
     tally = collections.Counter()
+    dtime = collections.Counter()
     for ev in prof.events():
         if not ev.name.startswith('aten::') or ev.device_time_total <= 0 or ev.cpu_parent is not None and ev.cpu_parent.name.startswith('aten::'):
             continue
@@ -48,9 +49,10 @@ def main():
                 where = fr
                 break
         tally[(ev.name, where)] += 1
-    for (op, where), n in sorted(tally.items(), key=lambda kv: -kv[1]):
-        print('%3d  %-28s %s' % (n, op, where))
-    print('total device-launching aten ops per step:', sum(tally.values()))
+        dtime[(ev.name, where)] += ev.device_time_total
+    for (op, where), n in sorted(tally.items(), key=lambda kv: -dtime[kv[0]]):
+        print('%3d  %8.1f us  %-28s %s' % (n, dtime[(op, where)], op, where))
+    print('total device-launching aten ops per step: %d, %.1f us of device time' % (sum(tally.values()), sum(dtime.values())))
 
 
 if __name__ == '__main__':
