@@ -1,0 +1,85 @@
+"""Software pipelining of consecutive inference batches on one MI355X (pipeline mode, not in the reference).
+
+A detector forward ends with ONE host read -- how many boxes survive per frame (CenterHead.finalize) -- and a DiscoNet forward starts with
+one -- which agents hold points (BEVMaker, reference bev_maker.py:156).  Run batch by batch, each of them drains the GPU: the kernels of the
+next batch are launched only after the read returns, and the first ~0.5 ms of every batch are launch-bound (rocprofv3 kernel trace of
+bench.py: 10 % of the step idle, profiles/r03_gpu_idle_*.txt).  `PipelinedDetector` keeps the device queue full instead:
+
+  submit(batch i):   [side stream]  copy-in of the points + agent histogram + its 528-byte read  (does not wait for batch i-1's kernels)
+                     [main stream]  the whole module chain of batch i, decode, NMS, the gather of the detections, an async copy of the counts
+                     then, on the host, the counts of batch i-1 (finished long ago) -> its exact-shape pred_dicts, which it returns
+  flush():           the pred_dicts of the last submitted batch
+
+Same kernels, same inputs, same order per batch: every batch's pred_dicts are bit-identical to `model(batch_dict)` run batch by batch
+(tests/test_gpu_e2e.py::test_pipelined_detector_*).  Not for models that correct the points in place (HunterJr: the corrector reads what
+the VFE of the same batch wrote -- nothing to gain) nor for training.
+"""
+import torch
+
+from pcp_amd import ops
+
+
+class PipelinedDetector:
+    def __init__(self, model):
+        assert not model.training
+        if getattr(model, 'corrector', None) is not None:
+            raise NotImplementedError('PipelinedDetector: models with a point corrector run batch by batch')
+        self.model = model
+        self.head = model.dense_head
+        self.side = None
+        self._pending = None          # (ob, os_, ol, counts_host, event, batch_size)
+        self._pinned = {}             # two pinned count buffers per batch size, used alternately
+        self._n = 0
+        self._has_makers = any(type(m).__name__ == 'BEVMaker' and m.maker_type in ('rsu', 'car') for m in model.module_list)
+
+    def _discover(self, points, batch_dict):
+        """the agent histogram of a DiscoNet batch on the side stream: its host read waits for that stream only"""
+        ids, rows = ops.column_id_counts(points, -1)
+        batch_dict['_pcp_agent_ids'] = (points, ids, rows)
+
+    @torch.no_grad()
+    def submit(self, points, batch_size, metadata, copy_from=None):
+        """points: (N, C) CUDA tensor the forward reads (it must stay untouched until the NEXT submit returns); copy_from: optional source
+        tensor copied into `points` first (on the side stream), e.g. the upload of the batch.  Returns the pred_dicts of the PREVIOUS
+        batch (None for the first)."""
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        bd = {'points': points, 'batch_size': batch_size, 'metadata': metadata}
+        if copy_from is not None or self._has_makers:
+            with torch.cuda.stream(self.side):
+                if copy_from is not None:
+                    points.copy_(copy_from, non_blocking=True)
+                if self._has_makers:
+                    self._discover(points, bd)
+                ready = self.side.record_event()
+            main.wait_event(ready)
+        self.head.defer_finalize = True
+        try:
+            bd = self.model._run_modules(bd)
+        finally:
+            self.head.defer_finalize = False
+        ob, os_, ol, cnt = self.head.gather_pending(bd['_pcp_pending_head'], batch_size)
+        key = (tuple(cnt.shape), cnt.dtype)
+        if key not in self._pinned:
+            self._pinned[key] = [torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True) for _ in range(2)]
+        counts_host = self._pinned[key][self._n & 1]
+        self._n += 1
+        counts_host.copy_(cnt, non_blocking=True)
+        ev = main.record_event()
+        prev, self._pending = self._pending, (ob, os_, ol, counts_host, ev, batch_size)
+        return self._finish(prev)
+
+    def flush(self):
+        prev, self._pending = self._pending, None
+        return self._finish(prev)
+
+    @staticmethod
+    def _finish(p):
+        if p is None:
+            return None
+        ob, os_, ol, counts_host, ev, batch_size = p
+        ev.synchronize()
+        counts = counts_host.numpy().copy()
+        return [dict(pred_boxes=ob[b, :int(counts[b])], pred_scores=os_[b, :int(counts[b])], pred_labels=ol[b, :int(counts[b])])
+                for b in range(batch_size)]

@@ -1049,6 +1049,48 @@ def test_overlapped_makers_give_the_bits_of_the_sequential_chain():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('overlap', [False, True])
+def test_pipelined_detector_returns_the_bits_of_batch_by_batch_inference(overlap):
+    """pcdet/models/pipelined.py: consecutive DiscoNet batches with the host reads (agent histogram on a side stream, box counts one batch
+    late) taken off the critical path -- six different clouds, every batch's detections bit-identical to `model(batch_dict)`"""
+    from pcdet.models.pipelined import PipelinedDetector
+    g = load_golden('g1_disco.npz')
+    model = _build(g)
+    for m in model.modules():
+        if hasattr(m, 'sparse_first_layer'):
+            m.materialize_pillars, m.reuse_buffers, m.sparse_first_layer = False, True, True
+    model.overlap_makers = overlap
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    base = torch.from_numpy(g['points']).cuda()
+    clouds = []
+    for it in range(6):
+        pts = base.clone()
+        pts[:, 1:3] += 0.017 * it
+        clouds.append(pts)
+    want = []
+    for pts in clouds:
+        with torch.no_grad():
+            pred, _ = model({'points': pts.clone(), 'batch_size': 2, 'metadata': metadata})
+        torch.cuda.synchronize()
+        want.append([{k: v.clone() for k, v in p.items()} for p in pred])
+    pipe = PipelinedDetector(model)
+    bufs = [torch.empty_like(base), torch.empty_like(base)]
+    got = []
+    for i, pts in enumerate(clouds):
+        out = pipe.submit(bufs[i & 1], 2, metadata, copy_from=pts)
+        assert (out is None) == (i == 0)
+        if out is not None:
+            got.append(out)
+    got.append(pipe.flush())
+    assert pipe.flush() is None and len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        for pa, pb in zip(a, b):
+            for k in ('pred_boxes', 'pred_scores', 'pred_labels'):
+                assert pa[k].shape == pb[k].shape and torch.equal(pa[k], pb[k]), (i, k)
+    assert any(not torch.equal(want[0][0]['pred_scores'], w[0]['pred_scores']) for w in want[1:])      # the clouds did differ
+
+
+@pytest.mark.gpu
 def test_recall_record_with_ground_truth_in_eval():
     """Detector3DTemplate.generate_recall_record (detector3d_template.py:347-389 of the reference) when eval batches carry gt_boxes: the
     3-D IoU of every detection with every box (BEV overlap kernel x height overlap) thresholded at RECALL_THRESH_LIST, against the same
