@@ -5,6 +5,7 @@ O=gpurun_out/r3final; mkdir -p $O
 timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 python bench.py --steps 20 --warmup 5 > $O/bench_disco.json 2> $O/bench_disco.err
 python bench.py --steps 20 --warmup 5 --no-overlap --no-cpu-baseline > $O/bench_disco_no_overlap.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-pipeline --no-cpu-baseline > $O/bench_disco_batch_by_batch.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --elide-dead-makers --no-cpu-baseline > $O/bench_disco_elided_dead_makers.json 2>/dev/null
 python bench.py --config car --steps 20 --warmup 5 > $O/bench_car.json 2>/dev/null
 python bench.py --config ego --steps 20 --warmup 5 > $O/bench_ego.json 2>/dev/null
