@@ -237,7 +237,8 @@ class ConvBNAct:
                 w3, b3, cp3 = forms['b3']
                 return ops.conv3x3_bf16x3(x, w3, b3, cin, cout, cp3, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off,
                                           plain=(algo == 'bf16'))
-        if stride == 1 and 'f4' in forms and x.shape[-1] % 4 == 0 and in_off % 4 == 0 and out.shape[-1] % 4 == 0 and out_off % 4 == 0:
+        if (stride == 1 and 'f4' in forms and x.shape[-1] % 4 == 0 and in_off % 4 == 0 and out.shape[-1] % 4 == 0 and out_off % 4 == 0
+                and x.numel() * 4 <= 0x7fffffff):           # the fused kernels' own limits (16-byte windows, 32-bit buffer offsets)
             kind, u, ub, ucp = forms['f4']
             run = ops.conv3x3_winograd4h if kind == '4h' else ops.conv3x3_winograd4f
             return run(x, u, ub, cin, cout, ucp, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
