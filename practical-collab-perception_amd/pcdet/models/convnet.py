@@ -39,7 +39,7 @@ WINOGRAD4F_MIN_WORKGROUPS = 256
 WINOGRAD4F_MAX_CIN = 448
 WINOGRAD4H = os.environ.get('PCP_WINO4H', 'auto')          # auto | 0 (never dispatch k_wino4h)
 WINOGRAD4H_MAX_CIN = 128
-WINOGRAD4H_MIN_WORKGROUPS = 256
+WINOGRAD4H_MIN_WORKGROUPS = int(os.environ.get('PCP_WINO4H_MIN_WGS', '256'))
 WINOGRAD4F_MAX_INPUT_BYTES = 0x7fffffff                    # buffer-descriptor addressing (tests lower it to exercise the fallback)
 
 
