@@ -20,6 +20,13 @@ from pcp_amd import ops
 
 
 class PipelinedDetector:
+    @staticmethod
+    def supports(model):
+        """CenterPoint-style detectors (module chain + CenterHead with a deferred finalize) without a point corrector"""
+        head = getattr(model, 'dense_head', None)
+        return (hasattr(model, '_run_modules') and getattr(model, 'corrector', None) is None and head is not None
+                and hasattr(head, 'gather_pending') and hasattr(head, 'device_postprocess'))
+
     def __init__(self, model):
         assert not model.training
         if getattr(model, 'corrector', None) is not None:
@@ -38,14 +45,15 @@ class PipelinedDetector:
         batch_dict['_pcp_agent_ids'] = (points, ids, rows)
 
     @torch.no_grad()
-    def submit(self, points, batch_size, metadata, copy_from=None):
+    def submit(self, points, batch_size, metadata, copy_from=None, extra=None):
         """points: (N, C) CUDA tensor the forward reads (it must stay untouched until the NEXT submit returns); copy_from: optional source
-        tensor copied into `points` first (on the side stream), e.g. the upload of the batch.  Returns the pred_dicts of the PREVIOUS
-        batch (None for the first)."""
+        tensor copied into `points` first (on the side stream), e.g. the upload of the batch; extra: the other entries of a dataloader's
+        batch_dict (frame ids, ...), passed through to the modules.  Returns the pred_dicts of the PREVIOUS batch (None for the first)."""
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream()
-        bd = {'points': points, 'batch_size': batch_size, 'metadata': metadata}
+        bd = dict(extra) if extra is not None else {}
+        bd.update({'points': points, 'batch_size': batch_size, 'metadata': metadata})
         if copy_from is not None or self._has_makers:
             with torch.cuda.stream(self.side):
                 if copy_from is not None:

@@ -15,8 +15,21 @@ def eval_one_epoch(cfg, args, model, dataloader, epoch_id, logger, dist_test=Fal
     infer_meter = common_utils.AverageMeter()
     model.eval()
     t_start = time.time()
+    # --fast (MI355X pipeline mode): consecutive batches software-pipelined -- the detections of batch i are read back while batch i+1 is
+    # queued (pcdet/models/pipelined.py; same detections, bit for bit).  Not with --infer_time (a per-batch wall time needs the sync).
+    pipe, waiting = None, None
+    if getattr(args, 'fast', False) and not getattr(args, 'infer_time', False):
+        from pcdet.models.pipelined import PipelinedDetector
+        if PipelinedDetector.supports(model):
+            pipe = PipelinedDetector(model)
     for batch_dict in dataloader:
         load_data_to_gpu(batch_dict)
+        if pipe is not None:
+            prev = pipe.submit(batch_dict['points'], batch_dict['batch_size'], batch_dict.get('metadata', None), extra=batch_dict)
+            if prev is not None:
+                det_annos += dataset.generate_prediction_dicts(waiting, prev, class_names)
+            waiting = batch_dict
+            continue
         if getattr(args, 'infer_time', False):
             torch.cuda.synchronize()
             t0 = time.time()
@@ -26,6 +39,8 @@ def eval_one_epoch(cfg, args, model, dataloader, epoch_id, logger, dist_test=Fal
             torch.cuda.synchronize()
             infer_meter.update((time.time() - t0) * 1000)
         det_annos += dataset.generate_prediction_dicts(batch_dict, pred_dicts, class_names)
+    if pipe is not None and waiting is not None:
+        det_annos += dataset.generate_prediction_dicts(waiting, pipe.flush(), class_names)
     if dist_test:
         det_annos = common_utils.merge_results_dist(det_annos, len(dataset))
     rank, _ = common_utils.get_dist_info()

@@ -1150,3 +1150,27 @@ def test_tools_test_py_runs_every_shipped_config(yaml_name, fast):
     assert 'Performance of EPOCH' in out
     m = re.search(r'(\d+) detections over (\d+) frames', out)
     assert m is not None and int(m.group(2)) == 6, out[-1500:]
+
+
+@pytest.mark.gpu
+def test_tools_test_py_fast_mode_pipelines_batches_and_reports_the_same_detections():
+    """`tools/test.py --fast` runs the eval loop through pcdet/models/pipelined.py (batch i read back while batch i+1 is queued); the
+    evaluation report -- detections over frames, per-class counts -- equals the one of the batch-by-batch loop (`--fast --infer_time`
+    keeps the per-batch synchronisation)"""
+    import os
+    import re
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = os.path.join(repo, 'practical-collab-perception_amd', 'tools')
+    reports = []
+    for extra in ([], ['--infer_time']):
+        cmd = [sys.executable, 'test.py', '--cfg_file', 'cfgs/v2x_sim_models/v2x_pointpillar_disco.yaml', '--batch_size', '2', '--fast'] + extra + \
+              ['--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '6000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '7']
+        r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
+        out = r.stdout + r.stderr
+        m = re.search(r'(\d+) detections over (\d+) frames.*', out)
+        assert m is not None and int(m.group(2)) == 7, out[-1500:]
+        reports.append(m.group(0))
+    assert reports[0] == reports[1], reports
