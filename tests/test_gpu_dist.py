@@ -253,3 +253,16 @@ def test_bench_two_ranks_through_the_real_kernels(extra):
     assert 0.55 < ratio < 1.6, (line['value'], one['value'])
     if '--train' not in extra:
         assert cfg['final_boxes_last_step'] > 0
+
+
+def test_bench_pipelined_default_and_batch_by_batch_agree(tmp_path):
+    """bench.py's default inference mode queues step i+1 before it reads step i's box counts (pcdet/models/pipelined.py); --no-pipeline runs
+    batch by batch.  Same workload, same final boxes; the line says which mode it measured; --layer-table writes the per-shape kernel table."""
+    table = tmp_path / 'layers.txt'
+    piped = _bench(['--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--layer-table', str(table)])
+    plain = _bench(['--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-pipeline'])
+    assert 'software-pipelined' in piped['config']['mode'] and 'software-pipelined' not in plain['config']['mode']
+    assert piped['config']['final_boxes_last_step'] == plain['config']['final_boxes_last_step'] > 0
+    assert piped['roofline']['kernel'] == plain['roofline']['kernel'] and piped['roofline']['next_mfma_kernels']
+    rows = table.read_text().splitlines()
+    assert rows[0].split()[:2] == ['kernel', 'shape'] and any(r.startswith('k_wino4h') for r in rows[1:])
