@@ -298,6 +298,10 @@ int pcp_boxes_bev_pairwise(const float *a, int32_t na, const float *b, int32_t n
  * ------------------------------------------------------------------------------------------------------------------ */
 int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst,
                      const float *theta_host, int32_t accumulate, void *stream);
+/* The same warp for n_jobs (source map, destination map, theta) triples of one geometry in ONE launch (the (agent, frame) pairs of a DiscoNet
+ * forward, v2x_fusion_disco.py:88-101): src_host / dst_host are HOST arrays of device pointers, theta_host n_jobs x 6 floats. */
+int pcp_warp_nearest_batch(const float *const *src_host, float *const *dst_host, const float *theta_host, int32_t n_jobs, int32_t h,
+                           int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream);
 /* maps_host: HOST array of n_agents (<= 16) DEVICE pointers, each (pixels, ld_map); weights: (pixels, ld_w) logits, one
  * column per agent; out[p, :] = sum_a softmax_a(weights[p, :])[a] * maps[a][p, :] */
 int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const float *weights, int32_t ld_w, int64_t pixels,

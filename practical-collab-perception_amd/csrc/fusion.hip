@@ -51,6 +51,44 @@ __global__ void k_warp_nearest(const float *__restrict__ src, float *__restrict_
   *o = v;
 }
 
+// every (agent, frame) warp of a DiscoNet forward in ONE launch: blockIdx.y = job; the per-pixel arithmetic is k_warp_nearest's
+constexpr int WARP_MAX_JOBS = 32;
+struct WarpJobs {
+  const float *src[WARP_MAX_JOBS];
+  float *dst[WARP_MAX_JOBS];
+  Theta th[WARP_MAX_JOBS];
+};
+
+__global__ void k_warp_nearest_batch(WarpJobs jobs, int h, int w, int c4, int ld_src, int ld_dst, int accumulate) {
+  const int j = blockIdx.y;
+  const float *__restrict__ src = jobs.src[j];
+  float *__restrict__ dst = jobs.dst[j];
+  const Theta th = jobs.th[j];
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)h * w * c4;
+  if (t >= total) return;
+  int q = (int)(t % c4);
+  int pix = (int)(t / c4);
+  int oy = pix / w, ox = pix % w;
+  float xn = base_coord(ox, w), yn = base_coord(oy, h);
+  float gx = xn * th.t[0] + yn * th.t[1] + th.t[2];
+  float gy = xn * th.t[3] + yn * th.t[4] + th.t[5];
+  float fx = (gx + 1.0f) * ((float)w / 2.0f) - 0.5f;
+  float fy = (gy + 1.0f) * ((float)h / 2.0f) - 0.5f;
+  float rx = nearbyintf(fx), ry = nearbyintf(fy);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1)) {
+    int sx = (int)rx, sy = (int)ry;
+    v = *reinterpret_cast<const float4 *>(src + ((long long)sy * w + sx) * ld_src + q * 4);
+  }
+  float4 *o = reinterpret_cast<float4 *>(dst + (long long)pix * ld_dst + q * 4);
+  if (accumulate) {
+    float4 cur = *o;
+    v.x += cur.x; v.y += cur.y; v.z += cur.z; v.w += cur.w;
+  }
+  *o = v;
+}
+
 constexpr int MAX_AGENTS = 16;
 struct MapPtrs { const float *p[MAX_AGENTS]; };
 
@@ -98,6 +136,27 @@ extern "C" int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t
   hipLaunchKernelGGL(k_warp_nearest, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, dst, h, w,
                      c / 4, ld_src, ld_dst, th, accumulate);
   PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_warp_nearest_batch(const float *const *src_host, float *const *dst_host, const float *theta_host, int32_t n_jobs,
+                                      int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream_) {
+  if (!src_host || !dst_host || !theta_host || n_jobs <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (ld_src & 3) || (ld_dst & 3))
+    return PCP_ERR_ARG;
+  const long long total = (long long)h * w * (c / 4);
+  for (int j0 = 0; j0 < n_jobs; j0 += WARP_MAX_JOBS) {
+    const int n = n_jobs - j0 < WARP_MAX_JOBS ? n_jobs - j0 : WARP_MAX_JOBS;
+    WarpJobs jobs{};
+    for (int j = 0; j < n; j++) {
+      if (!src_host[j0 + j] || !dst_host[j0 + j] || src_host[j0 + j] == dst_host[j0 + j]) return PCP_ERR_ARG;
+      jobs.src[j] = src_host[j0 + j];
+      jobs.dst[j] = dst_host[j0 + j];
+      for (int i = 0; i < 6; i++) jobs.th[j].t[i] = theta_host[(j0 + j) * 6 + i];
+    }
+    hipLaunchKernelGGL(k_warp_nearest_batch, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream_, jobs, h, w,
+                       c / 4, ld_src, ld_dst, accumulate);
+    PCP_CHECK_LAUNCH();
+  }
   return PCP_OK;
 }
 

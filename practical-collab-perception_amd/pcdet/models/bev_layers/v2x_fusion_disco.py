@@ -132,6 +132,7 @@ class V2XMidFusionDisco(PackedModule):
             wbuf = torch.zeros((B, H, W, max(4, (n_maps + 3) // 4 * 4)), dtype=torch.float32, device=dev)
             self._weight(pk, stack[0], stack[0], wbuf, 0)
         pre = batch_dict.get('bev_img_compressed', None)      # agent-sharded execution: maps compressed on the agent's own GPU
+        warps = []                                             # (source map, destination map, theta) of every (agent, frame) pair
         for a, (agent_idx, bev_img) in enumerate(agents, start=1):
             comp = pre[agent_idx] if pre is not None else self._compress(pk, ops.as_nhwc(bev_img))
             for b_idx, meta in enumerate(batch_dict['metadata']):
@@ -139,9 +140,12 @@ class V2XMidFusionDisco(PackedModule):
                     continue
                 T = fusion_host.ego_se3_agent(meta['se3_from_ego'][agent_idx])
                 theta = fusion_host.warp_theta(T, H, W, self.pc_min, self.pix_size)
-                ops.warp_nearest(comp[b_idx], stack[a, b_idx], theta, self.cc)
+                warps.append((comp[b_idx], stack[a, b_idx], theta))
             if not fuse_now:
+                ops.warp_nearest_batch(warps, self.cc)         # this agent's frames in one launch, then its weight logits
+                warps = []
                 self._weight(pk, stack[0], stack[a], wbuf, a)
+        ops.warp_nearest_batch(warps, self.cc)                 # fused weightor: every pair of the forward in ONE launch
         fused = torch.empty((B, H, W, self.cc), dtype=torch.float32, device=dev)
         if fuse_now:
             wf = pk['wf']

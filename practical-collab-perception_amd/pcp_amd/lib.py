@@ -144,6 +144,7 @@ SYMBOLS = {
     'pcp_nms_normal': (c_i32, [vp, vp, c_i32, c_i32, vp, c_f, c_i32, c_i32, vp, c_sz, vp, vp, vp]),
     'pcp_boxes_bev_pairwise': (c_i32, [vp, c_i32, vp, c_i32, c_i32, vp, vp]),
     'pcp_warp_nearest': (c_i32, [vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp]),
+    'pcp_warp_nearest_batch': (c_i32, [vp, vp, ctypes.POINTER(c_f), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
     'pcp_disco_weight_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, c_i32, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i32, vp, c_i32, vp]),
     'pcp_bev_sample_bilinear': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp,

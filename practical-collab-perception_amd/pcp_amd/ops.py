@@ -447,6 +447,24 @@ def warp_nearest(src, dst, theta, channels, accumulate=False, src_ch_off=0, dst_
                              1 if accumulate else 0, _stream()), 'pcp_warp_nearest')
 
 
+def warp_nearest_batch(jobs, channels, accumulate=False):
+    """jobs: list of (src, dst, theta) with (H, W, ld) single-frame maps of ONE geometry; all the warps in one launch (pcp_warp_nearest_batch),
+    pixel for pixel what warp_nearest gives job by job"""
+    if not jobs:
+        return
+    L = _lib.load()
+    _need_cuda(*[t for s_, d_, _t in jobs for t in (s_, d_)])
+    H, W, ld_s = jobs[0][0].shape
+    ld_d = jobs[0][1].shape[2]
+    for s_, d_, _t in jobs:
+        assert tuple(s_.shape) == (H, W, ld_s) and tuple(d_.shape[:2]) == (H, W) and d_.shape[2] == ld_d
+    n = len(jobs)
+    src = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _d, _t in jobs])
+    dst = (ctypes.c_void_p * n)(*[d_.data_ptr() for _s, d_, _t in jobs])
+    th = (ctypes.c_float * (6 * n))(*[float(v) for _s, _d, t in jobs for v in t])
+    check(L.pcp_warp_nearest_batch(src, dst, th, n, H, W, channels, ld_s, ld_d, 1 if accumulate else 0, _stream()), 'pcp_warp_nearest_batch')
+
+
 def softmax_fuse(maps, weights, channels, out):
     """maps: list of (B, H, W, ld_map) tensors (same ld); weights: (B, H, W, ld_w) logits, column a <-> maps[a]."""
     _need_cuda(weights, out, *maps)

@@ -365,6 +365,32 @@ def test_nms_sizes_against_oracle(n):
 # ---------------------------------------------------------------------------------------------------------------------
 # a11 / a12
 # ---------------------------------------------------------------------------------------------------------------------
+def test_warp_nearest_batch_is_the_job_by_job_warp():
+    """pcp_warp_nearest_batch (every (agent, frame) pair of a DiscoNet forward in one launch, chunks of 32 jobs) against pcp_warp_nearest job by
+    job: identical bits, with and without accumulation"""
+    ops = _ops()
+    d = dev()
+    rng = np.random.RandomState(11)
+    H, W, C = 40, 40, 8
+    jobs, want = [], []
+    for j in range(37):                                              # two launches: 32 + 5
+        src = torch.from_numpy(rng.uniform(-1, 1, (H, W, C + 4)).astype(np.float32)).to(d)
+        a = rng.uniform(-0.6, 0.6)
+        theta = [float(np.cos(a)), float(-np.sin(a)), float(rng.uniform(-0.4, 0.4)), float(np.sin(a)), float(np.cos(a)), float(rng.uniform(-0.4, 0.4))]
+        dst = torch.full((H, W, C), 0.25 * j, device=d)
+        ref = dst.clone()
+        jobs.append((src, dst, theta))
+        want.append((src, ref, theta))
+    for acc in (False, True):
+        for src, ref, theta in want:
+            ops.warp_nearest(src, ref, theta, C, accumulate=acc)
+        ops.warp_nearest_batch(jobs, C, accumulate=acc)
+        torch.cuda.synchronize()
+        for (_s, got, _t), (_s2, ref, _t2) in zip(jobs, want):
+            assert torch.equal(got, ref)
+    ops.warp_nearest_batch([], C)                                    # nothing to do
+
+
 def test_warp_nearest_matches_golden():
     ops = _ops()
     from pcp_amd import fusion_host
