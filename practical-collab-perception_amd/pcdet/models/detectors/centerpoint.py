@@ -81,7 +81,9 @@ class CenterPoint(Detector3DTemplate):
         main = torch.cuda.current_stream()
         if getattr(self, '_maker_streams', None) is None or len(self._maker_streams) != len(makers):
             self._maker_streams = [torch.cuda.Stream() for _ in makers]
-        ready = main.record_event()
+        # the makers read only the batch's points: in the pipelined mode (pcdet/models/pipelined.py) those were written on a side stream whose
+        # event is handed in, so the maker streams of batch i+1 need not wait for the main stream to finish batch i's head / decode / NMS
+        ready = batch_dict.get('_pcp_points_ready', None) or main.record_event()
         joins = []
 
         def join_all():

@@ -14,6 +14,8 @@ Same kernels, same inputs, same order per batch: every batch's pred_dicts are bi
 (tests/test_gpu_e2e.py::test_pipelined_detector_*).  Not for models that correct the points in place (HunterJr: the corrector reads what
 the VFE of the same batch wrote -- nothing to gain) nor for training.
 """
+import os
+
 import torch
 
 from pcp_amd import ops
@@ -37,6 +39,8 @@ class PipelinedDetector:
         self._pending = None          # (ob, os_, ol, counts_host, event, batch_size)
         self._pinned = {}             # two pinned count buffers per batch size, used alternately
         self._n = 0
+        # PCP_PIPELINE_EARLY_MAKERS=0: the maker streams of batch i+1 wait for the main stream (i.e. for batch i's tail), as `model()` does
+        self.early_makers = os.environ.get('PCP_PIPELINE_EARLY_MAKERS', '1') != '0'
         self._has_makers = any(type(m).__name__ == 'BEVMaker' and m.maker_type in ('rsu', 'car') for m in model.module_list)
 
     def _discover(self, points, batch_dict):
@@ -62,6 +66,8 @@ class PipelinedDetector:
                     self._discover(points, bd)
                 ready = self.side.record_event()
             main.wait_event(ready)
+            if copy_from is not None and self.early_makers:
+                bd['_pcp_points_ready'] = ready              # the BEV-maker streams start from here, not from the main stream's position
         self.head.defer_finalize = True
         try:
             bd = self.model._run_modules(bd)

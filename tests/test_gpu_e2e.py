@@ -919,6 +919,55 @@ def test_exact_final_set_on_well_conditioned_fixtures(case, pipeline):
             assert np.array_equal(np.sort(pred[b]['pred_labels'].cpu().numpy()), np.sort(rl))
 
 
+@pytest.mark.parametrize('case,n_batches', [('disco', 40), ('disco_full', 10), ('ego_full', 8)])
+def test_pipelined_detector_stress_many_batches_mini_and_full_size(case, n_batches):
+    """pcdet/models/pipelined.py with the BEV-maker streams of batch i+1 starting while batch i's trunk / fusion / head still run (two batches
+    in flight): many consecutive batches of DIFFERENT clouds at the mini size and at BASELINE's full size -- every batch's boxes, scores and
+    labels bit-identical to batch-by-batch `model(batch_dict)` (a cross-batch race on a persistent buffer would show up as a mismatch)"""
+    from pcdet.models.pipelined import PipelinedDetector
+    g = load_golden('g13_conditioned.npz')
+    model = _g13_model(g, case)
+    for m in model.modules():
+        if hasattr(m, 'materialize_pillars'):
+            m.materialize_pillars, m.reuse_buffers, m.sparse_first_layer = False, True, True
+    if hasattr(model, 'overlap_makers') and case.startswith('disco'):
+        model.overlap_makers = True
+    pts, B = _g13_points(case)
+    if case == 'disco':
+        metadata = [{'se3_from_ego': {0: g['disco_pose_0'], 2: g['disco_pose_2']}}, {'se3_from_ego': {0: g['disco_pose_0']}}]
+    elif case == 'disco_full':
+        metadata = [{'se3_from_ego': {a: g['disco_full_pose_%d' % a] for a in (0, 2, 3, 4, 5)}}]
+    else:
+        metadata = [{} for _ in range(B)]
+    base = torch.from_numpy(pts.copy()).cuda()
+    variants = []
+    for k in range(4):                                              # four different clouds, cycled
+        v = base.clone()
+        v[:, 1:3] += 0.011 * k
+        variants.append(v)
+    want = []
+    for v in variants:
+        with torch.no_grad():
+            pred, _ = model({'points': v.clone(), 'batch_size': B, 'metadata': metadata})
+        torch.cuda.synchronize()
+        want.append([{k: t.clone() for k, t in p.items()} for p in pred])
+    assert any(not torch.equal(want[0][0]['pred_scores'], w[0]['pred_scores']) or w[0]['pred_scores'].shape != want[0][0]['pred_scores'].shape
+               for w in want[1:])
+    pipe = PipelinedDetector(model)
+    bufs = [torch.empty_like(base), torch.empty_like(base)]
+    got = []
+    for i in range(n_batches):
+        out = pipe.submit(bufs[i & 1], B, metadata, copy_from=variants[i % 4])
+        if out is not None:
+            got.append(out)
+    got.append(pipe.flush())
+    assert len(got) == n_batches
+    for i, preds in enumerate(got):
+        for pa, pb in zip(preds, want[i % 4]):
+            for k in ('pred_boxes', 'pred_scores', 'pred_labels'):
+                assert pa[k].shape == pb[k].shape and torch.equal(pa[k], pb[k]), (i, k)
+
+
 def test_fused_weightor_equals_the_launch_per_stage_form():
     """V2XMidFusionDisco with the pixel weightor + softmax + weighted sum as ONE launch (pcp_disco_weight_fuse) against the round-2 form
     (three pointwise launches per map + k_softmax_fuse) on the DiscoNet mini fixture: fused map within 2e-5, identical final detections"""
