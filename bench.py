@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-pipeline', action='store_true', help='inference without a point corrector (ego / early / disco): run batch by batch, every '
                     "step ending in its own host read, instead of pcdet/models/pipelined.py (the next step's kernels are queued before the "
                     "previous step's box counts are read; all K steps and their K reads still lie inside the timed region)")
+    ap.add_argument('--pipeline-replicas', type=int, default=2, help='pipelined inference: 2 = consecutive steps alternate between the model and a '
+                    'deep copy of it on two HIP streams (step i+1 may run beside step i); 1 = one model, steps in order on one stream')
     ap.add_argument('--elide-dead-makers', action='store_true', help='DiscoNet inference: skip the BEV-maker passes whose output nothing reads '
                     '(reference quirk F3: the rsu map is overwritten by the car maker, bev_img_early feeds only the training loss); pred_dicts are '
                     'bit-identical; reported under its own metric name, never the headline')
@@ -633,7 +635,7 @@ def main(argv=None):
     if (not args.no_pipeline and not args.plugin_default and not args.train and not args.graph and args.shard == 'frame' and lately is None
             and getattr(model, 'corrector', None) is None and hasattr(model, '_run_modules')):
         from pcdet.models.pipelined import PipelinedDetector
-        pipelined = PipelinedDetector(model)
+        pipelined = PipelinedDetector(model, replicas=max(1, args.pipeline_replicas))
         work_bufs = [work, torch.empty_like(pristine)]
     pipe_state = {'n': 0}
 
@@ -771,7 +773,7 @@ def main(argv=None):
                                  '(kernel_ms_per_step and roofline come from an extra single-stream pass)' if overlapped else '') +
                                 ('; consecutive steps software-pipelined (pcdet/models/pipelined.py): the agent histogram is read on a side '
                                  'stream and the box counts of step i after step i+1 is queued, all reads inside the timed region '
-                                 '(--no-pipeline: batch by batch)' if was_pipelined else '') +
+                                 '(--no-pipeline: batch by batch)' + ('; steps alternate between %d replicas of the model on their own streams' % args.pipeline_replicas if args.pipeline_replicas > 1 else '') if was_pipelined else '') +
                                 '; outputs equal to the plugin-default path (tests/test_gpu_e2e.py::test_pipeline_mode_*, test_overlapped_makers_*)'),
                        'peak_device_memory_mb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
                        **({'elided': 'rsu BEV maker (overwritten by the car maker) and early BEV maker (training-only output): reference quirk F3'} if args.elide_dead_makers else {}),

@@ -108,8 +108,9 @@ class DynamicPillarVFE(VFETemplate):
                                 workspace=self._workspace if self.reuse_buffers else None)
         # Two VFEs of one forward that pillarise the SAME cloud on the SAME grid (DiscoNet: the early-fusion BEV maker and the ego branch
         # both see all points, bev_maker.py:212-230 / SURVEY F4) share one pillar list: the first to arrive builds it, the other waits for
-        # its event and only runs its own PFN.  The producer alternates between two workspaces so that the list of the previous forward is
-        # still intact when the consumer clears its persistent canvas from it.
+        # its event and only runs its own PFN.  The producer rotates through THREE workspaces: the consumer of forward i still reads the list
+        # of forward i-1 (it clears its persistent canvas from it), and in the pipelined mode (pcdet/models/pipelined.py) the producer of
+        # forward i+1 may already run then -- with two workspaces it would overwrite exactly that list (stale canvas rows for good).
         key = (points.data_ptr(), int(points.shape[0]), int(points.shape[1]), grid.nx, grid.ny, grid.batch_size, grid.min_x, grid.min_y, grid.min_z,
                grid.voxel_x, grid.voxel_y, grid.voxel_z)
         cur = torch.cuda.current_stream()
@@ -120,8 +121,13 @@ class DynamicPillarVFE(VFETemplate):
             for t in (vox.workspace, vox.voxel_coords, vox.counters):
                 t.record_stream(cur)
             return vox
-        self._workspace, self._workspace_alt = getattr(self, '_workspace_alt', None), self._workspace
-        vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=self._workspace)
+        ring = getattr(self, '_ws_ring', None)
+        if ring is None:
+            ring = self._ws_ring = [None, None, None]
+            self._ws_idx = -1
+        self._ws_idx = (self._ws_idx + 1) % 3
+        vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=ring[self._ws_idx])
+        ring[self._ws_idx] = vox.workspace
         share[key] = (vox, cur.record_event())
         return vox
 

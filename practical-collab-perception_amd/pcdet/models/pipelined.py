@@ -29,11 +29,26 @@ class PipelinedDetector:
         return (hasattr(model, '_run_modules') and getattr(model, 'corrector', None) is None and head is not None
                 and hasattr(head, 'gather_pending') and hasattr(head, 'device_postprocess'))
 
-    def __init__(self, model):
+    def __init__(self, model, replicas=1):
+        """replicas = 2: consecutive batches alternate between the model and a deep copy of it (same weights, its own persistent buffers and
+        packed weight forms), each on its own HIP stream -- batch i+1's whole forward may then run beside batch i's instead of behind it
+        (launches that leave CUs idle, e.g. the one-round layers at four frames, the head, decode and NMS, are filled by the other batch).
+        Batches of one replica stay in order on its stream; the two replicas share nothing mutable (the library's scratch buffers are keyed
+        by stream)."""
         assert not model.training
         if getattr(model, 'corrector', None) is not None:
             raise NotImplementedError('PipelinedDetector: models with a point corrector run batch by batch')
         self.model = model
+        self.models = [model]
+        if replicas > 1:
+            import copy
+            streams = getattr(model, '_maker_streams', None)
+            model._maker_streams = None                      # HIP streams are not copyable: every replica makes its own
+            try:
+                self.models += [copy.deepcopy(model) for _ in range(replicas - 1)]
+            finally:
+                model._maker_streams = streams
+        self.mains = None
         self.head = model.dense_head
         self.side = None
         self._pending = None          # (ob, os_, ol, counts_host, event, batch_size)
@@ -53,9 +68,16 @@ class PipelinedDetector:
         """points: (N, C) CUDA tensor the forward reads (it must stay untouched until the NEXT submit returns); copy_from: optional source
         tensor copied into `points` first (on the side stream), e.g. the upload of the batch; extra: the other entries of a dataloader's
         batch_dict (frame ids, ...), passed through to the modules.  Returns the pred_dicts of the PREVIOUS batch (None for the first)."""
-        main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream()
+            if len(self.models) > 1:
+                self.mains = [torch.cuda.Stream() for _ in self.models]
+        r = self._n % len(self.models)
+        model = self.models[r]
+        head = model.dense_head
+        main = self.mains[r] if self.mains is not None else torch.cuda.current_stream()
+        if self.mains is not None:
+            main.wait_stream(torch.cuda.current_stream())    # whatever the caller queued before (first batches: nothing)
         bd = dict(extra) if extra is not None else {}
         bd.update({'points': points, 'batch_size': batch_size, 'metadata': metadata})
         if copy_from is not None or self._has_makers:
@@ -68,19 +90,20 @@ class PipelinedDetector:
             main.wait_event(ready)
             if copy_from is not None and self.early_makers:
                 bd['_pcp_points_ready'] = ready              # the BEV-maker streams start from here, not from the main stream's position
-        self.head.defer_finalize = True
-        try:
-            bd = self.model._run_modules(bd)
-        finally:
-            self.head.defer_finalize = False
-        ob, os_, ol, cnt = self.head.gather_pending(bd['_pcp_pending_head'], batch_size)
-        key = (tuple(cnt.shape), cnt.dtype)
-        if key not in self._pinned:
-            self._pinned[key] = [torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True) for _ in range(2)]
-        counts_host = self._pinned[key][self._n & 1]
-        self._n += 1
-        counts_host.copy_(cnt, non_blocking=True)
-        ev = main.record_event()
+        with torch.cuda.stream(main):
+            head.defer_finalize = True
+            try:
+                bd = model._run_modules(bd)
+            finally:
+                head.defer_finalize = False
+            ob, os_, ol, cnt = head.gather_pending(bd['_pcp_pending_head'], batch_size)
+            key = (tuple(cnt.shape), cnt.dtype)
+            if key not in self._pinned:
+                self._pinned[key] = [torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True) for _ in range(2)]
+            counts_host = self._pinned[key][self._n & 1]
+            self._n += 1
+            counts_host.copy_(cnt, non_blocking=True)
+            ev = main.record_event()
         prev, self._pending = self._pending, (ob, os_, ol, counts_host, ev, batch_size)
         return self._finish(prev)
 
@@ -94,6 +117,9 @@ class PipelinedDetector:
             return None
         ob, os_, ol, counts_host, ev, batch_size = p
         ev.synchronize()
+        cur = torch.cuda.current_stream()
+        for t in (ob, os_, ol):
+            t.record_stream(cur)                             # allocated on the replica's stream, consumed on the caller's
         counts = counts_host.numpy().copy()
         return [dict(pred_boxes=ob[b, :int(counts[b])], pred_scores=os_[b, :int(counts[b])], pred_labels=ol[b, :int(counts[b])])
                 for b in range(batch_size)]

@@ -919,8 +919,9 @@ def test_exact_final_set_on_well_conditioned_fixtures(case, pipeline):
             assert np.array_equal(np.sort(pred[b]['pred_labels'].cpu().numpy()), np.sort(rl))
 
 
+@pytest.mark.parametrize('replicas', [1, 2])
 @pytest.mark.parametrize('case,n_batches', [('disco', 40), ('disco_full', 10), ('ego_full', 8)])
-def test_pipelined_detector_stress_many_batches_mini_and_full_size(case, n_batches):
+def test_pipelined_detector_stress_many_batches_mini_and_full_size(case, n_batches, replicas):
     """pcdet/models/pipelined.py with the BEV-maker streams of batch i+1 starting while batch i's trunk / fusion / head still run (two batches
     in flight): many consecutive batches of DIFFERENT clouds at the mini size and at BASELINE's full size -- every batch's boxes, scores and
     labels bit-identical to batch-by-batch `model(batch_dict)` (a cross-batch race on a persistent buffer would show up as a mismatch)"""
@@ -953,7 +954,7 @@ def test_pipelined_detector_stress_many_batches_mini_and_full_size(case, n_batch
         want.append([{k: t.clone() for k, t in p.items()} for p in pred])
     assert any(not torch.equal(want[0][0]['pred_scores'], w[0]['pred_scores']) or w[0]['pred_scores'].shape != want[0][0]['pred_scores'].shape
                for w in want[1:])
-    pipe = PipelinedDetector(model)
+    pipe = PipelinedDetector(model, replicas=replicas)        # 2: batches alternate between the model and a deep copy on two streams
     bufs = [torch.empty_like(base), torch.empty_like(base)]
     got = []
     for i in range(n_batches):
