@@ -635,6 +635,9 @@ def main(argv=None):
     if (not args.no_pipeline and not args.plugin_default and not args.train and not args.graph and args.shard == 'frame' and lately is None
             and getattr(model, 'corrector', None) is None and hasattr(model, '_run_modules')):
         from pcdet.models.pipelined import PipelinedDetector
+        shared_device = world > 1 and backend == 'gloo'            # functional check: several ranks on one GPU -- no second replica each
+        if shared_device:
+            args.pipeline_replicas = 1
         pipelined = PipelinedDetector(model, replicas=max(1, args.pipeline_replicas))
         work_bufs = [work, torch.empty_like(pristine)]
     pipe_state = {'n': 0}
