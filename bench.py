@@ -640,6 +640,8 @@ def main(argv=None):
             args.pipeline_replicas = 1
         pipelined = PipelinedDetector(model, replicas=max(1, args.pipeline_replicas))
         work_bufs = [work, torch.empty_like(pristine)]
+        work.copy_(pristine)
+        pipelined.prepare(work, batch, metas)       # setup: every replica builds its packed weights / buffers once, before the W warm-up steps
     pipe_state = {'n': 0}
 
     def step():

@@ -107,6 +107,15 @@ class PipelinedDetector:
         prev, self._pending = self._pending, (ob, os_, ol, counts_host, ev, batch_size)
         return self._finish(prev)
 
+    def prepare(self, points, batch_size, metadata):
+        """one forward per replica (results discarded): each replica builds its packed weight forms and persistent buffers on first use --
+        setup work, like building the model, that must not land in a measured or latency-critical batch"""
+        for _ in self.models:
+            self.submit(points, batch_size, metadata)
+        self.flush()
+        torch.cuda.synchronize()
+        self._n = 0
+
     def flush(self):
         prev, self._pending = self._pending, None
         return self._finish(prev)
