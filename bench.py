@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     'materialised (one host sync per VFE), dense canvas, no buffer reuse')
     ap.add_argument('--no-overlap', action='store_true', help='run the BEV-maker passes of a DiscoNet forward one after the other on the '
                                                                 'main stream (the pipeline mode overlaps them on side streams)')
-    ap.add_argument('--no-pipeline', action='store_true', help='inference without a point corrector (ego / early / disco): run batch by batch, every '
+    ap.add_argument('--no-pipeline', action='store_true', help='inference (car / ego / early / disco): run batch by batch, every '
                     "step ending in its own host read, instead of pcdet/models/pipelined.py (the next step's kernels are queued before the "
                     "previous step's box counts are read; all K steps and their K reads still lie inside the timed region)")
     ap.add_argument('--pipeline-replicas', type=int, default=2, help='pipelined inference: 2 = consecutive steps alternate between the model and a '
@@ -633,8 +633,9 @@ def main(argv=None):
 
     pipelined = None
     if (not args.no_pipeline and not args.plugin_default and not args.train and not args.graph and args.shard == 'frame' and lately is None
-            and getattr(model, 'corrector', None) is None and hasattr(model, '_run_modules')):
+            and hasattr(model, '_run_modules')):
         from pcdet.models.pipelined import PipelinedDetector
+        assert PipelinedDetector.supports(model)
         shared_device = world > 1 and backend == 'gloo'            # functional check: several ranks on one GPU -- no second replica each
         if shared_device:
             args.pipeline_replicas = 1

@@ -11,8 +11,8 @@ bench.py: 10 % of the step idle, profiles/r03_gpu_idle_*.txt).  `PipelinedDetect
   flush():           the pred_dicts of the last submitted batch
 
 Same kernels, same inputs, same order per batch: every batch's pred_dicts are bit-identical to `model(batch_dict)` run batch by batch
-(tests/test_gpu_e2e.py::test_pipelined_detector_*).  Not for models that correct the points in place (HunterJr: the corrector reads what
-the VFE of the same batch wrote -- nothing to gain) nor for training.
+(tests/test_gpu_e2e.py::test_pipelined_detector_*).  A model that corrects the points in place (HunterJr) works on its batch's own buffer
+(`points` of submit(), refilled through `copy_from`); not for training.
 """
 import os
 
@@ -26,8 +26,13 @@ class PipelinedDetector:
     def supports(model):
         """CenterPoint-style detectors (module chain + CenterHead with a deferred finalize) without a point corrector"""
         head = getattr(model, 'dense_head', None)
-        return (hasattr(model, '_run_modules') and getattr(model, 'corrector', None) is None and head is not None
+        return (hasattr(model, '_run_modules') and not PipelinedDetector._corrector_with_makers(model) and head is not None
                 and hasattr(head, 'gather_pending') and hasattr(head, 'device_postprocess'))
+
+    @staticmethod
+    def _corrector_with_makers(model):
+        # a corrector (HunterJr) rewrites the batch's points in place: fine on the batch's own buffer, not beside BEV makers that read them
+        return getattr(model, 'corrector', None) is not None and any(type(m).__name__ == 'BEVMaker' for m in model.module_list)
 
     def __init__(self, model, replicas=1):
         """replicas = 2: consecutive batches alternate between the model and a deep copy of it (same weights, its own persistent buffers and
@@ -36,8 +41,8 @@ class PipelinedDetector:
         Batches of one replica stay in order on its stream; the two replicas share nothing mutable (the library's scratch buffers are keyed
         by stream)."""
         assert not model.training
-        if getattr(model, 'corrector', None) is not None:
-            raise NotImplementedError('PipelinedDetector: models with a point corrector run batch by batch')
+        if self._corrector_with_makers(model):
+            raise NotImplementedError('PipelinedDetector: a point corrector beside BEV makers runs batch by batch')
         self.model = model
         self.models = [model]
         if replicas > 1:

@@ -920,7 +920,7 @@ def test_exact_final_set_on_well_conditioned_fixtures(case, pipeline):
 
 
 @pytest.mark.parametrize('replicas', [1, 2])
-@pytest.mark.parametrize('case,n_batches', [('disco', 40), ('disco_full', 10), ('ego_full', 8)])
+@pytest.mark.parametrize('case,n_batches', [('disco', 40), ('disco_full', 10), ('ego_full', 8), ('car_full', 8)])
 def test_pipelined_detector_stress_many_batches_mini_and_full_size(case, n_batches, replicas):
     """pcdet/models/pipelined.py with the BEV-maker streams of batch i+1 starting while batch i's trunk / fusion / head still run (two batches
     in flight): many consecutive batches of DIFFERENT clouds at the mini size and at BASELINE's full size -- every batch's boxes, scores and
