@@ -644,6 +644,15 @@ def main(argv=None):
         work.copy_(pristine)
         pipelined.prepare(work, batch, metas)       # setup: every replica builds its packed weights / buffers once, before the W warm-up steps
     pipe_state = {'n': 0}
+    lately_pipe = None
+    if (lately is not None and not args.no_pipeline and not args.plugin_default and not args.graph
+            and not (world > 1 and backend == 'gloo')):
+        from pcdet.models.lately_chain import PipelinedChain
+        lately_pipe = PipelinedChain(lately, replicas=max(1, args.pipeline_replicas))
+        lately_sets = [lately_inputs, dict(lately_inputs, remote_points=lately_pristine.clone())]      # two input sets, used alternately
+        for st_ in lately_sets:
+            st_['remote_points'].copy_(lately_pristine)
+        lately_pipe.prepare(lately_sets)
 
     def step():
         if pipelined is not None:
@@ -657,6 +666,12 @@ def main(argv=None):
             return train_step()
         if graphed is not None:
             return graphed(pristine)            # copy-in + every kernel of the path = one graph replay
+        if lately_pipe is not None:
+            i = pipe_state['n']
+            pipe_state['n'] = i + 1
+            cur_set = lately_sets[i & 1]
+            cur_set['remote_points'].copy_(lately_pristine)           # HunterJr corrects xyz in place: every step starts from the same bits
+            return lately_pipe.submit(cur_set)                        # pred_dicts of the PREVIOUS step
         if lately is not None:
             lately_inputs['remote_points'].copy_(lately_pristine)     # HunterJr corrects xyz in place: every step starts from the same bits
             return lately(lately_inputs)
@@ -670,6 +685,8 @@ def main(argv=None):
         step()
     if pipelined is not None:
         pipelined.flush()
+    if lately_pipe is not None:
+        lately_pipe.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -677,6 +694,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         preds = step()
+    if lately_pipe is not None:
+        preds = lately_pipe.flush()
     if pipelined is not None:
         preds = pipelined.flush()               # the last step's host read: all K reads lie inside the timed region
     torch.cuda.synchronize()
@@ -704,8 +723,9 @@ def main(argv=None):
     # every rank has to take part in the extra steps; only rank 0 records.
     INSTR_STEPS = 3
     timer = None
-    was_pipelined = pipelined is not None
+    was_pipelined = pipelined is not None or lately_pipe is not None
     pipelined = None                            # the instrumented pass runs batch by batch
+    lately_pipe = None
     if rank == 0:
         graphed = None                          # the instrumented pass runs eagerly (events around individual launches)
         if getattr(model, 'overlap_makers', False):

@@ -811,6 +811,50 @@ def test_lately_fusion_chain_exact_final_set_on_well_conditioned_weights(pipelin
         assert np.array_equal(np.sort(preds[b]['pred_labels'].cpu().numpy()), np.sort(g['ego_labels_%d' % b]))
 
 
+@pytest.mark.parametrize('replicas', [1, 2])
+def test_pipelined_lately_chain_returns_the_bits_of_the_chain(replicas):
+    """pcdet/models/lately_chain.py::PipelinedChain (config 3 with the box counts of batch i read after batch i+1 is queued, optionally two
+    copies of the chain on their own streams): 12 batches over three different scenes, every batch's detections bit-identical to
+    LatelyFusionChain.__call__"""
+    from pcdet.models.lately_chain import LatelyFusionChain, PipelinedChain
+    g = load_golden('g10_lately_chain.npz')
+    car, ego = _g10_models(g)
+    chain = LatelyFusionChain(car, ego, pipeline=True)
+    dev_ = torch.device('cuda', 0)
+    scenes = []
+    for k in range(3):
+        frames = _g10_frames(g)
+        for fr in frames:
+            fr['remote'] = [c.copy() for c in fr['remote']]
+            for c in fr['remote']:
+                c[:, 0:2] += 0.02 * k
+        scenes.append(LatelyFusionChain.build_inputs(frames, dev_))
+    pristine = [sc['remote_points'].clone() for sc in scenes]
+    want = []
+    for sc, pr in zip(scenes, pristine):
+        sc['remote_points'].copy_(pr)
+        pred = chain(sc)
+        torch.cuda.synchronize()
+        want.append([{k: t.clone() for k, t in p.items()} for p in pred])
+    assert any(w[0]['pred_scores'].shape != want[0][0]['pred_scores'].shape or not torch.equal(w[0]['pred_scores'], want[0][0]['pred_scores'])
+               for w in want[1:])
+    pipe = PipelinedChain(chain, replicas=replicas)
+    sets = [[dict(sc, remote_points=sc['remote_points'].clone()) for sc in scenes] for _ in range(2)]       # two input sets per scene
+    got = []
+    for i in range(12):
+        cur = sets[i & 1][i % 3]
+        cur['remote_points'].copy_(pristine[i % 3])
+        out = pipe.submit(cur)
+        if out is not None:
+            got.append(out)
+    got.append(pipe.flush())
+    assert len(got) == 12
+    for i, preds in enumerate(got):
+        for pa, pb in zip(preds, want[i % 3]):
+            for k in ('pred_boxes', 'pred_scores', 'pred_labels'):
+                assert pa[k].shape == pb[k].shape and torch.equal(pa[k], pb[k]), (i, k)
+
+
 def test_lately_fusion_ego_stage_on_the_reference_rows():
     """the ego detector on EXACTLY the augmented cloud the reference built (ego points + its ingested MoDAR rows): pillars bit exact, maps
     1e-3, decode + NMS exact on the reference's head maps"""
