@@ -51,6 +51,10 @@ class PipelinedDetector:
             model._maker_streams = None                      # HIP streams are not copyable: every replica makes its own
             try:
                 self.models += [copy.deepcopy(model) for _ in range(replicas - 1)]
+            except Exception as e:                           # a model that cannot be copied still pipelines, on one replica
+                import warnings
+                warnings.warn('PipelinedDetector: the model could not be deep-copied (%s): one replica' % e)
+                self.models = [model]
             finally:
                 model._maker_streams = streams
         self.mains = None
