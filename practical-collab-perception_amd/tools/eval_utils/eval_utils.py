@@ -21,7 +21,7 @@ def eval_one_epoch(cfg, args, model, dataloader, epoch_id, logger, dist_test=Fal
     if getattr(args, 'fast', False) and not getattr(args, 'infer_time', False):
         from pcdet.models.pipelined import PipelinedDetector
         if PipelinedDetector.supports(model):
-            pipe = PipelinedDetector(model)
+            pipe = PipelinedDetector(model, replicas=2)         # batches alternate between the model and a copy on their own streams
     for batch_dict in dataloader:
         load_data_to_gpu(batch_dict)
         if pipe is not None:
