@@ -640,10 +640,9 @@ def main(argv=None):
         pristine = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
 
     pipelined = None
+    from pcdet.models.pipelined import PipelinedDetector
     if (not args.no_pipeline and not args.plugin_default and not args.train and not args.graph and args.shard == 'frame' and lately is None
-            and hasattr(model, '_run_modules')):
-        from pcdet.models.pipelined import PipelinedDetector
-        assert PipelinedDetector.supports(model)
+            and PipelinedDetector.supports(model)):          # anything else (a head without a deferred finalize, ...) runs batch by batch
         shared_device = world > 1 and backend == 'gloo'            # functional check: several ranks on one GPU -- no second replica each
         if shared_device:
             args.pipeline_replicas = 1

@@ -99,6 +99,7 @@ class DynamicPillarVFE(VFETemplate):
         self._prev_vox = None
 
     def _voxelize(self, points, grid, batch_dict, want_inverse):
+        self._vox_borrowed = False
         ready = batch_dict.get('_pcp_vox_ready', None)
         if ready is not None and not want_inverse:
             return ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=ready['workspace'], cells_ready=True)
@@ -120,6 +121,7 @@ class DynamicPillarVFE(VFETemplate):
             cur.wait_event(ev)
             for t in (vox.workspace, vox.voxel_coords, vox.counters):
                 t.record_stream(cur)
+            self._vox_borrowed = True       # the producer VFE owns this workspace (one of its three ring slots): never adopt it
             return vox
         ring = getattr(self, '_ws_ring', None)
         if ring is None:
@@ -158,7 +160,7 @@ class DynamicPillarVFE(VFETemplate):
                 self._pf_buf = torch.empty((rows, 64), dtype=torch.float32, device=dev)
             ops.pfn_scatter(points, vox, self.num_raw_point_features, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=None,
                             pillar_features=self._pf_buf)
-            if self.reuse_buffers:
+            if self.reuse_buffers and not self._vox_borrowed:
                 self._workspace = vox.workspace
             batch_dict['_pcp_vfe'] = dict(canvas=None, vox=vox, pillar_rows=self._pf_buf)
             return batch_dict
@@ -181,7 +183,8 @@ class DynamicPillarVFE(VFETemplate):
         ops.pfn_scatter(points, vox, self.num_raw_point_features, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=canvas,
                         pillar_features=pf)
         if self.reuse_buffers:
-            self._workspace = vox.workspace
+            if not self._vox_borrowed:      # a borrowed list is still what the next canvas clear reads (_prev_vox), but a later un-shared
+                self._workspace = vox.workspace     # forward must pillarise into this VFE's OWN workspace, not into the producer's ring
             self._prev_vox = vox
         if self.materialize_pillars:
             num_pillars = int(vox.counters[0].item())            # the one host sync of the drop-in mode

@@ -91,8 +91,14 @@ class HunterTrain:
         # ---- locals / instances, object head
         meta = tops.hunter_meta(pts0, B, M, S, sweep_col=m.meta_sweep_col, inst_col=m.meta_inst_col)
         if meta.bad_rows:
-            raise ValueError('%d foreground rows carry a frame / instance / sweep index outside (batch %d, gt rows %d, NUM_SWEEPS %d)'
-                             % (meta.bad_rows, B, M, S))
+            # pcp_hunter_meta already treats such rows as background (they join no local group and no instance); a long run is not
+            # aborted for one mislabelled row -- the count is kept and reported once
+            self.out_of_table_rows = getattr(self, 'out_of_table_rows', 0) + meta.bad_rows
+            if not getattr(self, '_warned_out_of_table', False):
+                import warnings
+                warnings.warn('HunterJr training: %d foreground rows carry a frame / instance / sweep index outside (batch %d, gt rows %d, '
+                              'NUM_SWEEPS %d); they are treated as background (running count: .out_of_table_rows)' % (meta.bad_rows, B, M, S))
+                self._warned_out_of_table = True
         s = dict(B=B, H=H, W=W, C=C, N=N, cat=cat, pts0=pts0, pf=pf, local_feat=local_feat, head=head, meta=meta, gt=gt, itf=itf,
                  min_xy=min_xy, pix=pix, M=M, S=S)
         if meta.n_fg > 0:

@@ -27,7 +27,17 @@ class PipelinedDetector:
         """CenterPoint-style detectors (module chain + CenterHead with a deferred finalize) without a point corrector"""
         head = getattr(model, 'dense_head', None)
         return (hasattr(model, '_run_modules') and not PipelinedDetector._corrector_with_makers(model) and head is not None
-                and hasattr(head, 'gather_pending') and hasattr(head, 'device_postprocess'))
+                and hasattr(head, 'gather_pending') and hasattr(head, 'device_postprocess')
+                and not PipelinedDetector._head_writes_exchange_data(head))
+
+    @staticmethod
+    def _head_writes_exchange_data(head):
+        # GENERATING_EXCHANGE_DATA / RETURN_MODAR_POINTS are served AFTER the finalize of CenterHead.forward (the *_modar.pth files and
+        # batch_dict['mo_pts'] of the reference's exchange-database workflow, center_head.py:207-223); a deferred finalize would skip
+        # them silently, so such a head runs batch by batch
+        cfg = getattr(head, 'model_cfg', None)
+        get = (lambda k: cfg.get(k, False)) if hasattr(cfg, 'get') else (lambda k: getattr(cfg, k, False))
+        return bool(cfg is not None and (get('GENERATING_EXCHANGE_DATA') or get('RETURN_MODAR_POINTS')))
 
     @staticmethod
     def _corrector_with_makers(model):
@@ -43,6 +53,8 @@ class PipelinedDetector:
         assert not model.training
         if self._corrector_with_makers(model):
             raise NotImplementedError('PipelinedDetector: a point corrector beside BEV makers runs batch by batch')
+        if self._head_writes_exchange_data(model.dense_head):
+            raise NotImplementedError('PipelinedDetector: a head that writes exchange data (MoDAR) runs batch by batch')
         self.model = model
         self.models = [model]
         if replicas > 1:
@@ -90,6 +102,12 @@ class PipelinedDetector:
         bd = dict(extra) if extra is not None else {}
         bd.update({'points': points, 'batch_size': batch_size, 'metadata': metadata})
         if copy_from is not None or self._has_makers:
+            if copy_from is None:
+                # the caller filled `points` itself: whatever did that on the caller's stream (a non_blocking upload, a preprocessing
+                # kernel) is ordered in front of the side stream's reads.  With copy_from the contract is a host-visible source
+                # (pinned / pageable memory or a tensor that is complete): the side stream must NOT wait for the caller's stream, which
+                # with one replica is the stream batch i-1 still runs on
+                self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 if copy_from is not None:
                     points.copy_(copy_from, non_blocking=True)

@@ -18,15 +18,32 @@ from ..utils import v2x_exchange as ex
 from .bev_layers.bev_maker import BEVMaker
 
 
-def _select_frames(points, frames):
-    """rows of the given frames, renumbered 0..len(frames)-1 in that order (row order inside a frame is preserved)"""
-    col = points[:, 0]
-    out = []
-    for j, f in enumerate(frames):
-        rows = points[col == float(f)].clone()
-        rows[:, 0] = float(j)
-        out.append(rows)
-    return torch.cat(out, 0).contiguous() if out else points[:0]
+def _select_frames(points, frames, batch_size):
+    """rows of the given frames, renumbered 0..len(frames)-1 in that order (row order inside a frame is preserved).  One stable
+    compaction on the device (pcp_select_transform_compact with the FRAME column as the selector and identity poses: slot j takes the
+    rows of frames[j]) and ONE 4-byte host read of the kept-row count -- not a boolean mask + host sync per frame."""
+    import numpy as np
+    n = points.shape[0]
+    if not frames or n == 0:
+        return points[:0]
+    assert max(frames) < 64, 'frame ids are compared as the compaction kernel compares agent ids (0..63)'
+    eye = np.zeros((12,), np.float32)
+    eye[[0, 5, 10]] = 1.0
+    parts = []
+    per = max(1, min(8, 64 // batch_size))                                   # <= 8 slots and <= 64 (slot, frame) entries per launch
+    for lo in range(0, len(frames), per):
+        fr = frames[lo:lo + per]
+        S = len(fr)
+        present = np.zeros((S, batch_size), np.uint8)
+        for j, f in enumerate(fr):
+            present[j, f] = 1
+        slot_start = torch.empty(S + 1, dtype=torch.int32, device=points.device)
+        out = ops.select_transform_compact(points, 0, fr, np.tile(eye, (S, batch_size, 1)), present, n, slot_start=slot_start)
+        total = int(slot_start[S].item())
+        out = out[:total]
+        out[:, 0] = torch.floor(out[:, 0] / float(batch_size)) + float(lo)   # the kernel writes frame + slot * batch: slot -> lo + j
+        parts.append(out)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 0).contiguous()
 
 
 class AgentShardedEarlyFusion:
@@ -41,7 +58,7 @@ class AgentShardedEarlyFusion:
         frames = ex.shard_frames(batch_size, world, rank)
         if not frames:
             return frames, []
-        bd = {'points': _select_frames(union, frames), 'batch_size': len(frames), 'metadata': [metadata[f] for f in frames]}
+        bd = {'points': _select_frames(union, frames, batch_size), 'batch_size': len(frames), 'metadata': [metadata[f] for f in frames]}
         pred_dicts, _ = self.model(bd)
         return frames, pred_dicts
 
@@ -65,6 +82,9 @@ class AgentShardedMidFusion:
         union, _counts = ex.all_gather_v_rows(local_points, self.group)
         agent_ids = sorted({int(a) for md in metadata for a in md['se3_from_ego'].keys()} | {1})
         mine = self.agents_of_rank(agent_ids, world, rank)
+        # this rank's frames of the ego branch: selected now (its one small host read happens while the queue is still short)
+        frames = ex.shard_frames(batch_size, world, rank)
+        ego_points = _select_frames(union, frames, batch_size) if frames else None
         # ---- stage A: encode + compress this rank's agents ----------------------------------------------------------------------
         bd = {'points': union, 'batch_size': batch_size, 'metadata': metadata}
         for mk in self.makers:
@@ -94,19 +114,26 @@ class AgentShardedMidFusion:
         for i, a in enumerate(sorted(local)):
             stack[i] = local[a][0]
             ids[i, 0], ids[i, 1] = a, local[a][1]
-        all_stacks = ex.all_gather_maps(stack, self.group)
-        all_ids = ex.all_gather_maps(ids, self.group)
+        # the two all-gathers are issued asynchronously (RCCL runs them on its own stream); the ego VFE + backbone of this rank's frames
+        # need nothing from them and are queued meanwhile -- the exchange is waited for in front of the fusion module only
+        pend_stacks = ex.all_gather_maps_async(stack, self.group)
+        pend_ids = ex.all_gather_maps_async(ids, self.group)
+        # ---- stage B: the ego branch on this rank's frames ---------------------------------------------------------------------------
+        bd2 = None
+        chain = list(self.ego_chain)
+        if frames:
+            bd2 = {'points': ego_points, 'batch_size': len(frames), 'metadata': [metadata[f] for f in frames]}
+            while chain and chain[0] is not fusion:
+                bd2 = chain.pop(0)(bd2)
+        all_stacks, all_ids = pend_stacks.wait(), pend_ids.wait()                  # every rank takes part, with or without frames
+        if not frames:
+            return frames, []
         comp_all = {}
         for st, idt in zip(all_stacks, all_ids):
             for i, (a, last) in enumerate(idt.tolist()):
                 if a >= 0:
                     comp_all[int(a)] = st[i][:int(last)]
-        # ---- stage B: the ego branch on this rank's frames ---------------------------------------------------------------------------
-        frames = ex.shard_frames(batch_size, world, rank)
-        if not frames:
-            return frames, []
         fr = torch.tensor(frames, device=dev)
-        bd2 = {'points': _select_frames(union, frames), 'batch_size': len(frames), 'metadata': [metadata[f] for f in frames]}
         order = sorted(comp_all)                                                   # ascending agent id = the order BEVMaker inserts
         bd2['bev_img'] = {a: None for a in order}
         pre = {}
@@ -115,7 +142,7 @@ class AgentShardedMidFusion:
             full[:comp_all[a].shape[0]] = comp_all[a]
             pre[a] = full.index_select(0, fr).contiguous()
         bd2['bev_img_compressed'] = pre
-        for m in self.ego_chain:
+        for m in chain:
             bd2 = m(bd2)
         pred_dicts, _ = model.post_processing(bd2)
         return frames, pred_dicts

@@ -11,8 +11,16 @@ all-gather per exchange, no bucketing.
   are gathered on every rank that hosts an ego for some frame: all_gather_maps (bit-identical to single-device execution
   because the compressor precedes the warp and is applied per map -- v2x_fusion_disco.py:85).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# PCP_FORCE_COLLECTIVES=1: issue every collective even in a ONE-rank group (default: a single rank short-cuts them).  On a one-GPU box
+# this is how the RCCL code path itself -- librccl loaded, device buffers, the library's kernels on the device -- is exercised
+# (tests/test_gpu_dist.py::test_rccl_*); results are identical by construction.
+def force_collectives():
+    return os.environ.get('PCP_FORCE_COLLECTIVES', '0') == '1'
 
 
 def _world(group=None):
@@ -21,11 +29,15 @@ def _world(group=None):
     return 1, 0
 
 
+def _single(world):
+    return world == 1 and not (force_collectives() and dist.is_available() and dist.is_initialized())
+
+
 def all_gather_v_rows(rows, group=None):
     """rows: (n_r, C) tensor, n_r may differ per rank (0 allowed).  Returns (cat over ranks in rank order, list of n_r).
     Two collectives: sizes (world int64) and one padded payload all-gather."""
     world, _rank = _world(group)
-    if world == 1:
+    if _single(world):
         return rows, [rows.shape[0]]
     assert rows.dim() == 2
     n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
@@ -43,11 +55,34 @@ def all_gather_v_rows(rows, group=None):
 def all_gather_maps(local_map, group=None):
     """local_map: (..., H, W, C) tensor of identical shape on every rank -> list of per-rank maps (rank order)."""
     world, _rank = _world(group)
-    if world == 1:
+    if _single(world):
         return [local_map]
     recv = [torch.empty_like(local_map) for _ in range(world)]
     dist.all_gather(recv, local_map.contiguous(), group=group)
     return recv
+
+
+class PendingMaps:
+    """an all-gather of per-rank maps in flight (RCCL runs it on its own stream); wait() orders the current stream behind it"""
+
+    def __init__(self, recv, work):
+        self.recv, self.work = recv, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.recv
+
+
+def all_gather_maps_async(local_map, group=None):
+    """all_gather_maps that returns at once: the caller queues independent work (the ego branch up to the fusion module) and calls
+    .wait() where the maps are consumed"""
+    world, _rank = _world(group)
+    if _single(world):
+        return PendingMaps([local_map], None)
+    recv = [torch.empty_like(local_map) for _ in range(world)]
+    return PendingMaps(recv, dist.all_gather(recv, local_map.contiguous(), group=group, async_op=True))
 
 
 def gather_maps_to(local_map, dst, group=None):
@@ -94,7 +129,7 @@ def gather_modar(modar, foreground, dst, group=None):
     """RCCL gather of the (<= 83 x 9) MoDAR rows and the foreground rows of every agent on the ego's rank (README: 0.02 MB per agent):
     two ragged row gathers; returns lists indexed by rank on `dst`, (None, None) elsewhere."""
     world, rank = _world(group)
-    if world == 1:
+    if _single(world):
         return [modar], [foreground]
     allm, cm = all_gather_v_rows(modar, group)
     allf, cf = all_gather_v_rows(foreground, group)

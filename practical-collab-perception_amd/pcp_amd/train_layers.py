@@ -119,8 +119,16 @@ class ConvBNAct:
             cache = self.conv._pcp_train_pack = dict(step=-1)
         if bhw is not None and self.kind == '3x3' and cache.get('f4_key') != (tuple(bhw), os.environ.get('PCP_CONV_ALGO', 'auto')):
             cache['f4_key'] = (tuple(bhw), os.environ.get('PCP_CONV_ALGO', 'auto'))
-            cache['f4'] = (fused_f4_choice(*bhw, self.cin, self.cout) if self.stride == 1 else None, fused_f4_choice(*bhw, self.cout, self.cin))
-            cache['step'] = -1
+            f4_new = (fused_f4_choice(*bhw, self.cin, self.cout) if self.stride == 1 else None, fused_f4_choice(*bhw, self.cout, self.cin))
+            if f4_new != cache.get('f4'):
+                # another fused-F(4x4) form is needed (another batch / map shape, e.g. the last partial batch): take the slow path once so
+                # the new form is packed AND registered -- the group launch only repacks the forms it was given
+                cache['f4'] = f4_new
+                cache['step'] = -1
+                if cache.get('grouped'):
+                    PACK_GROUP.drop((id(self.conv), False))
+                    PACK_GROUP.drop((id(self.conv), True))
+                    cache['grouped'] = False
         if cache['step'] == StepClock.step:
             self._fw, self._bw = cache['fw'], cache['bw']
             return

@@ -426,6 +426,10 @@ class PackGroup:
         e = self.jobs.get(key)
         return e is not None and e[0]() is not None
 
+    def drop(self, key):
+        if self.jobs.pop(key, None) is not None:
+            self.dirty = True
+
     def run(self, device):
         L = _lib.load()
         dead = [k for k, e in self.jobs.items() if e[0]() is None]

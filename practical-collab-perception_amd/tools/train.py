@@ -15,6 +15,7 @@ the reference cannot read this build's optimizer state (its OptimWrapper expects
 """
 import argparse
 import os
+import pickle
 import sys
 from pathlib import Path
 
@@ -69,6 +70,29 @@ def init_distributed(args, cfg):
     return True, total_gpus
 
 
+
+def choose_resume_checkpoint(model, ckpt_dir, logger):
+    """newest checkpoint under ckpt_dir that can be read and holds every tensor of `model` at its shape, or None.  Nothing is loaded into
+    the model here (reference tools/train.py:143-156 tries the newest file and lets a torn one raise)."""
+    import glob
+    want = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    for f in sorted(glob.glob(str(Path(ckpt_dir) / '*.pth')), key=os.path.getmtime, reverse=True):
+        if f.endswith('_optim.pth'):
+            continue
+        try:
+            ck = torch.load(f, map_location='cpu', weights_only=False)
+            have = {k: tuple(v.shape) for k, v in ck['model_state'].items()}
+        except (OSError, EOFError, RuntimeError, KeyError, TypeError, AttributeError, ValueError, pickle.UnpicklingError) as e:
+            logger.info('could not resume from %s (%s: %s)' % (f, type(e).__name__, e))
+            continue
+        missing = [k for k in want if have.get(k) != want[k]]
+        if missing:
+            logger.info('could not resume from %s (%d tensors missing or of another shape, e.g. %s)' % (f, len(missing), missing[0]))
+            continue
+        return f
+    return None
+
+
 def main():
     args, cfg = parse_config()
     dist_train, total_gpus = init_distributed(args, cfg)
@@ -85,7 +109,8 @@ def main():
         ckpt_dir.mkdir(parents=True, exist_ok=True)
     logger = common_utils.create_logger(None, rank=cfg.LOCAL_RANK)
     if dist_train:
-        logger.info('total_batch_size: %d' % (total_gpus * args.batch_size))
+        import torch.distributed as dist
+        logger.info('total_batch_size: %d (%d ranks, backend %s)' % (total_gpus * args.batch_size, total_gpus, dist.get_backend()))
     log_config_to_file(cfg, logger=logger)
     train_set, train_loader, train_sampler = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, args.batch_size, dist_train,
                                                               workers=args.workers, logger=logger, training=True, total_epochs=args.epochs)
@@ -112,15 +137,15 @@ def main():
     if args.ckpt is not None:
         it, start_epoch = model.load_params_with_optimizer(args.ckpt, to_cpu=True, optimizer=optimizer, logger=logger)
     else:                                                   # resume from the newest loadable checkpoint (reference tools/train.py:143-156)
-        import glob
-        ckpt_list = sorted(glob.glob(str(ckpt_dir / '*.pth')), key=os.path.getmtime)
-        while ckpt_list:
-            try:
-                it, start_epoch = model.load_params_with_optimizer(ckpt_list[-1], to_cpu=True, optimizer=optimizer, logger=logger)
-                break
-            except Exception as e:                          # noqa: BLE001 -- a torn file from a killed run: try the one before
-                logger.info('could not resume from %s (%s)' % (ckpt_list[-1], e))
-                ckpt_list = ckpt_list[:-1]
+        # A checkpoint is VALIDATED (readable, every model key present with the right shape) before anything is loaded into the model or
+        # the optimizer, so a torn file from a killed run cannot leave the model half-overwritten; rank 0 chooses and broadcasts its
+        # choice, so all ranks resume from the same file even when a newer one appears while they start.
+        choice = [choose_resume_checkpoint(model, ckpt_dir, logger) if (cfg.LOCAL_RANK == 0 or not dist_train) else None]
+        if dist_train:
+            import torch.distributed as dist
+            dist.broadcast_object_list(choice, src=0)
+        if choice[0] is not None:
+            it, start_epoch = model.load_params_with_optimizer(choice[0], to_cpu=True, optimizer=optimizer, logger=logger)
     it, start_epoch = int(it), max(int(start_epoch), 0)
     lr_scheduler, lr_warmup = build_scheduler(optimizer, total_iters_each_epoch=len(train_loader), total_epochs=args.epochs,
                                               last_epoch=start_epoch - 1, optim_cfg=cfg.OPTIMIZATION)

@@ -25,10 +25,19 @@ def annealing_cos(start, end, pct):
 def all_reduce_flat_gradient(flat_g, group=None):
     """the ONE collective of a data-parallel training step: sum of the flat fp32 gradient over ranks (RCCL on GPUs, gloo in the CPU
     tests); the 1 / world averaging of DistributedDataParallel is folded into the optimizer kernel's grad_scale"""
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+    if _collectives_on(group):
         torch.distributed.all_reduce(flat_g, group=group)
         return 1.0 / torch.distributed.get_world_size(group)
     return 1.0
+
+
+def _collectives_on(group=None):
+    """more than one rank -- or PCP_FORCE_COLLECTIVES=1 in an initialised one-rank group (the RCCL path exercised on a one-GPU box)"""
+    import os
+    d = torch.distributed
+    if not (d.is_available() and d.is_initialized()):
+        return False
+    return d.get_world_size(group) > 1 or os.environ.get('PCP_FORCE_COLLECTIVES', '0') == '1'
 
 
 class FlatAdamOneCycle:

@@ -266,3 +266,113 @@ def test_bench_pipelined_default_and_batch_by_batch_agree(tmp_path):
     assert piped['roofline']['kernel'] == plain['roofline']['kernel'] and piped['roofline']['next_mfma_kernels']
     rows = table.read_text().splitlines()
     assert rows[0].split()[:2] == ['kernel', 'shape'] and any(r.startswith('k_wino4h') for r in rows[1:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL itself: a ONE-rank `nccl` process group on this box's MI355X.  PCP_FORCE_COLLECTIVES=1 makes every exchange of
+# the N > 1 path issue its collective although one rank could short-cut it: librccl is loaded, the payloads are device tensors, RCCL's
+# kernels run on the device.  A one-rank collective is an identity, so every result must equal the path without a process group.
+# ---------------------------------------------------------------------------------------------------------------------
+_RCCL_CHILD = r'''
+import json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+REPO, PKG = sys.argv[1], sys.argv[2]
+for p in (REPO, PKG, os.path.join(REPO, 'tests'), os.path.join(PKG, 'tools')):
+    sys.path.insert(0, p)
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+out = {}
+try:
+    from helpers import load_golden
+    from pcdet.models import build_network_from_meta, sharded
+    from pcdet.utils import v2x_exchange as ex
+    from pcp_amd import synth
+    assert ex.force_collectives()
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.randn((1234, 6), generator=g).to(dev)
+    got, counts = ex.all_gather_v_rows(rows)
+    out['rows_equal'] = bool(torch.equal(got, rows)) and counts == [1234] and got.data_ptr() != rows.data_ptr()
+    maps = torch.randn((2, 16, 16, 8), generator=g).to(dev)
+    rec = ex.all_gather_maps(maps)
+    out['maps_equal'] = len(rec) == 1 and bool(torch.equal(rec[0], maps)) and rec[0].data_ptr() != maps.data_ptr()
+    pend = ex.all_gather_maps_async(maps)
+    busy = torch.ones(1 << 20, device=dev).sum()                      # independent work queued between issue and wait
+    rec = pend.wait()
+    out['async_equal'] = bool(torch.equal(rec[0], maps)) and float(busy.item()) == float(1 << 20)
+    m, f = ex.gather_modar(torch.randn((7, 9), generator=g).to(dev), torch.randn((40, 13), generator=g).to(dev), 0)
+    out['modar_shapes'] = [list(m[0].shape), list(f[0].shape)]
+    # the flat-gradient all-reduce of a data-parallel training step (tools/train_utils/optimization)
+    from train_utils.optimization import all_reduce_flat_gradient
+    flat = torch.randn(4_800_000, generator=g).to(dev)                # 19 MB: config 5's gradient buffer
+    want = flat.clone()
+    scale = all_reduce_flat_gradient(flat)
+    out['allreduce_equal'] = scale == 1.0 and bool(torch.equal(flat, want))
+    # agent-sharded mid fusion and early fusion through the real kernels, collectives forced
+    for kind in ('disco', 'early'):
+        gold = load_golden('g1_%s.npz' % kind)
+        model = build_network_from_meta(gold['meta'])
+        st = synth.fill_state_dict(gold['meta']['state_shapes'])
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+        model = model.cuda().eval()
+        if kind == 'disco':
+            metadata = [{'se3_from_ego': {0: gold['pose_0'], 2: gold['pose_2']}}, {'se3_from_ego': {0: gold['pose_0']}}]
+            runner = sharded.AgentShardedMidFusion(model)
+        else:
+            metadata = [{}, {}]
+            runner = sharded.AgentShardedEarlyFusion(model)
+        pts = torch.from_numpy(gold['points']).cuda()
+        with torch.no_grad():
+            single, _ = model({'points': pts.clone(), 'batch_size': 2, 'metadata': metadata})
+        frames, preds = runner(pts.clone(), 2, metadata)
+        same = frames == [0, 1] and len(preds) == 2
+        for a, b in zip(single, preds):
+            for k in ('pred_boxes', 'pred_scores', 'pred_labels'):
+                same = same and a[k].shape == b[k].shape and bool(torch.equal(a[k], b[k]))
+        out[kind + '_equal'] = bool(same)
+        out[kind + '_boxes'] = int(sum(p['pred_boxes'].shape[0] for p in single))
+    torch.cuda.synchronize()
+    with open('/proc/self/maps') as fh:
+        out['librccl_mapped'] = any('librccl' in ln for ln in fh)
+    out['backend'] = dist.get_backend()
+finally:
+    dist.destroy_process_group()
+print('RCCL_RESULT ' + json.dumps(out))
+'''
+
+
+def test_rccl_one_rank_group_runs_every_collective_of_the_sharded_paths_on_device_tensors():
+    import json
+    import subprocess
+    env = dict(os.environ, PCP_FORCE_COLLECTIVES='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _RCCL_CHILD, REPO, PKG], capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RCCL_RESULT ')][0][len('RCCL_RESULT '):])
+    assert res['backend'] == 'nccl' and res['librccl_mapped'], res
+    for k in ('rows_equal', 'maps_equal', 'async_equal', 'allreduce_equal', 'disco_equal', 'early_equal'):
+        assert res[k] is True, (k, res)
+    assert res['modar_shapes'] == [[7, 9], [40, 13]]
+    assert res['disco_boxes'] > 0 and res['early_boxes'] > 0
+
+
+def test_rccl_one_rank_training_step_allreduces_the_flat_gradient_on_the_device(tmp_path):
+    """tools/train.py --launcher pytorch with ONE rank and the default backend (nccl = RCCL), collectives forced: the optimizer's
+    all-reduce runs on the device-resident flat gradient; the run finishes and the loss falls as in the gloo two-rank test"""
+    import re
+    import subprocess
+    tools = os.path.join(PKG, 'tools')
+    env = dict(os.environ, PCP_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('PCP_DIST_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
+           str(_free_port()), 'train.py', '--launcher', 'pytorch', '--cfg_file', 'cfgs/v2x_sim_models/v2x_pointpillar_disco.yaml',
+           '--batch_size', '2', '--epochs', '2', '--output_dir', str(tmp_path), '--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '3000',
+           'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '8', 'OPTIMIZATION.LR', '0.003']
+    r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
+    out = r.stdout + r.stderr
+    losses = [float(m) for m in re.findall(r'loss ([0-9.]+)  lr', out)]
+    assert len(losses) == 4 and losses[-1] < losses[0], losses
+    assert 'backend nccl' in out, out[-1500:]
