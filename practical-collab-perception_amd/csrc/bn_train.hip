@@ -10,9 +10,35 @@
 // read of (dout, x) for the two per-channel sums and one read + write for dx.  Per-channel sums are accumulated in float64
 // (per-thread partials, LDS tree, one partial per block and channel in the workspace, reduced in a fixed order by the finalize
 // kernel): bitwise reproducible, no atomics.
+//
+// Mixed-precision training (round 4, include/pcp_hip_mp.h): every kernel here is a template over the STORAGE type of each tensor it
+// touches (float | bf16, four channels per thread: 16-byte / 8-byte accesses); the arithmetic is fp32 (sums float64) in every
+// instantiation, and the <float, float> instantiations are the round-1..3 kernels unchanged.
 #include "pcp_common.h"
+#include "../../include/pcp_hip_mp.h"
 
 namespace {
+
+typedef __bf16 bf16_t;
+
+template <typename T> struct IO4;
+template <> struct IO4<float> {
+  static __device__ __forceinline__ float4 ld(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+  static __device__ __forceinline__ void st(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct IO4<bf16_t> {
+  static __device__ __forceinline__ float4 ld(const bf16_t *p) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void st(bf16_t *p, const float4 &v) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;      // round to nearest even (v_cvt_pk_bf16_f32)
+    *reinterpret_cast<b4 *>(p) = o;
+  }
+};
 
 constexpr int RED_THREADS = 256;
 constexpr int RED_MAX_BLOCKS = 1024;
@@ -20,8 +46,8 @@ constexpr int RED_MAX_BLOCKS = 1024;
 enum { RED_STATS = 0, RED_BNBWD = 1, RED_COLSUM = 2 };
 
 struct RedParams {
-  const float *x;        // STATS / COLSUM: the tensor; BNBWD: pre-BN conv output
-  const float *dout;     // BNBWD: upstream gradient
+  const void *x;         // STATS / COLSUM: the tensor; BNBWD: pre-BN conv output          (storage type XT)
+  const void *dout;      // BNBWD: upstream gradient                                       (storage type DT)
   long long rows;
   int c, ld_x, ld_d;
   const float *scale, *shift, *mean, *invstd;   // BNBWD
@@ -30,8 +56,10 @@ struct RedParams {
 };
 
 // thread layout: cg = c/4 float4 column groups, rpb = RED_THREADS / cg row slots per block pass
-template <int MODE>
+template <int MODE, typename XT, typename DT>
 __global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
+  const XT *px = reinterpret_cast<const XT *>(p.x);
+  const DT *pd = reinterpret_cast<const DT *>(p.dout);
   __shared__ double red[2][RED_THREADS][4];
   const int cg = p.c >> 2;
   const int rpb = RED_THREADS / cg;
@@ -76,15 +104,15 @@ __global__ __launch_bounds__(RED_THREADS) void k_col_reduce(RedParams p) {
       float4 v[4], d[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        v[u] = *reinterpret_cast<const float4 *>(p.x + (r + u * step) * p.ld_x + g * 4);
-        d[u] = MODE == RED_BNBWD ? *reinterpret_cast<const float4 *>(p.dout + (r + u * step) * p.ld_d + g * 4) : v[u];
+        v[u] = IO4<XT>::ld(px + (r + u * step) * p.ld_x + g * 4);
+        d[u] = MODE == RED_BNBWD ? IO4<DT>::ld(pd + (r + u * step) * p.ld_d + g * 4) : v[u];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accum(v[u], d[u]);
     }
     for (; r < p.rows; r += step) {
-      const float4 v = *reinterpret_cast<const float4 *>(p.x + r * p.ld_x + g * 4);
-      const float4 d = MODE == RED_BNBWD ? *reinterpret_cast<const float4 *>(p.dout + r * p.ld_d + g * 4) : v;
+      const float4 v = IO4<XT>::ld(px + r * p.ld_x + g * 4);
+      const float4 d = MODE == RED_BNBWD ? IO4<DT>::ld(pd + r * p.ld_d + g * 4) : v;
       accum(v, d);
     }
   }
@@ -198,30 +226,32 @@ __global__ __launch_bounds__(FIN_CH * FIN_PARTS) void k_colsum_finalize(const do
   if (accumulate) out[i] += (float)s0; else out[i] = (float)s0;
 }
 
-__global__ void k_scale_shift_act(const float *__restrict__ x, long long rows, int cg, int ld_x, const float *__restrict__ scale,
-                                  const float *__restrict__ shift, int relu, float *__restrict__ out, int ld_out) {
+template <typename XT, typename OT>
+__global__ void k_scale_shift_act(const XT *__restrict__ x, long long rows, int cg, int ld_x, const float *__restrict__ scale,
+                                  const float *__restrict__ shift, int relu, OT *__restrict__ out, int ld_out) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * cg) return;
   const int g = (int)(t % cg);
   const long long r = t / cg;
-  const float4 v = *reinterpret_cast<const float4 *>(x + r * ld_x + g * 4);
+  const float4 v = IO4<XT>::ld(x + r * ld_x + g * 4);
   const float4 sc = *reinterpret_cast<const float4 *>(scale + g * 4);
   const float4 sh = *reinterpret_cast<const float4 *>(shift + g * 4);
   float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
   if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-  *reinterpret_cast<float4 *>(out + r * ld_out + g * 4) = o;
+  IO4<OT>::st(out + r * ld_out + g * 4, o);
 }
 
-__global__ void k_bnbwd_apply(const float *__restrict__ dout, int ld_d, const float *__restrict__ x, int ld_x, long long rows, int cg,
+template <typename DT, typename XT, typename OT>
+__global__ void k_bnbwd_apply(const DT *dout, int ld_d, const XT *__restrict__ x, int ld_x, long long rows, int cg,
                               int c, const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
-                              const float *__restrict__ invstd, int relu, const float *__restrict__ coef, float *__restrict__ dx,
+                              const float *__restrict__ invstd, int relu, const float *__restrict__ coef, OT *dx,
                               int ld_dx) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * cg) return;
   const int g = (int)(t % cg);
   const long long r = t / cg;
-  const float4 v = *reinterpret_cast<const float4 *>(x + r * ld_x + g * 4);
-  const float4 d = *reinterpret_cast<const float4 *>(dout + r * ld_d + g * 4);
+  const float4 v = IO4<XT>::ld(x + r * ld_x + g * 4);
+  const float4 d = IO4<DT>::ld(dout + r * ld_d + g * 4);
   const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
   float o[4];
 #pragma unroll
@@ -232,23 +262,25 @@ __global__ void k_bnbwd_apply(const float *__restrict__ dout, int ld_d, const fl
     const float xh = (xv[i] - mean[ch]) * invstd[ch];
     o[i] = scale[ch] * (dz - coef[ch] - xh * coef[c + ch]);
   }
-  *reinterpret_cast<float4 *>(dx + r * ld_dx + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  IO4<OT>::st(dx + r * ld_dx + g * 4, make_float4(o[0], o[1], o[2], o[3]));
 }
 
-__global__ void k_accumulate(float *__restrict__ dst, int ld_dst, const float *__restrict__ src, int ld_src, long long rows, int cg,
+template <typename AT, typename BT>
+__global__ void k_accumulate(AT *__restrict__ dst, int ld_dst, const BT *__restrict__ src, int ld_src, long long rows, int cg,
                              float alpha) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * cg) return;
   const int g = (int)(t % cg);
   const long long r = t / cg;
-  float4 a = *reinterpret_cast<const float4 *>(dst + r * ld_dst + g * 4);
-  const float4 b = *reinterpret_cast<const float4 *>(src + r * ld_src + g * 4);
+  float4 a = IO4<AT>::ld(dst + r * ld_dst + g * 4);
+  const float4 b = IO4<BT>::ld(src + r * ld_src + g * 4);
   a.x = fmaf(alpha, b.x, a.x); a.y = fmaf(alpha, b.y, a.y); a.z = fmaf(alpha, b.z, a.z); a.w = fmaf(alpha, b.w, a.w);
-  *reinterpret_cast<float4 *>(dst + r * ld_dst + g * 4) = a;
+  IO4<AT>::st(dst + r * ld_dst + g * 4, a);
 }
 
 // out (B, 2h, 2w, c): out[b, 2y, 2x] = in[b, y, x], zero elsewhere (gradient of a stride-2 3x3 conv = stride-1 conv of this)
-__global__ void k_dilate2x(const float *__restrict__ in, int batch, int h, int w, int cg, int ld_in, float *__restrict__ out,
+template <typename T>
+__global__ void k_dilate2x(const T *__restrict__ in, int batch, int h, int w, int cg, int ld_in, T *__restrict__ out,
                            int ld_out) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)batch * 2 * h * 2 * w * cg;
@@ -260,12 +292,47 @@ __global__ void k_dilate2x(const float *__restrict__ in, int batch, int h, int w
   const int oy = (int)(pix % (2 * h));
   const int b = (int)(pix / (2 * h));
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!(ox & 1) && !(oy & 1)) v = *reinterpret_cast<const float4 *>(in + (((long long)b * h + (oy >> 1)) * w + (ox >> 1)) * ld_in + g * 4);
-  *reinterpret_cast<float4 *>(out + (((long long)b * 2 * h + oy) * 2 * w + ox) * ld_out + g * 4) = v;
+  if (!(ox & 1) && !(oy & 1)) v = IO4<T>::ld(in + (((long long)b * h + (oy >> 1)) * w + (ox >> 1)) * ld_in + g * 4);
+  IO4<T>::st(out + (((long long)b * 2 * h + oy) * 2 * w + ox) * ld_out + g * 4, v);
 }
 
 inline bool red_shape_ok(long long rows, int c, int ld) { return rows > 0 && c >= 4 && (c & 3) == 0 && (c >> 2) <= RED_THREADS && (ld & 3) == 0 && ld >= c; }
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+// four channels of a row: 16 bytes of float, 8 bytes of bf16
+inline bool al4ch(const void *p, int dtype) { return (((uintptr_t)p) & (dtype == PCP_DT_BF16 ? 7 : 15)) == 0; }
+inline bool dt_ok(int dtype) { return dtype == PCP_DT_F32 || dtype == PCP_DT_BF16; }
+
+template <int MODE>
+inline void launch_col_reduce(int nb, hipStream_t s, const RedParams &p, int xdt, int ddt) {
+  if (xdt == PCP_DT_BF16) {
+    if (ddt == PCP_DT_BF16) hipLaunchKernelGGL((k_col_reduce<MODE, bf16_t, bf16_t>), dim3(nb), dim3(RED_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((k_col_reduce<MODE, bf16_t, float>), dim3(nb), dim3(RED_THREADS), 0, s, p);
+  } else {
+    if (ddt == PCP_DT_BF16) hipLaunchKernelGGL((k_col_reduce<MODE, float, bf16_t>), dim3(nb), dim3(RED_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((k_col_reduce<MODE, float, float>), dim3(nb), dim3(RED_THREADS), 0, s, p);
+  }
+}
+
+template <typename DT, typename XT>
+inline void launch_bnbwd_apply2(int odt, unsigned blocks, hipStream_t s, const void *dout, int ld_d, const void *x, int ld_x, long long rows, int cg,
+                                int c, const float *scale, const float *shift, const float *mean, const float *invstd, int relu,
+                                const float *coef, void *dx, int ld_dx) {
+  if (odt == PCP_DT_BF16)
+    hipLaunchKernelGGL((k_bnbwd_apply<DT, XT, bf16_t>), dim3(blocks), dim3(256), 0, s, (const DT *)dout, ld_d, (const XT *)x, ld_x, rows, cg, c, scale,
+                       shift, mean, invstd, relu, coef, (bf16_t *)dx, ld_dx);
+  else
+    hipLaunchKernelGGL((k_bnbwd_apply<DT, XT, float>), dim3(blocks), dim3(256), 0, s, (const DT *)dout, ld_d, (const XT *)x, ld_x, rows, cg, c, scale,
+                       shift, mean, invstd, relu, coef, (float *)dx, ld_dx);
+}
+
+inline void launch_bnbwd_apply(int ddt, int xdt, int odt, unsigned blocks, hipStream_t s, const void *dout, int ld_d, const void *x, int ld_x,
+                               long long rows, int cg, int c, const float *scale, const float *shift, const float *mean, const float *invstd,
+                               int relu, const float *coef, void *dx, int ld_dx) {
+#define PCP_BNB(DT, XT) launch_bnbwd_apply2<DT, XT>(odt, blocks, s, dout, ld_d, x, ld_x, rows, cg, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx)
+  if (ddt == PCP_DT_BF16) { if (xdt == PCP_DT_BF16) PCP_BNB(bf16_t, bf16_t); else PCP_BNB(bf16_t, float); }
+  else { if (xdt == PCP_DT_BF16) PCP_BNB(float, bf16_t); else PCP_BNB(float, float); }
+#undef PCP_BNB
+}
 
 // one f64 atomic per (block, channel) lands on 2c addresses: keep the block count near the CU count (256) so the atomics of a
 // launch do not serialise at L2 (2048 blocks cost 40 us of pure atomic contention on a 64-channel map)
@@ -279,14 +346,13 @@ inline int red_grid(long long rows, int c) {
 
 }  // namespace
 
-extern "C" {
+// ---- implementations over (pointer, storage type) pairs; the fp32 entry points of pcp_hip_train.h pass PCP_DT_F32 everywhere ----------
+namespace {
 
-size_t pcp_bn_workspace_bytes(int32_t c) { return (size_t)RED_MAX_BLOCKS * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float); }
-
-int pcp_bn_train_stats(const float *x, int64_t rows, int32_t c, int32_t ld, const float *gamma, const float *beta, float eps,
-                       float momentum, float *running_mean, float *running_var, void *workspace, float *scale, float *shift,
-                       float *mean, float *invstd, void *stream) {
-  if (!x || !gamma || !beta || !workspace || !scale || !shift || !mean || !invstd || !red_shape_ok(rows, c, ld) || !al16(x))
+int bn_train_stats_impl(const void *x, int xdt, int64_t rows, int32_t c, int32_t ld, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, void *workspace, float *scale, float *shift, float *mean,
+                        float *invstd, void *stream) {
+  if (!x || !gamma || !beta || !workspace || !scale || !shift || !mean || !invstd || !red_shape_ok(rows, c, ld) || !dt_ok(xdt) || !al4ch(x, xdt))
     return PCP_ERR_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return PCP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -294,30 +360,36 @@ int pcp_bn_train_stats(const float *x, int64_t rows, int32_t c, int32_t ld, cons
   RedParams p{};
   p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
   const int nb = red_grid(rows, c);
-  hipLaunchKernelGGL(k_col_reduce<RED_STATS>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  launch_col_reduce<RED_STATS>(nb, s, p, xdt, xdt);
   hipLaunchKernelGGL(k_bn_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, (long long)rows, c, gamma, beta,
                      eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
-int pcp_scale_shift_act(const float *x, int64_t rows, int32_t c, int32_t ld_x, const float *scale, const float *shift, int32_t relu,
-                        float *out, int32_t ld_out, void *stream) {
-  if (!x || !scale || !shift || !out || rows <= 0 || c < 4 || (c & 3) || (ld_x & 3) || (ld_out & 3) || !al16(x) || !al16(out))
+int scale_shift_act_impl(const void *x, int xdt, int64_t rows, int32_t c, int32_t ld_x, const float *scale, const float *shift, int32_t relu,
+                         void *out, int odt, int32_t ld_out, void *stream) {
+  if (!x || !scale || !shift || !out || rows <= 0 || c < 4 || (c & 3) || (ld_x & 3) || (ld_out & 3) || !dt_ok(xdt) || !dt_ok(odt) ||
+      !al4ch(x, xdt) || !al4ch(out, odt))
     return PCP_ERR_ARG;
   const long long total = (long long)rows * (c >> 2);
-  hipLaunchKernelGGL(k_scale_shift_act, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows,
-                     c >> 2, ld_x, scale, shift, relu, out, ld_out);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+#define PCP_SSA(XT, OT) hipLaunchKernelGGL((k_scale_shift_act<XT, OT>), grid, dim3(256), 0, s, (const XT *)x, (long long)rows, c >> 2, ld_x, scale, shift, relu, (OT *)out, ld_out)
+  if (xdt == PCP_DT_BF16) { if (odt == PCP_DT_BF16) PCP_SSA(bf16_t, bf16_t); else PCP_SSA(bf16_t, float); }
+  else { if (odt == PCP_DT_BF16) PCP_SSA(float, bf16_t); else PCP_SSA(float, float); }
+#undef PCP_SSA
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
-int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
-                        const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, float *dgamma,
-                        float *dbeta, int32_t accumulate, float *dx, int32_t ld_dx, void *stream) {
+int bn_act_backward_impl(const void *dout, int ddt, int32_t ld_dout, const void *x, int xdt, int32_t ld_x, int64_t rows, int32_t c,
+                         const float *scale, const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace,
+                         float *dgamma, float *dbeta, int32_t accumulate, void *dx, int odt, int32_t ld_dx, void *stream) {
   if (!dout || !x || !scale || !shift || !mean || !invstd || !workspace || !dgamma || !dbeta || !dx || !red_shape_ok(rows, c, ld_x) ||
-      (ld_dout & 3) || (ld_dx & 3) || !al16(dout) || !al16(x) || !al16(dx))
+      (ld_dout & 3) || (ld_dx & 3) || !dt_ok(ddt) || !dt_ok(xdt) || !dt_ok(odt) || !al4ch(dout, ddt) || !al4ch(x, xdt) || !al4ch(dx, odt))
     return PCP_ERR_ARG;
+  if (dx == dout && odt != ddt) return PCP_ERR_ARG;          // in place only at one storage type
   hipStream_t s = (hipStream_t)stream;
   double *acc = (double *)workspace;
   float *coef = (float *)(acc + 2 * (size_t)c * RED_MAX_BLOCKS);
@@ -325,28 +397,140 @@ int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int3
   p.x = x; p.dout = dout; p.rows = rows; p.c = c; p.ld_x = ld_x; p.ld_d = ld_dout;
   p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.relu = relu; p.acc = acc;
   const int nb = red_grid(rows, c);
-  hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  launch_col_reduce<RED_BNBWD>(nb, s, p, xdt, ddt);
   hipLaunchKernelGGL(k_bnbwd_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, (long long)rows, c, dgamma,
                      dbeta, accumulate, coef);
   const long long total = (long long)rows * (c >> 2);
-  hipLaunchKernelGGL(k_bnbwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, ld_dout, x, ld_x, (long long)rows,
-                     c >> 2, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx);
+  launch_bnbwd_apply(ddt, xdt, odt, (unsigned)((total + 255) / 256), s, dout, ld_dout, x, ld_x, (long long)rows, c >> 2, c, scale, shift, mean,
+                     invstd, relu, coef, dx, ld_dx);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
-// ---- cross-rank BatchNorm (nn.SyncBatchNorm, tools/train.py --sync_bn): the two calls above split at their reduction ------------------
-int pcp_bn_train_sums(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, double *sums, void *stream) {
-  if (!x || !workspace || !sums || !red_shape_ok(rows, c, ld) || !al16(x)) return PCP_ERR_ARG;
+int bn_train_sums_impl(const void *x, int xdt, int64_t rows, int32_t c, int32_t ld, void *workspace, double *sums, void *stream) {
+  if (!x || !workspace || !sums || !red_shape_ok(rows, c, ld) || !dt_ok(xdt) || !al4ch(x, xdt)) return PCP_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   double *acc = (double *)workspace;
   RedParams p{};
   p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
   const int nb = red_grid(rows, c);
-  hipLaunchKernelGGL(k_col_reduce<RED_STATS>, dim3(nb), dim3(RED_THREADS), 0, s, p);
+  launch_col_reduce<RED_STATS>(nb, s, p, xdt, xdt);
   hipLaunchKernelGGL(k_sums_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, sums);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+int bn_bwd_sums_impl(const void *dout, int ddt, int32_t ld_dout, const void *x, int xdt, int32_t ld_x, int64_t rows, int32_t c,
+                     const float *scale, const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace,
+                     double *sums, void *stream) {
+  if (!dout || !x || !scale || !shift || !mean || !invstd || !workspace || !sums || !red_shape_ok(rows, c, ld_x) || (ld_dout & 3) ||
+      !dt_ok(ddt) || !dt_ok(xdt) || !al4ch(dout, ddt) || !al4ch(x, xdt))
+    return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  RedParams p{};
+  p.x = x; p.dout = dout; p.rows = rows; p.c = c; p.ld_x = ld_x; p.ld_d = ld_dout;
+  p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.relu = relu; p.acc = acc;
+  const int nb = red_grid(rows, c);
+  launch_col_reduce<RED_BNBWD>(nb, s, p, xdt, ddt);
+  hipLaunchKernelGGL(k_sums_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, sums);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int bn_bwd_apply_from_sums_impl(const void *dout, int ddt, int32_t ld_dout, const void *x, int xdt, int32_t ld_x, int64_t rows, int32_t c,
+                                const float *scale, const float *shift, const float *mean, const float *invstd, int32_t relu,
+                                const double *local_sums, const double *global_sums, int64_t total_rows, void *workspace, float *dgamma,
+                                float *dbeta, int32_t accumulate, void *dx, int odt, int32_t ld_dx, void *stream) {
+  if (!dout || !x || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !workspace || !dgamma || !dbeta || !dx ||
+      !red_shape_ok(rows, c, ld_x) || (ld_dout & 3) || (ld_dx & 3) || !dt_ok(ddt) || !dt_ok(xdt) || !dt_ok(odt) || !al4ch(dout, ddt) ||
+      !al4ch(x, xdt) || !al4ch(dx, odt) || total_rows < rows)
+    return PCP_ERR_ARG;
+  if (dx == dout && odt != ddt) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float *coef = (float *)((double *)workspace + 2 * (size_t)c * RED_MAX_BLOCKS);
+  hipLaunchKernelGGL(k_bnbwd_finalize_sync, dim3((c + 255) / 256), dim3(256), 0, s, local_sums, global_sums, (double)total_rows, c, dgamma, dbeta,
+                     accumulate, coef);
+  const long long total = (long long)rows * (c >> 2);
+  launch_bnbwd_apply(ddt, xdt, odt, (unsigned)((total + 255) / 256), s, dout, ld_dout, x, ld_x, (long long)rows, c >> 2, c, scale, shift, mean,
+                     invstd, relu, coef, dx, ld_dx);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int colsum_impl(const void *x, int xdt, int64_t rows, int32_t c, int32_t ld, void *workspace, float *out, int32_t accumulate, void *stream) {
+  if (!x || !workspace || !out || !red_shape_ok(rows, c, ld) || !dt_ok(xdt) || !al4ch(x, xdt)) return PCP_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  double *acc = (double *)workspace;
+  RedParams p{};
+  p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
+  const int nb = red_grid(rows, c);
+  launch_col_reduce<RED_COLSUM>(nb, s, p, xdt, xdt);
+  hipLaunchKernelGGL(k_colsum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, out, accumulate);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int accumulate_impl(void *dst, int adt, int32_t ld_dst, const void *src, int bdt, int32_t ld_src, int64_t rows, int32_t c, float alpha,
+                    void *stream) {
+  if (!dst || !src || rows <= 0 || c < 4 || (c & 3) || (ld_dst & 3) || (ld_src & 3) || !dt_ok(adt) || !dt_ok(bdt) || !al4ch(dst, adt) ||
+      !al4ch(src, bdt))
+    return PCP_ERR_ARG;
+  const long long total = (long long)rows * (c >> 2);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+#define PCP_ACC(AT, BT) hipLaunchKernelGGL((k_accumulate<AT, BT>), grid, dim3(256), 0, s, (AT *)dst, ld_dst, (const BT *)src, ld_src, (long long)rows, c >> 2, alpha)
+  if (adt == PCP_DT_BF16) { if (bdt == PCP_DT_BF16) PCP_ACC(bf16_t, bf16_t); else PCP_ACC(bf16_t, float); }
+  else { if (bdt == PCP_DT_BF16) PCP_ACC(float, bf16_t); else PCP_ACC(float, float); }
+#undef PCP_ACC
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int dilate2x_impl(const void *in, int dt, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_in, void *out, int32_t ld_out,
+                  void *stream) {
+  if (!in || !out || batch <= 0 || h <= 0 || w <= 0 || c < 4 || (c & 3) || (ld_in & 3) || (ld_out & 3) || !dt_ok(dt) || !al4ch(in, dt) ||
+      !al4ch(out, dt))
+    return PCP_ERR_ARG;
+  const long long total = (long long)batch * 4 * h * w * (c >> 2);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dt == PCP_DT_BF16)
+    hipLaunchKernelGGL((k_dilate2x<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)in, batch, h, w, c >> 2, ld_in, (bf16_t *)out, ld_out);
+  else
+    hipLaunchKernelGGL((k_dilate2x<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float *)in, batch, h, w, c >> 2, ld_in, (float *)out, ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pcp_bn_workspace_bytes(int32_t c) { return (size_t)RED_MAX_BLOCKS * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float); }
+
+// ---- fp32 entry points (include/pcp_hip_train.h) --------------------------------------------------------------------------------------
+int pcp_bn_train_stats(const float *x, int64_t rows, int32_t c, int32_t ld, const float *gamma, const float *beta, float eps,
+                       float momentum, float *running_mean, float *running_var, void *workspace, float *scale, float *shift,
+                       float *mean, float *invstd, void *stream) {
+  return bn_train_stats_impl(x, PCP_DT_F32, rows, c, ld, gamma, beta, eps, momentum, running_mean, running_var, workspace, scale, shift, mean,
+                             invstd, stream);
+}
+
+int pcp_scale_shift_act(const float *x, int64_t rows, int32_t c, int32_t ld_x, const float *scale, const float *shift, int32_t relu,
+                        float *out, int32_t ld_out, void *stream) {
+  return scale_shift_act_impl(x, PCP_DT_F32, rows, c, ld_x, scale, shift, relu, out, PCP_DT_F32, ld_out, stream);
+}
+
+int pcp_bn_act_backward(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
+                        const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, float *dgamma,
+                        float *dbeta, int32_t accumulate, float *dx, int32_t ld_dx, void *stream) {
+  return bn_act_backward_impl(dout, PCP_DT_F32, ld_dout, x, PCP_DT_F32, ld_x, rows, c, scale, shift, mean, invstd, relu, workspace, dgamma,
+                              dbeta, accumulate, dx, PCP_DT_F32, ld_dx, stream);
+}
+
+// ---- cross-rank BatchNorm (nn.SyncBatchNorm, tools/train.py --sync_bn): the two calls above split at their reduction ------------------
+int pcp_bn_train_sums(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, double *sums, void *stream) {
+  return bn_train_sums_impl(x, PCP_DT_F32, rows, c, ld, workspace, sums, stream);
 }
 
 int pcp_bn_train_stats_from_sums(const double *sums, int64_t total_rows, int32_t c, const float *gamma, const float *beta, float eps,
@@ -363,70 +547,82 @@ int pcp_bn_train_stats_from_sums(const double *sums, int64_t total_rows, int32_t
 
 int pcp_bn_bwd_sums(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
                     const float *shift, const float *mean, const float *invstd, int32_t relu, void *workspace, double *sums, void *stream) {
-  if (!dout || !x || !scale || !shift || !mean || !invstd || !workspace || !sums || !red_shape_ok(rows, c, ld_x) || (ld_dout & 3) ||
-      !al16(dout) || !al16(x))
-    return PCP_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  double *acc = (double *)workspace;
-  RedParams p{};
-  p.x = x; p.dout = dout; p.rows = rows; p.c = c; p.ld_x = ld_x; p.ld_d = ld_dout;
-  p.scale = scale; p.shift = shift; p.mean = mean; p.invstd = invstd; p.relu = relu; p.acc = acc;
-  const int nb = red_grid(rows, c);
-  hipLaunchKernelGGL(k_col_reduce<RED_BNBWD>, dim3(nb), dim3(RED_THREADS), 0, s, p);
-  hipLaunchKernelGGL(k_sums_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, sums);
-  PCP_CHECK_LAUNCH();
-  return PCP_OK;
+  return bn_bwd_sums_impl(dout, PCP_DT_F32, ld_dout, x, PCP_DT_F32, ld_x, rows, c, scale, shift, mean, invstd, relu, workspace, sums, stream);
 }
 
 int pcp_bn_bwd_apply_from_sums(const float *dout, int32_t ld_dout, const float *x, int32_t ld_x, int64_t rows, int32_t c, const float *scale,
                                const float *shift, const float *mean, const float *invstd, int32_t relu, const double *local_sums,
                                const double *global_sums, int64_t total_rows, void *workspace, float *dgamma, float *dbeta,
                                int32_t accumulate, float *dx, int32_t ld_dx, void *stream) {
-  if (!dout || !x || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !workspace || !dgamma || !dbeta || !dx ||
-      !red_shape_ok(rows, c, ld_x) || (ld_dout & 3) || (ld_dx & 3) || !al16(dout) || !al16(x) || !al16(dx) || total_rows < rows)
-    return PCP_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  float *coef = (float *)((double *)workspace + 2 * (size_t)c * RED_MAX_BLOCKS);
-  hipLaunchKernelGGL(k_bnbwd_finalize_sync, dim3((c + 255) / 256), dim3(256), 0, s, local_sums, global_sums, (double)total_rows, c, dgamma, dbeta,
-                     accumulate, coef);
-  const long long total = (long long)rows * (c >> 2);
-  hipLaunchKernelGGL(k_bnbwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, ld_dout, x, ld_x, (long long)rows,
-                     c >> 2, c, scale, shift, mean, invstd, relu, coef, dx, ld_dx);
-  PCP_CHECK_LAUNCH();
-  return PCP_OK;
+  return bn_bwd_apply_from_sums_impl(dout, PCP_DT_F32, ld_dout, x, PCP_DT_F32, ld_x, rows, c, scale, shift, mean, invstd, relu, local_sums,
+                                     global_sums, total_rows, workspace, dgamma, dbeta, accumulate, dx, PCP_DT_F32, ld_dx, stream);
 }
 
 int pcp_colsum(const float *x, int64_t rows, int32_t c, int32_t ld, void *workspace, float *out, int32_t accumulate, void *stream) {
-  if (!x || !workspace || !out || !red_shape_ok(rows, c, ld) || !al16(x)) return PCP_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  double *acc = (double *)workspace;
-  RedParams p{};
-  p.x = x; p.rows = rows; p.c = c; p.ld_x = ld; p.acc = acc;
-  const int nb = red_grid(rows, c);
-  hipLaunchKernelGGL(k_col_reduce<RED_COLSUM>, dim3(nb), dim3(RED_THREADS), 0, s, p);
-  hipLaunchKernelGGL(k_colsum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, s, acc, nb, c, out, accumulate);
-  PCP_CHECK_LAUNCH();
-  return PCP_OK;
+  return colsum_impl(x, PCP_DT_F32, rows, c, ld, workspace, out, accumulate, stream);
 }
 
 int pcp_accumulate(float *dst, int32_t ld_dst, const float *src, int32_t ld_src, int64_t rows, int32_t c, float alpha, void *stream) {
-  if (!dst || !src || rows <= 0 || c < 4 || (c & 3) || (ld_dst & 3) || (ld_src & 3) || !al16(dst) || !al16(src)) return PCP_ERR_ARG;
-  const long long total = (long long)rows * (c >> 2);
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src,
-                     (long long)rows, c >> 2, alpha);
-  PCP_CHECK_LAUNCH();
-  return PCP_OK;
+  return accumulate_impl(dst, PCP_DT_F32, ld_dst, src, PCP_DT_F32, ld_src, rows, c, alpha, stream);
 }
 
 int pcp_dilate2x(const float *in, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_in, float *out, int32_t ld_out,
                  void *stream) {
-  if (!in || !out || batch <= 0 || h <= 0 || w <= 0 || c < 4 || (c & 3) || (ld_in & 3) || (ld_out & 3) || !al16(in) || !al16(out))
-    return PCP_ERR_ARG;
-  const long long total = (long long)batch * 4 * h * w * (c >> 2);
-  hipLaunchKernelGGL(k_dilate2x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, batch, h, w, c >> 2, ld_in,
-                     out, ld_out);
-  PCP_CHECK_LAUNCH();
-  return PCP_OK;
+  return dilate2x_impl(in, PCP_DT_F32, batch, h, w, c, ld_in, out, ld_out, stream);
+}
+
+// ---- mixed-precision entry points (include/pcp_hip_mp.h): the same kernels with a storage type per tensor ---------------------------
+int pcp_mp_bn_train_stats(const void *x, int32_t x_dtype, int64_t rows, int32_t c, int32_t ld, const float *gamma, const float *beta, float eps,
+                          float momentum, float *running_mean, float *running_var, void *workspace, float *scale, float *shift,
+                          float *mean, float *invstd, void *stream) {
+  return bn_train_stats_impl(x, x_dtype, rows, c, ld, gamma, beta, eps, momentum, running_mean, running_var, workspace, scale, shift, mean,
+                             invstd, stream);
+}
+
+int pcp_mp_scale_shift_act(const void *x, int32_t x_dtype, int64_t rows, int32_t c, int32_t ld_x, const float *scale, const float *shift,
+                           int32_t relu, void *out, int32_t out_dtype, int32_t ld_out, void *stream) {
+  return scale_shift_act_impl(x, x_dtype, rows, c, ld_x, scale, shift, relu, out, out_dtype, ld_out, stream);
+}
+
+int pcp_mp_bn_act_backward(const void *dout, int32_t dout_dtype, int32_t ld_dout, const void *x, int32_t x_dtype, int32_t ld_x, int64_t rows,
+                           int32_t c, const float *scale, const float *shift, const float *mean, const float *invstd, int32_t relu,
+                           void *workspace, float *dgamma, float *dbeta, int32_t accumulate, void *dx, int32_t dx_dtype, int32_t ld_dx,
+                           void *stream) {
+  return bn_act_backward_impl(dout, dout_dtype, ld_dout, x, x_dtype, ld_x, rows, c, scale, shift, mean, invstd, relu, workspace, dgamma, dbeta,
+                              accumulate, dx, dx_dtype, ld_dx, stream);
+}
+
+int pcp_mp_bn_train_sums(const void *x, int32_t x_dtype, int64_t rows, int32_t c, int32_t ld, void *workspace, double *sums, void *stream) {
+  return bn_train_sums_impl(x, x_dtype, rows, c, ld, workspace, sums, stream);
+}
+
+int pcp_mp_bn_bwd_sums(const void *dout, int32_t dout_dtype, int32_t ld_dout, const void *x, int32_t x_dtype, int32_t ld_x, int64_t rows,
+                       int32_t c, const float *scale, const float *shift, const float *mean, const float *invstd, int32_t relu,
+                       void *workspace, double *sums, void *stream) {
+  return bn_bwd_sums_impl(dout, dout_dtype, ld_dout, x, x_dtype, ld_x, rows, c, scale, shift, mean, invstd, relu, workspace, sums, stream);
+}
+
+int pcp_mp_bn_bwd_apply_from_sums(const void *dout, int32_t dout_dtype, int32_t ld_dout, const void *x, int32_t x_dtype, int32_t ld_x,
+                                  int64_t rows, int32_t c, const float *scale, const float *shift, const float *mean, const float *invstd,
+                                  int32_t relu, const double *local_sums, const double *global_sums, int64_t total_rows, void *workspace,
+                                  float *dgamma, float *dbeta, int32_t accumulate, void *dx, int32_t dx_dtype, int32_t ld_dx, void *stream) {
+  return bn_bwd_apply_from_sums_impl(dout, dout_dtype, ld_dout, x, x_dtype, ld_x, rows, c, scale, shift, mean, invstd, relu, local_sums,
+                                     global_sums, total_rows, workspace, dgamma, dbeta, accumulate, dx, dx_dtype, ld_dx, stream);
+}
+
+int pcp_mp_colsum(const void *x, int32_t x_dtype, int64_t rows, int32_t c, int32_t ld, void *workspace, float *out, int32_t accumulate,
+                  void *stream) {
+  return colsum_impl(x, x_dtype, rows, c, ld, workspace, out, accumulate, stream);
+}
+
+int pcp_mp_accumulate(void *dst, int32_t dst_dtype, int32_t ld_dst, const void *src, int32_t src_dtype, int32_t ld_src, int64_t rows,
+                      int32_t c, float alpha, void *stream) {
+  return accumulate_impl(dst, dst_dtype, ld_dst, src, src_dtype, ld_src, rows, c, alpha, stream);
+}
+
+int pcp_mp_dilate2x(const void *in, int32_t dtype, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_in, void *out, int32_t ld_out,
+                    void *stream) {
+  return dilate2x_impl(in, dtype, batch, h, w, c, ld_in, out, ld_out, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,295 @@
+// Weight gradient of the 3x3 convolution for the bf16 training loop (include/pcp_hip_mp.h: pcp_mp_conv3x3_wgrad):
+//   dw[co][ci][ky][kx] (+)= sum over output pixels p of dy[p][co] * x[S p + (ky - 1, kx - 1)][ci]
+// a GEMM whose contraction runs over PIXELS, on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Replaces the weight-gradient half of the
+// autograd node of nn.Conv2d(k=3) (pcdet/models/backbones_2d/base_bev_backbone.py:30-69, dense_heads/center_head.py:24-29,75-82,
+// bev_layers/v2x_fusion_disco.py:51-63) as it runs under torch.cuda.amp.autocast; round 3's fp32 kernel is csrc/wgrad.hip.
+//
+// Both operands are NHWC (channel-contiguous) but the MFMA wants 8 consecutive k = 8 consecutive PIXELS of one channel per lane: the rows
+// are copied global -> LDS as they lie (128-byte pixel records = 64 channels, `buffer_load_dwordx4 ... lds`) and read back TRANSPOSED by
+// ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16 lanes).  The 32-byte channel chunks of a record are XOR-swizzled by bit 1 of the
+// pixel position (on the source address of the copy), which makes the four pixel rows of a transposed read hit four different bank groups.
+//
+// workgroup (4 waves = the quadrants of a 64 (co) x 64 (ci) tile, nine 32 x 32 accumulators per wave = all taps) owns one (co block, ci
+// block) pair, one frame, one 32-column strip and a run of output rows; it walks the run TR rows at a time.  LDS: dy rows double buffered,
+// x rows in a ring of three 4-row groups (every x row is fetched ONCE per strip: the halo rows of a stage are the previous / next group).
+// The copy of the next stage runs under the MFMAs of the current one; one barrier per stage.  Stride 2: the x rows are stored with even
+// and odd columns apart (the loader permutes), so the 16 pixels of a k step are consecutive records again.
+// Partial tiles (fp32, [pair][split][9][64][64]) go to the workspace; k_mp_wgrad_reduce sums them in split order (bitwise reproducible).
+// The kernel is HBM-bound by design: a 64 x 64 x 9 tile gives 224 flop per input byte, under the bf16 ridge of ~400.
+#include "pcp_common.h"
+#include "../../include/pcp_hip_mp.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr unsigned WG_OOB = 0x80000000u;
+constexpr int WG_THREADS = 256;
+constexpr int WG_DW = 32;                 // dy columns of a strip
+
+template <int S> struct WgCfg;
+template <> struct WgCfg<1> { static constexpr int TR = 4, XWP = 34, XHALF = 0; };      // XWP: x records per row in LDS
+template <> struct WgCfg<2> { static constexpr int TR = 2, XWP = 72, XHALF = 36; };     // [parity][36]
+
+struct WgParams {
+  const void *x, *dy;
+  float *partial;
+  int batch, h, w, oh, ow, cin, cout, ld_x, ld_dy;
+  int n_cob, n_cib, n_strips, n_rsplit, rows_per, n_split;
+  unsigned x_bytes, dy_bytes;
+};
+
+__device__ __forceinline__ int wg_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <int S>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
+  typedef WgCfg<S> C;
+  constexpr int TR = C::TR, XWP = C::XWP;
+  constexpr int XG_BYTES = 4 * XWP * 128;                 // one x group (4 rows)
+  constexpr int XGI = XG_BYTES / 1024;                    // wave-instructions per x group (17 | 36)
+  constexpr int DY_BYTES = TR * WG_DW * 128;              // one dy stage
+  constexpr int DYI = DY_BYTES / 1024;                    // 16 | 8
+  constexpr int NXL = (XGI + 3) / 4, NDL = (DYI + 3) / 4; // copy instructions per wave
+  static_assert(XG_BYTES % 1024 == 0 && DY_BYTES % 1024 == 0, "whole wave instructions");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * XG_BYTES + 2 * DY_BYTES];
+  unsigned char *xring = lds, *dybuf = lds + 3 * XG_BYTES;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;                // co half, ci half of the 64 x 64 tile
+
+  // ---- which (pair, split) --------------------------------------------------------------------------------------------------------------
+  const int n_pairs = p.n_cob * p.n_cib;
+  int lid = wg_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = lid % n_pairs;
+  const int split = lid / n_pairs;
+  const int cob = pair / p.n_cib, cib = pair % p.n_cib;
+  int sp = split;
+  const int rs = sp % p.n_rsplit;
+  sp /= p.n_rsplit;
+  const int strip = sp % p.n_strips;
+  const int b = sp / p.n_strips;
+  const int r0 = rs * p.rows_per, r1 = min(r0 + p.rows_per, p.oh);
+  const int c0 = strip * WG_DW;
+  const int n_st = (r1 - r0 + TR - 1) / TR;
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  // ---- copy plan ----------------------------------------------------------------------------------------------------------------------------
+  // x group instruction k of this wave = wave-instruction i = wave + 4k: LDS piece q = i*64 + lane = record (row, pos), 16-byte piece;
+  // the LDS chunk position c2' = piece >> 1 holds channel chunk c2 = c2' ^ sw(pos)
+  int xrow[NXL], xcol[NXL], xsrc[NXL];
+#pragma unroll
+  for (int k = 0; k < NXL; ++k) {
+    const int q = (wave + 4 * k) * 64 + lane;
+    const int rec = q >> 3, piece = q & 7;
+    xrow[k] = rec / XWP;
+    const int pos = rec - xrow[k] * XWP;
+    int xc = pos;
+    if (S == 2) { const int par = pos >= C::XHALF ? 1 : 0, idx = pos - par * C::XHALF; xc = 2 * idx + par; }
+    xcol[k] = (xc <= S * (WG_DW - 1) + 2) ? xc : -100000;                    // columns past the last tap of the strip: zeros, no traffic
+    const int c2 = (piece >> 1) ^ (((pos >> 1) & 1) << 1);
+    xsrc[k] = cib * 128 + ((c2 << 1) | (piece & 1)) * 16;
+  }
+  int drow[NDL], dcol[NDL], dsrc[NDL];
+#pragma unroll
+  for (int k = 0; k < NDL; ++k) {
+    const int q = (wave + 4 * k) * 64 + lane;
+    const int rec = q >> 3, piece = q & 7;
+    drow[k] = rec / WG_DW;
+    dcol[k] = rec % WG_DW;
+    const int c2 = (piece >> 1) ^ (((dcol[k] >> 1) & 1) << 1);
+    dsrc[k] = cob * 128 + ((c2 << 1) | (piece & 1)) * 16;
+  }
+  const int gx0 = S * c0 - 1;
+  auto issue_x = [&](int g) {                             // x rows [S r0 - 1 + 4g, +4) -> ring slot g % 3
+    unsigned char *base = xring + (g % 3) * XG_BYTES;
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) {
+      const int i = wave + 4 * k;
+      if (i < XGI) {
+        const int gy = S * r0 - 1 + 4 * g + xrow[k], gx = gx0 + xcol[k];
+        unsigned off = WG_OOB;
+        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) off = (unsigned)(((b * p.h + gy) * p.w + gx) * p.ld_x * 2 + xsrc[k]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+  auto issue_dy = [&](int s) {                            // dy rows [r0 + TR s, +TR) -> buffer s & 1
+    unsigned char *base = dybuf + (s & 1) * DY_BYTES;
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) {
+      const int i = wave + 4 * k;
+      if (i < DYI) {
+        const int gy = r0 + TR * s + drow[k], gx = c0 + dcol[k];
+        unsigned off = WG_OOB;
+        if (gy < r1 && gx < p.ow) off = (unsigned)(((b * p.oh + gy) * p.ow + gx) * p.ld_dy * 2 + dsrc[k]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- transposed-read addresses (bytes inside a row image; see the header comment) -------------------------------------------------------
+  // lane = (hh = lane >> 5, blk = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3): read t of k step kk takes pixel 16kk + 8hh + 4t + q,
+  // channels 32 half + 16 blk + 4 pp .. + 3
+  const int hh = lane >> 5, blk = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const int a_lane = (8 * hh + q4) * 128 + (((2 * wm + blk) ^ ((q4 >> 1) << 1)) * 32) + pp * 8;       // dy: pos = 16kk + 8hh + 4t + q
+  int b_lane[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    int pos = 8 * hh + q4, posoff;
+    if (S == 1) { pos += kx; posoff = 0; }
+    else { pos += (kx >> 1); posoff = (kx & 1) * C::XHALF; }
+    // the swizzle bit is bit 1 of the record position; 16kk + 4t and XHALF (36) leave it unchanged
+    b_lane[kx] = (pos + posoff) * 128 + (((2 * wn + blk) ^ (((pos >> 1) & 1) << 1)) * 32) + pp * 8;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  auto tr_read = [&](const unsigned char *addr) -> s16x4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(addr));
+  };
+
+  issue_x(0);
+  issue_x(1);
+  issue_dy(0);
+  for (int s = 0; s < n_st; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < n_st) {
+      issue_x(s + 2);
+      issue_dy(s + 1);
+    }
+    const unsigned char *dyb = dybuf + (s & 1) * DY_BYTES + a_lane;
+#pragma unroll
+    for (int rr = 0; rr < TR; ++rr) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const unsigned char *ap = dyb + (rr * WG_DW + 16 * kk) * 128;
+        const s16x4 a0 = tr_read(ap), a1 = tr_read(ap + 4 * 128);
+        const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int rel = S * rr + ky;                                   // x row relative to group s: 0 .. 5
+          // ring slot of that row: group (s + rel / 4) % 3, row rel % 4
+          const unsigned char *xrow_base = xring + ((s + (rel >> 2)) % 3) * XG_BYTES + (rel & 3) * (XWP * 128);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const unsigned char *bp = xrow_base + b_lane[kx] + (16 * kk) * 128;
+            const s16x4 b0 = tr_read(bp), b1 = tr_read(bp + 4 * 128);
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ky * 3 + kx], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partial tile: [pair][split][tap][co 64][ci 64]; lane (ci = lane & 31, hh) holds rows (e & 3) + 8 (e >> 2) + 4 hh of its quadrant -------
+  float *dst = p.partial + ((long long)pair * p.n_split + split) * (9 * 64 * 64);
+  const int ci = wn * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      dst[(t * 64 + co) * 64 + ci] = acc[t][e];
+    }
+}
+
+// dw[co][ci][tap] (+)= sum over splits, in split order
+__global__ void k_mp_wgrad_reduce(const float *__restrict__ partial, int n_split, int n_cob, int n_cib, int cout, int cin, float *__restrict__ dw,
+                                  int accumulate) {
+  const int pair = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;             // (tap, co, ci) of the 64 x 64 tile
+  if (e >= 9 * 64 * 64) return;
+  const int ci_l = e & 63, co_l = (e >> 6) & 63, tap = e >> 12;
+  const int cob = pair / n_cib, cib = pair % n_cib;
+  const int co = cob * 64 + co_l, ci = cib * 64 + ci_l;
+  if (co >= cout || ci >= cin) return;
+  const float *src = partial + (long long)pair * n_split * (9 * 64 * 64) + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < n_split; i += 4) {                                // four loads in flight; summed in split order
+    const float v0 = src[(long long)i * (9 * 64 * 64)], v1 = src[(long long)(i + 1) * (9 * 64 * 64)];
+    const float v2 = src[(long long)(i + 2) * (9 * 64 * 64)], v3 = src[(long long)(i + 3) * (9 * 64 * 64)];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; i < n_split; ++i) s0 += src[(long long)i * (9 * 64 * 64)];
+  const float sum = (s0 + s1) + (s2 + s3);
+  float *o = dw + ((long long)co * cin + ci) * 9 + tap;
+  *o = accumulate ? *o + sum : sum;
+}
+
+struct WgPlan { int n_cob, n_cib, n_strips, n_rsplit, rows_per, n_split, oh, ow; };
+
+bool wg_plan(const pcp_mp_wgrad3x3_t *d, WgPlan &pl) {
+  if (!d || d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->cin <= 0 || d->cout <= 0 || (d->stride != 1 && d->stride != 2)) return false;
+  if ((d->cin % 8) || (d->cout % 8) || (d->ld_x % 8) || (d->ld_dy % 8)) return false;
+  if (d->x_dtype != PCP_DT_BF16 || d->dy_dtype != PCP_DT_BF16) return false;
+  if (d->stride == 2 && ((d->in_h | d->in_w) & 1)) return false;
+  pl.oh = d->in_h / d->stride;
+  pl.ow = d->in_w / d->stride;
+  pl.n_cob = (d->cout + 63) / 64;
+  pl.n_cib = (d->cin + 63) / 64;
+  pl.n_strips = (pl.ow + WG_DW - 1) / WG_DW;
+  const int tr = d->stride == 1 ? 4 : 2;
+  const long long base = (long long)d->batch * pl.n_strips * pl.n_cob * pl.n_cib;
+  long long rsplit = (256 + base / 2) / base;                          // about one workgroup per CU
+  const int max_rs = (pl.oh + 2 * tr - 1) / (2 * tr);                  // at least two stages per workgroup
+  if (rsplit > max_rs) rsplit = max_rs;
+  if (rsplit < 1) rsplit = 1;
+  pl.rows_per = (int)(((pl.oh + rsplit - 1) / rsplit + tr - 1) / tr * tr);
+  pl.n_rsplit = (pl.oh + pl.rows_per - 1) / pl.rows_per;
+  pl.n_split = d->batch * pl.n_strips * pl.n_rsplit;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pcp_mp_conv3x3_wgrad_workspace_bytes(const pcp_mp_wgrad3x3_t *d) {
+  WgPlan pl;
+  if (!wg_plan(d, pl)) return 0;
+  return (size_t)pl.n_cob * pl.n_cib * pl.n_split * (9 * 64 * 64) * sizeof(float);
+}
+
+int pcp_mp_conv3x3_wgrad(const pcp_mp_wgrad3x3_t *d, const void *x, const void *dy, float *dw, void *workspace, size_t workspace_bytes,
+                         void *stream) {
+  WgPlan pl;
+  if (!x || !dy || !dw || !workspace || !wg_plan(d, pl)) return PCP_ERR_ARG;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)dy) & 15) || (((uintptr_t)workspace) & 15)) return PCP_ERR_ARG;
+  if (workspace_bytes < pcp_mp_conv3x3_wgrad_workspace_bytes(d)) return PCP_ERR_WORKSPACE;
+  const long long xb = (long long)d->batch * d->in_h * d->in_w * d->ld_x * 2, db = (long long)d->batch * pl.oh * pl.ow * d->ld_dy * 2;
+  if (xb >= 0x7fffffffLL || db >= 0x7fffffffLL) return PCP_ERR_UNSUPPORTED;
+  WgParams p;
+  p.x = x; p.dy = dy; p.partial = (float *)workspace;
+  p.batch = d->batch; p.h = d->in_h; p.w = d->in_w; p.oh = pl.oh; p.ow = pl.ow; p.cin = d->cin; p.cout = d->cout;
+  p.ld_x = d->ld_x; p.ld_dy = d->ld_dy;
+  p.n_cob = pl.n_cob; p.n_cib = pl.n_cib; p.n_strips = pl.n_strips; p.n_rsplit = pl.n_rsplit; p.rows_per = pl.rows_per; p.n_split = pl.n_split;
+  p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned nwg = (unsigned)(pl.n_cob * pl.n_cib * pl.n_split);
+  if (d->stride == 1) hipLaunchKernelGGL(k_mp_wgrad3x3<1>, dim3(nwg), dim3(WG_THREADS), 0, s, p);
+  else hipLaunchKernelGGL(k_mp_wgrad3x3<2>, dim3(nwg), dim3(WG_THREADS), 0, s, p);
+  hipLaunchKernelGGL(k_mp_wgrad_reduce, dim3((9 * 64 * 64 + 255) / 256, pl.n_cob * pl.n_cib), dim3(256), 0, s, (const float *)workspace, pl.n_split,
+                     pl.n_cob, pl.n_cib, d->cout, d->cin, dw, d->accumulate ? 1 : 0);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+}  // extern "C"

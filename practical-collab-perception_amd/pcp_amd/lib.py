@@ -34,6 +34,21 @@ class Conv3x3(ctypes.Structure):
                 ('stride', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32)]
 
 
+class MpConv3x3(ctypes.Structure):
+    """pcp_mp_conv3x3_t (include/pcp_hip_mp.h)"""
+    _fields_ = [('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32), ('cout', c_i32), ('cout_pad', c_i32),
+                ('stride', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32), ('in_dtype', c_i32), ('out_dtype', c_i32)]
+
+
+class MpWgrad3x3(ctypes.Structure):
+    """pcp_mp_wgrad3x3_t (include/pcp_hip_mp.h)"""
+    _fields_ = [('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32), ('cout', c_i32), ('stride', c_i32),
+                ('ld_x', c_i32), ('ld_dy', c_i32), ('x_dtype', c_i32), ('dy_dtype', c_i32), ('accumulate', c_i32)]
+
+
+DT_F32, DT_BF16 = 0, 1
+
+
 class Pointwise(ctypes.Structure):
     _fields_ = [('mode', c_i32), ('rows', c_i64), ('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32),
                 ('cout', c_i32), ('cout_pad', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32),
@@ -226,6 +241,27 @@ SYMBOLS.update({
     'pcp_pack_conv3x3_group_blocks': (c_i32, [vp]),
     'pcp_pack_conv3x3_group': (c_i32, [vp, c_i32, c_i32, vp]),
     'pcp_adam_step': (c_i32, [vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, vp, c_f, vp]),
+})
+
+# include/pcp_hip_mp.h (mixed-precision training loop, config 5)
+SYMBOLS.update({
+    'pcp_mp_bn_train_stats': (c_i32, [vp, c_i32, c_i64, c_i32, c_i32, vp, vp, c_f, c_f, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_mp_scale_shift_act': (c_i32, [vp, c_i32, c_i64, c_i32, c_i32, vp, vp, c_i32, vp, c_i32, c_i32, vp]),
+    'pcp_mp_bn_act_backward': (c_i32, [vp, c_i32, c_i32, vp, c_i32, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, vp, c_i32, vp, c_i32,
+                                       c_i32, vp]),
+    'pcp_mp_bn_train_sums': (c_i32, [vp, c_i32, c_i64, c_i32, c_i32, vp, vp, vp]),
+    'pcp_mp_bn_bwd_sums': (c_i32, [vp, c_i32, c_i32, vp, c_i32, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, vp]),
+    'pcp_mp_bn_bwd_apply_from_sums': (c_i32, [vp, c_i32, c_i32, vp, c_i32, c_i32, c_i64, c_i32, vp, vp, vp, vp, c_i32, vp, vp, c_i64, vp, vp, vp,
+                                              c_i32, vp, c_i32, c_i32, vp]),
+    'pcp_mp_colsum': (c_i32, [vp, c_i32, c_i64, c_i32, c_i32, vp, vp, c_i32, vp]),
+    'pcp_mp_accumulate': (c_i32, [vp, c_i32, c_i32, vp, c_i32, c_i32, c_i64, c_i32, c_f, vp]),
+    'pcp_mp_dilate2x': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp]),
+    'pcp_mp_conv3x3_packed_bytes': (c_sz, [c_i32, c_i32]),
+    'pcp_mp_pack_conv3x3': (c_i32, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
+    'pcp_mp_conv3x3': (c_i32, [ctypes.POINTER(MpConv3x3), vp, vp, vp, vp, vp]),
+    'pcp_mp_conv3x3_plan': (c_i32, [ctypes.POINTER(MpConv3x3), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
+    'pcp_mp_conv3x3_wgrad_workspace_bytes': (c_sz, [ctypes.POINTER(MpWgrad3x3)]),
+    'pcp_mp_conv3x3_wgrad': (c_i32, [ctypes.POINTER(MpWgrad3x3), vp, vp, vp, vp, c_sz, vp]),
 })
 
 _LIB = None

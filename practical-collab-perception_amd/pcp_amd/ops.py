@@ -139,7 +139,7 @@ def fill_zero(t):
 # ---------------------------------------------------------------------------------------------------------------------
 
 def _chan_ptr(t, ch_off):
-    return ctypes.c_void_p(t.data_ptr() + 4 * ch_off)
+    return ctypes.c_void_p(t.data_ptr() + t.element_size() * ch_off)
 
 
 def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):

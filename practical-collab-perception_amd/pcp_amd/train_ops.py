@@ -27,8 +27,21 @@ _WG_WS = Scratch()
 
 def _rows_c(x):
     """(..., ld) contiguous tensor -> (rows, ld)"""
-    assert x.is_contiguous() and x.dtype == torch.float32
+    assert x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
     return x.numel() // x.shape[-1], x.shape[-1]
+
+
+def _dt(t):
+    """storage-type code of include/pcp_hip_mp.h"""
+    if t.dtype == torch.float32:
+        return _lib.DT_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.DT_BF16
+    raise _lib.PcpError('tensor of %s: the training kernels store float32 or bfloat16' % t.dtype)
+
+
+def _all_f32(*ts):
+    return all(t.dtype == torch.float32 for t in ts)
 
 
 class BNVectors:
@@ -74,12 +87,17 @@ def bn_train_stats(x, c, gamma, beta, eps, momentum, running_mean, running_var, 
     if dist is not None:
         buf = torch.empty((2 * c + 1,), dtype=torch.float64, device=x.device)
         buf[2 * c:].fill_(float(rows))
-        check(L.pcp_bn_train_sums(_chan_ptr(x, ch_off), rows, c, ld, _p(ws), _p(buf), _stream()), 'pcp_bn_train_sums')
+        check(L.pcp_mp_bn_train_sums(_chan_ptr(x, ch_off), _dt(x), rows, c, ld, _p(ws), _p(buf), _stream()), 'pcp_mp_bn_train_sums')
         buf = _all_reduce_sums(dist, buf)
         total = int(round(float(buf[2 * c].item())))
         check(L.pcp_bn_train_stats_from_sums(_p(buf), total, c, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
                                              _p(running_var), _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), _stream()),
               'pcp_bn_train_stats_from_sums')
+        return vec
+    if not _all_f32(x):
+        check(L.pcp_mp_bn_train_stats(_chan_ptr(x, ch_off), _dt(x), rows, c, ld, _p(gamma), _p(beta), float(eps), float(momentum),
+                                      _p(running_mean), _p(running_var), _p(ws), _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd),
+                                      _stream()), 'pcp_mp_bn_train_stats')
         return vec
     check(L.pcp_bn_train_stats(_chan_ptr(x, ch_off), rows, c, ld, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
                                _p(running_var), _p(ws), _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), _stream()),
@@ -93,6 +111,10 @@ def scale_shift_act(x, c, vec, relu, out, in_ch_off=0, out_ch_off=0):
     rows, ld = _rows_c(x)
     rows_o, ld_o = _rows_c(out)
     assert rows == rows_o
+    if not _all_f32(x, out):
+        check(L.pcp_mp_scale_shift_act(_chan_ptr(x, in_ch_off), _dt(x), rows, c, ld, _p(vec.scale), _p(vec.shift), 1 if relu else 0,
+                                       _chan_ptr(out, out_ch_off), _dt(out), ld_o, _stream()), 'pcp_mp_scale_shift_act')
+        return out
     check(L.pcp_scale_shift_act(_chan_ptr(x, in_ch_off), rows, c, ld, _p(vec.scale), _p(vec.shift), 1 if relu else 0,
                                 _chan_ptr(out, out_ch_off), ld_o, _stream()), 'pcp_scale_shift_act')
     return out
@@ -113,14 +135,20 @@ def bn_act_backward(dout, x, c, vec, relu, dgamma, dbeta, accumulate=False, dx=N
     if dist is not None:
         local = torch.empty((2 * c + 1,), dtype=torch.float64, device=x.device)
         local[2 * c:].fill_(float(rows))
-        check(L.pcp_bn_bwd_sums(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale), _p(vec.shift),
-                                _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(local), _stream()), 'pcp_bn_bwd_sums')
+        check(L.pcp_mp_bn_bwd_sums(_chan_ptr(dout, dout_ch_off), _dt(dout), ld_d, _chan_ptr(x, x_ch_off), _dt(x), ld_x, rows, c, _p(vec.scale),
+                                   _p(vec.shift), _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(local), _stream()), 'pcp_mp_bn_bwd_sums')
         glob = _all_reduce_sums(dist, local.clone())
         total = int(round(float(glob[2 * c].item())))
-        check(L.pcp_bn_bwd_apply_from_sums(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale),
-                                           _p(vec.shift), _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(local), _p(glob), total, _p(ws),
-                                           _p(dgamma), _p(dbeta), 1 if accumulate else 0, _chan_ptr(dx, dx_ch_off), ld_dx, _stream()),
-              'pcp_bn_bwd_apply_from_sums')
+        check(L.pcp_mp_bn_bwd_apply_from_sums(_chan_ptr(dout, dout_ch_off), _dt(dout), ld_d, _chan_ptr(x, x_ch_off), _dt(x), ld_x, rows, c,
+                                              _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(local), _p(glob),
+                                              total, _p(ws), _p(dgamma), _p(dbeta), 1 if accumulate else 0, _chan_ptr(dx, dx_ch_off), _dt(dx),
+                                              ld_dx, _stream()), 'pcp_mp_bn_bwd_apply_from_sums')
+        return dx
+    if not _all_f32(dout, x, dx):
+        check(L.pcp_mp_bn_act_backward(_chan_ptr(dout, dout_ch_off), _dt(dout), ld_d, _chan_ptr(x, x_ch_off), _dt(x), ld_x, rows, c,
+                                       _p(vec.scale), _p(vec.shift), _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(dgamma),
+                                       _p(dbeta), 1 if accumulate else 0, _chan_ptr(dx, dx_ch_off), _dt(dx), ld_dx, _stream()),
+              'pcp_mp_bn_act_backward')
         return dx
     check(L.pcp_bn_act_backward(_chan_ptr(dout, dout_ch_off), ld_d, _chan_ptr(x, x_ch_off), ld_x, rows, c, _p(vec.scale), _p(vec.shift),
                                 _p(vec.mean), _p(vec.invstd), 1 if relu else 0, _p(ws), _p(dgamma), _p(dbeta), 1 if accumulate else 0,
@@ -133,6 +161,9 @@ def colsum(x, c, out, accumulate=False, ch_off=0):
     L = _lib.load()
     rows, ld = _rows_c(x)
     ws = _BN_WS.get(L.pcp_bn_workspace_bytes(c), x.device)
+    if not _all_f32(x):
+        check(L.pcp_mp_colsum(_chan_ptr(x, ch_off), _dt(x), rows, c, ld, _p(ws), _p(out), 1 if accumulate else 0, _stream()), 'pcp_mp_colsum')
+        return out
     check(L.pcp_colsum(_chan_ptr(x, ch_off), rows, c, ld, _p(ws), _p(out), 1 if accumulate else 0, _stream()), 'pcp_colsum')
     return out
 
@@ -143,6 +174,10 @@ def accumulate(dst, src, c, alpha=1.0, dst_ch_off=0, src_ch_off=0):
     rows, ld_d = _rows_c(dst)
     rows_s, ld_s = _rows_c(src)
     assert rows == rows_s
+    if not _all_f32(dst, src):
+        check(L.pcp_mp_accumulate(_chan_ptr(dst, dst_ch_off), _dt(dst), ld_d, _chan_ptr(src, src_ch_off), _dt(src), ld_s, rows, c, float(alpha),
+                                  _stream()), 'pcp_mp_accumulate')
+        return dst
     check(L.pcp_accumulate(_chan_ptr(dst, dst_ch_off), ld_d, _chan_ptr(src, src_ch_off), ld_s, rows, c, float(alpha), _stream()),
           'pcp_accumulate')
     return dst
@@ -153,7 +188,11 @@ def dilate2x(x, c, out=None, ch_off=0):
     L = _lib.load()
     B, H, W, ld = x.shape
     if out is None:
-        out = torch.empty((B, 2 * H, 2 * W, c), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, 2 * H, 2 * W, c), dtype=x.dtype, device=x.device)
+    if not _all_f32(x, out):
+        assert out.dtype == x.dtype
+        check(L.pcp_mp_dilate2x(_chan_ptr(x, ch_off), _dt(x), B, H, W, c, ld, _p(out), out.shape[-1], _stream()), 'pcp_mp_dilate2x')
+        return out
     check(L.pcp_dilate2x(_chan_ptr(x, ch_off), B, H, W, c, ld, _p(out), out.shape[-1], _stream()), 'pcp_dilate2x')
     return out
 
@@ -170,6 +209,61 @@ def conv3x3_wgrad(x, dy, cin, cout, stride, dw, accumulate=False, x_ch_off=0, dy
     ws = _WG_WS.get(need, x.device)
     check(L.pcp_conv3x3_wgrad(ctypes.byref(d), _chan_ptr(x, x_ch_off), _chan_ptr(dy, dy_ch_off), _p(ws), ws.numel(), _p(dw),
                               1 if accumulate else 0, _stream()), 'pcp_conv3x3_wgrad')
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mixed-precision (bf16) convolution kernels of the training loop (include/pcp_hip_mp.h)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def mp_pack_conv3x3(w, transpose=False, out=None, fold_scale=None):
+    """(cout, cin, 3, 3) float32 -> the bf16 weight form of pcp_mp_conv3x3 (a bfloat16 tensor); transpose: the data-gradient form.
+    Returns (packed, out_pad)."""
+    _need_cuda(w, out, fold_scale)
+    L = _lib.load()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    K, O = (cout, cin) if transpose else (cin, cout)
+    opad = (O + 63) // 64 * 64
+    n = L.pcp_mp_conv3x3_packed_bytes(K, opad) // 2
+    if n == 0:
+        raise _lib.PcpError('pcp_mp_pack_conv3x3: %d contraction channels (need a multiple of 16)' % K)
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    assert out.numel() == n and out.dtype == torch.bfloat16 and w.is_contiguous() and w.dtype == torch.float32
+    check(L.pcp_mp_pack_conv3x3(_p(w), cout, cin, 1 if transpose else 0, _p(fold_scale), _p(out), opad, _stream()), 'pcp_mp_pack_conv3x3')
+    return out, opad
+
+
+def mp_conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=False, out=None, out_dtype=torch.bfloat16, in_ch_off=0, out_ch_off=0):
+    """x: (B, H, W, ld) float32 | bfloat16 NHWC; out: same for the output (allocated (B, Ho, Wo, cout) of out_dtype when None)."""
+    _need_cuda(x, packed, bias, out)
+    L = _lib.load()
+    B, H, W, ld_in = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cout), dtype=out_dtype, device=x.device)
+    assert tuple(out.shape[:3]) == (B, Ho, Wo) and x.is_contiguous() and out.is_contiguous()
+    assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3] and bias.numel() >= cout_pad
+    d = _lib.MpConv3x3(B, H, W, cin, cout, cout_pad, stride, ld_in, out.shape[3], 1 if relu else 0, _dt(x), _dt(out))
+    check(L.pcp_mp_conv3x3(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()), 'pcp_mp_conv3x3')
+    return out
+
+
+def mp_conv3x3_wgrad(x, dy, cin, cout, stride, dw, accumulate=False, x_ch_off=0, dy_ch_off=0):
+    """x: (B, H, W, ld) bfloat16, dy: (B, H/stride, W/stride, ld) bfloat16, dw: (cout, cin, 3, 3) float32"""
+    _need_cuda(x, dy, dw)
+    L = _lib.load()
+    B, H, W, ld_x = x.shape
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    assert dw.shape == (cout, cin, 3, 3) and dw.is_contiguous() and x.is_contiguous() and dy.is_contiguous()
+    assert dy.shape[0] == B and dy.shape[1] == H // stride and dy.shape[2] == W // stride
+    d = _lib.MpWgrad3x3(B, H, W, cin, cout, stride, ld_x, dy.shape[3], _lib.DT_BF16, _lib.DT_BF16, 1 if accumulate else 0)
+    need = L.pcp_mp_conv3x3_wgrad_workspace_bytes(ctypes.byref(d))
+    if need == 0:
+        raise _lib.PcpError('pcp_mp_conv3x3_wgrad: unsupported shape %s / %s (cin %d, cout %d, stride %d)' % (tuple(x.shape), tuple(dy.shape), cin, cout, stride))
+    ws = _WG_WS.get(need, x.device)
+    check(L.pcp_mp_conv3x3_wgrad(ctypes.byref(d), _chan_ptr(x, x_ch_off), _chan_ptr(dy, dy_ch_off), _p(dw), _p(ws), ws.numel(), _stream()),
+          'pcp_mp_conv3x3_wgrad')
     return dw
 
 

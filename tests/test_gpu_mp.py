@@ -1,0 +1,207 @@
+"""Mixed-precision (bf16) training kernels of include/pcp_hip_mp.h against torch CPU references.  The checker computes in float64 on the
+SAME bf16-rounded operands the kernel multiplies, so the only differences left are the fp32 accumulation order and the final rounding of a
+bf16 output: tolerances 2e-4 of the output scale for fp32 outputs, 1 bf16 ulp (2^-8 relative) for bf16 outputs.  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pcp_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _u(seed, col, shape, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(synth.uniform(9100 + seed, col, n, lo, hi).reshape(shape).astype(np.float32))
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _nhwc(x, dtype=torch.float32):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+
+
+def _check(got, want, out_bf16, what):
+    got = got.detach().float().cpu().double()
+    want = want.double()
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got - want).abs().max())
+    tol = (2.0 ** -8) * 1.01 + 2e-4 if out_bf16 else 2e-4
+    assert err <= tol * scale, '%s: max err %.3e of scale %.3e (tol %.1e)' % (what, err, scale, tol)
+
+
+CONV_CASES = [
+    # cin, cout, stride, (B, H, W), in_bf16, out_bf16, relu        -- which kernel
+    (64, 64, 1, (2, 40, 72), True, True, True),        # fast, 8-row items, ragged tile (40 = 5 x 8, 72 = 2.25 x 32)
+    (64, 128, 1, (1, 16, 32), True, False, False),     # fast, fp32 output, two channel blocks
+    (128, 64, 1, (3, 33, 31), True, True, False),      # fast, 4 slices, odd map
+    (32, 64, 1, (1, 8, 32), True, True, True),         # fast, ONE slice per item
+    (384, 64, 1, (1, 24, 40), True, True, True),       # fast, 12 slices (CenterHead shared conv)
+    (64, 64, 1, (20, 64, 64), True, True, True),       # fast, 16-row items (>= 512 items), several items per workgroup
+    (64, 72, 1, (1, 16, 32), True, True, False),       # fast, cout not a multiple of 64 (masked channel groups)
+    (64, 64, 2, (2, 32, 48), True, True, True),        # general kernel, stride 2
+    (64, 128, 2, (1, 24, 40), False, True, False),     # general kernel, fp32 input (the canvas), stride 2
+    (16, 64, 1, (1, 19, 23), False, False, True),      # general kernel, cin = 16, fp32 in and out
+    (48, 64, 1, (1, 16, 32), True, True, False),       # general kernel, cin % 32 == 16 with bf16 input
+]
+
+
+@pytest.mark.parametrize('cin,cout,stride,shape,in_bf16,out_bf16,relu', CONV_CASES)
+def test_mp_conv3x3_forward_and_data_gradient_forms(cin, cout, stride, shape, in_bf16, out_bf16, relu):
+    import ctypes
+    from pcp_amd import lib, train_ops as tops
+    B, H, W = shape
+    x = _u(1, cin + cout, (B, cin, H, W))
+    w = _u(2, cin * 3 + cout, (cout, cin, 3, 3), -0.2, 0.2)
+    bias = _u(3, cout, (cout,))
+    xq, wq = _bf(x), _bf(w)
+    want = F.conv2d(xq.double(), wq.double(), bias.double(), stride=stride, padding=1)
+    if relu:
+        want = want.clamp_min(0)
+    packed, opad = tops.mp_pack_conv3x3(w.to(DEV))
+    bp = torch.zeros(opad, device=DEV)
+    bp[:cout] = bias.to(DEV)
+    xin = _nhwc(x, torch.bfloat16 if in_bf16 else torch.float32)
+    d = lib.MpConv3x3(B, H, W, cin, cout, opad, stride, cin, cout, 1 if relu else 0, lib.DT_BF16 if in_bf16 else lib.DT_F32,
+                      lib.DT_BF16 if out_bf16 else lib.DT_F32)
+    fast = ctypes.c_int32(-1)
+    lib.load().pcp_mp_conv3x3_plan(ctypes.byref(d), ctypes.byref(fast), None)
+    assert fast.value == (1 if (stride == 1 and in_bf16 and cin % 32 == 0) else 0)
+    out = tops.mp_conv3x3(xin, packed, bp, cin, cout, opad, stride=stride, relu=relu, out_dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    torch.cuda.synchronize()
+    _check(out.permute(0, 3, 1, 2), want, out_bf16, 'forward')
+    if stride == 1 and cout % 16 == 0:
+        # data gradient = the same kernel with the transposed / flipped weight form: dx = conv_transpose(dy, w)
+        dy = _u(4, cin + 7, (B, cout, H, W))
+        dyq = _bf(dy)
+        want_dx = F.conv_transpose2d(dyq.double(), wq.double(), stride=1, padding=1)
+        packed_t, ipad = tops.mp_pack_conv3x3(w.to(DEV), transpose=True)
+        zb = torch.zeros(ipad, device=DEV)
+        dx = tops.mp_conv3x3(_nhwc(dy, torch.bfloat16 if in_bf16 else torch.float32), packed_t, zb, cout, cin, ipad, stride=1, relu=False,
+                             out_dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        torch.cuda.synchronize()
+        _check(dx.permute(0, 3, 1, 2), want_dx, out_bf16, 'data gradient')
+
+
+def test_mp_conv3x3_channel_windows_of_wider_buffers():
+    """input read from a channel window of a wider bf16 buffer, output written into a window of a wider buffer; the rest is untouched"""
+    from pcp_amd import train_ops as tops
+    B, H, W, cin, cout = 2, 16, 40, 64, 64
+    x = _u(11, 1, (B, cin, H, W))
+    w = _u(12, 2, (cout, cin, 3, 3), -0.2, 0.2)
+    want = F.conv2d(_bf(x).double(), _bf(w).double(), None, padding=1)
+    packed, opad = tops.mp_pack_conv3x3(w.to(DEV))
+    wide_in = torch.full((B, H, W, 96), 7.0, dtype=torch.bfloat16, device=DEV)
+    wide_in[..., 16:80] = _nhwc(x, torch.bfloat16)
+    wide_out = torch.full((B, H, W, 128), -3.0, dtype=torch.bfloat16, device=DEV)
+    tops.mp_conv3x3(wide_in, packed, torch.zeros(opad, device=DEV), cin, cout, opad, out=wide_out, in_ch_off=16, out_ch_off=32)
+    torch.cuda.synchronize()
+    _check(wide_out[..., 32:96].permute(0, 3, 1, 2), want, True, 'window')
+    assert float((wide_out[..., :32].float() + 3.0).abs().max()) == 0.0 and float((wide_out[..., 96:].float() + 3.0).abs().max()) == 0.0
+
+
+WGRAD_CASES = [
+    # cin, cout, stride, (B, H, W)
+    (64, 64, 1, (2, 24, 40)),          # one pair, ragged strip (40 = 1.25 x 32), 24 rows = 6 stages
+    (128, 64, 1, (1, 16, 32)),         # two ci blocks
+    (64, 128, 1, (3, 33, 31)),         # two co blocks, odd map, partial last stage
+    (64, 64, 2, (2, 32, 48)),          # stride 2 (even / odd column images)
+    (128, 256, 2, (1, 16, 64)),        # stride 2, several pairs
+    (64, 16, 1, (1, 12, 20)),          # cout < 64 (the padded head maps): rows 16..63 of the tile are discarded
+    (320, 16, 1, (1, 8, 32)),          # cin = 5 x 64 (the five CenterHead branches side by side)
+    (64, 64, 1, (4, 128, 128)),        # several row splits per strip
+]
+
+
+@pytest.mark.parametrize('cin,cout,stride,shape', WGRAD_CASES)
+def test_mp_conv3x3_wgrad(cin, cout, stride, shape):
+    from pcp_amd import train_ops as tops
+    B, H, W = shape
+    x = _u(21, cin, (B, cin, H, W))
+    dy = _u(22, cout, (B, cout, H // stride, W // stride))
+    xq, dyq = _bf(x).double().requires_grad_(False), _bf(dy).double()
+    wref = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xq, wref, None, stride=stride, padding=1).backward(dyq)
+    want = wref.grad
+    dw = torch.full((cout, cin, 3, 3), 5.0, dtype=torch.float32, device=DEV)
+    tops.mp_conv3x3_wgrad(_nhwc(x, torch.bfloat16), _nhwc(dy, torch.bfloat16), cin, cout, stride, dw)
+    torch.cuda.synchronize()
+    _check(dw, want, False, 'dw')
+    before = dw.clone()
+    tops.mp_conv3x3_wgrad(_nhwc(x, torch.bfloat16), _nhwc(dy, torch.bfloat16), cin, cout, stride, dw, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, before + before)                 # accumulate adds the same (bitwise reproducible) sums
+
+
+def test_mp_wgrad_channel_windows():
+    from pcp_amd import train_ops as tops
+    B, H, W, cin, cout = 1, 16, 32, 64, 64
+    x = _u(31, 1, (B, cin, H, W))
+    dy = _u(32, 2, (B, cout, H, W))
+    wref = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(_bf(x).double(), wref, None, padding=1).backward(_bf(dy).double())
+    wx = torch.full((B, H, W, 128), 9.0, dtype=torch.bfloat16, device=DEV)
+    wx[..., 64:] = _nhwc(x, torch.bfloat16)
+    wdy = torch.full((B, H, W, 72), 9.0, dtype=torch.bfloat16, device=DEV)
+    wdy[..., 8:] = _nhwc(dy, torch.bfloat16)
+    dw = torch.zeros((cout, cin, 3, 3), device=DEV)
+    tops.mp_conv3x3_wgrad(wx, wdy, cin, cout, 1, dw, x_ch_off=64, dy_ch_off=8)
+    torch.cuda.synchronize()
+    _check(dw, wref.grad, False, 'dw windows')
+
+
+@pytest.mark.parametrize('xd,dd,od', [(torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32, torch.bfloat16),
+                                       (torch.float32, torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16, torch.float32)])
+def test_mp_batchnorm_relu_forward_backward_storage_types(xd, dd, od):
+    """training-mode BatchNorm + ReLU with bf16 / fp32 storage per tensor against float64 torch on the same stored values"""
+    from pcp_amd import train_ops as tops
+    c, rows = 64, 3000
+    x = _u(41, 1, (rows, c), -2.0, 3.0)
+    dy = _u(42, 2, (rows, c))
+    gamma, beta = _u(43, 3, (c,), 0.5, 1.5), _u(44, 4, (c,), -0.5, 0.5)
+    xs = x.to(xd)
+    dys = dy.to(dd)
+    xr = xs.double().requires_grad_(True)
+    bn = F.batch_norm(xr, None, None, gamma.double(), beta.double(), True, 0.0, 1e-3)
+    act = bn.clamp_min(0)
+    act.backward(dys.double())
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    xg = xs.to(DEV).contiguous()
+    vec = tops.bn_train_stats(xg, c, gamma.to(DEV), beta.to(DEV), 1e-3, 0.01, rm, rv)
+    out = torch.empty((rows, c), dtype=od, device=DEV)
+    tops.scale_shift_act(xg, c, vec, True, out)
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    dx = torch.empty((rows, c), dtype=od, device=DEV)
+    tops.bn_act_backward(dys.to(DEV).contiguous(), xg, c, vec, True, dg, db, dx=dx)
+    torch.cuda.synchronize()
+    _check(out, act.detach(), od == torch.bfloat16, 'activation')
+    _check(dx, xr.grad, od == torch.bfloat16, 'dx')
+    # dgamma / dbeta: the ReLU mask is decided on fp32 fma(x, scale, shift), torch's on float64 -- elements within rounding of zero may flip
+    np.testing.assert_allclose(db.cpu().double().numpy(), (dys.double() * (act.detach() > 0)).sum(0).numpy(), rtol=0, atol=2e-3 * rows ** 0.5)
+    want_mean = xs.double().mean(0)
+    np.testing.assert_allclose(vec.mean.cpu().double().numpy(), want_mean.numpy(), rtol=0, atol=1e-6)
+
+
+def test_mp_colsum_accumulate_dilate_storage_types():
+    from pcp_amd import train_ops as tops
+    x = _u(51, 1, (2, 6, 10, 32))
+    xb = x.to(torch.bfloat16).to(DEV)
+    out = torch.zeros(32, device=DEV)
+    tops.colsum(xb, 32, out)
+    np.testing.assert_allclose(out.cpu().numpy(), xb.float().cpu().reshape(-1, 32).double().sum(0).numpy(), rtol=0, atol=1e-4)
+    d = tops.dilate2x(xb, 32)
+    assert d.dtype == torch.bfloat16 and tuple(d.shape) == (2, 12, 20, 32)
+    assert torch.equal(d[:, ::2, ::2], xb) and float(d[:, 1::2].float().abs().max()) == 0.0 and float(d[:, :, 1::2].float().abs().max()) == 0.0
+    a32 = _u(52, 2, (120, 32)).to(DEV)
+    want = a32 + 0.5 * xb.float().reshape(-1, 32)
+    tops.accumulate(a32, xb.reshape(-1, 32), 32, alpha=0.5)                    # fp32 += bf16
+    assert float((a32 - want).abs().max()) <= 1e-6
+    ab = _u(53, 3, (120, 32)).to(torch.bfloat16).to(DEV)
+    want_b = (ab.float() + xb.float().reshape(-1, 32)).to(torch.bfloat16)
+    tops.accumulate(ab, xb.reshape(-1, 32), 32)                                # bf16 += bf16 (fp32 add, one rounding)
+    torch.cuda.synchronize()
+    assert torch.equal(ab, want_b)
