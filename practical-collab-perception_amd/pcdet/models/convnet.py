@@ -45,7 +45,7 @@ WINOGRAD4F_MAX_INPUT_BYTES = 0x7fffffff                    # buffer-descriptor a
 
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f', 'w4h')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f', 'w4h', 'mp')
 
     def _use_winograd4f(self, x, out, out_ch_off, in_ch_off=0):
         algo = conv_algo()
@@ -127,6 +127,18 @@ class PackedConv:
         return B * ((Ho + th - 1) // th) * ((Wo + 15) // 16) * (self.b3[2] // 64) >= B3_MIN_WORKGROUPS
 
     def run(self, x, out=None, in_ch_off=0, out_ch_off=0):
+        if getattr(self, 'mp', None) is not None and self.kind == '3x3' and _plain_bf16():
+            # the bf16 loop of config 5 (include/pcp_hip_mp.h): frozen teachers inside a training iteration run the bf16 kernels on bf16
+            # activations -- BatchNorm folded into the bf16 weights + fp32 bias; an fp32 input (the sparse first layer's output, a canvas)
+            # is cast once, the output is bf16 unless the caller's buffer says float32
+            from pcp_amd import train_ops as tops
+            if x.dtype != torch.bfloat16 or in_ch_off % 8 or x.shape[-1] % 8:
+                x, in_ch_off = x[..., in_ch_off:in_ch_off + self.cin].to(torch.bfloat16).contiguous(), 0
+            wp, bp, cp = self.mp
+            return tops.mp_conv3x3(x, wp, bp, self.cin, self.cout, cp, stride=self.stride, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                   out_ch_off=out_ch_off)
+        if x.dtype != torch.float32:
+            x, in_ch_off = x[..., in_ch_off:in_ch_off + self.cin].float().contiguous(), 0      # the fp32 kernels' view of a bf16 activation
         if self._use_bf16x3(x):
             w3, b3, cp3 = self.b3
             return ops.conv3x3_bf16x3(x, w3, b3, self.cin, self.cout, cp3, stride=self.stride, relu=self.relu, out=out,
@@ -178,6 +190,15 @@ def _fold(conv, bn, out_axis):
                         out_axis=out_axis)
 
 
+def _pack_mp(w, b):
+    """(folded) fp32 weights -> the bf16 form of pcp_mp_conv3x3 + padded fp32 bias"""
+    from pcp_amd import train_ops as tops
+    wp, opad = tops.mp_pack_conv3x3(w.contiguous().float())
+    bp = torch.zeros(opad, dtype=torch.float32, device=w.device)
+    bp[:b.numel()] = b
+    return wp, bp, opad
+
+
 def pack_conv_module(conv, bn=None, relu=True):
     """conv: nn.Conv2d (3x3 s1/s2 p1 | 1x1 | k2 s2) or nn.ConvTranspose2d (k1 s1 | k2 s2)."""
     pc = PackedConv()
@@ -188,6 +209,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc.w4 = None
     pc.w4f = None
     pc.w4h = None
+    pc.mp = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
         k, s = conv.kernel_size[0], conv.stride[0]
@@ -210,8 +232,10 @@ def pack_conv_module(conv, bn=None, relu=True):
         pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
         if s == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48:
             pc.wino = pack.pack_conv3x3_winograd(w, b)
-        if conv_algo() in ('bf16x3', 'bf16') and pc.cin % pack.CK == 0 and pc.cout >= 48:
+        if conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48:
             pc.b3 = pack.pack_conv3x3_bf16x3(w, b)
+        if conv_algo() == 'bf16' and pc.cin % 16 == 0 and pc.cout % 8 == 0 and w.is_cuda:
+            pc.mp = _pack_mp(w, b)
         if _winograd4_shape(pc.cin, pc.cout, s):
             pc.w4 = pack.pack_conv3x3_winograd4(w, b)
         if _winograd4f_shape(pc.cin, pc.cout, s):
@@ -236,7 +260,8 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.cin, pc.cout = w.shape[1], w.shape[0]
     pc.w, pc.b, pc.cout_pad = pack.pack_conv3x3(w, b)
     pc.wino = pack.pack_conv3x3_winograd(w, b) if (stride == 1 and pc.cin % pack.WINO_CK == 0 and pc.cout >= 48) else None
-    pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() in ('bf16x3', 'bf16') and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
+    pc.b3 = pack.pack_conv3x3_bf16x3(w, b) if (conv_algo() == 'bf16x3' and pc.cin % pack.CK == 0 and pc.cout >= 48) else None
+    pc.mp = _pack_mp(w, b) if (conv_algo() == 'bf16' and pc.cin % 16 == 0 and pc.cout % 8 == 0 and w.is_cuda) else None
     pc.w4 = pack.pack_conv3x3_winograd4(w, b) if _winograd4_shape(pc.cin, pc.cout, stride) else None
     pc.w4f = pack.pack_conv3x3_winograd4f(w, b) if _winograd4f_shape(pc.cin, pc.cout, stride) else None
     pc.w4h = None

@@ -98,6 +98,7 @@ class VFETrain:
             return None
         s = self.saved
         l0, l1 = self.m.pfn_layers[0], self.m.pfn_layers[1]
+        dcanvas = tl.as_f32(dcanvas)                     # the bf16 loop hands the canvas gradient over as bf16; the PFN kernels are fp32
         dev = dcanvas.device
         w = self._weights()
         Nk = s['Nk']
@@ -201,7 +202,7 @@ class FusionTrain:
             if agent_idx not in self.comp_agents:
                 self.comp_agents[agent_idx] = self.mk_comp('agent%d' % agent_idx)
             a0, a1 = self.comp_agents[agent_idx]
-            comp = a1.forward(a0.forward(Act(ops.as_nhwc(img))))            # BatchNorm sees this agent's batch (train mode), no gradient
+            comp = a1.forward(a0.forward(Act(ops.as_nhwc(img))), out_dtype=torch.float32)   # BatchNorm sees this agent's batch (train mode), no gradient; fp32 for the warp
             cats[a][..., :cc].copy_(ego)
             for b_idx, meta in enumerate(metadata):
                 if agent_idx not in meta['se3_from_ego'] or b_idx >= comp.t.shape[0]:
@@ -221,7 +222,7 @@ class FusionTrain:
         map_ptrs = [cats[0].data_ptr()] + [cats[a].data_ptr() + 4 * cc for a in range(1, n_maps)]
         fused = _empty((B, H, W, cc), dev)
         ops.softmax_fuse_raw(map_ptrs, logits, cc, 2 * cc, fused)
-        out = self.d1.forward(self.d0.forward(Act(fused)))
+        out = self.d1.forward(self.d0.forward(Act(fused)), out_dtype=torch.float32)      # fp32: the distillation loss and the head read it
         self.saved = dict(cats=cats, h2=h2, logits=logits, map_ptrs=map_ptrs, n_maps=n_maps)
         loss = None
         self.dgrad_distill = None
@@ -238,7 +239,7 @@ class FusionTrain:
         dev = dout.t.device
         if self.dgrad_distill is not None:
             tops.accumulate(dout.t, self.dgrad_distill, dout.c, dst_ch_off=dout.off)
-        g = self.d0.backward(self.d1.backward(dout))                           # dL/d fused (B, H, W, cc)
+        g = self.d0.backward(self.d1.backward(dout), dx_dtype=torch.float32)   # dL/d fused (B, H, W, cc), fp32 for pcp_disco_fuse_backward
         n_maps = s['n_maps']
         B, H, W = g.t.shape[0], g.t.shape[1], g.t.shape[2]
         d_ego = _empty((B, H, W, cc), dev)

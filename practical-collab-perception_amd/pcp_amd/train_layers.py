@@ -46,6 +46,28 @@ def fused_f4_choice(B, H, W, cin, cout):
     return None
 
 
+def mp_mode():
+    """PCP_CONV_ALGO=bf16: the mixed-precision training loop (include/pcp_hip_mp.h) -- the 3x3 layers store their activations and
+    gradients as bf16 and run forward / data-gradient / weight-gradient on the bf16 matrix cores; master weights, BatchNorm, losses
+    and the optimizer stay fp32"""
+    return os.environ.get('PCP_CONV_ALGO', 'auto') == 'bf16'
+
+
+def as_f32(t, off=0, c=None):
+    """contiguous float32 copy of a channel window (the fp32-only kernels' view of a bf16 activation); fp32 full-width input: itself"""
+    c = t.shape[-1] - off if c is None else c
+    if t.dtype == torch.float32 and off == 0 and c == t.shape[-1]:
+        return t
+    return t[..., off:off + c].float().contiguous()
+
+
+def as_bf16(t, off=0, c=None):
+    c = t.shape[-1] - off if c is None else c
+    if t.dtype == torch.bfloat16 and off == 0 and c == t.shape[-1]:
+        return t
+    return t[..., off:off + c].to(torch.bfloat16).contiguous()
+
+
 PACK_GROUP = tops.PackGroup()
 PACK_GROUPING = os.environ.get('PCP_PACK_GROUP', '1') != '0'
 
@@ -130,6 +152,20 @@ class ConvBNAct:
                     PACK_GROUP.drop((id(self.conv), True))
                     cache['grouped'] = False
         if cache['step'] == StepClock.step:
+            self._fw, self._bw = cache['fw'], cache['bw']
+            return
+        if self.kind == '3x3' and mp_mode() and self.cin % 16 == 0 and self.cout % 16 == 0:
+            # bf16 weight forms (forward + data gradient) from the fp32 master weights, persistent buffers, two small launches per step
+            w = self.conv.weight.detach()
+            wc = w if w.is_contiguous() else w.contiguous()
+            mpb = cache.setdefault('mp', {})
+            fwp, fo = tops.mp_pack_conv3x3(wc, False, out=mpb.get('fw'))
+            bwp, bo = tops.mp_pack_conv3x3(wc, True, out=mpb.get('bw'))
+            mpb['fw'], mpb['bw'] = fwp, bwp
+            zeros = _zeros_like_cache(_ZERO_BIAS, w.device, 2048, w.device)
+            b = self.conv.bias.detach() if self.conv.bias is not None else None
+            fb = zeros if b is None else (b if fo == self.cout else pack.pad_bias(b, fo))
+            cache['fw'], cache['bw'], cache['step'] = dict(mp=(fwp, fb, fo)), dict(mp=(bwp, zeros, bo)), StepClock.step
             self._fw, self._bw = cache['fw'], cache['bw']
             return
         if (self.kind == '3x3' and cache.get('grouped') and PACK_GROUP.has((id(self.conv), False))
@@ -267,16 +303,33 @@ class ConvBNAct:
             return (B, 2 * H, 2 * W)
         return (B, H, W)
 
-    def forward(self, x, out=None):
-        """x: Act.  out: Act to write the activation into (a channel window of a wider buffer) or None.  Returns Act."""
+    def forward(self, x, out=None, out_dtype=None):
+        """x: Act.  out: Act to write the activation into (a channel window of a wider buffer) or None.  Returns Act.
+        Mixed-precision mode (mp_mode()): a 3x3 layer takes fp32 or bf16 input, keeps its conv output as bf16 and writes its activation
+        as bf16 unless `out` / `out_dtype` say float32 (a consumer that is an fp32-only kernel); the other kinds compute in fp32."""
         self._repack(tuple(x.t.shape[:3]))
         dev = x.t.device
         shp = self.out_shape(x)
         need_post = self.bn is not None or self.relu
-        y_t = torch.empty(shp + (self.cout,), dtype=torch.float32, device=dev) if (need_post or out is None) else None
-        y = Act(y_t, 0, self.cout) if y_t is not None else out
         k = self.kind
-        if k == '3x3':
+        mp = k == '3x3' and 'mp' in self._fw
+        if mp:
+            if x.t.dtype != torch.bfloat16 or x.off % 8 or x.t.shape[-1] % 8:
+                x = Act(as_bf16(x.t, x.off, x.c).contiguous(), 0, x.c)   # one cast; the fast kernel and the weight gradient both read the bf16 copy
+            act_dtype = out.t.dtype if out is not None else (out_dtype or torch.bfloat16)
+            y_dtype = torch.bfloat16 if need_post else act_dtype
+        else:
+            if x.t.dtype != torch.float32:
+                x = Act(as_f32(x.t, x.off, x.c), 0, x.c)
+            act_dtype = y_dtype = torch.float32
+            if out is not None and out.t.dtype != torch.float32:
+                raise NotImplementedError('%s: fp32 layer kind %s cannot write a bf16 buffer' % (self.name, k))
+        y_t = torch.empty(shp + (self.cout,), dtype=y_dtype, device=dev) if (need_post or out is None) else None
+        y = Act(y_t, 0, self.cout) if y_t is not None else out
+        if mp:
+            wp, bp, cp = self._fw['mp']
+            tops.mp_conv3x3(x.t, wp, bp, self.cin, self.cout, cp, stride=self.stride, relu=False, out=y.t, in_ch_off=x.off, out_ch_off=y.off)
+        elif k == '3x3':
             self._run3x3(self._fw, x.t, self.cin, self.cout, self.stride, y.t, x.off, y.off)
         else:
             mode = {'plain': lib.PW_PLAIN, 'plainT': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[k]
@@ -286,7 +339,7 @@ class ConvBNAct:
             self.saved = (x, y)
             return y
         if out is None:
-            out = Act(torch.empty(shp + (self.cout,), dtype=torch.float32, device=dev), 0, self.cout)
+            out = Act(torch.empty(shp + (self.cout,), dtype=act_dtype, device=dev), 0, self.cout)
         if self.bn is not None:
             bn = self.bn
             self.vec = tops.bn_train_stats(y.t, self.cout, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
@@ -302,25 +355,39 @@ class ConvBNAct:
         self.saved = (x, y)
         return out
 
-    def backward(self, dout, need_dx=True, accumulate=False, dx_out=None):
-        """dout: Act (gradient of the layer output; overwritten in place by the gradient of the conv output).
-        Returns Act dx (or None).  accumulate: add to param.grad instead of overwriting (a module applied several times)."""
+    def backward(self, dout, need_dx=True, accumulate=False, dx_out=None, dx_dtype=None):
+        """dout: Act (gradient of the layer output; overwritten in place by the gradient of the conv output when the storage types allow).
+        Returns Act dx (or None).  accumulate: add to param.grad instead of overwriting (a module applied several times).
+        Mixed-precision 3x3 layers take fp32 or bf16 gradients, keep the conv-output gradient as bf16 (the operand of both gradient
+        GEMMs) and return dx as bf16 unless dx_out / dx_dtype say float32."""
         x, y = self.saved
         dev = dout.t.device
-        acc = 1 if accumulate else 0
+        k = self.kind
+        mp = k == '3x3' and 'mp' in self._fw
+        if not mp and dout.t.dtype != torch.float32:
+            dout = Act(as_f32(dout.t, dout.off, dout.c), 0, dout.c)
+        dy = dout
         if self.bn is not None:
             g_w, g_b = ensure_grad(self.bn.weight), ensure_grad(self.bn.bias)
+            # in place on dout, whatever its storage type (callers rely on it: the CenterHead runs ONE data-gradient conv over the five
+            # branch gradients it handed to five layers)
             tops.bn_act_backward(dout.t, y.t, self.cout, self.vec, self.relu, g_w, g_b, accumulate=accumulate, dout_ch_off=dout.off,
                                  x_ch_off=y.off)
+            if mp and (dout.t.dtype != torch.bfloat16 or dout.off % 8 or dout.t.shape[-1] % 8):
+                dy = Act(as_bf16(dout.t, dout.off, dout.c).contiguous(), 0, dout.c)
         elif self.relu:
             raise NotImplementedError('%s: ReLU without BatchNorm is handled by the fused fusion kernels' % self.name)
-        dy = dout
+        elif mp and (dout.t.dtype != torch.bfloat16 or dout.off % 8 or dout.t.shape[-1] % 8):
+            dy = Act(as_bf16(dout.t, dout.off, dout.c).contiguous(), 0, dout.c)
+        if mp and (dy.off % 8 or dy.t.shape[-1] % 8):
+            dy = Act(dy.t[..., dy.off:dy.off + dy.c].contiguous(), 0, dy.c)
         if self.conv.bias is not None:
             tops.colsum(dy.t, self.cout, ensure_grad(self.conv.bias), accumulate=accumulate, ch_off=dy.off)
         gw = ensure_grad(self.conv.weight)
-        k = self.kind
         rows = x.rows
-        if k == '3x3':
+        if mp:
+            tops.mp_conv3x3_wgrad(x.t, dy.t, self.cin, self.cout, self.stride, gw, accumulate=accumulate, x_ch_off=x.off, dy_ch_off=dy.off)
+        elif k == '3x3':
             tops.conv3x3_wgrad(x.t, dy.t, self.cin, self.cout, self.stride, gw, accumulate=accumulate, x_ch_off=x.off, dy_ch_off=dy.off)
         elif k == 'plain':
             tops.pointwise_wgrad(tops.rowmap(dy.t, self.cout, dy.off), tops.rowmap(x.t, self.cin, x.off), rows,
@@ -348,8 +415,15 @@ class ConvBNAct:
             return None
         self._repack(tuple(x.t.shape[:3]))
         if dx_out is None:
-            dx_out = Act(torch.empty(tuple(x.t.shape[:-1]) + (self.cin,), dtype=torch.float32, device=dev), 0, self.cin)
-        if k == '3x3':
+            dt = (dx_dtype or torch.bfloat16) if mp else torch.float32
+            dx_out = Act(torch.empty(tuple(x.t.shape[:-1]) + (self.cin,), dtype=dt, device=dev), 0, self.cin)
+        if mp:
+            src = dy
+            if self.stride == 2:
+                src = Act(tops.dilate2x(dy.t, self.cout, ch_off=dy.off), 0, self.cout)
+            wp, bp, cp = self._bw['mp']
+            tops.mp_conv3x3(src.t, wp, bp, self.cout, self.cin, cp, stride=1, relu=False, out=dx_out.t, in_ch_off=src.off, out_ch_off=dx_out.off)
+        elif k == '3x3':
             src = dy
             if self.stride == 2:
                 src = Act(tops.dilate2x(dy.t, self.cout, ch_off=dy.off), 0, self.cout)

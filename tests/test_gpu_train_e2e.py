@@ -135,20 +135,19 @@ def test_disco_train_step_matches_reference_and_oracle():
 
 
 def test_mixed_precision_bf16_training_step_tracks_the_fp32_reference(monkeypatch):
-    """PCP_CONV_ALGO=bf16 (BASELINE.json config 5: "training loop bf16"): forward / data-gradient 3x3 convs -- the frozen teachers' too --
-    with plain bf16 products (8 mantissa bits), everything else fp32.  Not a parity mode: the first-iteration loss of the reference's
-    train loop (golden g7) must be reproduced to 1 %, its clipped-gradient norm to 5 %, and two optimizer steps must stay finite."""
+    """PCP_CONV_ALGO=bf16 (BASELINE.json config 5: "training loop bf16", include/pcp_hip_mp.h): bf16 activation / gradient storage in the
+    conv stacks, forward / data-gradient / WEIGHT-gradient 3x3 convs on the bf16 matrix cores -- the frozen teachers' forward too --,
+    fp32 master weights, BatchNorm, losses and optimizer.  Not a parity mode: the first-iteration loss of the reference's train loop
+    (golden g7) must be reproduced to 1 %, its clipped-gradient norm to 5 %, and two optimizer steps must stay finite."""
     monkeypatch.setenv('PCP_CONV_ALGO', 'bf16')
     sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
     from train_utils.optimization import build_optimizer, build_scheduler
     from pcdet.config import EasyDict
-    from pcp_amd import ops, train_layers
-    from pcdet.models import convnet
-    monkeypatch.setattr(train_layers, 'B3_MIN_WORKGROUPS', 0)      # the mini geometry never fills the chip: force the bf16 launches
-    monkeypatch.setattr(convnet, 'B3_MIN_WORKGROUPS', 0)
-    calls = []
-    orig = ops.conv3x3_bf16x3
-    monkeypatch.setattr(ops, 'conv3x3_bf16x3', lambda *a, **k: (calls.append(k.get('plain', False)), orig(*a, **k))[1])
+    from pcp_amd import train_ops as tops
+    calls = {'conv': [], 'wgrad': 0}
+    orig_c, orig_w = tops.mp_conv3x3, tops.mp_conv3x3_wgrad
+    monkeypatch.setattr(tops, 'mp_conv3x3', lambda x, *a, **k: (calls['conv'].append(x.dtype), orig_c(x, *a, **k))[1])
+    monkeypatch.setattr(tops, 'mp_conv3x3_wgrad', lambda *a, **k: (calls.__setitem__('wgrad', calls['wgrad'] + 1), orig_w(*a, **k))[1])
     g = load_golden('g7_train.npz')
     meta = g['meta']
     model = _build(g)
@@ -169,8 +168,99 @@ def test_mixed_precision_bf16_training_step_tracks_the_fp32_reference(monkeypatc
         opt.step()
         if it == 0:
             assert abs(opt.grad_norm() - float(g['it0_grad_norm'])) <= 5e-2 * float(g['it0_grad_norm']), opt.grad_norm()
-    assert calls and all(calls)                      # the bf16 launches ran, all with single products
+    # the bf16 kernels ran: every conv launch read bf16 activations, and every 3x3 layer's weight gradient came from the bf16 GEMM
+    assert len(calls['conv']) > 40 and all(d == torch.bfloat16 for d in calls['conv']) and calls['wgrad'] >= 2 * 20, calls
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def _full_size_disco(monkeypatch, algo):
+    sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
+    from train_utils.optimization import build_optimizer, build_scheduler
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import DatasetInfo, build_network
+    monkeypatch.setenv('PCP_CONV_ALGO', algo)
+    g = load_golden('g7_train_full.npz')
+    cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_disco.yaml'),
+                             EasyDict())
+    for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
+        cfg.MODEL[key].CKPT = None
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    ds = DatasetInfo(cfg.CLASS_NAMES, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, vs, len(cfg.DATA_CONFIG.POINT_FEATURE_ENCODING.used_feature_list))
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    st = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.to(DEV)
+    ocfg = EasyDict(json.loads(str(g['optimization_json'])))
+    opt = build_optimizer(model, ocfg)
+    agents = (0, 1, 2, 3, 4, 5)
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    poses = {a: g['pose_%d' % a] for a in agents if a != 1}
+    batch = lambda: {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}],
+                     'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}
+    return g, model, opt, ocfg, batch, build_scheduler
+
+
+def test_bf16_full_size_first_iteration_tracks_the_reference(monkeypatch):
+    """config 5 at BASELINE's full size in the bf16 loop -- the first-iteration loss of the reference's own train step
+    (golden g7_train_full) to 1 %, the clipped-gradient norm to 5 %"""
+    g, model, opt, ocfg, batch, build_scheduler = _full_size_disco(monkeypatch, 'bf16')
+    sched, _ = build_scheduler(opt, 5, ocfg.NUM_EPOCHS, -1, ocfg)
+    sched.step(0)
+    model.train()
+    opt.zero_grad()
+    ret, tb, _disp = model(batch())
+    ret['loss'].backward()
+    lv = float(ret['loss'].detach())
+    assert abs(lv - float(g['loss'])) <= 1e-2 * abs(float(g['loss'])), (lv, float(g['loss']))
+    ref = g['grad_digest']                                   # per tensor: [L2 norm, sum, max |.|] of the reference's gradients
+    ref_norm = float(np.sqrt((ref[:, 0] ** 2).sum()))
+    opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+    opt.step()
+    assert abs(opt.grad_norm() - ref_norm) <= 5e-2 * ref_norm, (opt.grad_norm(), ref_norm)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_bf16_loss_curve_tracks_the_fp32_loop_over_20_iterations(monkeypatch):
+    """the same 20 iterations (full size, one frame, the recipe's one-cycle schedule) in the fp32 loop, in the fp32 loop with ANOTHER
+    summation order (direct kernels instead of Winograd: both exact fp32 arithmetic) and in the bf16 loop.  This short, steep schedule is
+    chaotic: the two fp32 loops drift up to ~15 % apart per iteration (profiles/r04_loss_curves.txt), so "within 2 % per iteration" is not
+    a property even fp32 has.  What is asserted: the first three iterations (before the drift amplifies) within 2.5 % of fp32; the bf16
+    loop's largest deviation from the fp32 loop at most 2 x the deviation between the two fp32 loops (5 % floor); the mean of the last five
+    iterations within 8 %; and the loss falls by > 10 x like the fp32 loop's."""
+    curves = {}
+    for algo in ('auto', 'direct', 'bf16'):
+        g, model, opt, ocfg, batch, build_scheduler = _full_size_disco(monkeypatch, algo)
+        sched, _ = build_scheduler(opt, 20, 1, -1, ocfg)
+        losses = []
+        for it in range(20):
+            sched.step(it)
+            model.train()
+            opt.zero_grad()
+            ret, tb, _disp = model(batch())
+            model.update_global_step()
+            ret['loss'].backward()
+            opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+            opt.step()
+            losses.append(float(ret['loss'].detach()))
+        curves[algo] = np.array(losses)
+        del model, opt
+        torch.cuda.empty_cache()
+    a, d, b = curves['auto'], curves['direct'], curves['bf16']
+    for k in ('auto', 'direct', 'bf16'):
+        print('%-6s loop:' % k, np.round(curves[k], 4).tolist())
+    assert np.isfinite(b).all()
+    dev_fp32 = float((np.abs(d - a) / a).max())
+    dev_bf16 = float((np.abs(b - a) / a).max())
+    print('max relative deviation from the fp32 loop: fp32 direct kernels %.4f, bf16 %.4f' % (dev_fp32, dev_bf16))
+    assert float((np.abs(b[:3] - a[:3]) / a[:3]).max()) <= 2.5e-2, (a[:3], b[:3])
+    assert dev_bf16 <= max(2.0 * dev_fp32, 5e-2), (dev_bf16, dev_fp32)
+    assert abs(b[-5:].mean() - a[-5:].mean()) <= 8e-2 * a[-5:].mean(), (a[-5:], b[-5:])
+    assert b[-1] < 0.1 * b[0] and a[-1] < 0.1 * a[0]
 
 
 def test_single_model_train_step_matches_reference():
