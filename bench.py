@@ -306,6 +306,23 @@ class AbiTimer:
                 real.pcp_conv3x3_winograd4h_plan(ctypes.byref(d), ctypes.byref(fl))
                 return ('k_wino4h (3x3 s1 fused Winograd F(4x4,3x3), two 4-wave workgroups per CU, v_mfma_f32_16x16x4_f32)', fl.value,
                         2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
+            if name == 'pcp_mp_conv3x3':
+                # the bf16 training loop's convolution (forward, data gradient, frozen teachers): v_mfma_f32_32x32x16_bf16, bf16 activations
+                d = a[0]._obj
+                s = d.stride
+                ho, wo = (d.in_h - 1) // s + 1, (d.in_w - 1) // s + 1
+                fast, fl = ctypes.c_int32(0), ctypes.c_double(0.0)
+                real.pcp_mp_conv3x3_plan(ctypes.byref(d), ctypes.byref(fast), ctypes.byref(fl))
+                lab = ('k_mp_conv3x3_s1 (3x3 s1, bf16 activations, persistent direct-to-LDS implicit GEMM, v_mfma_f32_32x32x16_bf16)' if fast.value
+                       else 'k_mp_conv3x3_gen<s%d> (3x3, register-staged bf16 implicit GEMM, v_mfma_f32_32x32x16_bf16)' % s)
+                return lab, fl.value, 2.0 * d.batch * ho * wo * d.cout * 9 * d.cin, 'mfma', MFMA_BF16_PEAK_TFLOPS
+            if name == 'pcp_mp_conv3x3_wgrad':
+                d = a[0]._obj
+                s = d.stride
+                ho, wo = d.in_h // s, d.in_w // s
+                r64 = lambda v: (v + 63) // 64 * 64
+                return ('k_mp_wgrad3x3 (3x3 weight gradient, bf16 pixel-contraction GEMM on transposed LDS reads, split over pixels, v_mfma_f32_32x32x16_bf16)',
+                        2.0 * d.batch * ho * wo * r64(d.cout) * 9 * r64(d.cin), 2.0 * d.batch * ho * wo * d.cout * 9 * d.cin, 'mfma', MFMA_BF16_PEAK_TFLOPS)
             if name == 'pcp_conv3x3_wgrad':
                 # pixel-contraction GEMM of the weight gradient: 64(co) x 64(ci) x 9-tap tiles, padding channels included in `executed`
                 d = a[0]._obj
@@ -340,7 +357,7 @@ class AbiTimer:
             d = getattr(a[0], '_obj', None) if a else None
             if d is None:
                 return ''
-            if name.startswith('pcp_conv3x3'):
+            if name.startswith('pcp_conv3x3') or name.startswith('pcp_mp_conv3x3'):
                 return 'B%d %dx%d %d->%d s%d' % (d.batch, d.in_h, d.in_w, d.cin, d.cout, getattr(d, 'stride', 1) or 1)
             if name == 'pcp_pointwise':
                 return 'mode%d rows %d B%d %dx%d %d->%d' % (d.mode, d.rows, d.batch, d.in_h, d.in_w, d.cin, d.cout)
@@ -784,8 +801,9 @@ def main(argv=None):
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
             'dtype': {'bf16x3': 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
-                      'bf16': 'mixed precision [opt-in, --train only]: forward / data-gradient 3x3 conv products in bf16 (8 mantissa bits), f32 accumulate, '
-                              'f32 master weights, weight gradients, BatchNorm, losses and optimizer'}.get(algo, 'f32'),
+                      'bf16': 'bf16 training loop [--train only]: bf16 activation / gradient storage between the 3x3 layers, forward / data-gradient / '
+                              'weight-gradient 3x3 convs (teachers included) on v_mfma_f32_32x32x16_bf16 with f32 accumulate; f32 master weights, BatchNorm '
+                              'statistics, 1x1 / k2s2 layers, PFN, losses and optimizer'}.get(algo, 'f32'),
             'data': 'synthetic' + (' (ring distribution)' if args.dist == 'ring' else ''),
             'config': {'workload': conf['name'] if not args.train else ('v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)'

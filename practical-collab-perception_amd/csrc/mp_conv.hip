@@ -19,6 +19,7 @@
 // k_mp_conv3x3_gen -- everything else (stride 2, fp32 input, cin % 32 == 16): register-staged, converts while staging.
 #include "pcp_common.h"
 #include "../../include/pcp_hip_mp.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,12 +44,25 @@ struct McParams {
   int batch, h, w_, cin, cout, cout_pad, ld_in, ld_out, relu;
   int tiles_y, tiles_x, n_nb, n_items, n_slices;
   unsigned in_bytes, w_bytes, out_bytes;
+  int diag;               // timing-only builds (PCP_MP_DIAG): 4 = no copies after the first stage (wrong results)
 };
 
 __device__ __forceinline__ int mc_xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
+
+#ifdef MC_STAMP
+// diagnostic build (csrc/build_variant.sh stamp "-DMC_STAMP", tools/stamp_mc.py): s_memtime stamps of wave 0 of every workgroup, kept in
+// memory nothing else reads
+__device__ unsigned long long mc_stamps[1024 * 16];
+#define MC_T(i)                                                                                         \
+  do {                                                                                                  \
+    if (tid == 0 && blockIdx.x < 1024) mc_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define MC_T(i) do { } while (0)
+#endif
 
 template <int TH, bool OUT_BF16>
 __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McParams p) {
@@ -65,6 +79,7 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, c32 = lane & 31, h = lane >> 5;
+  MC_T(0);
 
   // ---- this workgroup's run of items (XCD-contiguous: neighbours in the run share patch halos and weights in one L2) --------------------
   const int nwg = gridDim.x;
@@ -94,43 +109,56 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
     if (pp >= NPIX) ppy[k] = -10000;                              // padding chunks of the last patch instruction: zeros
   }
   unsigned poff[NLD];
-  int cur_b = 0, cur_oy0 = 0, cur_ox0 = 0, cur_nb = 0;            // coordinates of the item whose stage is being COMPUTED
   int ld_nb = 0;                                                  // 64-channel block of the item whose stage is being COPIED
-  auto item_coords = [&](int it, int &b, int &oy0, int &ox0, int &nb) {
-    nb = it % p.n_nb;
+  // item -> (64-channel block fastest, tile column, tile row, frame): decoded ONCE (integer divisions by run-time values cost ~50
+  // instructions each on this ISA), then advanced as counters
+  struct Coords { int nb, tx, ty, b; };
+  auto decode = [&](int it) {
+    Coords c;
+    c.nb = it % p.n_nb;
     int sp = it / p.n_nb;
-    const int tx = sp % p.tiles_x;
+    c.tx = sp % p.tiles_x;
     sp /= p.tiles_x;
-    const int ty = sp % p.tiles_y;
-    b = sp / p.tiles_y;
-    oy0 = ty * TH;
-    ox0 = tx * MC_TW;
+    c.ty = sp % p.tiles_y;
+    c.b = sp / p.tiles_y;
+    return c;
   };
-  auto plan_item = [&](int it) {
-    int b, oy0, ox0;
-    item_coords(it, b, oy0, ox0, ld_nb);
+  auto advance = [&](Coords &c) {
+    if (++c.nb == p.n_nb) {
+      c.nb = 0;
+      if (++c.tx == p.tiles_x) {
+        c.tx = 0;
+        if (++c.ty == p.tiles_y) { c.ty = 0; ++c.b; }
+      }
+    }
+  };
+  Coords ld_c = decode(it_begin), cur_c = ld_c;                   // the item being COPIED / being COMPUTED
+  auto plan_item = [&]() {
+    const int oy0 = ld_c.ty * TH, ox0 = ld_c.tx * MC_TW;
+    ld_nb = ld_c.nb;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int iy = oy0 - 1 + ppy[k], ix = ox0 - 1 + ppx[k];
       poff[k] = MC_OOB;
-      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w_) poff[k] = (unsigned)(((b * p.h + iy) * p.w_ + ix) * p.ld_in * 2 + pch[k]);
+      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w_) poff[k] = (unsigned)(((ld_c.b * p.h + iy) * p.w_ + ix) * p.ld_in * 2 + pch[k]);
     }
   };
-  auto issue = [&](int slice, int buf) {
+  // copy instruction k of this wave for (slice, buffer); the instructions of a stage are issued ONE PER MULTIPLY STEP inside the product
+  // loop of the previous stage: issued back to back they block the wave for ~200 cycles each (in-kernel stamps, tools/stamp_mc.py: the
+  // CU's vector-memory path takes 64 B/clk, a stage is 76 KB), i.e. ~2 000 cycles per stage in which the wave multiplies nothing
+  auto issue_one = [&](int k, int slice, int buf) {
     unsigned char *base = lds + buf * STAGE;
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const int i = wave + k * NWAVE;                              // wave-uniform
-      if (i < PBI) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void *)(base + i * 1024), 16, (int)poff[k], slice * (MC_CK * 2), 0, 0);
-      } else if (i < WI) {
-        const int j = i - PBI;                                     // 0 .. 35: 18 wave-instructions per 16-channel k step
-        const int ks = j >= 18 ? 1 : 0;
-        const int soff = ((slice * 2 + ks) * p.n_nb + ld_nb) * (MC_WCHUNK * 2) + (j - ks * 18) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void *)(base + i * 1024), 16, lane * 16, soff, 0, 0);
-      }
+    const int i = wave + k * NWAVE;                                // wave-uniform
+    if (i < PBI) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void *)(base + i * 1024), 16, (int)poff[k], slice * (MC_CK * 2), 0, 0);
+    } else if (i < WI) {
+      const int j = i - PBI;                                       // 0 .. 35: 18 wave-instructions per 16-channel k step
+      const int ks = j >= 18 ? 1 : 0;
+      const int soff = ((slice * 2 + ks) * p.n_nb + ld_nb) * (MC_WCHUNK * 2) + (j - ks * 18) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void *)(base + i * 1024), 16, lane * 16, soff, 0, 0);
     }
   };
+  static_assert(NLD <= 18, "one copy instruction per multiply step");
 
   // ---- fragment addresses --------------------------------------------------------------------------------------------------------------------
   // B (pixels): lane (c32, h) of output row r, tap (ky, kx), k step ks reads the 16 bytes of channels ks*16 + h*8 .. +7 of patch pixel
@@ -151,22 +179,24 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
   float *bias_lds = reinterpret_cast<float *>(lds + 2 * STAGE);
 
   for (int i = tid; i < p.cout_pad; i += NTHR) bias_lds[i] = p.bias[i];      // before the first copy is issued: no plain load inside the loop
-  plan_item(it_begin);
-  issue(0, 0);
+  plan_item();
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) issue_one(k, 0, 0);
   int it = it_begin, slice = 0;
-  item_coords(it, cur_b, cur_oy0, cur_ox0, cur_nb);
   bool stores_behind = false;                                     // the previous stage ended an item: its NST stores are younger than the copy
   for (int q = 0; q < n_stages; ++q) {
     const int buf = q & 1;
     if (stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (q < 4) MC_T(1 + 3 * q);
     // next stage: same item next slice, or first slice of the next item
     int nslice = slice + 1, nit = it;
     if (nslice == p.n_slices) { nslice = 0; nit = it + 1; }
-    if (q + 1 < n_stages) {
-      if (nslice == 0) plan_item(nit);
-      issue(nslice, buf ^ 1);
+    const bool copy_next = q + 1 < n_stages && !(p.diag & 4);
+    if (copy_next && nslice == 0) {
+      advance(ld_c);
+      plan_item();
     }
     if (slice == 0) {
 #pragma unroll
@@ -176,6 +206,7 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[nt][mt][e] = 0.f;
     }
+    if (q < 4) MC_T(2 + 3 * q);
     // ---- the stage's products: 2 k steps x 9 taps x (2 x 2) MFMAs per wave ---------------------------------------------------------------
     {
       const unsigned char *pb = lds + buf * STAGE + brow0;
@@ -192,24 +223,30 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
 #pragma unroll
       for (int step = 0; step < 18; ++step) {
         const int cur = step & 1;
+        // the four fragment reads of step + 1 are ISSUED before the four MFMAs of this step (fenced: hipcc otherwise sinks every read to
+        // just in front of its first use, and the single wave of a SIMD then waits out the LDS latency once per step)
         if (step + 1 < 18) load(step + 1, a[cur ^ 1], b[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][nt], b[cur][mt], acc[nt][mt], 0, 0, 0);
+        if (step < NLD && copy_next) issue_one(step, nslice, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (q < 4) MC_T(3 + 3 * q);
     stores_behind = false;
     if (slice == p.n_slices - 1) {
       // ---- epilogue: bias (+ ReLU), 16-byte stores; lane (c32, h) holds channels nt*32 + 8g + 4h + (0..3) of pixel (row mt, column c32) ------
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int oy = cur_oy0 + wave * 2 + mt, ox = cur_ox0 + c32;
+        const int oy = cur_c.ty * TH + wave * 2 + mt, ox = cur_c.tx * MC_TW + c32;
         const bool pix_ok = oy < p.h && ox < p.w_;
-        const unsigned pix_off = (unsigned)(((cur_b * p.h + oy) * p.w_ + ox) * p.ld_out);     // elements
+        const unsigned pix_off = (unsigned)(((cur_c.b * p.h + oy) * p.w_ + ox) * p.ld_out);   // elements
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const int ch0 = cur_nb * MC_BN + nt * 32;
+          const int ch0 = cur_c.nb * MC_BN + nt * 32;
           float v[16];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -254,9 +291,14 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
     slice = nslice;
     if (nit != it) {
       it = nit;
-      if (it < it_end) item_coords(it, cur_b, cur_oy0, cur_ox0, cur_nb);
+      advance(cur_c);
     }
+    if (q == 3) MC_T(13);
   }
+  MC_T(14);
+#ifdef MC_STAMP
+  if (tid == 0 && blockIdx.x < 1024) mc_stamps[blockIdx.x * 16 + 15] = (unsigned long long)n_stages;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -464,14 +506,27 @@ bool mc_fast_ok(const pcp_mp_conv3x3_t *d) {
 }
 
 int mc_tile_rows(const pcp_mp_conv3x3_t *d) {
-  // 16-row items (8 waves) once they give every CU two items, else 8-row items (4 waves)
+  // 16-row items (8 waves, two per SIMD) once they give every CU an item, else 8-row items (4 waves): 128->128 @128^2 x 4 frames 21.7 vs
+  // 25.9 us with 256 sixteen-row items, 256->256 @64^2 30.3 vs 24.0 us with only 128 of them
   const long long big = (long long)d->batch * ((d->in_h + 15) / 16) * ((d->in_w + MC_TW - 1) / MC_TW) * (d->cout_pad / MC_BN);
-  return big >= 512 ? 16 : 8;
+  static long long min16 = 0;                                    // PCP_MP_TH16_MIN: A/B knob for the item-size rule
+  if (min16 == 0) {
+    const char *e = getenv("PCP_MP_TH16_MIN");
+    min16 = e ? atoll(e) : 256;
+    if (min16 <= 0) min16 = 256;
+  }
+  return big >= min16 ? 16 : 8;
 }
 
 }  // namespace
 
 extern "C" {
+
+#ifdef MC_STAMP
+int pcp_debug_read_mc(void *dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mc_stamps), bytes < sizeof(mc_stamps) ? bytes : sizeof(mc_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t pcp_mp_conv3x3_packed_bytes(int32_t k_channels, int32_t out_pad) {
   if (k_channels <= 0 || (k_channels % 16) || out_pad <= 0 || (out_pad % 64)) return 0;
@@ -535,6 +590,7 @@ int pcp_mp_conv3x3(const pcp_mp_conv3x3_t *d, const void *in, const void *w_pack
       p.n_items = d->batch * p.tiles_y * p.tiles_x * p.n_nb;
       p.n_slices = d->cin / MC_CK;
       p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
+      { const char *e = getenv("PCP_MP_DIAG"); p.diag = e ? atoi(e) : 0; }
       static int n_cu = 0;                                        // one process drives one device (bench.py / tools: one rank per GPU)
       if (n_cu == 0) {
         int dev = 0, v = 0;

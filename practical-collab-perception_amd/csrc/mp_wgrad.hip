@@ -14,7 +14,7 @@
 // x rows in a ring of three 4-row groups (every x row is fetched ONCE per strip: the halo rows of a stage are the previous / next group).
 // The copy of the next stage runs under the MFMAs of the current one; one barrier per stage.  Stride 2: the x rows are stored with even
 // and odd columns apart (the loader permutes), so the 16 pixels of a k step are consecutive records again.
-// Partial tiles (fp32, [pair][split][9][64][64]) go to the workspace; k_mp_wgrad_reduce sums them in split order (bitwise reproducible).
+// Partial tiles (fp32, accumulator order) go to the workspace; k_mp_wgrad_reduce sums them in split order (bitwise reproducible).
 // The kernel is HBM-bound by design: a 64 x 64 x 9 tile gives 224 flop per input byte, under the bf16 ridge of ~400.
 #include "pcp_common.h"
 #include "../../include/pcp_hip_mp.h"
@@ -32,8 +32,8 @@ constexpr int WG_THREADS = 256;
 constexpr int WG_DW = 32;                 // dy columns of a strip
 
 template <int S> struct WgCfg;
-template <> struct WgCfg<1> { static constexpr int TR = 4, XWP = 34, XHALF = 0; };      // XWP: x records per row in LDS
-template <> struct WgCfg<2> { static constexpr int TR = 2, XWP = 72, XHALF = 36; };     // [parity][36]
+template <> struct WgCfg<1> { static constexpr int TR = 4, XWP = 34, XHALF = 0, DEPTH = 1; };      // XWP: x records per row in LDS; DEPTH: stages of copy in flight (2 measured no faster)
+template <> struct WgCfg<2> { static constexpr int TR = 2, XWP = 72, XHALF = 36, DEPTH = 1; };     // [parity][36]; a third group ahead would not fit the LDS
 
 struct WgParams {
   const void *x, *dy;
@@ -57,9 +57,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
   constexpr int DY_BYTES = TR * WG_DW * 128;              // one dy stage
   constexpr int DYI = DY_BYTES / 1024;                    // 16 | 8
   constexpr int NXL = (XGI + 3) / 4, NDL = (DYI + 3) / 4; // copy instructions per wave
+  constexpr int D = C::DEPTH;                             // stages the copy runs ahead: 33 KB in flight per CU (D = 1) held the strip walk at ~3 TB/s
+  constexpr int NXG = D + 2, NDY = D + 1;                 // x groups / dy stages resident
   static_assert(XG_BYTES % 1024 == 0 && DY_BYTES % 1024 == 0, "whole wave instructions");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * XG_BYTES + 2 * DY_BYTES];
-  unsigned char *xring = lds, *dybuf = lds + 3 * XG_BYTES;
+  static_assert(NXG * XG_BYTES + NDY * DY_BYTES <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NXG * XG_BYTES + NDY * DY_BYTES];
+  unsigned char *xring = lds, *dybuf = lds + NXG * XG_BYTES;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,31 +114,35 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
     dsrc[k] = cob * 128 + ((c2 << 1) | (piece & 1)) * 16;
   }
   const int gx0 = S * c0 - 1;
-  auto issue_x = [&](int g) {                             // x rows [S r0 - 1 + 4g, +4) -> ring slot g % 3
-    unsigned char *base = xring + (g % 3) * XG_BYTES;
-#pragma unroll
-    for (int k = 0; k < NXL; ++k) {
-      const int i = wave + 4 * k;
-      if (i < XGI) {
-        const int gy = S * r0 - 1 + 4 * g + xrow[k], gx = gx0 + xcol[k];
-        unsigned off = WG_OOB;
-        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) off = (unsigned)(((b * p.h + gy) * p.w + gx) * p.ld_x * 2 + xsrc[k]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
-      }
+  // one copy instruction at a time: inside the main loop they are spread over the multiply steps (issued back to back they block the wave
+  // for ~200 cycles each: the CU's vector-memory path takes 64 B/clk -- measured on k_mp_conv3x3_s1, tools/stamp_mc.py)
+  auto issue_x_one = [&](int k, int g) {                  // x rows [S r0 - 1 + 4g, +4) -> ring slot g % NXG
+    unsigned char *base = xring + (g % NXG) * XG_BYTES;
+    const int i = wave + 4 * k;
+    if (i < XGI) {
+      const int gy = S * r0 - 1 + 4 * g + xrow[k], gx = gx0 + xcol[k];
+      unsigned off = WG_OOB;
+      if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) off = (unsigned)(((b * p.h + gy) * p.w + gx) * p.ld_x * 2 + xsrc[k]);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
     }
   };
-  auto issue_dy = [&](int s) {                            // dy rows [r0 + TR s, +TR) -> buffer s & 1
-    unsigned char *base = dybuf + (s & 1) * DY_BYTES;
-#pragma unroll
-    for (int k = 0; k < NDL; ++k) {
-      const int i = wave + 4 * k;
-      if (i < DYI) {
-        const int gy = r0 + TR * s + drow[k], gx = c0 + dcol[k];
-        unsigned off = WG_OOB;
-        if (gy < r1 && gx < p.ow) off = (unsigned)(((b * p.oh + gy) * p.ow + gx) * p.ld_dy * 2 + dsrc[k]);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
-      }
+  auto issue_dy_one = [&](int k, int s) {                 // dy rows [r0 + TR s, +TR) -> buffer s % NDY
+    unsigned char *base = dybuf + (s % NDY) * DY_BYTES;
+    const int i = wave + 4 * k;
+    if (i < DYI) {
+      const int gy = r0 + TR * s + drow[k], gx = c0 + dcol[k];
+      unsigned off = WG_OOB;
+      if (gy < r1 && gx < p.ow) off = (unsigned)(((b * p.oh + gy) * p.ow + gx) * p.ld_dy * 2 + dsrc[k]);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
     }
+  };
+  auto issue_x = [&](int g) {
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) issue_x_one(k, g);
+  };
+  auto issue_dy = [&](int s) {
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) issue_dy_one(k, s);
   };
 
   // ---- transposed-read addresses (bytes inside a row image; see the header comment) -------------------------------------------------------
@@ -163,60 +170,95 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(addr));
   };
 
+  // copy instructions this wave issues per batch (x group + dy stage): what may stay in flight across the barrier when D = 2
+  int n_batch = 0;
+#pragma unroll
+  for (int k = 0; k < NXL; ++k) n_batch += (wave + 4 * k < XGI) ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < NDL; ++k) n_batch += (wave + 4 * k < DYI) ? 1 : 0;
   issue_x(0);
   issue_x(1);
   issue_dy(0);
+  if (D == 2 && n_st > 1) {
+    issue_x(2);
+    issue_dy(1);
+  }
   for (int s = 0; s < n_st; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (s + 1 < n_st) {
-      issue_x(s + 2);
-      issue_dy(s + 1);
+    // stage s needs x groups s, s + 1 and dy stage s; with D = 2 the batch issued during stage s - 1 (x group s + 2, dy stage s + 1) may
+    // still be in flight: the wait leaves exactly this wave's share of it outstanding (a wave's copies complete in issue order)
+    if (D == 2 && s + 1 < n_st) {
+      if (n_batch == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (n_batch == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const unsigned char *dyb = dybuf + (s & 1) * DY_BYTES + a_lane;
+    __builtin_amdgcn_s_barrier();
+    const bool copy_next = s + D < n_st;
+    const unsigned char *dyb = dybuf + (s % NDY) * DY_BYTES + a_lane;
+    constexpr int NIT = TR * 2, NC = NXL + NDL;            // multiply iterations (16-pixel k steps) of a stage, its copy instructions
+    constexpr int NSTEP = NIT * 9;                         // one MFMA per (k step, tap)
+    const int g0 = s % NXG, g1 = (s + 1) % NXG;
+    // operand reads, software pipelined by hand: the two transposed reads of step st + 1 are issued BEFORE the MFMA of step st (fenced --
+    // with one wave per SIMD nothing else hides the LDS latency, and hipcc sinks every read to just in front of its use)
+    auto rd_a = [&](int itn) -> bf16x8 {
+      const int rr = itn >> 1, kk = itn & 1;
+      const unsigned char *ap = dyb + (rr * WG_DW + 16 * kk) * 128;
+      const s16x4 a0 = tr_read(ap), a1 = tr_read(ap + 4 * 128);
+      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto rd_b = [&](int st) -> bf16x8 {
+      const int itn = st / 9, tap = st % 9, rr = itn >> 1, kk = itn & 1, ky = tap / 3, kx = tap % 3;
+      const int rel = S * rr + ky;                                       // x row relative to group s: 0 .. 5
+      const unsigned char *bp = xring + ((rel >> 2) ? g1 : g0) * XG_BYTES + (rel & 3) * (XWP * 128) + b_lane[kx] + (16 * kk) * 128;
+      const s16x4 b0 = tr_read(bp), b1 = tr_read(bp + 4 * 128);
+      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    bf16x8 aq[2], bq[2];
+    aq[0] = rd_a(0);
+    bq[0] = rd_b(0);
 #pragma unroll
-    for (int rr = 0; rr < TR; ++rr) {
+    for (int st = 0; st < NSTEP; ++st) {
+      const int itn = st / 9, tap = st % 9;
+      if (st + 1 < NSTEP) bq[(st + 1) & 1] = rd_b(st + 1);
+      if (tap == 5 && itn + 1 < NIT) aq[(itn + 1) & 1] = rd_a(itn + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[itn & 1], bq[st & 1], acc[tap], 0, 0, 0);
+      // the copy instructions of stage s + D, spread over the k steps (x group s + D + 1 first, then dy stage s + D)
+      if (tap == 8 && copy_next) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const unsigned char *ap = dyb + (rr * WG_DW + 16 * kk) * 128;
-        const s16x4 a0 = tr_read(ap), a1 = tr_read(ap + 4 * 128);
-        const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int rel = S * rr + ky;                                   // x row relative to group s: 0 .. 5
-          // ring slot of that row: group (s + rel / 4) % 3, row rel % 4
-          const unsigned char *xrow_base = xring + ((s + (rel >> 2)) % 3) * XG_BYTES + (rel & 3) * (XWP * 128);
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const unsigned char *bp = xrow_base + b_lane[kx] + (16 * kk) * 128;
-            const s16x4 b0 = tr_read(bp), b1 = tr_read(bp + 4 * 128);
-            const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ky * 3 + kx], 0, 0, 0);
+        for (int c = 0; c < NC; ++c)
+          if (c * NIT / NC == itn) {
+            if (c < NXL) issue_x_one(c, s + D + 1);
+            else issue_dy_one(c - NXL, s + D);
           }
-        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  // ---- partial tile: [pair][split][tap][co 64][ci 64]; lane (ci = lane & 31, hh) holds rows (e & 3) + 8 (e >> 2) + 4 hh of its quadrant -------
+  // ---- partial tile in ACCUMULATOR order: [pair][split][tap][wave][quad g][lane][4] -- every store instruction of a wave writes 1 KB of
+  // contiguous memory (16 bytes per lane); k_mp_wgrad_reduce undoes the permutation.  Element (t, w, g, l, i) is dw[co][ci][t] with
+  // co = 32 (w >> 1) + 8 g + 4 (l >> 5) + i, ci = 32 (w & 1) + (l & 31).  (144 dword stores per wave in [co][ci] order made the tail as long
+  // as the whole multiply loop -- the epilogue is store-ISSUE bound; 16-byte stores in a [ci][co] order scatter 64 pieces per instruction
+  // and were slower still: profiles/r04_mp_wgrad_variants.txt) -----------------------------------------------------------------------------------
   float *dst = p.partial + ((long long)pair * p.n_split + split) * (9 * 64 * 64);
-  const int ci = wn * 32 + (lane & 31);
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-      dst[(t * 64 + co) * 64 + ci] = acc[t][e];
-    }
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4 *>(dst + ((((t * 4 + wave) * 4 + g) * 64 + lane) << 2)) =
+          f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
 }
 
 // dw[co][ci][tap] (+)= sum over splits, in split order
 __global__ void k_mp_wgrad_reduce(const float *__restrict__ partial, int n_split, int n_cob, int n_cib, int cout, int cin, float *__restrict__ dw,
                                   int accumulate) {
   const int pair = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;             // (tap, co, ci) of the 64 x 64 tile
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;             // element of the 9 x 64 x 64 tile in the partials' order
   if (e >= 9 * 64 * 64) return;
-  const int ci_l = e & 63, co_l = (e >> 6) & 63, tap = e >> 12;
+  const int i4 = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 3, w = (e >> 10) & 3, tap = e >> 12;      // accumulator order of k_mp_wgrad3x3
+  const int co_l = 32 * (w >> 1) + 8 * g + 4 * (l >> 5) + i4, ci_l = 32 * (w & 1) + (l & 31);
   const int cob = pair / n_cib, cib = pair % n_cib;
   const int co = cob * 64 + co_l, ci = cib * 64 + ci_l;
   if (co >= cout || ci >= cin) return;

@@ -83,7 +83,7 @@ class VFETrain:
             arg1 = _empty((max(P, 1), 64), dev, torch.int32)
             tops.pfn_train_out(vox, x1, self.vec1, pf, arg1, canvas)
             for nrm in (l0.norm, l1.norm):
-                nrm.num_batches_tracked += 1
+                tl.bump_batches_tracked(nrm)
             self.saved = dict(vox=vox, Nk=Nk, P=P, fk=fk, x0=x0, in1=in1, arg0=arg0, x1=x1, arg1=arg1)
         else:
             self.saved = None

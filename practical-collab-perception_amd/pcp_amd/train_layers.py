@@ -79,6 +79,36 @@ class StepClock:
     @classmethod
     def tick(cls):
         cls.step += 1
+        flush_batches_tracked()
+
+
+# nn.BatchNorm's num_batches_tracked += 1 is one tiny launch per BatchNorm per forward (47 per DiscoNet iteration): the increments are
+# collected and applied by ONE multi-tensor add per optimizer step (and before any state_dict() through flush_batches_tracked()).
+_PENDING_NBT = {}
+
+
+def bump_batches_tracked(bn):
+    t = bn.num_batches_tracked
+    if t is None:
+        return
+    e = _PENDING_NBT.get(id(t))
+    if e is None:
+        _PENDING_NBT[id(t)] = [t, 1]
+    else:
+        e[1] += 1
+    if len(_PENDING_NBT) > 4096:
+        flush_batches_tracked()
+
+
+def flush_batches_tracked():
+    if not _PENDING_NBT:
+        return
+    by_count = {}
+    for t, n in _PENDING_NBT.values():
+        by_count.setdefault((n, t.device), []).append(t)
+    _PENDING_NBT.clear()
+    for (n, _dev), ts in by_count.items():
+        torch._foreach_add_(ts, n)
 
 
 def ensure_grad(p):
@@ -344,8 +374,7 @@ class ConvBNAct:
             bn = self.bn
             self.vec = tops.bn_train_stats(y.t, self.cout, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum,
                                            bn.running_mean, bn.running_var, vec=self.vec, ch_off=y.off)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+            bump_batches_tracked(bn)
         else:
             if self.vec is None:
                 self.vec = tops.BNVectors(self.cout, dev)
@@ -469,8 +498,7 @@ class LinearBNAct:
         bn = self.bn
         self.vec = tops.bn_train_stats(y, self.cout, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                        vec=self.vec)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        bump_batches_tracked(bn)
         out = torch.empty_like(y)
         tops.scale_shift_act(y, self.cout, self.vec, self.relu, out)
         self.saved = (x, y)

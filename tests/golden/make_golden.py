@@ -1445,26 +1445,32 @@ def g13_conditioned():
         WEIGHT_SCHEME = 'survey'
 
 
-def g13_chain():
+def g13_chain(full=False):
     """BASELINE config 3 as a chain (the g10 scene: 2 frames x 5 remote agents x 2 000 points, mini geometry) on WELL-CONDITIONED weights:
     the remote detector's gain and SCORE_THRESH are tuned so that the final sets of all ten remote passes are perturbation-invariant, the
     ego detector's on the augmented cloud the reference's own ingestion lines build.  tests/golden/g13_chain.npz holds the clouds, the
     MoDAR rows of every pass and the final detections of the ego pass, which the GPU test demands EXACTLY (1e-3) of the whole device-side
-    chain (pcdet/models/lately_chain.py)."""
+    chain (pcdet/models/lately_chain.py).
+    full=True: the same at BASELINE's FULL size -- one frame, 6 agents x 60 000 points, the YAMLs' own 102.4 m range --
+    into tests/golden/g13_chain_full.npz.  The clouds are synth.agent_cloud streams (regenerated by the test from the recorded agent ids,
+    not stored); the foreground rows are stored as a count + digest."""
     global WEIGHT_SCHEME
     rh.install()
     sys.path.insert(0, REPO)
     from oracle import exchange as oex
     from pcdet.datasets.nuscenes.nuscenes_temporal_utils import apply_se3_
     from torch_scatter import scatter
-    B, remote_agents, n_pts = 2, (0, 2, 3, 4, 5), 2000
+    B, remote_agents, n_pts = (1, (0, 2, 3, 4, 5), 60000) if full else (2, (0, 2, 3, 4, 5), 2000)
+    ckw = {} if full else {'xy_half': 13.1}
+    ov = {} if full else {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE}
+    base_agent = 700 if full else 200
     out = {}
     try:
         clouds = {}
         for f in range(B):
-            clouds[(f, 'ego')] = synth.agent_cloud(agent=200 + 10 * f + 1, n_points=n_pts, layout='car', xy_half=13.1)
+            clouds[(f, 'ego')] = synth.agent_cloud(agent=base_agent + 10 * f + 1, n_points=n_pts, layout='car', **ckw)
             for slot, a in enumerate(remote_agents):
-                clouds[(f, slot)] = synth.agent_cloud(agent=200 + 10 * f + a, n_points=n_pts, layout='car', xy_half=13.1)
+                clouds[(f, slot)] = synth.agent_cloud(agent=base_agent + 10 * f + a, n_points=n_pts, layout='car', **ckw)
 
         def car_passes(car):
             res = {}
@@ -1482,7 +1488,7 @@ def g13_chain():
         car = car_cfg = car_shapes = None
         for gain in G13_GAINS:
             WEIGHT_SCHEME = 'gain:%g' % gain
-            car_cfg = rh.load_cfg('v2x_pointpillar_basic_car.yaml', {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE})
+            car_cfg = rh.load_cfg('v2x_pointpillar_basic_car.yaml', dict(ov))
             car_cfg.MODEL.DENSE_HEAD.RETURN_MODAR_POINTS = True
             car_cfg.MODEL.CORRECTOR.RETURN_SCENE_FLOW = True
             car, _ = rh.build_model(car_cfg)
@@ -1508,7 +1514,8 @@ def g13_chain():
         ego_rows = []
         for f in range(B):
             ego_cloud = clouds[(f, 'ego')]
-            out['ego_cloud_%d' % f] = ego_cloud
+            if not full:
+                out['ego_cloud_%d' % f] = ego_cloud
             max_sweep_idx = float(ego_cloud[:, -2].max())
             out['max_sweep_idx_%d' % f] = np.array(max_sweep_idx)
             pts13 = np.zeros((ego_cloud.shape[0], 13))
@@ -1516,14 +1523,20 @@ def g13_chain():
             pts13[:, -2:] = ego_cloud[:, -2:]
             for slot, a in enumerate(remote_agents):
                 pose = np.linalg.inv(synth.agent_pose(a))
-                pose[:3, 3] *= 0.25
+                if not full:
+                    pose[:3, 3] *= 0.25
                 key = '%d_%d' % (f, slot)
-                out['remote_cloud_' + key] = clouds[(f, slot)]
+                if not full:
+                    out['remote_cloud_' + key] = clouds[(f, slot)]
                 out['target_se3_lidar_' + key] = pose
                 bd = res[(f, slot)][0]
                 modar = bd['mo_pts'].numpy().copy() if 'mo_pts' in bd else np.zeros((0, 9), np.float32)
                 fg = bd['scene_flow'].numpy().copy() if 'scene_flow' in bd else np.zeros((0, 13), np.float32)
-                out['modar_' + key], out['foreground_' + key] = modar, fg
+                out['modar_' + key] = modar
+                if full:
+                    out['foreground_digest_' + key] = np.array([fg.shape[0], float(np.abs(fg.astype(np.float64)).sum())])
+                else:
+                    out['foreground_' + key] = fg
                 modar_t = torch.from_numpy(modar.copy())
                 if fg.shape[0] > 0 and modar.shape[0] > 0:
                     foregr = torch.from_numpy(fg.copy())
@@ -1544,12 +1557,14 @@ def g13_chain():
                 pts13 = np.concatenate((pts13, modar_))
             ego_rows.append(pts13.astype(np.float32))
             print('   g13 chain frame', f, 'modar', [out['modar_%d_%d' % (f, sl)].shape[0] for sl in range(5)], 'foreground',
-                  [out['foreground_%d_%d' % (f, sl)].shape[0] for sl in range(5)])
+                  [int(out['foreground_digest_%d_%d' % (f, sl)][0]) if full else out['foreground_%d_%d' % (f, sl)].shape[0] for sl in range(5)])
         ego_pts = synth.collate(ego_rows)
-        out['ego_points'] = ego_pts
+        if not full:
+            out['ego_points'] = ego_pts
+        out['ego_points_rows'] = np.array(ego_pts.shape[0])
         # ---- ego detector on the augmented cloud ---------------------------------------------------------------------------------------------
         def build_ego():
-            cfg = rh.load_cfg('v2x_pointpillar_basic_ego.yaml', {'DATA_CONFIG.POINT_CLOUD_RANGE': MINI_RANGE})
+            cfg = rh.load_cfg('v2x_pointpillar_basic_ego.yaml', dict(ov))
             model, _ds = rh.build_model(cfg)
             shapes = fill_weights(model)
             return cfg, model, shapes
@@ -1557,16 +1572,68 @@ def g13_chain():
                                                                     'metadata': [{} for _ in range(B)]}, 'ego', out)
         ego_cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = thr_ego
         out['meta_json'] = np.array(json.dumps(dict(
-            car=dict(model=rh.to_plain(car_cfg.MODEL), pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(car_cfg.CLASS_NAMES),
+            car=dict(model=rh.to_plain(car_cfg.MODEL), pc_range=[float(v) for v in car_cfg.DATA_CONFIG.POINT_CLOUD_RANGE], voxel_size=[0.2, 0.2, 8.0], class_names=list(car_cfg.CLASS_NAMES),
                      yaml='v2x_pointpillar_basic_car.yaml', layout='car', state_shapes=car_shapes),
-            ego=dict(model=rh.to_plain(ego_cfg.MODEL), pc_range=MINI_RANGE, voxel_size=[0.2, 0.2, 8.0], class_names=list(ego_cfg.CLASS_NAMES),
+            ego=dict(model=rh.to_plain(ego_cfg.MODEL), pc_range=[float(v) for v in ego_cfg.DATA_CONFIG.POINT_CLOUD_RANGE], voxel_size=[0.2, 0.2, 8.0], class_names=list(ego_cfg.CLASS_NAMES),
                      yaml='v2x_pointpillar_basic_ego.yaml', layout='lately', state_shapes=ego_shapes),
-            frames=B, remote_agents=list(remote_agents), car_seg_bias_shift=G10_SEG_BIAS_SHIFT, noise=G13_NOISE, trials=G13_TRIALS)))
-        np.savez_compressed(os.path.join(HERE, 'g13_chain.npz'), **out)
+            frames=B, remote_agents=list(remote_agents), base_agent=base_agent, n_points=n_pts, full=bool(full), car_seg_bias_shift=G10_SEG_BIAS_SHIFT, noise=G13_NOISE, trials=G13_TRIALS)))
+        np.savez_compressed(os.path.join(HERE, 'g13_chain_full.npz' if full else 'g13_chain.npz'), **out)
         print('g13 chain: car', str(out['car_weight_scheme']), float(out['car_score_thresh']), 'ego', str(out['ego_weight_scheme']),
               float(out['ego_score_thresh']), 'final', [out['ego_boxes_%d' % b].shape[0] for b in range(B)])
     finally:
         WEIGHT_SCHEME = 'survey'
+
+
+def g14_late_fusion():
+    """V2XLateFusion (reference pcdet/models/detectors/v2x_late_fusion.py:13-54) driven with synthetic exchange boxes: the reference's own
+    forward -- concatenation in dict order, SCORE_THRESH, class-agnostic rotated NMS (thr 0.3, pre 4096, post 500) -- and its 'ego_only'
+    branch.  Scene: true objects seen by several agents with jittered boxes (NMS must merge them), some scores under the threshold, one
+    agent without boxes, near-duplicate scores.  tests/golden/g14_late_fusion.npz holds the inputs and the reference's pred_dicts."""
+    rh.install()
+    cfg = rh.load_cfg('v2x_late_fusion.yaml')
+    model, _ = rh.build_model(cfg)
+    rng = np.random.RandomState(1404)
+    out = {}
+    frames = []
+    for f, (n_obj, agents) in enumerate([(60, (0, 1, 2, 3, 4, 5)), (25, (1, 3)), (140, (0, 1, 2, 4))]):
+        centers = np.concatenate([rng.uniform(-48, 48, (n_obj, 2)), rng.uniform(-2.5, -0.5, (n_obj, 1))], 1)
+        dims = np.stack([rng.uniform(3.5, 5.2, n_obj), rng.uniform(1.6, 2.2, n_obj), rng.uniform(1.4, 1.9, n_obj)], 1)
+        yaw = rng.uniform(-np.pi, np.pi, (n_obj, 1))
+        ex = {}
+        for a in agents:
+            seen = rng.rand(n_obj) < 0.7
+            k = int(seen.sum())
+            b = np.concatenate([centers[seen] + rng.normal(0, 0.25, (k, 3)) * [1, 1, 0.2], dims[seen] * rng.uniform(0.93, 1.07, (k, 3)),
+                                yaw[seen] + rng.normal(0, 0.08, (k, 1))], 1)
+            sc = rng.uniform(0.05, 0.95, (k, 1))
+            sc[rng.rand(k) < 0.15] = 0.08                                # under SCORE_THRESH
+            if k > 4:
+                sc[1] = sc[0]                                            # a tie
+            fp = rng.randint(0, 6)                                       # a few false positives of this agent alone
+            bf = np.concatenate([rng.uniform(-50, 50, (fp, 2)), rng.uniform(-2, -1, (fp, 1)), rng.uniform(3.8, 4.8, (fp, 1)),
+                                 rng.uniform(1.7, 2.0, (fp, 1)), rng.uniform(1.5, 1.7, (fp, 1)), rng.uniform(-3, 3, (fp, 1))], 1)
+            rows = np.concatenate([np.concatenate([b, sc, np.ones((k, 1))], 1),
+                                   np.concatenate([bf, rng.uniform(0.11, 0.4, (fp, 1)), np.ones((fp, 1))], 1)], 0)
+            ex[a] = rows.astype(np.float32)
+        if f == 0:
+            ex[2] = np.zeros((0, 9), np.float32)                         # an agent that detected nothing
+        frames.append(ex)
+        out['agents_%d' % f] = np.array(list(ex.keys()))
+        for a, rows in ex.items():
+            out['exchange_%d_%d' % (f, a)] = rows
+    for method in ('nms', 'ego_only'):
+        model.model_cfg.BOX_FUSION_METHOD = method
+        use = frames if method == 'nms' else frames[:2]
+        with torch.no_grad():
+            pred, _rec = model({'metadata': [{'exchange_boxes': ex} for ex in use], 'batch_size': len(use)})
+        out[method + '_frames'] = np.array(len(use))
+        for b, d in enumerate(pred):
+            out['%s_boxes_%d' % (method, b)] = d['pred_boxes'].numpy().copy()
+            out['%s_scores_%d' % (method, b)] = d['pred_scores'].numpy().copy()
+            out['%s_labels_%d' % (method, b)] = d['pred_labels'].numpy().copy()
+        print('g14', method, [int(d['pred_boxes'].shape[0]) for d in pred], 'from', [sum(r.shape[0] for r in ex.values()) for ex in use])
+    out['meta_json'] = np.array(json.dumps(dict(model=rh.to_plain(cfg.MODEL), class_names=list(cfg.CLASS_NAMES))))
+    np.savez_compressed(os.path.join(HERE, 'g14_late_fusion.npz'), **out)
 
 
 if __name__ == '__main__':
@@ -1576,6 +1643,10 @@ if __name__ == '__main__':
         g13_conditioned()
     if 'g13c' in todo:
         g13_chain()
+    if 'g13cf' in todo:
+        g13_chain(full=True)
+    if 'g14' in todo:
+        g14_late_fusion()
     if 'g3' in todo:
         g3_nms()
     if 'g4' in todo:

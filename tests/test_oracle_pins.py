@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import arch_of, load_golden, match_boxes
+from helpers import arch_of, assert_same_final_set, load_golden, match_boxes
 from oracle import bev as obev
 from oracle import model as omodel
 from oracle import nms as onms
@@ -113,6 +113,20 @@ def test_g3_nms_known_answer():
     for thr, key in ((0.2, 'keep_02'), (0.3, 'keep_03')):
         keep = onms.nms_gpu(boxes, scores, thr)
         assert np.array_equal(keep, g[key])
+
+
+def test_g14_late_fusion_box_nms():
+    """the oracle's class-agnostic rotated NMS on the exchange boxes of tests/golden/g14_late_fusion.npz against what the REFERENCE's
+    V2XLateFusion.forward returned for them (v2x_late_fusion.py:13-54): a second, denser pin of the NMS restatement (220 / 40 / 381 boxes
+    with several views of every object)"""
+    g = load_golden('g14_late_fusion.npz')
+    pp = g['meta']['model']['POST_PROCESSING']
+    for f in range(int(g['nms_frames'])):
+        rows = np.concatenate([g['exchange_%d_%d' % (f, int(a))] for a in g['agents_%d' % f] if g['exchange_%d_%d' % (f, int(a))].shape[0] > 0])
+        sel, sc = onms.class_agnostic_nms(rows[:, 7], rows[:, :7], pp['NMS_CONFIG']['NMS_THRESH'], pp['NMS_CONFIG']['NMS_PRE_MAXSIZE'],
+                                          pp['NMS_CONFIG']['NMS_POST_MAXSIZE'], score_thresh=pp['SCORE_THRESH'])
+        want_b, want_s = g['nms_boxes_%d' % f], g['nms_scores_%d' % f]
+        assert_same_final_set(want_b, want_s, rows[sel, :7], sc, tol=0.0)
 
 
 def test_ref_build_matches_oracle_when_present():
