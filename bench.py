@@ -95,6 +95,10 @@ def parse_args(argv=None):
                     "agent: configs early / disco only -- each rank holds the points of ITS agents, one all-gather of raw points (early) or "
                     "of compressed BEV maps (disco) per step, then the frames of the batch are dealt to the ranks (pcdet/models/sharded.py; "
                     "strong scaling: the group processes ONE batch per step)")
+    ap.add_argument('--latency', type=int, default=0, help='B = 1 latency mode (SURVEY 8(d)): time N single-frame forwards one by one, points '
+                    'resident in HBM -> final boxes readable on the host (every forward ends in its host read; no cross-frame pipelining, no '
+                    'second replica), and print p50 / p99 / mean ms per frame as the JSON line; --graph replays the forward as one hipGraph '
+                    'where the config supports it')
     ap.add_argument('--train', action='store_true', help='configs ego / early / disco: time full training iterations (forward + backward + '
                     'clip + fused Adam one-cycle step; data parallel over ranks with one RCCL all-reduce of the flat gradient)')
     return ap.parse_args(argv)
@@ -266,6 +270,11 @@ class AbiTimer:
     def __init__(self):
         self.records = []           # (label, e0, e1, exec_flops, alg_flops, bound, peak)
         self.w4 = []                # (in_ms, gemm_ms, out_ms, gemm_flops, alg_flops)
+        self.vfe_P, self.vfe_bytes = {}, 0.0
+        import ctypes
+        import torch
+        self.rt = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+        self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 
     def install(self):
         import ctypes
@@ -385,6 +394,19 @@ class AbiTimer:
                     r = fn(*a)
                     e1.record(s)
                     timer.records.append((e0, e1) + describe(name, a) + (shape_of(name, a),))
+                    # VFE stage: algorithmic bytes = points once + P coords + the canvas (dense) or the P pillar rows
+                    if name in ('pcp_voxelize', 'pcp_voxelize_cells_ready'):
+                        cptr = a[9] if name == 'pcp_voxelize' else a[8]
+                        s.synchronize()                 # between two event pairs: no launch's measured duration contains this wait
+                        host = (ctypes.c_int32 * 4)()
+                        timer.rt.hipMemcpy(host, cptr, 16, 2)
+                        timer.vfe_P[s.cuda_stream] = int(host[0])
+                    elif name == 'pcp_pfn_scatter':
+                        n, stride, g = int(a[1]), int(a[2]), a[4]._obj
+                        P = timer.vfe_P.get(s.cuda_stream, 0)
+                        canvas = a[11]
+                        dense = bool(getattr(canvas, 'value', canvas))
+                        timer.vfe_bytes += 4.0 * n * stride + 16.0 * P + (4.0 * g.batch_size * g.ny * g.nx * 64 if dense else 4.0 * 64 * P)
                     return r
                 return wrapped
         lib._LIB = Proxy()
@@ -629,7 +651,8 @@ def main(argv=None):
     def train_step():
         ts = train_state
         ts['sched'].step(ts['it'])
-        model.train()
+        if not model.training:
+            model.train()
         ts['opt'].zero_grad()
         bd = {'points': pristine, 'batch_size': batch, 'metadata': metas, 'gt_boxes': ts['gt']}
         if 'instances_tf' in ts:
@@ -658,8 +681,8 @@ def main(argv=None):
 
     pipelined = None
     from pcdet.models.pipelined import PipelinedDetector
-    if (not args.no_pipeline and not args.plugin_default and not args.train and not args.graph and args.shard == 'frame' and lately is None
-            and PipelinedDetector.supports(model)):          # anything else (a head without a deferred finalize, ...) runs batch by batch
+    if (not args.no_pipeline and not args.latency and not args.plugin_default and not args.train and not args.graph and args.shard == 'frame'
+            and lately is None and PipelinedDetector.supports(model)):          # anything else (a head without a deferred finalize, ...) runs batch by batch
         shared_device = world > 1 and backend == 'gloo'            # functional check: several ranks on one GPU -- no second replica each
         if shared_device:
             args.pipeline_replicas = 1
@@ -669,7 +692,7 @@ def main(argv=None):
         pipelined.prepare(work, batch, metas)       # setup: every replica builds its packed weights / buffers once, before the W warm-up steps
     pipe_state = {'n': 0}
     lately_pipe = None
-    if (lately is not None and not args.no_pipeline and not args.plugin_default and not args.graph
+    if (lately is not None and not args.no_pipeline and not args.latency and not args.plugin_default and not args.graph
             and not (world > 1 and backend == 'gloo')):
         from pcdet.models.lately_chain import PipelinedChain
         lately_pipe = PipelinedChain(lately, replicas=max(1, args.pipeline_replicas))
@@ -705,6 +728,31 @@ def main(argv=None):
             pred_dicts, _ = model(bd)
         return pred_dicts
 
+    if args.latency > 0:
+        # ---- B = 1 latency: one frame at a time, every forward ends in its own host read -------------------------------------------------
+        assert pipelined is None and lately_pipe is None and train_state is None and sharded_runner is None
+        for _ in range(max(args.warmup, 5)):
+            step()
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(args.latency):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            preds = step()
+            n_last = int(sum(p['pred_boxes'].shape[0] for p in preds))          # exact-shape tensors: the count was read on the host
+            torch.cuda.synchronize()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        lat = np.sort(np.array(lat))
+        if rank == 0:
+            print(json.dumps({'metric': 'latency per frame (60k-pt cloud, %d agent%s), B = %d' % (conf['agents_in_cloud'], 's' if conf['agents_in_cloud'] > 1 else '', batch),
+                              'value': round(float(np.percentile(lat, 50)), 4), 'unit': 'ms', 'p50_ms': round(float(np.percentile(lat, 50)), 4),
+                              'p99_ms': round(float(np.percentile(lat, 99)), 4), 'mean_ms': round(float(lat.mean()), 4), 'min_ms': round(float(lat[0]), 4),
+                              'frames_timed': int(args.latency), 'n_gpus': 1, 'higher_is_better': False, 'dtype': 'f32', 'data': 'synthetic',
+                              'config': {'workload': conf['name'], 'yaml': conf['yaml'], 'frames_per_step': batch, 'hipgraph': bool(args.graph),
+                                         'mode': 'one forward at a time: points resident in HBM -> boxes on the host; no cross-frame pipelining, one model replica'
+                                                 + ('; BEV-maker passes on their own HIP streams' if overlapped else ''),
+                                         'final_boxes_last_frame': n_last}}))
+        return
     for _ in range(args.warmup):
         step()
     if pipelined is not None:
@@ -794,6 +842,20 @@ def main(argv=None):
         roof['all_mfma_kernels'] = {'executed_tflops': round(sum(f['exec_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
                                     'algorithmic_tflops': round(sum(f['alg_flops'] for f in mf) / max(sum(f['ms'] for f in mf), 1e-9) / 1e9, 3),
                                     'ms_per_step': round(sum(f['ms_per_step'] for f in mf), 3)}
+        # the HBM-bound VFE stage -- pillariser + fused PFN / scatter (+ canvas clear) -- against the HBM peak; (iii): the
+        # latency-bound tail (decode + rotated NMS + gather) in microseconds per step
+        vfe_ms = sum(f['ms_per_step'] for f in fams if f['kernel'].split(' ')[0] in ('pcp_voxelize', 'k_pfn', 'pcp_canvas_clear', 'pcp_select_transform_compact'))
+        vfe_bytes = timer.vfe_bytes / INSTR_STEPS
+        vfe_roof = None
+        if vfe_ms > 0 and vfe_bytes > 0:
+            gbs = vfe_bytes / (vfe_ms * 1e-3) / 1e9
+            vfe_roof = {'bound': 'hbm', 'stage': 'pillarise (+ agent selection) + fused PFN + scatter / pillar rows, all VFE passes of the step',
+                        'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                        'algorithmic_mb_per_step': round(vfe_bytes / 1e6, 2), 'ms_per_step': round(vfe_ms, 4),
+                        'note': 'algorithmic bytes (SURVEY 8(d) row 1): points read once + 16 B per pillar + the dense canvas or the 256-B pillar rows; '
+                                'time = HIP events around the launches of the instrumented single-stream pass'}
+        decode_nms_us = round(1e3 * sum(f['ms_per_step'] for f in fams if f['kernel'].split(' ')[0] in
+                                        ('pcp_centerhead_decode', 'pcp_nms_rotated', 'pcp_nms_normal', 'pcp_gather_detections', 'pcp_anchor_decode', 'pcp_topk_boxes')), 1)
         line = {
             'metric': ('frames/sec (60k-pt cloud, 6 agents)' if conf['agents_in_cloud'] == 6 else 'frames/sec (60k-pt cloud, 1 agent)') +
                       (' [dead BEV-maker passes elided: NOT the headline]' if args.elide_dead_makers else ''),
@@ -830,6 +892,9 @@ def main(argv=None):
                        **({'elided': 'rsu BEV maker (overwritten by the car maker) and early BEV maker (training-only output): reference quirk F3'} if args.elide_dead_makers else {}),
                        'final_boxes_last_step': n_boxes, **({'loss_last_step': train_state['last_loss']} if args.train else {})},
             'roofline': roof,
+            'roofline_hbm': vfe_roof,
+            'decode_nms_us': decode_nms_us,
+            'pipelined_replicas': (max(1, args.pipeline_replicas) if was_pipelined else 0),
             'kernel_ms_per_step': {f['kernel'].split(' ')[0]: round(f['ms_per_step'], 4) for f in fams[:14]},
             'kernel_ms_per_step_total': round(sum(f['ms_per_step'] for f in fams), 3),
         }

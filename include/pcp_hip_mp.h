@@ -19,6 +19,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "pcp_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -58,6 +60,19 @@ int pcp_mp_accumulate(void *dst, int32_t dst_dtype, int32_t ld_dst, const void *
 int pcp_mp_dilate2x(const void *in, int32_t dtype, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_in, void *out, int32_t ld_out,
                     void *stream);
 
+/* pcp_pfn_train_out / pcp_pfn_train_route_out_grad (pcp_hip_train.h) with a storage type for the BEV canvas and its gradient: in the bf16
+ * loop the canvas is written as bf16 by the PFN's last kernel (it is the bf16 input of the first backbone layer and of that layer's weight
+ * gradient) and the canvas gradient the backbone hands back is read as bf16 -- no fp32 canvas, no casts. */
+int pcp_mp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+                         const float *shift1, float *pillar_features, int32_t *arg1, void *canvas, int32_t canvas_dtype, void *stream);
+int pcp_mp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const void *dcanvas,
+                                    int32_t dcanvas_dtype, const float *dpillar, const int32_t *arg1, float *dz1, void *stream);
+
+/* pcp_sparse_conv3x3_s2 (pcp_hip.h: the first backbone layer run from the pillar list) with a storage type for its OUTPUT map: the frozen
+ * teachers of the bf16 loop hand bf16 to their second layer directly (fp32 arithmetic inside, one rounding on store). */
+int pcp_mp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *w_packed,
+                             const float *bias, int32_t cout, int32_t relu, void *out, int32_t out_dtype, int32_t ld_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * 3x3 convolution (padding 1, stride 1 | 2) + bias (+ ReLU) on the bf16 matrix cores, fp32 accumulation.
  * Replaces nn.Conv2d(k=3) [+ folded eval-mode BatchNorm + ReLU for the frozen teachers] of base_bev_backbone.py:30-69,
@@ -82,6 +97,17 @@ typedef struct {
 size_t pcp_mp_conv3x3_packed_bytes(int32_t contraction_channels, int32_t out_channels_pad);
 int pcp_mp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t transpose, const float *fold_scale, void *packed, int32_t out_pad,
                         void *stream);
+/* The same pack for MANY layers in one launch (every 3x3 layer of the trainable branch, both forms, once per optimizer step): a job table
+ * in DEVICE memory; block_start = first block of the job in the grouped launch (jobs in ascending order),
+ * pcp_mp_pack_conv3x3_group_blocks(job) = blocks the job needs (-1: invalid).  Bit-identical to per-layer pcp_mp_pack_conv3x3 calls. */
+typedef struct {
+  const float *w;              /* (cout, cin, 3, 3) float32 master weights */
+  void *packed;                /* destination, pcp_mp_conv3x3_packed_bytes */
+  int32_t cout, cin, transpose, out_pad;
+  int32_t block_start, reserved;
+} pcp_mp_pack_job_t;
+int pcp_mp_pack_conv3x3_group_blocks(const pcp_mp_pack_job_t *job);
+int pcp_mp_pack_conv3x3_group(const pcp_mp_pack_job_t *jobs_device, int32_t n_jobs, int32_t total_blocks, void *stream);
 int pcp_mp_conv3x3(const pcp_mp_conv3x3_t *desc, const void *in, const void *w_packed, const float *bias, void *out, void *stream);
 /* which kernel a descriptor goes to (1 = k_mp_conv3x3_s1, the direct-to-LDS persistent kernel; 0 = the general kernel) and the flops the
  * launch executes on the matrix pipe (padding channels / tiles included); either output may be NULL */

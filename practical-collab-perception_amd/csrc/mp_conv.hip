@@ -500,6 +500,36 @@ __global__ void k_mp_pack3x3(const float *__restrict__ w, int cout, int cin, int
   dst[t] = (__bf16)v;
 }
 
+// every 3x3 layer's two bf16 forms in ONE launch per optimizer step: block -> job by binary search over the jobs' first blocks
+__global__ __launch_bounds__(256) void k_mp_pack3x3_group(const pcp_mp_pack_job_t *__restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pcp_mp_pack_job_t j = jobs[lo];
+  const long long t = (long long)((int)blockIdx.x - j.block_start) * blockDim.x + threadIdx.x;
+  const int K = j.transpose ? j.cout : j.cin;
+  const long long total = (long long)(K / 16) * (j.out_pad / 64) * MC_WCHUNK;
+  if (t >= total) return;
+  const int jj = (int)(t & 7);
+  long long u = t >> 3;
+  const int o64 = (int)(u & 63);
+  u >>= 6;
+  const int hh = (int)(u & 1);
+  u >>= 1;
+  const int tap = (int)(u % 9);
+  u /= 9;
+  const int n_nb = j.out_pad / 64;
+  const int nb = (int)(u % n_nb);
+  const int ks = (int)(u / n_nb);
+  const int o = nb * 64 + o64, k = ks * 16 + hh * 8 + jj;
+  const int O = j.transpose ? j.cin : j.cout;
+  float v = 0.f;
+  if (o < O) v = j.transpose ? j.w[(((long long)k * j.cin + o) * 9) + (8 - tap)] : j.w[(((long long)o * j.cin + k) * 9) + tap];
+  reinterpret_cast<__bf16 *>(j.packed)[t] = (__bf16)v;
+}
+
 bool mc_fast_ok(const pcp_mp_conv3x3_t *d) {
   return d->cout_pad <= MC_MAX_COUT && d->stride == 1 && d->in_dtype == PCP_DT_BF16 && d->cin % MC_CK == 0 && (d->ld_in & 7) == 0 &&
          (d->out_dtype == PCP_DT_BF16 ? ((d->cout & 7) == 0 && (d->ld_out & 7) == 0) : ((d->cout & 3) == 0 && (d->ld_out & 3) == 0));
@@ -541,6 +571,22 @@ int pcp_mp_pack_conv3x3(const float *w, int32_t cout, int32_t cin, int32_t trans
   const long long total = (long long)(K / 16) * (out_pad / 64) * MC_WCHUNK;
   hipLaunchKernelGGL(k_mp_pack3x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transpose ? 1 : 0,
                      fold_scale, (__bf16 *)packed, out_pad, total);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_mp_pack_conv3x3_group_blocks(const pcp_mp_pack_job_t *job) {
+  if (!job || !job->w || !job->packed || job->cout <= 0 || job->cin <= 0 || job->out_pad <= 0 || (job->out_pad % 64)) return -1;
+  const int K = job->transpose ? job->cout : job->cin, O = job->transpose ? job->cin : job->cout;
+  if ((K % 16) || job->out_pad < O) return -1;
+  const long long total = (long long)(K / 16) * (job->out_pad / 64) * MC_WCHUNK;
+  if (total > 0x7fffffffLL) return -1;
+  return (int)((total + 255) / 256);
+}
+
+int pcp_mp_pack_conv3x3_group(const pcp_mp_pack_job_t *jobs_device, int32_t n_jobs, int32_t total_blocks, void *stream) {
+  if (!jobs_device || n_jobs <= 0 || total_blocks <= 0) return PCP_ERR_ARG;
+  hipLaunchKernelGGL(k_mp_pack3x3_group, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

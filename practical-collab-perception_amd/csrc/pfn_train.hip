@@ -12,6 +12,7 @@
 //             route_mid dL/d a0 = d in1[:, :32] + [row is arg-max] * sum_pillar d in1[:, 32:]
 // Arg-max ties go to the first row in bucket order (torch_scatter keeps one index; ties need bit-identical rows).
 #include "pcp_common.h"
+#include "../../include/pcp_hip_mp.h"
 
 namespace {
 
@@ -125,10 +126,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_mid(const int *__restrict__
   }
 }
 
+// CT: storage type of the canvas (float; __bf16 in the bf16 training loop, include/pcp_hip_mp.h: the first backbone layer and its weight
+// gradient read the canvas as bf16 anyway, so the fp32 canvas + its cast are skipped)
+template <typename CT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
                                                         const int *__restrict__ counters, pcp_grid_t g, const float *__restrict__ x1,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                        float *__restrict__ pf, int *__restrict__ arg1, float *__restrict__ canvas) {
+                                                        float *__restrict__ pf, int *__restrict__ arg1, CT *__restrict__ canvas) {
   const int P = counters[0];
   const int lane = threadIdx.x & 63;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -149,13 +153,14 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__
       const int cell = pillar_cell[p];
       const int b = cell / plane, rem = cell % plane;
       const int cx = rem / g.ny, cy = rem % g.ny;
-      canvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + lane] = best;
+      canvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + lane] = (CT)best;
     }
   }
 }
 
+template <typename CT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__restrict__ pillar_cell, const int *__restrict__ counters,
-                                                              pcp_grid_t g, const float *__restrict__ dcanvas, const float *__restrict__ dpf,
+                                                              pcp_grid_t g, const CT *__restrict__ dcanvas, const float *__restrict__ dpf,
                                                               const int *__restrict__ arg1, float *__restrict__ dz1) {
   const int P = counters[0];
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__rest
     const int cell = pillar_cell[p];
     const int b = cell / plane, rem = cell % plane;
     const int cx = rem / g.ny, cy = rem % g.ny;
-    gval = dcanvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + c];
+    gval = (float)dcanvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + c];
   } else {
     gval = dpf[t];
   }
@@ -253,20 +258,36 @@ int pcp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t
   return PCP_OK;
 }
 
-int pcp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
-                      const float *shift1, float *pillar_features, int32_t *arg1, float *canvas, void *stream) {
+static int pfn_train_out_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+                              const float *shift1, float *pillar_features, int32_t *arg1, void *canvas, int canvas_bf16, void *stream) {
   if (!grid || !vox_workspace || !x1 || !scale1 || !shift1 || !arg1 || n < 0) return PCP_ERR_ARG;
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  hipLaunchKernelGGL(k_pfnt_out, dim3(pillar_wave_blocks(n < cells ? n : cells)), dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start,
-                     v.pillar_cell, v.counters, *grid, x1, scale1, shift1, pillar_features, arg1, canvas);
+  const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
+  if (canvas_bf16)
+    hipLaunchKernelGGL(k_pfnt_out<__bf16>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.pillar_cell, v.counters, *grid, x1,
+                       scale1, shift1, pillar_features, arg1, (__bf16 *)canvas);
+  else
+    hipLaunchKernelGGL(k_pfnt_out<float>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.pillar_cell, v.counters, *grid, x1,
+                       scale1, shift1, pillar_features, arg1, (float *)canvas);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
-int pcp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const float *dcanvas,
-                                 const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
+int pcp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+                      const float *shift1, float *pillar_features, int32_t *arg1, float *canvas, void *stream) {
+  return pfn_train_out_impl(grid, vox_workspace, n, x1, scale1, shift1, pillar_features, arg1, canvas, 0, stream);
+}
+
+int pcp_mp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+                         const float *shift1, float *pillar_features, int32_t *arg1, void *canvas, int32_t canvas_dtype, void *stream) {
+  if (canvas_dtype != 0 && canvas_dtype != 1) return PCP_ERR_ARG;
+  return pfn_train_out_impl(grid, vox_workspace, n, x1, scale1, shift1, pillar_features, arg1, canvas, canvas_dtype, stream);
+}
+
+static int pfn_route_out_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const void *dcanvas,
+                              int dcanvas_bf16, const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
   if (!grid || !vox_workspace || !arg1 || !dz1 || n < 0 || kept_rows < 0 || kept_rows > n) return PCP_ERR_ARG;
   if ((dcanvas == nullptr) == (dpillar == nullptr)) return PCP_ERR_ARG;
   if (n == 0 || kept_rows == 0) return PCP_OK;
@@ -275,10 +296,26 @@ int pcp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspa
   if (pcp_zero_async(dz1, (size_t)kept_rows * C1 * sizeof(float), s) != PCP_OK) return PCP_ERR_LAUNCH;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   const int64_t max_pillars = kept_rows < cells ? kept_rows : cells;
-  hipLaunchKernelGGL(k_pfnt_route_out, dim3((unsigned)((max_pillars * C1 + PT_THREADS - 1) / PT_THREADS)), dim3(PT_THREADS), 0, s,
-                     v.pillar_cell, v.counters, *grid, dcanvas, dpillar, arg1, dz1);
+  const dim3 gridd((unsigned)((max_pillars * C1 + PT_THREADS - 1) / PT_THREADS));
+  if (dcanvas_bf16)
+    hipLaunchKernelGGL(k_pfnt_route_out<__bf16>, gridd, dim3(PT_THREADS), 0, s, v.pillar_cell, v.counters, *grid, (const __bf16 *)dcanvas, dpillar,
+                       arg1, dz1);
+  else
+    hipLaunchKernelGGL(k_pfnt_route_out<float>, gridd, dim3(PT_THREADS), 0, s, v.pillar_cell, v.counters, *grid, (const float *)dcanvas, dpillar, arg1,
+                       dz1);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+int pcp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const float *dcanvas,
+                                 const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
+  return pfn_route_out_impl(grid, vox_workspace, n, kept_rows, dcanvas, 0, dpillar, arg1, dz1, stream);
+}
+
+int pcp_mp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const void *dcanvas,
+                                    int32_t dcanvas_dtype, const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
+  if (dcanvas_dtype != 0 && dcanvas_dtype != 1) return PCP_ERR_ARG;
+  return pfn_route_out_impl(grid, vox_workspace, n, kept_rows, dcanvas, dcanvas_dtype, dpillar, arg1, dz1, stream);
 }
 
 int pcp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *din1, const int32_t *arg0,

@@ -33,6 +33,8 @@ struct SpParams {
 };
 
 
+// OUT_BF16: the output map stored as bf16 (the frozen teachers of the bf16 training loop, include/pcp_hip_mp.h); same arithmetic
+template <bool OUT_BF16>
 __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
   __shared__ __attribute__((aligned(16))) float acc[SP_PIX * 64];          // per-pixel accumulators
 #ifdef SP_ROW_SPLIT
@@ -364,7 +366,15 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
           v.z = fmaxf(v.z, 0.f);
           v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<f32x4 *>(p.out + ((long long)(b * p.ho + oy) * p.wo + ox) * p.ld_out + n4) = v;
+        const long long o = ((long long)(b * p.ho + oy) * p.wo + ox) * p.ld_out + n4;
+        if (OUT_BF16) {
+          typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+          b4 q;
+          q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
+          *reinterpret_cast<b4 *>(reinterpret_cast<__bf16 *>(p.out) + o) = q;
+        } else {
+          *reinterpret_cast<f32x4 *>(p.out + o) = v;
+        }
       }
     }
   }
@@ -372,12 +382,11 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
 
 }  // namespace
 
-extern "C" int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n,
-                                     const float *w_packed, const float *bias, int32_t cout, int32_t relu, float *out, int32_t ld_out,
-                                     void *stream_) {
+static int sparse_conv_impl(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *w_packed,
+                            const float *bias, int32_t cout, int32_t relu, void *out, int out_bf16, int32_t ld_out, void *stream_) {
   if (!pillar_features || !grid || !vox_workspace || !w_packed || !bias || !out || n < 0) return PCP_ERR_ARG;
   if (cout <= 0 || cout > 64 || cout % 4 != 0 || ld_out % 4 != 0 || ld_out < cout) return PCP_ERR_UNSUPPORTED;
-  if ((((uintptr_t)pillar_features) & 15) || (((uintptr_t)w_packed) & 15) || (((uintptr_t)bias) & 15) || (((uintptr_t)out) & 15))
+  if ((((uintptr_t)pillar_features) & 15) || (((uintptr_t)w_packed) & 15) || (((uintptr_t)bias) & 15) || (((uintptr_t)out) & (out_bf16 ? 7 : 15)))
     return PCP_ERR_ARG;
   if (grid->batch_size <= 0 || grid->nx <= 0 || grid->ny <= 0) return PCP_ERR_ARG;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
@@ -385,7 +394,7 @@ extern "C" int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_gri
   SpParams p;
   p.pf = pillar_features;
   p.cell_rank = reinterpret_cast<const int *>(reinterpret_cast<const char *>(vox_workspace) + L.cell_rank);
-  p.w = w_packed; p.bias = bias; p.out = out;
+  p.w = w_packed; p.bias = bias; p.out = (float *)out;
   p.batch = grid->batch_size; p.nx = grid->nx; p.ny = grid->ny;
   p.ho = (grid->ny - 1) / 2 + 1;
   p.wo = (grid->nx - 1) / 2 + 1;
@@ -394,7 +403,22 @@ extern "C" int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_gri
   p.tiles_y = (p.ho + SP_TH - 1) / SP_TH;
   const long long blocks = (long long)p.batch * p.tiles_x * p.tiles_y;
   if (blocks > 0x7fffffffLL) return PCP_ERR_ARG;
-  hipLaunchKernelGGL(k_sparse_conv_s2, dim3((unsigned)blocks), dim3(SP_THREADS), 0, (hipStream_t)stream_, p);
+  if (out_bf16) hipLaunchKernelGGL(k_sparse_conv_s2<true>, dim3((unsigned)blocks), dim3(SP_THREADS), 0, (hipStream_t)stream_, p);
+  else hipLaunchKernelGGL(k_sparse_conv_s2<false>, dim3((unsigned)blocks), dim3(SP_THREADS), 0, (hipStream_t)stream_, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+extern "C" int pcp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n,
+                                     const float *w_packed, const float *bias, int32_t cout, int32_t relu, float *out, int32_t ld_out,
+                                     void *stream_) {
+  return sparse_conv_impl(pillar_features, grid, vox_workspace, n, w_packed, bias, cout, relu, out, 0, ld_out, stream_);
+}
+
+// include/pcp_hip_mp.h: the same launch with a storage type for the output map
+extern "C" int pcp_mp_sparse_conv3x3_s2(const float *pillar_features, const pcp_grid_t *grid, const void *vox_workspace, int64_t n,
+                                        const float *w_packed, const float *bias, int32_t cout, int32_t relu, void *out, int32_t out_dtype,
+                                        int32_t ld_out, void *stream_) {
+  if (out_dtype != 0 && out_dtype != 1) return PCP_ERR_ARG;
+  return sparse_conv_impl(pillar_features, grid, vox_workspace, n, w_packed, bias, cout, relu, out, out_dtype, ld_out, stream_);
 }

@@ -105,7 +105,11 @@ class BaseBEVBackbone(PackedModule):
                 raise RuntimeError('the VFE skipped the dense canvas but this backbone has no sparse first layer '
                                    '(needs Conv2d(64, <= 64, 3, stride 2)); unset sparse_first_layer')
             wsp, bsp, c0 = pk['sparse0']
-            x = ops.sparse_conv3x3_s2(stash['pillar_rows'], stash['vox'], wsp, bsp, c0, relu=True)
+            from ..convnet import _plain_bf16
+            nxt = pk['blocks'][0][1] if len(pk['blocks'][0]) > 1 else None
+            to_bf16 = _plain_bf16() and nxt is not None and getattr(nxt, 'mp', None) is not None       # bf16 loop: the next layer reads bf16
+            x = ops.sparse_conv3x3_s2(stash['pillar_rows'], stash['vox'], wsp, bsp, c0, relu=True,
+                                      out_dtype=torch.bfloat16 if to_bf16 else torch.float32)
             in_h = stash['vox'].grid.ny
             first_done = True
         else:

@@ -133,14 +133,17 @@ class V2XMidFusionDisco(PackedModule):
             self._weight(pk, stack[0], stack[0], wbuf, 0)
         pre = batch_dict.get('bev_img_compressed', None)      # agent-sharded execution: maps compressed on the agent's own GPU
         warps = []                                             # (source map, destination map, theta) of every (agent, frame) pair
+        # the 2 x 3 affine of every pair, all at once on the host (the poses are metadata: nothing on the device is waited for)
+        pairs = [(agent_idx, b_idx) for agent_idx, _img in agents for b_idx, meta in enumerate(batch_dict['metadata'])
+                 if agent_idx in meta['se3_from_ego']]
+        thetas = dict(zip(pairs, fusion_host.warp_thetas([batch_dict['metadata'][b]['se3_from_ego'][a_] for a_, b in pairs], H, W, self.pc_min,
+                                                         self.pix_size)))
         for a, (agent_idx, bev_img) in enumerate(agents, start=1):
             comp = pre[agent_idx] if pre is not None else self._compress(pk, ops.as_nhwc(bev_img))
             for b_idx, meta in enumerate(batch_dict['metadata']):
                 if agent_idx not in meta['se3_from_ego'] or b_idx >= comp.shape[0]:
                     continue
-                T = fusion_host.ego_se3_agent(meta['se3_from_ego'][agent_idx])
-                theta = fusion_host.warp_theta(T, H, W, self.pc_min, self.pix_size)
-                warps.append((comp[b_idx], stack[a, b_idx], theta))
+                warps.append((comp[b_idx], stack[a, b_idx], thetas[(agent_idx, b_idx)]))
             if not fuse_now:
                 ops.warp_nearest_batch(warps, self.cc)         # this agent's frames in one launch, then its weight logits
                 warps = []

@@ -271,8 +271,9 @@ class CenterHead(PackedModule):
         train_tape(data_dict).append(('dense_head', self._backward_from_loss))
         return data_dict
 
-    def get_loss(self):
-        """focal + L1 losses AND dL/d(head maps) in one pass (the gradient is consumed by loss.backward())."""
+    def get_loss(self, read_back=True):
+        """focal + L1 losses AND dL/d(head maps) in one pass (the gradient is consumed by loss.backward()).
+        read_back=False: the tb_dict values stay device scalars (CenterPoint.eager_backward reads them after queuing the backward)."""
         from pcp_amd import lib
         from pcp_amd import train_ops as tops
         st = self._train_state
@@ -290,7 +291,7 @@ class CenterHead(PackedModule):
         dhead = torch.empty_like(buf)
         losses = tops.centerhead_loss(buf, d, st['heat'], st['tb'], st['inds'], st['mask'], dhead=dhead)
         st['dhead'] = dhead
-        vals = losses.tolist()
+        vals = losses.tolist() if read_back else losses
         tb_dict = {'hm_loss_head_0': vals[0], 'loc_loss_head_0': vals[1], 'rpn_loss': vals[2]}
         return losses[2], tb_dict
 

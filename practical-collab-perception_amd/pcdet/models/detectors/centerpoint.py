@@ -19,10 +19,21 @@ class _HipBackward(torch.autograd.Function):
         scale = float(grad_out)
         if scale != 1.0:
             raise NotImplementedError('scale the loss through the optimizer (grad_scale), not through loss.backward(gradient=...)')
-        g = None
-        for _name, fn in reversed(ctx.tape):
-            g = fn(g)
+        run_tape(ctx.tape)
         return None, None, None
+
+
+class Tape(list):
+    """the backward closures a training forward recorded; `done` once they ran"""
+    done = False
+
+
+def run_tape(tape):
+    g = None
+    for _name, fn in reversed(tape):
+        g = fn(g)
+    if isinstance(tape, Tape):
+        tape.done = True
 
 
 def hip_loss(value, tape):
@@ -116,8 +127,9 @@ class CenterPoint(Detector3DTemplate):
     def forward(self, batch_dict):
         batch_dict = self._run_modules(batch_dict)
         if self.training:
+            tape = batch_dict.get('_pcp_tape', [])
             loss, tb_dict, disp_dict = self.get_training_loss()
-            return {'loss': hip_loss(loss, batch_dict.get('_pcp_tape', []))}, tb_dict, disp_dict
+            return {'loss': hip_loss(loss, tape)}, tb_dict, disp_dict
         pred_dicts, recall_dicts = self.post_processing(batch_dict)
         if self.model_cfg.get('RETURN_BATCH_DICT', False):
             return pred_dicts, batch_dict
@@ -125,18 +137,19 @@ class CenterPoint(Detector3DTemplate):
 
     def get_training_loss(self):
         disp_dict = {}
+        rd = lambda t: t.item()
         loss_rpn, tb_dict = self.dense_head.get_loss()
-        tb_dict = {'loss_rpn': loss_rpn.item(), **tb_dict}
+        tb_dict = {'loss_rpn': rd(loss_rpn), **tb_dict}
         loss = loss_rpn
         if self.corrector is not None:
             loss_corrector, tb_dict = self.corrector.get_training_loss(tb_dict)
-            tb_dict['loss_corrector'] = loss_corrector.item()
+            tb_dict['loss_corrector'] = rd(loss_corrector)
             loss = loss + loss_corrector
         if self.v2x_mid_fusion is not None:
             distill = self.v2x_mid_fusion.loss_dict['loss_distill']
             loss = loss + distill
-            tb_dict['loss_mid_fusion_distill'] = distill.item() if hasattr(distill, 'item') else 0.0
-        tb_dict['loss_total'] = loss.item()
+            tb_dict['loss_mid_fusion_distill'] = rd(distill) if hasattr(distill, 'item') else 0.0
+        tb_dict['loss_total'] = rd(loss)
         return loss, tb_dict, disp_dict
 
     def post_processing(self, batch_dict):

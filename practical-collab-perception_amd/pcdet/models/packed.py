@@ -49,4 +49,8 @@ def require_eval_hip(module, what):
 
 def train_tape(batch_dict):
     """list of backward closures, appended in forward order by the train-mode modules; the detector runs it reversed."""
-    return batch_dict.setdefault('_pcp_tape', [])
+    tape = batch_dict.get('_pcp_tape')
+    if tape is None:
+        from .detectors.centerpoint import Tape
+        tape = batch_dict['_pcp_tape'] = Tape()
+    return tape

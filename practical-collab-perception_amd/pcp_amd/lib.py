@@ -46,6 +46,12 @@ class MpWgrad3x3(ctypes.Structure):
                 ('ld_x', c_i32), ('ld_dy', c_i32), ('x_dtype', c_i32), ('dy_dtype', c_i32), ('accumulate', c_i32)]
 
 
+class MpPackJob(ctypes.Structure):
+    """pcp_mp_pack_job_t (include/pcp_hip_mp.h)"""
+    _fields_ = [('w', vp), ('packed', vp), ('cout', c_i32), ('cin', c_i32), ('transpose', c_i32), ('out_pad', c_i32), ('block_start', c_i32),
+                ('reserved', c_i32)]
+
+
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -256,8 +262,13 @@ SYMBOLS.update({
     'pcp_mp_colsum': (c_i32, [vp, c_i32, c_i64, c_i32, c_i32, vp, vp, c_i32, vp]),
     'pcp_mp_accumulate': (c_i32, [vp, c_i32, c_i32, vp, c_i32, c_i32, c_i64, c_i32, c_f, vp]),
     'pcp_mp_dilate2x': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp]),
+    'pcp_mp_pfn_train_out': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp, c_i32, vp]),
+    'pcp_mp_pfn_train_route_out_grad': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, c_i64, vp, c_i32, vp, vp, vp, vp]),
+    'pcp_mp_sparse_conv3x3_s2': (c_i32, [vp, ctypes.POINTER(Grid), vp, c_i64, vp, vp, c_i32, c_i32, vp, c_i32, c_i32, vp]),
     'pcp_mp_conv3x3_packed_bytes': (c_sz, [c_i32, c_i32]),
     'pcp_mp_pack_conv3x3': (c_i32, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
+    'pcp_mp_pack_conv3x3_group_blocks': (c_i32, [vp]),
+    'pcp_mp_pack_conv3x3_group': (c_i32, [vp, c_i32, c_i32, vp]),
     'pcp_mp_conv3x3': (c_i32, [ctypes.POINTER(MpConv3x3), vp, vp, vp, vp, vp]),
     'pcp_mp_conv3x3_plan': (c_i32, [ctypes.POINTER(MpConv3x3), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
     'pcp_mp_conv3x3_wgrad_workspace_bytes': (c_sz, [ctypes.POINTER(MpWgrad3x3)]),

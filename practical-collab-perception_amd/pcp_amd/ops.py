@@ -103,7 +103,7 @@ def voxelize(points, grid, want_inverse=True, want_counts=True, workspace=None, 
     res.voxel_coords = torch.empty((cap, 4), dtype=torch.int32, device=points.device)
     res.unq_inv = torch.empty((cap,), dtype=torch.int64, device=points.device) if want_inverse else None
     res.unq_cnt = torch.empty((cap,), dtype=torch.int32, device=points.device) if want_counts else None
-    res.counters = torch.zeros((4,), dtype=torch.int32, device=points.device)
+    res.counters = torch.empty((4,), dtype=torch.int32, device=points.device)      # all four written by the scan kernel (no fill launch)
     if cells_ready:
         check(L.pcp_voxelize_cells_ready(_p(points), n, stride, ctypes.byref(grid), _p(workspace), workspace.numel(), _p(res.voxel_coords),
                                          _p(res.unq_cnt), _p(res.counters), _stream()), 'pcp_voxelize_cells_ready')
@@ -158,7 +158,7 @@ def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None,
     return out
 
 
-def sparse_conv3x3_s2(pillar_features, vox, w_packed, bias, cout, relu=True, out=None):
+def sparse_conv3x3_s2(pillar_features, vox, w_packed, bias, cout, relu=True, out=None, out_dtype=torch.float32):
     """first backbone layer (ZeroPad2d(1) + 3x3 stride-2 conv + folded BN + ReLU) straight from the pillar list: pillar_features (>= P, 64)
     in pillar-rank order and the voxelize result whose workspace still holds the cell -> rank table.  Returns (B, ny/2, nx/2, cout)."""
     _need_cuda(pillar_features, w_packed, bias, out)
@@ -166,8 +166,12 @@ def sparse_conv3x3_s2(pillar_features, vox, w_packed, bias, cout, relu=True, out
     g = vox.grid
     B, ho, wo = g.batch_size, (g.ny - 1) // 2 + 1, (g.nx - 1) // 2 + 1
     if out is None:
-        out = torch.empty((B, ho, wo, cout), dtype=torch.float32, device=pillar_features.device)
+        out = torch.empty((B, ho, wo, cout), dtype=out_dtype, device=pillar_features.device)
     assert out.shape[:3] == (B, ho, wo) and out.is_contiguous() and pillar_features.is_contiguous() and pillar_features.shape[1] == 64
+    if out.dtype == torch.bfloat16:      # bf16 training loop: the teacher's second layer reads bf16 (include/pcp_hip_mp.h)
+        check(L.pcp_mp_sparse_conv3x3_s2(_p(pillar_features), ctypes.byref(g), _p(vox.workspace), vox.n, _p(w_packed), _p(bias), cout,
+                                         1 if relu else 0, _p(out), _lib.DT_BF16, out.shape[3], _stream()), 'pcp_mp_sparse_conv3x3_s2')
+        return out
     check(L.pcp_sparse_conv3x3_s2(_p(pillar_features), ctypes.byref(g), _p(vox.workspace), vox.n, _p(w_packed), _p(bias), cout,
                                   1 if relu else 0, _p(out), out.shape[3], _stream()), 'pcp_sparse_conv3x3_s2')
     return out

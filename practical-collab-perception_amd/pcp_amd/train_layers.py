@@ -69,6 +69,7 @@ def as_bf16(t, off=0, c=None):
 
 
 PACK_GROUP = tops.PackGroup()
+MP_PACK_GROUP = tops.MpPackGroup()
 PACK_GROUPING = os.environ.get('PCP_PACK_GROUP', '1') != '0'
 
 
@@ -189,9 +190,22 @@ class ConvBNAct:
             w = self.conv.weight.detach()
             wc = w if w.is_contiguous() else w.contiguous()
             mpb = cache.setdefault('mp', {})
-            fwp, fo = tops.mp_pack_conv3x3(wc, False, out=mpb.get('fw'))
-            bwp, bo = tops.mp_pack_conv3x3(wc, True, out=mpb.get('bw'))
-            mpb['fw'], mpb['bw'] = fwp, bwp
+            grouped = (PACK_GROUPING and wc.data_ptr() == w.data_ptr() and 'fw' in mpb and MP_PACK_GROUP.has((id(self.conv), False), w.data_ptr())
+                       and MP_PACK_GROUP.has((id(self.conv), True), w.data_ptr()))
+            if grouped:
+                # steps after the first: ONE launch repacks every registered layer, issued by whichever layer asks first in a step
+                if MP_PACK_GROUP.step != StepClock.step:
+                    MP_PACK_GROUP.run(w.device)
+                    MP_PACK_GROUP.step = StepClock.step
+                fwp, bwp = mpb['fw'], mpb['bw']
+                fo, bo = pack.round_up(self.cout, 64), pack.round_up(self.cin, 64)
+            else:
+                fwp, fo = tops.mp_pack_conv3x3(wc, False, out=mpb.get('fw'))
+                bwp, bo = tops.mp_pack_conv3x3(wc, True, out=mpb.get('bw'))
+                mpb['fw'], mpb['bw'] = fwp, bwp
+                if PACK_GROUPING and wc.data_ptr() == w.data_ptr():          # the parameter's own storage: later steps go through the group launch
+                    MP_PACK_GROUP.add((id(self.conv), False), self.conv, wc, False, fwp, fo)
+                    MP_PACK_GROUP.add((id(self.conv), True), self.conv, wc, True, bwp, bo)
             zeros = _zeros_like_cache(_ZERO_BIAS, w.device, 2048, w.device)
             b = self.conv.bias.detach() if self.conv.bias is not None else None
             fb = zeros if b is None else (b if fo == self.cout else pack.pad_bias(b, fo))

@@ -234,6 +234,50 @@ def mp_pack_conv3x3(w, transpose=False, out=None, fold_scale=None):
     return out, opad
 
 
+class MpPackGroup:
+    """the bf16 weight forms of every 3x3 layer (forward + data gradient) rebuilt by ONE launch per optimizer step (pcp_mp_pack_conv3x3_group:
+    55 four-microsecond launches per DiscoNet iteration otherwise).  Jobs hold weak references to their conv modules."""
+
+    def __init__(self):
+        self.jobs = {}
+        self.dirty = True
+        self.table = None
+        self.total = 0
+        self.step = -1
+
+    def add(self, key, owner, w, transpose, packed, out_pad):
+        import weakref
+        j = _lib.MpPackJob(w.data_ptr(), packed.data_ptr(), int(w.shape[0]), int(w.shape[1]), 1 if transpose else 0, int(out_pad), 0, 0)
+        if _lib.load().pcp_mp_pack_conv3x3_group_blocks(ctypes.byref(j)) <= 0:
+            raise _lib.PcpError('pcp_mp_pack_conv3x3_group: invalid job')
+        self.jobs[key] = (weakref.ref(owner), j, (w, packed))
+        self.dirty = True
+
+    def has(self, key, w_ptr):
+        e = self.jobs.get(key)
+        return e is not None and e[0]() is not None and e[1].w == w_ptr
+
+    def run(self, device):
+        L = _lib.load()
+        dead = [k for k, e in self.jobs.items() if e[0]() is None]
+        for k in dead:
+            del self.jobs[k]
+            self.dirty = True
+        if not self.jobs:
+            return
+        if self.dirty or self.table is None or self.table.device != device:
+            arr = (_lib.MpPackJob * len(self.jobs))()
+            start = 0
+            for i, (_o, j, _t) in enumerate(self.jobs.values()):
+                j.block_start = start
+                start += L.pcp_mp_pack_conv3x3_group_blocks(ctypes.byref(j))
+                arr[i] = j
+            self.total = start
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            self.dirty = False
+        check(L.pcp_mp_pack_conv3x3_group(_p(self.table), len(self.jobs), self.total, _stream()), 'pcp_mp_pack_conv3x3_group')
+
+
 def mp_conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=False, out=None, out_dtype=torch.bfloat16, in_ch_off=0, out_ch_off=0):
     """x: (B, H, W, ld) float32 | bfloat16 NHWC; out: same for the output (allocated (B, Ho, Wo, cout) of out_dtype when None)."""
     _need_cuda(x, packed, bias, out)
@@ -411,13 +455,23 @@ def pfn_train_mid(vox, x0, vec0, in1, arg0):
 
 
 def pfn_train_out(vox, x1, vec1, pillar_features, arg1, canvas):
+    """canvas: (B, ny, nx, 64) float32, or bfloat16 in the bf16 loop (pre-zeroed either way)"""
     L = _lib.load()
+    if canvas is not None and canvas.dtype == torch.bfloat16:
+        check(L.pcp_mp_pfn_train_out(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x1), _p(vec1.scale), _p(vec1.shift),
+                                     _p(pillar_features), _p(arg1), _p(canvas), _lib.DT_BF16, _stream()), 'pcp_mp_pfn_train_out')
+        return
     check(L.pcp_pfn_train_out(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x1), _p(vec1.scale), _p(vec1.shift),
                               _p(pillar_features), _p(arg1), _p(canvas), _stream()), 'pcp_pfn_train_out')
 
 
 def pfn_train_route_out_grad(vox, kept_rows, arg1, dz1, dcanvas=None, dpillar=None):
     L = _lib.load()
+    if dcanvas is not None and dcanvas.dtype == torch.bfloat16:
+        assert dcanvas.is_contiguous()
+        check(L.pcp_mp_pfn_train_route_out_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, kept_rows, _p(dcanvas), _lib.DT_BF16, _p(dpillar),
+                                                _p(arg1), _p(dz1), _stream()), 'pcp_mp_pfn_train_route_out_grad')
+        return
     check(L.pcp_pfn_train_route_out_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, kept_rows, _p(dcanvas), _p(dpillar), _p(arg1),
                                          _p(dz1), _stream()), 'pcp_pfn_train_route_out_grad')
 

@@ -205,3 +205,66 @@ def test_mp_colsum_accumulate_dilate_storage_types():
     tops.accumulate(ab, xb.reshape(-1, 32), 32)                                # bf16 += bf16 (fp32 add, one rounding)
     torch.cuda.synchronize()
     assert torch.equal(ab, want_b)
+
+
+def test_mp_grouped_weight_pack_equals_the_per_layer_pack():
+    """pcp_mp_pack_conv3x3_group (one launch for many layers, both forms) writes the bits of per-layer pcp_mp_pack_conv3x3 calls"""
+    import torch.nn as nn
+    from pcp_amd import train_ops as tops
+    convs = [nn.Conv2d(64, 64, 3, bias=False), nn.Conv2d(64, 128, 3, bias=False), nn.Conv2d(384, 64, 3), nn.Conv2d(128, 48, 3)]
+    grp = tops.MpPackGroup()
+    single = {}
+    for i, c in enumerate(convs):
+        c.weight.data = _u(60 + i, 1, tuple(c.weight.shape), -0.3, 0.3)
+        c.to(DEV)
+        for tr in (False, True):
+            if tr and c.weight.shape[0] % 16:
+                continue
+            ref, opad = tops.mp_pack_conv3x3(c.weight.detach(), tr)
+            single[(i, tr)] = ref
+            dst = torch.full_like(ref, 7.0)
+            grp.add((i, tr), c, c.weight.detach(), tr, dst, opad)
+    grp.run(torch.device(DEV))
+    torch.cuda.synchronize()
+    for key, (_o, _j, (w, dst)) in grp.jobs.items():
+        assert torch.equal(dst.view(torch.int16), single[key].view(torch.int16)), key
+
+
+def test_mp_sparse_first_layer_bf16_output_and_bf16_canvas_kernels():
+    """storage-typed variants used by the bf16 loop outside the conv kernels: the sparse first layer writing bf16 = its fp32 output rounded
+    once; the PFN's last training kernel writing a bf16 canvas = the fp32 canvas rounded; the canvas-gradient gather reading bf16"""
+    from pcp_amd import ops, pack, train_ops as tops
+    pts = np.concatenate([synth.agent_cloud(agent=a, n_points=6000, layout='car') for a in range(2)], 0)
+    points = torch.from_numpy(synth.collate([pts])).to(DEV)
+    grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], 1)
+    vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False)
+    P = int(vox.counters[0].item())
+    pf = _u(71, 1, (points.shape[0], 64)).to(DEV).contiguous()
+    w = _u(72, 2, (64, 64, 3, 3), -0.2, 0.2)
+    b = _u(73, 3, (64,))
+    wsp, bsp = pack.pack_conv3x3_sparse_s2(w, b)
+    o32 = ops.sparse_conv3x3_s2(pf, vox, wsp.to(DEV), bsp.to(DEV), 64, relu=True)
+    o16 = ops.sparse_conv3x3_s2(pf, vox, wsp.to(DEV), bsp.to(DEV), 64, relu=True, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.to(torch.bfloat16)) and float(o32.abs().max()) > 0
+    # PFN training tail: canvas in both storage types from the same x1
+    Nk = int(vox.counters[1].item())
+    x1 = _u(74, 4, (Nk, 64)).to(DEV).contiguous()
+    vec = tops.BNVectors(64, torch.device(DEV))
+    vec.scale.fill_(0.9)
+    vec.shift.fill_(0.05)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        canvas = torch.zeros((1, 512, 512, 64), dtype=dt, device=DEV)
+        pfo = torch.empty((max(P, 1), 64), device=DEV)
+        arg1 = torch.empty((max(P, 1), 64), dtype=torch.int32, device=DEV)
+        tops.pfn_train_out(vox, x1, vec, pfo, arg1, canvas)
+        outs[dt] = (canvas, arg1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[torch.bfloat16][0], outs[torch.float32][0].to(torch.bfloat16)) and float(outs[torch.float32][0].abs().max()) > 0
+    dcan = _u(75, 5, (1, 512, 512, 64)).to(DEV)
+    dz_a, dz_b = torch.empty((Nk, 64), device=DEV), torch.empty((Nk, 64), device=DEV)
+    tops.pfn_train_route_out_grad(vox, Nk, outs[torch.float32][1], dz_a, dcanvas=dcan.to(torch.bfloat16).float().contiguous())
+    tops.pfn_train_route_out_grad(vox, Nk, outs[torch.float32][1], dz_b, dcanvas=dcan.to(torch.bfloat16).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(dz_a, dz_b) and float(dz_a.abs().max()) > 0

@@ -381,3 +381,31 @@ def test_auto_resume_validates_a_checkpoint_before_anything_is_loaded(tmp_path):
     assert train_tool.choose_resume_checkpoint(model, tmp_path, log) == str(good)
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k])
+
+
+def test_vectorised_warp_thetas_equal_the_reference_arithmetic_bit_for_bit():
+    """pcp_amd/fusion_host.py::warp_thetas (all (agent, frame) pairs of a forward in one numpy pass) against warp_theta, the torch-CPU
+    restatement of the reference's transform_bev_img parameter arithmetic (v2x_fusion_disco.py:32-35): 3 000 random rigid poses, two map
+    geometries, every one of the six floats identical -- including the fused (2, 2) @ (2, 1) product, which a plain mul + add gets wrong
+    in a quarter of the cases"""
+    from pcp_amd import fusion_host as fh
+    rng = np.random.RandomState(11)
+    poses = []
+    for _ in range(3000):
+        a = rng.uniform(-np.pi, np.pi)
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T[:3, 3] = rng.uniform(-90, 90, 3)
+        poses.append(T)
+    for h, pc_min, pix in ((128, -51.2, 0.8), (16, -12.8, 1.6)):
+        assert fh._calibrated(h, pc_min, pix)                       # on this machine torch's small matmul is the fused chain the numpy form emulates
+        fast = fh.warp_thetas(poses, h, h, pc_min, pix)
+        slow = [fh.warp_theta(fh.ego_se3_agent(T), h, h, pc_min, pix) for T in poses]
+        assert fast == slow
+    # the plain mul + add form is NOT the reference's arithmetic (so the emulation above is doing something)
+    T32 = np.stack([np.linalg.inv(T) for T in poses]).astype(np.float32)
+    rt = np.transpose(T32[:, :2, :2], (0, 2, 1))
+    tp = np.float32(2.0) * ((T32[:, :2, 3] - np.float32(-51.2)) / np.float32(0.8)) / np.float32(128) - np.float32(1.0)
+    naive = -(rt[:, :, 0] * tp[:, 0:1] + rt[:, :, 1] * tp[:, 1:2])
+    ref = np.array(fh.warp_thetas(poses, 128, 128, -51.2, 0.8), dtype=np.float32).reshape(-1, 2, 3)[:, :, 2]
+    assert (naive != ref).mean() > 0.05
