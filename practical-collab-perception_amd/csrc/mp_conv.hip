@@ -231,7 +231,12 @@ __global__ __launch_bounds__(TH * 32, TH == 16 ? 2 : 1) void k_mp_conv3x3_s1(McP
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][nt], b[cur][mt], acc[nt][mt], 0, 0, 0);
-        if (step < NLD && copy_next) issue_one(step, nslice, buf ^ 1);
+        // copies early in the stage: two per step over the first half of the copy list's steps, so that the last one is issued ~13 steps
+        // (about a memory latency) before the wait at the top of the next stage
+        if (copy_next) {
+          if (2 * step < NLD) issue_one(2 * step, nslice, buf ^ 1);
+          if (2 * step + 1 < NLD) issue_one(2 * step + 1, nslice, buf ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }

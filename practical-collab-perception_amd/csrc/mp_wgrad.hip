@@ -9,7 +9,7 @@
 // ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16 lanes).  The 32-byte channel chunks of a record are XOR-swizzled by bit 1 of the
 // pixel position (on the source address of the copy), which makes the four pixel rows of a transposed read hit four different bank groups.
 //
-// workgroup (4 waves = the quadrants of a 64 (co) x 64 (ci) tile, nine 32 x 32 accumulators per wave = all taps) owns one (co block, ci
+// workgroup (8 waves = the quadrants of a 64 (co) x 64 (ci) tile x two tap halves, five / four 32 x 32 accumulators each) owns one (co block, ci
 // block) pair, one frame, one 32-column strip and a run of output rows; it walks the run TR rows at a time.  LDS: dy rows double buffered,
 // x rows in a ring of three 4-row groups (every x row is fetched ONCE per strip: the halo rows of a stage are the previous / next group).
 // The copy of the next stage runs under the MFMAs of the current one; one barrier per stage.  Stride 2: the x rows are stored with even
@@ -18,6 +18,7 @@
 // The kernel is HBM-bound by design: a 64 x 64 x 9 tile gives 224 flop per input byte, under the bf16 ridge of ~400.
 #include "pcp_common.h"
 #include "../../include/pcp_hip_mp.h"
+#include <type_traits>
 
 namespace {
 
@@ -28,11 +29,14 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr unsigned WG_OOB = 0x80000000u;
-constexpr int WG_THREADS = 256;
+constexpr int WG_THREADS = 512;            // wave = (quadrant of the tile, half of the taps)
 constexpr int WG_DW = 32;                 // dy columns of a strip
 
+#ifndef WG_DEPTH_S1
+#define WG_DEPTH_S1 2
+#endif
 template <int S> struct WgCfg;
-template <> struct WgCfg<1> { static constexpr int TR = 4, XWP = 34, XHALF = 0, DEPTH = 1; };      // XWP: x records per row in LDS; DEPTH: stages of copy in flight (2 measured no faster)
+template <> struct WgCfg<1> { static constexpr int TR = 4, XWP = 34, XHALF = 0, DEPTH = WG_DEPTH_S1; };      // XWP: x records per row in LDS; DEPTH: stages of copy in flight (2 measured no faster)
 template <> struct WgCfg<2> { static constexpr int TR = 2, XWP = 72, XHALF = 36, DEPTH = 1; };     // [parity][36]; a third group ahead would not fit the LDS
 
 struct WgParams {
@@ -48,15 +52,25 @@ __device__ __forceinline__ int wg_xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+#ifdef WG_STAMP
+__device__ unsigned long long wg_stamps[1024 * 24];
+#define WG_T(i)                                                                                         \
+  do {                                                                                                  \
+    if (tid == 0 && blockIdx.x < 1024 && (i) < 24) wg_stamps[blockIdx.x * 24 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define WG_T(i) do { } while (0)
+#endif
+
 template <int S>
-__global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
+__global__ __launch_bounds__(WG_THREADS, 2) void k_mp_wgrad3x3(WgParams p) {
   typedef WgCfg<S> C;
   constexpr int TR = C::TR, XWP = C::XWP;
   constexpr int XG_BYTES = 4 * XWP * 128;                 // one x group (4 rows)
   constexpr int XGI = XG_BYTES / 1024;                    // wave-instructions per x group (17 | 36)
   constexpr int DY_BYTES = TR * WG_DW * 128;              // one dy stage
   constexpr int DYI = DY_BYTES / 1024;                    // 16 | 8
-  constexpr int NXL = (XGI + 3) / 4, NDL = (DYI + 3) / 4; // copy instructions per wave
+  constexpr int NXL = (XGI + 7) / 8, NDL = (DYI + 7) / 8; // copy instructions per wave (all eight waves copy)
   constexpr int D = C::DEPTH;                             // stages the copy runs ahead: 33 KB in flight per CU (D = 1) held the strip walk at ~3 TB/s
   constexpr int NXG = D + 2, NDY = D + 1;                 // x groups / dy stages resident
   static_assert(XG_BYTES % 1024 == 0 && DY_BYTES % 1024 == 0, "whole wave instructions");
@@ -67,7 +81,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;                // co half, ci half of the 64 x 64 tile
+  // EIGHT multiplying waves, two per SIMD: wave = (quadrant of the 64 x 64 tile, half of the taps: 0-4 | 5-8).  With ONE wave per SIMD a
+  // `buffer_load ... lds` blocked the only instruction stream of the SIMD for hundreds of cycles (in-kernel stamps, tools/stamp_wg.py: a
+  // stage took 7 500 cycles with its nine copies, 3 300 without); four extra loader waves did not fit the register file beside 144
+  // accumulators.  Two waves with 80 / 64 accumulators do, and each one's copy stalls run under the other one's MFMAs.
+  const int lw = wave & 3;                                // quadrant
+  const int th = wave >> 2;                               // tap half
+  const int wm = lw >> 1, wn = lw & 1;                    // co half, ci half of the 64 x 64 tile
+  WG_T(0);
 
   // ---- which (pair, split) --------------------------------------------------------------------------------------------------------------
   const int n_pairs = p.n_cob * p.n_cib;
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
   int xrow[NXL], xcol[NXL], xsrc[NXL];
 #pragma unroll
   for (int k = 0; k < NXL; ++k) {
-    const int q = (wave + 4 * k) * 64 + lane;
+    const int q = (wave + 8 * k) * 64 + lane;
     const int rec = q >> 3, piece = q & 7;
     xrow[k] = rec / XWP;
     const int pos = rec - xrow[k] * XWP;
@@ -106,7 +127,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
   int drow[NDL], dcol[NDL], dsrc[NDL];
 #pragma unroll
   for (int k = 0; k < NDL; ++k) {
-    const int q = (wave + 4 * k) * 64 + lane;
+    const int q = (wave + 8 * k) * 64 + lane;
     const int rec = q >> 3, piece = q & 7;
     drow[k] = rec / WG_DW;
     dcol[k] = rec % WG_DW;
@@ -116,23 +137,40 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
   const int gx0 = S * c0 - 1;
   // one copy instruction at a time: inside the main loop they are spread over the multiply steps (issued back to back they block the wave
   // for ~200 cycles each: the CU's vector-memory path takes 64 B/clk -- measured on k_mp_conv3x3_s1, tools/stamp_mc.py)
+  // per copy instruction: the byte offset for group / stage 0, its first global row and whether its column is inside the map -- the offset
+  // of group g is then one multiply-add away (the copy's own address arithmetic runs on the SIMD the MFMAs want)
+  unsigned xoff0[NXL], doff0[NDL];
+  int xgy0[NXL], dgy0[NDL];
+  bool xcol_ok[NXL], dcol_ok[NDL];
+#pragma unroll
+  for (int k = 0; k < NXL; ++k) {
+    xgy0[k] = S * r0 - 1 + xrow[k];
+    const int gx = gx0 + xcol[k];
+    xcol_ok[k] = gx >= 0 && gx < p.w && (wave + 8 * k) < XGI;
+    xoff0[k] = (unsigned)(((b * p.h + xgy0[k]) * p.w + gx) * p.ld_x * 2 + xsrc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NDL; ++k) {
+    dgy0[k] = r0 + drow[k];
+    const int gx = c0 + dcol[k];
+    dcol_ok[k] = gx < p.ow && (wave + 8 * k) < DYI;
+    doff0[k] = (unsigned)(((b * p.oh + dgy0[k]) * p.ow + gx) * p.ld_dy * 2 + dsrc[k]);
+  }
+  const unsigned xstep = (unsigned)(4 * p.w * p.ld_x * 2), dstep = (unsigned)(TR * p.ow * p.ld_dy * 2);
   auto issue_x_one = [&](int k, int g) {                  // x rows [S r0 - 1 + 4g, +4) -> ring slot g % NXG
     unsigned char *base = xring + (g % NXG) * XG_BYTES;
-    const int i = wave + 4 * k;
+    const int i = wave + 8 * k;
     if (i < XGI) {
-      const int gy = S * r0 - 1 + 4 * g + xrow[k], gx = gx0 + xcol[k];
-      unsigned off = WG_OOB;
-      if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) off = (unsigned)(((b * p.h + gy) * p.w + gx) * p.ld_x * 2 + xsrc[k]);
+      const int gy = xgy0[k] + 4 * g;
+      const unsigned off = (xcol_ok[k] && gy >= 0 && gy < p.h) ? xoff0[k] + (unsigned)g * xstep : WG_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
     }
   };
   auto issue_dy_one = [&](int k, int s) {                 // dy rows [r0 + TR s, +TR) -> buffer s % NDY
     unsigned char *base = dybuf + (s % NDY) * DY_BYTES;
-    const int i = wave + 4 * k;
+    const int i = wave + 8 * k;
     if (i < DYI) {
-      const int gy = r0 + TR * s + drow[k], gx = c0 + dcol[k];
-      unsigned off = WG_OOB;
-      if (gy < r1 && gx < p.ow) off = (unsigned)(((b * p.oh + gy) * p.ow + gx) * p.ld_dy * 2 + dsrc[k]);
+      const unsigned off = (dcol_ok[k] && dgy0[k] + TR * s < r1) ? doff0[k] + (unsigned)s * dstep : WG_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_void *)(base + i * 1024), 16, (int)off, 0, 0, 0);
     }
   };
@@ -160,9 +198,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
     b_lane[kx] = (pos + posoff) * 128 + (((2 * wn + blk) ^ (((pos >> 1) & 1) << 1)) * 32) + pp * 8;
   }
 
-  f32x16 acc[9];
+  f32x16 acc[5];                                          // taps 5 th .. 5 th + 4 (the second half has four)
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 5; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
@@ -173,9 +211,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
   // copy instructions this wave issues per batch (x group + dy stage): what may stay in flight across the barrier when D = 2
   int n_batch = 0;
 #pragma unroll
-  for (int k = 0; k < NXL; ++k) n_batch += (wave + 4 * k < XGI) ? 1 : 0;
+  for (int k = 0; k < NXL; ++k) n_batch += (wave + 8 * k < XGI) ? 1 : 0;
 #pragma unroll
-  for (int k = 0; k < NDL; ++k) n_batch += (wave + 4 * k < DYI) ? 1 : 0;
+  for (int k = 0; k < NDL; ++k) n_batch += (wave + 8 * k < DYI) ? 1 : 0;
   issue_x(0);
   issue_x(1);
   issue_dy(0);
@@ -183,24 +221,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
     issue_x(2);
     issue_dy(1);
   }
-  for (int s = 0; s < n_st; ++s) {
-    // stage s needs x groups s, s + 1 and dy stage s; with D = 2 the batch issued during stage s - 1 (x group s + 2, dy stage s + 1) may
-    // still be in flight: the wait leaves exactly this wave's share of it outstanding (a wave's copies complete in issue order)
-    if (D == 2 && s + 1 < n_st) {
-      if (n_batch == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else if (n_batch == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    const bool copy_next = s + D < n_st;
+  // one stage of products for a tap half known at compile time (TH: 0 -> taps 0..4, 1 -> taps 5..8)
+  auto stage = [&](auto th_tag, int s, bool copy_next) {
+    constexpr int TH = decltype(th_tag)::value;
+    constexpr int T0 = 5 * TH, NT = TH ? 4 : 5;
+    constexpr int NIT = TR * 2, NC = NXL + NDL;            // 16-pixel k steps of a stage, copy instructions of a stage (this wave)
+    constexpr int NSTEP = NIT * NT;                        // one MFMA per (k step, tap)
     const unsigned char *dyb = dybuf + (s % NDY) * DY_BYTES + a_lane;
-    constexpr int NIT = TR * 2, NC = NXL + NDL;            // multiply iterations (16-pixel k steps) of a stage, its copy instructions
-    constexpr int NSTEP = NIT * 9;                         // one MFMA per (k step, tap)
     const int g0 = s % NXG, g1 = (s + 1) % NXG;
-    // operand reads, software pipelined by hand: the two transposed reads of step st + 1 are issued BEFORE the MFMA of step st (fenced --
-    // with one wave per SIMD nothing else hides the LDS latency, and hipcc sinks every read to just in front of its use)
+    // operand reads, software pipelined by hand: the two transposed reads of step st + 1 are issued BEFORE the MFMA of step st (fenced:
+    // hipcc otherwise sinks every read to just in front of its use)
     auto rd_a = [&](int itn) -> bf16x8 {
       const int rr = itn >> 1, kk = itn & 1;
       const unsigned char *ap = dyb + (rr * WG_DW + 16 * kk) * 128;
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
       return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto rd_b = [&](int st) -> bf16x8 {
-      const int itn = st / 9, tap = st % 9, rr = itn >> 1, kk = itn & 1, ky = tap / 3, kx = tap % 3;
+      const int itn = st / NT, tap = T0 + st % NT, rr = itn >> 1, kk = itn & 1, ky = tap / 3, kx = tap % 3;
       const int rel = S * rr + ky;                                       // x row relative to group s: 0 .. 5
       const unsigned char *bp = xring + ((rel >> 2) ? g1 : g0) * XG_BYTES + (rel & 3) * (XWP * 128) + b_lane[kx] + (16 * kk) * 128;
       const s16x4 b0 = tr_read(bp), b1 = tr_read(bp + 4 * 128);
@@ -219,36 +249,62 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mp_wgrad3x3(WgParams p) {
     bq[0] = rd_b(0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
-      const int itn = st / 9, tap = st % 9;
+      const int itn = st / NT, tl = st % NT;
       if (st + 1 < NSTEP) bq[(st + 1) & 1] = rd_b(st + 1);
-      if (tap == 5 && itn + 1 < NIT) aq[(itn + 1) & 1] = rd_a(itn + 1);
+      if (tl == NT - 2 && itn + 1 < NIT) aq[(itn + 1) & 1] = rd_a(itn + 1);
       __builtin_amdgcn_sched_barrier(0);
-      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[itn & 1], bq[st & 1], acc[tap], 0, 0, 0);
-      // the copy instructions of stage s + D, spread over the k steps (x group s + D + 1 first, then dy stage s + D)
-      if (tap == 8 && copy_next) {
+      acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[itn & 1], bq[st & 1], acc[tl], 0, 0, 0);
+      // this wave's copy instructions of stage s + D, spread over the k steps (x group s + D + 1 first, then dy stage s + D)
+      if (tl == NT - 1 && copy_next) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-          if (c * NIT / NC == itn) {
+          if (c * (NIT / 2) / NC + (NIT / 2) * TH == itn) {          // the two waves of a SIMD copy in different halves of the stage
             if (c < NXL) issue_x_one(c, s + D + 1);
             else issue_dy_one(c - NXL, s + D);
           }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  for (int s = 0; s < n_st; ++s) {
+    // stage s needs x groups s, s + 1 and dy stage s; with D = 2 the batch issued during stage s - 1 (x group s + 2, dy stage s + 1) may
+    // still be in flight: the wait leaves exactly this wave's share of it outstanding (a wave's copies complete in issue order)
+    if (D == 2 && s + 1 < n_st) {
+      if (n_batch == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (n_batch == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (s < 10) WG_T(1 + 2 * s);
+    const bool copy_next = s + D < n_st;
+    if (th == 0) stage(std::integral_constant<int, 0>{}, s, copy_next);
+    else stage(std::integral_constant<int, 1>{}, s, copy_next);
+    if (s < 10) WG_T(2 + 2 * s);
   }
+  WG_T(21);
 
-  // ---- partial tile in ACCUMULATOR order: [pair][split][tap][wave][quad g][lane][4] -- every store instruction of a wave writes 1 KB of
+  // ---- partial tile in ACCUMULATOR order: [pair][split][tap][quadrant][quad g][lane][4] -- every store instruction of a wave writes 1 KB of
   // contiguous memory (16 bytes per lane); k_mp_wgrad_reduce undoes the permutation.  Element (t, w, g, l, i) is dw[co][ci][t] with
   // co = 32 (w >> 1) + 8 g + 4 (l >> 5) + i, ci = 32 (w & 1) + (l & 31).  (144 dword stores per wave in [co][ci] order made the tail as long
   // as the whole multiply loop -- the epilogue is store-ISSUE bound; 16-byte stores in a [ci][co] order scatter 64 pieces per instruction
   // and were slower still: profiles/r04_mp_wgrad_variants.txt) -----------------------------------------------------------------------------------
   float *dst = p.partial + ((long long)pair * p.n_split + split) * (9 * 64 * 64);
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int tl = 0; tl < 5; ++tl) {
+    const int t = 5 * th + tl;
+    if (t < 9) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<f32x4 *>(dst + ((((t * 4 + wave) * 4 + g) * 64 + lane) << 2)) =
-          f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4 *>(dst + ((((t * 4 + lw) * 4 + g) * 64 + lane) << 2)) =
+            f32x4{acc[tl][4 * g], acc[tl][4 * g + 1], acc[tl][4 * g + 2], acc[tl][4 * g + 3]};
+    }
+  }
+  WG_T(22);
+#ifdef WG_STAMP
+  if (tid == 0 && blockIdx.x < 1024) wg_stamps[blockIdx.x * 24 + 23] = (unsigned long long)n_st;
+#endif
 }
 
 // dw[co][ci][tap] (+)= sum over splits, in split order
@@ -303,6 +359,12 @@ bool wg_plan(const pcp_mp_wgrad3x3_t *d, WgPlan &pl) {
 }  // namespace
 
 extern "C" {
+
+#ifdef WG_STAMP
+int pcp_debug_read_wg(void *dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(wg_stamps), bytes < sizeof(wg_stamps) ? bytes : sizeof(wg_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t pcp_mp_conv3x3_wgrad_workspace_bytes(const pcp_mp_wgrad3x3_t *d) {
   WgPlan pl;
