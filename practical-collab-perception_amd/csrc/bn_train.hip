@@ -41,7 +41,7 @@ template <> struct IO4<bf16_t> {
 };
 
 constexpr int RED_THREADS = 256;
-constexpr int RED_MAX_BLOCKS = 1024;
+constexpr int RED_MAX_BLOCKS = 512;      // partials per reduction: the finalize kernels read nb x 2c doubles (1024 -> 512: their ~9 us halve, the streaming pass keeps its rate)
 
 enum { RED_STATS = 0, RED_BNBWD = 1, RED_COLSUM = 2 };
 

@@ -28,10 +28,18 @@ class Tape(list):
     done = False
 
 
+# set by the data-parallel optimizer (tools/train_utils/optimization: FlatAdamOneCycle.attach_overlap): called with the name of every module
+# whose backward closure has just been queued, so the gradient all-reduce of the modules that finish FIRST in the backward pass (head,
+# fusion) runs under the backward of the rest (backbone, VFE) -- what DistributedDataParallel's buckets do at the reference's train.py:161
+GRAD_READY_HOOK = None
+
+
 def run_tape(tape):
     g = None
-    for _name, fn in reversed(tape):
+    for name, fn in reversed(tape):
         g = fn(g)
+        if GRAD_READY_HOOK is not None:
+            GRAD_READY_HOOK(name)
     if isinstance(tape, Tape):
         tape.done = True
 

@@ -74,6 +74,43 @@ class FlatAdamOneCycle:
                                                                           torch.distributed.is_initialized()) else 1
         self.ref_order = reference_param_order(model, self.params)
 
+    # ---- gradient all-reduce overlapped with the backward pass (two buckets) -------------------------------------------------------------
+    def attach_overlap(self, model, first_done=('dense_head', 'v2x_mid_fusion')):
+        """Splits the flat gradient where the parameters of the modules that finish FIRST in the backward pass begin (`first_done`, in
+        registration order the LAST ones: ... backbone | fusion | head) and all-reduces that tail asynchronously as soon as their
+        backward closures have been queued; the head of the buffer follows in step().  A no-op without a multi-rank group (or
+        PCP_FORCE_COLLECTIVES=1), or when those parameters are not one contiguous tail of the flat buffer."""
+        from pcdet.models.detectors import centerpoint
+        self._tail_off, self._tail_work, self._tail_trigger = None, None, None
+        if not _collectives_on(self.process_group):
+            return False
+        owner = {}
+        for mname, mod in model.named_children():
+            for p in mod.parameters():
+                owner[id(p)] = mname
+        off, tail_start, seen_tail = 0, None, False
+        for p in self.params:
+            in_tail = owner.get(id(p)) in first_done
+            if in_tail and tail_start is None:
+                tail_start = off
+            if seen_tail and not in_tail:
+                return False                               # not contiguous: keep the single all-reduce
+            seen_tail = seen_tail or in_tail
+            off += (p.numel() + 3) // 4 * 4
+        if tail_start is None or tail_start == 0:
+            return False
+        present = [n for n in first_done if hasattr(model, n) and getattr(model, n) is not None]
+        self._tail_off = tail_start
+        self._tail_trigger = present[-1]                   # the tape runs in reverse registration order: the last listed finishes last
+        centerpoint.GRAD_READY_HOOK = self._grad_ready
+        return True
+
+    def _grad_ready(self, name):
+        if self._tail_off is None or name != self._tail_trigger or self._tail_work is not None:
+            return
+        self._tail_work = torch.distributed.all_reduce(self.flat_g[self._tail_off:], group=self.process_group, async_op=True)
+        self.overlapped_reductions = getattr(self, 'overlapped_reductions', 0) + 1
+
     def zero_grad(self):
         off = 0
         for p in self.params:                                               # re-attach views a foreign zero_grad(set_to_none) dropped
@@ -89,7 +126,13 @@ class FlatAdamOneCycle:
         return self.sqnorm
 
     def step(self):
-        scale = all_reduce_flat_gradient(self.flat_g, self.process_group)   # RCCL, one bucket; DDP-style averaging via grad_scale
+        if getattr(self, '_tail_work', None) is not None:
+            # bucket 2 (head + fusion) has been in flight since their backward was queued; bucket 1 is the rest
+            scale = all_reduce_flat_gradient(self.flat_g[:self._tail_off], self.process_group)
+            self._tail_work.wait()
+            self._tail_work = None
+        else:
+            scale = all_reduce_flat_gradient(self.flat_g, self.process_group)   # RCCL, one bucket; DDP-style averaging via grad_scale
         self.t += 1
         if self.max_norm is not None:
             tops.grad_sqnorm(self.flat_g, out=self.sqnorm)
@@ -196,7 +239,9 @@ class OneCycle:
 def build_optimizer(model, optim_cfg):
     if optim_cfg.OPTIMIZER != 'adam_onecycle':
         raise NotImplementedError('the fused optimizer implements adam_onecycle (the recipe of every V2X-Sim config), got %s' % optim_cfg.OPTIMIZER)
-    return FlatAdamOneCycle(model, wd=optim_cfg.WEIGHT_DECAY, beta2=0.99)
+    opt = FlatAdamOneCycle(model, wd=optim_cfg.WEIGHT_DECAY, beta2=0.99)
+    opt.attach_overlap(model)           # multi-rank groups only: head + fusion gradients reduced under the backbone's backward
+    return opt
 
 
 def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):

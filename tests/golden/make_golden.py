@@ -1636,6 +1636,35 @@ def g14_late_fusion():
     np.savez_compressed(os.path.join(HERE, 'g14_late_fusion.npz'), **out)
 
 
+def g15_multi_classes_nms():
+    """model_nms_utils.multi_classes_nms (reference pcdet/models/model_utils/model_nms_utils.py:28-66) on synthetic 3-class candidates
+    (the g14 scene generator: several jittered views per object, scores under the threshold): the reference's own per-class loop ->
+    tests/golden/g15_multi_classes_nms.npz"""
+    rh.install()
+    from pcdet.models.model_utils import model_nms_utils as ref_nms
+    rng = np.random.RandomState(1505)
+    n_obj, views = 70, 4
+    centers = np.concatenate([rng.uniform(-48, 48, (n_obj, 2)), rng.uniform(-2.5, -0.5, (n_obj, 1))], 1)
+    dims = np.stack([rng.uniform(0.6, 5.2, n_obj), rng.uniform(0.6, 2.2, n_obj), rng.uniform(1.2, 1.9, n_obj)], 1)
+    yaw = rng.uniform(-np.pi, np.pi, (n_obj, 1))
+    idx = np.repeat(np.arange(n_obj), views)
+    n = idx.shape[0]
+    boxes = np.concatenate([centers[idx] + rng.normal(0, 0.2, (n, 3)) * [1, 1, 0.2], dims[idx] * rng.uniform(0.95, 1.05, (n, 3)),
+                            yaw[idx] + rng.normal(0, 0.06, (n, 1)), rng.uniform(-1, 1, (n, 2))], 1).astype(np.float32)      # (N, 7 + 2)
+    cls = rng.uniform(0.0, 0.3, (n, 3)).astype(np.float32)
+    true_cls = rng.randint(0, 3, n_obj)[idx]
+    cls[np.arange(n), true_cls] = rng.uniform(0.05, 0.98, n).astype(np.float32)
+    cfg = rh.AttrDict(dict(NMS_TYPE='nms_gpu', NMS_THRESH=0.2, NMS_PRE_MAXSIZE=100, NMS_POST_MAXSIZE=30, MULTI_CLASSES_NMS=True))
+    out = {'boxes': boxes, 'cls_scores': cls}
+    for tag, thr in (('thr', 0.1), ('nothr', None)):
+        with torch.no_grad():
+            sc, lb, bx = ref_nms.multi_classes_nms(torch.from_numpy(cls.copy()), torch.from_numpy(boxes.copy()), cfg, score_thresh=thr)
+        out[tag + '_scores'], out[tag + '_labels'], out[tag + '_boxes'] = sc.numpy().copy(), lb.numpy().copy(), bx.numpy().copy()
+        print('g15', tag, [int((lb == k).sum()) for k in range(3)])
+    out['meta_json'] = np.array(json.dumps(dict(nms_config=dict(cfg), score_thresh=0.1)))
+    np.savez_compressed(os.path.join(HERE, 'g15_multi_classes_nms.npz'), **out)
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
@@ -1647,6 +1676,8 @@ if __name__ == '__main__':
         g13_chain(full=True)
     if 'g14' in todo:
         g14_late_fusion()
+    if 'g15' in todo:
+        g15_multi_classes_nms()
     if 'g3' in todo:
         g3_nms()
     if 'g4' in todo:

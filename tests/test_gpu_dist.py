@@ -333,6 +333,37 @@ try:
                 same = same and a[k].shape == b[k].shape and bool(torch.equal(a[k], b[k]))
         out[kind + '_equal'] = bool(same)
         out[kind + '_boxes'] = int(sum(p['pred_boxes'].shape[0] for p in single))
+    # a training step whose gradient all-reduce runs in two buckets, the head + fusion bucket asynchronously under the backbone's backward
+    from pcdet.config import EasyDict
+    from train_utils.optimization import build_optimizer
+    from pcdet.models.detectors import centerpoint
+    gold = load_golden('g7_train.npz')
+    grads = {}
+    for overlap in (True, False):
+        model = build_network_from_meta(gold['meta'])
+        st = synth.fill_state_dict(gold['meta']['state_shapes'])
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+        model = model.cuda()
+        opt = build_optimizer(model, EasyDict(gold['meta']['optimization']))
+        if overlap:
+            out['overlap_attached'] = opt._tail_off is not None and 0 < opt._tail_off < opt.flat_g.numel()
+        else:
+            centerpoint.GRAD_READY_HOOK = None
+            opt._tail_off = None
+        model.train()
+        opt.zero_grad()
+        metadata = [{'se3_from_ego': {0: gold['pose_0'], 2: gold['pose_2']}}, {'se3_from_ego': {0: gold['pose_0']}}]
+        ret, tb, _ = model({'points': torch.from_numpy(gold['points']).cuda(), 'batch_size': 2, 'metadata': metadata,
+                            'gt_boxes': torch.from_numpy(gold['gt_boxes']).cuda()})
+        ret['loss'].backward()
+        if overlap:
+            out['overlap_in_flight'] = opt._tail_work is not None and getattr(opt, 'overlapped_reductions', 0) == 1
+        opt.clip_grad_norm(10.0)
+        g_before = opt.flat_g.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        grads[overlap] = (g_before, opt.flat_p.clone())
+    out['overlap_same_update'] = bool(torch.equal(grads[True][1], grads[False][1]))
     torch.cuda.synchronize()
     with open('/proc/self/maps') as fh:
         out['librccl_mapped'] = any('librccl' in ln for ln in fh)
@@ -352,7 +383,8 @@ def test_rccl_one_rank_group_runs_every_collective_of_the_sharded_paths_on_devic
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RCCL_RESULT ')][0][len('RCCL_RESULT '):])
     assert res['backend'] == 'nccl' and res['librccl_mapped'], res
-    for k in ('rows_equal', 'maps_equal', 'async_equal', 'allreduce_equal', 'disco_equal', 'early_equal'):
+    for k in ('rows_equal', 'maps_equal', 'async_equal', 'allreduce_equal', 'disco_equal', 'early_equal', 'overlap_attached', 'overlap_in_flight',
+              'overlap_same_update'):
         assert res[k] is True, (k, res)
     assert res['modar_shapes'] == [[7, 9], [40, 13]]
     assert res['disco_boxes'] > 0 and res['early_boxes'] > 0

@@ -330,6 +330,26 @@ def test_v2x_late_fusion_equals_the_references_own_forward(method):
         assert np.array_equal(np.sort(pred[b]['pred_labels'].cpu().numpy()), np.sort(g['%s_labels_%d' % (method, b)]))
 
 
+def test_multi_classes_nms_equals_the_references_loop():
+    """model_nms_utils.multi_classes_nms on the device NMS against tests/golden/g15_multi_classes_nms.npz (the reference's per-class loop,
+    model_nms_utils.py:28-66): per class the same kept boxes (all 9 columns) and scores, classes in ascending order"""
+    from pcdet.config import EasyDict
+    from pcdet.models.model_utils import model_nms_utils
+    g = load_golden('g15_multi_classes_nms.npz')
+    cfg = EasyDict(g['meta']['nms_config'])
+    for tag, thr in (('thr', g['meta']['score_thresh']), ('nothr', None)):
+        sc, lb, bx = model_nms_utils.multi_classes_nms(torch.from_numpy(g['cls_scores']).cuda(), torch.from_numpy(g['boxes']).cuda(), cfg, score_thresh=thr)
+        torch.cuda.synchronize()
+        sc, lb, bx = sc.cpu().numpy(), lb.cpu().numpy(), bx.cpu().numpy()
+        assert np.array_equal(lb, g[tag + '_labels']) and bx.shape == g[tag + '_boxes'].shape
+        for k in range(3):
+            m = lb == k
+            want_b, want_s = g[tag + '_boxes'][g[tag + '_labels'] == k], g[tag + '_scores'][g[tag + '_labels'] == k]
+            assert_same_final_set(want_b[:, :7], want_s, bx[m][:, :7], sc[m], tol=0.0)
+            ow, og = np.lexsort((want_b[:, 0], -want_s)), np.lexsort((bx[m][:, 0], -sc[m]))
+            assert np.array_equal(want_b[ow], bx[m][og])
+
+
 @pytest.mark.parametrize('tag', ['ego', 'car'])
 def test_hipgraph_replay_equals_eager(tag):
     from pcdet.models.graphed import GraphedDetector

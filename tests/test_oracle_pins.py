@@ -129,6 +129,24 @@ def test_g14_late_fusion_box_nms():
         assert_same_final_set(want_b, want_s, rows[sel, :7], sc, tol=0.0)
 
 
+def test_g15_multi_classes_nms():
+    """the reference's per-class NMS loop (model_nms_utils.py:28-66, golden g15) restated with the oracle's NMS, class by class"""
+    g = load_golden('g15_multi_classes_nms.npz')
+    cfg = g['meta']['nms_config']
+    for tag, thr in (('thr', g['meta']['score_thresh']), ('nothr', None)):
+        sc, lb, bx = [], [], []
+        for k in range(3):
+            s = g['cls_scores'][:, k]
+            sel, kept = onms.class_agnostic_nms(s, g['boxes'][:, :7], cfg['NMS_THRESH'], cfg['NMS_PRE_MAXSIZE'], cfg['NMS_POST_MAXSIZE'], score_thresh=thr)
+            sc.append(kept)
+            lb.append(np.full(len(sel), k))
+            bx.append(g['boxes'][sel])
+        assert np.array_equal(np.concatenate(lb), g[tag + '_labels'])
+        for k in range(3):
+            m = g[tag + '_labels'] == k
+            assert_same_final_set(g[tag + '_boxes'][m][:, :7], g[tag + '_scores'][m], bx[k][:, :7], sc[k], tol=0.0)
+
+
 def test_ref_build_matches_oracle_when_present():
     so = os.path.join(os.path.dirname(onms.__file__), '_ref', 'ref_iou3d_cpu.so')
     if not os.path.isfile(so):
