@@ -900,28 +900,55 @@ def main(argv=None):
         }
         if world > 1 and backend != 'nccl':
             line['data'] += ' -- FUNCTIONAL CHECK ONLY: backend %s, %d ranks on %d device(s)' % (backend, world, n_dev)
-        if world == 1 and not args.train and not args.graph and args.shard == 'frame' and algo == 'auto' and args.optin:
-            # informational: the same workload with the OPT-IN split-bf16 convolution arithmetic (never part of `value`)
-            os.environ['PCP_CONV_ALGO'] = 'bf16x3'
-            for m in model.modules():
-                if hasattr(m, 'invalidate_packed'):
-                    m.invalidate_packed()
-            for _ in range(args.warmup):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            alt = time.perf_counter() - t1
-            os.environ['PCP_CONV_ALGO'] = 'auto'
-            for m in model.modules():
-                if hasattr(m, 'invalidate_packed'):
-                    m.invalidate_packed()
-            line['optin_bf16x3'] = {'value': round(batch * args.steps / alt, 3), 'unit': 'frames/s', 'ms_per_step': round(1e3 * alt / args.steps, 4),
-                                    'note': 'NOT the headline: 3x3 conv products as split bf16 (hi + lo, 16 mantissa bits; 3 bf16 MFMAs per '
-                                            'product, f32 accumulate), ~1e-5 relative error, all parity tests pass at unchanged tolerances; '
-                                            'enable with --conv-algo bf16x3 / PCP_CONV_ALGO=bf16x3'}
+        if world == 1 and not args.train and not args.graph and args.shard == 'frame' and algo == 'auto' and args.optin and lately is None:
+            # informational: the same workload with the OPT-IN arithmetic modes (never part of `value` / `dtype`): split bf16 (three MFMAs per
+            # product, ~1e-5) and plain bf16 activations + products (the training loop's kernels, include/pcp_hip_mp.h; NOT inside the 1e-3
+            # parity bar -- the error of every head map against this run's own fp32 maps is printed beside the rate)
+            def plain_forward():
+                work.copy_(pristine)
+                bd_ = {'points': work, 'batch_size': batch, 'metadata': metas}
+                with torch.no_grad():
+                    pd_, _ = model(bd_)
+                torch.cuda.synchronize()
+                maps = {k: v.detach().float().clone() for k, v in model.dense_head.forward_ret_dict['pred_dicts'][0].items()}
+                maps['spatial_features_2d'] = bd_['spatial_features_2d'].detach().float().clone()
+                return pd_, maps
+
+            def set_algo(a_):
+                os.environ['PCP_CONV_ALGO'] = a_
+                for m in model.modules():
+                    if hasattr(m, 'invalidate_packed'):
+                        m.invalidate_packed()
+            ref_pred, ref_maps = plain_forward()
+            for mode, note in (('bf16x3', '3x3 conv products as split bf16 (hi + lo, 16 mantissa bits; 3 bf16 MFMAs per product, f32 accumulate), f32 tensors'),
+                               ('bf16', 'bf16 activation storage between the 3x3 layers + bf16 products on the training loop\'s kernels (k_mp_conv3x3_*), f32 accumulate, '
+                                        'f32 1x1 / k2s2 layers, PFN, fusion, decode, NMS')):
+                set_algo(mode)
+                got_pred, got_maps = plain_forward()
+                errs = {}
+                for k, v in ref_maps.items():
+                    scale = float(v.abs().max())
+                    errs[k] = {'max_abs_err': round(float((got_maps[k] - v).abs().max()), 6), 'map_abs_max': round(scale, 4)}
+                from helpers import match_boxes
+                matched = total = 0
+                for pa, pb in zip(ref_pred, got_pred):
+                    n_, _w = match_boxes(pa['pred_boxes'].cpu().numpy(), pa['pred_scores'].cpu().numpy(), pb['pred_boxes'].cpu().numpy(),
+                                         pb['pred_scores'].cpu().numpy(), tol=1e-3)
+                    matched += n_
+                    total += pa['pred_boxes'].shape[0]
+                for _ in range(args.warmup):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                alt = time.perf_counter() - t1
+                line['optin_' + mode] = {'value': round(batch * args.steps / alt, 3), 'unit': 'frames/s', 'ms_per_step': round(1e3 * alt / args.steps, 4),
+                                         'head_map_errors_vs_this_runs_fp32_maps': errs,
+                                         'final_boxes_matching_fp32_within_1e-3': '%d of %d' % (matched, total),
+                                         'note': 'NOT the headline, batch by batch on one stream: ' + note + '; enable with PCP_CONV_ALGO=' + mode}
+            set_algo('auto')
         if not args.no_cpu_baseline and world == 1:                    # rank 0 at N = 1 only (the contract); N > 1 lines carry null
             if args.config == 'lately6':
                 line['cpu_baseline'] = cpu_baseline_lately(car_cfg, car_state, cfg, state, lately_frames[0])

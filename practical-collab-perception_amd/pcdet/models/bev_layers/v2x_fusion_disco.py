@@ -87,7 +87,11 @@ class V2XMidFusionDisco(PackedModule):
                     b3=b3.float().reshape(1).contiguous())
 
     def _compress(self, pk, x_nhwc, out=None):
-        return pk['c1'].run(pk['c0'].run(x_nhwc), out=out)
+        h = pk['c0'].run(x_nhwc)
+        if out is None:
+            # a compressed map is what goes on the wire and into the fp32 warp: float32 whatever precision the convolutions ran in
+            out = torch.empty(tuple(h.shape[:3]) + (pk['c1'].cout,), dtype=torch.float32, device=h.device)
+        return pk['c1'].run(h, out=out)
 
     def compress_maps(self, bev_img_nchw):
         """the shared compressor on one agent's (B', 384, H, W) map -> (B', H, W, cc) NHWC (eval): what a remote GPU sends"""
@@ -155,6 +159,7 @@ class V2XMidFusionDisco(PackedModule):
             ops.disco_weight_fuse([stack[a] for a in range(n_maps)], wf['w1'], wf['b1'], wf['w2'], wf['b2'], wf['w3'], wf['b3'], self.cc, fused)
         else:
             ops.softmax_fuse([stack[a] for a in range(n_maps)], wbuf, self.cc, fused)
-        out = pk['d1'].run(pk['d0'].run(fused))
+        # the published map stays float32 also under PCP_CONV_ALGO=bf16 (the sharded detector and the heads read it as float)
+        out = pk['d1'].run(pk['d0'].run(fused), out=torch.empty((B, H, W, pk['d1'].cout), dtype=torch.float32, device=dev))
         batch_dict['spatial_features_2d'] = ops.nchw_view(out)
         return batch_dict

@@ -126,6 +126,8 @@ class CenterHead(PackedModule):
         buf = torch.zeros((B, H, W, ld), dtype=torch.float32, device=x.device)
         if 'stage1' in entry:
             mid = entry['stage1'].run(x)
+            if mid.dtype != torch.float32:          # opt-in bf16 arithmetic (PCP_CONV_ALGO=bf16): the grouped final convs read fp32
+                mid = mid.float()
             if 'stage2_grouped' in entry:
                 wg, bg, goffs = entry['stage2_grouped']
                 ops.conv3x3_grouped_small(mid, wg, bg, goffs, buf)

@@ -24,6 +24,14 @@ def _need_cuda(*tensors):
             raise _lib.PcpError('the HIP hot path needs CUDA/ROCm tensors (got a %s tensor); no CPU fallback exists' % t.device)
 
 
+def _need_f32(what, *tensors):
+    """the fp32 kernels read their maps as float: a bf16 tensor (an output of the bf16 loop, include/pcp_hip_mp.h) handed to one of them
+    would be read past its end"""
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.PcpError('%s reads float32 maps, got %s (cast the bf16 activation first)' % (what, t.dtype))
+
+
 def _zeros_views(device, specs):
     """several zero-initialised output tensors carved out of ONE allocation (one fill launch instead of one per tensor).
     specs: [(shape, dtype)], all 4-byte dtypes; every view starts 16-byte aligned."""
@@ -145,6 +153,7 @@ def _chan_ptr(t, ch_off):
 def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None, in_ch_off=0, out_ch_off=0):
     """x: (B, H, W, ld_in) float32 NHWC.  out: (B, Ho, Wo, ld_out) or None (allocated with ld_out = cout)."""
     _need_cuda(x, packed, bias, out)
+    _need_f32('pcp_conv3x3', x, out)
     L = _lib.load()
     B, H, W, ld_in = x.shape
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
@@ -320,6 +329,7 @@ def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, i
     """mode PW_PLAIN: x (..., ld_in) rows; PW_SPACE2DEPTH / PW_DEPTH2SPACE: x (B, H, W, ld_in).
     PLAIN extras: x2 supplies contraction channels [k_split, cin) (a cat without the copy); residual is added last."""
     _need_cuda(x, packed, bias, out, x2, residual)
+    _need_f32('pcp_pointwise', x, out, x2, residual)
     L = _lib.load()
     ld_in = x.shape[-1]
     if mode == _lib.PW_PLAIN:
@@ -444,6 +454,7 @@ def boxes_bev_pairwise(a, b, mode):
 def warp_nearest(src, dst, theta, channels, accumulate=False, src_ch_off=0, dst_ch_off=0):
     """src, dst: (H, W, ld) NHWC single-frame maps; theta: 6 python floats (row-major 2x3)."""
     _need_cuda(src, dst)
+    _need_f32('pcp_warp_nearest', src, dst)
     L = _lib.load()
     H, W, ld_s = src.shape
     th = (ctypes.c_float * 6)(*[float(v) for v in theta])
@@ -458,6 +469,7 @@ def warp_nearest_batch(jobs, channels, accumulate=False):
         return
     L = _lib.load()
     _need_cuda(*[t for s_, d_, _t in jobs for t in (s_, d_)])
+    _need_f32('pcp_warp_nearest_batch', *[t for s_, d_, _t in jobs for t in (s_, d_)])
     H, W, ld_s = jobs[0][0].shape
     ld_d = jobs[0][1].shape[2]
     for s_, d_, _t in jobs:
@@ -472,6 +484,7 @@ def warp_nearest_batch(jobs, channels, accumulate=False):
 def softmax_fuse(maps, weights, channels, out):
     """maps: list of (B, H, W, ld_map) tensors (same ld); weights: (B, H, W, ld_w) logits, column a <-> maps[a]."""
     _need_cuda(weights, out, *maps)
+    _need_f32('pcp_softmax_fuse', weights, out, *maps)
     L = _lib.load()
     n = len(maps)
     arr = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
@@ -485,6 +498,7 @@ def disco_weight_fuse(maps, w1, b1, w2, b2, w3, b3, channels, out, logits=None):
     """the DiscoNet pixel weightor + softmax over the maps + weighted sum as one launch (include/pcp_hip.h: pcp_disco_weight_fuse).
     maps: list of (..., ld_map) tensors sharing one pixel stride, maps[0] = ego; BN-folded float32 weights; out (..., ld_out)."""
     _need_cuda(w1, b1, w2, b2, w3, b3, out, logits, *maps)
+    _need_f32('pcp_disco_weight_fuse', out, logits, *maps)
     L = _lib.load()
     n = len(maps)
     arr = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
