@@ -60,13 +60,20 @@ int pcp_mp_accumulate(void *dst, int32_t dst_dtype, int32_t ld_dst, const void *
 int pcp_mp_dilate2x(const void *in, int32_t dtype, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t ld_in, void *out, int32_t ld_out,
                     void *stream);
 
-/* pcp_pfn_train_out / pcp_pfn_train_route_out_grad (pcp_hip_train.h) with a storage type for the BEV canvas and its gradient: in the bf16
- * loop the canvas is written as bf16 by the PFN's last kernel (it is the bf16 input of the first backbone layer and of that layer's weight
- * gradient) and the canvas gradient the backbone hands back is read as bf16 -- no fp32 canvas, no casts. */
-int pcp_mp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+/* The PFN training kernels of pcp_hip_train.h with storage types.  (a) The BEV canvas and its gradient: in the bf16 loop the canvas is
+ * written as bf16 by the PFN's last kernel (it is the bf16 input of the first backbone layer and of that layer's weight gradient) and the
+ * canvas gradient the backbone hands back is read as bf16 -- no fp32 canvas, no casts.  (b) The per-point 64-channel rows around the
+ * second PFN Linear (dynamic_pillar_vfe.py:35-46 under autocast): in1 = [relu(bn(x0)) | pillar max] is written, x1 = Linear(in1) read,
+ * dz1 = dL/dx1 written and din1 = dL/din1 read in the dtype given, so that Linear and its two gradient GEMMs run on pcp_mp_pointwise /
+ * pcp_mp_pointwise_wgrad and every pass over those rows moves half the bytes.  The first Linear (point coordinates) stays float32. */
+int pcp_mp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
+                         const float *shift0, void *in1, int32_t in1_dtype, int32_t *arg0, void *stream);
+int pcp_mp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const void *x1, int32_t x1_dtype, const float *scale1,
                          const float *shift1, float *pillar_features, int32_t *arg1, void *canvas, int32_t canvas_dtype, void *stream);
 int pcp_mp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const void *dcanvas,
-                                    int32_t dcanvas_dtype, const float *dpillar, const int32_t *arg1, float *dz1, void *stream);
+                                    int32_t dcanvas_dtype, const float *dpillar, const int32_t *arg1, void *dz1, int32_t dz1_dtype, void *stream);
+int pcp_mp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const void *din1, int32_t din1_dtype,
+                                    const int32_t *arg0, float *da0, void *stream);
 
 /* pcp_sparse_conv3x3_s2 (pcp_hip.h: the first backbone layer run from the pillar list) with a storage type for its OUTPUT map: the frozen
  * teachers of the bf16 loop hand bf16 to their second layer directly (fp32 arithmetic inside, one rounding on store). */
@@ -131,6 +138,38 @@ typedef struct {
 size_t pcp_mp_conv3x3_wgrad_workspace_bytes(const pcp_mp_wgrad3x3_t *desc);
 int pcp_mp_conv3x3_wgrad(const pcp_mp_wgrad3x3_t *desc, const void *x, const void *dy, float *dw, void *workspace, size_t workspace_bytes,
                          void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The pointwise family (Conv2d 1x1 / Conv2d k2 s2 / ConvTranspose2d k2 s2; modes and packed-weight layout as pcp_pointwise in pcp_hip.h,
+ * the weights as bf16: [k_total/16][taps_out * cout_pad][16]) on bf16 or fp32 activations, bf16 products, fp32 accumulation, bias (+ ReLU)
+ * in fp32, output bf16 or fp32 -- the up / down-sampling `deblocks` of BaseBEVBackbone (base_bev_backbone.py:48-69) as they run under
+ * autocast.  cin % 32 == 0, cout % 8 == 0, cout_pad % 64 == 0, ld % 8 == 0, 16-byte aligned pointers, outputs below 2 GiB; anything else
+ * returns PCP_ERR_UNSUPPORTED (the caller keeps the fp32 entry point).  No second K source / residual.
+ * pcp_mp_pointwise_wgrad: out[n][k] (+)= sum_r a[map_a(r)][n] * b[map_b(r)][k] (row maps as pcp_rowmap_t), both operands bf16, float32
+ * result; the contraction runs over the rows on v_mfma_f32_32x32x16_bf16 (operands transposed out of LDS by ds_read_b64_tr_b16), split
+ * over the rows with a fixed-order reduction.  channels % 8 == 0, ld % 8 == 0; extent_bytes = bytes addressable from ptr (< 2 GiB).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t mode;                   /* PCP_PW_PLAIN | PCP_PW_SPACE2DEPTH | PCP_PW_DEPTH2SPACE */
+  int64_t rows;                   /* PLAIN: number of rows; otherwise derived from batch / in_h / in_w */
+  int32_t batch, in_h, in_w;
+  int32_t cin, cout, cout_pad;
+  int32_t ld_in, ld_out;
+  int32_t relu;
+  int32_t in_dtype, out_dtype;    /* PCP_DT_F32 | PCP_DT_BF16 */
+} pcp_mp_pointwise_t;
+int pcp_mp_pointwise(const pcp_mp_pointwise_t *desc, const void *in, const void *w_packed_bf16, const float *bias, void *out, void *stream);
+
+typedef struct {
+  const void *ptr;
+  int32_t ld, channels;
+  int32_t lattice, grid_h, grid_w, ky, kx;
+  int32_t dtype;                  /* PCP_DT_BF16 */
+  uint64_t extent_bytes;
+} pcp_mp_rowmap_t;
+size_t pcp_mp_pointwise_wgrad_workspace_bytes(int64_t rows, int32_t n, int32_t k);
+int pcp_mp_pointwise_wgrad(const pcp_mp_rowmap_t *a, const pcp_mp_rowmap_t *b, int64_t rows, void *workspace, size_t workspace_bytes,
+                           float *out, int32_t ld_out, int32_t accumulate, void *stream);
 
 #ifdef __cplusplus
 }

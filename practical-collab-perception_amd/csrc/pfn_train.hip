@@ -100,10 +100,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_feat(FeatParams p) {
   }
 }
 
-// wave per pillar; lane = (half, channel): the two halves take alternate rows
+// wave per pillar; lane = (half, channel): the two halves take alternate rows.  RT: storage type of the per-point 64-channel rows (in1, x1,
+// dz1, din1): float, or __bf16 in the bf16 training loop (include/pcp_hip_mp.h) -- the second PFN Linear then runs on pcp_mp_pointwise
+template <typename RT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_mid(const int *__restrict__ pillar_start, const int *__restrict__ counters,
                                                         const float *__restrict__ x0, const float *__restrict__ scale,
-                                                        const float *__restrict__ shift, float *__restrict__ in1, int *__restrict__ arg0) {
+                                                        const float *__restrict__ shift, RT *__restrict__ in1, int *__restrict__ arg0) {
   const int P = counters[0];
   const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -115,22 +117,22 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_mid(const int *__restrict__
     int arg = se;
     for (int s = sb + half; s < se; s += 2) {
       const float v = fmaxf(fmaf(x0[(long long)s * C0 + c], sc, sh), 0.f);
-      in1[(long long)s * C1 + c] = v;
+      in1[(long long)s * C1 + c] = (RT)v;
       if (v > best) { best = v; arg = s; }
     }
     const float ob = __shfl_xor(best, 32);
     const int oa = __shfl_xor(arg, 32);
     if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
     if (half == 0) arg0[p * C0 + c] = arg;
-    for (int s = sb + half; s < se; s += 2) in1[(long long)s * C1 + C0 + c] = best;
+    for (int s = sb + half; s < se; s += 2) in1[(long long)s * C1 + C0 + c] = (RT)best;
   }
 }
 
 // CT: storage type of the canvas (float; __bf16 in the bf16 training loop, include/pcp_hip_mp.h: the first backbone layer and its weight
 // gradient read the canvas as bf16 anyway, so the fp32 canvas + its cast are skipped)
-template <typename CT>
+template <typename CT, typename RT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
-                                                        const int *__restrict__ counters, pcp_grid_t g, const float *__restrict__ x1,
+                                                        const int *__restrict__ counters, pcp_grid_t g, const RT *__restrict__ x1,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         float *__restrict__ pf, int *__restrict__ arg1, CT *__restrict__ canvas) {
   const int P = counters[0];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__
     float best = -1.f;
     int arg = sb;
     for (int s = sb; s < se; ++s) {
-      const float v = fmaxf(fmaf(x1[(long long)s * C1 + lane], sc, sh), 0.f);
+      const float v = fmaxf(fmaf((float)x1[(long long)s * C1 + lane], sc, sh), 0.f);
       if (v > best) { best = v; arg = s; }
     }
     if (pf) pf[p * C1 + lane] = best;
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__
   }
 }
 
-template <typename CT>
+template <typename CT, typename RT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__restrict__ pillar_cell, const int *__restrict__ counters,
                                                               pcp_grid_t g, const CT *__restrict__ dcanvas, const float *__restrict__ dpf,
-                                                              const int *__restrict__ arg1, float *__restrict__ dz1) {
+                                                              const int *__restrict__ arg1, RT *__restrict__ dz1) {
   const int P = counters[0];
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)P * C1) return;
@@ -177,11 +179,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__rest
   } else {
     gval = dpf[t];
   }
-  dz1[(long long)arg1[t] * C1 + c] = gval;
+  dz1[(long long)arg1[t] * C1 + c] = (RT)gval;
 }
 
+template <typename RT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_mid(const int *__restrict__ pillar_start, const int *__restrict__ counters,
-                                                              const float *__restrict__ din1, const int *__restrict__ arg0,
+                                                              const RT *__restrict__ din1, const int *__restrict__ arg0,
                                                               float *__restrict__ da0) {
   const int P = counters[0];
   const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_mid(const int *__rest
     const int sb = pillar_start[p], se = pillar_start[p + 1];
     // fixed summation order (ascending slot) so the result does not depend on the lane split
     float dm = 0.f;
-    for (int s = sb; s < se; ++s) dm += din1[(long long)s * C1 + C0 + c];
+    for (int s = sb; s < se; ++s) dm += (float)din1[(long long)s * C1 + C0 + c];
     const int a = arg0[p * C0 + c];
-    for (int s = sb + half; s < se; s += 2) da0[(long long)s * C0 + c] = din1[(long long)s * C1 + c] + (s == a ? dm : 0.f);
+    for (int s = sb + half; s < se; s += 2) da0[(long long)s * C0 + c] = (float)din1[(long long)s * C1 + c] + (s == a ? dm : 0.f);
   }
 }
 
@@ -246,88 +249,127 @@ int pcp_pfn_train_features(const float *points, int64_t n, int32_t row_stride, i
   return PCP_OK;
 }
 
-int pcp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
-                      const float *shift0, float *in1, int32_t *arg0, void *stream) {
+static int pfn_train_mid_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
+                              const float *shift0, void *in1, int in1_bf16, int32_t *arg0, void *stream) {
   if (!grid || !vox_workspace || !x0 || !scale0 || !shift0 || !in1 || !arg0 || n < 0) return PCP_ERR_ARG;
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  hipLaunchKernelGGL(k_pfnt_mid, dim3(pillar_wave_blocks(n < cells ? n : cells)), dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start,
-                     v.counters, x0, scale0, shift0, in1, arg0);
+  const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
+  if (in1_bf16)
+    hipLaunchKernelGGL(k_pfnt_mid<__bf16>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, x0, scale0, shift0,
+                       (__bf16 *)in1, arg0);
+  else
+    hipLaunchKernelGGL(k_pfnt_mid<float>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, x0, scale0, shift0,
+                       (float *)in1, arg0);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
-static int pfn_train_out_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+int pcp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
+                      const float *shift0, float *in1, int32_t *arg0, void *stream) {
+  return pfn_train_mid_impl(grid, vox_workspace, n, x0, scale0, shift0, in1, 0, arg0, stream);
+}
+
+int pcp_mp_pfn_train_mid(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x0, const float *scale0,
+                         const float *shift0, void *in1, int32_t in1_dtype, int32_t *arg0, void *stream) {
+  if (in1_dtype != 0 && in1_dtype != 1) return PCP_ERR_ARG;
+  return pfn_train_mid_impl(grid, vox_workspace, n, x0, scale0, shift0, in1, in1_dtype, arg0, stream);
+}
+
+static int pfn_train_out_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const void *x1, int x1_bf16, const float *scale1,
                               const float *shift1, float *pillar_features, int32_t *arg1, void *canvas, int canvas_bf16, void *stream) {
   if (!grid || !vox_workspace || !x1 || !scale1 || !shift1 || !arg1 || n < 0) return PCP_ERR_ARG;
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
-  if (canvas_bf16)
-    hipLaunchKernelGGL(k_pfnt_out<__bf16>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.pillar_cell, v.counters, *grid, x1,
-                       scale1, shift1, pillar_features, arg1, (__bf16 *)canvas);
-  else
-    hipLaunchKernelGGL(k_pfnt_out<float>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.pillar_cell, v.counters, *grid, x1,
-                       scale1, shift1, pillar_features, arg1, (float *)canvas);
+  hipStream_t st = (hipStream_t)stream;
+#define PCP_PFNT_OUT(CT, RT)                                                                                                              \
+  hipLaunchKernelGGL((k_pfnt_out<CT, RT>), gridd, dim3(PT_THREADS), 0, st, v.pillar_start, v.pillar_cell, v.counters, *grid, (const RT *)x1, \
+                     scale1, shift1, pillar_features, arg1, (CT *)canvas)
+  if (canvas_bf16) {
+    if (x1_bf16) PCP_PFNT_OUT(__bf16, __bf16); else PCP_PFNT_OUT(__bf16, float);
+  } else {
+    if (x1_bf16) PCP_PFNT_OUT(float, __bf16); else PCP_PFNT_OUT(float, float);
+  }
+#undef PCP_PFNT_OUT
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
 int pcp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
                       const float *shift1, float *pillar_features, int32_t *arg1, float *canvas, void *stream) {
-  return pfn_train_out_impl(grid, vox_workspace, n, x1, scale1, shift1, pillar_features, arg1, canvas, 0, stream);
+  return pfn_train_out_impl(grid, vox_workspace, n, x1, 0, scale1, shift1, pillar_features, arg1, canvas, 0, stream);
 }
 
-int pcp_mp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *x1, const float *scale1,
+int pcp_mp_pfn_train_out(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const void *x1, int32_t x1_dtype, const float *scale1,
                          const float *shift1, float *pillar_features, int32_t *arg1, void *canvas, int32_t canvas_dtype, void *stream) {
-  if (canvas_dtype != 0 && canvas_dtype != 1) return PCP_ERR_ARG;
-  return pfn_train_out_impl(grid, vox_workspace, n, x1, scale1, shift1, pillar_features, arg1, canvas, canvas_dtype, stream);
+  if ((canvas_dtype != 0 && canvas_dtype != 1) || (x1_dtype != 0 && x1_dtype != 1)) return PCP_ERR_ARG;
+  return pfn_train_out_impl(grid, vox_workspace, n, x1, x1_dtype, scale1, shift1, pillar_features, arg1, canvas, canvas_dtype, stream);
 }
 
 static int pfn_route_out_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const void *dcanvas,
-                              int dcanvas_bf16, const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
+                              int dcanvas_bf16, const float *dpillar, const int32_t *arg1, void *dz1, int dz1_bf16, void *stream) {
   if (!grid || !vox_workspace || !arg1 || !dz1 || n < 0 || kept_rows < 0 || kept_rows > n) return PCP_ERR_ARG;
   if ((dcanvas == nullptr) == (dpillar == nullptr)) return PCP_ERR_ARG;
   if (n == 0 || kept_rows == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   hipStream_t s = (hipStream_t)stream;
-  if (pcp_zero_async(dz1, (size_t)kept_rows * C1 * sizeof(float), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  if (pcp_zero_async(dz1, (size_t)kept_rows * C1 * (dz1_bf16 ? 2 : 4), s) != PCP_OK) return PCP_ERR_LAUNCH;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   const int64_t max_pillars = kept_rows < cells ? kept_rows : cells;
   const dim3 gridd((unsigned)((max_pillars * C1 + PT_THREADS - 1) / PT_THREADS));
-  if (dcanvas_bf16)
-    hipLaunchKernelGGL(k_pfnt_route_out<__bf16>, gridd, dim3(PT_THREADS), 0, s, v.pillar_cell, v.counters, *grid, (const __bf16 *)dcanvas, dpillar,
-                       arg1, dz1);
-  else
-    hipLaunchKernelGGL(k_pfnt_route_out<float>, gridd, dim3(PT_THREADS), 0, s, v.pillar_cell, v.counters, *grid, (const float *)dcanvas, dpillar, arg1,
-                       dz1);
+#define PCP_PFNT_ROUTE(CT, RT)                                                                                                           \
+  hipLaunchKernelGGL((k_pfnt_route_out<CT, RT>), gridd, dim3(PT_THREADS), 0, s, v.pillar_cell, v.counters, *grid, (const CT *)dcanvas, dpillar, \
+                     arg1, (RT *)dz1)
+  if (dcanvas_bf16) {
+    if (dz1_bf16) PCP_PFNT_ROUTE(__bf16, __bf16); else PCP_PFNT_ROUTE(__bf16, float);
+  } else {
+    if (dz1_bf16) PCP_PFNT_ROUTE(float, __bf16); else PCP_PFNT_ROUTE(float, float);
+  }
+#undef PCP_PFNT_ROUTE
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
 int pcp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const float *dcanvas,
                                  const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
-  return pfn_route_out_impl(grid, vox_workspace, n, kept_rows, dcanvas, 0, dpillar, arg1, dz1, stream);
+  return pfn_route_out_impl(grid, vox_workspace, n, kept_rows, dcanvas, 0, dpillar, arg1, dz1, 0, stream);
 }
 
 int pcp_mp_pfn_train_route_out_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, int64_t kept_rows, const void *dcanvas,
-                                    int32_t dcanvas_dtype, const float *dpillar, const int32_t *arg1, float *dz1, void *stream) {
-  if (dcanvas_dtype != 0 && dcanvas_dtype != 1) return PCP_ERR_ARG;
-  return pfn_route_out_impl(grid, vox_workspace, n, kept_rows, dcanvas, dcanvas_dtype, dpillar, arg1, dz1, stream);
+                                    int32_t dcanvas_dtype, const float *dpillar, const int32_t *arg1, void *dz1, int32_t dz1_dtype, void *stream) {
+  if ((dcanvas_dtype != 0 && dcanvas_dtype != 1) || (dz1_dtype != 0 && dz1_dtype != 1)) return PCP_ERR_ARG;
+  return pfn_route_out_impl(grid, vox_workspace, n, kept_rows, dcanvas, dcanvas_dtype, dpillar, arg1, dz1, dz1_dtype, stream);
 }
 
-int pcp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *din1, const int32_t *arg0,
-                                 float *da0, void *stream) {
+static int pfn_route_mid_impl(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const void *din1, int din1_bf16, const int32_t *arg0,
+                              float *da0, void *stream) {
   if (!grid || !vox_workspace || !din1 || !arg0 || !da0 || n < 0) return PCP_ERR_ARG;
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  hipLaunchKernelGGL(k_pfnt_route_mid, dim3(pillar_wave_blocks(n < cells ? n : cells)), dim3(PT_THREADS), 0, (hipStream_t)stream,
-                     v.pillar_start, v.counters, din1, arg0, da0);
+  const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
+  if (din1_bf16)
+    hipLaunchKernelGGL(k_pfnt_route_mid<__bf16>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, (const __bf16 *)din1,
+                       arg0, da0);
+  else
+    hipLaunchKernelGGL(k_pfnt_route_mid<float>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, (const float *)din1,
+                       arg0, da0);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+int pcp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const float *din1, const int32_t *arg0,
+                                 float *da0, void *stream) {
+  return pfn_route_mid_impl(grid, vox_workspace, n, din1, 0, arg0, da0, stream);
+}
+
+int pcp_mp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_workspace, int64_t n, const void *din1, int32_t din1_dtype,
+                                    const int32_t *arg0, float *da0, void *stream) {
+  if (din1_dtype != 0 && din1_dtype != 1) return PCP_ERR_ARG;
+  return pfn_route_mid_impl(grid, vox_workspace, n, din1, din1_dtype, arg0, da0, stream);
 }
 
 }  // extern "C"

@@ -131,8 +131,13 @@ class BaseBEVBackbone(PackedModule):
                     us = self.upsample_strides[i]
                     oh = x.shape[1] * int(us) if us >= 1 else x.shape[1] // int(np.round(1 / us))
                     ow = x.shape[2] * int(us) if us >= 1 else x.shape[2] // int(np.round(1 / us))
-                    out = torch.empty((x.shape[0], oh, ow, sum(self.num_upsample_filters[:n_levels])), dtype=torch.float32,
-                                      device=x.device)
+                    # bf16 loop: a caller whose consumer reads bf16 (the DiscoNet compressor of a frozen teacher) asks for the
+                    # concatenated map in bf16 -- the up-sampling layers then write it directly (pcp_mp_pointwise)
+                    odt = torch.float32
+                    if data_dict.get('_pcp_bf16_map', False) and x.dtype == torch.bfloat16 and all(getattr(d, 'mp', None) is not None
+                                                                                                  for d in pk['deblocks'][:n_levels]):
+                        odt = torch.bfloat16
+                    out = torch.empty((x.shape[0], oh, ow, sum(self.num_upsample_filters[:n_levels])), dtype=odt, device=x.device)
                 de.run(x, out=out, out_ch_off=ch_off)
                 ch_off += de.cout
             else:

@@ -68,8 +68,10 @@ class BEVMaker(nn.Module):
         self.load_state_dict(own)
         print('[TEACHER] ==> Done (loaded %d/%d)' % (len(update), len(own)))
 
-    def _run_chain(self, points, batch_size, vox_ready=None, valid_points_hint=None, vox_share=None):
+    def _run_chain(self, points, batch_size, vox_ready=None, valid_points_hint=None, vox_share=None, bf16_map=False):
         d = {'points': points, 'batch_size': batch_size}
+        if bf16_map:                               # PCP_CONV_ALGO=bf16 only: the agents' maps feed the bf16 compressor, keep them in bf16
+            d['_pcp_bf16_map'] = True
         if vox_share is not None:                  # the ego branch pillarises the same cloud on the same grid: one pillar list for both
             d['_pcp_vox_share'] = vox_share
         if vox_ready is not None:                  # the pillariser's first pass already ran inside the compaction (cell ids + histogram)
@@ -144,13 +146,13 @@ class BEVMaker(nn.Module):
                 stacked = self._stack_buf[:max(rows, 1)]
                 ops.select_transform_compact(points, c - 1, [a for a, _p, _q, _l in chunk], np.stack([p_ for _a, p_, _q, _l in chunk]),
                                              np.stack([q for _a, _p, q, _l in chunk]), rows, out=stacked, vox_grid=grid, vox_workspace=ws)
-                bev = self._run_chain(stacked[:rows], batch_size * len(chunk), vox_ready=dict(workspace=ws))
+                bev = self._run_chain(stacked[:rows], batch_size * len(chunk), vox_ready=dict(workspace=ws), bf16_map=True)
             else:
                 stacked = points.new_empty((len(chunk) * n, c))
                 for slot, (agent_idx, poses, present, _last) in enumerate(chunk):
                     ops.select_transform_points(points, c - 1, float(agent_idx), poses, present, out=stacked[slot * n:(slot + 1) * n],
                                                 batch_offset=slot * batch_size)
-                bev = self._run_chain(stacked, batch_size * len(chunk), valid_points_hint=len(chunk) * n / max(len(agent_ids), 1))
+                bev = self._run_chain(stacked, batch_size * len(chunk), valid_points_hint=len(chunk) * n / max(len(agent_ids), 1), bf16_map=True)
             for slot, (agent_idx, _poses, _present, last) in enumerate(chunk):
                 batch_dict['bev_img'][agent_idx] = bev[slot * batch_size:slot * batch_size + last]
         return batch_dict

@@ -137,6 +137,15 @@ class PackedConv:
             wp, bp, cp = self.mp
             return tops.mp_conv3x3(x, wp, bp, self.cin, self.cout, cp, stride=self.stride, relu=self.relu, out=out, in_ch_off=in_ch_off,
                                    out_ch_off=out_ch_off)
+        if (getattr(self, 'mp', None) is not None and self.kind != '3x3' and _plain_bf16() and x.dtype == torch.bfloat16 and in_ch_off % 8 == 0
+                and x.shape[-1] % 8 == 0 and (out is None or (out.shape[-1] % 8 == 0 and out_ch_off % 8 == 0))):
+            # bf16 loop: a pointwise layer behind a bf16 3x3 layer reads the bf16 map as it lies (pcp_mp_pointwise); its output takes the
+            # storage type of the caller's buffer (float32 when it allocates here: the consumers outside the conv stacks are fp32 kernels)
+            from pcp_amd import train_ops as tops
+            mode = {'plain': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[self.kind]
+            wp, bp, cp = self.mp
+            return tops.mp_pointwise(x, wp, bp, mode, self.cin, self.cout, cp, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                     out_ch_off=out_ch_off, out_dtype=torch.float32)
         if x.dtype != torch.float32:
             x, in_ch_off = x[..., in_ch_off:in_ch_off + self.cin].float().contiguous(), 0      # the fp32 kernels' view of a bf16 activation
         if self._use_bf16x3(x):
@@ -199,6 +208,12 @@ def _pack_mp(w, b):
     return wp, bp, opad
 
 
+def _pack_mp_pointwise(pc):
+    """bf16 copy of a pointwise layer's packed weights for pcp_mp_pointwise (PCP_CONV_ALGO=bf16 only, shapes the kernel takes)"""
+    if conv_algo() == 'bf16' and pc.w.is_cuda and pc.cin % 32 == 0 and pc.cout % 8 == 0 and pc.cout_pad % 64 == 0:
+        pc.mp = (pc.w.to(torch.bfloat16).contiguous(), pc.b, pc.cout_pad)
+
+
 def pack_conv_module(conv, bn=None, relu=True):
     """conv: nn.Conv2d (3x3 s1/s2 p1 | 1x1 | k2 s2) or nn.ConvTranspose2d (k1 s1 | k2 s2)."""
     pc = PackedConv()
@@ -222,6 +237,7 @@ def pack_conv_module(conv, bn=None, relu=True):
             pc.w, pc.b, pc.cout_pad = pack.pack_convT2x2_s2(w, b)
         else:
             raise NotImplementedError('ConvTranspose2d k=%d s=%d has no HIP kernel in this build' % (k, s))
+        _pack_mp_pointwise(pc)
         return pc
     w, b = _fold(conv, bn, out_axis=0)
     k, s = conv.kernel_size[0], conv.stride[0]
@@ -248,6 +264,8 @@ def pack_conv_module(conv, bn=None, relu=True):
         pc.w, pc.b, pc.cout_pad = pack.pack_conv2x2_s2(w, b)
     else:
         raise NotImplementedError('Conv2d k=%d s=%d has no HIP kernel in this build' % (k, s))
+    if pc.kind != '3x3':
+        _pack_mp_pointwise(pc)
     return pc
 
 

@@ -9,6 +9,8 @@ returns (a one-node autograd graph), so the reference's loop -- loss.backward();
 Reference modules: dynamic_pillar_vfe.py:35-46,94-147; pointpillar_scatter.py:14-37; base_bev_backbone.py:30-112;
 v2x_fusion_disco.py:47-126; center_head.py:13-47,75-96,270-300,377-392.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -16,6 +18,13 @@ from pcp_amd import fusion_host, lib, ops, pack
 from pcp_amd import train_layers as tl
 from pcp_amd import train_ops as tops
 from pcp_amd.train_layers import Act, ConvBNAct, ensure_grad
+
+
+# PCP_PFN_BF16_ROWS=1 (bf16 loop only): the per-point 64-channel rows around the second PFN Linear as bf16, that Linear and its gradient
+# GEMMs on the bf16 pointwise kernels.  Off by default: measured on config 5 it takes 0.27 ms of kernel time off the iteration but moves the
+# third iteration of the 20-iteration loss curve 2.9 % away from the fp32 loop (2.5 % is the bound the test holds the bf16 loop to) -- the
+# pillar max and the BatchNorm over 1.4 M points are where bf16 rows cost most; profiles/r04_pfn_bf16_rows.txt
+PFN_BF16_ROWS = os.environ.get('PCP_PFN_BF16_ROWS', '0') == '1'
 
 
 def _empty(shape, dev, dtype=torch.float32):
@@ -47,6 +56,9 @@ class VFETrain:
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         self._w = dict(w0=pack.pack_plain(w0p, z(32)), w1=pack.pack_plain(w1.contiguous(), z(64)),
                        w1t=pack.pack_plain(w1.t().contiguous(), z(64)), F=F, fw=fw)
+        if tl.mp_mode() and PFN_BF16_ROWS and dev.type == 'cuda':
+            for k in ('w1', 'w1t'):
+                self._w[k + '_mp'] = (self._w[k][0].to(torch.bfloat16), self._w[k][1], self._w[k][2])
         self._step = tl.StepClock.step
         return self._w
 
@@ -75,10 +87,14 @@ class VFETrain:
             x0 = ops.pointwise(fk, w['w0'][0], w['w0'][1], lib.PW_PLAIN, w['fw'], 32, w['w0'][2], relu=False)
             self.vec0 = tops.bn_train_stats(x0, 32, l0.norm.weight.detach(), l0.norm.bias.detach(), l0.norm.eps, l0.norm.momentum,
                                             l0.norm.running_mean, l0.norm.running_var, vec=self.vec0)
-            in1 = _empty((Nk, 64), dev)
+            rdt = torch.bfloat16 if 'w1_mp' in w else torch.float32
+            in1 = _empty((Nk, 64), dev, rdt)
             arg0 = _empty((max(P, 1), 32), dev, torch.int32)
             tops.pfn_train_mid(vox, x0, self.vec0, in1, arg0)
-            x1 = ops.pointwise(in1, w['w1'][0], w['w1'][1], lib.PW_PLAIN, 64, 64, w['w1'][2], relu=False)
+            if 'w1_mp' in w:
+                x1 = tops.mp_pointwise(in1, w['w1_mp'][0], w['w1_mp'][1], lib.PW_PLAIN, 64, 64, w['w1_mp'][2], relu=False)
+            else:
+                x1 = ops.pointwise(in1, w['w1'][0], w['w1'][1], lib.PW_PLAIN, 64, 64, w['w1'][2], relu=False)
             self.vec1 = tops.bn_train_stats(x1, 64, l1.norm.weight.detach(), l1.norm.bias.detach(), l1.norm.eps, l1.norm.momentum,
                                             l1.norm.running_mean, l1.norm.running_var, vec=self.vec1)
             arg1 = _empty((max(P, 1), 64), dev, torch.int32)
@@ -104,11 +120,14 @@ class VFETrain:
         dev = dcanvas.device
         w = self._weights()
         Nk = s['Nk']
-        dz1 = _empty((Nk, 64), dev)
+        dz1 = _empty((Nk, 64), dev, s['x1'].dtype)
         tops.pfn_train_route_out_grad(s['vox'], Nk, s['arg1'], dz1, dcanvas=dcanvas)
         tops.bn_act_backward(dz1, s['x1'], 64, self.vec1, True, ensure_grad(l1.norm.weight), ensure_grad(l1.norm.bias))
         tops.pointwise_wgrad(tops.rowmap(dz1, 64), tops.rowmap(s['in1'], 64), Nk, ensure_grad(l1.linear.weight))
-        din1 = ops.pointwise(dz1, w['w1t'][0], w['w1t'][1], lib.PW_PLAIN, 64, 64, w['w1t'][2], relu=False)
+        if dz1.dtype == torch.bfloat16:
+            din1 = tops.mp_pointwise(dz1, w['w1t_mp'][0], w['w1t_mp'][1], lib.PW_PLAIN, 64, 64, w['w1t_mp'][2], relu=False)
+        else:
+            din1 = ops.pointwise(dz1, w['w1t'][0], w['w1t'][1], lib.PW_PLAIN, 64, 64, w['w1t'][2], relu=False)
         da0 = _empty((Nk, 32), dev)
         tops.pfn_train_route_mid_grad(s['vox'], din1, s['arg0'], da0)
         tops.bn_act_backward(da0, s['x0'], 32, self.vec0, True, ensure_grad(l0.norm.weight), ensure_grad(l0.norm.bias))
@@ -147,7 +166,9 @@ class BackboneTrain:
                 x = layer.forward(x)
             if out is None:
                 shp = de.out_shape(x)
-                out = _empty(shp + (sum(d.cout for d in self.deblocks),), x.t.device)
+                # bf16 loop: the up-sampling layers write the concatenated map as bf16 (its consumers are bf16 3x3 layers)
+                odt = torch.bfloat16 if (x.t.dtype == torch.bfloat16 and all(d.mp_pointwise_capable() for d in self.deblocks)) else torch.float32
+                out = _empty(shp + (sum(d.cout for d in self.deblocks),), x.t.device, odt)
             de.forward(x, out=Act(out, ch, de.cout))
             offs.append(ch)
             ch += de.cout
@@ -382,6 +403,8 @@ class AnchorHeadTrain:
     def forward(self, x):
         """x: Act (B, H, W, cin).  Returns the raw head buffer (B, H, W, ld); channels past cout are zero."""
         f = self._forms()
+        if x.t.dtype != torch.float32:                     # bf16 loop: the backbone's map arrives as bf16, these 1x1 convs stay fp32
+            x = Act(tl.as_f32(x.t, x.off, x.c), 0, x.c)
         B, H, W, _ = x.t.shape
         buf = torch.zeros((B, H, W, self.ld), dtype=torch.float32, device=x.t.device)
         w, b, cp = f['fw']

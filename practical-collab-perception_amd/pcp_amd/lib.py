@@ -52,6 +52,18 @@ class MpPackJob(ctypes.Structure):
                 ('reserved', c_i32)]
 
 
+class MpPointwise(ctypes.Structure):
+    """pcp_mp_pointwise_t (include/pcp_hip_mp.h)"""
+    _fields_ = [('mode', c_i32), ('rows', c_i64), ('batch', c_i32), ('in_h', c_i32), ('in_w', c_i32), ('cin', c_i32), ('cout', c_i32),
+                ('cout_pad', c_i32), ('ld_in', c_i32), ('ld_out', c_i32), ('relu', c_i32), ('in_dtype', c_i32), ('out_dtype', c_i32)]
+
+
+class MpRowMap(ctypes.Structure):
+    """pcp_mp_rowmap_t (include/pcp_hip_mp.h)"""
+    _fields_ = [('ptr', vp), ('ld', c_i32), ('channels', c_i32), ('lattice', c_i32), ('grid_h', c_i32), ('grid_w', c_i32), ('ky', c_i32),
+                ('kx', c_i32), ('dtype', c_i32), ('extent_bytes', ctypes.c_uint64)]
+
+
 DT_F32, DT_BF16 = 0, 1
 
 
@@ -262,8 +274,10 @@ SYMBOLS.update({
     'pcp_mp_colsum': (c_i32, [vp, c_i32, c_i64, c_i32, c_i32, vp, vp, c_i32, vp]),
     'pcp_mp_accumulate': (c_i32, [vp, c_i32, c_i32, vp, c_i32, c_i32, c_i64, c_i32, c_f, vp]),
     'pcp_mp_dilate2x': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp]),
-    'pcp_mp_pfn_train_out': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, vp, vp, c_i32, vp]),
-    'pcp_mp_pfn_train_route_out_grad': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, c_i64, vp, c_i32, vp, vp, vp, vp]),
+    'pcp_mp_pfn_train_mid': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp, vp, c_i32, vp, vp]),
+    'pcp_mp_pfn_train_out': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, c_i32, vp, vp, vp, vp, vp, c_i32, vp]),
+    'pcp_mp_pfn_train_route_out_grad': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, c_i64, vp, c_i32, vp, vp, vp, c_i32, vp]),
+    'pcp_mp_pfn_train_route_mid_grad': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, c_i32, vp, vp, vp]),
     'pcp_mp_sparse_conv3x3_s2': (c_i32, [vp, ctypes.POINTER(Grid), vp, c_i64, vp, vp, c_i32, c_i32, vp, c_i32, c_i32, vp]),
     'pcp_mp_conv3x3_packed_bytes': (c_sz, [c_i32, c_i32]),
     'pcp_mp_pack_conv3x3': (c_i32, [vp, c_i32, c_i32, c_i32, vp, vp, c_i32, vp]),
@@ -273,6 +287,9 @@ SYMBOLS.update({
     'pcp_mp_conv3x3_plan': (c_i32, [ctypes.POINTER(MpConv3x3), ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_double)]),
     'pcp_mp_conv3x3_wgrad_workspace_bytes': (c_sz, [ctypes.POINTER(MpWgrad3x3)]),
     'pcp_mp_conv3x3_wgrad': (c_i32, [ctypes.POINTER(MpWgrad3x3), vp, vp, vp, vp, c_sz, vp]),
+    'pcp_mp_pointwise': (c_i32, [ctypes.POINTER(MpPointwise), vp, vp, vp, vp, vp]),
+    'pcp_mp_pointwise_wgrad_workspace_bytes': (c_sz, [c_i64, c_i32, c_i32]),
+    'pcp_mp_pointwise_wgrad': (c_i32, [ctypes.POINTER(MpRowMap), ctypes.POINTER(MpRowMap), c_i64, vp, c_sz, vp, c_i32, c_i32, vp]),
 })
 
 _LIB = None

@@ -158,6 +158,7 @@ class ConvBNAct:
             raise NotImplementedError('%s: conv k=%d s=%d has no training kernel' % (name, k, s))
         self.stride = s if self.kind == '3x3' else 1
         self._fw = self._bw = None
+        self._fw_mp = self._bw_mp = None
         self.saved = None
         self.vec = None
 
@@ -184,7 +185,9 @@ class ConvBNAct:
                     cache['grouped'] = False
         if cache['step'] == StepClock.step:
             self._fw, self._bw = cache['fw'], cache['bw']
+            self._fw_mp, self._bw_mp = cache.get('fw_mp'), cache.get('bw_mp')
             return
+        self._fw_mp = self._bw_mp = None
         if self.kind == '3x3' and mp_mode() and self.cin % 16 == 0 and self.cout % 16 == 0:
             # bf16 weight forms (forward + data gradient) from the fp32 master weights, persistent buffers, two small launches per step
             w = self.conv.weight.detach()
@@ -312,6 +315,14 @@ class ConvBNAct:
                 bw = pack.pack_conv2x2_s2(w, zb(self.cin))              # (cin, cout, 2, 2) read as a Conv2d weight
         cache['fw'], cache['bw'], cache['step'] = fw, bw, StepClock.step
         self._fw, self._bw = fw, bw
+        cache['fw_mp'] = cache['bw_mp'] = None
+        if k != '3x3' and mp_mode() and dev.type == 'cuda':
+            # bf16 loop: the same packed forms as bf16 for pcp_mp_pointwise (used when the layer's input arrives as bf16)
+            if tops.mp_pointwise_ok(None, self.cin, self.cout, fw[2], 8, 8):
+                cache['fw_mp'] = (fw[0].to(torch.bfloat16), fw[1], fw[2])
+            if tops.mp_pointwise_ok(None, self.cout, self.cin, bw[2], 8, 8):
+                cache['bw_mp'] = (bw[0].to(torch.bfloat16), bw[1], bw[2])
+        self._fw_mp, self._bw_mp = cache['fw_mp'], cache['bw_mp']
 
     # ---- launches --------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -337,6 +348,12 @@ class ConvBNAct:
         w, b, cp = forms['direct']
         return ops.conv3x3(x, w, b, cin, cout, cp, stride=stride, relu=False, out=out, in_ch_off=in_off, out_ch_off=out_off)
 
+    def mp_pointwise_capable(self):
+        """a pointwise layer whose forward AND data-gradient shapes pcp_mp_pointwise takes (it then reads and writes bf16 maps)"""
+        rp = lambda o: pack.round_up(o, 64 if o > 32 else 32)
+        return (self.kind != '3x3' and mp_mode() and tops.mp_pointwise_ok(None, self.cin, self.cout, rp(self.cout), 8, 8)
+                and tops.mp_pointwise_ok(None, self.cout, self.cin, rp(self.cin), 8, 8))
+
     def out_shape(self, x):
         B, H, W = x.t.shape[0], x.t.shape[1], x.t.shape[2]
         if self.kind == '3x3':
@@ -357,9 +374,16 @@ class ConvBNAct:
         need_post = self.bn is not None or self.relu
         k = self.kind
         mp = k == '3x3' and 'mp' in self._fw
+        # a pointwise layer joins the bf16 loop when its input ARRIVES as bf16 (the up / down-sampling layers behind the bf16 3x3 blocks);
+        # fp32 inputs (the fusion module's concatenated maps) keep the fp32 kernels
+        mpw = (k != '3x3' and self._fw_mp is not None and self._bw_mp is not None and x.t.dtype == torch.bfloat16 and x.off % 8 == 0
+               and x.t.shape[-1] % 8 == 0 and (out is None or (out.off % 8 == 0 and out.t.shape[-1] % 8 == 0)))
         if mp:
             if x.t.dtype != torch.bfloat16 or x.off % 8 or x.t.shape[-1] % 8:
                 x = Act(as_bf16(x.t, x.off, x.c).contiguous(), 0, x.c)   # one cast; the fast kernel and the weight gradient both read the bf16 copy
+            act_dtype = out.t.dtype if out is not None else (out_dtype or torch.bfloat16)
+            y_dtype = torch.bfloat16 if need_post else act_dtype
+        elif mpw:
             act_dtype = out.t.dtype if out is not None else (out_dtype or torch.bfloat16)
             y_dtype = torch.bfloat16 if need_post else act_dtype
         else:
@@ -377,8 +401,13 @@ class ConvBNAct:
             self._run3x3(self._fw, x.t, self.cin, self.cout, self.stride, y.t, x.off, y.off)
         else:
             mode = {'plain': lib.PW_PLAIN, 'plainT': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[k]
-            w, b, cp = self._fw
-            ops.pointwise(x.t, w, b, mode, self.cin, self.cout, cp, relu=False, out=y.t, in_ch_off=x.off, out_ch_off=y.off)
+            if mpw:
+                w, b, cp = self._fw_mp
+                tops.mp_pointwise(x.t, w, b, mode, self.cin, self.cout, cp, relu=False, out=y.t, in_ch_off=x.off, out_ch_off=y.off)
+            else:
+                w, b, cp = self._fw
+                ops.pointwise(x.t, w, b, mode, self.cin, self.cout, cp, relu=False, out=y.t, in_ch_off=x.off, out_ch_off=y.off)
+        self._mpw = mpw
         if not need_post:
             self.saved = (x, y)
             return y
@@ -406,7 +435,7 @@ class ConvBNAct:
         x, y = self.saved
         dev = dout.t.device
         k = self.kind
-        mp = k == '3x3' and 'mp' in self._fw
+        mp = (k == '3x3' and 'mp' in self._fw) or (k != '3x3' and getattr(self, '_mpw', False))     # bf16 operands for both gradient GEMMs
         if not mp and dout.t.dtype != torch.float32:
             dout = Act(as_f32(dout.t, dout.off, dout.c), 0, dout.c)
         dy = dout
@@ -428,7 +457,7 @@ class ConvBNAct:
             tops.colsum(dy.t, self.cout, ensure_grad(self.conv.bias), accumulate=accumulate, ch_off=dy.off)
         gw = ensure_grad(self.conv.weight)
         rows = x.rows
-        if mp:
+        if mp and k == '3x3':
             tops.mp_conv3x3_wgrad(x.t, dy.t, self.cin, self.cout, self.stride, gw, accumulate=accumulate, x_ch_off=x.off, dy_ch_off=dy.off)
         elif k == '3x3':
             tops.conv3x3_wgrad(x.t, dy.t, self.cin, self.cout, self.stride, gw, accumulate=accumulate, x_ch_off=x.off, dy_ch_off=dy.off)
@@ -460,7 +489,11 @@ class ConvBNAct:
         if dx_out is None:
             dt = (dx_dtype or torch.bfloat16) if mp else torch.float32
             dx_out = Act(torch.empty(tuple(x.t.shape[:-1]) + (self.cin,), dtype=dt, device=dev), 0, self.cin)
-        if mp:
+        if mp and k != '3x3':
+            mode = {'plain': lib.PW_PLAIN, 'plainT': lib.PW_PLAIN, 's2d': lib.PW_DEPTH2SPACE, 'd2s': lib.PW_SPACE2DEPTH}[k]
+            w, b, cp = self._bw_mp
+            tops.mp_pointwise(dy.t, w, b, mode, self.cout, self.cin, cp, relu=False, out=dx_out.t, in_ch_off=dy.off, out_ch_off=dx_out.off)
+        elif mp:
             src = dy
             if self.stride == 2:
                 src = Act(tops.dilate2x(dy.t, self.cout, ch_off=dy.off), 0, self.cout)

@@ -312,19 +312,63 @@ def mp_conv3x3_wgrad(x, dy, cin, cout, stride, dw, accumulate=False, x_ch_off=0,
 
 
 def rowmap(t, channels, ch_off=0, lattice=None):
-    """lattice: None (row r = pixel r) or (grid_h, grid_w, ky, kx)"""
+    """lattice: None (row r = pixel r) or (grid_h, grid_w, ky, kx).  A bfloat16 tensor gives the row map of the bf16 kernel
+    (pcp_mp_rowmap_t, include/pcp_hip_mp.h)."""
     gh, gw, ky, kx = lattice if lattice is not None else (0, 0, 0, 0)
+    if t.dtype == torch.bfloat16:
+        return _lib.MpRowMap(t.data_ptr() + 2 * ch_off, t.shape[-1], channels, 0 if lattice is None else 1, gh, gw, ky, kx, _lib.DT_BF16,
+                             2 * (t.numel() - ch_off))
+    assert t.dtype == torch.float32
     return RowMap(t.data_ptr() + 4 * ch_off, t.shape[-1], channels, 0 if lattice is None else 1, gh, gw, ky, kx)
 
 
 def pointwise_wgrad(a, b, rows, out, accumulate=False):
-    """out[n, k] (+)= sum_r a[map(r), n] * b[map(r), k];  a, b: RowMap (see rowmap());  out: (n, k) row-major (ld = out.stride(0))."""
+    """out[n, k] (+)= sum_r a[map(r), n] * b[map(r), k];  a, b: row maps of ONE storage type (see rowmap());  out: (n, k) row-major
+    (ld = out.stride(0)).  bf16 operands run pcp_mp_pointwise_wgrad (bf16 products), fp32 ones pcp_pointwise_wgrad."""
     L = _lib.load()
     assert out.dtype == torch.float32 and out.stride(-1) == 1 and out.shape == (a.channels, b.channels)
+    mp = isinstance(a, _lib.MpRowMap)
+    if mp != isinstance(b, _lib.MpRowMap):
+        raise _lib.PcpError('pointwise_wgrad: the two operands must share one storage type')
+    if mp:
+        need = L.pcp_mp_pointwise_wgrad_workspace_bytes(rows, a.channels, b.channels)
+        ws = _WG_WS.get(need, out.device)
+        check(L.pcp_mp_pointwise_wgrad(ctypes.byref(a), ctypes.byref(b), rows, _p(ws), ws.numel(), _p(out), out.stride(0),
+                                       1 if accumulate else 0, _stream()), 'pcp_mp_pointwise_wgrad')
+        return out
     need = L.pcp_pointwise_wgrad_workspace_bytes(rows, a.channels, b.channels)
     ws = _WG_WS.get(need, out.device)
     check(L.pcp_pointwise_wgrad(ctypes.byref(a), ctypes.byref(b), rows, _p(ws), ws.numel(), _p(out), out.stride(0),
                                 1 if accumulate else 0, _stream()), 'pcp_pointwise_wgrad')
+    return out
+
+
+def mp_pointwise_ok(mode, cin, cout, cout_pad, ld_in, ld_out):
+    """the shapes pcp_mp_pointwise takes (anything else stays on the fp32 entry point)"""
+    return cin % 32 == 0 and cout % 8 == 0 and cout_pad % 64 == 0 and ld_in % 8 == 0 and ld_out % 8 == 0
+
+
+def mp_pointwise(x, w_bf16, bias, mode, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0, out_dtype=torch.bfloat16):
+    """pointwise family with bf16 products (include/pcp_hip_mp.h: pcp_mp_pointwise).  x: bf16 or fp32 NHWC map / rows; w_bf16: the fp32
+    pack of pack.pack_plain / pack_conv2x2_s2 / pack_convT2x2_s2 cast to bfloat16; out: bf16 or fp32 (allocated as out_dtype when None)."""
+    _need_cuda(x, w_bf16, bias, out)
+    L = _lib.load()
+    assert w_bf16.dtype == torch.bfloat16 and bias.dtype == torch.float32 and x.is_contiguous()
+    ld_in = x.shape[-1]
+    if mode == _lib.PW_PLAIN:
+        rows = x.numel() // ld_in
+        B = H = W = 0
+        oshape = tuple(x.shape[:-1])
+    else:
+        B, H, W, _ = x.shape
+        rows = 0
+        oshape = (B, H // 2, W // 2) if mode == _lib.PW_SPACE2DEPTH else (B, 2 * H, 2 * W)
+    if out is None:
+        out = torch.empty(oshape + (cout,), dtype=out_dtype, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape[:-1]) == oshape
+    d = _lib.MpPointwise(mode, rows, B, H, W, cin, cout, cout_pad, ld_in, out.shape[-1], 1 if relu else 0, _dt(x), _dt(out))
+    check(L.pcp_mp_pointwise(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(w_bf16), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
+          'pcp_mp_pointwise')
     return out
 
 
@@ -449,28 +493,36 @@ def pfn_train_features(points, vox, num_raw, fbuf, slot_pillar):
 
 
 def pfn_train_mid(vox, x0, vec0, in1, arg0):
+    """in1: (N, 64) float32, or bfloat16 in the bf16 loop"""
     L = _lib.load()
+    if in1.dtype == torch.bfloat16:
+        check(L.pcp_mp_pfn_train_mid(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x0), _p(vec0.scale), _p(vec0.shift), _p(in1), _lib.DT_BF16,
+                                     _p(arg0), _stream()), 'pcp_mp_pfn_train_mid')
+        return
     check(L.pcp_pfn_train_mid(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x0), _p(vec0.scale), _p(vec0.shift), _p(in1), _p(arg0),
                               _stream()), 'pcp_pfn_train_mid')
 
 
 def pfn_train_out(vox, x1, vec1, pillar_features, arg1, canvas):
-    """canvas: (B, ny, nx, 64) float32, or bfloat16 in the bf16 loop (pre-zeroed either way)"""
+    """canvas: (B, ny, nx, 64) float32, or bfloat16 in the bf16 loop (pre-zeroed either way); x1: (N, 64) float32 or bfloat16"""
     L = _lib.load()
-    if canvas is not None and canvas.dtype == torch.bfloat16:
-        check(L.pcp_mp_pfn_train_out(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x1), _p(vec1.scale), _p(vec1.shift),
-                                     _p(pillar_features), _p(arg1), _p(canvas), _lib.DT_BF16, _stream()), 'pcp_mp_pfn_train_out')
+    if (canvas is not None and canvas.dtype == torch.bfloat16) or x1.dtype == torch.bfloat16:
+        check(L.pcp_mp_pfn_train_out(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x1), _dt(x1), _p(vec1.scale), _p(vec1.shift),
+                                     _p(pillar_features), _p(arg1), _p(canvas), _dt(canvas) if canvas is not None else _lib.DT_F32, _stream()),
+              'pcp_mp_pfn_train_out')
         return
     check(L.pcp_pfn_train_out(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(x1), _p(vec1.scale), _p(vec1.shift),
                               _p(pillar_features), _p(arg1), _p(canvas), _stream()), 'pcp_pfn_train_out')
 
 
 def pfn_train_route_out_grad(vox, kept_rows, arg1, dz1, dcanvas=None, dpillar=None):
+    """dz1: (N, 64) float32 or bfloat16 (zero-filled here); dcanvas: float32 or bfloat16"""
     L = _lib.load()
-    if dcanvas is not None and dcanvas.dtype == torch.bfloat16:
-        assert dcanvas.is_contiguous()
-        check(L.pcp_mp_pfn_train_route_out_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, kept_rows, _p(dcanvas), _lib.DT_BF16, _p(dpillar),
-                                                _p(arg1), _p(dz1), _stream()), 'pcp_mp_pfn_train_route_out_grad')
+    if (dcanvas is not None and dcanvas.dtype == torch.bfloat16) or dz1.dtype == torch.bfloat16:
+        assert dcanvas is None or dcanvas.is_contiguous()
+        check(L.pcp_mp_pfn_train_route_out_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, kept_rows, _p(dcanvas),
+                                                _dt(dcanvas) if dcanvas is not None else _lib.DT_F32, _p(dpillar), _p(arg1), _p(dz1), _dt(dz1),
+                                                _stream()), 'pcp_mp_pfn_train_route_out_grad')
         return
     check(L.pcp_pfn_train_route_out_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, kept_rows, _p(dcanvas), _p(dpillar), _p(arg1),
                                          _p(dz1), _stream()), 'pcp_pfn_train_route_out_grad')
@@ -478,6 +530,10 @@ def pfn_train_route_out_grad(vox, kept_rows, arg1, dz1, dcanvas=None, dpillar=No
 
 def pfn_train_route_mid_grad(vox, din1, arg0, da0):
     L = _lib.load()
+    if din1.dtype == torch.bfloat16:
+        check(L.pcp_mp_pfn_train_route_mid_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(din1), _lib.DT_BF16, _p(arg0), _p(da0),
+                                                _stream()), 'pcp_mp_pfn_train_route_mid_grad')
+        return
     check(L.pcp_pfn_train_route_mid_grad(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(din1), _p(arg0), _p(da0), _stream()),
           'pcp_pfn_train_route_mid_grad')
 

@@ -268,3 +268,170 @@ def test_mp_sparse_first_layer_bf16_output_and_bf16_canvas_kernels():
     tops.pfn_train_route_out_grad(vox, Nk, outs[torch.float32][1], dz_b, dcanvas=dcan.to(torch.bfloat16).contiguous())
     torch.cuda.synchronize()
     assert torch.equal(dz_a, dz_b) and float(dz_a.abs().max()) > 0
+
+
+def test_mp_pfn_training_kernels_with_bf16_point_rows():
+    """the per-point 64-channel rows around the second PFN Linear as bf16: pfn_train_mid writes the fp32 rows rounded once; pfn_train_out,
+    the routing of the canvas gradient and the routing through the pillar max read / write bf16 rows with the results of the fp32 kernels
+    on the same (rounded) values"""
+    from pcp_amd import ops, train_ops as tops
+    pts = np.concatenate([synth.agent_cloud(agent=a, n_points=5000, layout='car') for a in range(2)], 0)
+    points = torch.from_numpy(synth.collate([pts])).to(DEV)
+    grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], 1)
+    vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False)
+    P, Nk = int(vox.counters[0].item()), int(vox.counters[1].item())
+    dev = torch.device(DEV)
+    x0 = _u(81, 1, (Nk, 32)).to(DEV).contiguous()
+    vec0 = tops.BNVectors(32, dev)
+    vec0.scale.fill_(1.1)
+    vec0.shift.fill_(0.02)
+    in1 = {dt: torch.empty((Nk, 64), dtype=dt, device=DEV) for dt in (torch.float32, torch.bfloat16)}
+    arg0 = {dt: torch.empty((max(P, 1), 32), dtype=torch.int32, device=DEV) for dt in in1}
+    for dt in in1:
+        tops.pfn_train_mid(vox, x0, vec0, in1[dt], arg0[dt])
+    torch.cuda.synchronize()
+    assert torch.equal(in1[torch.bfloat16], in1[torch.float32].to(torch.bfloat16)) and torch.equal(arg0[torch.float32], arg0[torch.bfloat16])
+    assert float(in1[torch.float32].abs().max()) > 0
+    # last kernel: bf16 x1 == fp32 kernel on the rounded x1
+    x1 = _u(82, 2, (Nk, 64)).to(DEV).to(torch.bfloat16).contiguous()
+    vec1 = tops.BNVectors(64, dev)
+    vec1.scale.fill_(0.9)
+    vec1.shift.fill_(0.05)
+    res = {}
+    for xin in (x1, x1.float()):
+        canvas = torch.zeros((1, 512, 512, 64), dtype=torch.bfloat16, device=DEV)
+        pfo = torch.empty((max(P, 1), 64), device=DEV)
+        arg1 = torch.empty((max(P, 1), 64), dtype=torch.int32, device=DEV)
+        tops.pfn_train_out(vox, xin, vec1, pfo, arg1, canvas)
+        res[xin.dtype] = (canvas, pfo[:P].clone(), arg1[:P].clone())
+    torch.cuda.synchronize()
+    for a, b in zip(res[torch.bfloat16], res[torch.float32]):
+        assert torch.equal(a, b)
+    # canvas gradient -> dz1 as bf16 == the fp32 routing rounded; routing through the pillar max from bf16 din1 == fp32 kernel on the rounded din1
+    dcan = _u(83, 3, (1, 512, 512, 64)).to(DEV).to(torch.bfloat16).contiguous()
+    dz = {dt: torch.empty((Nk, 64), dtype=dt, device=DEV) for dt in (torch.float32, torch.bfloat16)}
+    for dt in dz:
+        tops.pfn_train_route_out_grad(vox, Nk, res[torch.float32][2], dz[dt], dcanvas=dcan)
+    din1 = _u(84, 4, (Nk, 64)).to(DEV).to(torch.bfloat16).contiguous()
+    da = {}
+    for xin in (din1, din1.float()):
+        out = torch.empty((Nk, 32), device=DEV)
+        tops.pfn_train_route_mid_grad(vox, xin, arg0[torch.float32], out)
+        da[xin.dtype] = out
+    torch.cuda.synchronize()
+    assert torch.equal(dz[torch.bfloat16], dz[torch.float32].to(torch.bfloat16)) and float(dz[torch.float32].abs().max()) > 0
+    assert torch.equal(da[torch.bfloat16], da[torch.float32]) and float(da[torch.float32].abs().max()) > 0
+
+
+# ---- the pointwise family (pcp_mp_pointwise, pcp_mp_pointwise_wgrad) --------------------------------------------------------------------------
+
+PW_CASES = [
+    # kind, cin, cout, (B, H, W), in_bf16, out_bf16, relu
+    ('plain', 64, 128, (1, 25, 40), True, True, True),          # 1000 rows: a ragged last pixel tile
+    ('plain', 256, 64, (2, 16, 16), False, False, False),       # fp32 in and out (converted while staged)
+    ('plain', 128, 72, (1, 9, 32), True, False, True),          # cout not a multiple of 64: masked channel groups
+    ('s2d', 64, 128, (2, 32, 48), True, True, True),            # Conv2d k2 s2
+    ('s2d', 128, 128, (1, 16, 24), False, True, False),
+    ('d2s', 128, 128, (2, 16, 24), True, True, True),           # ConvTranspose2d k2 s2
+    ('d2s', 256, 64, (1, 8, 20), True, False, False),
+]
+
+
+def _pw_layer(kind, cin, cout):
+    if kind == 'plain':
+        return torch.nn.Conv2d(cin, cout, 1, bias=True)
+    if kind == 's2d':
+        return torch.nn.Conv2d(cin, cout, 2, stride=2, bias=True)
+    return torch.nn.ConvTranspose2d(cin, cout, 2, stride=2, bias=True)
+
+
+def _pw_pack(kind, w, b):
+    from pcp_amd import pack
+    f = {'plain': lambda: pack.pack_plain(w.reshape(w.shape[0], -1), b), 's2d': lambda: pack.pack_conv2x2_s2(w, b),
+         'd2s': lambda: pack.pack_convT2x2_s2(w, b)}[kind]
+    wp, bp, cp = f()
+    return wp.to(DEV).to(torch.bfloat16).contiguous(), bp.to(DEV).float().contiguous(), cp
+
+
+@pytest.mark.parametrize('kind,cin,cout,shape,in_bf16,out_bf16,relu', PW_CASES)
+def test_mp_pointwise_forward_modes_and_storage_types(kind, cin, cout, shape, in_bf16, out_bf16, relu):
+    from pcp_amd import lib, train_ops as tops
+    B, H, W = shape
+    x = _u(31, cin + cout, (B, cin, H, W))
+    layer = _pw_layer(kind, cin, cout)
+    w = _u(32, cin * 3 + cout, tuple(layer.weight.shape), -0.2, 0.2)
+    bias = _u(33, cout, (cout,))
+    with torch.no_grad():
+        layer.weight.copy_(_bf(w))
+        layer.bias.copy_(bias)
+        want = layer.double()(_bf(x).double())
+        if relu:
+            want = want.clamp_min(0)
+    wp, bp, cp = _pw_pack(kind, w, bias)
+    mode = {'plain': lib.PW_PLAIN, 's2d': lib.PW_SPACE2DEPTH, 'd2s': lib.PW_DEPTH2SPACE}[kind]
+    xin = _nhwc(x, torch.bfloat16 if in_bf16 else torch.float32)
+    got = tops.mp_pointwise(xin, wp, bp, mode, cin, cout, cp, relu=relu, out_dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    assert got.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+    _check(got.permute(0, 3, 1, 2), want, out_bf16, 'mp_pointwise %s %d->%d' % (kind, cin, cout))
+
+
+def test_mp_pointwise_channel_windows_of_wider_buffers():
+    from pcp_amd import lib, train_ops as tops
+    cin, cout, B, H, W = 64, 128, 2, 12, 20
+    x = _u(41, 1, (B, cin, H, W))
+    w = _u(42, 2, (cout, cin, 1, 1), -0.2, 0.2)
+    bias = _u(43, 3, (cout,))
+    want = F.conv2d(_bf(x).double(), _bf(w).double(), bias.double())
+    wp, bp, cp = _pw_pack('plain', w, bias)
+    wide_in = torch.full((B, H, W, cin + 32), 7.0, dtype=torch.bfloat16, device=DEV)
+    wide_in[..., 16:16 + cin] = _nhwc(x, torch.bfloat16)
+    wide_out = torch.full((B, H, W, cout + 64), -3.0, dtype=torch.bfloat16, device=DEV)
+    tops.mp_pointwise(wide_in, wp, bp, lib.PW_PLAIN, cin, cout, cp, relu=False, out=wide_out, in_ch_off=16, out_ch_off=32)
+    _check(wide_out[..., 32:32 + cout].permute(0, 3, 1, 2), want, True, 'windowed mp_pointwise')
+    assert float(wide_out[..., :32].float().min()) == -3.0 and float(wide_out[..., 32 + cout:].float().max()) == -3.0
+
+
+PWG_CASES = [
+    # kind, cin, cout, (B, H, W) of the layer input
+    ('plain', 64, 128, (2, 24, 40)),
+    ('plain', 256, 64, (1, 16, 16)),
+    ('plain', 72, 40, (1, 13, 29)),             # channels that are not multiples of 64, ragged rows
+    ('s2d', 64, 128, (2, 32, 48)),
+    ('d2s', 128, 64, (2, 16, 24)),
+]
+
+
+@pytest.mark.parametrize('kind,cin,cout,shape', PWG_CASES)
+def test_mp_pointwise_wgrad_of_the_three_layer_kinds(kind, cin, cout, shape):
+    from pcp_amd import train_ops as tops
+    B, H, W = shape
+    layer = _pw_layer(kind, cin, cout).double()
+    x = _u(51, cin, (B, cin, H, W))
+    xr = _bf(x).double().requires_grad_(False)
+    y = layer(xr)
+    dy = _u(52, cout, tuple(y.shape))
+    (y * _bf(dy).double()).sum().backward()
+    want = layer.weight.grad                                     # plain / s2d: (cout, cin, k, k); d2s: (cin, cout, 2, 2)
+    xd, dyd = _nhwc(x, torch.bfloat16), _nhwc(dy, torch.bfloat16)
+    rows = B * H * W
+    if kind == 'plain':
+        got = torch.empty((cout, cin), dtype=torch.float32, device=DEV)
+        tops.pointwise_wgrad(tops.rowmap(dyd, cout), tops.rowmap(xd, cin), rows, got)
+        got = got.reshape(cout, cin, 1, 1)
+    elif kind == 's2d':
+        Ho, Wo = H // 2, W // 2
+        tmp = torch.empty((4, cout, cin), dtype=torch.float32, device=DEV)
+        for tap in range(4):
+            tops.pointwise_wgrad(tops.rowmap(dyd, cout), tops.rowmap(xd, cin, lattice=(Ho, Wo, tap // 2, tap % 2)), B * Ho * Wo, tmp[tap])
+        got = tmp.permute(1, 2, 0).reshape(cout, cin, 2, 2)
+    else:
+        tmp = torch.empty((4, cin, cout), dtype=torch.float32, device=DEV)
+        for tap in range(4):
+            tops.pointwise_wgrad(tops.rowmap(xd, cin), tops.rowmap(dyd, cout, lattice=(H, W, tap // 2, tap % 2)), rows, tmp[tap])
+        got = tmp.permute(1, 2, 0).reshape(cin, cout, 2, 2)
+    _check(got, want, False, 'mp_pointwise_wgrad %s' % kind)
+    # accumulate: a second call adds the same gradient
+    if kind == 'plain':
+        acc = got.reshape(cout, cin).clone()
+        tops.pointwise_wgrad(tops.rowmap(dyd, cout), tops.rowmap(xd, cin), rows, acc, accumulate=True)
+        _check(acc.reshape(cout, cin, 1, 1), 2 * want, False, 'accumulating mp_pointwise_wgrad')
