@@ -88,7 +88,7 @@ def parse_args(argv=None):
                     'us per launch, executed TFLOP/s) to this file')
     ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
-    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'winograd4h', 'bf16x3', 'bf16'],
+    ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'winograd4h', 'winograd4c', 'bf16x3', 'bf16'],
                     help='3x3 convolution arithmetic (default auto = fp32 MFMA: direct / Winograd).  bf16x3 is the OPT-IN split-bf16 mode '
                          '(three bf16 MFMAs per product, fp32 accumulate, ~1e-5 relative error); the JSON line then says so in `dtype`')
     ap.add_argument('--shard', default='frame', choices=['frame', 'agent'], help="frame (default): every rank is a replica on its own frames; "
@@ -315,6 +315,13 @@ class AbiTimer:
                 real.pcp_conv3x3_winograd4h_plan(ctypes.byref(d), ctypes.byref(fl))
                 return ('k_wino4h (3x3 s1 fused Winograd F(4x4,3x3), two 4-wave workgroups per CU, v_mfma_f32_16x16x4_f32)', fl.value,
                         2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma', MFMA_F32_PEAK_TFLOPS)
+            if name == 'pcp_conv3x3_winograd4c':
+                d = a[0]._obj
+                fl = ctypes.c_double(0.0)
+                real.pcp_conv3x3_winograd4c_plan(ctypes.byref(d), ctypes.byref(fl))
+                return ('k_wino4c (3x3 s1 fused Winograd F(4x4,3x3), two 4-wave workgroups per CU, waves split over output channels, output '
+                        'transform in registers, v_mfma_f32_16x16x4_f32)', fl.value, 2.0 * d.batch * d.in_h * d.in_w * d.cout * 9 * d.cin, 'mfma',
+                        MFMA_F32_PEAK_TFLOPS)
             if name == 'pcp_mp_conv3x3':
                 # the bf16 training loop's convolution (forward, data gradient, frozen teachers): v_mfma_f32_32x32x16_bf16, bf16 activations
                 d = a[0]._obj

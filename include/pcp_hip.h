@@ -159,6 +159,15 @@ int pcp_conv3x3_winograd4h(const pcp_conv3x3_t *desc, const float *in, const flo
                            void *stream);
 int pcp_conv3x3_winograd4h_plan(const pcp_conv3x3_t *desc, double *executed_flops);
 
+/* The same items and workgroups with the four waves split over OUTPUT CHANNELS instead of Winograd positions (csrc/wino4c.hip): a lane holds
+ * all 36 position values of four consecutive channels of one tile, so the output transform, bias and ReLU run in registers -- no LDS image
+ * of the accumulators, no epilogue barriers.  Bit-identical outputs to pcp_conv3x3_winograd4h.  Same descriptor rules; weights packed by
+ * pcp_amd/pack.py::pack_conv3x3_winograd4c: [cin/8][cout_pad/16][18 position pairs][64 lanes][4], lane l = 16 kq + c, value 2 e + ks =
+ * U[position 2 q + e][input channel 8 s + 4 ks + kq][output channel 16 g + c]. */
+int pcp_conv3x3_winograd4c(const pcp_conv3x3_t *desc, const float *in, const float *u_packed, const float *bias, float *out,
+                           void *stream);
+int pcp_conv3x3_winograd4c_plan(const pcp_conv3x3_t *desc, double *executed_flops);
+
 /* Measurement query (bench.py's roofline line): which instantiation pcp_conv3x3_winograd launches for `desc` (variant = 1: 32-tile
  * workgroups k_conv3x3_wino<1>, 2: 64-tile workgroups k_conv3x3_wino<2>) and the flops that launch EXECUTES on the matrix pipe
  * (16 products per 2x2 output tile and (cin, cout) pair, padding tiles and channels included).  Either output may be NULL. */

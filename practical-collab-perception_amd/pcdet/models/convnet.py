@@ -17,7 +17,7 @@ WINOGRAD_MIN_WORKGROUPS = 256
 B3_MIN_WORKGROUPS = 256
 WINOGRAD4_MIN_COUT = 256
 WINOGRAD4_MIN_WORKGROUPS = 512
-CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | winograd4f | winograd4h | bf16x3 (opt-in: split-bf16 products)
+CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | winograd4f | winograd4h | winograd4c | bf16x3 (opt-in: split-bf16 products)
 
 
 def conv_algo():
@@ -45,7 +45,7 @@ WINOGRAD4F_MAX_INPUT_BYTES = 0x7fffffff                    # buffer-descriptor a
 
 class PackedConv:
     """One fused conv(+BN)(+ReLU) launch description."""
-    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f', 'w4h', 'mp')
+    __slots__ = ('kind', 'w', 'b', 'cin', 'cout', 'cout_pad', 'stride', 'relu', 'wino', 'b3', 'w4', 'w4f', 'w4h', 'w4c', 'mp')
 
     def _use_winograd4f(self, x, out, out_ch_off, in_ch_off=0):
         algo = conv_algo()
@@ -57,7 +57,7 @@ class PackedConv:
         # Outside them the launch returns PCP_ERR_UNSUPPORTED / PCP_ERR_ARG, so the dispatch falls through to the other kernels instead
         if x.shape[-1] % 4 != 0 or in_ch_off % 4 != 0 or x.numel() * 4 > WINOGRAD4F_MAX_INPUT_BYTES:
             return False
-        if algo in ('winograd4f', 'winograd4h'):
+        if algo in ('winograd4f', 'winograd4h', 'winograd4c'):
             return True
         B, H, W, _ = x.shape
         wgs = B * ((H + 15) // 16) * ((W + 31) // 32) * (self.w4f[2] // 64)
@@ -75,7 +75,7 @@ class PackedConv:
         Interleaved A/B on MI355X (tools/bench_w4h.py, profiles/r03_wino4h_ab.txt): 4h wins up to 128 input channels wherever its
         grid covers the chip (>= 256 workgroups), by 3-4 % on full grids and 20-40 % on the grids 4f fills unevenly; 4f keeps cin >= 256."""
         algo = conv_algo()
-        if algo == 'winograd4h':
+        if algo in ('winograd4h', 'winograd4c'):
             return True
         if algo == 'winograd4f' or WINOGRAD4H == '0':
             return False
@@ -92,6 +92,11 @@ class PackedConv:
         if getattr(self, 'w4h', None) is None:
             self.w4h = (pack.repack_winograd4f_to_4h(self.w4f[0]), self.w4f[1], self.w4f[2])
         return self.w4h
+
+    def _w4c(self):
+        if getattr(self, 'w4c', None) is None:
+            self.w4c = (pack.repack_winograd4f_to_4c(self.w4f[0]), self.w4f[1], self.w4f[2])
+        return self.w4c
 
     def _use_winograd4(self, x):
         algo = conv_algo()
@@ -154,6 +159,12 @@ class PackedConv:
                                       in_ch_off=in_ch_off, out_ch_off=out_ch_off, plain=_plain_bf16())
         if self._use_winograd4f(x, out, out_ch_off, in_ch_off):
             if self._prefer_winograd4h(x):
+                # the half-size items: k_wino4c (round 4: waves split over the output channels, output transform in registers; the bits of
+                # k_wino4h, 2 - 6 % faster on every shape of the step, profiles/r04_wino4c_ab.txt) unless k_wino4h is asked for by name
+                if conv_algo() != 'winograd4h':
+                    u, ub, ucp = self._w4c()
+                    return ops.conv3x3_winograd4c(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
+                                                  out_ch_off=out_ch_off)
                 u, ub, ucp = self._w4h()
                 return ops.conv3x3_winograd4h(x, u, ub, self.cin, self.cout, ucp, relu=self.relu, out=out, in_ch_off=in_ch_off,
                                               out_ch_off=out_ch_off)
@@ -184,7 +195,7 @@ def _winograd4_shape(cin, cout, stride):
 def _winograd4f_shape(cin, cout, stride):
     # layers auto dispatch never sends to the fused kernel (cin above its cap with the through-memory form available) do not get the
     # 4x-sized fused weight form packed at all; PCP_CONV_ALGO=winograd4f packs it for every eligible layer
-    if conv_algo() not in ('winograd4f', 'winograd4h') and cin > WINOGRAD4F_MAX_CIN and _winograd4_shape(cin, cout, stride):
+    if conv_algo() not in ('winograd4f', 'winograd4h', 'winograd4c') and cin > WINOGRAD4F_MAX_CIN and _winograd4_shape(cin, cout, stride):
         return False
     return (stride == 1 and cin % 8 == 0 and cout % 4 == 0 and cout >= 48 and conv_algo() not in ('direct', 'winograd', 'winograd4', 'bf16x3', 'bf16'))
 
@@ -224,6 +235,7 @@ def pack_conv_module(conv, bn=None, relu=True):
     pc.w4 = None
     pc.w4f = None
     pc.w4h = None
+    pc.w4c = None
     pc.mp = None
     if isinstance(conv, nn.ConvTranspose2d):
         w, b = _fold(conv, bn, out_axis=1)
@@ -283,4 +295,5 @@ def pack_conv_raw(w, b, relu, stride=1):
     pc.w4 = pack.pack_conv3x3_winograd4(w, b) if _winograd4_shape(pc.cin, pc.cout, stride) else None
     pc.w4f = pack.pack_conv3x3_winograd4f(w, b) if _winograd4f_shape(pc.cin, pc.cout, stride) else None
     pc.w4h = None
+    pc.w4c = None
     return pc

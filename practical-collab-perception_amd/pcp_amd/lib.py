@@ -155,6 +155,8 @@ SYMBOLS = {
     'pcp_conv3x3_winograd4f_plan': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(ctypes.c_double)]),
     'pcp_conv3x3_winograd4h': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
     'pcp_conv3x3_winograd4h_plan': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(ctypes.c_double)]),
+    'pcp_conv3x3_winograd4c': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),
+    'pcp_conv3x3_winograd4c_plan': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(ctypes.c_double)]),
     'pcp_conv3x3_winograd4_workspace_bytes': (c_i32, [ctypes.POINTER(Conv3x3), ctypes.POINTER(c_sz)]),
     'pcp_conv3x3_winograd4': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp, vp]),
     'pcp_conv3x3_winograd4_timed': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float),

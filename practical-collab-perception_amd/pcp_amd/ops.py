@@ -249,6 +249,23 @@ def conv3x3_winograd4h(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=No
     return out
 
 
+def conv3x3_winograd4c(x, u_packed, bias, cin, cout, cout_pad, relu=True, out=None, in_ch_off=0, out_ch_off=0):
+    """stride-1 3x3 conv through the fused F(4x4,3x3) kernel whose waves split the output channels (csrc/wino4c.hip: the output transform
+    in registers; weights from pack.pack_conv3x3_winograd4c); same tensor contract and the same bits as conv3x3_winograd4h."""
+    _need_cuda(x, u_packed, bias, out)
+    _need_f32('pcp_conv3x3_winograd4c', x, out)
+    L = _lib.load()
+    B, H, W, ld_in = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    assert out.shape[:3] == (B, H, W) and x.is_contiguous() and out.is_contiguous()
+    assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3]
+    d = Conv3x3(B, H, W, cin, cout, cout_pad, 1, ld_in, out.shape[3], 1 if relu else 0)
+    check(L.pcp_conv3x3_winograd4c(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(u_packed), _p(bias), _chan_ptr(out, out_ch_off),
+                                   _stream()), 'pcp_conv3x3_winograd4c')
+    return out
+
+
 _W4_WORKSPACE = {}
 _W4_RETIRED = []
 

@@ -152,6 +152,21 @@ def repack_winograd4f_to_4h(packed):
     return v.permute(0, 1, 2, 6, 4, 3, 5).contiguous().view(S, 36, cout_pad // 64, 64, 8)
 
 
+def pack_conv3x3_winograd4c(w, bias):
+    """the F(4x4,3x3) filter transform in the fragment order of csrc/wino4c.hip: [cin/8][cout_pad/16][18 position pairs][64 lanes][4]; lane
+    l = 16 kq + c holds, at index 2 e + ks, U[position 2 q + e][input channel 8 s + 4 ks + kq][output channel 16 g + c] (the A operand of
+    v_mfma_f32_16x16x4_f32 for both k steps of two positions: one 16-byte load per lane and position pair)"""
+    packed, b, cout_pad = pack_conv3x3_winograd4f(w, bias)                      # [S, 36, cout_pad, 8]
+    return repack_winograd4f_to_4c(packed), b, cout_pad
+
+
+def repack_winograd4f_to_4c(packed):
+    """[cin/8][36][cout_pad][8] (k_wino4f's order) -> k_wino4c's order (a pure permutation)"""
+    S, _p, cout_pad, _k = packed.shape
+    v = packed.view(S, 18, 2, cout_pad // 16, 16, 2, 4)                         # [s, q, e, g, c, ks, kq]
+    return v.permute(0, 3, 1, 6, 4, 2, 5).contiguous().view(S, cout_pad // 16, 18, 64, 4)
+
+
 def winograd4_reference(x, packed, bias, cout):
     """Plain-torch evaluation of the packed F(4x4,3x3) form with the transforms of csrc/wino4.hip (validates matrices + layout on the
     CPU): x (B, cin, H, W), H, W multiples of 4."""

@@ -128,7 +128,7 @@ def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monke
         assert (128, 384) in calls and (384, 384) in calls
 
 
-@pytest.mark.parametrize('algo', ['winograd4f', 'winograd4h'])
+@pytest.mark.parametrize('algo', ['winograd4f', 'winograd4h', 'winograd4c'])
 @pytest.mark.parametrize('tag', ['car', 'ego', 'disco'])
 def test_reference_outputs_with_every_eligible_layer_forced_onto_fused_winograd4(tag, algo, monkeypatch):
     """the mini geometry never reaches the workgroup count at which `auto` picks the FUSED F(4x4,3x3) kernel (csrc/wino4f.hip); force it on

@@ -561,10 +561,10 @@ def test_conv3x3_winograd_ws_channel_windows_and_bad_arguments():
                                                       (384, 64, 16, 32, True, 1), (64, 320, 32, 32, True, 1), (64, 100, 20, 36, False, 2),
                                                       (24, 128, 7, 9, True, 1), (128, 384, 24, 40, True, 1), (128, 128, 64, 64, True, 3),
                                                       (256, 256, 64, 64, True, 1)])
-@pytest.mark.parametrize('kernel', ['winograd4f', 'winograd4h'])
+@pytest.mark.parametrize('kernel', ['winograd4f', 'winograd4h', 'winograd4c'])
 def test_conv3x3_winograd4f_matches_torch_cpu(cin, cout, h, w, relu, batch, kernel):
-    """both fused F(4x4) kernels: k_wino4f (eight-wave workgroup, 16 x 32-pixel items) and k_wino4h (two four-wave workgroups per CU,
-    16 x 16-pixel items, csrc/wino4h.hip)"""
+    """the fused F(4x4) kernels: k_wino4f (eight-wave workgroup, 16 x 32-pixel items), k_wino4h (two four-wave workgroups per CU,
+    16 x 16-pixel items, csrc/wino4h.hip) and k_wino4c (the same items, waves split over output channels, csrc/wino4c.hip)"""
     ops = _ops()
     from pcp_amd import pack
     x = torch.from_numpy(_rand(271, (batch, cin, h, w)))
@@ -584,7 +584,7 @@ def test_conv3x3_winograd4f_matches_torch_cpu(cin, cout, h, w, relu, batch, kern
     assert torch.equal(got, got2)                                            # deterministic
 
 
-@pytest.mark.parametrize('kernel', ['winograd4f', 'winograd4h'])
+@pytest.mark.parametrize('kernel', ['winograd4f', 'winograd4h', 'winograd4c'])
 def test_conv3x3_winograd4f_channel_windows_and_bad_arguments(kernel):
     ops = _ops()
     from pcp_amd import lib, pack
@@ -606,6 +606,23 @@ def test_conv3x3_winograd4f_channel_windows_and_bad_arguments(kernel):
         run(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
 
 
+@pytest.mark.parametrize('cin,cout,h,w,batch', [(64, 64, 32, 32, 1), (128, 128, 48, 80, 2), (16, 52, 37, 50, 2), (384, 64, 16, 32, 1), (72, 132, 20, 100, 3)])
+def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch):
+    """k_wino4c multiplies the same products in the same k order as k_wino4h and runs the same output transform per lane: bitwise equal"""
+    ops = _ops()
+    from pcp_amd import pack
+    d = dev()
+    x = ops.as_nhwc(torch.from_numpy(_rand(291, (batch, cin, h, w))).to(d))
+    wt = torch.from_numpy(_rand(292, (cout, cin, 3, 3), -0.05, 0.05))
+    b = torch.from_numpy(_rand(293, (cout,), -0.2, 0.2))
+    uh, bh, cph = pack.pack_conv3x3_winograd4h(wt, b)
+    uc, bc, cpc = pack.pack_conv3x3_winograd4c(wt, b)
+    oh = ops.conv3x3_winograd4h(x, uh.to(d), bh.to(d), cin, cout, cph, relu=True)
+    oc = ops.conv3x3_winograd4c(x, uc.to(d), bc.to(d), cin, cout, cpc, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(oh, oc) and float(oh.abs().max()) > 0
+
+
 def test_auto_dispatch_falls_back_when_the_fused_f4_kernel_refuses(monkeypatch):
     """a layer the fused F(4x4) kernel cannot take (over its 2 GiB input limit -- lowered here) still runs in auto mode, on the
     F(2x2) kernel, with the same result (every conv kernel of the library needs 16-byte aligned channel windows, so there is no fallback for
@@ -623,7 +640,7 @@ def test_auto_dispatch_falls_back_when_the_fused_f4_kernel_refuses(monkeypatch):
     x = torch.from_numpy(_rand(281, (8, 128, 128, 72))).to(d)                     # 8 x 8 x 4 = 256 workgroups: auto picks the fused kernel
     assert pc._use_winograd4f(x, None, 0, 4)
     assert pc._prefer_winograd4h(x)                                                # 64 input channels, 512 half-size items: k_wino4h
-    want = pc.run(x, in_ch_off=4)                                                  # fused F(4x4), two workgroups per CU
+    want = pc.run(x, in_ch_off=4)                                                  # fused F(4x4), two workgroups per CU (k_wino4c)
     monkeypatch.setattr(convnet, 'WINOGRAD4H', '0')
     assert pc._use_winograd4f(x, None, 0, 4) and not pc._prefer_winograd4h(x)
     want8 = pc.run(x, in_ch_off=4)                                                 # fused F(4x4), one eight-wave workgroup per CU

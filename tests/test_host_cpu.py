@@ -314,6 +314,13 @@ def test_winograd4h_weight_order_is_the_documented_permutation_and_dispatch_rule
     for (s, pos, n, lane, j) in [(0, 0, 0, 0, 0), (1, 35, 1, 63, 7), (0, 17, 1, 37, 5), (1, 4, 0, 22, 2)]:
         kq, c, nb, ks = lane >> 4, lane & 15, j >> 1, j & 1
         assert ph[s, pos, n, lane, j] == pf[s, pos, 64 * n + 16 * nb + c, 4 * ks + kq]
+    # k_wino4c (include/pcp_hip.h): [cin/8][cout_pad/16][18 position pairs][64 lanes][4], lane l = 16 kq + c, index 2 e + ks =
+    # U[position 2 q + e][input channel 8 s + 4 ks + kq][output channel 16 g + c]
+    pc4, bc4, cpc4 = pack.pack_conv3x3_winograd4c(w, b)
+    assert cpc4 == 128 and tuple(pc4.shape) == (2, 8, 18, 64, 4) and torch.equal(bc4, _bf)
+    for (s, g, q, lane, j) in [(0, 0, 0, 0, 0), (1, 7, 17, 63, 3), (0, 4, 9, 37, 1), (1, 2, 3, 22, 2)]:
+        kq, c, e, ks = lane >> 4, lane & 15, j >> 1, j & 1
+        assert pc4[s, g, q, lane, j] == pf[s, 2 * q + e, 16 * g + c, 4 * ks + kq]
     pc = convnet.pack_conv_module(nn.Conv2d(128, 128, 3, padding=1, bias=False), None, relu=True)
     assert pc._prefer_winograd4h(torch.empty((20, 64, 64, 128), device='meta'))          # 640 items: the layer F(2x2) used to keep
     assert pc._use_winograd4f(torch.empty((20, 64, 64, 128), device='meta'), None, 0, 0)
