@@ -48,6 +48,7 @@ struct Conv3Params {
   int ld_in, ld_out;
   int relu;
   int tiles_x, tiles_y, n_tiles;
+  int vec_out;          // output rows 16-byte aligned: 16-byte stores
 };
 
 template <int S, int TH, int TW, int BN, int WAVES_M, int WAVES_N>
@@ -178,32 +179,45 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(Conv3Params p) {
         for (int i = 0; i < MI; i++)
 #pragma unroll
           for (int j = 0; j < NI; j++) {
-            acc[i][j] = mfma32(af[i].x, bf[j].x, acc[i][j]);
-            acc[i][j] = mfma32(af[i].y, bf[j].y, acc[i][j]);
-            acc[i][j] = mfma32(af[i].z, bf[j].z, acc[i][j]);
-            acc[i][j] = mfma32(af[i].w, bf[j].w, acc[i][j]);
+            // weights = A operand (rows = output channels), pixels = B operand (columns): four consecutive channels of one pixel per
+            // accumulator quad -> 16-byte stores
+            acc[i][j] = mfma32(bf[j].x, af[i].x, acc[i][j]);
+            acc[i][j] = mfma32(bf[j].y, af[i].y, acc[i][j]);
+            acc[i][j] = mfma32(bf[j].z, af[i].z, acc[i][j]);
+            acc[i][j] = mfma32(bf[j].w, af[i].w, acc[i][j]);
           }
       }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: bias + ReLU, 128-B row segments ------------------------------------------------------------------
+  // ---- epilogue: bias + ReLU; lane (r, h) holds channels nb + 8 q + 4 h + (0..3) of pixel wm * WTM + i * 32 + r in accumulator quad q -----
 #pragma unroll
   for (int j = 0; j < NI; j++) {
-    const int n = n0 + wn * WTN + j * 32 + r;
-    const float bias = p.bias[n];
-    const bool n_ok = n < p.cout;
+    const int nb = n0 + wn * WTN + j * 32;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
+      const int m = wm * WTM + i * 32 + r;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      if (oy >= p.out_h || ox >= p.out_w) continue;
+      float *orow = p.out + ((long long)(b * p.out_h + oy) * p.out_w + ox) * p.ld_out;
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        int m = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        int oy = oy0 + m / TW, ox = ox0 + m % TW;
-        float v = acc[i][j][e] + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (n_ok && oy < p.out_h && ox < p.out_w)
-          p.out[((long long)(b * p.out_h + oy) * p.out_w + ox) * p.ld_out + n] = v;
+      for (int q = 0; q < 4; q++) {
+        const int co = nb + 8 * q + 4 * h;
+        if (co >= p.cout) continue;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co);          // padded to cout_pad
+        f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + bias;
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (co + 3 < p.cout && p.vec_out) {
+          *reinterpret_cast<f32x4 *>(orow + co) = v;
+        } else {
+          orow[co] = v.x;
+          if (co + 1 < p.cout) orow[co + 1] = v.y;
+          if (co + 2 < p.cout) orow[co + 2] = v.z;
+          if (co + 3 < p.cout) orow[co + 3] = v.w;
+        }
       }
     }
   }
@@ -227,6 +241,7 @@ struct PwParams {
   int ld_in, ld_out;
   int relu;
   int n_tiles;
+  int vec_out;          // output rows 16-byte aligned (ld_out % 4 == 0, aligned base): 16-byte stores
 };
 
 template <int MODE, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -348,42 +363,62 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_pointwise(PwParams p) {
       for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < NI; j++) {
-          acc[i][j] = mfma32(af[i].x, bf[j].x, acc[i][j]);
-          acc[i][j] = mfma32(af[i].y, bf[j].y, acc[i][j]);
-          acc[i][j] = mfma32(af[i].z, bf[j].z, acc[i][j]);
-          acc[i][j] = mfma32(af[i].w, bf[j].w, acc[i][j]);
+          // the WEIGHTS are the A operand (rows = output channels), the pixels the B operand (columns): a lane ends up with four consecutive
+          // channels of one pixel per accumulator quad -> 16-byte stores
+          acc[i][j] = mfma32(bf[j].x, af[i].x, acc[i][j]);
+          acc[i][j] = mfma32(bf[j].y, af[i].y, acc[i][j]);
+          acc[i][j] = mfma32(bf[j].z, af[i].z, acc[i][j]);
+          acc[i][j] = mfma32(bf[j].w, af[i].w, acc[i][j]);
         }
     }
     __syncthreads();
   }
 
+  // epilogue: lane (r, h) holds channels nb + 8 q + 4 h + (0..3) of pixel m0 + wm * WTM + i * 32 + r in accumulator quad q
 #pragma unroll
   for (int j = 0; j < NI; j++) {
-    const int n = n0 + wn * WTN + j * 32 + r;
-    int tap = 0, co = n;
+    const int nb = n0 + wn * WTN + j * 32;
+    int tap = 0, cb = nb;
     if (MODE == PCP_PW_DEPTH2SPACE) {
-      tap = n / p.cout_pad;
-      co = n % p.cout_pad;
+      tap = nb / p.cout_pad;
+      cb = nb % p.cout_pad;
     }
-    const bool n_ok = (n < p.n_total) && (co < p.cout);
-    const float bias = n_ok ? p.bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
+      const long long m = m0 + wm * WTM + i * 32 + r;
+      if (m >= p.rows || nb >= p.n_total) continue;
+      long long opix = m;
+      if (MODE == PCP_PW_DEPTH2SPACE) {
+        int ix = (int)(m % p.in_w);
+        long long t = m / p.in_w;
+        int iy = (int)(t % p.in_h), bb = (int)(t / p.in_h);
+        opix = ((long long)bb * (2 * p.in_h) + 2 * iy + (tap >> 1)) * (2 * p.in_w) + 2 * ix + (tap & 1);
+      }
+      float *orow = p.out + opix * p.ld_out;
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        long long m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (!n_ok || m >= p.rows) continue;
-        float v = acc[i][j][e] + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (MODE == PCP_PW_PLAIN && p.residual) v += p.residual[m * p.ld_res + co];
-        long long opix = m;
-        if (MODE == PCP_PW_DEPTH2SPACE) {
-          int ix = (int)(m % p.in_w);
-          long long t = m / p.in_w;
-          int iy = (int)(t % p.in_h), bb = (int)(t / p.in_h);
-          opix = ((long long)bb * (2 * p.in_h) + 2 * iy + (tap >> 1)) * (2 * p.in_w) + 2 * ix + (tap & 1);
+      for (int q = 0; q < 4; q++) {
+        const int co = cb + 8 * q + 4 * h;
+        if (co >= p.cout) continue;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co);          // bias is padded to cout_pad
+        f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + bias;
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        p.out[opix * p.ld_out + co] = v;
+        if (MODE == PCP_PW_PLAIN && p.residual) {
+          const float *rr = p.residual + m * p.ld_res + co;
+          v.x += rr[0];
+          if (co + 1 < p.cout) v.y += rr[1];
+          if (co + 2 < p.cout) v.z += rr[2];
+          if (co + 3 < p.cout) v.w += rr[3];
+        }
+        if (co + 3 < p.cout && p.vec_out) {
+          *reinterpret_cast<f32x4 *>(orow + co) = v;
+        } else {
+          orow[co] = v.x;
+          if (co + 1 < p.cout) orow[co + 1] = v.y;
+          if (co + 2 < p.cout) orow[co + 2] = v.z;
+          if (co + 3 < p.cout) orow[co + 3] = v.w;
+        }
       }
     }
   }
@@ -401,6 +436,7 @@ int launch_conv3(const pcp_conv3x3_t *d, const float *in, const float *w, const 
   p.tiles_x = (p.out_w + TW - 1) / TW;
   p.tiles_y = (p.out_h + TH - 1) / TH;
   p.n_tiles = d->cout_pad / BN;
+  p.vec_out = (d->ld_out % 4 == 0 && (((uintptr_t)out) & 15) == 0) ? 1 : 0;
   long long blocks = (long long)d->batch * p.tiles_x * p.tiles_y * p.n_tiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
   hipLaunchKernelGGL((k_conv3x3<S, TH, TW, BN, WM, WN>), dim3((unsigned)blocks), dim3(CONV_THREADS), 0, st, p);
@@ -457,6 +493,7 @@ extern "C" int pcp_pointwise(const pcp_pointwise_t *d, const float *in, const fl
   p.cin = d->cin; p.cout = d->cout; p.cout_pad = d->cout_pad;
   p.ld_in = d->ld_in; p.ld_out = d->ld_out; p.relu = d->relu;
   p.n_tiles = 0;
+  p.vec_out = (d->ld_out % 4 == 0 && (((uintptr_t)out) & 15) == 0) ? 1 : 0;
   switch (d->mode) {
     case PCP_PW_PLAIN:
       if (d->rows <= 0) return d->rows == 0 ? PCP_OK : PCP_ERR_ARG;
