@@ -455,7 +455,7 @@ class AbiTimer:
         return out
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
+PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json')
 
 
 def pmc_traffic(config, kernel_label):

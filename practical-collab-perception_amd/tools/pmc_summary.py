@@ -10,7 +10,7 @@ from collections import defaultdict
 
 # kernel label -> the source file whose SHA-256 is recorded next to the counters: bench.py reports `traffic` only while that file is
 # unchanged (a kernel edited after the PMC pass would otherwise keep quoting stale bytes)
-SOURCES = {'k_wino4f': 'wino4f.hip', 'k_wino4h': 'wino4h.hip', 'k_conv3x3_wino<1>': 'wino.hip', 'k_conv3x3_wino<2>': 'wino.hip', 'k_wino_ws': 'wino_ws.hip',
+SOURCES = {'k_wino4f': 'wino4f.hip', 'k_wino4h': 'wino4h.hip', 'k_wino4c': 'wino4c.hip', 'k_conv3x3_wino<1>': 'wino.hip', 'k_conv3x3_wino<2>': 'wino.hip', 'k_wino_ws': 'wino_ws.hip',
            'k_w4_gemm': 'wino4.hip', 'k_w4_input': 'wino4.hip', 'k_w4_output': 'wino4.hip', 'k_conv3x3_direct<s1>': 'conv.hip',
            'k_conv3x3_direct<s2>': 'conv.hip', 'k_pointwise<plain>': 'conv.hip', 'k_pointwise<conv_k2s2>': 'conv.hip',
            'k_pointwise<convT_k2s2>': 'conv.hip', 'k_pfn': 'pfn.hip', 'k_sparse_conv_s2': 'sparseconv.hip', 'k_point_head': 'pointhead.hip',
@@ -29,7 +29,7 @@ def source_sha(label):
 
 
 # substring of the rocprof kernel name -> bench.py label key
-KEYS = [('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_conv3x3_wino<2>', 'k_conv3x3_wino<2>'), ('k_wino4f', 'k_wino4f'), ('k_wino4h', 'k_wino4h'), ('k_wino_ws', 'k_wino_ws'),
+KEYS = [('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_conv3x3_wino<2>', 'k_conv3x3_wino<2>'), ('k_wino4f', 'k_wino4f'), ('k_wino4h', 'k_wino4h'), ('k_wino4c', 'k_wino4c'), ('k_wino_ws', 'k_wino_ws'),
         ('k_w4_gemm', 'k_w4_gemm'), ('k_w4_input', 'k_w4_input'), ('k_w4_output', 'k_w4_output'),
         ('k_conv3x3<1,', 'k_conv3x3_direct<s1>'), ('k_conv3x3<2,', 'k_conv3x3_direct<s2>'),
         ('k_pointwise<0', 'k_pointwise<plain>'), ('k_pointwise<1', 'k_pointwise<conv_k2s2>'), ('k_pointwise<2', 'k_pointwise<convT_k2s2>'),
