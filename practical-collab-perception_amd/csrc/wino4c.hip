@@ -1,7 +1,7 @@
 // a6 / a7 / a12 -- 3x3 stride-1 convolution as fused Winograd F(4x4, 3x3), two four-wave workgroups per CU, waves split over OUTPUT CHANNELS
 // (round 4).
 //
-// k_wino4c (wino4h.hip) splits the 36 Winograd positions over its four waves, so the output transform Y = A^T M A needs values from all four
+// k_wino4h (wino4h.hip) splits the 36 Winograd positions over its four waves, so the output transform Y = A^T M A needs values from all four
 // waves: accumulators -> LDS (a 73.7 KB image per 32-channel half) -> two barriers per half -> transform -> stores, 11 % of an item's time
 // (19 % on the 64 -> 64 layers) and the reason the kernel needs the LDS twice over.  Here wave w owns the 16 output channels 16w .. 16w + 15
 // of the item at ALL 36 positions (36 accumulator blocks of v_mfma_f32_16x16x4_f32, rows = channels, columns = the 16 tiles): a lane ends
@@ -9,11 +9,11 @@
 // in registers and leave as sixteen 16-byte stores per lane -- no LDS image, no barrier, and a wave that is done with its multiplies does
 // not wait for the others.
 //
-//   item / workgroup / slices / input transform / raw staging: exactly k_wino4c (16 x 16 output pixels x 64 output channels, 8-channel
+//   item / workgroup / slices / input transform / raw staging: exactly k_wino4h (16 x 16 output pixels x 64 output channels, 8-channel
 //              slices, V[pos][k][tile] in LDS, one barrier per slice in front of the slice's last block)
 //   A operand = U^T fragments from L2: [cin/8][cout_pad/16][18 position pairs][64 lanes][4 = (position parity, k step)] -- a wave's slice is
 //              one 18-KB run, one 16-byte load per lane and position PAIR (pack.repack_winograd4f_to_4c)
-//   B operand = V[pos][k][tile]: one ds_read2st64_b32 per position (all 36 positions per wave: four times k_wino4c's LDS reads, still
+//   B operand = V[pos][k][tile]: one ds_read2st64_b32 per position (all 36 positions per wave: four times k_wino4h's LDS reads, still
 //              under a quarter of the LDS bandwidth)
 //   a slice = nine fenced blocks of four positions (eight MFMAs: k step 0 of the four, then k step 1 -- dependent MFMAs are four apart)
 //   LDS: 69 KB per workgroup (raw x2, V x2).
@@ -21,6 +21,7 @@
 // Same arithmetic as k_wino4c (same products, same k order); only the output transform's summation runs per lane instead of per thread pair
 // -- identical operations in identical order, so the outputs are bit-identical to k_wino4c's (tests/test_gpu_ops.py).
 #include "pcp_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifdef H4_STAMP
@@ -100,30 +101,44 @@ __device__ __forceinline__ int xcd_remap_h4(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// B^T x for the 6-point transform (points 0, +-1, +-2, inf)
+// B^T x for the 6-point transform (points 0, +-1, +-2, inf).  Contraction is spelt out (no compiler-chosen fma grouping): k_wino4h and both
+// forms of k_wino4c run exactly these operations, so their outputs agree bit for bit.
 __device__ __forceinline__ void h4_bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
                                        float (&t)[6]) {
-  const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+#pragma clang fp contract(off)
+  const float p = __builtin_fmaf(-4.f, d2, d4), q = __builtin_fmaf(-4.f, d1, d3);
   const float r = d4 - d2, s = 2.f * (d3 - d1);
-  t[0] = 4.f * d0 - 5.f * d2 + d4;
+  t[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
   t[1] = p + q;
   t[2] = p - q;
   t[3] = r + s;
   t[4] = r - s;
-  t[5] = 4.f * d1 - 5.f * d3 + d5;
+  t[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
 }
 
-// A^T m for float4 lanes: 6 -> 4
+// A^T m for float4 lanes: 6 -> 4 (same rule: explicit fma)
 __device__ __forceinline__ void h4_at6v(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, const f32x4 m5,
                                         f32x4 (&y)[4]) {
+#pragma clang fp contract(off)
   const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-  y[0] = m0 + s12 + s34;
-  y[1] = d12 + 2.f * d34;
-  y[2] = s12 + 4.f * s34;
-  y[3] = d12 + 8.f * d34 + m5;
+  const f32x4 c2 = f32x4{2.f, 2.f, 2.f, 2.f}, c4 = f32x4{4.f, 4.f, 4.f, 4.f}, c8 = f32x4{8.f, 8.f, 8.f, 8.f};
+  y[0] = (m0 + s12) + s34;
+  y[1] = __builtin_elementwise_fma(c2, d34, d12);
+  y[2] = __builtin_elementwise_fma(c4, s34, s12);
+  y[3] = __builtin_elementwise_fma(c8, d34, d12) + m5;
 }
 
-__global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
+// NW = waves per workgroup = 16-channel blocks per item.  NW = 4 (the default): 64-channel items, two workgroups per CU.  NW = 8 (opt-in,
+// see the launcher): 128-channel items, ONE eight-wave workgroup per CU -- the eight waves share one V image, so the input transform and the
+// raw staging are done once per 128 output channels instead of once per 64 (waves 0-3 transform, all eight stage the raw patch and multiply).
+// On this chip every non-MFMA instruction of a SIMD's waves costs matrix-pipe time (profiles/experiments/r04_wino4s); halving them per
+// product buys 3 - 4 % per layer, which the exposed prologue of a single workgroup per CU gives back inside the pipelined step.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_wino4c(H4Params p) {
+  constexpr int THREADS = NW * 64;
+  constexpr int RAW_PER = (H4_RAW_ITEMS + THREADS - 1) / THREADS;            // 3 | 2
+  constexpr int WBN = NW * 16;                                              // output channels per item
+  constexpr int URING = NW == 4 ? H4_URING : 2;     // blocks the U fragments are requested ahead (the eight-wave form spills at 3)
   __shared__ __attribute__((aligned(16))) float lds[H4_LDS_FLOATS];
   float *rawb = lds;                            // [2][H4_RAW_FLOATS]
   float *vb = lds + 2 * H4_RAW_FLOATS;          // [2][H4_V_FLOATS]
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
 #endif
   const int lid = xcd_remap_h4(blockIdx.x, gridDim.x);
 #ifdef H4_N_FAST
-  const int n_blocks = p.cout_pad / H4_WBN;     // N tile as the fast index: the workgroups sharing a raw patch run together on one XCD
+  const int n_blocks = p.cout_pad / WBN;     // N tile as the fast index: the workgroups sharing a raw patch run together on one XCD
   const int nt = lid % n_blocks;
   int sp = lid / n_blocks;
 #else
@@ -157,15 +172,15 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
   const int tile_y = sp % p.tiles_y;
   const int b = sp / p.tiles_y;
   const int oy0 = tile_y * 16, ox0 = tile_x * 16;
-  const int n0 = nt * H4_WBN;
+  const int n0 = nt * WBN;
 
   // ---- raw patch staging (as in wino4f: clamped / out-of-range buffer offsets, static load count) ---------------------------------------
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
-  unsigned roff[H4_RAW_PER];
-  int rdst[H4_RAW_PER];
+  unsigned roff[RAW_PER];
+  int rdst[RAW_PER];
 #pragma unroll
-  for (int i = 0; i < H4_RAW_PER; i++) {
-    int idx = tid + i * H4_THREADS;
+  for (int i = 0; i < RAW_PER; i++) {
+    int idx = tid + i * THREADS;
     if (idx >= H4_RAW_ITEMS) idx -= H4_RAW_ITEMS;          // surplus threads repeat an item
     const int q = idx & 1, pix = idx >> 1;
     const int py = pix / H4_RAW_W, px = pix % H4_RAW_W;
@@ -174,20 +189,20 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
     roff[i] = 0x80000000u;                                 // out of range -> 0
     if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) roff[i] = (unsigned)((((long long)(b * p.h + iy) * p.w + ix) * p.ld_in + q * 4) * 4);
   }
-  f32x4 rreg[H4_RAW_PER];
+  f32x4 rreg[RAW_PER];
   auto raw_load = [&](int slice) {
 #ifdef H4_DIAG_NO_RLOAD
     if (slice > 2) return;                                   // timing-only build: no raw loads in the main loop (the LDS stores of stale registers stay)
 #endif
     const int soff = slice * (H4_CK * 4);
 #pragma unroll
-    for (int i = 0; i < H4_RAW_PER; i++)
+    for (int i = 0; i < RAW_PER; i++)
       rreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)roff[i], soff, 0));
   };
   auto raw_store = [&](int buf) {
     float *dst = rawb + buf * H4_RAW_FLOATS;
 #pragma unroll
-    for (int i = 0; i < H4_RAW_PER; i++) {
+    for (int i = 0; i < RAW_PER; i++) {
       const f32x4 v = rreg[i];
       dst[rdst[i]] = v.x;
       dst[rdst[i] + H4_PLANE] = v.y;
@@ -198,7 +213,8 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
 
   // ---- input transform: item = (tile, channel) on the lane pair (l, l + 32); wave w owns channels 2w, 2w + 1 of all 16 tiles ------------
   const int t_li = lane & 31;
-  const int t_tile = t_li & 15, t_ch = 2 * wave + (t_li >> 4);
+  const bool tf = NW == 4 || wave < 4;                    // this wave runs the input transform (wave-uniform)
+  const int t_tile = t_li & 15, t_ch = 2 * (wave & 3) + (t_li >> 4);
   const int t_src = t_ch * H4_PLANE + (4 * (t_tile >> 2) + 3 * h) * H4_RP + 4 * (t_tile & 3);
   const int t_dst = t_ch * 16 + t_tile + (3 * h) * H4_VP;
   auto transform = [&](int rbuf, int vbuf) {
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
   const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u), 0, p.u_bytes, 0x00020000);
   const int u_lane = lane * 16;                                                       // bytes, per lane
   const int u_slice = (p.cout_pad / 16) * (18 * 64 * 4 * 4);                          // bytes between slices
-  const int u_base = (nt * 4 + wave) * (18 * 64 * 4 * 4);                             // wave-uniform: this wave's 16-channel block
+  const int u_base = (nt * NW + wave) * (18 * 64 * 4 * 4);                             // wave-uniform: this wave's 16-channel block
   const int n_slices = p.cin / H4_CK;
   const int last = n_slices - 1;
   f32x4 uq[18];
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
 #endif
 
   // One pipeline step = nine fenced blocks (wino4f's round-3 schedule): block pi = position pi's eight MFMAs + the V read H4_VRING positions
-  // ahead + the U fragment H4_URING positions ahead (wrapping into the next slice) + one ninth of the slice's other work.
+  // ahead + the U fragment URING positions ahead (wrapping into the next slice) + one ninth of the slice's other work.
   auto step_blocks = [&](int s, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     const int cur = s & 1, nxt = cur ^ 1;
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
       }
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        const int q = 2 * (pi + H4_URING) + e;
+        const int q = 2 * (pi + URING) + e;
         if (q < 18) u_load(s, q);
         else if (!LAST) u_load(s + 1, q - 18);
       }
@@ -336,21 +352,14 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
     float wr[3][6];
     float top[3][3], bot[3][3];
     auto other = [&](int blk) {
-#ifdef H4_DIAG_NO_RAW
-      if (blk == 1) h4_bt6(lo[0].x, lo[0].y, lo[0].z, lo[0].w, hi[0].x, hi[0].y, wr[0]);      // timing-only build: no raw staging at all
-      if (blk == 2) h4_bt6(lo[1].x, lo[1].y, lo[1].z, lo[1].w, hi[1].x, hi[1].y, wr[1]);
-      if (blk == 3) h4_bt6(lo[2].x, lo[2].y, lo[2].z, lo[2].w, hi[2].x, hi[2].y, wr[2]);
-#elif defined(H4_RAW_EARLY)
-      if (blk == 0) { rstore(0); rstore(1); rstore(2); raw_load(min(s + 3, last)); }       // three more blocks of flight time for the raw patch
+      if (blk == 0) rstore(0);
+      if (blk == 1) rstore(1);
+      if (blk == 2 && RAW_PER > 2) rstore(RAW_PER > 2 ? 2 : 0);
+      if (blk == 3) raw_load(min(s + 3, last));
+      if (!tf) return;
       if (blk == 1) h4_bt6(lo[0].x, lo[0].y, lo[0].z, lo[0].w, hi[0].x, hi[0].y, wr[0]);
       if (blk == 2) h4_bt6(lo[1].x, lo[1].y, lo[1].z, lo[1].w, hi[1].x, hi[1].y, wr[1]);
       if (blk == 3) h4_bt6(lo[2].x, lo[2].y, lo[2].z, lo[2].w, hi[2].x, hi[2].y, wr[2]);
-#else
-      if (blk == 0) rstore(0);
-      if (blk == 1) { h4_bt6(lo[0].x, lo[0].y, lo[0].z, lo[0].w, hi[0].x, hi[0].y, wr[0]); rstore(1); }
-      if (blk == 2) { h4_bt6(lo[1].x, lo[1].y, lo[1].z, lo[1].w, hi[1].x, hi[1].y, wr[1]); rstore(2); }
-      if (blk == 3) { h4_bt6(lo[2].x, lo[2].y, lo[2].z, lo[2].w, hi[2].x, hi[2].y, wr[2]); raw_load(min(s + 3, last)); }
-#endif
       if (blk == 4) {
 #pragma unroll
         for (int rr = 0; rr < 3; rr++)
@@ -400,10 +409,12 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
             vq[i][j][1] = vn[(4 * i + j) * H4_VP + 64];
           }
         }
+      if (tf) {
 #pragma unroll
-      for (int rr = 0; rr < 3; rr++) {
-        lo[rr] = *reinterpret_cast<const f32x4 *>(tn + rr * H4_RP);
-        hi[rr] = *reinterpret_cast<const float2 *>(tn + rr * H4_RP + 4);
+        for (int rr = 0; rr < 3; rr++) {
+          lo[rr] = *reinterpret_cast<const f32x4 *>(tn + rr * H4_RP);
+          hi[rr] = *reinterpret_cast<const float2 *>(tn + rr * H4_RP + 4);
+        }
       }
       fence();
       mm(8);
@@ -442,16 +453,16 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
 
   // ---- prologue: raw(0), raw(1) -> LDS; V(0); rreg <- raw(2); first U fragments -----------------------------------------------------------
   {
-    f32x4 r0[H4_RAW_PER];
+    f32x4 r0[RAW_PER];
     raw_load(0);
 #pragma unroll
-    for (int i = 0; i < H4_RAW_PER; i++) r0[i] = rreg[i];
+    for (int i = 0; i < RAW_PER; i++) r0[i] = rreg[i];
     raw_load(min(1, last));
 #pragma unroll
-    for (int q = 0; q < 2 * H4_URING; q++) u_load(0, q);
+    for (int q = 0; q < 2 * URING; q++) u_load(0, q);
     float *dst = rawb;
 #pragma unroll
-    for (int i = 0; i < H4_RAW_PER; i++) {
+    for (int i = 0; i < RAW_PER; i++) {
       const f32x4 v = r0[i];
       dst[rdst[i]] = v.x;
       dst[rdst[i] + H4_PLANE] = v.y;
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
     raw_load(min(2, last));
   }
   __syncthreads();
-  transform(0, 0);
+  if (tf) transform(0, 0);
   __syncthreads();
 #ifdef H4_EARLY_BARRIER
 #pragma unroll
@@ -472,10 +483,12 @@ __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4c(H4Params p) {
       vq[i][j][0] = vb[v_off + (4 * i + j) * H4_VP];
       vq[i][j][1] = vb[v_off + (4 * i + j) * H4_VP + 64];
     }
+  if (tf) {
 #pragma unroll
-  for (int rr = 0; rr < 3; rr++) {                       // raw(1) for the transform that runs beside slice 0 (a dead read when cin = 8)
-    lo[rr] = *reinterpret_cast<const f32x4 *>(rawb + H4_RAW_FLOATS + t_src + rr * H4_RP);
-    hi[rr] = *reinterpret_cast<const float2 *>(rawb + H4_RAW_FLOATS + t_src + rr * H4_RP + 4);
+    for (int rr = 0; rr < 3; rr++) {                     // raw(1) for the transform that runs beside slice 0 (a dead read when cin = 8)
+      lo[rr] = *reinterpret_cast<const f32x4 *>(rawb + H4_RAW_FLOATS + t_src + rr * H4_RP);
+      hi[rr] = *reinterpret_cast<const float2 *>(rawb + H4_RAW_FLOATS + t_src + rr * H4_RP + 4);
+    }
   }
 #endif
 
@@ -560,9 +573,18 @@ extern "C" int pcp_conv3x3_winograd4c(const pcp_conv3x3_t *d, const float *in, c
   if (rc != PCP_OK) return rc;
   if ((((uintptr_t)in) & 15) || (((uintptr_t)u_packed) & 15) || (((uintptr_t)out) & 15) || (((uintptr_t)bias) & 15)) return PCP_ERR_ARG;
   p.in = in; p.u = u_packed; p.bias = bias; p.out = out;
-  const long long blocks = (long long)p.n_spatial * (d->cout_pad / H4_WBN);
+  // The 128-channel form (one eight-wave workgroup per CU, the input transform shared by all eight waves) is OPT-IN (PCP_WINO4C_NW=8, needs
+  // cout_pad % 128 == 0): interleaved per-layer timing has it 3 - 4 % ahead of the 64-channel form on the 128^2 maps (B20 128->128: 308.7 ->
+  // 297.6 us) and 15 - 28 % behind on 64^2 maps whose 128-channel items cover the chip 0.5 or 1.25 times; inside bench.py -- two replicas'
+  // kernels sharing the chip -- a dispatch rule that picks it only where it wins measured 374.6 against 376.6 frames/s without it, so the
+  // default stays the 64-channel form (profiles/r04_wino4c_ab.txt).  Same weights, same bits.
+  const char *env = getenv("PCP_WINO4C_NW");
+  const bool wide = env && atoi(env) == 8;
+  if (wide && d->cout_pad % 128 != 0) return PCP_ERR_UNSUPPORTED;
+  const long long blocks = (long long)p.n_spatial * (d->cout_pad / (wide ? 128 : 64));
   if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
-  hipLaunchKernelGGL(k_wino4c, dim3((unsigned)blocks), dim3(H4_THREADS), 0, (hipStream_t)stream_, p);
+  if (wide) hipLaunchKernelGGL(k_wino4c<8>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream_, p);
+  else hipLaunchKernelGGL(k_wino4c<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -102,27 +102,31 @@ __device__ __forceinline__ int xcd_remap_h4(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// B^T x for the 6-point transform (points 0, +-1, +-2, inf)
+// B^T x for the 6-point transform (points 0, +-1, +-2, inf).  Contraction is spelt out (no compiler-chosen fma grouping): k_wino4h and both
+// forms of k_wino4c run exactly these operations, so their outputs agree bit for bit.
 __device__ __forceinline__ void h4_bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
                                        float (&t)[6]) {
-  const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+#pragma clang fp contract(off)
+  const float p = __builtin_fmaf(-4.f, d2, d4), q = __builtin_fmaf(-4.f, d1, d3);
   const float r = d4 - d2, s = 2.f * (d3 - d1);
-  t[0] = 4.f * d0 - 5.f * d2 + d4;
+  t[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
   t[1] = p + q;
   t[2] = p - q;
   t[3] = r + s;
   t[4] = r - s;
-  t[5] = 4.f * d1 - 5.f * d3 + d5;
+  t[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
 }
 
-// A^T m for float4 lanes: 6 -> 4
+// A^T m for float4 lanes: 6 -> 4 (same rule: explicit fma)
 __device__ __forceinline__ void h4_at6v(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, const f32x4 m5,
                                         f32x4 (&y)[4]) {
+#pragma clang fp contract(off)
   const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-  y[0] = m0 + s12 + s34;
-  y[1] = d12 + 2.f * d34;
-  y[2] = s12 + 4.f * s34;
-  y[3] = d12 + 8.f * d34 + m5;
+  const f32x4 c2 = f32x4{2.f, 2.f, 2.f, 2.f}, c4 = f32x4{4.f, 4.f, 4.f, 4.f}, c8 = f32x4{8.f, 8.f, 8.f, 8.f};
+  y[0] = (m0 + s12) + s34;
+  y[1] = __builtin_elementwise_fma(c2, d34, d12);
+  y[2] = __builtin_elementwise_fma(c4, s34, s12);
+  y[3] = __builtin_elementwise_fma(c8, d34, d12) + m5;
 }
 
 __global__ __launch_bounds__(H4_THREADS, 2) void k_wino4h(H4Params p) {

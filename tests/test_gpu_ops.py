@@ -606,18 +606,27 @@ def test_conv3x3_winograd4f_channel_windows_and_bad_arguments(kernel):
         run(x, packed.to(d), bp.to(d), cin, cout, cpad, relu=False, out=out, in_ch_off=2)
 
 
-@pytest.mark.parametrize('cin,cout,h,w,batch', [(64, 64, 32, 32, 1), (128, 128, 48, 80, 2), (16, 52, 37, 50, 2), (384, 64, 16, 32, 1), (72, 132, 20, 100, 3)])
-def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch):
-    """k_wino4c multiplies the same products in the same k order as k_wino4h and runs the same output transform per lane: bitwise equal"""
+@pytest.mark.parametrize('nw', ['4', '8'])
+@pytest.mark.parametrize('cin,cout,h,w,batch', [(64, 64, 32, 32, 1), (128, 128, 48, 80, 2), (16, 52, 37, 50, 2), (384, 64, 16, 32, 1), (72, 132, 20, 100, 3),
+                                                 (64, 384, 33, 47, 1), (8, 128, 16, 16, 1)])
+def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch, nw, monkeypatch):
+    """k_wino4c multiplies the same products in the same k order as k_wino4h and runs the same transform operations per lane: bitwise equal,
+    in its 64-channel form (two four-wave workgroups per CU) and in its 128-channel form (one eight-wave workgroup, shared input transform;
+    PCP_WINO4C_NW forces a form, the 128-channel one exists where cout_pad is a multiple of 128)"""
     ops = _ops()
-    from pcp_amd import pack
+    from pcp_amd import lib, pack
     d = dev()
+    monkeypatch.setenv('PCP_WINO4C_NW', nw)
     x = ops.as_nhwc(torch.from_numpy(_rand(291, (batch, cin, h, w))).to(d))
     wt = torch.from_numpy(_rand(292, (cout, cin, 3, 3), -0.05, 0.05))
     b = torch.from_numpy(_rand(293, (cout,), -0.2, 0.2))
     uh, bh, cph = pack.pack_conv3x3_winograd4h(wt, b)
     uc, bc, cpc = pack.pack_conv3x3_winograd4c(wt, b)
     oh = ops.conv3x3_winograd4h(x, uh.to(d), bh.to(d), cin, cout, cph, relu=True)
+    if nw == '8' and cpc % 128 != 0:
+        with pytest.raises(lib.PcpError):
+            ops.conv3x3_winograd4c(x, uc.to(d), bc.to(d), cin, cout, cpc, relu=True)
+        return
     oc = ops.conv3x3_winograd4c(x, uc.to(d), bc.to(d), cin, cout, cpc, relu=True)
     torch.cuda.synchronize()
     assert torch.equal(oh, oc) and float(oh.abs().max()) > 0
