@@ -265,7 +265,7 @@ def test_bench_pipelined_default_and_batch_by_batch_agree(tmp_path):
     assert piped['config']['final_boxes_last_step'] == plain['config']['final_boxes_last_step'] > 0
     assert piped['roofline']['kernel'] == plain['roofline']['kernel'] and piped['roofline']['next_mfma_kernels']
     rows = table.read_text().splitlines()
-    assert rows[0].split()[:2] == ['kernel', 'shape'] and any(r.startswith('k_wino4h') for r in rows[1:])
+    assert rows[0].split()[:2] == ['kernel', 'shape'] and any(r.startswith('k_wino4c') for r in rows[1:])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
