@@ -110,6 +110,42 @@ def test_disco_mid_fusion_matches_reference_outputs():
     _check_postprocessing_is_exact(model, g, 'head_', 2, ['final_boxes_%d', 'final_scores_%d', 'post_%d_near_iou', 'post_%d_near_score'])
 
 
+def test_disco_inference_under_opt_in_bf16_arithmetic_stays_typed_and_close(monkeypatch):
+    """PCP_CONV_ALGO=bf16 in INFERENCE (bench.py --optin; not the headline): bf16 activation storage between the conv layers, the agents' maps
+    bf16 into the compressor.  Every map that leaves the conv stacks towards an fp32-only kernel (warp, fusion, head tail, decode) must be
+    float32 again -- a bf16 map read as float runs past its end (the fp32 wrappers reject it) -- and the results stay within bf16 noise of the
+    reference's float32 maps (2 % of each map's scale; the 1e-3 bar belongs to the fp32 path)."""
+    monkeypatch.setenv('PCP_CONV_ALGO', 'bf16')
+    from pcp_amd import lib, ops
+    g = load_golden('g1_disco.npz')
+    model = _build(g)
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0']}}]
+    batch = {'points': torch.from_numpy(g['points']).cuda(), 'batch_size': 2, 'metadata': metadata}
+    calls = []
+    from pcp_amd import train_ops as tops
+    orig = tops.mp_conv3x3
+    monkeypatch.setattr(tops, 'mp_conv3x3', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad():
+        pred_dicts, _ = model(batch)
+    torch.cuda.synchronize()
+    assert len(calls) >= 15                                                      # the bf16 kernels really ran
+    assert batch['spatial_features_2d'].dtype == torch.float32
+    assert batch['bev_img_early'].dtype == torch.float32                         # the distillation teacher's map is consumed by an fp32 kernel
+    for name, want in (('spatial_features_2d', g['spatial_features_2d']),):
+        got = batch[name].float().cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max(), name
+    hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        want = g['head_' + name]
+        assert hd[name].dtype == torch.float32
+        assert np.abs(hd[name].cpu().numpy() - want).max() <= 2e-2 * max(np.abs(want).max(), 1.0), name
+    assert all(p['pred_boxes'].shape[0] > 0 for p in pred_dicts)
+    # the typed guard: an fp32-only wrapper handed a bf16 map raises instead of reading past its end
+    with pytest.raises(lib.PcpError):
+        ops.warp_nearest_batch([(torch.zeros((8, 8, 16), dtype=torch.bfloat16, device='cuda'), torch.zeros((8, 8, 16), device='cuda'),
+                                 [1.0, 0.0, 0.0, 0.0, 1.0, 0.0])], 16)
+
+
 @pytest.mark.parametrize('tag', ['car', 'disco'])
 def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monkeypatch):
     """the mini geometry never reaches the workgroup count at which `auto` picks the F(4x4,3x3) path (csrc/wino4.hip); force it on every
