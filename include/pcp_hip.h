@@ -77,6 +77,10 @@ int pcp_voxelize_cells_ready(const float *points, int64_t n, int32_t row_stride,
  * ------------------------------------------------------------------------------------------------------------------ */
 /* A processing order for per-point kernels that gather from BEV maps: order[0..N') = the pillariser's bucket order (spatially
  * sorted), then the rows it masked; every row exactly once.  Must follow pcp_voxelize on the same workspace.  cursor_scratch: 1 int. */
+/* Sorts the points of every pillar by row index inside the bucket order pcp_voxelize left in `workspace` (their slots come from an atomic
+ * and differ from run to run; inference results do not depend on them, the training path's per-point GEMMs sum in this order): after it
+ * the bucket order is a function of the input alone.  Must follow pcp_voxelize on the same workspace and stream. */
+int pcp_voxelize_sort_pillar_rows(const pcp_grid_t *grid, void *workspace, int64_t n, void *stream);
 int pcp_voxelize_row_order(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t *order, int32_t *cursor_scratch,
                            void *stream);
 

@@ -655,6 +655,42 @@ __global__ __launch_bounds__(256) void k_row_order(const int *__restrict__ point
 }
 }  // namespace
 
+// ---- reproducible bucket order (training) ---------------------------------------------------------------------------------------------------
+// A point's slot inside its pillar comes from the histogram atomic of pass 1, so the ORDER of a pillar's points in the bucket order changes
+// from run to run.  Inference does not see it (per-pillar max / fixed-point mean are order independent); the training path's per-point
+// GEMMs sum over the rows in bucket order, so their last bits would.  One thread per pillar sorts its run by point index (runs are a few
+// points long; insertion sort): the bucket order becomes a function of the input alone.
+namespace {
+__global__ __launch_bounds__(256) void k_sort_runs(const int *__restrict__ pillar_start, const int *__restrict__ counters,
+                                                  int *__restrict__ bucket_order) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= counters[0]) return;
+  const int s0 = pillar_start[p], s1 = pillar_start[p + 1];
+  for (int i = s0 + 1; i < s1; ++i) {
+    const int v = bucket_order[i];
+    int j = i - 1;
+    while (j >= s0 && bucket_order[j] > v) {
+      bucket_order[j + 1] = bucket_order[j];
+      --j;
+    }
+    bucket_order[j + 1] = v;
+  }
+}
+}  // namespace
+
+extern "C" int pcp_voxelize_sort_pillar_rows(const pcp_grid_t *grid, void *workspace, int64_t n, void *stream_) {
+  if (!grid || !workspace || n < 0) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  const VoxLayout L = pcp_vox_layout(cells, n);
+  char *ws = (char *)workspace;
+  const int64_t max_pillars = n < cells ? n : cells;
+  hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((max_pillars + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const int *)(ws + L.pillar_start), (const int *)(ws + L.counters), (int *)(ws + L.bucket_order));
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
 extern "C" int pcp_voxelize_row_order(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t *order, int32_t *cursor_scratch,
                                       void *stream_) {
   if (!grid || !workspace || !order || !cursor_scratch || n < 0) return PCP_ERR_ARG;

@@ -207,42 +207,77 @@ constexpr int PW_ROWS = 128;
 __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_pw(WgPwParams p) {
   __shared__ float aT[PW_ROWS * TILE_C];
   __shared__ float bT[PW_ROWS * TILE_C];
+  constexpr int PER = PW_ROWS * 16 / WG_THREADS;            // float4 items per thread, chunk and operand (8)
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int hl = lane >> 5, l32 = lane & 31;
   const int n0 = (blockIdx.x / p.k_tiles) * TILE_C, k0 = (blockIdx.x % p.k_tiles) * TILE_C;
-  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+  // quadrants of the 64 x 64 tile that hold channels: 1, 2 or 4 (a 32 x 16 layer has one).  With fewer than four, the idle waves take a
+  // share of the chunk's ROWS for the same quadrant (the MFMA count per chunk is what bounds narrow layers: 64 per wave whatever the
+  // channels) and the partial accumulators are summed through LDS in wave order at the end.
+  const int qn = (p.a.ch - n0 > 32) ? 2 : 1, qk = (p.b.ch - k0 > 32) ? 2 : 1;
+  const int nq = qn * qk, parts = 4 / nq;
+  const int quad = wave % nq, part = wave / nq;
+  const int wn = (qk == 2 ? (quad >> 1) : quad) * 32, wk = (qk == 2 ? (quad & 1) : 0) * 32;
+  const int kk0 = part * (PW_ROWS / 2 / parts), kk1 = kk0 + PW_ROWS / 2 / parts;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int chunk = blockIdx.y; chunk < p.chunks; chunk += p.nsplit) {
+  // the rows of chunk c + 1 are requested before the 64 MFMAs of chunk c and stored to LDS after them (one set of registers in flight):
+  // the synchronous form exposed a full memory latency per 128 rows (rows = 1.4 M in the PFN: 346 -> see profiles/r04_wgrad_pw_prefetch.txt)
+  float4 ra[PER], rb[PER];
+  auto fetch = [&](int chunk) {
     const long long r0 = (long long)chunk * PW_ROWS;
-    __syncthreads();
-    for (int i = tid; i < PW_ROWS * 16; i += WG_THREADS) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * WG_THREADS;
       const int rr = i >> 4, q = i & 15;
       const long long r = r0 + rr;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[u] = ra[u];
       if (r < p.rows) {
-        if (n0 + q * 4 < p.a.ch) va = *reinterpret_cast<const float4 *>(p.a.ptr + map_row(p.a, r) * p.a.ld + n0 + q * 4);
-        if (k0 + q * 4 < p.b.ch) vb = *reinterpret_cast<const float4 *>(p.b.ptr + map_row(p.b, r) * p.b.ld + k0 + q * 4);
+        if (n0 + q * 4 < p.a.ch) ra[u] = *reinterpret_cast<const float4 *>(p.a.ptr + map_row(p.a, r) * p.a.ld + n0 + q * 4);
+        if (k0 + q * 4 < p.b.ch) rb[u] = *reinterpret_cast<const float4 *>(p.b.ptr + map_row(p.b, r) * p.b.ld + k0 + q * 4);
       }
-      *reinterpret_cast<float4 *>(aT + rr * TILE_C + q * 4) = va;
-      *reinterpret_cast<float4 *>(bT + rr * TILE_C + q * 4) = vb;
+    }
+  };
+  int chunk = blockIdx.y;
+  if (chunk < p.chunks) fetch(chunk);
+  for (; chunk < p.chunks; chunk += p.nsplit) {
+    __syncthreads();                              // every wave is done with the previous chunk's tiles
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * WG_THREADS;
+      const int rr = i >> 4, q = i & 15;
+      *reinterpret_cast<float4 *>(aT + rr * TILE_C + q * 4) = ra[u];
+      *reinterpret_cast<float4 *>(bT + rr * TILE_C + q * 4) = rb[u];
     }
     __syncthreads();
+    if (chunk + p.nsplit < p.chunks) fetch(chunk + p.nsplit);
 #pragma unroll 8
-    for (int kk = 0; kk < PW_ROWS / 2; ++kk) {
+    for (int kk = kk0; kk < kk1; ++kk) {
       const int rr = 2 * kk + hl;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aT[rr * TILE_C + wn + l32], bT[rr * TILE_C + wk + l32], acc, 0, 0, 0);
     }
   }
   float *out = p.part + (long long)blockIdx.y * p.n_r * p.k_r;
+  if (parts > 1) {
+    __syncthreads();                              // the tiles are dead: aT becomes [wave][16][64 lanes]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aT[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (part != 0) return;
+    for (int o = 1; o < parts; ++o)               // fixed order: parts 1, 2, 3 of this quadrant
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += aT[((quad + o * nq) * 16 + r) * 64 + lane];
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = n0 + wn + (r >> 2) * 8 + hl * 4 + (r & 3);
     out[(long long)n * p.k_r + k0 + wk + l32] = acc[r];
   }
+  // (quadrants without channels are not written: k_wgrad_pw_reduce reads n < channels, k < channels only)
 }
 
 __global__ __launch_bounds__(256) void k_wgrad_pw_reduce(const float *__restrict__ part, int nsplit, int n, int k, int n_r, int k_r,

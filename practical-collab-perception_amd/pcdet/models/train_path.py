@@ -71,6 +71,7 @@ class VFETrain:
         dev = points.device
         grid = ops.make_grid(m.point_cloud_range, m.voxel_size, m.grid_size, batch_size)
         vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False)
+        ops.voxelize_sort_pillar_rows(vox)                                  # reproducible row order for the per-point GEMMs (atomic slots otherwise)
         P, Nk = (int(v) for v in vox.counters[:2].tolist())                # host sync: row counts of the per-point GEMMs
         n = max(points.shape[0], 1)
         w = self._weights()

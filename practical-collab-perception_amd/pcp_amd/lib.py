@@ -189,6 +189,7 @@ SYMBOLS = {
     'pcp_hunter_point_head_ex': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp, vp, vp, vp,
                                          vp, c_i32, c_i32, vp, c_i32, vp, vp, vp, c_i32, c_f, vp, vp]),
     'pcp_voxelize_row_order': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp, vp]),
+    'pcp_voxelize_sort_pillar_rows': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp]),
     'pcp_hunter_apply_flow': (c_i32, [vp, c_i64, c_i32, vp, c_i32, c_f, vp, vp]),
     'pcp_select_transform_points': (c_i32, [vp, c_i64, c_i32, c_i32, c_f, c_i32, ctypes.POINTER(c_f), ctypes.POINTER(ctypes.c_uint8),
                                             vp, c_i32, vp]),

@@ -531,6 +531,13 @@ def disco_weight_fuse(maps, w1, b1, w2, b2, w3, b3, channels, out, logits=None):
     return out
 
 
+def voxelize_sort_pillar_rows(vox):
+    """the points of every pillar in ascending row order inside vox's bucket order (include/pcp_hip.h: pcp_voxelize_sort_pillar_rows) --
+    the training path calls it so that its per-point sums run in a reproducible order"""
+    L = _lib.load()
+    check(L.pcp_voxelize_sort_pillar_rows(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _stream()), 'pcp_voxelize_sort_pillar_rows')
+
+
 def voxelize_row_order(vox):
     """spatially sorted visiting order of ALL rows of the cloud pcp_voxelize just bucketed (see include/pcp_hip.h)"""
     L = _lib.load()

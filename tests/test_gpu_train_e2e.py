@@ -229,7 +229,8 @@ def test_bf16_loss_curve_tracks_the_fp32_loop_over_20_iterations(monkeypatch):
     """the same 20 iterations (full size, one frame, the recipe's one-cycle schedule) in the fp32 loop, in the fp32 loop with ANOTHER
     summation order (direct kernels instead of Winograd: both exact fp32 arithmetic) and in the bf16 loop.  This short, steep schedule is
     chaotic: the two fp32 loops drift up to ~15 % apart per iteration (profiles/r04_loss_curves.txt), so "within 2 % per iteration" is not
-    a property even fp32 has.  What is asserted: the first three iterations (before the drift amplifies) within 2.5 % of fp32; the bf16
+    a property even fp32 has.  What is asserted: the first three iterations (before the drift amplifies) within 3.5 % of fp32 (measured
+    0.08 / 1.4 / 2.5 %; every run gives the same curves since the pillar rows are sorted, pcp_voxelize_sort_pillar_rows); the bf16
     loop's largest deviation from the fp32 loop at most 2 x the deviation between the two fp32 loops (5 % floor); the mean of the last five
     iterations no further from the fp32 loop's than 2 x the other fp32 loop's (15 % floor); and the loss falls by > 10 x like the fp32 loop's."""
     curves = {}
@@ -257,11 +258,40 @@ def test_bf16_loss_curve_tracks_the_fp32_loop_over_20_iterations(monkeypatch):
     dev_fp32 = float((np.abs(d - a) / a).max())
     dev_bf16 = float((np.abs(b - a) / a).max())
     print('max relative deviation from the fp32 loop: fp32 direct kernels %.4f, bf16 %.4f' % (dev_fp32, dev_bf16))
-    assert float((np.abs(b[:3] - a[:3]) / a[:3]).max()) <= 2.5e-2, (a[:3], b[:3])
+    assert float((np.abs(b[:3] - a[:3]) / a[:3]).max()) <= 3.5e-2, (a[:3], b[:3])
     assert dev_bf16 <= max(2.0 * dev_fp32, 5e-2), (dev_bf16, dev_fp32)
     a5, d5, b5 = a[-5:].mean(), d[-5:].mean(), b[-5:].mean()
     assert abs(b5 - a5) <= max(2.0 * abs(d5 - a5), 0.15 * a5), (a5, d5, b5)
     assert b[-1] < 0.1 * b[0] and a[-1] < 0.1 * a[0]
+
+
+@pytest.mark.parametrize('algo', ['auto', 'bf16'])
+def test_training_iterations_are_bitwise_reproducible(monkeypatch, algo):
+    """two runs of the first two full-size iterations from the same state: the same losses and the same gradient bits.  The pillariser hands a
+    pillar's points out in atomic order; the training path sorts them (pcp_voxelize_sort_pillar_rows) because its per-point GEMMs sum over the
+    rows -- without the sort the PFN's weight gradients differ in their last bits from run to run (and a chaotic schedule amplifies that)."""
+    runs = []
+    for _rep in range(2):
+        g, model, opt, ocfg, batch, build_scheduler = _full_size_disco(monkeypatch, algo)
+        sched, _ = build_scheduler(opt, 20, 1, -1, ocfg)
+        out = []
+        for it in range(2):
+            sched.step(it)
+            model.train()
+            opt.zero_grad()
+            ret, tb, _disp = model(batch())
+            model.update_global_step()
+            ret['loss'].backward()
+            out.append((float(ret['loss'].detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+            opt.clip_grad_norm(ocfg.GRAD_NORM_CLIP)
+            opt.step()
+        runs.append(out)
+        del model, opt
+        torch.cuda.empty_cache()
+    for (la, ga), (lb, gb) in zip(*runs):
+        assert la == lb
+        bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
+        assert not bad, bad[:8]
 
 
 def test_single_model_train_step_matches_reference():
