@@ -100,86 +100,125 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_feat(FeatParams p) {
   }
 }
 
-// wave per pillar; lane = (half, channel): the two halves take alternate rows.  RT: storage type of the per-point 64-channel rows (in1, x1,
-// dz1, din1): float, or __bf16 in the bf16 training loop (include/pcp_hip_mp.h) -- the second PFN Linear then runs on pcp_mp_pointwise
+// The four routing kernels: a SUB-GROUP of lanes per pillar (8 lanes x 4 channels for the 32-channel rows, 16 lanes x 4 channels for the
+// 64-channel rows), so a wave works on 8 / 4 pillars at once with 16-byte accesses; a pillar's rows (two on average) are walked in bucket
+// order by its own lanes, no cross-lane traffic.  (Rounds 1-3 gave a whole wave to a pillar: 64 lanes x 4 bytes per row and one pillar's
+// chain of dependent loads per wave -- 214 .. 306 us per kernel on 1.4 M points.)
+// RT: storage type of the per-point 64-channel rows (in1, x1, dz1, din1): float, or __bf16 in the bf16 training loop
+// (include/pcp_hip_mp.h) -- the second PFN Linear then runs on pcp_mp_pointwise.
+template <typename T> struct Row4;
+template <> struct Row4<float> {
+  static __device__ __forceinline__ f32x4 ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+  static __device__ __forceinline__ void st(float *p, const f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+};
+template <> struct Row4<__bf16> {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4 ld(const __bf16 *p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t *>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  static __device__ __forceinline__ void st(__bf16 *p, const f32x4 v) {
+    bf16x4_t o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4_t *>(p) = o;
+  }
+};
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 template <typename RT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_mid(const int *__restrict__ pillar_start, const int *__restrict__ counters,
                                                         const float *__restrict__ x0, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, RT *__restrict__ in1, int *__restrict__ arg0) {
   const int P = counters[0];
-  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
-  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
-  const float sc = scale[c], sh = shift[c];
-  for (long long p = wave0; p < P; p += nw) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nt = (long long)gridDim.x * blockDim.x;
+  const int c = (int)(t & 7) * 4;                                  // this lane's four channels of the 32
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+  for (long long p = t >> 3; p < P; p += nt >> 3) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
-    float best = -1.f;
-    int arg = se;
-    for (int s = sb + half; s < se; s += 2) {
-      const float v = fmaxf(fmaf(x0[(long long)s * C0 + c], sc, sh), 0.f);
-      in1[(long long)s * C1 + c] = (RT)v;
-      if (v > best) { best = v; arg = s; }
+    f32x4 best = f32x4{-1.f, -1.f, -1.f, -1.f};
+    i32x4 arg = i32x4{se, se, se, se};
+    for (int s = sb; s < se; ++s) {
+      const f32x4 x = *reinterpret_cast<const f32x4 *>(x0 + (long long)s * C0 + c);
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = fmaxf(fmaf(x[i], sc[i], sh[i]), 0.f);
+        if (v[i] > best[i]) { best[i] = v[i]; arg[i] = s; }         // first row in bucket order wins a tie
+      }
+      Row4<RT>::st(in1 + (long long)s * C1 + c, v);
     }
-    const float ob = __shfl_xor(best, 32);
-    const int oa = __shfl_xor(arg, 32);
-    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-    if (half == 0) arg0[p * C0 + c] = arg;
-    for (int s = sb + half; s < se; s += 2) in1[(long long)s * C1 + C0 + c] = (RT)best;
+    *reinterpret_cast<i32x4 *>(arg0 + p * C0 + c) = arg;
+    for (int s = sb; s < se; ++s) Row4<RT>::st(in1 + (long long)s * C1 + C0 + c, best);
   }
 }
 
-// CT: storage type of the canvas (float; __bf16 in the bf16 training loop, include/pcp_hip_mp.h: the first backbone layer and its weight
-// gradient read the canvas as bf16 anyway, so the fp32 canvas + its cast are skipped)
+// CT: storage type of the canvas (float; __bf16 in the bf16 training loop: the first backbone layer and its weight gradient read the
+// canvas as bf16 anyway, so the fp32 canvas + its cast are skipped)
 template <typename CT, typename RT>
 __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
                                                         const int *__restrict__ counters, pcp_grid_t g, const RT *__restrict__ x1,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         float *__restrict__ pf, int *__restrict__ arg1, CT *__restrict__ canvas) {
   const int P = counters[0];
-  const int lane = threadIdx.x & 63;
-  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
-  const float sc = scale[lane], sh = shift[lane];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nt = (long long)gridDim.x * blockDim.x;
+  const int c = (int)(t & 15) * 4;                                 // this lane's four channels of the 64
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
   const int plane = g.nx * g.ny;
-  for (long long p = wave0; p < P; p += nw) {
+  for (long long p = t >> 4; p < P; p += nt >> 4) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
-    float best = -1.f;
-    int arg = sb;
+    f32x4 best = f32x4{-1.f, -1.f, -1.f, -1.f};
+    i32x4 arg = i32x4{sb, sb, sb, sb};
     for (int s = sb; s < se; ++s) {
-      const float v = fmaxf(fmaf((float)x1[(long long)s * C1 + lane], sc, sh), 0.f);
-      if (v > best) { best = v; arg = s; }
+      const f32x4 x = Row4<RT>::ld(x1 + (long long)s * C1 + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = fmaxf(fmaf(x[i], sc[i], sh[i]), 0.f);
+        if (v > best[i]) { best[i] = v; arg[i] = s; }
+      }
     }
-    if (pf) pf[p * C1 + lane] = best;
-    arg1[p * C1 + lane] = arg;
+    if (pf) *reinterpret_cast<f32x4 *>(pf + p * C1 + c) = best;
+    *reinterpret_cast<i32x4 *>(arg1 + p * C1 + c) = arg;
     if (canvas) {
       const int cell = pillar_cell[p];
       const int b = cell / plane, rem = cell % plane;
       const int cx = rem / g.ny, cy = rem % g.ny;
-      canvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + lane] = (CT)best;
+      Row4<CT>::st(canvas + (((long long)b * g.ny + cy) * g.nx + cx) * C1 + c, best);
     }
   }
 }
 
+// writes EVERY row of dz1 (the gradient at the arg-max row, zero elsewhere): no zero fill of the 357-MB tensor in front of it
 template <typename CT, typename RT>
-__global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__restrict__ pillar_cell, const int *__restrict__ counters,
-                                                              pcp_grid_t g, const CT *__restrict__ dcanvas, const float *__restrict__ dpf,
-                                                              const int *__restrict__ arg1, RT *__restrict__ dz1) {
+__global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
+                                                              const int *__restrict__ counters, pcp_grid_t g, const CT *__restrict__ dcanvas,
+                                                              const float *__restrict__ dpf, const int *__restrict__ arg1,
+                                                              RT *__restrict__ dz1) {
   const int P = counters[0];
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)P * C1) return;
-  const long long p = t >> 6;
-  const int c = (int)(t & 63);
-  float gval;
-  if (dcanvas) {
-    const int plane = g.nx * g.ny;
-    const int cell = pillar_cell[p];
-    const int b = cell / plane, rem = cell % plane;
-    const int cx = rem / g.ny, cy = rem % g.ny;
-    gval = (float)dcanvas[(((long long)b * g.ny + cy) * g.nx + cx) * C1 + c];
-  } else {
-    gval = dpf[t];
+  const long long nt = (long long)gridDim.x * blockDim.x;
+  const int c = (int)(t & 15) * 4;
+  const int plane = g.nx * g.ny;
+  for (long long p = t >> 4; p < P; p += nt >> 4) {
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    f32x4 gv;
+    if (dcanvas) {
+      const int cell = pillar_cell[p];
+      const int b = cell / plane, rem = cell % plane;
+      const int cx = rem / g.ny, cy = rem % g.ny;
+      gv = Row4<CT>::ld(dcanvas + (((long long)b * g.ny + cy) * g.nx + cx) * C1 + c);
+    } else {
+      gv = *reinterpret_cast<const f32x4 *>(dpf + p * C1 + c);
+    }
+    const i32x4 arg = *reinterpret_cast<const i32x4 *>(arg1 + p * C1 + c);
+    for (int s = sb; s < se; ++s) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = arg[i] == s ? gv[i] : 0.f;
+      Row4<RT>::st(dz1 + (long long)s * C1 + c, v);
+    }
   }
-  dz1[(long long)arg1[t] * C1 + c] = (RT)gval;
 }
 
 template <typename RT>
@@ -187,16 +226,21 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_mid(const int *__rest
                                                               const RT *__restrict__ din1, const int *__restrict__ arg0,
                                                               float *__restrict__ da0) {
   const int P = counters[0];
-  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
-  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
-  for (long long p = wave0; p < P; p += nw) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nt = (long long)gridDim.x * blockDim.x;
+  const int c = (int)(t & 7) * 4;
+  for (long long p = t >> 3; p < P; p += nt >> 3) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
-    // fixed summation order (ascending slot) so the result does not depend on the lane split
-    float dm = 0.f;
-    for (int s = sb; s < se; ++s) dm += (float)din1[(long long)s * C1 + C0 + c];
-    const int a = arg0[p * C0 + c];
-    for (int s = sb + half; s < se; s += 2) da0[(long long)s * C0 + c] = (float)din1[(long long)s * C1 + c] + (s == a ? dm : 0.f);
+    // fixed summation order (ascending slot)
+    f32x4 dm = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = sb; s < se; ++s) dm += Row4<RT>::ld(din1 + (long long)s * C1 + C0 + c);
+    const i32x4 a = *reinterpret_cast<const i32x4 *>(arg0 + p * C0 + c);
+    for (int s = sb; s < se; ++s) {
+      f32x4 v = Row4<RT>::ld(din1 + (long long)s * C1 + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (s == a[i] ? dm[i] : 0.f);
+      *reinterpret_cast<f32x4 *>(da0 + (long long)s * C0 + c) = v;
+    }
   }
 }
 
@@ -214,9 +258,9 @@ inline WsView view_ws(const void *workspace, const pcp_grid_t *grid, int64_t n) 
   return v;
 }
 
-inline int pillar_wave_blocks(int64_t max_pillars) {
-  int64_t b = (max_pillars + 3) / 4;          // 4 waves per block
-  if (b > 8192) b = 8192;
+inline int pillar_blocks(int64_t max_pillars, int lanes_per_pillar) {
+  int64_t b = (max_pillars * lanes_per_pillar + PT_THREADS - 1) / PT_THREADS;
+  if (b > 16384) b = 16384;                   // grid-stride beyond
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -255,7 +299,7 @@ static int pfn_train_mid_impl(const pcp_grid_t *grid, const void *vox_workspace,
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
+  const dim3 gridd(pillar_blocks(n < cells ? n : cells, 8));
   if (in1_bf16)
     hipLaunchKernelGGL(k_pfnt_mid<__bf16>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, x0, scale0, shift0,
                        (__bf16 *)in1, arg0);
@@ -283,7 +327,7 @@ static int pfn_train_out_impl(const pcp_grid_t *grid, const void *vox_workspace,
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
+  const dim3 gridd(pillar_blocks(n < cells ? n : cells, 16));
   hipStream_t st = (hipStream_t)stream;
 #define PCP_PFNT_OUT(CT, RT)                                                                                                              \
   hipLaunchKernelGGL((k_pfnt_out<CT, RT>), gridd, dim3(PT_THREADS), 0, st, v.pillar_start, v.pillar_cell, v.counters, *grid, (const RT *)x1, \
@@ -316,13 +360,13 @@ static int pfn_route_out_impl(const pcp_grid_t *grid, const void *vox_workspace,
   if (n == 0 || kept_rows == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   hipStream_t s = (hipStream_t)stream;
-  if (pcp_zero_async(dz1, (size_t)kept_rows * C1 * (dz1_bf16 ? 2 : 4), s) != PCP_OK) return PCP_ERR_LAUNCH;
+  // every kept row belongs to exactly one pillar and the kernel writes all of a pillar's rows: dz1 needs no zero fill
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   const int64_t max_pillars = kept_rows < cells ? kept_rows : cells;
-  const dim3 gridd((unsigned)((max_pillars * C1 + PT_THREADS - 1) / PT_THREADS));
+  const dim3 gridd(pillar_blocks(max_pillars, 16));
 #define PCP_PFNT_ROUTE(CT, RT)                                                                                                           \
-  hipLaunchKernelGGL((k_pfnt_route_out<CT, RT>), gridd, dim3(PT_THREADS), 0, s, v.pillar_cell, v.counters, *grid, (const CT *)dcanvas, dpillar, \
-                     arg1, (RT *)dz1)
+  hipLaunchKernelGGL((k_pfnt_route_out<CT, RT>), gridd, dim3(PT_THREADS), 0, s, v.pillar_start, v.pillar_cell, v.counters, *grid,            \
+                     (const CT *)dcanvas, dpillar, arg1, (RT *)dz1)
   if (dcanvas_bf16) {
     if (dz1_bf16) PCP_PFNT_ROUTE(__bf16, __bf16); else PCP_PFNT_ROUTE(__bf16, float);
   } else {
@@ -350,7 +394,7 @@ static int pfn_route_mid_impl(const pcp_grid_t *grid, const void *vox_workspace,
   if (n == 0) return PCP_OK;
   const WsView v = view_ws(vox_workspace, grid, n);
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  const dim3 gridd(pillar_wave_blocks(n < cells ? n : cells));
+  const dim3 gridd(pillar_blocks(n < cells ? n : cells, 8));
   if (din1_bf16)
     hipLaunchKernelGGL(k_pfnt_route_mid<__bf16>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, (const __bf16 *)din1,
                        arg0, da0);
