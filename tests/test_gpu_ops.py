@@ -1307,3 +1307,41 @@ def test_modar_ingest_batched_equals_the_per_pair_ingestion():
                                     t(frames)).cpu().numpy().reshape(G, M, 14)
     want = oex.modar_ingest(g['modar_' + keys[0]], None, g['target_se3_lidar_' + keys[0]], float(sweeps[0]))
     np.testing.assert_allclose(out2[0, :counts[0], 1:], want, rtol=0, atol=5e-6)
+
+
+def test_voxelize_sort_pillar_rows_makes_the_bucket_order_a_function_of_the_input():
+    """the pillariser hands the points of a pillar out in atomic order; pcp_voxelize_sort_pillar_rows (training path) sorts every pillar's run
+    by point index: the bucket order stays grouped by pillar (pillars ascending), holds every kept point once, ascends inside each pillar and
+    is the same for two runs"""
+    ops = _ops()
+    from pcp_amd import synth
+    d = dev()
+    rng = np.random.RandomState(7)
+    n = 40000
+    pts = np.zeros((n, 6), dtype=np.float32)
+    pts[:, 0] = rng.randint(0, 2, n)
+    pts[:, 1:3] = rng.uniform(-6.0, 6.0, (n, 2))                    # 60 x 60 cells of 0.2 m: ~5 points per pillar and frame
+    pts[:, 3] = rng.uniform(-7.0, -1.0, n)
+    pts[rng.rand(n) < 0.05, 1] = 500.0                              # out of range rows
+    points = torch.from_numpy(pts).to(d)
+    grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], 2)
+    orders = []
+    for _rep in range(2):
+        vox = ops.voxelize(points, grid, want_inverse=True, want_counts=True)
+        ops.voxelize_sort_pillar_rows(vox)
+        order = ops.voxelize_row_order(vox)
+        torch.cuda.synchronize()
+        kept = int(vox.counters[1].item())
+        orders.append(order[:kept].cpu().numpy().copy())
+    o = orders[0]
+    assert np.array_equal(o, orders[1])
+    inside = np.abs(pts[:, 1]) < 51.2
+    assert kept == int(inside.sum()) and np.array_equal(np.sort(o), np.nonzero(inside)[0])
+    # pillar id of every point from the CPU: (frame, x cell, y cell) in the reference's merged order
+    cx = np.floor((pts[:, 1] + 51.2) / 0.2).astype(np.int64)
+    cy = np.floor((pts[:, 2] + 51.2) / 0.2).astype(np.int64)
+    merged = pts[:, 0].astype(np.int64) * 512 * 512 + cx * 512 + cy
+    m = merged[o]
+    assert (np.diff(m) >= 0).all()                                   # grouped by pillar, pillars ascending
+    same = np.diff(m) == 0
+    assert (np.diff(o)[same] > 0).all() and same.sum() > 10000       # ascending point index inside every pillar
