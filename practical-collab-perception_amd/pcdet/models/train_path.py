@@ -217,7 +217,9 @@ class FusionTrain:
         n_maps = 1 + len(agents)
         if n_maps > 8:
             raise NotImplementedError('fusion training kernels are built for <= 8 maps (config 5 has 6)')
-        cats = [torch.zeros((B, H, W, 2 * cc), dtype=torch.float32, device=dev) for _ in range(n_maps)]
+        # [ego | warped agent] per map.  Every pixel of a present (agent, frame) pair is written by the warp (zeros outside the agent's map) and
+        # the ego halves by copies: only the agent half of an ABSENT pair needs a fill (none in a batch where every agent sees every frame)
+        cats = [torch.empty((B, H, W, 2 * cc), dtype=torch.float32, device=dev) for _ in range(n_maps)]
         c0, c1 = self.comp_ego
         c1.forward(c0.forward(ego_in), out=Act(cats[0], 0, cc))
         ego = cats[0][..., :cc]
@@ -232,6 +234,7 @@ class FusionTrain:
             cats[a][..., :cc].copy_(ego)
             for b_idx, meta in enumerate(metadata):
                 if agent_idx not in meta['se3_from_ego'] or b_idx >= comp.t.shape[0]:
+                    cats[a][b_idx, :, :, cc:].zero_()
                     continue
                 ops.warp_nearest(comp.t[b_idx], cats[a][b_idx], thetas[(agent_idx, b_idx)], cc, dst_ch_off=cc)
         h2 = []
