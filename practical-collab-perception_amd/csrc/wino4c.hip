@@ -573,14 +573,13 @@ extern "C" int pcp_conv3x3_winograd4c(const pcp_conv3x3_t *d, const float *in, c
   if (rc != PCP_OK) return rc;
   if ((((uintptr_t)in) & 15) || (((uintptr_t)u_packed) & 15) || (((uintptr_t)out) & 15) || (((uintptr_t)bias) & 15)) return PCP_ERR_ARG;
   p.in = in; p.u = u_packed; p.bias = bias; p.out = out;
-  // The 128-channel form (one eight-wave workgroup per CU, the input transform shared by all eight waves) is OPT-IN (PCP_WINO4C_NW=8, needs
-  // cout_pad % 128 == 0): interleaved per-layer timing has it 3 - 4 % ahead of the 64-channel form on the 128^2 maps (B20 128->128: 308.7 ->
+  // The 128-channel form (one eight-wave workgroup per CU, the input transform shared by all eight waves) is OPT-IN (PCP_WINO4C_NW=8, on layers
+  // with cout_pad % 128 == 0): interleaved per-layer timing has it 3 - 4 % ahead of the 64-channel form on the 128^2 maps (B20 128->128: 308.7 ->
   // 297.6 us) and 15 - 28 % behind on 64^2 maps whose 128-channel items cover the chip 0.5 or 1.25 times; inside bench.py -- two replicas'
   // kernels sharing the chip -- a dispatch rule that picks it only where it wins measured 374.6 against 376.6 frames/s without it, so the
   // default stays the 64-channel form (profiles/r04_wino4c_ab.txt).  Same weights, same bits.
   const char *env = getenv("PCP_WINO4C_NW");
-  const bool wide = env && atoi(env) == 8;
-  if (wide && d->cout_pad % 128 != 0) return PCP_ERR_UNSUPPORTED;
+  const bool wide = env && atoi(env) == 8 && d->cout_pad % 128 == 0;      // layers without whole 128-channel blocks keep the 64-channel form
   const long long blocks = (long long)p.n_spatial * (d->cout_pad / (wide ? 128 : 64));
   if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
   if (wide) hipLaunchKernelGGL(k_wino4c<8>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream_, p);

@@ -164,6 +164,14 @@ def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monke
         assert (128, 384) in calls and (384, 384) in calls
 
 
+def test_reference_outputs_with_the_128_channel_form_of_wino4c(monkeypatch):
+    """PCP_WINO4C_NW=8 (opt-in): every fused-F(4x4) layer with whole 128-channel output blocks runs as one eight-wave workgroup per CU with a
+    shared input transform; same bits, so the DiscoNet goldens hold unchanged"""
+    monkeypatch.setenv('PCP_CONV_ALGO', 'winograd4c')
+    monkeypatch.setenv('PCP_WINO4C_NW', '8')
+    test_disco_mid_fusion_matches_reference_outputs()
+
+
 @pytest.mark.parametrize('algo', ['winograd4f', 'winograd4h', 'winograd4c'])
 @pytest.mark.parametrize('tag', ['car', 'ego', 'disco'])
 def test_reference_outputs_with_every_eligible_layer_forced_onto_fused_winograd4(tag, algo, monkeypatch):

@@ -612,7 +612,7 @@ def test_conv3x3_winograd4f_channel_windows_and_bad_arguments(kernel):
 def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch, nw, monkeypatch):
     """k_wino4c multiplies the same products in the same k order as k_wino4h and runs the same transform operations per lane: bitwise equal,
     in its 64-channel form (two four-wave workgroups per CU) and in its 128-channel form (one eight-wave workgroup, shared input transform;
-    PCP_WINO4C_NW forces a form, the 128-channel one exists where cout_pad is a multiple of 128)"""
+    PCP_WINO4C_NW=8 selects the 128-channel form wherever cout_pad is a multiple of 128)"""
     ops = _ops()
     from pcp_amd import lib, pack
     d = dev()
@@ -623,10 +623,6 @@ def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch, nw, monkeypatch
     uh, bh, cph = pack.pack_conv3x3_winograd4h(wt, b)
     uc, bc, cpc = pack.pack_conv3x3_winograd4c(wt, b)
     oh = ops.conv3x3_winograd4h(x, uh.to(d), bh.to(d), cin, cout, cph, relu=True)
-    if nw == '8' and cpc % 128 != 0:
-        with pytest.raises(lib.PcpError):
-            ops.conv3x3_winograd4c(x, uc.to(d), bc.to(d), cin, cout, cpc, relu=True)
-        return
     oc = ops.conv3x3_winograd4c(x, uc.to(d), bc.to(d), cin, cout, cpc, relu=True)
     torch.cuda.synchronize()
     assert torch.equal(oh, oc) and float(oh.abs().max()) > 0
