@@ -171,6 +171,20 @@ size_t pcp_mp_pointwise_wgrad_workspace_bytes(int64_t rows, int32_t n, int32_t k
 int pcp_mp_pointwise_wgrad(const pcp_mp_rowmap_t *a, const pcp_mp_rowmap_t *b, int64_t rows, void *workspace, size_t workspace_bytes,
                            float *out, int32_t ld_out, int32_t accumulate, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The DiscoNet fusion module's stacked maps ([ego | warped agent] per map, v2x_fusion_disco.py:85-115) as bf16 in the bf16 loop:
+ * pcp_warp_nearest, pcp_softmax_fuse (pcp_hip.h) and pcp_disco_fuse_backward (pcp_hip_train.h) with a storage type for the maps.
+ * Arithmetic (softmax, weighted sum, dot products) stays float32; only the map loads / the warp's stores change type.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int pcp_mp_warp_nearest(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int32_t h, int32_t w, int32_t c, int32_t ld_src,
+                        int32_t ld_dst, const float *theta_host, int32_t accumulate, void *stream);
+int pcp_mp_softmax_fuse(const void *const *maps_host, int32_t map_dtype, int32_t n_agents, const float *weights, int32_t ld_w, int64_t pixels,
+                        int32_t c, int32_t ld_map, int32_t ld_out, float *out, void *stream);
+int pcp_mp_disco_fuse_backward(const void *const *maps_host, int32_t map_dtype, int32_t n_agents, int32_t ld_map, int32_t c, const float *logits,
+                               int32_t ld_w, const float *dfused, int32_t ld_df, const float *const *h2_host, int32_t ld_h, const float *w4,
+                               int64_t pixels, float *dmap0, int32_t ld_dm, float *const *dh2_host, void *workspace, float *dw4, float *db4,
+                               int32_t accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

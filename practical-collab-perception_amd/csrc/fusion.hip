@@ -22,9 +22,29 @@ __device__ __forceinline__ float base_coord(int i, int n) {
   return v * (float)(n - 1) / (float)n;
 }
 
-__global__ void k_warp_nearest(const float *__restrict__ src, float *__restrict__ dst, int h, int w, int c4, int ld_src,
+// storage-typed four-channel access (float | __bf16): the bf16 training loop keeps the fusion module's stacked maps as bf16
+template <typename T> struct Map4;
+template <> struct Map4<float> {
+  static __device__ __forceinline__ float4 ld(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+  static __device__ __forceinline__ void st(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Map4<__bf16> {
+  typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ float4 ld(const __bf16 *p) {
+    const b4 v = *reinterpret_cast<const b4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  static __device__ __forceinline__ void st(__bf16 *p, const float4 &v) {
+    b4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<b4 *>(p) = o;
+  }
+};
+
+template <typename ST, typename DT>
+__global__ void k_warp_nearest(const ST *__restrict__ src, DT *__restrict__ dst, int h, int w, int c4, int ld_src,
                                int ld_dst, Theta th, int accumulate) {
-  // one thread per (pixel, float4 of channels)
+  // one thread per (pixel, four channels)
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)h * w * c4;
   if (t >= total) return;
@@ -41,14 +61,14 @@ __global__ void k_warp_nearest(const float *__restrict__ src, float *__restrict_
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1)) {
     int sx = (int)rx, sy = (int)ry;
-    v = *reinterpret_cast<const float4 *>(src + ((long long)sy * w + sx) * ld_src + q * 4);
+    v = Map4<ST>::ld(src + ((long long)sy * w + sx) * ld_src + q * 4);
   }
-  float4 *o = reinterpret_cast<float4 *>(dst + (long long)pix * ld_dst + q * 4);
+  DT *o = dst + (long long)pix * ld_dst + q * 4;
   if (accumulate) {
-    float4 cur = *o;
+    float4 cur = Map4<DT>::ld(o);
     v.x += cur.x; v.y += cur.y; v.z += cur.z; v.w += cur.w;
   }
-  *o = v;
+  Map4<DT>::st(o, v);
 }
 
 // every (agent, frame) warp of a DiscoNet forward in ONE launch: blockIdx.y = job; the per-pixel arithmetic is k_warp_nearest's
@@ -91,8 +111,10 @@ __global__ void k_warp_nearest_batch(WarpJobs jobs, int h, int w, int c4, int ld
 
 constexpr int MAX_AGENTS = 16;
 struct MapPtrs { const float *p[MAX_AGENTS]; };
+struct VMapPtrs { const void *p[MAX_AGENTS]; };
 
-__global__ void k_softmax_fuse(MapPtrs maps, int n_agents, const float *__restrict__ weights, int ld_w, long long pixels,
+template <typename MT>
+__global__ void k_softmax_fuse(VMapPtrs maps, int n_agents, const float *__restrict__ weights, int ld_w, long long pixels,
                                int c4, int ld_map, int ld_out, float *__restrict__ out) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= pixels * c4) return;
@@ -118,7 +140,7 @@ __global__ void k_softmax_fuse(MapPtrs maps, int n_agents, const float *__restri
   for (int a = 0; a < MAX_AGENTS; a++)
     if (a < n_agents) {
       float s = wv[a] / den;
-      float4 m = *reinterpret_cast<const float4 *>(maps.p[a] + pix * ld_map + q * 4);
+      float4 m = Map4<MT>::ld(reinterpret_cast<const MT *>(maps.p[a]) + pix * ld_map + q * 4);
       acc.x += m.x * s; acc.y += m.y * s; acc.z += m.z * s; acc.w += m.w * s;
     }
   *reinterpret_cast<float4 *>(out + pix * ld_out + q * 4) = acc;
@@ -133,7 +155,7 @@ extern "C" int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t
   Theta th;
   for (int i = 0; i < 6; i++) th.t[i] = theta_host[i];
   long long total = (long long)h * w * (c / 4);
-  hipLaunchKernelGGL(k_warp_nearest, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, dst, h, w,
+  hipLaunchKernelGGL((k_warp_nearest<float, float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, dst, h, w,
                      c / 4, ld_src, ld_dst, th, accumulate);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
@@ -165,11 +187,48 @@ extern "C" int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents,
   if (!maps_host || !weights || !out || n_agents <= 0 || n_agents > MAX_AGENTS || pixels <= 0 || c <= 0 || (c & 3) ||
       (ld_map & 3) || (ld_out & 3) || ld_w < n_agents)
     return PCP_ERR_ARG;
-  MapPtrs mp;
+  VMapPtrs mp;
   for (int a = 0; a < MAX_AGENTS; a++) mp.p[a] = a < n_agents ? maps_host[a] : nullptr;
   long long total = pixels * (c / 4);
-  hipLaunchKernelGGL(k_softmax_fuse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, mp, n_agents,
+  hipLaunchKernelGGL((k_softmax_fuse<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, mp, n_agents,
                      weights, ld_w, (long long)pixels, c / 4, ld_map, ld_out, out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+// storage-typed forms for the bf16 training loop (include/pcp_hip_mp.h)
+extern "C" int pcp_mp_warp_nearest(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int32_t h, int32_t w, int32_t c,
+                                   int32_t ld_src, int32_t ld_dst, const float *theta_host, int32_t accumulate, void *stream_) {
+  if (!src || !dst || !theta_host || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (ld_src & 3) || (ld_dst & 3)) return PCP_ERR_ARG;
+  if (src == dst || (src_dtype | dst_dtype) & ~1) return PCP_ERR_ARG;
+  Theta th;
+  for (int i = 0; i < 6; i++) th.t[i] = theta_host[i];
+  const long long total = (long long)h * w * (c / 4);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream_;
+#define PCP_WARP(ST, DT) hipLaunchKernelGGL((k_warp_nearest<ST, DT>), grid, dim3(256), 0, st, (const ST *)src, (DT *)dst, h, w, c / 4, ld_src, ld_dst, th, accumulate)
+  if (src_dtype == 1) { if (dst_dtype == 1) PCP_WARP(__bf16, __bf16); else PCP_WARP(__bf16, float); }
+  else { if (dst_dtype == 1) PCP_WARP(float, __bf16); else PCP_WARP(float, float); }
+#undef PCP_WARP
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_mp_softmax_fuse(const void *const *maps_host, int32_t map_dtype, int32_t n_agents, const float *weights, int32_t ld_w,
+                                   int64_t pixels, int32_t c, int32_t ld_map, int32_t ld_out, float *out, void *stream_) {
+  if (!maps_host || !weights || !out || n_agents <= 0 || n_agents > MAX_AGENTS || pixels <= 0 || c <= 0 || (c & 3) ||
+      (ld_map & 3) || (ld_out & 3) || ld_w < n_agents || (map_dtype & ~1))
+    return PCP_ERR_ARG;
+  VMapPtrs mp;
+  for (int a = 0; a < MAX_AGENTS; a++) mp.p[a] = a < n_agents ? maps_host[a] : nullptr;
+  const long long total = pixels * (c / 4);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (map_dtype == 1)
+    hipLaunchKernelGGL((k_softmax_fuse<__bf16>), grid, dim3(256), 0, (hipStream_t)stream_, mp, n_agents, weights, ld_w, (long long)pixels, c / 4,
+                       ld_map, ld_out, out);
+  else
+    hipLaunchKernelGGL((k_softmax_fuse<float>), grid, dim3(256), 0, (hipStream_t)stream_, mp, n_agents, weights, ld_w, (long long)pixels, c / 4,
+                       ld_map, ld_out, out);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

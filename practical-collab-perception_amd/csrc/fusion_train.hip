@@ -35,7 +35,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_fuse_backward(Ptrs maps, int n_agents, int ld_map, int c, const float *__restrict__ logits,
+struct VPtrs { const void *p[FT_MAX_AGENTS]; };
+
+// MT: storage type of the stacked maps (float; __bf16 in the bf16 training loop)
+template <typename MT>
+__global__ __launch_bounds__(256) void k_fuse_backward(VPtrs maps, int n_agents, int ld_map, int c, const float *__restrict__ logits,
                                                       int ld_w, const float *__restrict__ dfused, int ld_df, Ptrs h2, int ld_h,
                                                       const float *__restrict__ w4, long long pixels, float *__restrict__ dmap0, int ld_dm,
                                                       MutPtrs dh2, double *acc) {
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void k_fuse_backward(Ptrs maps, int n_agents, 
 #pragma unroll
         for (int i = 0; i < FT_MAXV; ++i) {
           const int ch = lane + 64 * i;
-          if (ch < c) s = fmaf(df[i], maps.p[a][pix * ld_map + ch], s);
+          if (ch < c) s = fmaf(df[i], (float)reinterpret_cast<const MT *>(maps.p[a])[pix * ld_map + ch], s);
         }
         dot[a] = wave_sum(s);
         lg[a] = logits[pix * ld_w + a];
@@ -135,13 +139,14 @@ int pcp_disco_weight_logits(const float *const *h2_host, int32_t n_agents, int32
 
 size_t pcp_disco_fuse_backward_workspace_bytes(void) { return 32 * sizeof(double); }
 
-int pcp_disco_fuse_backward(const float *const *maps_host, int32_t n_agents, int32_t ld_map, int32_t c, const float *logits, int32_t ld_w,
-                            const float *dfused, int32_t ld_df, const float *const *h2_host, int32_t ld_h, const float *w4,
-                            int64_t pixels, float *dmap0, int32_t ld_dm, float *const *dh2_host, void *workspace, float *dw4, float *db4,
-                            int32_t accumulate, void *stream) {
+static int fuse_backward_impl(const void *const *maps_host, int map_bf16, int32_t n_agents, int32_t ld_map, int32_t c, const float *logits,
+                              int32_t ld_w, const float *dfused, int32_t ld_df, const float *const *h2_host, int32_t ld_h, const float *w4,
+                              int64_t pixels, float *dmap0, int32_t ld_dm, float *const *dh2_host, void *workspace, float *dw4, float *db4,
+                              int32_t accumulate, void *stream) {
   if (!maps_host || !logits || !dfused || !h2_host || !w4 || !dmap0 || !dh2_host || !workspace || !dw4 || !db4) return PCP_ERR_ARG;
   if (n_agents <= 0 || n_agents > FT_MAX_AGENTS || c <= 0 || c > 64 * FT_MAXV || pixels <= 0) return PCP_ERR_ARG;
-  Ptrs m, h;
+  VPtrs m;
+  Ptrs h;
   MutPtrs dh;
   for (int a = 0; a < FT_MAX_AGENTS; ++a) {
     m.p[a] = a < n_agents ? maps_host[a] : nullptr;
@@ -153,11 +158,32 @@ int pcp_disco_fuse_backward(const float *const *maps_host, int32_t n_agents, int
   if (pcp_zero_async(acc, 32 * sizeof(double), s) != PCP_OK) return PCP_ERR_LAUNCH;
   long long blocks = (pixels + 3) / 4;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_fuse_backward, dim3((unsigned)blocks), dim3(256), 0, s, m, n_agents, ld_map, c, logits, ld_w, dfused, ld_df, h, ld_h,
-                     w4, (long long)pixels, dmap0, ld_dm, dh, acc);
+  if (map_bf16)
+    hipLaunchKernelGGL((k_fuse_backward<__bf16>), dim3((unsigned)blocks), dim3(256), 0, s, m, n_agents, ld_map, c, logits, ld_w, dfused, ld_df, h,
+                       ld_h, w4, (long long)pixels, dmap0, ld_dm, dh, acc);
+  else
+    hipLaunchKernelGGL((k_fuse_backward<float>), dim3((unsigned)blocks), dim3(256), 0, s, m, n_agents, ld_map, c, logits, ld_w, dfused, ld_df, h,
+                       ld_h, w4, (long long)pixels, dmap0, ld_dm, dh, acc);
   hipLaunchKernelGGL(k_w4_finalize, dim3(1), dim3(64), 0, s, acc, dw4, db4, accumulate);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+int pcp_disco_fuse_backward(const float *const *maps_host, int32_t n_agents, int32_t ld_map, int32_t c, const float *logits, int32_t ld_w,
+                            const float *dfused, int32_t ld_df, const float *const *h2_host, int32_t ld_h, const float *w4,
+                            int64_t pixels, float *dmap0, int32_t ld_dm, float *const *dh2_host, void *workspace, float *dw4, float *db4,
+                            int32_t accumulate, void *stream) {
+  return fuse_backward_impl((const void *const *)maps_host, 0, n_agents, ld_map, c, logits, ld_w, dfused, ld_df, h2_host, ld_h, w4, pixels, dmap0,
+                            ld_dm, dh2_host, workspace, dw4, db4, accumulate, stream);
+}
+
+int pcp_mp_disco_fuse_backward(const void *const *maps_host, int32_t map_dtype, int32_t n_agents, int32_t ld_map, int32_t c, const float *logits,
+                               int32_t ld_w, const float *dfused, int32_t ld_df, const float *const *h2_host, int32_t ld_h, const float *w4,
+                               int64_t pixels, float *dmap0, int32_t ld_dm, float *const *dh2_host, void *workspace, float *dw4, float *db4,
+                               int32_t accumulate, void *stream) {
+  if (map_dtype & ~1) return PCP_ERR_ARG;
+  return fuse_backward_impl(maps_host, map_dtype, n_agents, ld_map, c, logits, ld_w, dfused, ld_df, h2_host, ld_h, w4, pixels, dmap0, ld_dm,
+                            dh2_host, workspace, dw4, db4, accumulate, stream);
 }
 
 }  // extern "C"

@@ -219,7 +219,11 @@ class FusionTrain:
             raise NotImplementedError('fusion training kernels are built for <= 8 maps (config 5 has 6)')
         # [ego | warped agent] per map.  Every pixel of a present (agent, frame) pair is written by the warp (zeros outside the agent's map) and
         # the ego halves by copies: only the agent half of an ABSENT pair needs a fill (none in a batch where every agent sees every frame)
-        cats = [torch.empty((B, H, W, 2 * cc), dtype=torch.float32, device=dev) for _ in range(n_maps)]
+        # bf16 loop: the stacked maps are bf16 (written by the bf16 compressor, read by the weightor's first 1x1 layer on pcp_mp_pointwise and by
+        # the storage-typed fusion kernels; softmax / weighted sum / gradients stay float32)
+        mdt = torch.bfloat16 if (tl.mp_mode() and cc % 8 == 0) else torch.float32
+        esz = 2 if mdt == torch.bfloat16 else 4
+        cats = [torch.empty((B, H, W, 2 * cc), dtype=mdt, device=dev) for _ in range(n_maps)]
         c0, c1 = self.comp_ego
         c1.forward(c0.forward(ego_in), out=Act(cats[0], 0, cc))
         ego = cats[0][..., :cc]
@@ -230,7 +234,7 @@ class FusionTrain:
             if agent_idx not in self.comp_agents:
                 self.comp_agents[agent_idx] = self.mk_comp('agent%d' % agent_idx)
             a0, a1 = self.comp_agents[agent_idx]
-            comp = a1.forward(a0.forward(Act(ops.as_nhwc(img))), out_dtype=torch.float32)   # BatchNorm sees this agent's batch (train mode), no gradient; fp32 for the warp
+            comp = a1.forward(a0.forward(Act(ops.as_nhwc(img))), out_dtype=mdt)   # BatchNorm sees this agent's batch (train mode), no gradient
             cats[a][..., :cc].copy_(ego)
             for b_idx, meta in enumerate(metadata):
                 if agent_idx not in meta['se3_from_ego'] or b_idx >= comp.t.shape[0]:
@@ -246,11 +250,11 @@ class FusionTrain:
         pw = fu.pixel_weightor
         logits = torch.zeros((B, H, W, 8), dtype=torch.float32, device=dev)
         tops.disco_weight_logits(h2, pw.conv1_4.weight.detach().reshape(-1).contiguous(), pw.conv1_4.bias.detach(), logits)
-        map_ptrs = [cats[0].data_ptr()] + [cats[a].data_ptr() + 4 * cc for a in range(1, n_maps)]
+        map_ptrs = [cats[0].data_ptr()] + [cats[a].data_ptr() + esz * cc for a in range(1, n_maps)]
         fused = _empty((B, H, W, cc), dev)
-        ops.softmax_fuse_raw(map_ptrs, logits, cc, 2 * cc, fused)
+        ops.softmax_fuse_raw(map_ptrs, logits, cc, 2 * cc, fused, map_dtype=mdt)
         out = self.d1.forward(self.d0.forward(Act(fused)), out_dtype=torch.float32)      # fp32: the distillation loss and the head read it
-        self.saved = dict(cats=cats, h2=h2, logits=logits, map_ptrs=map_ptrs, n_maps=n_maps)
+        self.saved = dict(cats=cats, h2=h2, logits=logits, map_ptrs=map_ptrs, n_maps=n_maps, mdt=mdt)
         loss = None
         self.dgrad_distill = None
         if bev_early is not None:
@@ -275,7 +279,7 @@ class FusionTrain:
         gw4 = ensure_grad(pw.conv1_4.weight)
         gb4 = ensure_grad(pw.conv1_4.bias)
         tops.disco_fuse_backward(s['map_ptrs'], 2 * cc, cc, s['logits'], g.t, s['h2'], pw.conv1_4.weight.detach().reshape(-1).contiguous(),
-                                 d_ego, dh2, gw4.view(-1), gb4)
+                                 d_ego, dh2, gw4.view(-1), gb4, map_dtype=s['mdt'])
         for a in range(n_maps):
             w1, w2 = self.weights[a]
             dcat = w1.backward(w2.backward(Act(dh2[a]), accumulate=a > 0), accumulate=a > 0)

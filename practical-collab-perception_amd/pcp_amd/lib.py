@@ -291,6 +291,10 @@ SYMBOLS.update({
     'pcp_mp_conv3x3_wgrad_workspace_bytes': (c_sz, [ctypes.POINTER(MpWgrad3x3)]),
     'pcp_mp_conv3x3_wgrad': (c_i32, [ctypes.POINTER(MpWgrad3x3), vp, vp, vp, vp, c_sz, vp]),
     'pcp_mp_pointwise': (c_i32, [ctypes.POINTER(MpPointwise), vp, vp, vp, vp, vp]),
+    'pcp_mp_warp_nearest': (c_i32, [vp, c_i32, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp]),
+    'pcp_mp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
+    'pcp_mp_disco_fuse_backward': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, c_i32, c_i32, vp, c_i32, vp, c_i32, ctypes.POINTER(vp), c_i32, vp, c_i64,
+                                           vp, c_i32, ctypes.POINTER(vp), vp, vp, vp, c_i32, vp]),
     'pcp_mp_pointwise_wgrad_workspace_bytes': (c_sz, [c_i64, c_i32, c_i32]),
     'pcp_mp_pointwise_wgrad': (c_i32, [ctypes.POINTER(MpRowMap), ctypes.POINTER(MpRowMap), c_i64, vp, c_sz, vp, c_i32, c_i32, vp]),
 })

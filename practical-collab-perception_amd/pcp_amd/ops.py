@@ -468,15 +468,26 @@ def boxes_bev_pairwise(a, b, mode):
 # a11 / a12 / a14
 # ---------------------------------------------------------------------------------------------------------------------
 
+def _dtc(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
 def warp_nearest(src, dst, theta, channels, accumulate=False, src_ch_off=0, dst_ch_off=0):
-    """src, dst: (H, W, ld) NHWC single-frame maps; theta: 6 python floats (row-major 2x3)."""
+    """src, dst: (H, W, ld) NHWC single-frame maps, float32 -- or bfloat16 on either side in the bf16 training loop (pcp_mp_warp_nearest);
+    theta: 6 python floats (row-major 2x3)."""
     _need_cuda(src, dst)
-    _need_f32('pcp_warp_nearest', src, dst)
     L = _lib.load()
     H, W, ld_s = src.shape
     th = (ctypes.c_float * 6)(*[float(v) for v in theta])
-    check(L.pcp_warp_nearest(_chan_ptr(src, src_ch_off), _chan_ptr(dst, dst_ch_off), H, W, channels, ld_s, dst.shape[2], th,
-                             1 if accumulate else 0, _stream()), 'pcp_warp_nearest')
+    if src.dtype == torch.float32 and dst.dtype == torch.float32:
+        check(L.pcp_warp_nearest(_chan_ptr(src, src_ch_off), _chan_ptr(dst, dst_ch_off), H, W, channels, ld_s, dst.shape[2], th,
+                                 1 if accumulate else 0, _stream()), 'pcp_warp_nearest')
+        return
+    for t in (src, dst):
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.PcpError('pcp_mp_warp_nearest stores float32 or bfloat16 maps, got %s' % t.dtype)
+    check(L.pcp_mp_warp_nearest(_chan_ptr(src, src_ch_off), _dtc(src), _chan_ptr(dst, dst_ch_off), _dtc(dst), H, W, channels, ld_s, dst.shape[2],
+                                th, 1 if accumulate else 0, _stream()), 'pcp_mp_warp_nearest')
 
 
 def warp_nearest_batch(jobs, channels, accumulate=False):
@@ -676,13 +687,18 @@ def select_transform_points(points, agent_col, agent, poses, present, out=None, 
     return out
 
 
-def softmax_fuse_raw(map_ptrs, weights, channels, ld_map, out):
-    """like softmax_fuse but the maps are raw device addresses sharing one pixel stride (channel windows of one buffer)."""
+def softmax_fuse_raw(map_ptrs, weights, channels, ld_map, out, map_dtype=torch.float32):
+    """like softmax_fuse but the maps are raw device addresses sharing one pixel stride (channel windows of one buffer); map_dtype
+    bfloat16: the bf16 training loop's stacked maps (pcp_mp_softmax_fuse; ld_map counts elements)."""
     _need_cuda(weights, out)
     L = _lib.load()
     n = len(map_ptrs)
     arr = (ctypes.c_void_p * n)(*map_ptrs)
     pixels = weights.numel() // weights.shape[-1]
+    if map_dtype == torch.bfloat16:
+        check(L.pcp_mp_softmax_fuse(arr, 1, n, _p(weights), weights.shape[-1], pixels, channels, ld_map, out.shape[-1], _p(out), _stream()),
+              'pcp_mp_softmax_fuse')
+        return out
     check(L.pcp_softmax_fuse(arr, n, _p(weights), weights.shape[-1], pixels, channels, ld_map, out.shape[-1], _p(out),
                              _stream()), 'pcp_softmax_fuse')
     return out

@@ -554,10 +554,17 @@ def disco_weight_logits(h2_list, w4, b4, logits):
                                     _p(logits), logits.shape[-1], _stream()), 'pcp_disco_weight_logits')
 
 
-def disco_fuse_backward(map_ptrs, ld_map, c, logits, dfused, h2_list, w4, dmap0, dh2_list, dw4, db4, accumulate=False):
+def disco_fuse_backward(map_ptrs, ld_map, c, logits, dfused, h2_list, w4, dmap0, dh2_list, dw4, db4, accumulate=False, map_dtype=torch.float32):
+    """map_dtype bfloat16: the stacked maps of the bf16 loop (pcp_mp_disco_fuse_backward; ld_map counts elements)"""
     L = _lib.load()
     pixels = logits.numel() // logits.shape[-1]
     ws = _BN_WS.get(L.pcp_disco_fuse_backward_workspace_bytes(), logits.device)
+    if map_dtype == torch.bfloat16:
+        check(L.pcp_mp_disco_fuse_backward(_ptr_array(map_ptrs), 1, len(map_ptrs), ld_map, c, _p(logits), logits.shape[-1], _p(dfused),
+                                           dfused.shape[-1], _ptr_array([t.data_ptr() for t in h2_list]), h2_list[0].shape[-1], _p(w4), pixels,
+                                           _p(dmap0), dmap0.shape[-1], _ptr_array([t.data_ptr() for t in dh2_list]), _p(ws), _p(dw4), _p(db4),
+                                           1 if accumulate else 0, _stream()), 'pcp_mp_disco_fuse_backward')
+        return
     check(L.pcp_disco_fuse_backward(_ptr_array(map_ptrs), len(map_ptrs), ld_map, c, _p(logits), logits.shape[-1], _p(dfused),
                                     dfused.shape[-1], _ptr_array([t.data_ptr() for t in h2_list]), h2_list[0].shape[-1], _p(w4), pixels,
                                     _p(dmap0), dmap0.shape[-1], _ptr_array([t.data_ptr() for t in dh2_list]), _p(ws), _p(dw4), _p(db4),

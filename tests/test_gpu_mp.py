@@ -435,3 +435,49 @@ def test_mp_pointwise_wgrad_of_the_three_layer_kinds(kind, cin, cout, shape):
         acc = got.reshape(cout, cin).clone()
         tops.pointwise_wgrad(tops.rowmap(dyd, cout), tops.rowmap(xd, cin), rows, acc, accumulate=True)
         _check(acc.reshape(cout, cin, 1, 1), 2 * want, False, 'accumulating mp_pointwise_wgrad')
+
+
+# ---- the fusion module's stacked maps as bf16 (pcp_mp_warp_nearest, pcp_mp_softmax_fuse, pcp_mp_disco_fuse_backward) ---------------------------
+
+def test_mp_fusion_kernels_on_bf16_maps_equal_the_fp32_kernels_on_the_rounded_maps():
+    """the storage-typed forms change the map loads / the warp's stores only: a bf16 source warped to bf16 is the fp32 warp of the same
+    values (exact: nearest-neighbour copies); softmax-weighted fusion and its backward over bf16 maps are bit for bit the fp32 kernels over the
+    same (rounded) maps"""
+    from pcp_amd import ops, train_ops as tops
+    H, W, C, n = 24, 40, 128, 4
+    th = [0.92, 0.11, 0.05, -0.09, 0.97, -0.04]
+    src = _u(91, 1, (H, W, C)).to(DEV)
+    src_b = src.to(torch.bfloat16)
+    want = torch.zeros((H, W, 2 * C), device=DEV)
+    ops.warp_nearest(src_b.float().contiguous(), want, th, C, dst_ch_off=C)
+    for sdt, ddt in ((torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32)):
+        s_in = src_b if sdt == torch.bfloat16 else src_b.float().contiguous()
+        dst = torch.full((H, W, 2 * C), 5.0, dtype=ddt, device=DEV)
+        ops.warp_nearest(s_in, dst, th, C, dst_ch_off=C)
+        torch.cuda.synchronize()
+        assert torch.equal(dst[..., C:].float(), want[..., C:]) and float(dst[..., :C].float().min()) == 5.0
+    assert float(want[..., C:].abs().max()) > 0
+    # fusion forward / backward: maps = channel windows [C, 2C) of n (B, H, W, 2C) buffers, as FusionTrain lays them out
+    B = 2
+    cats_b = [_u(92 + a, 2, (B, H, W, 2 * C)).to(DEV).to(torch.bfloat16).contiguous() for a in range(n)]
+    cats_f = [c.float().contiguous() for c in cats_b]
+    logits = _u(97, 3, (B, H, W, 8)).to(DEV).contiguous()
+    out_f, out_b = torch.empty((B, H, W, C), device=DEV), torch.empty((B, H, W, C), device=DEV)
+    ops.softmax_fuse_raw([c.data_ptr() + 4 * C for c in cats_f], logits, C, 2 * C, out_f)
+    ops.softmax_fuse_raw([c.data_ptr() + 2 * C for c in cats_b], logits, C, 2 * C, out_b, map_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(out_f, out_b) and float(out_f.abs().max()) > 0
+    dfused = _u(98, 4, (B, H, W, C)).to(DEV).contiguous()
+    h2 = [_u(99 + a, 5, (B, H, W, 16), 0.0, 1.0).to(DEV).contiguous() for a in range(n)]
+    w4 = _u(105, 6, (16,), -0.5, 0.5).to(DEV)
+    res = []
+    for cats, esz, mdt in ((cats_f, 4, torch.float32), (cats_b, 2, torch.bfloat16)):
+        d_ego = torch.empty((B, H, W, C), device=DEV)
+        dh2 = [torch.empty((B, H, W, 16), device=DEV) for _ in range(n)]
+        dw4, db4 = torch.zeros(16, device=DEV), torch.zeros(1, device=DEV)
+        tops.disco_fuse_backward([c.data_ptr() + esz * C for c in cats], 2 * C, C, logits, dfused, h2, w4, d_ego, dh2, dw4, db4, map_dtype=mdt)
+        torch.cuda.synchronize()
+        res.append([d_ego] + dh2)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().max()) > 0 and float(res[0][1].abs().max()) > 0
