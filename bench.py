@@ -363,6 +363,8 @@ class AbiTimer:
                 return 'k_pointwise<%s> (fp32 MFMA GEMM)' % tag, fl, fl * d.cout / max(d.cout_pad, 1), 'mfma', MFMA_F32_PEAK_TFLOPS
             label = {'pcp_pfn_scatter': 'k_pfn (fused PFN + scatter)', 'pcp_sparse_conv3x3_s2': 'k_sparse_conv_s2 (first backbone layer from the pillar list)',
                      'pcp_voxelize': 'pcp_voxelize (all its launches)', 'pcp_voxelize_cells_ready': 'pcp_voxelize (all its launches)',
+                     'pcp_pillarise_rows': 'pcp_pillarise_rows (histogram + single-pass scan + rows in pillar order, all its launches)',
+                     'pcp_pfn_rows': 'k_pfn_rows (fused PFN + scatter, one wave per ~30-point run of pillars)',
                      'pcp_select_transform_compact': 'pcp_select_transform_compact (agent selection + pose + compaction + cell ids, all its launches)',
                      'pcp_disco_weight_fuse': 'k_weight_fuse (DiscoNet pixel weightor + softmax + weighted sum, one launch)', 'pcp_nms_rotated': 'pcp_nms_rotated (all its launches)',
                      'pcp_hunter_point_head_ex': 'k_point_head', 'pcp_hunter_point_head': 'k_point_head',
@@ -402,12 +404,19 @@ class AbiTimer:
                     e1.record(s)
                     timer.records.append((e0, e1) + describe(name, a) + (shape_of(name, a),))
                     # VFE stage: algorithmic bytes = points once + P coords + the canvas (dense) or the P pillar rows
-                    if name in ('pcp_voxelize', 'pcp_voxelize_cells_ready'):
-                        cptr = a[9] if name == 'pcp_voxelize' else a[8]
+                    if name in ('pcp_voxelize', 'pcp_voxelize_cells_ready', 'pcp_pillarise_rows'):
+                        cptr = a[{'pcp_voxelize': 9, 'pcp_voxelize_cells_ready': 8, 'pcp_pillarise_rows': 10}[name]]
                         s.synchronize()                 # between two event pairs: no launch's measured duration contains this wait
                         host = (ctypes.c_int32 * 4)()
                         timer.rt.hipMemcpy(host, cptr, 16, 2)
                         timer.vfe_P[s.cuda_stream] = int(host[0])
+                        timer.vfe_P[(s.cuda_stream, 'stride')] = int(a[2])
+                    elif name == 'pcp_pfn_rows':
+                        n, g = int(a[2]), a[0]._obj
+                        P, stride = timer.vfe_P.get(s.cuda_stream, 0), timer.vfe_P.get((s.cuda_stream, 'stride'), 0)
+                        canvas = a[9]
+                        dense = bool(getattr(canvas, 'value', canvas))
+                        timer.vfe_bytes += 4.0 * n * stride + 16.0 * P + (4.0 * g.batch_size * g.ny * g.nx * 64 if dense else 4.0 * 64 * P)
                     elif name == 'pcp_pfn_scatter':
                         n, stride, g = int(a[1]), int(a[2]), a[4]._obj
                         P = timer.vfe_P.get(s.cuda_stream, 0)
@@ -851,7 +860,7 @@ def main(argv=None):
                                     'ms_per_step': round(sum(f['ms_per_step'] for f in mf), 3)}
         # the HBM-bound VFE stage -- pillariser + fused PFN / scatter (+ canvas clear) -- against the HBM peak; (iii): the
         # latency-bound tail (decode + rotated NMS + gather) in microseconds per step
-        vfe_ms = sum(f['ms_per_step'] for f in fams if f['kernel'].split(' ')[0] in ('pcp_voxelize', 'k_pfn', 'pcp_canvas_clear', 'pcp_select_transform_compact'))
+        vfe_ms = sum(f['ms_per_step'] for f in fams if f['kernel'].split(' ')[0] in ('pcp_voxelize', 'k_pfn', 'pcp_canvas_clear', 'pcp_select_transform_compact', 'pcp_pillarise_rows', 'k_pfn_rows'))
         vfe_bytes = timer.vfe_bytes / INSTR_STEPS
         vfe_roof = None
         if vfe_ms > 0 and vfe_bytes > 0:

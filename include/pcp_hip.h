@@ -88,6 +88,26 @@ int pcp_pfn_scatter(const float *points, int64_t n, int32_t row_stride, int32_t 
                     const void *workspace, const float *w0, const float *b0, const float *w1, const float *b1,
                     float *pillar_features, float *canvas, void *stream);
 
+/* Round 5: the same two steps rebuilt for the memory system (csrc/voxelize.hip, csrc/pfn_rows.hip).
+ * pcp_pillarise_rows = pcp_voxelize (same outputs, voxel_coords / unq_inv / unq_cnt may each be NULL) + the kept rows written IN PILLAR
+ * ORDER into the workspace (32- or 64-byte records: raw columns 1 .. num_raw of the row, pillar rank, cell, frame) + one 8-byte
+ * descriptor per wave tile of pcp_pfn_rows.  Workspace: pcp_pillarise_rows_workspace_bytes (its front part is laid out as
+ * pcp_voxelize lays it out: pcp_sparse_conv3x3_s2 and the training kernels read it unchanged).  flags: PCP_ROWS_CELLS_READY = the
+ * rows' cell ids and histogram are already in the workspace (pcp_select_transform_compact with vox_grid; no unq_inv then),
+ * PCP_ROWS_BUCKET_ORDER = also leave the bucket order (row indices grouped by pillar) for pcp_voxelize_row_order / the training path.
+ * pcp_pfn_rows: the fused feature build + PFN x2 + scatter of pcp_pfn_scatter on those records; one WAVE per ~30-point run of pillars,
+ * no workgroup barriers, both layers on fp32 MFMA with the weights as the A operand.  canvas (B, ny, nx, 64): written COMPLETELY --
+ * pillar rows and zero rows for the empty cells -- so it needs no zero fill and no pcp_canvas_clear; pillar_features (P, 64) or NULL.
+ * num_raw in {3, 4, 5, 11}; nx, ny <= 65535.  Must follow pcp_pillarise_rows on the same workspace and stream. */
+#define PCP_ROWS_CELLS_READY 1
+#define PCP_ROWS_BUCKET_ORDER 2
+size_t pcp_pillarise_rows_workspace_bytes(const pcp_grid_t *grid, int64_t max_points, int32_t num_raw);
+int pcp_pillarise_rows(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid,
+                       void *workspace, size_t workspace_bytes, int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt,
+                       int32_t *counters, int32_t flags, void *stream);
+int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
+                 const float *w1, const float *b1, float *pillar_features, float *canvas, void *stream);
+
 /* zero the canvas rows written by an earlier pcp_pfn_scatter (reads the pillar list still held in that call's
  * workspace; n = the point count of that call): P * 256 B instead of re-zeroing B * ny * nx * 256 B */
 int pcp_canvas_clear(const pcp_grid_t *grid, const void *workspace, int64_t n, float *canvas, void *stream);

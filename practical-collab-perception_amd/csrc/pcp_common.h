@@ -41,9 +41,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---- workspace layout of pcp_voxelize / pcp_pfn_scatter (offsets in bytes, all 256-B aligned) -----------------------
 struct VoxLayout {
   size_t cell_count;    // int32 [cells]   points per cell (zeroed every call)
-  size_t cell_fill;     // int32 [cells]   (round 1-2: bucket cursor of a second atomic pass; unused since round 3, kept in the layout)
   size_t cell_rank;     // int32 [cells]   pillar rank, -1 if empty
-  size_t cell_start;    // int32 [cells]   first slot of the cell in bucket order
+  size_t cell_rs;       // int2  [cells]   occupied cells: {pillar rank, first slot of the cell in bucket order} (one 8-byte gather per point)
   size_t point_cell;    // int32 [n]       merged cell id or -1
   size_t point_rank;    // int32 [n]       arrival rank of the row inside its cell (the value the histogram atomic returned)
   size_t bucket_order;  // int32 [n]       point rows grouped by pillar (ascending merged id)
@@ -59,9 +58,8 @@ static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = pcp_align_up(off + bytes, 256); return o; };
   L.cell_count = take((size_t)cells * 4);
-  L.cell_fill = take((size_t)cells * 4);
   L.cell_rank = take((size_t)cells * 4);
-  L.cell_start = take((size_t)cells * 4);
+  L.cell_rs = take((size_t)cells * 8);
   L.point_cell = take((size_t)n * 4);
   L.point_rank = take((size_t)n * 4);
   L.bucket_order = take((size_t)n * 4);
@@ -72,4 +70,28 @@ static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
   L.counters = take(64);
   L.total = off;
   return L;
+}
+
+// ---- round 5: rows in pillar order + wave tiles for pcp_pfn_rows (csrc/pfn_rows.hip) ---------------------------------------------------
+// The first VoxLayout fields keep their offsets, so a rows workspace is also a pcp_voxelize workspace (cell -> rank table for the sparse
+// first layer, bucket order for the training kernels).
+//   srows      float [n][rs]   the kept rows in SLOT order (slot = position in the bucket order: pillars ascending, a pillar's points
+//                              consecutive): [raw 0 .. num_raw) | zero pad | pillar rank | cx << 16 | cy | (b * ny + cy) * nx + cx], rs = 8 (num_raw <= 5) or 16
+//   tile_desc  int2  [n/T + 2] wave tile t owns the pillars whose first slot lies in [T t, T (t + 1)): {first such pillar, its first slot};
+//                              written for every t with 0 < T t <= N' (entry 0 is {0, 0})
+constexpr int PCP_PFN_TILE = 30;
+static inline int pcp_rows_stride(int num_raw) { return num_raw <= 5 ? 8 : 16; }
+struct RowsLayout {
+  VoxLayout v;
+  size_t srows, tile_desc, total;
+};
+static inline RowsLayout pcp_rows_layout(int64_t cells, int64_t n, int num_raw) {
+  RowsLayout R;
+  R.v = pcp_vox_layout(cells, n);
+  size_t off = R.v.total;
+  auto take = [&](size_t bytes) { size_t o = off; off = pcp_align_up(off + bytes, 256); return o; };
+  R.srows = take((size_t)n * pcp_rows_stride(num_raw) * 4);
+  R.tile_desc = take((size_t)(n / PCP_PFN_TILE + 2) * 8);
+  R.total = off;
+  return R;
 }

@@ -1,0 +1,635 @@
+// a2 / a3 / a5, round 5 -- PillarFeatureNet + scatter rebuilt for the memory system: wave-autonomous, register-chained, streaming.
+//
+// Reference path replaced (pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:110-126, :35-46 and
+// pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37):
+//   mean = scatter_mean(xyz); f = [raw, xyz - mean, xyz - cell_centre]; x = relu(bn(W0 f)); xm = scatter_max(x);
+//   y = relu(bn(W1 [x, xm[inv]])); out = scatter_max(y); canvas[:, y, x] = out.
+//
+// What k_pfn (csrc/pfn.hip, rounds 1-4) measured: 0.33 matrix-pipe busy, 0.39 of the wave cycles parked -- a 64-pillar workgroup sat
+// behind a chain of dependent gathers (counters -> pillar_start -> bucket_order -> rows), three barriers per 64-point chunk and an LDS
+// round trip of the layer-0 tile between the two layers.  Here:
+//   * pcp_pillarise_rows leaves the kept rows IN PILLAR ORDER (32- or 64-byte records that carry the pillar rank, cell and frame), so a
+//     wave's input is one contiguous run: coalesced 16-byte loads, no index chain;
+//   * ONE WAVE owns a tile: the pillars whose first slot lies in [30 t, 30 (t + 1)) -- about 30 points, at most 30 pillars, any number of
+//     points per pillar -- found from an 8-byte descriptor the pillariser's scan wrote.  No workgroup barrier anywhere; every per-pillar
+//     reduction (fixed-point xyz sums, running maxima of both layers) is an LDS atomic in the wave's private 13 KB;
+//   * both layers run on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand and 16 points as the B operand: the accumulator of layer 0
+//     (lane (n, g): channels 16 b + 4 g + i of point n) IS the B operand of layer 1 -- no LDS round trip, no shuffle; the layer-0 bias rides
+//     on a spare feature slot; a lane ends with four consecutive channels of one pillar: 16-byte stores;
+//   * dense clouds: the wave also zero-fills the EMPTY cells between its pillars (it reads the 30 - 60 entries of the cell -> rank table
+//     that cover its range), so the canvas is written exactly once -- no clear-by-list pass, no zero fill.
+// Order independence (bitwise reproducible results whatever the arrival order inside a pillar): means accumulate in 2^-24 fixed point
+// (integer adds commute), maxima are order independent, every per-point product has a fixed summation order.
+//
+// Algorithmic HBM bytes per launch: n' * 32 (rows) + P * 256 (pillar rows) or B * ny * nx * 256 (canvas).  Matrix work: 2 * (12 * 32 + 32 * 64)
+// flop per point + 2 * 32 * 64 per pillar -- at the fp32 MFMA rate (157 TFLOP/s) about as long as the bytes take at the copy rate: the kernel
+// is balanced between the two, which is why neither may wait for the other.
+#include <stdlib.h>
+#include "pcp_common.h"
+
+namespace {
+
+constexpr int PR_THREADS = 256;                 // four independent waves; the workgroup exists only to share the launch
+constexpr int PR_T = PCP_PFN_TILE;
+constexpr int PR_MAXP = 32;                     // pillars per wave tile (<= PR_T: every owned pillar starts at a different slot of the window)
+
+struct PrParams {
+  const float *srows;                           // [N'][RS]
+  const int2 *tile_desc;
+  const int *counters;                          // P, N'
+  const int *cell_rank;                         // canvas mode: occupancy of the cells between this wave's pillars
+  const float *w0, *b0, *w1, *b1;
+  float *pillar_features;                       // (P, 64) or null
+  float *canvas;                                // (B, ny, nx, 64) or null
+  pcp_grid_t g;
+  long long cells;
+  int n_tiles_max;                              // tiles the host sized the grid for (ceil(n / T) + 1)
+  unsigned long long plane_m, ny_m;             // exact division of a cell id (< 2^31) by nx * ny and by ny: (c * m) >> sh
+  int plane_sh, ny_sh;
+};
+
+// floor(c / d) for 0 <= c < 2^31 as one 64-bit multiply and a shift: m = floor(2^(31 + s) / d) + 1 with 2^s >= d (exact for 31-bit c)
+inline void magic_div(unsigned d, unsigned long long *m, int *sh) {
+  int s = 0;
+  while ((1ULL << s) < d) s++;
+  *m = ((1ULL << (31 + s)) / d) + 1ULL;
+  *sh = 31 + s;
+}
+__device__ __forceinline__ int div_magic(int c, unsigned long long m, int sh) { return (int)(((unsigned long long)(unsigned)c * m) >> sh); }
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4a mfma16(float a, float b, f32x4a c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// feature index of layer-0 k-step s for lane group g (-1: no feature, -2: the constant 1 that carries the bias)
+template <int NUM_RAW>
+__device__ __forceinline__ int feat_index(int s, int g) {
+  if (g < 3) {
+    if (s == 0) return g;                       // x, y, z
+    if (s == 1) return NUM_RAW + g;             // f_cluster
+    if (s == 2) return NUM_RAW + 3 + g;         // f_center
+  } else {
+    if (s == 0) return NUM_RAW > 3 ? 3 : -2;
+    if (s == 1) return NUM_RAW > 4 ? 4 : (NUM_RAW > 3 ? -2 : -1);
+    if (s == 2) return NUM_RAW > 5 ? 5 : (NUM_RAW > 4 ? -2 : -1);
+  }
+  const int k = 6 + 4 * (s - 3) + g;
+  if (k < NUM_RAW) return k;
+  return (k == NUM_RAW && NUM_RAW > 5) ? -2 : -1;
+}
+// number of layer-0 k-steps: every feature and the bias slot must have a (step, group) home
+// relu on the bits: a negative float is a negative integer (one v_max_i32; fmaxf costs a canonicalising v_max_f32 more)
+__device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+template <int NUM_RAW>
+constexpr int l0_steps() { return NUM_RAW <= 5 ? 3 : 3 + (NUM_RAW - 6 + 1 + 3) / 4; }
+
+
+// round(a * 2^24) as a 64-bit integer without a trip through f64: a - floor(a) is exact in fp32 and adding the (even) integer part does not
+// change a round-half-even decision, so hi * 2^24 + rint(frac * 2^24) == rint(a * 2^24)
+__device__ __forceinline__ long long fixed24(float a) {
+  const float fl = floorf(a);
+  const float fr = __fsub_rn(a, fl);
+  const long long hi = (long long)(int)fl;
+  const unsigned lo = (unsigned)(int)rintf(fr * 16777216.0f);
+  return hi * 16777216LL + (long long)lo;
+}
+
+#ifdef PR_STAMP
+// diagnostic build (csrc/build_variant.sh prstamp "-DPR_STAMP=<workgroup>"): shader cycles wave 0 of that workgroup spends per phase, summed
+// over its tiles; read by tools/stamp_pfn_rows.py.  No stamp executes in the product build.
+__device__ unsigned long long pr_dbg[16];
+#define PR_MARK(k)                                                \
+  do {                                                            \
+    if (stamp) {                                                  \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      st_acc[k] += now_ - st_last;                                \
+      st_last = now_;                                             \
+    }                                                             \
+  } while (0)
+#else
+#define PR_MARK(k) do {} while (0)
+#endif
+
+// WPS: waves per SIMD the register allocation is held to (3: 168 registers, 2: 256)
+template <int NUM_RAW, int WPS>
+__global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
+  constexpr int RS = NUM_RAW <= 5 ? 8 : 16;
+  constexpr int RQ = RS / 4;                                  // 16-byte pieces of a record
+  constexpr int S0 = l0_steps<NUM_RAW>();
+  constexpr int F = NUM_RAW + 6;
+  constexpr int NPRE = 2;                                     // 16-point column tiles of a wave tile that travel in registers (32 slots: nearly all)
+  // wave-private LDS (no barrier ever orders it: the LDS executes one wave's instructions in order)
+  __shared__ __attribute__((aligned(16))) unsigned long long s_sum[4][PR_MAXP * 4];       // [pillar][x, y, z, count] fixed point; then means
+  __shared__ __attribute__((aligned(16))) float s_xmax[4][32 * 32];                       // [channel][pillar column] running max of layer 0 (>= 0)
+  __shared__ __attribute__((aligned(16))) float s_dmax[4][64 * 32];                       // [channel][pillar column] running max of W1a . x
+  __shared__ __attribute__((aligned(16))) float s_b1[64];                                 // every wave writes the same values: no barrier needed
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  unsigned long long *sum = s_sum[wave];
+  float *meanf = reinterpret_cast<float *>(sum);              // [pillar][4]: mean x, y, z | canvas row (int bits); aliases the sums
+  float *xmax = s_xmax[wave];
+  float *dmax = s_dmax[wave];
+  const int skew = 16 * (g & 1);                              // pillar column of lane group g: (lp + skew) & 31 -> conflict-free banks
+
+  // ---- once per wave: weight fragments, LDS init ----------------------------------------------------------------------------------
+  float w0f[2][S0];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int s = 0; s < S0; s++) {
+      const int fi = feat_index<NUM_RAW>(s, g);
+      w0f[b][s] = fi >= 0 ? p.w0[(16 * b + n) * F + fi] : (fi == -2 ? p.b0[16 * b + n] : 0.f);
+    }
+  f32x4 w1a[4][2], w1b[4][2];                                 // [row block r][k block b]: W1[16 r + n][16 b + 4 g + i], + 32 for the max half
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const float *wr = p.w1 + (16 * r + n) * 64 + 16 * b + 4 * g;
+      w1a[r][b] = *reinterpret_cast<const f32x4 *>(wr);
+      w1b[r][b] = *reinterpret_cast<const f32x4 *>(wr + 32);
+    }
+  for (int i = lane; i < PR_MAXP * 4; i += 64) sum[i] = 0ULL;
+  for (int i = lane; i < 32 * 32; i += 64) xmax[i] = 0.f;
+  for (int i = lane; i < 64 * 32; i += 64) dmax[i] = -__builtin_inff();
+  s_b1[lane] = p.b1[lane];
+
+  // counters of pcp_pillarise_rows: pillars, kept points, records of multi-point pillars (slots [0, Nm)), single-point pillars (slots [Nm, N'))
+  const int Nv = p.counters[1], Nm = p.counters[2], S = p.counters[3];
+  const int n_tiles = min(Nm / PR_T + 1, p.n_tiles_max);      // wave tiles over the multi-point records
+  const int n_sing = (S + 63) >> 6;                           // units of 64 single-point pillars
+  const int plane = p.g.nx * p.g.ny;
+  // cell-centre offsets exactly as the reference constructor rounds them (dynamic_pillar_vfe.py:80-82)
+  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
+  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
+  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
+  const float vsel = g == 0 ? p.g.voxel_x : (g == 1 ? p.g.voxel_y : 0.f);
+  const float osel = g == 0 ? x_off : (g == 1 ? y_off : z_off);
+  // wave-uniform reads (tile descriptors, the record that ends a tile's cell range) go through the scalar cache: their waits count on
+  // lgkmcnt, so they never order behind this wave's vector stores (the tables were written by the kernel in front of this one)
+  typedef __attribute__((address_space(4))) const int *cint_p;
+  const cint_p desc_c = (cint_p)(unsigned long long)p.tile_desc;
+  const cint_p rows_c = (cint_p)(unsigned long long)p.srows;
+
+  // a wave owns a CONTIGUOUS run of work units: wave tiles first, then the units of singles
+  const int n_units = n_tiles + n_sing;
+  const int n_waves = gridDim.x * 4;
+  const int per_wave = (n_units + n_waves - 1) / n_waves;
+  const int u_begin = (blockIdx.x * 4 + wave) * per_wave;
+  const int u_end = min(u_begin + per_wave, n_units);
+  if (u_begin >= u_end) return;
+
+  auto first_slot = [&](int t) -> int {                        // first record of wave tile t; tiles past the multi-point records: Nm
+    if (t == 0) return 0;
+    return ((long long)t * PR_T <= Nm) ? desc_c[2 * (long long)t + 1] : Nm;
+  };
+  // What a lane keeps of a record: lane (n, g) multiplies point n's features {x | y | z | raw 3}[g] and their derived ones, so it loads
+  // exactly its own column (a per-lane address: no register-indexed select) and the record's last 16 bytes.
+  struct Rec {
+    float a;                 // raw[min(g, 3)]
+    f32x4 q;                 // RS 8: {raw 4, rank, cx << 16 | cy, canvas row}; RS 16: {pad, rank, cell, canvas row}
+    float e4, e5, e6g, e10;  // RS 16 only: raw 4, raw 5, raw 6 + g, raw 10
+  };
+  const int acol = g < 3 ? g : 3;
+  auto load_rec = [&](Rec &r, int slot) {
+    const float *src = p.srows + (long long)slot * RS;
+    r.a = src[acol];
+    r.q = *reinterpret_cast<const f32x4 *>(src + RS - 4);
+    if (RS == 16) {
+      r.e4 = src[4];
+      r.e5 = src[5];
+      r.e6g = src[6 + g];
+      r.e10 = src[10];
+    }
+  };
+  auto load_recs = [&](Rec (&dst)[NPRE], int a0, int b0s) {
+#pragma unroll
+    for (int j = 0; j < NPRE; j++) {
+      const int slot = a0 + 16 * j + n;
+      if (slot < b0s) load_rec(dst[j], slot);
+    }
+  };
+  // merged cell id of a record from its packed cell and canvas row, on the scalar unit (b = row / (nx * ny))
+  auto cell_scalar = [&](int cxcy, int crow) -> int {
+    const int fb = (int)(((unsigned long long)(unsigned)crow * p.plane_m) >> p.plane_sh);
+    return fb * plane + (cxcy >> 16) * p.g.ny + (cxcy & 0xffff);
+  };
+  // the features of a point (f_cluster = 0 for the only point of a pillar) and layer 0 on them: x^T (32 channels x 16 points) = W0 . f^T,
+  // bias on the spare feature slot, ReLU
+  auto layer0 = [&](const Rec &rr, float cluster, f32x4a &x0, f32x4a &x1) {
+    const int cxcy = __float_as_int(rr.q.z);
+    const float av = rr.a;
+    const float cf = (float)(g == 0 ? (cxcy >> 16) : (cxcy & 0xffff));
+    const float centre = __fadd_rn(__fmul_rn(cf, vsel), osel);
+    float f[S0];
+    const float raw4 = RS == 8 ? rr.q.x : rr.e4;
+    f[0] = (g < 3 || NUM_RAW > 3) ? av : 1.f;
+    f[1] = g < 3 ? cluster : (NUM_RAW > 4 ? raw4 : (NUM_RAW > 3 ? 1.f : 0.f));
+    f[2] = g < 3 ? __fsub_rn(av, centre) : (NUM_RAW > 5 ? rr.e5 : (NUM_RAW > 4 ? 1.f : 0.f));
+    if (S0 > 3) f[3] = rr.e6g;                                               // raws 6 .. 9
+    if (S0 > 4) f[4] = g == 0 ? rr.e10 : (g == 1 ? 1.f : 0.f);               // raw 10 | the constant 1 of the bias
+    x0 = f32x4a{0.f, 0.f, 0.f, 0.f};
+    x1 = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S0; s++) {
+      x0 = mfma16(w0f[0][s], f[s], x0);
+      x1 = mfma16(w0f[1][s], f[s], x1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      x0[i] = relu_f(x0[i]);
+      x1[i] = relu_f(x1[i]);
+    }
+  };
+
+#ifdef PR_STAMP
+  const bool stamp = blockIdx.x == PR_STAMP && wave == 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+
+  // =================================== wave tiles over the records of multi-point pillars ===================================================
+  const int t_begin = u_begin, t_end = min(u_end, n_tiles);
+  if (t_begin < t_end) {
+    int acur = first_slot(t_begin), anext = first_slot(t_begin + 1), ann = first_slot(t_begin + 2);
+    Rec bufa[NPRE], bufb[NPRE];
+#pragma unroll
+    for (int j = 0; j < NPRE; j++) {
+      bufa[j].a = bufb[j].a = 0.f;
+      bufa[j].q = bufb[j].q = f32x4{0.f, 0.f, 0.f, 0.f};
+      bufa[j].e4 = bufa[j].e5 = bufa[j].e6g = bufa[j].e10 = bufb[j].e4 = bufb[j].e5 = bufb[j].e6g = bufb[j].e10 = 0.f;
+    }
+    load_recs(bufa, acur, anext);
+
+    // one tile; `cur` holds its first 32 records, `nxt` receives the next tile's (the caller alternates the two buffers: no register copies)
+    auto tile_body = [&](int t, Rec (&cur)[NPRE], Rec (&nxt)[NPRE]) {
+      const int a = acur, bslot = anext;
+      // ---- prefetch: the next tile's records (its first slot arrived a tile ago), the first slot three tiles on, the occupancy of this
+      // tile's cell range
+      load_recs(nxt, bslot, ann);                              // behind the last tile: bslot == Nm, nothing is loaded
+      const int an3 = first_slot(t + 3);
+      int lo = 0;
+      if (a > 0 && a < bslot)
+        lo = cell_scalar(__builtin_amdgcn_readfirstlane(__float_as_int(cur[0].q.z)), __builtin_amdgcn_readfirstlane(__float_as_int(cur[0].q.w)));
+      int occ = 0, hi = (int)p.cells;                         // cell range [lo, hi) of this tile: hi = the cell of the record behind it
+      if (p.canvas && a < bslot) {
+        if (lo + lane < (int)p.cells) occ = p.cell_rank[lo + lane];
+        if (bslot < Nm) hi = cell_scalar(rows_c[(long long)bslot * RS + RS - 2], rows_c[(long long)bslot * RS + RS - 1]);
+      }
+      PR_MARK(0);
+
+      if (a >= bslot) {
+        // no multi-point pillar at all: nobody owns the canvas's empty cells, the first wave zero-fills them (slow, tiny clouds only)
+        if (t == 0 && Nm == 0 && p.canvas) {
+          for (int c0 = 0; c0 < (int)p.cells; c0 += 64) {
+            const int c = c0 + lane;
+            unsigned long long m = __ballot(c < (int)p.cells && p.cell_rank[c < (int)p.cells ? c : 0] < 0);
+            while (m) {
+              const int pos = __builtin_ctzll(m);
+              m &= m - 1;
+              const int cell = c0 + pos;
+              const int fb = div_magic(cell, p.plane_m, p.plane_sh), rem = cell - fb * plane;
+              const int cx = div_magic(rem, p.ny_m, p.ny_sh), cy = rem - cx * p.g.ny;
+              if (g == 0) *reinterpret_cast<f32x4 *>(p.canvas + (((long long)fb * p.g.ny + cy) * p.g.nx + cx) * 64 + 4 * n) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+      } else {
+        const int ncol = (bslot - a + 15) >> 4;
+        // local pillar index of every record: the number of pillar heads (rank differs from the record in front) up to it.  The ranks of
+        // a tile are not consecutive (single-point pillars lie between them in rank order), the records are.
+        int heads = 0, last_rank = -1;
+        auto local_pillar = [&](const Rec &r, bool valid) -> int {
+          const int rk = __float_as_int(r.q.y);
+          const int prev = __builtin_amdgcn_update_dpp(last_rank, rk, 0x111, 0xf, 0xf, false);      // row_shr:1, lane n = 0 keeps last_rank
+          const unsigned long long hm = __ballot(valid && rk != prev) & 0xffffULL;                    // row g = 0 (all four rows agree)
+          const int lp = heads + __builtin_popcountll(hm & ((2ULL << n) - 1ULL)) - 1;
+          heads += __builtin_popcountll(hm);
+          last_rank = __builtin_amdgcn_readlane(rk, 15);
+          return valid ? lp : 0;
+        };
+        int lpj[NPRE];
+#pragma unroll
+        for (int j = 0; j < NPRE; j++) lpj[j] = (j < ncol) ? local_pillar(cur[j], a + 16 * j + n < bslot) : 0;
+
+        // ---- phase A: fixed-point xyz sums and the point count of every pillar ---------------------------------------------------------
+        auto phase_a = [&](const Rec &r, int lp) {
+          const unsigned long long q = g < 3 ? (unsigned long long)fixed24(r.a) : 1ULL;
+          __hip_atomic_fetch_add(&sum[lp * 4 + g], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+#pragma unroll
+        for (int j = 0; j < NPRE; j++)
+          if (a + 16 * j + n < bslot) phase_a(cur[j], lpj[j]);
+        {
+          // crowded tiles: the records past the first 32 slots are read where they are used (twice: here and in phase C)
+          const int heads0 = heads, last0 = last_rank;
+          for (int j = NPRE; j < ncol; j++) {
+            const int slot = a + 16 * j + n;
+            const bool valid = slot < bslot;
+            Rec r;
+            load_rec(r, valid ? slot : bslot - 1);
+            const int lp = local_pillar(r, valid);
+            if (valid) phase_a(r, lp);
+          }
+          if (ncol > NPRE) {                                   // phase C walks the same records again from the same state
+            heads = heads0;
+            last_rank = last0;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        PR_MARK(1);
+        // ---- phase B: means (the sums' memory is reused: [pillar][4] floats); 16 * k < np is decided on the counts themselves --------------
+        {
+          long long sv[2];
+          unsigned cntv[2];
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int lp = n + 16 * k;
+            sv[k] = (long long)sum[lp * 4 + g];
+            cntv[k] = (unsigned)sum[lp * 4 + 3];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int lp = n + 16 * k;
+            if (g < 3 && cntv[k] > 0) {
+              // sum / count in f64 by reciprocal + one Newton step + one residual correction (the f64 divide is ~10x the instructions)
+              const double c = (double)cntv[k], sd = (double)sv[k] * (1.0 / 16777216.0);
+              double rc = __builtin_amdgcn_rcp(c);
+              rc = __builtin_fma(__builtin_fma(-c, rc, 1.0), rc, rc);
+              double qd = sd * rc;
+              qd = __builtin_fma(__builtin_fma(-c, qd, sd), rc, qd);
+              meanf[lp * 4 + g] = (float)qd;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+
+        PR_MARK(2);
+        // ---- phase C: per 16 points: features -> layer 0 -> running max -> point half of layer 1 -> running max --------------------------
+        int *pinfo = reinterpret_cast<int *>(sum) + PR_MAXP * 4;     // [pillar][4] ints in the upper half of the sums' memory: rank, canvas row
+        auto phase_c = [&](const Rec &rr, int lp, bool valid) {
+          const int col = (lp + skew) & 31;
+          float *xb = xmax + (4 * g) * 32 + col, *db = dmax + (4 * g) * 32 + col;     // + compile-time offsets per (block, i)
+          if (g == 3 && valid) *reinterpret_cast<float2 *>(&pinfo[lp * 4]) = make_float2(rr.q.y, rr.q.w);   // every point of the pillar writes the same pair
+          const float mean = meanf[lp * 4 + acol];
+          f32x4a x0, x1;
+          layer0(rr, __fsub_rn(rr.a, mean), x0, x1);
+          if (valid) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              __hip_atomic_fetch_max(&xb[i * 32], x0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_max(&xb[(16 + i) * 32], x1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          // point half of layer 1: d^T (64 x 16) = W1[:, :32] . x^T -- the layer-0 accumulators are the B operand as they stand
+          f32x4a dacc[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) dacc[r] = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][0][i], x0[i], dacc[r]);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][1][i], x1[i], dacc[r]);
+          if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                __hip_atomic_fetch_max(&db[(16 * r + i) * 32], dacc[r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < NPRE; j++)
+          if (j < ncol) phase_c(cur[j], lpj[j], a + 16 * j + n < bslot);
+        for (int j = NPRE; j < ncol; j++) {
+          const int slot = a + 16 * j + n;
+          const bool valid = slot < bslot;
+          Rec rr;
+          load_rec(rr, valid ? slot : bslot - 1);
+          const int lp = local_pillar(rr, valid);
+          phase_c(rr, lp, valid);
+        }
+        const int np = heads;                                  // pillars of the tile (<= PR_T: each starts at another slot of the window)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        PR_MARK(3);
+        // Everything prefetched at the top of the tile is waited for HERE, in front of the first store of the tile: hipcc cannot count the
+        // stores below (data-dependent loops), so any later wait on a load would be vmcnt(0) and would sit behind them.  From here to the
+        // top of the next tile no vector load is waited for.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        unsigned long long empty0 = 0ULL;
+        if (p.canvas) empty0 = __ballot(lo + lane < hi && occ < 0);
+        // ---- phase D: per 16 pillars: out = relu(b1 + W1[:, 32:] . xmax + dmax), 16-byte stores; the LDS words are reset as they are read ----
+        for (int k = 0; k * 16 < np; k++) {
+          const int lp = n + 16 * k;
+          const bool live = lp < np;
+          const int col = (lp + skew) & 31;
+          float *xb = xmax + (4 * g) * 32 + col, *db = dmax + (4 * g) * 32 + col;
+          float xm0[4], xm1[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            xm0[i] = __hip_atomic_exchange(&xb[i * 32], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            xm1[i] = __hip_atomic_exchange(&xb[(16 + i) * 32], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          f32x4a o[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(&s_b1[16 * r + 4 * g]);
+            o[r] = f32x4a{bv.x, bv.y, bv.z, bv.w};
+          }
+          float dm[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              dm[r][i] = __hip_atomic_exchange(&db[(16 * r + i) * 32], -__builtin_inff(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int2 pi = *reinterpret_cast<const int2 *>(&pinfo[min(lp, PR_MAXP - 1) * 4]);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][0][i], xm0[i], o[r]);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][1][i], xm1[i], o[r]);
+          if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              f32x4 v;
+              v.x = relu_f(o[r][0] + dm[r][0]);
+              v.y = relu_f(o[r][1] + dm[r][1]);
+              v.z = relu_f(o[r][2] + dm[r][2]);
+              v.w = relu_f(o[r][3] + dm[r][3]);
+              if (p.pillar_features) *reinterpret_cast<f32x4 *>(p.pillar_features + (long long)pi.x * 64 + 16 * r + 4 * g) = v;
+              if (p.canvas) *reinterpret_cast<f32x4 *>(p.canvas + (long long)pi.y * 64 + 16 * r + 4 * g) = v;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the sums of the next tile start from zero (the means, ranks and canvas rows sat in their memory)
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(sum) + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+        PR_MARK(4);
+        // ---- phase E (canvas): zero rows for the empty cells of this wave's cell range --------------------------------------------------
+        if (p.canvas) {
+          // range: from the tile's first pillar (from cell 0 for the tile that holds record 0) up to the first multi-point pillar behind it
+          for (int c0 = lo; c0 < hi; c0 += 64) {
+            unsigned long long m = empty0;
+            if (c0 != lo) {
+              const int c = c0 + lane;
+              m = __ballot(c < hi && p.cell_rank[c < hi ? c : lo] < 0);
+            }
+            while (m) {
+              // four empty cells per store instruction: lane group g takes the g-th lowest set bit
+              int pos[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                pos[q] = m ? __builtin_ctzll(m) : -1;
+                m &= m - 1;
+              }
+              const int mine = g == 0 ? pos[0] : (g == 1 ? pos[1] : (g == 2 ? pos[2] : pos[3]));
+              if (mine >= 0) {
+                const int cell = c0 + mine;
+                const int fb = div_magic(cell, p.plane_m, p.plane_sh), rem = cell - fb * plane;
+                const int cx = div_magic(rem, p.ny_m, p.ny_sh), cy = rem - cx * p.g.ny;
+                const long long row = ((long long)fb * p.g.ny + cy) * p.g.nx + cx;
+                *reinterpret_cast<f32x4 *>(p.canvas + row * 64 + 4 * n) = f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
+          }
+        }
+      }
+      PR_MARK(5);
+      acur = anext;
+      anext = ann;
+      ann = an3;
+    };
+    for (int t = t_begin; t < t_end; t += 2) {
+      tile_body(t, bufa, bufb);
+      if (t + 1 < t_end) tile_body(t + 1, bufb, bufa);
+    }
+  }
+
+  // =================================== single-point pillars: 64 per unit, no per-pillar reduction ============================================
+  // The only point of a pillar is its own mean (f_cluster = 0, exactly what scatter_mean of one value gives) and its own maximum:
+  // out = relu(b1 + (W1[:, :32] + W1[:, 32:]) . relu(W0 f + b0)) -- one 32-deep product instead of two, no LDS traffic at all.
+  const int s_begin = max(u_begin, n_tiles) - n_tiles, s_end = u_end - n_tiles;
+  if (s_begin < s_end) {
+    f32x4 w1c[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) w1c[r][b] = w1a[r][b] + w1b[r][b];
+    Rec rec[4], recn[4];
+    auto load4 = [&](Rec (&dst)[4], int unit) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int slot = Nm + 64 * unit + 16 * j + n;
+        dst[j].a = 0.f;
+        dst[j].q = f32x4{0.f, 0.f, 0.f, 0.f};
+        dst[j].e4 = dst[j].e5 = dst[j].e6g = dst[j].e10 = 0.f;
+        if (slot < Nv) load_rec(dst[j], slot);
+      }
+    };
+    auto unit_body = [&](int unit, Rec (&cur)[4], Rec (&nxt)[4]) {
+      if (unit + 1 < s_end) load4(nxt, unit + 1);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool valid = Nm + 64 * unit + 16 * j + n < Nv;
+        f32x4a x0, x1;
+        layer0(cur[j], 0.f, x0, x1);
+        f32x4a o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(&s_b1[16 * r + 4 * g]);
+          o[r] = f32x4a{bv.x, bv.y, bv.z, bv.w};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[r] = mfma16(w1c[r][0][i], x0[i], o[r]);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[r] = mfma16(w1c[r][1][i], x1[i], o[r]);
+        if (valid) {
+          const long long prow = __float_as_int(cur[j].q.y), crow = __float_as_int(cur[j].q.w);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const f32x4 v = f32x4{relu_f(o[r][0]), relu_f(o[r][1]), relu_f(o[r][2]), relu_f(o[r][3])};
+            if (p.pillar_features) *reinterpret_cast<f32x4 *>(p.pillar_features + prow * 64 + 16 * r + 4 * g) = v;
+            if (p.canvas) *reinterpret_cast<f32x4 *>(p.canvas + crow * 64 + 16 * r + 4 * g) = v;
+          }
+        }
+      }
+    };
+    load4(rec, s_begin);
+    for (int u = s_begin; u < s_end; u += 2) {
+      unit_body(u, rec, recn);
+      if (u + 1 < s_end) unit_body(u + 1, recn, rec);
+    }
+  }
+#ifdef PR_STAMP
+  if (stamp && lane == 0) {
+    for (int k = 0; k < 8; k++) pr_dbg[k] = st_acc[k];
+    pr_dbg[8] = (unsigned long long)max(min(u_end, n_tiles) - u_begin, 0);
+  }
+#endif
+}
+
+}  // namespace
+
+#ifdef PR_STAMP
+extern "C" int pcp_debug_read_pfn_rows(void *dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pr_dbg), bytes) == hipSuccess ? 0 : 3;
+}
+#endif
+
+extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
+                            const float *w1, const float *b1, float *pillar_features, float *canvas, void *stream_) {
+  if (!grid || !workspace || !w0 || !b0 || !w1 || !b1 || n < 0) return PCP_ERR_ARG;
+  if ((((uintptr_t)w1) & 15) || (((uintptr_t)b1) & 15) || (((uintptr_t)pillar_features) & 15) || (((uintptr_t)canvas) & 15)) return PCP_ERR_ARG;
+  if (grid->batch_size <= 0 || grid->nx <= 0 || grid->ny <= 0 || grid->nx > 65535 || grid->ny > 65535) return PCP_ERR_ARG;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  if (cells >= (1LL << 31) || n >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
+  if (num_raw != 3 && num_raw != 4 && num_raw != 5 && num_raw != 11) return PCP_ERR_UNSUPPORTED;
+  const RowsLayout R = pcp_rows_layout(cells, n > 0 ? n : 1, num_raw);
+  const char *ws = (const char *)workspace;
+  PrParams p;
+  p.srows = (const float *)(ws + R.srows);
+  p.tile_desc = (const int2 *)(ws + R.tile_desc);
+  p.counters = (const int *)(ws + R.v.counters);
+  p.cell_rank = (const int *)(ws + R.v.cell_rank);
+  p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
+  p.pillar_features = pillar_features;
+  p.canvas = canvas;
+  p.g = *grid;
+  p.cells = cells;
+  p.n_tiles_max = (int)(n / PR_T + 1);
+  magic_div((unsigned)(grid->nx * grid->ny), &p.plane_m, &p.plane_sh);
+  magic_div((unsigned)grid->ny, &p.ny_m, &p.ny_sh);
+  static const int wps = [] { const char *e = getenv("PCP_PFN_WPS"); return e ? atoi(e) : 2; }();     // A/B knob (tools/bench_frontend.py)
+  int blocks = (p.n_tiles_max + 3) / 4;
+  if (blocks > 256 * wps) blocks = 256 * wps;
+  hipStream_t stream = (hipStream_t)stream_;
+#define PCP_PFN_ROWS(NR)                                                                                            \
+  do {                                                                                                              \
+    if (wps == 3) hipLaunchKernelGGL((k_pfn_rows<NR, 3>), dim3(blocks), dim3(PR_THREADS), 0, stream, p);             \
+    else hipLaunchKernelGGL((k_pfn_rows<NR, 2>), dim3(blocks), dim3(PR_THREADS), 0, stream, p);                      \
+  } while (0)
+  switch (num_raw) {
+    case 5: PCP_PFN_ROWS(5); break;
+    case 11: PCP_PFN_ROWS(11); break;
+    case 3: PCP_PFN_ROWS(3); break;
+    case 4: PCP_PFN_ROWS(4); break;
+    default: return PCP_ERR_UNSUPPORTED;
+  }
+#undef PCP_PFN_ROWS
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}

@@ -66,7 +66,320 @@ __device__ __forceinline__ void block_scan_excl(T (&v)[SCAN_ITEMS], T *lds_wave 
   __syncthreads();
 }
 
-// pass 1 over points: cell id per row, per-cell histogram, valid rows per 1024-row tile
+__device__ __forceinline__ u64 pack_cell(int cnt) { return cnt > 0 ? ((1ULL << 32) | (u64)(unsigned)cnt) : 0ULL; }
+
+// ---- round 5: the cell passes -------------------------------------------------------------------------------------------------------------
+// Round 4 ran three launches (tile sums, a one-workgroup scan of them, per-cell outputs).  A single-pass decoupled look-back scan was built
+// and measured first this round: 25 us per 1 M cells, 69 us per 5.2 M -- every workgroup polls the same few status lines of one L2 channel
+// (512 x 256 polls per round).  What runs now has NO inter-workgroup dependency: k_cell_tile_sums leaves one (pillars, points) pair per
+// 2048-cell tile, and every workgroup of k_cell_finish adds up the pairs in front of its own tile itself (at most 2 560 x 8 bytes, coalesced,
+// from L2) before it scans its tile.
+constexpr int CS_ITEMS = 8;
+constexpr int CS_TILE = SCAN_THREADS * CS_ITEMS;     // 2048 cells per workgroup
+
+struct CellScanOut {
+  int *cell_rank, *pillar_cell, *pillar_start, *voxel_coords, *unq_cnt, *counters_ws, *counters_out;
+  int2 *cell_rs;
+  int2 *tile_desc;               // rows mode only
+};
+
+__device__ __forceinline__ void load_cell_counts(const int *__restrict__ cell_count, long long base, long long cells, int (&cnt)[CS_ITEMS]) {
+  if (base + CS_ITEMS <= cells) {
+    const int4 a = *reinterpret_cast<const int4 *>(cell_count + base), b = *reinterpret_cast<const int4 *>(cell_count + base + 4);
+    cnt[0] = a.x; cnt[1] = a.y; cnt[2] = a.z; cnt[3] = a.w; cnt[4] = b.x; cnt[5] = b.y; cnt[6] = b.z; cnt[7] = b.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < CS_ITEMS; i++) cnt[i] = (base + i < cells) ? cell_count[base + i] : 0;
+  }
+}
+
+// SEG (rows mode): pillars of exactly one point are counted apart -- their records go behind those of all multi-point pillars, where
+// pcp_pfn_rows runs them through a path without per-pillar reductions.  The scanned pair is then (pillars << 32 | slots of the multi-point
+// pillars) plus a 32-bit count of singles; without SEG every pillar counts as "multi" and the singles count stays zero.
+template <bool SEG>
+__device__ __forceinline__ u64 pack_cell_seg(int cnt) {
+  if (cnt <= 0) return 0ULL;
+  return (1ULL << 32) | (u64)(unsigned)((SEG && cnt == 1) ? 0 : cnt);
+}
+
+template <bool SEG>
+__global__ __launch_bounds__(SCAN_THREADS) void k_cell_tile_sums(const int *__restrict__ cell_count, long long cells, u64 *__restrict__ tile_sums,
+                                                                 unsigned *__restrict__ tile_singles) {
+  __shared__ u64 wave_tot[SCAN_THREADS / 64];
+  __shared__ unsigned wave_one[SCAN_THREADS / 64];
+  int cnt[CS_ITEMS];
+  load_cell_counts(cell_count, (long long)blockIdx.x * CS_TILE + (long long)threadIdx.x * CS_ITEMS, cells, cnt);
+  u64 s = 0;
+  unsigned ones = 0;
+#pragma unroll
+  for (int i = 0; i < CS_ITEMS; i++) {
+    s += pack_cell_seg<SEG>(cnt[i]);
+    ones += (SEG && cnt[i] == 1) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s += __shfl_xor(s, d, 64);
+    ones += __shfl_xor(ones, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wave_tot[threadIdx.x >> 6] = s;
+    wave_one[threadIdx.x >> 6] = ones;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+    unsigned t1 = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+      t += wave_tot[w];
+      t1 += wave_one[w];
+    }
+    tile_sums[blockIdx.x] = t;
+    tile_singles[blockIdx.x] = t1;
+  }
+}
+
+template <bool SEG>
+__global__ __launch_bounds__(SCAN_THREADS) void k_cell_finish(const int *__restrict__ cell_count, long long cells, pcp_grid_t g,
+                                                              const u64 *__restrict__ tile_sums, const unsigned *__restrict__ tile_singles,
+                                                              int n_tiles, CellScanOut o) {
+  __shared__ u64 lds64[SCAN_THREADS / 64 + 1];
+  __shared__ unsigned lds32[SCAN_THREADS / 64 + 1];
+  __shared__ u64 red[SCAN_THREADS / 64];
+  __shared__ unsigned red1[SCAN_THREADS / 64];
+  const int tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)tile * CS_TILE + (long long)threadIdx.x * CS_ITEMS;
+  int cnt[CS_ITEMS];
+  load_cell_counts(cell_count, base, cells, cnt);
+  // the sums of the tiles in front of this one
+  u64 pre = 0;
+  unsigned pre1 = 0;
+  for (int i = threadIdx.x; i < tile; i += SCAN_THREADS) {
+    pre += tile_sums[i];
+    if (SEG) pre1 += tile_singles[i];
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    pre += __shfl_xor(pre, d, 64);
+    if (SEG) pre1 += __shfl_xor(pre1, d, 64);
+  }
+  if (lane == 0) {
+    red[wave] = pre;
+    red1[wave] = pre1;
+  }
+  // exclusive scan of the (pillars, multi slots) pairs and of the singles inside the workgroup
+  u64 v[CS_ITEMS], local = 0;
+  unsigned v1[CS_ITEMS], local1 = 0;
+#pragma unroll
+  for (int i = 0; i < CS_ITEMS; i++) {
+    v[i] = local;
+    v1[i] = local1;
+    local += pack_cell_seg<SEG>(cnt[i]);
+    local1 += (SEG && cnt[i] == 1) ? 1u : 0u;
+  }
+  u64 incl = local;
+  unsigned incl1 = local1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u64 up = __shfl_up(incl, d, 64);
+    const unsigned up1 = SEG ? __shfl_up(incl1, d, 64) : 0u;
+    if (lane >= d) {
+      incl += up;
+      incl1 += up1;
+    }
+  }
+  if (lane == 63) {
+    lds64[wave] = incl;
+    lds32[wave] = incl1;
+  }
+  __syncthreads();
+  u64 wave_base = 0, agg = 0, excl = 0;
+  unsigned wave_base1 = 0, agg1 = 0, excl1 = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; w++) {
+    const u64 sw = lds64[w];
+    const unsigned sw1 = lds32[w];
+    if (w < wave) {
+      wave_base += sw;
+      wave_base1 += sw1;
+    }
+    agg += sw;
+    agg1 += sw1;
+    excl += red[w];
+    excl1 += red1[w];
+  }
+  if (threadIdx.x == 0) {
+    if (tile == n_tiles - 1) {
+      const u64 tot = excl + agg;
+      const int P = (int)(tot >> 32), Nm = (int)(tot & 0xffffffffULL), S = (int)(excl1 + agg1);
+      // counters: pillars, kept points, records of multi-point pillars (= kept points unless singles are set apart), single-point pillars
+      o.counters_ws[0] = P; o.counters_ws[1] = Nm + S; o.counters_ws[2] = Nm; o.counters_ws[3] = S;
+      if (o.counters_out) { o.counters_out[0] = P; o.counters_out[1] = Nm + S; o.counters_out[2] = SEG ? Nm : 0; o.counters_out[3] = SEG ? S : 0; }
+      o.pillar_start[P] = Nm + S;
+    }
+    if (tile == 0 && o.tile_desc) o.tile_desc[0] = make_int2(0, 0);
+  }
+  const u64 blk = excl + wave_base + incl - local;
+  const unsigned blk1 = excl1 + wave_base1 + incl1 - local1;
+  const int plane = g.nx * g.ny;
+  int rank_out[CS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < CS_ITEMS; i++) {
+    const long long c = base + i;
+    rank_out[i] = -1;
+    if (c < cells && cnt[i] > 0) {
+      const u64 e = v[i] + blk;
+      const int rank = (int)(e >> 32);
+      const bool single = SEG && cnt[i] == 1;
+      // first slot: a multi-point pillar's run among the multi-point records; a single's index among the singles, tagged (its slot is that
+      // index behind ALL multi-point records, whose number only the last workgroup knows: the point pass adds counters[2])
+      const int start = single ? (int)(0x80000000u | (v1[i] + blk1)) : (int)(e & 0xffffffffULL);
+      rank_out[i] = rank;
+      o.cell_rs[c] = make_int2(rank, start);
+      o.pillar_cell[rank] = (int)c;
+      o.pillar_start[rank] = start;
+      if (o.voxel_coords) {
+        const int b = (int)(c / plane), rem = (int)(c % plane);
+        const int cx = rem / g.ny, cy = rem % g.ny;
+        *reinterpret_cast<int4 *>(o.voxel_coords + 4LL * rank) = make_int4(b, 0, cy, cx);       // [batch, z, y, x] (dynamic_pillar_vfe.py:138-143)
+      }
+      if (o.unq_cnt) o.unq_cnt[rank] = cnt[i];
+      if (o.tile_desc && !single) {
+        // the NEXT multi-point pillar is the first one of every wave tile whose first slot lies in (start, start + cnt]: {its first
+        // record, that record's slot}; the record carries the pillar's rank
+        const int end = start + cnt[i];
+        for (int t = start / PCP_PFN_TILE + 1; t <= end / PCP_PFN_TILE; ++t) o.tile_desc[t] = make_int2(end, end);
+      }
+    }
+  }
+  // the cell -> rank table (every cell: the sparse first layer and the PFN's gap fill read empty cells too) as two 16-byte stores
+  if (base + CS_ITEMS <= cells) {
+    *reinterpret_cast<int4 *>(o.cell_rank + base) = make_int4(rank_out[0], rank_out[1], rank_out[2], rank_out[3]);
+    *reinterpret_cast<int4 *>(o.cell_rank + base + 4) = make_int4(rank_out[4], rank_out[5], rank_out[6], rank_out[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CS_ITEMS; i++)
+      if (base + i < cells) o.cell_rank[base + i] = rank_out[i];
+  }
+}
+
+// exclusive prefix over the per-tile kept-row counts (only the unq_inv path needs it)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_point_tiles(int *__restrict__ pt_block_sums, int n_pblk) {
+  __shared__ int lds32[SCAN_THREADS / 64 + 1];
+  int carry = 0;
+  for (int base = 0; base < n_pblk; base += SCAN_TILE) {
+    int v[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+      int idx = base + threadIdx.x * SCAN_ITEMS + i;
+      v[i] = idx < n_pblk ? pt_block_sums[idx] : 0;
+    }
+    int tot;
+    block_scan_excl<int>(v, lds32, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+      int idx = base + threadIdx.x * SCAN_ITEMS + i;
+      if (idx < n_pblk) pt_block_sums[idx] = v[i] + carry;
+    }
+    carry += tot;
+  }
+}
+
+// the row of the bucket order a kept point lands in; rows mode: the point's row is written there, ready for pcp_pfn_rows
+template <int RS>
+__device__ __forceinline__ void emit_point(const float *__restrict__ points, int stride, int num_raw, const pcp_grid_t &g, long long r, int cell,
+                                           int rank, int slot, int *__restrict__ bucket_order, float *__restrict__ srows) {
+  if (bucket_order) bucket_order[slot] = (int)r;
+  if (RS > 0) {
+    const float *row = points + r * stride;
+    const int plane = g.nx * g.ny;
+    const int b = cell / plane, rem = cell - b * plane;
+    const int cx = rem / g.ny, cy = rem - cx * g.ny;
+    float v[RS > 0 ? RS : 1];
+#pragma unroll
+    for (int k = 0; k < RS - 3; k++) v[k] = k < num_raw ? row[1 + k] : 0.f;
+    v[RS - 3] = __int_as_float(rank);
+    v[RS - 2] = __int_as_float((cx << 16) | cy);
+    v[RS - 1] = __int_as_float((b * g.ny + cy) * g.nx + cx);      // row of the (B, ny, nx, 64) canvas
+    f32x4 *dst = reinterpret_cast<f32x4 *>(srows + (long long)slot * RS);
+#pragma unroll
+    for (int q = 0; q < RS / 4; q++) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  }
+}
+
+// last pass over points, one thread per row (no unq_inv)
+template <int RS>
+__global__ __launch_bounds__(SCAN_THREADS) void k_point_place(const float *__restrict__ points, long long n, int stride, int num_raw, pcp_grid_t g,
+                                                              const int *__restrict__ point_cell, const int *__restrict__ point_rank,
+                                                              const int2 *__restrict__ cell_rs, const int *__restrict__ counters,
+                                                              int *__restrict__ bucket_order, float *__restrict__ srows) {
+  const long long r = (long long)blockIdx.x * SCAN_THREADS + threadIdx.x;
+  if (r >= n) return;
+  const int cell = point_cell[r];
+  if (cell < 0) return;
+  const int2 rs = cell_rs[cell];
+  const int slot = rs.y < 0 ? counters[2] + (rs.y & 0x7fffffff) : rs.y + point_rank[r];      // tagged: a single-point pillar (rows mode)
+  emit_point<RS>(points, stride, num_raw, g, r, cell, rs.x, slot, bucket_order, srows);
+}
+
+// last pass over points with the stable compaction position -> unq_inv
+template <int RS>
+__global__ __launch_bounds__(SCAN_THREADS) void k_point_finish(const float *__restrict__ points, long long n, int stride, int num_raw, pcp_grid_t g,
+                                                               const int *__restrict__ point_cell, const int *__restrict__ pt_block_sums,
+                                                               const int2 *__restrict__ cell_rs, const int *__restrict__ counters,
+                                                               const int *__restrict__ point_rank, long long *__restrict__ unq_inv,
+                                                               int *__restrict__ bucket_order, float *__restrict__ srows) {
+  __shared__ int lds32[SCAN_THREADS / 64 + 1];
+  // items of one thread must be consecutive rows for a stable compaction
+  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  int cell[SCAN_ITEMS], v[SCAN_ITEMS], prank[SCAN_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    cell[i] = (base + i < n) ? point_cell[base + i] : -1;
+    prank[i] = cell[i] >= 0 ? point_rank[base + i] : 0;
+    v[i] = cell[i] >= 0 ? 1 : 0;
+  }
+  int tot;
+  block_scan_excl<int>(v, lds32, &tot);
+  const int blk = pt_block_sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (cell[i] < 0) continue;
+    const int2 rs = cell_rs[cell[i]];
+    unq_inv[v[i] + blk] = (long long)rs.x;
+    const int slot = rs.y < 0 ? counters[2] + (rs.y & 0x7fffffff) : rs.y + prank[i];
+    emit_point<RS>(points, stride, num_raw, g, base + i, cell[i], rs.x, slot, bucket_order, srows);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t pcp_voxelize_workspace_bytes(const pcp_grid_t *grid, int64_t max_points) {
+  if (!grid || max_points < 0) return 0;
+  int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  return pcp_vox_layout(cells, max_points > 0 ? max_points : 1).total;
+}
+
+extern "C" size_t pcp_pillarise_rows_workspace_bytes(const pcp_grid_t *grid, int64_t max_points, int32_t num_raw) {
+  if (!grid || max_points < 0 || num_raw < 3 || num_raw > 13) return 0;
+  int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  return pcp_rows_layout(cells, max_points > 0 ? max_points : 1, num_raw).total;
+}
+
+namespace {
+
+struct ScanScratch { u64 *tile_sums; unsigned *tile_singles; int *pt_bs; int n_ctiles, n_pblk; };
+inline ScanScratch scan_scratch(char *ws, const VoxLayout &L, int64_t cells, int64_t n) {
+  ScanScratch s;
+  s.n_ctiles = (int)((cells + CS_TILE - 1) / CS_TILE);
+  s.n_pblk = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  s.tile_sums = (u64 *)(ws + L.block_sums);
+  s.tile_singles = (unsigned *)(ws + L.block_sums + pcp_align_up((size_t)s.n_ctiles * 8 + 8, 16));
+  s.pt_bs = (int *)(ws + L.block_sums + pcp_align_up((size_t)s.n_ctiles * 8 + 8, 16) + pcp_align_up((size_t)s.n_ctiles * 4 + 4, 16));
+  return s;
+}
+
+// pass 1 over points: cell id per row, per-cell histogram (its return value = the row's slot inside its cell), kept rows per 1024-row tile
 __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__restrict__ points, long long n, int stride,
                                                               pcp_grid_t g, int *__restrict__ cell_count,
                                                               int *__restrict__ point_cell, int *__restrict__ point_rank,
@@ -81,7 +394,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__res
       int c = point_to_cell(points + r * stride, g);
       point_cell[r] = c;
       if (c >= 0) {
-        // the histogram atomic's return value IS the row's slot inside its cell: k_point_finish needs no second atomic pass (and no
+        // the histogram atomic's return value IS the row's slot inside its cell: the last pass needs no second atomic pass (and no
         // second zeroed table); the order inside a cell is arrival order either way
         point_rank[r] = atomicAdd(&cell_count[c], 1);
         valid++;
@@ -99,220 +412,88 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__res
   }
 }
 
-__device__ __forceinline__ u64 pack_cell(int cnt) { return cnt > 0 ? ((1ULL << 32) | (u64)(unsigned)cnt) : 0ULL; }
-
-// pass 1 over cells: (occupied cells, points) per 1024-cell tile, packed hi/lo in one u64
-__global__ __launch_bounds__(SCAN_THREADS) void k_cell_tile_sums(const int *__restrict__ cell_count, long long cells,
-                                                                 u64 *__restrict__ cell_block_sums) {
-  __shared__ u64 wave_tot[SCAN_THREADS / 64];
-  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  u64 s = 0;
-  if (base + SCAN_ITEMS <= cells) {
-    int4 c = *reinterpret_cast<const int4 *>(cell_count + base);
-    s = pack_cell(c.x) + pack_cell(c.y) + pack_cell(c.z) + pack_cell(c.w);
-  } else {
-    for (int i = 0; i < SCAN_ITEMS; i++)
-      if (base + i < cells) s += pack_cell(cell_count[base + i]);
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 t = 0;
-    for (int w = 0; w < SCAN_THREADS / 64; w++) t += wave_tot[w];
-    cell_block_sums[blockIdx.x] = t;
-  }
-}
-
-// pass 2: block 0 turns the cell tile sums into exclusive prefixes (and publishes P, N'); block 1 does the point tiles.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(u64 *__restrict__ cell_block_sums, int n_cblk,
-                                                                 int *__restrict__ pt_block_sums, int n_pblk,
-                                                                 int *__restrict__ counters_ws, int *__restrict__ counters_out,
-                                                                 int *__restrict__ pillar_start) {
-  __shared__ u64 lds64[SCAN_THREADS / 64 + 1];
-  __shared__ int lds32[SCAN_THREADS / 64 + 1];
-  if (blockIdx.x == 0) {
-    u64 carry = 0;
-    for (int base = 0; base < n_cblk; base += SCAN_TILE) {
-      u64 v[SCAN_ITEMS];
-#pragma unroll
-      for (int i = 0; i < SCAN_ITEMS; i++) {
-        int idx = base + threadIdx.x * SCAN_ITEMS + i;
-        v[i] = idx < n_cblk ? cell_block_sums[idx] : 0ULL;
-      }
-      u64 tot;
-      block_scan_excl<u64>(v, lds64, &tot);
-#pragma unroll
-      for (int i = 0; i < SCAN_ITEMS; i++) {
-        int idx = base + threadIdx.x * SCAN_ITEMS + i;
-        if (idx < n_cblk) cell_block_sums[idx] = v[i] + carry;
-      }
-      carry += tot;
-    }
-    if (threadIdx.x == 0) {
-      int P = (int)(carry >> 32), Nv = (int)(carry & 0xffffffffULL);
-      counters_ws[0] = P;
-      counters_ws[1] = Nv;
-      counters_ws[2] = 0;
-      counters_ws[3] = 0;
-      if (counters_out) {
-        counters_out[0] = P;
-        counters_out[1] = Nv;
-        counters_out[2] = 0;
-        counters_out[3] = 0;
-      }
-      pillar_start[P] = Nv;
-    }
-  } else {
-    int carry = 0;
-    for (int base = 0; base < n_pblk; base += SCAN_TILE) {
-      int v[SCAN_ITEMS];
-#pragma unroll
-      for (int i = 0; i < SCAN_ITEMS; i++) {
-        int idx = base + threadIdx.x * SCAN_ITEMS + i;
-        v[i] = idx < n_pblk ? pt_block_sums[idx] : 0;
-      }
-      int tot;
-      block_scan_excl<int>(v, lds32, &tot);
-#pragma unroll
-      for (int i = 0; i < SCAN_ITEMS; i++) {
-        int idx = base + threadIdx.x * SCAN_ITEMS + i;
-        if (idx < n_pblk) pt_block_sums[idx] = v[i] + carry;
-      }
-      carry += tot;
-    }
-  }
-}
-
-// pass 3 over cells: rank + first slot of every cell; per-pillar outputs (coords, counts, pillar tables)
-__global__ __launch_bounds__(SCAN_THREADS) void k_cell_finish(const int *__restrict__ cell_count, long long cells, pcp_grid_t g,
-                                                              const u64 *__restrict__ cell_block_sums,
-                                                              int *__restrict__ cell_rank, int *__restrict__ cell_start,
-                                                              int *__restrict__ pillar_cell, int *__restrict__ pillar_start,
-                                                              int *__restrict__ voxel_coords, int *__restrict__ unq_cnt) {
-  __shared__ u64 lds64[SCAN_THREADS / 64 + 1];
-  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  int cnt[SCAN_ITEMS];
-  u64 v[SCAN_ITEMS];
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    cnt[i] = (base + i < cells) ? cell_count[base + i] : 0;
-    v[i] = pack_cell(cnt[i]);
-  }
-  u64 tot;
-  block_scan_excl<u64>(v, lds64, &tot);
-  const u64 blk = cell_block_sums[blockIdx.x];
-  const int plane = g.nx * g.ny;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    long long c = base + i;
-    if (c >= cells) continue;
-    u64 e = v[i] + blk;
-    int rank = (int)(e >> 32), start = (int)(e & 0xffffffffULL);
-    cell_start[c] = start;
-    if (cnt[i] > 0) {
-      cell_rank[c] = rank;
-      pillar_cell[rank] = (int)c;
-      pillar_start[rank] = start;
-      int b = (int)(c / plane), rem = (int)(c % plane);
-      int cx = rem / g.ny, cy = rem % g.ny;
-      int4 vc = make_int4(b, 0, cy, cx);                        // [batch, z, y, x] (dynamic_pillar_vfe.py:138-143)
-      *reinterpret_cast<int4 *>(voxel_coords + 4LL * rank) = vc;
-      if (unq_cnt) unq_cnt[rank] = cnt[i];
-    } else {
-      cell_rank[c] = -1;
-    }
-  }
-}
-
-// pass 3 over points: stable compaction position -> unq_inv; bucket slot -> bucket_order
-__global__ __launch_bounds__(SCAN_THREADS) void k_point_finish(const int *__restrict__ point_cell, long long n,
-                                                               const int *__restrict__ pt_block_sums,
-                                                               const int *__restrict__ cell_rank, const int *__restrict__ cell_start,
-                                                               const int *__restrict__ point_rank, long long *__restrict__ unq_inv,
-                                                               int *__restrict__ bucket_order) {
-  __shared__ int lds32[SCAN_THREADS / 64 + 1];
-  // items of one thread must be consecutive rows for a stable compaction
-  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  int cell[SCAN_ITEMS], v[SCAN_ITEMS], prank[SCAN_ITEMS];
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    cell[i] = (base + i < n) ? point_cell[base + i] : -1;
-    prank[i] = cell[i] >= 0 ? point_rank[base + i] : 0;
-    v[i] = cell[i] >= 0 ? 1 : 0;
-  }
-  int tot;
-  block_scan_excl<int>(v, lds32, &tot);
-  const int blk = pt_block_sums[blockIdx.x];
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    if (cell[i] < 0) continue;
-    int pos = v[i] + blk;
-    if (unq_inv) unq_inv[pos] = (long long)cell_rank[cell[i]];
-    int slot = cell_start[cell[i]] + prank[i];
-    bucket_order[slot] = (int)(base + i);
-  }
-}
-
-}  // namespace
-
-extern "C" size_t pcp_voxelize_workspace_bytes(const pcp_grid_t *grid, int64_t max_points) {
-  if (!grid || max_points < 0) return 0;
-  int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
-  return pcp_vox_layout(cells, max_points > 0 ? max_points : 1).total;
-}
-
-namespace {
-
-// the pillariser's passes behind the per-point cell ids.  cells_ready: cell_count / point_cell were filled by the caller's own pass over
-// the rows (pcp_select_transform_compact emits them while the transformed row is in registers), so the zero fill and k_point_cells are
-// skipped; the stable compaction position (unq_inv) needs k_point_cells' per-tile sums and is not available in that mode.
+// The pillariser: zero fill of the histogram, k_point_cells, k_cell_tile_sums, k_cell_finish, k_point_place (five launches; round 4: six).
+// cells_ready: cell_count / point_cell / point_rank were filled by the caller's own pass over the rows (pcp_select_transform_compact emits them
+// while the transformed row is in registers): three launches.  The stable compaction position (unq_inv)
+// needs k_point_cells' per-tile sums and is not available in that mode.  rows_raw > 0: rows mode (RowsLayout workspace).
 int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid, void *workspace, size_t workspace_bytes,
-               int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt, int32_t *counters, hipStream_t stream, bool cells_ready) {
-  if (!grid || !workspace || !voxel_coords || n < 0 || row_stride < 3) return PCP_ERR_ARG;
+               int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt, int32_t *counters, hipStream_t stream, bool cells_ready,
+               int rows_raw, bool want_bucket_order) {
+  if (!grid || !workspace || n < 0 || row_stride < 3) return PCP_ERR_ARG;
+  if (rows_raw == 0 && !voxel_coords) return PCP_ERR_ARG;
   if (n > 0 && !points) return PCP_ERR_ARG;
   if (grid->nx <= 0 || grid->ny <= 0 || grid->batch_size <= 0) return PCP_ERR_ARG;
   if (cells_ready && unq_inv) return PCP_ERR_ARG;
+  if (rows_raw && (rows_raw < 3 || rows_raw > 13 || row_stride < 1 + rows_raw || grid->nx > 65535 || grid->ny > 65535)) return PCP_ERR_ARG;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   if (cells >= (1LL << 31) || n >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
   const int64_t n_alloc = n > 0 ? n : 1;
   VoxLayout L = pcp_vox_layout(cells, n_alloc);
-  if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
+  RowsLayout R;
+  if (rows_raw) {
+    R = pcp_rows_layout(cells, n_alloc, rows_raw);
+    if (workspace_bytes < R.total) return PCP_ERR_WORKSPACE;
+  } else if (workspace_bytes < L.total) {
+    return PCP_ERR_WORKSPACE;
+  }
   char *ws = (char *)workspace;
   int *cell_count = (int *)(ws + L.cell_count);
   int *point_rank = (int *)(ws + L.point_rank);
-  int *cell_rank = (int *)(ws + L.cell_rank);
-  int *cell_start = (int *)(ws + L.cell_start);
   int *point_cell = (int *)(ws + L.point_cell);
-  int *bucket_order = (int *)(ws + L.bucket_order);
-  int *pillar_cell = (int *)(ws + L.pillar_cell);
-  int *pillar_start = (int *)(ws + L.pillar_start);
-  const int n_cblk = (int)((cells + SCAN_TILE - 1) / SCAN_TILE);
-  const int n_pblk = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-  u64 *cell_bs = (u64 *)(ws + L.block_sums);
-  int *pt_bs = (int *)(ws + L.block_sums + (size_t)n_cblk * 8 + 8);
-  int *counters_ws = (int *)(ws + L.counters);
+  const ScanScratch sc = scan_scratch(ws, L, cells, n);
+  CellScanOut o;
+  o.cell_rank = (int *)(ws + L.cell_rank);
+  o.cell_rs = (int2 *)(ws + L.cell_rs);
+  o.pillar_cell = (int *)(ws + L.pillar_cell);
+  o.pillar_start = (int *)(ws + L.pillar_start);
+  o.voxel_coords = voxel_coords;
+  o.unq_cnt = unq_cnt;
+  o.counters_ws = (int *)(ws + L.counters);
+  o.counters_out = counters;
+  o.tile_desc = rows_raw ? (int2 *)(ws + R.tile_desc) : nullptr;
+  int *bucket_order = (want_bucket_order || !rows_raw) ? (int *)(ws + L.bucket_order) : nullptr;
+  float *srows = rows_raw ? (float *)(ws + R.srows) : nullptr;
+  const int rs = rows_raw ? pcp_rows_stride(rows_raw) : 0;
 
   if (!cells_ready) {
-    if (pcp_zero_async(cell_count, L.cell_fill - L.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
-    if (n_pblk > 0) {
-      hipLaunchKernelGGL(k_point_cells, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
-                         *grid, cell_count, point_cell, point_rank, pt_bs);
+    if (pcp_zero_async(cell_count, (size_t)cells * 4, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+    if (sc.n_pblk > 0) {
+      hipLaunchKernelGGL(k_point_cells, dim3(sc.n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
+                         *grid, cell_count, point_cell, point_rank, sc.pt_bs);
       PCP_CHECK_LAUNCH();
     }
   }
-  hipLaunchKernelGGL(k_cell_tile_sums, dim3(n_cblk), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, cell_bs);
+  if (rows_raw) {
+    hipLaunchKernelGGL(k_cell_tile_sums<true>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, sc.tile_sums,
+                       sc.tile_singles);
+    PCP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_cell_finish<true>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, *grid,
+                       sc.tile_sums, sc.tile_singles, sc.n_ctiles, o);
+  } else {
+    hipLaunchKernelGGL(k_cell_tile_sums<false>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, sc.tile_sums,
+                       sc.tile_singles);
+    PCP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_cell_finish<false>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, *grid,
+                       sc.tile_sums, sc.tile_singles, sc.n_ctiles, o);
+  }
   PCP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(cells_ready ? 1 : 2), dim3(SCAN_THREADS), 0, stream, cell_bs, n_cblk, pt_bs, n_pblk, counters_ws,
-                     counters, pillar_start);
-  PCP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_cell_finish, dim3(n_cblk), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, *grid, cell_bs,
-                     cell_rank, cell_start, pillar_cell, pillar_start, voxel_coords, unq_cnt);
-  PCP_CHECK_LAUNCH();
-  if (n_pblk > 0) {
-    hipLaunchKernelGGL(k_point_finish, dim3(n_pblk), dim3(SCAN_THREADS), 0, stream, point_cell, (long long)n, pt_bs, cell_rank,
-                       cell_start, point_rank, (long long *)unq_inv, bucket_order);
+  if (sc.n_pblk > 0) {
+    const int nb1 = (int)((n + SCAN_THREADS - 1) / SCAN_THREADS);
+    if (unq_inv) {
+      hipLaunchKernelGGL(k_scan_point_tiles, dim3(1), dim3(SCAN_THREADS), 0, stream, sc.pt_bs, sc.n_pblk);
+      PCP_CHECK_LAUNCH();
+#define PCP_FINISH(RS_)                                                                                                                      \
+  hipLaunchKernelGGL(k_point_finish<RS_>, dim3(sc.n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, rows_raw,   \
+                     *grid, point_cell, sc.pt_bs, o.cell_rs, o.counters_ws, point_rank, (long long *)unq_inv, bucket_order, srows)
+      if (rs == 0) PCP_FINISH(0); else if (rs == 8) PCP_FINISH(8); else PCP_FINISH(16);
+#undef PCP_FINISH
+    } else {
+#define PCP_PLACE(RS_)                                                                                                                       \
+  hipLaunchKernelGGL(k_point_place<RS_>, dim3(nb1), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, rows_raw, *grid,    \
+                     point_cell, point_rank, o.cell_rs, o.counters_ws, bucket_order, srows)
+      if (rs == 0) PCP_PLACE(0); else if (rs == 8) PCP_PLACE(8); else PCP_PLACE(16);
+#undef PCP_PLACE
+    }
     PCP_CHECK_LAUNCH();
   }
   return PCP_OK;
@@ -324,14 +505,22 @@ extern "C" int pcp_voxelize(const float *points, int64_t n, int32_t row_stride, 
                             size_t workspace_bytes, int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt,
                             int32_t *counters, void *stream_) {
   return vox_passes(points, n, row_stride, grid, workspace, workspace_bytes, voxel_coords, unq_inv, unq_cnt, counters,
-                    (hipStream_t)stream_, false);
+                    (hipStream_t)stream_, false, 0, true);
 }
 
 extern "C" int pcp_voxelize_cells_ready(const float *points, int64_t n, int32_t row_stride, const pcp_grid_t *grid, void *workspace,
                                         size_t workspace_bytes, int32_t *voxel_coords, int32_t *unq_cnt, int32_t *counters,
                                         void *stream_) {
   return vox_passes(points, n, row_stride, grid, workspace, workspace_bytes, voxel_coords, nullptr, unq_cnt, counters,
-                    (hipStream_t)stream_, true);
+                    (hipStream_t)stream_, true, 0, true);
+}
+
+extern "C" int pcp_pillarise_rows(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, const pcp_grid_t *grid, void *workspace,
+                                  size_t workspace_bytes, int32_t *voxel_coords, int64_t *unq_inv, int32_t *unq_cnt, int32_t *counters,
+                                  int32_t flags, void *stream_) {
+  if (num_raw < 3 || (flags & ~3)) return PCP_ERR_ARG;
+  return vox_passes(points, n, row_stride, grid, workspace, workspace_bytes, voxel_coords, unq_inv, unq_cnt, counters, (hipStream_t)stream_,
+                    (flags & PCP_ROWS_CELLS_READY) != 0, num_raw, (flags & PCP_ROWS_BUCKET_ORDER) != 0);
 }
 
 
@@ -594,7 +783,7 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
     cell_count = (int *)((char *)vox_workspace + V.cell_count);
     point_cell = (int *)((char *)vox_workspace + V.point_cell);
     point_rank = (int *)((char *)vox_workspace + V.point_rank);
-    if (pcp_zero_async(cell_count, V.cell_fill - V.cell_count, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+    if (pcp_zero_async(cell_count, (size_t)cells * 4, stream) != PCP_OK) return PCP_ERR_LAUNCH;
   } else {
     g = pcp_grid_t{};
   }

@@ -1,5 +1,5 @@
-"""DynPillarVFE on gfx950: one pcp_voxelize (dense count + scan, no sort) and one fused pcp_pfn_scatter launch replace
-torch.unique + 3 torch_scatter calls + 2 Linear/BN/ReLU stacks + the canvas scatter of the reference
+"""DynPillarVFE on gfx950: one pcp_pillarise_rows (dense count + scan, no sort; rows left in pillar order) and one fused pcp_pfn_rows
+launch replace torch.unique + 3 torch_scatter calls + 2 Linear/BN/ReLU stacks + the canvas scatter of the reference
 (pcdet/models/backbones_3d/vfe/dynamic_pillar_vfe.py:49-147).  Parameter names and shapes are the reference's
 (vfe.pfn_layers.{i}.linear.weight, vfe.pfn_layers.{i}.norm.*), so published checkpoints load unchanged.
 """
@@ -49,6 +49,8 @@ class DynamicPillarVFE(VFETemplate):
         self.use_absolute_xyz = self.model_cfg.USE_ABSLOTE_XYZ
         if self.with_distance or not self.use_absolute_xyz:
             raise NotImplementedError('the fused PFN kernel covers USE_ABSLOTE_XYZ=True, WITH_DISTANCE=False (all five configs)')
+        if num_point_features not in (3, 4, 5, 11):
+            raise NotImplementedError('the fused PFN kernel is built for 3, 4, 5 or 11 raw point features (all five configs use 5 or 11)')
         in_dim = num_point_features + 6
         self.num_filters = list(self.model_cfg.NUM_FILTERS)
         if self.num_filters != [64, 64]:
@@ -64,14 +66,14 @@ class DynamicPillarVFE(VFETemplate):
         self.scale_y = self.grid_size[1]
         # knobs of the MI355X pipeline (not in the reference)
         self.materialize_pillars = True     # expose exact-shape pillar_features / voxel_coords (costs one host sync)
-        self.reuse_buffers = False          # keep canvas + workspace across frames, clear by pillar list
+        self.reuse_buffers = False          # keep canvas + workspace across frames
         # pipeline mode only: hand the pillar list (pillar rows + the pillariser's cell -> rank table) to the backbone, whose first layer
         # then runs from it (pcp_sparse_conv3x3_s2) and NO dense canvas is written; `spatial_features` is None in that case.  Used when
         # the cloud is sparse enough (points <= SPARSE_MAX_FILL x cells) -- a crowded canvas is faster through the dense kernel.
         self.sparse_first_layer = False
+        self.keep_bucket_order = False      # also leave the row indices grouped by pillar (HunterJr's point head visits the points in that order)
         self._pf_buf = None
         self._canvas = None
-        self._prev_vox = None
         self._workspace = None
 
     def _forward_train(self, batch_dict):
@@ -91,36 +93,33 @@ class DynamicPillarVFE(VFETemplate):
         w1, b1 = self.pfn_layers[1].folded()
         return dict(w0=w0.contiguous(), b0=b0.contiguous(), w1=w1.contiguous(), b1=b1.contiguous())
 
-    def release_canvas_rows(self):
-        """zero the persistent canvas rows of the previous (dense) frame NOW: needed when a caller is about to write into the
-        pillariser workspace that still holds that frame's pillar list (BEVMaker's compaction emits cell ids into it)"""
-        if self.reuse_buffers and self._prev_vox is not None and self._canvas is not None:
-            ops.canvas_clear(self._prev_vox, self._canvas)
-        self._prev_vox = None
-
-    def _voxelize(self, points, grid, batch_dict, want_inverse):
+    def _pillarise(self, points, grid, batch_dict):
+        """pcp_pillarise_rows on `points`: the rows in pillar order + the wave tiles of pcp_pfn_rows, in this VFE's workspace"""
+        nr = self.num_raw_point_features
         self._vox_borrowed = False
+        kw = dict(want_coords=self.materialize_pillars, bucket_order=self.keep_bucket_order)
+        want_inv = self.materialize_pillars       # drop-in mode also leaves unq_inv (bit exact against the reference's digest in the tests)
         ready = batch_dict.get('_pcp_vox_ready', None)
-        if ready is not None and not want_inverse:
-            return ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=ready['workspace'], cells_ready=True)
+        if ready is not None:
+            return ops.pillarise_rows(points, grid, nr, workspace=ready['workspace'], cells_ready=True, **kw)
         share = batch_dict.get('_pcp_vox_share', None)
-        if share is None or want_inverse or not self.reuse_buffers:
-            return ops.voxelize(points, grid, want_inverse=want_inverse, want_counts=False,
-                                workspace=self._workspace if self.reuse_buffers else None)
+        if share is None or not self.reuse_buffers:
+            return ops.pillarise_rows(points, grid, nr, workspace=self._workspace if self.reuse_buffers else None, want_inverse=want_inv, **kw)
         # Two VFEs of one forward that pillarise the SAME cloud on the SAME grid (DiscoNet: the early-fusion BEV maker and the ego branch
         # both see all points, bev_maker.py:212-230 / SURVEY F4) share one pillar list: the first to arrive builds it, the other waits for
-        # its event and only runs its own PFN.  The producer rotates through THREE workspaces: the consumer of forward i still reads the list
-        # of forward i-1 (it clears its persistent canvas from it), and in the pipelined mode (pcdet/models/pipelined.py) the producer of
-        # forward i+1 may already run then -- with two workspaces it would overwrite exactly that list (stale canvas rows for good).
-        key = (points.data_ptr(), int(points.shape[0]), int(points.shape[1]), grid.nx, grid.ny, grid.batch_size, grid.min_x, grid.min_y, grid.min_z,
+        # its event and only runs its own PFN.  The producer rotates through THREE workspaces: in the pipelined mode
+        # (pcdet/models/pipelined.py) the producer of forward i+1 may already run while the consumer of forward i still reads the list.
+        key = (points.data_ptr(), int(points.shape[0]), int(points.shape[1]), nr, grid.nx, grid.ny, grid.batch_size, grid.min_x, grid.min_y, grid.min_z,
                grid.voxel_x, grid.voxel_y, grid.voxel_z)
         cur = torch.cuda.current_stream()
         ent = share.get(key)
         if ent is not None:
             vox, ev = ent
             cur.wait_event(ev)
-            for t in (vox.workspace, vox.voxel_coords, vox.counters):
+            for t in (vox.workspace, vox.counters):
                 t.record_stream(cur)
+            if vox.voxel_coords is not None:
+                vox.voxel_coords.record_stream(cur)
             self._vox_borrowed = True       # the producer VFE owns this workspace (one of its three ring slots): never adopt it
             return vox
         ring = getattr(self, '_ws_ring', None)
@@ -128,7 +127,7 @@ class DynamicPillarVFE(VFETemplate):
             ring = self._ws_ring = [None, None, None]
             self._ws_idx = -1
         self._ws_idx = (self._ws_idx + 1) % 3
-        vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False, workspace=ring[self._ws_idx])
+        vox = ops.pillarise_rows(points, grid, nr, workspace=ring[self._ws_idx], **kw)
         ring[self._ws_idx] = vox.workspace
         share[key] = (vox, cur.record_event())
         return vox
@@ -147,45 +146,28 @@ class DynamicPillarVFE(VFETemplate):
         dev = points.device
         nx, ny = self.grid_size[0], self.grid_size[1]
         n_eff = batch_dict.get('_pcp_valid_points_hint', points.shape[0])
-        if (self.sparse_first_layer and not self.materialize_pillars and self.num_filters[-1] == 64
-                and n_eff <= SPARSE_MAX_FILL * batch_size * nx * ny):
-            if self.reuse_buffers and self._prev_vox is not None and self._canvas is not None:
-                # a dense frame came before this sparse one: its pillars are still on the persistent canvas and its pillar list lives in the
-                # workspace pcp_voxelize is about to overwrite -- clear now, or the next dense frame would inherit them
-                ops.canvas_clear(self._prev_vox, self._canvas)
-            self._prev_vox = None
-            vox = self._voxelize(points, grid, batch_dict, False)
-            rows = max(points.shape[0], 1)
+        sparse = (self.sparse_first_layer and not self.materialize_pillars and self.num_filters[-1] == 64
+                  and n_eff <= SPARSE_MAX_FILL * batch_size * nx * ny)
+        vox = self._pillarise(points, grid, batch_dict)
+        if self.reuse_buffers and not self._vox_borrowed:
+            self._workspace = vox.workspace
+        rows = max(points.shape[0], 1)
+        if sparse:
+            # pillar rows only: the backbone's first layer gathers them through the cell -> rank table in the workspace
             if self._pf_buf is None or self._pf_buf.shape[0] < rows or self._pf_buf.device != dev or not self.reuse_buffers:
                 self._pf_buf = torch.empty((rows, 64), dtype=torch.float32, device=dev)
-            ops.pfn_scatter(points, vox, self.num_raw_point_features, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=None,
-                            pillar_features=self._pf_buf)
-            if self.reuse_buffers and not self._vox_borrowed:
-                self._workspace = vox.workspace
+            ops.pfn_rows(vox, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=None, pillar_features=self._pf_buf)
             batch_dict['_pcp_vfe'] = dict(canvas=None, vox=vox, pillar_rows=self._pf_buf)
             return batch_dict
+        # dense canvas: pcp_pfn_rows writes every row of it (pillar rows and zero rows), so it is neither zero-filled nor cleared
         if self.reuse_buffers:
             if self._canvas is None or self._canvas.shape[0] != batch_size or self._canvas.device != dev:
-                self._canvas = torch.zeros((batch_size, ny, nx, 64), dtype=torch.float32, device=dev)
-                self._prev_vox = None
-                self._workspace = None
-            elif self._prev_vox is not None:
-                ops.canvas_clear(self._prev_vox, self._canvas)
+                self._canvas = torch.empty((batch_size, ny, nx, 64), dtype=torch.float32, device=dev)
             canvas = self._canvas
         else:
-            canvas = torch.zeros((batch_size, ny, nx, 64), dtype=torch.float32, device=dev)
-        # stream order makes one workspace enough: the clear above has consumed the previous pillar list before
-        # pcp_voxelize overwrites it
-        vox = self._voxelize(points, grid, batch_dict, self.materialize_pillars)
-        pf = None
-        if self.materialize_pillars:
-            pf = torch.empty((max(points.shape[0], 1), 64), dtype=torch.float32, device=dev)
-        ops.pfn_scatter(points, vox, self.num_raw_point_features, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=canvas,
-                        pillar_features=pf)
-        if self.reuse_buffers:
-            if not self._vox_borrowed:      # a borrowed list is still what the next canvas clear reads (_prev_vox), but a later un-shared
-                self._workspace = vox.workspace     # forward must pillarise into this VFE's OWN workspace, not into the producer's ring
-            self._prev_vox = vox
+            canvas = torch.empty((batch_size, ny, nx, 64), dtype=torch.float32, device=dev)
+        pf = torch.empty((rows, 64), dtype=torch.float32, device=dev) if self.materialize_pillars else None
+        ops.pfn_rows(vox, pk['w0'], pk['b0'], pk['w1'], pk['b1'], canvas=canvas, pillar_features=pf)
         if self.materialize_pillars:
             num_pillars = int(vox.counters[0].item())            # the one host sync of the drop-in mode
             batch_dict['voxel_features'] = batch_dict['pillar_features'] = pf[:num_pillars]

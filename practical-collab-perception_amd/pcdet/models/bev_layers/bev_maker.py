@@ -136,8 +136,8 @@ class BEVMaker(nn.Module):
                 rows = sum(int(agent_rows[a]) for a, _p, _q, _l in chunk)
                 vfe_mod = self.module_list[0]
                 grid = ops.make_grid(vfe_mod.point_cloud_range, vfe_mod.voxel_size, vfe_mod.grid_size, batch_size * len(chunk))
-                vfe_mod.release_canvas_rows()          # a dense previous frame: its pillar list is consumed before the workspace is reused
-                ws = ops.voxelize_workspace(grid, max(rows, 1), points.device, vfe_mod._workspace if vfe_mod.reuse_buffers else None)
+                ws = ops.rows_workspace(grid, max(rows, 1), vfe_mod.num_raw_point_features, points.device,
+                                        vfe_mod._workspace if vfe_mod.reuse_buffers else None)
                 if vfe_mod.reuse_buffers:
                     vfe_mod._workspace = ws
                 if (self._stack_buf is None or self._stack_buf.shape[0] < max(rows, 1) or self._stack_buf.shape[1] != c

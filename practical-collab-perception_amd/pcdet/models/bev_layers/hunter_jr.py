@@ -159,7 +159,7 @@ class HunterJr(PackedModule):
             # points then hit L2; results are written at the original rows, so the output does not change
             stash = batch_dict.get('_pcp_vfe', None)
             order = None
-            if self.sorted_gather and stash is not None and stash['vox'].n == points.shape[0]:
+            if self.sorted_gather and stash is not None and stash['vox'].n == points.shape[0] and getattr(stash['vox'], 'has_bucket_order', True):
                 order = ops.voxelize_row_order(stash['vox'])
             # one launch: sample -> MLP -> heads -> dynamic-foreground correction (in place) -> re-sampling of the corrected rows
             pf, head8, dyn = ops.hunter_point_head(cat, points, min_xy, pix, *pk['fused'], channels=C, order=order,

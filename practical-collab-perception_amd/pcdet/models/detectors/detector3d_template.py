@@ -107,6 +107,8 @@ class Detector3DTemplate(nn.Module):
         model_info_dict['num_point_features'] = corrector.num_points_feat
         model_info_dict['module_list'].append(corrector)
         model_info_dict['num_bev_features'] = corrector.num_points_feat
+        if getattr(self, 'vfe', None) is not None and hasattr(self.vfe, 'keep_bucket_order'):
+            self.vfe.keep_bucket_order = True      # HunterJr's point head visits the points in the pillariser's bucket order
         return corrector, model_info_dict
 
     def build_v2x_mid_fusion(self, model_info_dict):

@@ -78,7 +78,7 @@ def nchw_view(x_nhwc):
 # ---------------------------------------------------------------------------------------------------------------------
 
 class VoxelizeResult:
-    __slots__ = ('workspace', 'voxel_coords', 'unq_inv', 'unq_cnt', 'counters', 'n', 'grid', 'row_stride')
+    __slots__ = ('workspace', 'voxel_coords', 'unq_inv', 'unq_cnt', 'counters', 'n', 'grid', 'row_stride', 'num_raw', 'has_bucket_order')
 
 
 def voxelize_workspace(grid, n, device, workspace=None):
@@ -107,6 +107,8 @@ def voxelize(points, grid, want_inverse=True, want_counts=True, workspace=None, 
     res.n = n
     res.grid = grid
     res.row_stride = stride
+    res.num_raw = None
+    res.has_bucket_order = True
     cap = max(n, 1)
     res.voxel_coords = torch.empty((cap, 4), dtype=torch.int32, device=points.device)
     res.unq_inv = torch.empty((cap,), dtype=torch.int64, device=points.device) if want_inverse else None
@@ -130,6 +132,67 @@ def pfn_scatter(points, vox, num_raw, w0, b0, w1, b1, canvas=None, pillar_featur
     assert w0.shape == (32, num_raw + 6) and w1.shape == (64, 64) and b0.shape == (32,) and b1.shape == (64,)
     check(L.pcp_pfn_scatter(_p(points), vox.n, vox.row_stride, num_raw, ctypes.byref(vox.grid), _p(vox.workspace), _p(w0), _p(b0),
                             _p(w1), _p(b1), _p(pillar_features), _p(canvas), _stream()), 'pcp_pfn_scatter')
+
+
+ROWS_CELLS_READY, ROWS_BUCKET_ORDER = 1, 2
+
+
+def rows_workspace(grid, n, num_raw, device, workspace=None):
+    """a pcp_pillarise_rows workspace large enough for (grid, n rows, num_raw); `workspace` is returned unchanged when it already is"""
+    need = _lib.load().pcp_pillarise_rows_workspace_bytes(ctypes.byref(grid), n, num_raw)
+    if workspace is None or workspace.numel() < need or workspace.device != device:
+        workspace = torch.empty(need, dtype=torch.uint8, device=device)
+    return workspace
+
+
+def pillarise_rows(points, grid, num_raw, want_inverse=False, want_counts=False, want_coords=False, workspace=None, cells_ready=False,
+                   bucket_order=False):
+    """round 5 pillariser (four launches): pcp_voxelize's outputs (each optional) + the kept rows in pillar order + the wave-tile
+    descriptors pfn_rows reads, all in the workspace.  Returns a VoxelizeResult (res.num_raw set: the PFN must use the same)."""
+    _need_cuda(points)
+    L = _lib.load()
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
+    n, stride = points.shape
+    need = L.pcp_pillarise_rows_workspace_bytes(ctypes.byref(grid), n, num_raw)
+    if need == 0:
+        raise _lib.PcpError('pcp_pillarise_rows: unsupported (grid, num_raw=%d)' % num_raw)
+    if cells_ready:
+        assert workspace is not None and workspace.numel() >= need and not want_inverse
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=points.device)
+    res = VoxelizeResult()
+    res.workspace = workspace
+    res.n = n
+    res.grid = grid
+    res.row_stride = stride
+    res.num_raw = num_raw
+    res.has_bucket_order = bool(bucket_order)
+    cap = max(n, 1)
+    dev = points.device
+    res.voxel_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev) if want_coords else None
+    res.unq_inv = torch.empty((cap,), dtype=torch.int64, device=dev) if want_inverse else None
+    res.unq_cnt = torch.empty((cap,), dtype=torch.int32, device=dev) if want_counts else None
+    res.counters = torch.empty((4,), dtype=torch.int32, device=dev)
+    flags = (ROWS_CELLS_READY if cells_ready else 0) | (ROWS_BUCKET_ORDER if bucket_order else 0)
+    check(L.pcp_pillarise_rows(_p(points), n, stride, num_raw, ctypes.byref(grid), _p(workspace), workspace.numel(), _p(res.voxel_coords),
+                               _p(res.unq_inv), _p(res.unq_cnt), _p(res.counters), flags, _stream()), 'pcp_pillarise_rows')
+    return res
+
+
+def pfn_rows(vox, w0, b0, w1, b1, canvas=None, pillar_features=None):
+    """fused PFN + scatter on the records pillarise_rows left in vox.workspace.  canvas (B, ny, nx, 64) is written completely (pillar
+    rows and zero rows): torch.empty is enough."""
+    _need_cuda(w0, b0, w1, b1, canvas, pillar_features)
+    _need_f32('pcp_pfn_rows', canvas, pillar_features)
+    L = _lib.load()
+    num_raw = vox.num_raw
+    for t in (w0, b0, w1, b1):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert w0.shape == (32, num_raw + 6) and w1.shape == (64, 64) and b0.shape == (32,) and b1.shape == (64,)
+    if canvas is not None:
+        assert canvas.is_contiguous() and tuple(canvas.shape) == (vox.grid.batch_size, vox.grid.ny, vox.grid.nx, 64)
+    check(L.pcp_pfn_rows(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, num_raw, _p(w0), _p(b0), _p(w1), _p(b1), _p(pillar_features),
+                         _p(canvas), _stream()), 'pcp_pfn_rows')
 
 
 def canvas_clear(vox, canvas):

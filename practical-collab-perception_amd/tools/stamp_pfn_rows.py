@@ -1,0 +1,43 @@
+"""In-kernel s_memtime stamps of one k_pfn_rows wave (build: csrc/build_variant.sh prstamp "-DPR_STAMP=<workgroup>"): shader cycles per phase,
+summed over the wave's tiles.  usage: stamp_pfn_rows.py [frames=4] [agents=6] [dense=1].  Diagnostic tool, not part of the product path."""
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+PKG = Path(__file__).resolve().parent.parent
+os.environ['PCP_HIP_LIB'] = str(PKG / 'lib' / 'variants' / 'libpcp_hip_prstamp.so')
+sys.path.insert(0, str(PKG))
+from pcp_amd import ops, synth  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+agents = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+dense = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+d = torch.device('cuda:0')
+frames = [np.concatenate([synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b) for a in range(agents)], 0) for b in range(B)]
+pts = torch.from_numpy(synth.collate(frames)).to(d)
+grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], B)
+w0 = torch.randn(32, 11, device=d) * 0.1
+b0 = torch.zeros(32, device=d)
+w1 = torch.randn(64, 64, device=d) * 0.1
+b1 = torch.zeros(64, device=d)
+rows = ops.pillarise_rows(pts, grid, 5)
+canvas = torch.empty((B, 512, 512, 64), device=d) if dense else None
+pf = None if dense else torch.empty((pts.shape[0], 64), device=d)
+raw = ctypes.CDLL(os.environ['PCP_HIP_LIB'])
+names = ['prefetch issue', 'A sums', 'B means', 'C layers', 'D epilogue', 'E gap fill']
+for rep in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.pfn_rows(rows, w0, b0, w1, b1, canvas=canvas, pillar_features=pf)
+    e1.record()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    raw.pcp_debug_read_pfn_rows(buf, 16 * 8)
+    tiles = max(int(buf[8]), 1)
+    tot = sum(buf[k] for k in range(6))
+    print('rep %d: %.1f us, %d tiles of the stamped wave, %d cycles per tile: ' % (rep, e0.elapsed_time(e1) * 1e3, tiles, tot // tiles)
+          + '  '.join('%s %d' % (names[k], buf[k] // tiles) for k in range(6)))

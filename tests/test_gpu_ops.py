@@ -153,6 +153,208 @@ def test_pfn_scatter_matches_oracle(layout, num_raw, n):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# round 5: rows in pillar order + the wave-autonomous PFN (pcp_pillarise_rows, pcp_pfn_rows)
+# ---------------------------------------------------------------------------------------------------------------------
+def _folded_vfe(num_raw, seed=11):
+    from pcp_amd import pack
+    st = _vfe_weights(num_raw, seed)
+    t = lambda k: torch.from_numpy(st[k])
+    w0, b0 = pack.fold_bn(t('vfe.pfn_layers.0.linear.weight'), t('vfe.pfn_layers.0.norm.weight'), t('vfe.pfn_layers.0.norm.bias'),
+                          t('vfe.pfn_layers.0.norm.running_mean'), t('vfe.pfn_layers.0.norm.running_var'), 1e-3)
+    w1, b1 = pack.fold_bn(t('vfe.pfn_layers.1.linear.weight'), t('vfe.pfn_layers.1.norm.weight'), t('vfe.pfn_layers.1.norm.bias'),
+                          t('vfe.pfn_layers.1.norm.running_mean'), t('vfe.pfn_layers.1.norm.running_var'), 1e-3)
+    d = dev()
+    return st, (w0.to(d).contiguous(), b0.to(d).contiguous(), w1.to(d).contiguous(), b1.to(d).contiguous())
+
+
+@pytest.mark.parametrize('case', ['car_1x60k', 'early_6x60k', 'batch3_ragged', 'empty', 'all_masked', 'edges'])
+def test_pillarise_rows_bit_exact(case):
+    """the round-5 pillariser against the oracle (same cases as pcp_voxelize) + the records it leaves: row k of pillar r holds the raw
+    columns of one of r's points, r itself, its cell and its canvas row; every kept point exactly once."""
+    ops = _ops()
+    B = 1
+    if case == 'car_1x60k':
+        pts = synth.collate([synth.agent_cloud(0, 60000, 'car')])
+    elif case == 'early_6x60k':
+        pts = synth.collate([np.concatenate([synth.agent_cloud(a, 60000, 'early') for a in range(6)], 0)])
+    elif case == 'batch3_ragged':
+        B = 3
+        pts = synth.collate([synth.agent_cloud(1, 5000, 'car'), synth.agent_cloud(2, 17, 'car'), synth.agent_cloud(3, 30001, 'car', dist='ring')])
+    elif case == 'empty':
+        pts = np.zeros((0, 8), np.float32)
+    elif case == 'all_masked':
+        pts = synth.collate([synth.agent_cloud(0, 1000, 'car')])
+        pts[:, 1] += 500.0
+    else:
+        xs = np.array([-51.2, -51.200001, 51.2, 51.199997, 0.0, 0.2, 0.19999999, -0.2, 0.6000000238, 0.6, np.nan, np.inf, -np.inf, 10.0],
+                      np.float32)
+        pts = np.zeros((xs.shape[0] * 2, 8), np.float32)
+        pts[:xs.shape[0], 1] = xs
+        pts[:xs.shape[0], 2] = 1.0
+        pts[xs.shape[0]:, 1] = 1.0
+        pts[xs.shape[0]:, 2] = xs
+        pts[:, 3] = -1.0
+    ref = opil.voxelize(pts, 5, PC_RANGE, VOXEL, GRID) if pts.shape[0] else None
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
+    res = ops.pillarise_rows(torch.from_numpy(pts).to(dev()), g, 5, want_inverse=True, want_counts=True, want_coords=True, bucket_order=True)
+    torch.cuda.synchronize()
+    P, Nv = [int(v) for v in res.counters[:2].cpu()]
+    if ref is None:
+        assert P == 0 and Nv == 0
+        return
+    assert P == ref['unq'].shape[0] and Nv == ref['inv'].shape[0]
+    assert np.array_equal(res.voxel_coords[:P].cpu().numpy(), ref['coords'])
+    assert np.array_equal(res.unq_inv[:Nv].cpu().numpy(), ref['inv'])
+    assert np.array_equal(res.unq_cnt[:P].cpu().numpy().astype(np.int64), ref['cnt'])
+    if Nv == 0:
+        return
+    # the records: decode the workspace with the layout the header documents (front part = pcp_voxelize's, then n rows of 8 floats)
+    L = __import__('pcp_amd.lib', fromlist=['lib']).load()
+    import ctypes
+    front = L.pcp_voxelize_workspace_bytes(ctypes.byref(g), max(pts.shape[0], 1))
+    rows = res.workspace[front:front + max(pts.shape[0], 1) * 32].view(torch.float32).view(-1, 8)[:Nv].cpu()
+    rank = rows[:, 5].view(torch.int32).numpy()
+    # slot order: the multi-point pillars ascending (runs of cnt records), then the single-point pillars ascending
+    multi, single = np.nonzero(ref['cnt'] > 1)[0], np.nonzero(ref['cnt'] == 1)[0]
+    assert np.array_equal(rank, np.concatenate([np.repeat(multi, ref['cnt'][multi]), single]))
+    assert [int(v) for v in res.counters[2:].cpu()] == [int(ref['cnt'][multi].sum()), int(single.shape[0])]
+    cxcy = rows[:, 6].view(torch.int32).numpy()
+    crow = rows[:, 7].view(torch.int32).numpy()                                        # row of the (B, ny, nx, 64) canvas
+    vc = ref['coords'][rank]
+    assert np.array_equal(np.stack([cxcy & 0xffff, cxcy >> 16], 1), vc[:, 2:]) and np.array_equal(crow, (vc[:, 0] * 512 + vc[:, 2]) * 512 + vc[:, 3])
+    # every kept input row appears exactly once (compare as multisets of the 5 raw columns + pillar)
+    keep = np.nonzero(ref['keep'])[0]
+    src = pts[:, 1:6]
+    assert keep.shape[0] == Nv
+    a = np.concatenate([src[keep].view(np.int32), ref['inv'][:, None].astype(np.int32)], 1)
+    b = np.concatenate([rows[:, :5].numpy().view(np.int32), rank[:, None]], 1)
+    assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+
+
+def _crowded_cloud(num_cols=8):
+    """a cloud with pillars of every size: one cell with 700 points, one with 33, runs of 1 .. 17, isolated points, an empty frame in the
+    middle of the batch and points in the very first / very last cell of the grid"""
+    rs = np.random.RandomState(5)
+    rows = []
+    def cell_points(b, cx, cy, k):
+        q = np.zeros((k, num_cols), np.float32)
+        q[:, 0] = b
+        q[:, 1] = -51.2 + 0.2 * cx + rs.uniform(0.01, 0.19, k)
+        q[:, 2] = -51.2 + 0.2 * cy + rs.uniform(0.01, 0.19, k)
+        q[:, 3] = rs.uniform(-8, 0, k)
+        q[:, 4:] = rs.uniform(0, 1, (k, num_cols - 4))
+        rows.append(q)
+    cell_points(0, 0, 0, 3)
+    cell_points(0, 100, 7, 700)
+    cell_points(0, 100, 8, 33)
+    for k in range(1, 18):
+        cell_points(0, 200 + k, 300, k)
+    for k in range(40):
+        cell_points(2, 3 * k, 5 * k + 1, 1)
+    cell_points(2, 511, 511, 2)
+    cell_points(3, 250, 250, 64)
+    cell_points(3, 250, 251, 31)
+    cell_points(3, 250, 252, 30)
+    cell_points(3, 250, 253, 29)
+    pts = np.concatenate(rows, 0)
+    return pts[rs.permutation(pts.shape[0])]
+
+
+@pytest.mark.parametrize('layout,num_raw,n', [('car', 5, 60000), ('lately', 11, 20000), ('car', 5, 300), ('crowded', 5, 0), ('crowded', 11, 0)])
+def test_pfn_rows_matches_oracle(layout, num_raw, n):
+    ops = _ops()
+    B = 2
+    if layout == 'crowded':
+        B = 4
+        pts = _crowded_cloud(8 if num_raw == 5 else 14)
+    else:
+        pts = synth.collate([synth.agent_cloud(3, n, layout), synth.agent_cloud(4, n // 2, layout, dist='ring')])
+    st, (w0, b0, w1, b1) = _folded_vfe(num_raw)
+    arch = dict(num_raw=num_raw, pc_range=PC_RANGE, voxel_size=VOXEL, grid_size=GRID, vfe_filters=[64, 64])
+    ref = opil.vfe_forward(pts, st, arch)
+    d = dev()
+    pd = torch.from_numpy(pts).to(d)
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
+    vox = ops.pillarise_rows(pd, g, num_raw, want_coords=True)
+    P = int(vox.counters[0])
+    canvas = torch.full((B, 512, 512, 64), float('nan'), device=d)              # the kernel must write EVERY row: pillar rows and zero rows
+    pf = torch.full((max(P, 1), 64), float('nan'), device=d)
+    ops.pfn_rows(vox, w0, b0, w1, b1, canvas=canvas, pillar_features=pf)
+    torch.cuda.synchronize()
+    assert P == ref['pillar_features'].shape[0]
+    # fp32 with a different summation order and folded BN: 2e-5 absolute on O(1) features
+    np.testing.assert_allclose(pf.cpu().numpy(), ref['pillar_features'], rtol=1e-4, atol=2e-5)
+    want = torch.from_numpy(ref['spatial_features']).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(canvas.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    vc = vox.voxel_coords[:P].long()
+    assert torch.equal(canvas[vc[:, 0], vc[:, 2], vc[:, 3]], pf[:P])            # the canvas holds exactly the pillar rows, bit for bit
+    assert int((canvas != 0).any(-1).sum()) <= P                                # and zeros everywhere else
+    # against the rounds 1-4 kernel on the same cloud (same means, same features; only the summation order inside the products differs)
+    vox_old = ops.voxelize(pd, g)
+    pf_old = torch.zeros_like(pf)
+    ops.pfn_scatter(pd, vox_old, num_raw, w0, b0, w1, b1, canvas=None, pillar_features=pf_old)
+    torch.cuda.synchronize()
+    assert float((pf - pf_old).abs().max()) < 1e-5
+    # determinism (fixed-point means, order-independent maxima, fixed product order): a second pillarisation has another arrival order
+    pf2 = torch.zeros_like(pf)
+    vox2 = ops.pillarise_rows(pd, g, num_raw)
+    ops.pfn_rows(vox2, w0, b0, w1, b1, canvas=None, pillar_features=pf2)
+    torch.cuda.synchronize()
+    assert torch.equal(pf, pf2)
+
+
+def test_pfn_rows_empty_cloud_and_single_point():
+    ops = _ops()
+    _st, (w0, b0, w1, b1) = _folded_vfe(5)
+    d = dev()
+    g = ops.make_grid([-6.4, -6.4, -8, 6.4, 6.4, 0], VOXEL, [64, 64, 1], 2)
+    for pts in (np.zeros((0, 8), np.float32), np.array([[1, 0.05, 0.05, -1, 0.5, 0.1, 0, -1]], np.float32)):
+        pd = torch.from_numpy(pts).to(d)
+        vox = ops.pillarise_rows(pd, g, 5, want_coords=True)
+        canvas = torch.full((2, 64, 64, 64), float('nan'), device=d)
+        ops.pfn_rows(vox, w0, b0, w1, b1, canvas=canvas)
+        torch.cuda.synchronize()
+        P = int(vox.counters[0])
+        assert P == pts.shape[0]
+        assert not bool(torch.isnan(canvas).any())
+        assert int((canvas != 0).any(-1).sum()) == P
+        if P:
+            assert bool((canvas[1, 32, 32] != 0).any())
+
+
+def test_pfn_rows_after_select_transform_compact_equals_the_plain_chain():
+    """the BEV makers' entry: compaction emits the cell ids, pcp_pillarise_rows(CELLS_READY) finishes; same pillar rows as pillarising the
+    compacted cloud from scratch"""
+    ops = _ops()
+    d = dev()
+    B = 2
+    frames = [np.concatenate([synth.agent_cloud(a + 7 * b, 4000, 'disco') for a in range(3)], 0) for b in range(B)]
+    for b in range(B):
+        frames[b][:, -1] = np.repeat(np.arange(3), 4000)
+    pts = torch.from_numpy(synth.collate(frames)).to(d)
+    n, c = pts.shape
+    agents = [0, 2]
+    poses = np.tile(np.eye(4, dtype=np.float32)[:3].reshape(1, 1, 12), (2, B, 1))
+    poses[1, :, 3] = 1.5
+    present = np.ones((2, B), np.uint8)
+    rows = 2 * B * 4000
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, B * 2)
+    ws = ops.rows_workspace(g, rows, 5, d)
+    out = torch.empty((rows, c), device=d)
+    ops.select_transform_compact(pts, c - 1, agents, poses, present, rows, out=out, vox_grid=g, vox_workspace=ws)
+    vox = ops.pillarise_rows(out, g, 5, workspace=ws, cells_ready=True)
+    _st, (w0, b0, w1, b1) = _folded_vfe(5)
+    pf = torch.zeros((rows, 64), device=d)
+    ops.pfn_rows(vox, w0, b0, w1, b1, pillar_features=pf)
+    vox2 = ops.pillarise_rows(out, g, 5)
+    pf2 = torch.zeros((rows, 64), device=d)
+    ops.pfn_rows(vox2, w0, b0, w1, b1, pillar_features=pf2)
+    torch.cuda.synchronize()
+    assert torch.equal(vox.counters[:2], vox2.counters[:2]) and int(vox.counters[0]) > 1000
+    assert torch.equal(pf, pf2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # a6 / a7 convolutions
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('cin,cout,h,w,stride,relu,batch', [
