@@ -522,6 +522,18 @@ def dry_run(args, world, rank):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     seen = 1
+    layout = {'workload': 'dry run'}
+    if world > 1 and args.shard == 'agent':
+        # the row split of --shard agent (agent % world) and the exchanges of the sharded runners on CPU tensors: ranks without an
+        # agent contribute empty row blocks, ranks without a frame still take part in every collective
+        from pcdet.utils import v2x_exchange as ex
+        agents = [a for a in range(6) if a % world == rank]
+        rows = torch.full((4 * len(agents), 3), float(rank))
+        _union, counts = ex.all_gather_v_rows(rows)
+        frames = torch.tensor([len(ex.shard_frames(batch, world, rank))])
+        per = [torch.zeros_like(frames) for _ in range(world)]
+        dist.all_gather(per, frames)
+        layout.update(rows_per_rank=[int(c) for c in counts], frames_per_rank=[int(p.item()) for p in per])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -534,7 +546,7 @@ def dry_run(args, world, rank):
                           'ranks_seen_by_collective': seen, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                           'dtype': 'f32', 'data': 'DRY RUN: no kernels executed (launcher / aggregation self-test)',
-                          'config': {'workload': 'dry run'}, 'roofline': None, 'cpu_baseline': None}))
+                          'config': layout, 'roofline': None, 'cpu_baseline': None}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,19 +12,26 @@ import numpy as np
 F32 = np.float32
 
 
-def points_in_boxes(points, boxes):
-    """points (M, 3), boxes (T, 7) float32 -> (M,) int32: first containing box or -1."""
+def points_in_boxes(points, boxes, margin=1e-5):
+    """points (M, 3), boxes (T, 7) float32 -> (M,) int32: first containing box or -1.
+
+    Follows check_pt_in_box3d of /root/reference/pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:23-36 (MARGIN 1e-5, the kernel
+    points_in_boxes_gpu runs, :313-336: the first box that contains the point) and, with margin=1e-2, check_pt_in_box3d_cpu of
+    roiaware_pool3d.cpp:123-137 -- the same test with another constant -- which IS compiled from the reference (oracle/_ref) and pins this
+    restatement.  C semantics kept: the z test and the two face tests compare in double (dz / 2.0, dx / 2.0 + MARGIN with MARGIN a float
+    constant), the rotation is float arithmetic on cos / sin evaluated in double and rounded to float."""
     pts = np.asarray(points, dtype=F32)
     bx = np.asarray(boxes, dtype=F32)
     out = np.full(pts.shape[0], -1, dtype=np.int32)
+    mg = np.float64(F32(margin))
     for k in range(bx.shape[0] - 1, -1, -1):                       # reverse order so the FIRST containing box wins
         cx, cy, cz, dx, dy, dz, rz = (bx[k, i] for i in range(7))
-        inz = np.abs(pts[:, 2] - cz) <= dz / F32(2.0)
-        cosa, sina = F32(np.cos(-rz)), F32(np.sin(-rz))
+        inz = ~(np.abs(pts[:, 2] - cz).astype(np.float64) > np.float64(dz) / 2.0)
+        cosa, sina = F32(np.cos(np.float64(-rz))), F32(np.sin(np.float64(-rz)))
         sx, sy = pts[:, 0] - cx, pts[:, 1] - cy
         lx = sx * cosa + sy * (-sina)
         ly = sx * sina + sy * cosa
-        inside = inz & (np.abs(lx) < dx / F32(2.0) + F32(1e-5)) & (np.abs(ly) < dy / F32(2.0) + F32(1e-5))
+        inside = inz & (np.abs(lx).astype(np.float64) < np.float64(dx) / 2.0 + mg) & (np.abs(ly).astype(np.float64) < np.float64(dy) / 2.0 + mg)
         out[inside] = k
     return out
 

@@ -461,7 +461,8 @@ extern "C" int pcp_conv3x3(const pcp_conv3x3_t *d, const float *in, const float 
                            void *stream_) {
   if (!d || !in || !w_packed || !bias || !out) return PCP_ERR_ARG;
   if (d->cin <= 0 || d->cin % CK != 0 || d->cout <= 0 || d->cout_pad < d->cout || d->cout_pad % 32 != 0) return PCP_ERR_ARG;
-  if (d->ld_in % 4 != 0 || (((uintptr_t)in) & 15) || (((uintptr_t)w_packed) & 15)) return PCP_ERR_ARG;
+  // bias: cout_pad floats, read 16 bytes at a time by the epilogue (pack_conv3x3 pads it; an exact-length or unaligned slice is an error)
+  if (d->ld_in % 4 != 0 || (((uintptr_t)in) & 15) || (((uintptr_t)w_packed) & 15) || (((uintptr_t)bias) & 15)) return PCP_ERR_ARG;
   if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0) return PCP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
   if (d->stride == 1) {
@@ -478,7 +479,8 @@ extern "C" int pcp_pointwise(const pcp_pointwise_t *d, const float *in, const fl
                              void *stream_) {
   if (!d || !in || !w_packed || !bias || !out) return PCP_ERR_ARG;
   if (d->cin <= 0 || d->cin % CK != 0 || d->cout <= 0 || d->cout_pad < d->cout || d->cout_pad % 32 != 0) return PCP_ERR_ARG;
-  if (d->ld_in % 4 != 0 || (((uintptr_t)in) & 15) || (((uintptr_t)w_packed) & 15)) return PCP_ERR_ARG;
+  // bias: cout_pad floats, read 16 bytes at a time by the epilogue
+  if (d->ld_in % 4 != 0 || (((uintptr_t)in) & 15) || (((uintptr_t)w_packed) & 15) || (((uintptr_t)bias) & 15)) return PCP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream_;
   PwParams p;
   p.in = in; p.w = w_packed; p.bias = bias; p.out = out;

@@ -533,7 +533,7 @@ extern "C" int pcp_pillarise_rows(const float *points, int64_t n, int32_t row_st
 // index -1 (the host sizes `out` from the per-agent row counts of pcp_column_id_counts; rows of absent frames make total smaller).
 // With a pillariser workspace the transformed row's cell id is emitted while the row is in registers (k_point_cells fused).
 //   k_stc_count   per 1024-row tile and slot: rows kept                          (reads the frame and agent columns)
-//   k_stc_scan    one workgroup: exclusive prefix over (slot-major, tile) -> tile offsets, slot starts, total
+//   (round 5: no scan launch -- every workgroup of k_stc_scatter adds the per-tile counts in front of it up itself)
 //   k_stc_scatter rank inside the tile (ballot prefix, item-major row order), transform, write, [cell id + histogram], tail fill
 namespace {
 
@@ -584,46 +584,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_count(const float *__restr
   }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_stc_scan(int *__restrict__ tile_cnt, int n_entries, int n_tiles, int n_slots,
-                                                           int *__restrict__ slot_start_ws, int *__restrict__ slot_start_out) {
-  __shared__ int lds32[SCAN_THREADS / 64 + 1];
-  int carry = 0;
-  for (int base = 0; base < n_entries; base += SCAN_TILE) {
-    int v[SCAN_ITEMS];
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-      const int idx = base + threadIdx.x * SCAN_ITEMS + i;
-      v[i] = idx < n_entries ? tile_cnt[idx] : 0;
-    }
-    int tot;
-    block_scan_excl<int>(v, lds32, &tot);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-      const int idx = base + threadIdx.x * SCAN_ITEMS + i;
-      if (idx < n_entries) {
-        const int e = v[i] + carry;
-        tile_cnt[idx] = e;
-        if (idx % n_tiles == 0) {
-          slot_start_ws[idx / n_tiles] = e;
-          if (slot_start_out) slot_start_out[idx / n_tiles] = e;
-        }
-      }
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    slot_start_ws[n_slots] = carry;
-    if (slot_start_out) slot_start_out[n_slots] = carry;
-  }
-  if (n_entries == 0 && (int)threadIdx.x < n_slots) {   // empty source
-    slot_start_ws[threadIdx.x] = 0;
-    if (slot_start_out) slot_start_out[threadIdx.x] = 0;
-  }
-}
-
 __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__restrict__ points, long long n, int stride, int agent_col,
                                                               StcTable t, int n_tiles, const int *__restrict__ tile_off,
-                                                              const int *__restrict__ slot_start, float *__restrict__ out,
+                                                              int *__restrict__ slot_start_out, float *__restrict__ out,
                                                               long long out_rows, int emit_cells, pcp_grid_t g,
                                                               int *__restrict__ cell_count, int *__restrict__ point_cell,
                                                               int *__restrict__ point_rank) {
@@ -644,9 +607,63 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
       if (slot[i] == k) rank[i] = __popcll(bal & lt);
     }
   }
+  // first row of (slot, this tile) = rows of all earlier slots + rows of this slot in earlier tiles: every workgroup adds the per-tile
+  // counts up itself (n_slots x n_tiles ints, a few KB from L2) -- no scan launch, no dependency between workgroups
+  __shared__ int slot_total[STC_MAX_SLOTS], slot_before[STC_MAX_SLOTS], red_tot[SCAN_THREADS / 64][STC_MAX_SLOTS], red_bef[SCAN_THREADS / 64][STC_MAX_SLOTS];
+  {
+    int tot[STC_MAX_SLOTS], bef[STC_MAX_SLOTS];
+#pragma unroll
+    for (int k = 0; k < STC_MAX_SLOTS; k++) tot[k] = bef[k] = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += SCAN_THREADS) {
+#pragma unroll
+      for (int k = 0; k < STC_MAX_SLOTS; k++)
+        if (k < t.n_slots) {
+          const int c = tile_off[(long long)k * n_tiles + i];
+          tot[k] += c;
+          if (i < (int)blockIdx.x) bef[k] += c;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < STC_MAX_SLOTS; k++) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        tot[k] += __shfl_xor(tot[k], d, 64);
+        bef[k] += __shfl_xor(bef[k], d, 64);
+      }
+      if (lane == 0) {
+        red_tot[wave][k] = tot[k];
+        red_bef[wave][k] = bef[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < STC_MAX_SLOTS) {
+    int a = 0, b = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+      a += red_tot[w][threadIdx.x];
+      b += red_bef[w][threadIdx.x];
+    }
+    slot_total[threadIdx.x] = a;
+    slot_before[threadIdx.x] = b;
+  }
+  __syncthreads();
+  int total = 0;
+  {
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < STC_MAX_SLOTS; k++) {
+      if (k < t.n_slots) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && slot_start_out) slot_start_out[k] = run;
+        if ((int)threadIdx.x == k) slot_before[k] += run;     // the owner thread of slot k below
+        run += slot_total[k];
+      }
+    }
+    total = run;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && slot_start_out) slot_start_out[t.n_slots] = total;
+  }
   __syncthreads();
   if (threadIdx.x < t.n_slots) {                       // rows of one slot keep the input order: items, then waves, then lanes
-    int run = (int)blockIdx.x < n_tiles ? tile_off[(long long)threadIdx.x * n_tiles + blockIdx.x] : 0;
+    int run = slot_before[threadIdx.x];
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++)
 #pragma unroll
@@ -657,7 +674,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
       }
   }
   __syncthreads();
-  const int total = slot_start[t.n_slots];
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
     const long long r = base + i * SCAN_THREADS + threadIdx.x;
@@ -789,7 +805,6 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
   }
   char *ws = (char *)workspace;
   int *tile_cnt = (int *)(ws + L.tile_cnt);
-  int *slot_start_ws = (int *)(ws + L.slot_start);
   // the grid covers the source rows and the destination (tail fill)
   const long long span = n > out_rows ? n : out_rows;
   const int n_tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
@@ -799,14 +814,13 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
                        n_tiles, tile_cnt);
     PCP_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_stc_scan, dim3(1), dim3(SCAN_THREADS), 0, stream, tile_cnt, n_tiles * n_slots, n_tiles > 0 ? n_tiles : 1, (int)n_slots,
-                     slot_start_ws, slot_start);
-  PCP_CHECK_LAUNCH();
   if (n_blocks > 0) {
     hipLaunchKernelGGL(k_stc_scatter, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, (int)agent_col, t,
-                       n_tiles > 0 ? n_tiles : 1, tile_cnt, slot_start_ws, out, (long long)out_rows, vox_grid ? 1 : 0, g, cell_count,
+                       n_tiles, tile_cnt, slot_start, out, (long long)out_rows, vox_grid ? 1 : 0, g, cell_count,
                        point_cell, point_rank);
     PCP_CHECK_LAUNCH();
+  } else if (slot_start && pcp_zero_async(slot_start, (size_t)(n_slots + 1) * 4, stream) != PCP_OK) {
+    return PCP_ERR_LAUNCH;
   }
   return PCP_OK;
 }

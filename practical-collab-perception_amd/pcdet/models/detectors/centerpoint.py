@@ -10,8 +10,9 @@ class _HipBackward(torch.autograd.Function):
     modules recorded (reverse order), which deposit the gradients in param.grad."""
 
     @staticmethod
-    def forward(ctx, anchor, value, tape):
+    def forward(ctx, anchor, value, tape, hook=None):
         ctx.tape = tape
+        ctx.hook = hook
         return value.detach().clone()
 
     @staticmethod
@@ -19,8 +20,8 @@ class _HipBackward(torch.autograd.Function):
         scale = float(grad_out)
         if scale != 1.0:
             raise NotImplementedError('scale the loss through the optimizer (grad_scale), not through loss.backward(gradient=...)')
-        run_tape(ctx.tape)
-        return None, None, None
+        run_tape(ctx.tape, ctx.hook)
+        return None, None, None, None
 
 
 class Tape(list):
@@ -28,25 +29,24 @@ class Tape(list):
     done = False
 
 
-# set by the data-parallel optimizer (tools/train_utils/optimization: FlatAdamOneCycle.attach_overlap): called with the name of every module
-# whose backward closure has just been queued, so the gradient all-reduce of the modules that finish FIRST in the backward pass (head,
-# fusion) runs under the backward of the rest (backbone, VFE) -- what DistributedDataParallel's buckets do at the reference's train.py:161
-GRAD_READY_HOOK = None
-
-
-def run_tape(tape):
+# `hook`: set on the MODEL by its data-parallel optimizer (tools/train_utils/optimization: FlatAdamOneCycle.attach_overlap, attribute
+# `_pcp_grad_ready_hook`) and carried by the loss node of every forward of THAT model: called with the name of each module whose backward
+# closure has just been queued, so the gradient all-reduce of the modules that finish FIRST in the backward pass (head, fusion) runs under
+# the backward of the rest (backbone, VFE) -- what DistributedDataParallel's buckets do at the reference's train.py:161.  (Round 4 kept the
+# hook in a process global: a second optimizer in the process replaced it, and another model's backward fired this one's reduction.)
+def run_tape(tape, hook=None):
     g = None
     for name, fn in reversed(tape):
         g = fn(g)
-        if GRAD_READY_HOOK is not None:
-            GRAD_READY_HOOK(name)
+        if hook is not None:
+            hook(name)
     if isinstance(tape, Tape):
         tape.done = True
 
 
-def hip_loss(value, tape):
+def hip_loss(value, tape, hook=None):
     anchor = torch.zeros((), dtype=torch.float32, device=value.device, requires_grad=True)
-    return _HipBackward.apply(anchor, value, tape)
+    return _HipBackward.apply(anchor, value, tape, hook)
 
 
 class CenterPoint(Detector3DTemplate):
@@ -137,7 +137,7 @@ class CenterPoint(Detector3DTemplate):
         if self.training:
             tape = batch_dict.get('_pcp_tape', [])
             loss, tb_dict, disp_dict = self.get_training_loss()
-            return {'loss': hip_loss(loss, tape)}, tb_dict, disp_dict
+            return {'loss': hip_loss(loss, tape, getattr(self, '_pcp_grad_ready_hook', None))}, tb_dict, disp_dict
         pred_dicts, recall_dicts = self.post_processing(batch_dict)
         if self.model_cfg.get('RETURN_BATCH_DICT', False):
             return pred_dicts, batch_dict

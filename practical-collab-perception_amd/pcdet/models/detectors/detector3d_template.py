@@ -20,6 +20,8 @@ from ...ops.iou3d_nms import iou3d_nms_utils
 class Detector3DTemplate(nn.Module):
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__()
+        from ..packed import _flush_counters
+        self.register_state_dict_pre_hook(_flush_counters)      # checkpoints see the deferred BatchNorm counters (pcp_amd/train_layers.py)
         self.model_cfg = model_cfg
         self.num_class = num_class
         self.dataset = dataset

@@ -3,16 +3,25 @@ cache whenever the parameters may have changed: .to()/.cuda() (_apply), load_sta
 import torch.nn as nn
 
 
+def _flush_counters(module, prefix, keep_vars):
+    """state_dict pre-hook: the deferred num_batches_tracked increments of the training path land before the counters are read"""
+    from pcp_amd.train_layers import flush_batches_tracked
+    flush_batches_tracked()
+
+
 class PackedModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._pcp_cache = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._weights_replaced())
+        self.register_state_dict_pre_hook(_flush_counters)
 
     def _weights_replaced(self):
-        """load_state_dict: the folded inference weights AND the per-step packed forms of the train-mode layers are stale"""
+        """load_state_dict: the folded inference weights AND the per-step packed forms of the train-mode layers are stale; BatchNorm
+        counter increments collected before the load no longer apply to the loaded counters"""
         self.invalidate_packed()
-        from pcp_amd.train_layers import StepClock
+        from pcp_amd.train_layers import StepClock, drop_pending_batches_tracked
+        drop_pending_batches_tracked(self)
         StepClock.tick()
 
     def invalidate_packed(self):

@@ -62,11 +62,14 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
     return keep[:int(cnt.item())].long(), None
 
 
-def nms_normal_gpu(boxes, scores, thresh, **kwargs):
-    """reference :102-117 (-> nms_normal_gpu, iou3d_nms.cpp:139-188): score sort + axis-aligned IoU mask + greedy, all on the device"""
+def nms_normal_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+    """reference :102-117 (-> nms_normal_gpu, iou3d_nms.cpp:139-188): score sort + axis-aligned IoU mask + greedy, all on the device.
+    pre_maxsize: the reference's callers cut to topk(NMS_PRE_MAXSIZE) BEFORE either NMS type (model_nms_utils.py:15,50); the callers here
+    hand the whole candidate list over and the op applies the cut behind its own score sort (same candidates, same order)."""
     assert boxes.shape[1] == 7
     n = boxes.shape[0]
     if n == 0:
         return torch.zeros((0,), dtype=torch.long, device=boxes.device), None
-    keep, cnt = ops.nms_normal(boxes.float().contiguous(), scores.float().contiguous(), thresh, n, n)
+    pre = int(pre_maxsize) if pre_maxsize is not None else n
+    keep, cnt = ops.nms_normal(boxes.float().contiguous(), scores.float().contiguous(), thresh, pre, n)
     return keep[:int(cnt.item())].long(), None

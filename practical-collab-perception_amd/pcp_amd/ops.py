@@ -224,6 +224,7 @@ def conv3x3(x, packed, bias, cin, cout, cout_pad, stride=1, relu=True, out=None,
         out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     assert out.shape[:3] == (B, Ho, Wo) and x.is_contiguous() and out.is_contiguous()
     assert in_ch_off + cin <= ld_in and out_ch_off + cout <= out.shape[3]
+    assert bias.numel() >= cout_pad, 'bias must hold cout_pad values (the epilogue reads it 16 bytes at a time)'
     d = Conv3x3(B, H, W, cin, cout, cout_pad, stride, ld_in, out.shape[3], 1 if relu else 0)
     check(L.pcp_conv3x3(ctypes.byref(d), _chan_ptr(x, in_ch_off), _p(packed), _p(bias), _chan_ptr(out, out_ch_off), _stream()),
           'pcp_conv3x3')
@@ -423,6 +424,7 @@ def pointwise(x, packed, bias, mode, cin, cout, cout_pad, relu=True, out=None, i
         if out is None:
             shp = (B, H // 2, W // 2, cout) if mode == _lib.PW_SPACE2DEPTH else (B, 2 * H, 2 * W, cout)
             out = torch.empty(shp, dtype=torch.float32, device=x.device)
+    assert bias.numel() >= cout_pad, 'bias must hold cout_pad values (the epilogue reads it 16 bytes at a time)'
     assert x.is_contiguous() and out.is_contiguous()
     d = Pointwise(mode, rows, B, H, W, cin, cout, cout_pad, ld_in, out.shape[-1], 1 if relu else 0)
     if x2 is not None:

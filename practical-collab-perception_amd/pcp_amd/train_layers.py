@@ -84,7 +84,8 @@ class StepClock:
 
 
 # nn.BatchNorm's num_batches_tracked += 1 is one tiny launch per BatchNorm per forward (47 per DiscoNet iteration): the increments are
-# collected and applied by ONE multi-tensor add per optimizer step (and before any state_dict() through flush_batches_tracked()).
+# collected and applied by ONE multi-tensor add per optimizer step, and before any state_dict(): PackedModule and Detector3DTemplate register
+# flush_batches_tracked() as a state_dict pre-hook, so a checkpoint taken between a forward and optimizer.step() carries current counters.
 _PENDING_NBT = {}
 
 
@@ -99,6 +100,16 @@ def bump_batches_tracked(bn):
         e[1] += 1
     if len(_PENDING_NBT) > 4096:
         flush_batches_tracked()
+
+
+def drop_pending_batches_tracked(module):
+    """forget the collected increments of `module`'s BatchNorm counters (they were just replaced by load_state_dict: adding increments
+    from before the load would corrupt the loaded values)"""
+    if not _PENDING_NBT:
+        return
+    for name, buf in module.named_buffers():
+        if name.endswith('num_batches_tracked'):
+            _PENDING_NBT.pop(id(buf), None)
 
 
 def flush_batches_tracked():

@@ -304,7 +304,11 @@ def mp_conv3x3_wgrad(x, dy, cin, cout, stride, dw, accumulate=False, x_ch_off=0,
     d = _lib.MpWgrad3x3(B, H, W, cin, cout, stride, ld_x, dy.shape[3], _lib.DT_BF16, _lib.DT_BF16, 1 if accumulate else 0)
     need = L.pcp_mp_conv3x3_wgrad_workspace_bytes(ctypes.byref(d))
     if need == 0:
-        raise _lib.PcpError('pcp_mp_conv3x3_wgrad: unsupported shape %s / %s (cin %d, cout %d, stride %d)' % (tuple(x.shape), tuple(dy.shape), cin, cout, stride))
+        # a shape the bf16 pixel-contraction kernel has no plan for: the fp32 weight-gradient kernel on fp32 copies of the
+        # window -- slower, same contract (it raises itself where it has no kernel either)
+        xf = x[..., x_ch_off:x_ch_off + cin].float().contiguous()
+        dyf = dy[..., dy_ch_off:dy_ch_off + cout].float().contiguous()
+        return conv3x3_wgrad(xf, dyf, cin, cout, stride, dw, accumulate=accumulate)
     ws = _WG_WS.get(need, x.device)
     check(L.pcp_mp_conv3x3_wgrad(ctypes.byref(d), _chan_ptr(x, x_ch_off), _chan_ptr(dy, dy_ch_off), _p(dw), _p(ws), ws.numel(), _stream()),
           'pcp_mp_conv3x3_wgrad')

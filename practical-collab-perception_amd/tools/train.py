@@ -71,11 +71,39 @@ def init_distributed(args, cfg):
 
 
 
-def choose_resume_checkpoint(model, ckpt_dir, logger):
-    """newest checkpoint under ckpt_dir that can be read and holds every tensor of `model` at its shape, or None.  Nothing is loaded into
-    the model here (reference tools/train.py:143-156 tries the newest file and lets a torn one raise)."""
+def _optimizer_payload_ok(ck, path, n_flat):
+    """the optimizer half of a checkpoint is loadable: absent (moments restart), the fused optimizer's own dict with flat buffers of this
+    model's size, a reference torch-Adam dict (mapped tensor by tensor later; a mismatch there only resets the moments), or a readable
+    `<name>_optim.pth` side file of one of those kinds.  -> (ok, reason)"""
+    sd = ck.get('optimizer_state', None)
+    if sd is None:
+        side = '%s_optim.%s' % (path[:-4], path[-3:])
+        if not os.path.exists(side):
+            return True, ''
+        try:
+            sd = torch.load(side, map_location='cpu', weights_only=False)['optimizer_state']
+        except (OSError, EOFError, RuntimeError, KeyError, TypeError, AttributeError, ValueError, pickle.UnpicklingError) as e:
+            return False, 'optimizer side file unreadable (%s: %s)' % (type(e).__name__, e)
+    if not isinstance(sd, dict):
+        return False, 'optimizer_state is a %s' % type(sd).__name__
+    if 'state' in sd and 'param_groups' in sd:
+        return True, ''
+    for k in ('t', 'exp_avg', 'exp_avg_sq', 'lr', 'mom'):
+        if k not in sd:
+            return False, 'optimizer_state lacks %r' % k
+    for k in ('exp_avg', 'exp_avg_sq'):
+        if not torch.is_tensor(sd[k]) or (n_flat is not None and sd[k].numel() != n_flat):
+            return False, 'optimizer_state[%r] holds %s values, the model needs %s' % (k, sd[k].numel() if torch.is_tensor(sd[k]) else '?', n_flat)
+    return True, ''
+
+
+def choose_resume_checkpoint(model, ckpt_dir, logger, optimizer=None):
+    """newest checkpoint under ckpt_dir that can be read, holds EXACTLY the tensors of `model` at their shapes (the loader is strict: an
+    extra key would raise after validation) and whose optimizer payload fits `optimizer`, or None.  Nothing is loaded into the model
+    here (reference tools/train.py:143-156 tries the newest file and lets a torn one raise).  -> path"""
     import glob
     want = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    n_flat = optimizer.flat_p.numel() if optimizer is not None and hasattr(optimizer, 'flat_p') else None
     for f in sorted(glob.glob(str(Path(ckpt_dir) / '*.pth')), key=os.path.getmtime, reverse=True):
         if f.endswith('_optim.pth'):
             continue
@@ -88,6 +116,14 @@ def choose_resume_checkpoint(model, ckpt_dir, logger):
         missing = [k for k in want if have.get(k) != want[k]]
         if missing:
             logger.info('could not resume from %s (%d tensors missing or of another shape, e.g. %s)' % (f, len(missing), missing[0]))
+            continue
+        extra = [k for k in have if k not in want]
+        if extra:
+            logger.info('could not resume from %s (%d tensors the model does not have, e.g. %s)' % (f, len(extra), extra[0]))
+            continue
+        ok, why = _optimizer_payload_ok(ck, f, n_flat) if optimizer is not None else (True, '')
+        if not ok:
+            logger.info('could not resume from %s (%s)' % (f, why))
             continue
         return f
     return None
@@ -140,7 +176,7 @@ def main():
         # A checkpoint is VALIDATED (readable, every model key present with the right shape) before anything is loaded into the model or
         # the optimizer, so a torn file from a killed run cannot leave the model half-overwritten; rank 0 chooses and broadcasts its
         # choice, so all ranks resume from the same file even when a newer one appears while they start.
-        choice = [choose_resume_checkpoint(model, ckpt_dir, logger) if (cfg.LOCAL_RANK == 0 or not dist_train) else None]
+        choice = [choose_resume_checkpoint(model, ckpt_dir, logger, optimizer) if (cfg.LOCAL_RANK == 0 or not dist_train) else None]
         if dist_train:
             import torch.distributed as dist
             dist.broadcast_object_list(choice, src=0)

@@ -40,6 +40,50 @@ def _collectives_on(group=None):
     return d.get_world_size(group) > 1 or os.environ.get('PCP_FORCE_COLLECTIVES', '0') == '1'
 
 
+class OverlappedFlatReduce:
+    """The two-bucket gradient all-reduce of one optimizer: the TAIL of the flat gradient (the parameters whose backward finishes first)
+    is reduced asynchronously while the rest of the backward pass runs, the head follows in finish().
+
+    Correct for any number of backward() calls per step (round 4's in-place form was not): the tail is reduced in a COPY, so the live
+    buffer keeps this rank's own sums.  One backward since the last finish(): the reduced copy replaces the tail and only the head is
+    reduced in finish().  A second backward (gradient accumulation) adds to the live buffer after the copy was taken: finish() then drops
+    the copy and reduces the whole buffer once.  abandon() (zero_grad without a step) waits for the copy and drops it.
+    Works on any tensor torch.distributed can reduce (the CPU test drives it with gloo)."""
+
+    def __init__(self, flat_g, tail_off, group=None):
+        self.flat_g, self.tail_off, self.group = flat_g, int(tail_off), group
+        self.work, self.copy, self.backwards = None, None, 0
+        self.started = 0                                   # asynchronous tail reductions issued (tests)
+
+    def grad_ready(self):
+        """the tail's gradients of one backward pass are complete (queued)"""
+        self.backwards += 1
+        if self.backwards == 1:
+            self.copy = self.flat_g[self.tail_off:].clone()
+            self.work = torch.distributed.all_reduce(self.copy, group=self.group, async_op=True)
+            self.started += 1
+
+    def finish(self):
+        """reduces what is left; returns the 1 / world scale the optimizer kernel folds in"""
+        world = torch.distributed.get_world_size(self.group)
+        if self.work is None:
+            torch.distributed.all_reduce(self.flat_g, group=self.group)
+        elif self.backwards == 1:
+            torch.distributed.all_reduce(self.flat_g[:self.tail_off], group=self.group)
+            self.work.wait()
+            self.flat_g[self.tail_off:].copy_(self.copy)
+        else:
+            self.work.wait()                               # the copy misses the later backward passes: one full reduction instead
+            torch.distributed.all_reduce(self.flat_g, group=self.group)
+        self.work, self.copy, self.backwards = None, None, 0
+        return 1.0 / world
+
+    def abandon(self):
+        if self.work is not None:
+            self.work.wait()
+        self.work, self.copy, self.backwards = None, None, 0
+
+
 class FlatAdamOneCycle:
     """optimizer.zero_grad() / .step() / .lr / .mom like the reference's OptimWrapper; `clip_grad_norm(max_norm)` replaces
     torch.nn.utils.clip_grad_norm_ (it only records max_norm: the scaling happens inside the fused step)."""
@@ -80,8 +124,7 @@ class FlatAdamOneCycle:
         registration order the LAST ones: ... backbone | fusion | head) and all-reduces that tail asynchronously as soon as their
         backward closures have been queued; the head of the buffer follows in step().  A no-op without a multi-rank group (or
         PCP_FORCE_COLLECTIVES=1), or when those parameters are not one contiguous tail of the flat buffer."""
-        from pcdet.models.detectors import centerpoint
-        self._tail_off, self._tail_work, self._tail_trigger = None, None, None
+        self._tail_off, self._tail_trigger, self._overlap = None, None, None
         if not _collectives_on(self.process_group):
             return False
         owner = {}
@@ -102,14 +145,23 @@ class FlatAdamOneCycle:
         present = [n for n in first_done if hasattr(model, n) and getattr(model, n) is not None]
         self._tail_off = tail_start
         self._tail_trigger = present[-1]                   # the tape runs in reverse registration order: the last listed finishes last
-        centerpoint.GRAD_READY_HOOK = self._grad_ready
+        self._overlap = OverlappedFlatReduce(self.flat_g, tail_start, self.process_group)
+        model._pcp_grad_ready_hook = self._grad_ready      # carried by the loss node of THIS model's forwards only (centerpoint.hip_loss)
         return True
 
+    def detach_overlap(self, model):
+        """back to the single all-reduce in step()"""
+        if self._overlap is not None:
+            self._overlap.abandon()
+        self._tail_off, self._tail_trigger, self._overlap = None, None, None
+        if getattr(model, '_pcp_grad_ready_hook', None) == self._grad_ready:
+            model._pcp_grad_ready_hook = None
+
     def _grad_ready(self, name):
-        if self._tail_off is None or name != self._tail_trigger or self._tail_work is not None:
+        if self._overlap is None or name != self._tail_trigger:
             return
-        self._tail_work = torch.distributed.all_reduce(self.flat_g[self._tail_off:], group=self.process_group, async_op=True)
-        self.overlapped_reductions = getattr(self, 'overlapped_reductions', 0) + 1
+        self._overlap.grad_ready()
+        self.overlapped_reductions = self._overlap.started
 
     def zero_grad(self):
         off = 0
@@ -118,6 +170,8 @@ class FlatAdamOneCycle:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
             off += (n + 3) // 4 * 4
+        if getattr(self, '_overlap', None) is not None:
+            self._overlap.abandon()                                         # a step that was skipped: its tail reduction is dropped
         tops_zero(self.flat_g)
 
     def clip_grad_norm(self, max_norm):
@@ -126,11 +180,9 @@ class FlatAdamOneCycle:
         return self.sqnorm
 
     def step(self):
-        if getattr(self, '_tail_work', None) is not None:
+        if getattr(self, '_overlap', None) is not None:
             # bucket 2 (head + fusion) has been in flight since their backward was queued; bucket 1 is the rest
-            scale = all_reduce_flat_gradient(self.flat_g[:self._tail_off], self.process_group)
-            self._tail_work.wait()
-            self._tail_work = None
+            scale = self._overlap.finish()
         else:
             scale = all_reduce_flat_gradient(self.flat_g, self.process_group)   # RCCL, one bucket; DDP-style averaging via grad_scale
         self.t += 1

@@ -669,7 +669,10 @@ def g7b_train_single(tag, yaml_name, layout):
 def g8_exchange():
     """Lately-fusion exchange: runs the reference's own apply_se3_ and the lines of v2x_sim_dataset_ego.py:196-232
     (torch.unique + scatter(mean) through the shim) on seeded MoDAR boxes / foreground points.  points_in_boxes_gpu is CUDA-only in
-    the reference; its indices come from oracle/exchange.py (restated from the kernel source) and are stored as data."""
+    the reference; its indices come from oracle/exchange.py (restated from the kernel source) and are stored as data.  Round 5: the
+    reference's own points_in_boxes_cpu (roiaware_pool3d.cpp:143-166, compiled from where it lies by oracle/build_ref.py) runs on the same
+    boxes and points: its first-true index per point is stored as `box_idx_ref_cpu` (the CPU function tests with MARGIN 1e-2, the CUDA kernel
+    with 1e-5: the two agree outside a 1 cm band around the box faces, `box_idx_margin_band` marks the points inside it)."""
     rh.install()
     sys.path.insert(0, REPO)
     from oracle import exchange as oex
@@ -718,6 +721,14 @@ def g8_exchange():
     rows[:, -1] = -1
     out = dict(modar=modar, foreground=fg, pose=T, max_sweep_idx=np.array(max_sweep_idx), box_idx=box_idx.numpy().astype(np.int32),
                rows=rows.astype(np.float32))
+    from oracle import build_ref
+    ref_mask = build_ref.ref_points_in_boxes_cpu(fg[:, :3], modar[:, :7])                  # (boxes, points), the reference's compiled code
+    assert ref_mask is not None, 'oracle/_ref/ref_roiaware_pool3d.so could not be built'
+    ref_first = np.where(ref_mask.any(0), ref_mask.argmax(0), -1).astype(np.int32)
+    band = ref_first != out['box_idx']
+    assert np.array_equal(ref_first, oex.points_in_boxes(fg[:, :3], modar[:, :7], margin=1e-2)) and 0 < int(band.sum()) < 20
+    out['box_idx_ref_cpu'] = ref_first
+    out['box_idx_margin_band'] = band
     # no-foreground variant (path_foregr missing, :205)
     mod2 = modar.copy()
     mod2[:, :7] = apply_se3_(T, boxes_=mod2[:, :7], return_transformed=True)

@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -78,6 +79,23 @@ def _body_merge(rank, world):
     return frames, merged
 
 
+def _body_world8(rank, world):
+    """the layout the driver's 8-GPU run produces: 6 agents and 4 frames on 8 ranks -- ranks 6, 7 hold no rows, ranks 5 .. 7 encode no agent,
+    ranks 4 .. 7 detect on no frame"""
+    from pcdet.models.sharded import AgentShardedMidFusion
+    from pcdet.utils import common_utils, v2x_exchange as ex
+    n = 3 + rank if rank < 6 else 0                               # rows of agent `rank` (agent ids 0 .. 5 dealt agent % world)
+    rows = torch.full((n, 4), float(rank))
+    rows[:, 0] = torch.arange(n) % 4                              # frame index column
+    union, counts = ex.all_gather_v_rows(rows)
+    frames = ex.shard_frames(4, world, rank)
+    merged = common_utils.merge_results_dist([{'frame': f, 'rank': rank} for f in frames], 4)
+    mine = AgentShardedMidFusion.agents_of_rank([0, 1, 2, 3, 4, 5], world, rank)
+    stack = torch.full((1, 2, 2, 2, 3), float(rank))              # the fixed-shape map stack every rank contributes, agents or not
+    maps = ex.all_gather_maps_async(stack).wait()
+    return counts, union[:, 1].tolist(), frames, merged, mine, [float(m.mean()) for m in maps]
+
+
 # ---- tests ---------------------------------------------------------------------------------------------------------------
 
 def test_all_gather_v_rows_ragged():
@@ -109,6 +127,35 @@ def test_map_gathers():
     r0, r1 = _run('_body_maps')
     assert r0[0] == [1.0, 2.0] and r1[0] == [1.0, 2.0]
     assert r0[1] is None and r1[1] == [1.0, 2.0]
+
+
+def test_world_8_layout_with_ranks_that_own_no_agent_and_no_frame():
+    """every multi-process test was world 2 with agents AND frames on each rank; the 8-GPU run has neither on some"""
+    out = _run('_body_world8', world=8)
+    counts = [3, 4, 5, 6, 7, 8, 0, 0]
+    for rank, (cnt, col, frames, merged, mine, maps) in enumerate(out):
+        assert cnt == counts
+        assert col == [float(r) for r in range(6) for _ in range(3 + r)]          # rank-major union, empty ranks contribute nothing
+        assert frames == ([rank] if rank < 4 else [])
+        assert maps == [float(r) for r in range(8)]
+        if rank == 0:
+            assert [(d['frame'], d['rank']) for d in merged] == [(f, f) for f in range(4)]      # dataset order, one frame per rank 0 .. 3
+        else:
+            assert merged is None
+    assert [o[4] for o in out] == [[0], [2], [3], [4], [5], [], [], []]          # remote agents round-robin; the ego (1) is nobody's
+
+
+@pytest.mark.parametrize('shard', ['frame', 'agent'])
+def test_bench_gpus_8_dry_run(shard):
+    """`python bench.py --gpus 8` (the driver's scaling run) starts eight ranks itself; with --shard agent the dry run also walks the
+    agent % world row split and the ragged gather with the two ranks that get no agent"""
+    r, line = _bench(['--gpus', '8', '--steps', '2', '--warmup', '1', '--shard', shard] + (['--config', 'disco'] if shard == 'agent' else []),
+                     {'PCP_BENCH_DRY_RUN': '1'}, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 8 and line['ranks_seen_by_collective'] == 8 and 'DRY RUN' in line['data']
+    assert line['ms_per_step'] >= 2 * 8 * 0.9                                    # the slowest rank sleeps 2 ms x 8 per step: MAX over ranks
+    if shard == 'agent':
+        assert line['config']['rows_per_rank'] == [4, 4, 4, 4, 4, 4, 0, 0] and line['config']['frames_per_rank'] == [1, 1, 1, 1, 0, 0, 0, 0]
 
 
 def test_frame_sharding_and_result_merge_keep_dataset_order():
@@ -144,6 +191,69 @@ def test_flat_gradient_allreduce_gives_identical_replicas():
     assert out[0][1] == 0.5 and out[1][1] == 0.5
     assert out[0][0] < 1e-7 and out[1][0] < 1e-7
     assert out[0][2] == out[1][2]
+
+
+def _body_overlapped_reduce(rank, world):
+    """the two-bucket reduction against the single all-reduce with DIFFERENT gradients per rank -- one backward per
+    step, two backward passes before a step (gradient accumulation), a step that is skipped (zero_grad in between), and two optimizers in
+    one process whose hooks must not fire each other's reduction."""
+    sys.path.insert(0, os.path.join(PKG, 'tools'))
+    from train_utils.optimization import OverlappedFlatReduce
+    from pcdet.models.detectors.centerpoint import run_tape
+    from pcp_amd import synth
+    n, tail = 1000, 640
+    grad = lambda step, part: torch.from_numpy(synth.uniform(5, 100 * step + 10 * part + rank, n, -1, 1))      # rank-dependent
+    want = lambda step, parts: sum(torch.from_numpy(synth.uniform(5, 100 * step + 10 * p_ + r, n, -1, 1)) for p_ in parts for r in range(world))
+    out = {}
+    flat = torch.zeros(n)
+    red = OverlappedFlatReduce(flat, tail)
+    # (1) one backward per step: the tail is ready first (and reduced while the "backbone" still writes the head)
+    flat.zero_()
+    g = grad(1, 0)
+    flat[tail:] += g[tail:]
+    red.grad_ready()
+    flat[:tail] += g[:tail]
+    scale = red.finish()
+    out['one_backward'] = bool(torch.allclose(flat, want(1, [0]), atol=1e-6)) and scale == 1.0 / world and red.started == 1
+    # (2) gradient accumulation: a second backward adds to the tail AFTER its first reduction was issued
+    flat.zero_()
+    for part in (0, 1):
+        g = grad(2, part)
+        flat[tail:] += g[tail:]
+        red.grad_ready()
+        flat[:tail] += g[:tail]
+    red.finish()
+    out['two_backwards'] = bool(torch.allclose(flat, want(2, [0, 1]), atol=1e-6)) and red.started == 2
+    # (3) a skipped step: backward, zero_grad (abandon), backward, step
+    flat.zero_()
+    flat += grad(3, 0)
+    red.grad_ready()
+    red.abandon()
+    flat.zero_()
+    flat += grad(3, 1)
+    red.grad_ready()
+    red.finish()
+    out['skipped_step'] = bool(torch.allclose(flat, want(3, [1]), atol=1e-6))
+    # (4) the hook travels with the loss node of ITS model: running model B's tape fires B's reducer only
+    fa, fb = torch.zeros(n), torch.zeros(n)
+    ra, rb = OverlappedFlatReduce(fa, tail), OverlappedFlatReduce(fb, tail)
+    fired = []
+    hook_a = lambda name: (fired.append(('a', name)), ra.grad_ready())[0] if name == 'dense_head' else None
+    hook_b = lambda name: (fired.append(('b', name)), rb.grad_ready())[0] if name == 'dense_head' else None
+    fb += grad(4, 0)
+    run_tape([('vfe', lambda g_: None), ('dense_head', lambda g_: None)], hook_b)
+    out['other_models_tape_leaves_this_one_alone'] = ra.work is None and rb.work is not None and fired == [('b', 'dense_head')]
+    rb.finish()
+    fa += grad(4, 1)
+    run_tape([('vfe', lambda g_: None), ('dense_head', lambda g_: None)], hook_a)
+    ra.finish()
+    out['both_correct'] = bool(torch.allclose(fb, want(4, [0]), atol=1e-6) and torch.allclose(fa, want(4, [1]), atol=1e-6))
+    return out
+
+
+def test_overlapped_two_bucket_reduce_equals_the_single_all_reduce():
+    for out in _run('_body_overlapped_reduce'):
+        assert all(out.values()), out
 
 
 # ---- bench.py --gpus N: the launcher itself ------------------------------------------------------------------------------

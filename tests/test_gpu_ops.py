@@ -938,6 +938,29 @@ def test_nms_normal_gpu_matches_oracle(n):
         assert 0 < want.shape[0] < n                                                  # the threshold bites
 
 
+def test_multi_classes_nms_cuts_to_pre_maxsize_for_the_axis_aligned_type_too():
+    """the reference cuts every class to topk(NMS_PRE_MAXSIZE) before EITHER NMS type (model_nms_utils.py:50); nms_normal_gpu
+    used to swallow pre_maxsize.  700 candidates of one class, PRE_MAXSIZE 200: the result is the reference's own line order --
+    topk, NMS on the cut list -- restated with the oracle."""
+    from pcdet.config import EasyDict
+    from pcdet.models.model_utils import model_nms_utils as M
+    boxes, scores = _random_boxes(700, 4321)
+    cls = np.stack([scores, 0.5 * scores[::-1]], 1).astype(np.float32)
+    for nms_type, oracle_fn in (('nms_normal_gpu', onms.nms_normal_gpu), ('nms_gpu', onms.nms_gpu)):
+        cfg = EasyDict(NMS_TYPE=nms_type, NMS_THRESH=0.25, NMS_PRE_MAXSIZE=200, NMS_POST_MAXSIZE=50)
+        ps, pl, pb = M.multi_classes_nms(torch.from_numpy(cls).to(dev()), torch.from_numpy(boxes).to(dev()), cfg, score_thresh=0.05)
+        want_s, want_l = [], []
+        for k in range(2):
+            m = cls[:, k] >= 0.05
+            sc, bx = cls[m, k], boxes[m]
+            idx = np.argsort(-sc, kind='stable')[:200]                               # topk(PRE_MAXSIZE)
+            keep = oracle_fn(bx[idx], sc[idx], 0.25)[:50]
+            want_s.append(sc[idx][keep])
+            want_l.append(np.full(len(keep), k))
+        assert ps.cpu().numpy().tolist() == np.concatenate(want_s).tolist() and pl.cpu().numpy().tolist() == np.concatenate(want_l).tolist()
+        assert pb.shape[0] == ps.shape[0] > 10
+
+
 def test_boxes_bev_iou_cpu_takes_cpu_tensors_and_numpy():
     """iou3d_nms_utils.boxes_bev_iou_cpu (reference :12-29): CPU tensors / numpy in, the same kind out, values = the C oracle's (which is
     pinned bit for bit on the reference's own iou3d_cpu.cpp, tests/test_oracle_pins.py)"""

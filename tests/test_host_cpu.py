@@ -388,6 +388,22 @@ def test_auto_resume_validates_a_checkpoint_before_anything_is_loaded(tmp_path):
     assert train_tool.choose_resume_checkpoint(model, tmp_path, log) == str(good)
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k])
+    # with an optimizer to restore, its payload is validated too (the loader used to raise AFTER the model was overwritten):
+    # the junk side file of `good` disqualifies it, a checkpoint with an extra tensor is refused (strict loading), one whose moments have
+    # the flat buffer's size is taken, one of another size is not
+    class _Opt:
+        flat_p = torch.zeros(100)
+    assert train_tool.choose_resume_checkpoint(model, tmp_path, log, _Opt()) is None
+    sd = {k: v + 2 for k, v in before.items()}
+    moments = lambda n: {'t': 3, 'exp_avg': torch.zeros(n), 'exp_avg_sq': torch.zeros(n), 'lr': 1e-3, 'mom': 0.9}
+    fits, small, extra = tmp_path / 'checkpoint_epoch_4.pth', tmp_path / 'checkpoint_epoch_5.pth', tmp_path / 'checkpoint_epoch_6.pth'
+    torch.save({'model_state': sd, 'epoch': 4, 'it': 40, 'optimizer_state': moments(100)}, fits)
+    torch.save({'model_state': sd, 'epoch': 5, 'it': 50, 'optimizer_state': moments(64)}, small)
+    torch.save({'model_state': dict(sd, stray=torch.zeros(1)), 'epoch': 6, 'it': 60, 'optimizer_state': moments(100)}, extra)
+    for i, f in enumerate((fits, small, extra)):
+        os.utime(f, (now + 10 + i, now + 10 + i))
+    assert train_tool.choose_resume_checkpoint(model, tmp_path, log, _Opt()) == str(fits)
+    assert train_tool.choose_resume_checkpoint(model, tmp_path, log) == str(small)         # no optimizer to restore: only the model half counts
 
 
 def test_vectorised_warp_thetas_equal_the_reference_arithmetic_bit_for_bit():
@@ -416,3 +432,27 @@ def test_vectorised_warp_thetas_equal_the_reference_arithmetic_bit_for_bit():
     naive = -(rt[:, :, 0] * tp[:, 0:1] + rt[:, :, 1] * tp[:, 1:2])
     ref = np.array(fh.warp_thetas(poses, 128, 128, -51.2, 0.8), dtype=np.float32).reshape(-1, 2, 3)[:, :, 2]
     assert (naive != ref).mean() > 0.05
+
+
+def test_deferred_batchnorm_counters_are_flushed_before_state_dict_and_dropped_on_load():
+    """num_batches_tracked increments of the training path are collected and applied once per optimizer step; a state_dict()
+    taken between a forward and the step must still see them, and a load_state_dict() must not have older increments added on top."""
+    import torch.nn as nn
+    from pcdet.models.packed import PackedModule
+    from pcp_amd import train_layers as tl
+
+    class M(PackedModule):
+        def __init__(self):
+            super().__init__()
+            self.bn = nn.BatchNorm2d(4)
+    m = M()
+    tl.bump_batches_tracked(m.bn)
+    tl.bump_batches_tracked(m.bn)
+    sd = m.state_dict()
+    assert int(sd['bn.num_batches_tracked']) == 2
+    tl.bump_batches_tracked(m.bn)                                # a warm-up forward, then a checkpoint is loaded
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd['bn.num_batches_tracked'] = torch.tensor(7)
+    m.load_state_dict(sd)
+    tl.StepClock.tick()
+    assert int(m.bn.num_batches_tracked) == 7
