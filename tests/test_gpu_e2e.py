@@ -1402,3 +1402,105 @@ def test_tools_test_py_fast_mode_pipelines_batches_and_reports_the_same_detectio
         assert m is not None and int(m.group(2)) == 7, out[-1500:]
         reports.append(m.group(0))
     assert reports[0] == reports[1], reports
+
+
+# ---- regression tests of the ADVICE r3 fixes -----------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_fast_mode_with_exchange_data_generation_writes_the_same_modar_files(tmp_path):
+    """`tools/test.py --fast` with DENSE_HEAD.GENERATING_EXCHANGE_DATA (the reference's exchange-database workflow, center_head.py:409-427):
+    PipelinedDetector.supports() must refuse the head (a deferred finalize would skip the *_modar.pth files silently) and the loop falls back
+    to batch by batch -- the same files with the same boxes as without --fast."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = os.path.join(repo, 'practical-collab-perception_amd', 'tools')
+    got = {}
+    for tag, extra in (('plain', []), ('fast', ['--fast'])):
+        out_dir = tmp_path / tag
+        out_dir.mkdir()
+        cmd = [sys.executable, 'test.py', '--cfg_file', 'cfgs/v2x_sim_models/v2x_pointpillar_basic_car.yaml', '--batch_size', '2'] + extra + \
+              ['--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '6000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '5',
+               'MODEL.DENSE_HEAD.GENERATING_EXCHANGE_DATA', 'True', 'MODEL.DENSE_HEAD.DATABASE_EXCHANGE_DATA', str(out_dir),
+               'MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH', '0.02']
+        r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
+        got[tag] = {f: torch.load(str(out_dir / f), map_location='cpu') for f in sorted(os.listdir(out_dir)) if f.endswith('_modar.pth')}
+    assert len(got['plain']) >= 3 and sorted(got['plain']) == sorted(got['fast'])
+    for f, a in got['plain'].items():
+        b = got['fast'][f]
+        assert a.shape == b.shape and a.shape[1] == 9
+        # --fast takes the first backbone layer from the pillar list (another summation order): rounding-level differences only
+        assert torch.allclose(a, b, atol=1e-4), f
+
+
+@pytest.mark.gpu
+def test_pipelined_detector_refuses_heads_that_write_exchange_data_and_waits_for_the_callers_stream():
+    from helpers import load_golden
+    from pcdet.models import build_network_from_meta
+    from pcdet.models.pipelined import PipelinedDetector
+    from pcp_amd import synth
+    g = load_golden('g1_ego.npz')
+    model = build_network_from_meta(g['meta'])
+    st = synth.fill_state_dict(g['meta']['state_shapes'])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.cuda().eval()
+    assert PipelinedDetector.supports(model)
+    model.dense_head.model_cfg['RETURN_MODAR_POINTS'] = True
+    try:
+        assert not PipelinedDetector.supports(model)
+        with pytest.raises(NotImplementedError):
+            PipelinedDetector(model)
+    finally:
+        model.dense_head.model_cfg['RETURN_MODAR_POINTS'] = False
+    # copy_from is None and the caller fills `points` on ITS stream with a non-blocking copy behind a long kernel: the forward must see the
+    # filled rows (the side / main streams wait for the caller's stream), i.e. give the detections of the plain call
+    pts_host = torch.from_numpy(g['points']).pin_memory()
+    with torch.no_grad():
+        want, _ = model({'points': pts_host.cuda(), 'batch_size': 2, 'metadata': [{}, {}]})
+    pipe = PipelinedDetector(model, replicas=2)
+    buf = torch.zeros_like(pts_host, device='cuda')
+    caller = torch.cuda.Stream()
+    with torch.cuda.stream(caller):
+        big = torch.empty((4096, 4096), device='cuda')
+        for _ in range(20):
+            big = big @ big.clamp_(-1e-3, 1e-3)                 # keeps the caller's stream busy in front of the upload
+        buf.copy_(pts_host, non_blocking=True)
+        pipe.submit(buf, 2, [{}, {}])
+        got = pipe.flush()
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a['pred_boxes'], b['pred_boxes']) and torch.equal(a['pred_scores'], b['pred_scores'])
+    assert sum(a['pred_boxes'].shape[0] for a in want) > 0
+
+
+@pytest.mark.gpu
+def test_vfe_never_adopts_a_shared_pillar_workspace_across_a_share_to_no_share_transition():
+    """two VFEs of a forward that pillarise the same cloud share the producer's pillar list (DiscoNet: early maker + ego branch).  The
+    consumer must keep pillarising into its OWN workspace when a later forward does not share: adopting the producer's ring slot would
+    let the two overwrite each other's lists."""
+    from pcdet.models.backbones_3d.vfe.dynamic_pillar_vfe import DynamicPillarVFE
+    from pcdet.config import EasyDict
+    cfg = EasyDict(NAME='DynPillarVFE', WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_NORM=True, NUM_FILTERS=[64, 64])
+    mk = lambda: DynamicPillarVFE(model_cfg=cfg, num_point_features=5, voxel_size=[0.2, 0.2, 8.0], grid_size=[64, 64, 1],
+                                  point_cloud_range=[-6.4, -6.4, -8, 6.4, 6.4, 0]).cuda().eval()
+    prod, cons = mk(), mk()
+    for v in (prod, cons):
+        v.materialize_pillars, v.reuse_buffers = False, True
+    from pcp_amd import synth
+    pts = torch.from_numpy(synth.collate([synth.agent_cloud(0, 3000, 'car', xy_half=6.6), synth.agent_cloud(1, 2000, 'car', xy_half=6.6)])).cuda()
+    with torch.no_grad():
+        share = {}
+        a = prod({'points': pts, 'batch_size': 2, '_pcp_vox_share': share})
+        b = cons({'points': pts, 'batch_size': 2, '_pcp_vox_share': share})
+        assert b['_pcp_vfe']['vox'] is a['_pcp_vfe']['vox']                       # shared: one pillar list
+        own_before = cons._workspace
+        assert own_before is None or own_before.data_ptr() != a['_pcp_vfe']['vox'].workspace.data_ptr()
+        c = cons({'points': pts, 'batch_size': 2})                                # no share: must not write into the producer's slot
+        assert c['_pcp_vfe']['vox'].workspace.data_ptr() not in [w.data_ptr() for w in prod._ws_ring if w is not None]
+        want = prod({'points': pts, 'batch_size': 2})['_pcp_vfe']['canvas'].clone()
+        cons.load_state_dict(prod.state_dict())
+        got = cons({'points': pts, 'batch_size': 2})['_pcp_vfe']['canvas']
+    torch.cuda.synchronize()
+    assert torch.equal(want, got)
