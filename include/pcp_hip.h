@@ -347,6 +347,13 @@ int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const floa
 int pcp_disco_weight_fuse(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
                           const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                           float *out, int32_t ld_out, float *logits, int32_t ld_w, void *stream);
+/* The same launch with maps that may not exist, decided on the device (DiscoNet under hipGraph): map a leaves the softmax -- weight exactly
+ * 0, the others exactly the softmax over the maps that exist -- when live_index_host[a] >= 0 and live[live_index_host[a]] == 0 (`live`: the
+ * flags of pcp_agent_frame_live; the ego map passes -1).  What the reference does by not having the agent in batch_dict['bev_img'] at all
+ * (v2x_fusion_disco.py:83). */
+int pcp_disco_weight_fuse_live(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
+                               const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                               float *out, int32_t ld_out, const int32_t *live_index_host, const int32_t *live, void *stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -415,6 +422,16 @@ int pcp_column_id_counts(const float *points, int64_t n, int32_t row_stride, int
  * vox_grid != NULL (batch_size = n_slots * batch): the cell id of every written row and the per-cell histogram are emitted into
  * vox_workspace, laid out as pcp_voxelize lays it out for (vox_grid, out_rows); follow with pcp_voxelize_cells_ready on the same
  * arguments instead of pcp_voxelize (its first pass over the rows is then already done). */
+/* Round 5 (DiscoNet under hipGraph): which (agent, frame) maps of a BEV maker exist, decided on the device instead of by the host read of
+ * bev_maker.py:156.  pcp_agent_frame_live: live[a * batch + b] (64 * batch int32, 16-byte aligned) = 1 iff agent a (id in `agent_col`,
+ * 0..63) holds a row anywhere in the batch (an agent without rows is skipped by the reference's maker; which frames of an agent exist is
+ * metadata, known on the host).  pcp_zero_maps_unless: `maps` =
+ * n_maps (<= 256) consecutive maps of map_elems floats; map m is zero-filled unless live[flag_index_host[m]] != 0 (flag_index_host[m] < 0:
+ * left alone).  Both capturable: no host read. */
+int pcp_agent_frame_live(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t batch, int32_t *live,
+                         void *stream);
+int pcp_zero_maps_unless(float *maps, int64_t map_elems, int32_t n_maps, const int32_t *flag_index_host, const int32_t *live,
+                         void *stream);
 size_t pcp_select_transform_compact_workspace_bytes(int64_t n, int32_t n_slots);
 int pcp_select_transform_compact(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
                                  const float *agents_host, int32_t batch, const float *poses_host, const uint8_t *present_host,

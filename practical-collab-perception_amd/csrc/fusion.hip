@@ -255,6 +255,8 @@ struct WfParams {
   long long pixels;
   const float *w1, *b1, *w2, *b2, *w3, *b3;     // BN folded: w1 (64, 2C) row-major, w2 (16, 64), w3 (16)
   float *out, *logits;                          // logits: optional (pixels, ld_w) copy of the pre-softmax weights
+  const int *live;                              // optional device flags: map a takes part in the softmax iff live_idx[a] < 0 or live[live_idx[a]] != 0
+  int live_idx[MAX_AGENTS];
 };
 
 }  // namespace
@@ -345,6 +347,9 @@ __global__ __launch_bounds__(256, 2) void k_weight_fuse(WfParams p) {
 #pragma unroll
         for (int k = 0; k < WF_H2; k++) l = fmaf(p.w3[k], h2[tid][k], l);
         l = fmaxf(l, 0.f);
+        // a map that does not exist (hipGraph mode: an agent without rows, decided on the device) leaves the softmax: weight exactly 0,
+        // the other weights exactly those of the softmax over the maps that do exist
+        if (p.live && p.live_idx[a_i] >= 0 && p.live[p.live_idx[a_i]] == 0) l = -INFINITY;
         lg[a_i][tid] = l;
         if (p.logits && px0 + tid < p.pixels) p.logits[(px0 + tid) * p.ld_w + a_i] = l;
       }
@@ -402,9 +407,10 @@ __global__ __launch_bounds__(256, 2) void k_weight_fuse(WfParams p) {
 
 }  // namespace
 
-extern "C" int pcp_disco_weight_fuse(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
-                                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
-                                     float *out, int32_t ld_out, float *logits, int32_t ld_w, void *stream_) {
+static int disco_weight_fuse_impl(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
+                                  const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                  float *out, int32_t ld_out, float *logits, int32_t ld_w, const int32_t *live_index_host, const int32_t *live,
+                                  void *stream_) {
   if (!maps_host || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || n_maps <= 0 || n_maps > MAX_AGENTS || pixels <= 0) return PCP_ERR_ARG;
   if (c != WF_C) return PCP_ERR_UNSUPPORTED;
   if ((ld_map & 3) || (ld_out & 3) || ld_map < c || ld_out < c || (logits && ld_w < n_maps)) return PCP_ERR_ARG;
@@ -416,9 +422,24 @@ extern "C" int pcp_disco_weight_fuse(const float *const *maps_host, int32_t n_ma
   }
   p.n_maps = n_maps; p.ld_map = ld_map; p.ld_out = ld_out; p.ld_w = ld_w; p.pixels = pixels;
   p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.out = out; p.logits = logits;
+  p.live = live_index_host ? live : nullptr;
+  for (int a = 0; a < MAX_AGENTS; a++) p.live_idx[a] = (live_index_host && a < n_maps) ? live_index_host[a] : -1;
   const long long n_tiles = (pixels + WF_PX - 1) / WF_PX;
   const unsigned blocks = (unsigned)(n_tiles < 512 ? n_tiles : 512);
   hipLaunchKernelGGL(k_weight_fuse, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+extern "C" int pcp_disco_weight_fuse(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
+                                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                     float *out, int32_t ld_out, float *logits, int32_t ld_w, void *stream_) {
+  return disco_weight_fuse_impl(maps_host, n_maps, c, ld_map, pixels, w1, b1, w2, b2, w3, b3, out, ld_out, logits, ld_w, nullptr, nullptr, stream_);
+}
+
+extern "C" int pcp_disco_weight_fuse_live(const float *const *maps_host, int32_t n_maps, int32_t c, int32_t ld_map, int64_t pixels,
+                                          const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                          float *out, int32_t ld_out, const int32_t *live_index_host, const int32_t *live, void *stream_) {
+  if (!live_index_host || !live) return PCP_ERR_ARG;
+  return disco_weight_fuse_impl(maps_host, n_maps, c, ld_map, pixels, w1, b1, w2, b2, w3, b3, out, ld_out, nullptr, 0, live_index_host, live, stream_);
 }

@@ -761,6 +761,77 @@ extern "C" int pcp_column_id_counts(const float *points, int64_t n, int32_t row_
   return PCP_OK;
 }
 
+// ---- which (agent, frame) maps of a BEV maker exist, decided on the DEVICE (round 5: DiscoNet under hipGraph) -------------------------------------
+// Reference behaviour (bev_maker.py:153-190): an agent without a single row in the batch is skipped -- it is not in batch_dict['bev_img'] and
+// takes no part in the fusion's softmax; which FRAMES of an agent exist is metadata (se3_from_ego), known on the host.  The eager path reads
+// the per-agent row counts back to decide this (the reference syncs at the same place); a captured graph cannot, so the makers run for every
+// agent the metadata lists and the maps of agents without rows are zeroed (pcp_zero_maps_unless) and leave the softmax
+// (pcp_disco_weight_fuse_live) from these flags.
+//   live[a * batch + b] = 1 iff agent a holds a row anywhere in the batch (the same value for every frame b of the agent).
+namespace {
+__global__ __launch_bounds__(256) void k_agent_frame_hist(const float *__restrict__ points, long long n, int stride, int col, int batch,
+                                                          int *__restrict__ hist) {
+  extern __shared__ int s_hist[];                       // [64][batch]
+  for (int i = threadIdx.x; i < 64 * batch; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float a = points[i * stride + col], fb = points[i * stride];
+    if (a > -1.f && a < 64.f && fb >= 0.f && fb < (float)batch) atomicAdd(&s_hist[(int)a * batch + (int)fb], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * batch; i += 256)
+    if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+__global__ void k_agent_frame_live(int *__restrict__ hist_live, int batch) {
+  const int a = threadIdx.x;                            // 64 threads: one agent each, flags written over its own histogram row
+  int total = 0;
+  for (int b = 0; b < batch; b++) total += hist_live[a * batch + b];
+  for (int b = 0; b < batch; b++) hist_live[a * batch + b] = total > 0 ? 1 : 0;
+}
+constexpr int ZM_MAX = 256;
+struct ZmTable { int idx[ZM_MAX]; };
+__global__ __launch_bounds__(256) void k_zero_maps_unless(float *__restrict__ maps, long long map_elems, ZmTable t, const int *__restrict__ live) {
+  const int m = blockIdx.y;
+  const int k = t.idx[m];
+  if (k < 0 || live[k] != 0) return;
+  f32x4 *dst = reinterpret_cast<f32x4 *>(maps + (long long)m * map_elems);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < map_elems / 4; i += (long long)gridDim.x * 256) dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+}  // namespace
+
+extern "C" int pcp_agent_frame_live(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t batch, int32_t *live,
+                                    void *stream_) {
+  if (!live || n < 0 || row_stride <= 0 || agent_col < 0 || agent_col >= row_stride || batch <= 0 || batch > 64 || (((uintptr_t)live) & 15))
+    return PCP_ERR_ARG;
+  if (n > 0 && !points) return PCP_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (pcp_zero_async(live, (size_t)64 * batch * 4, stream) != PCP_OK) return PCP_ERR_LAUNCH;
+  if (n > 0) {
+    long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_agent_frame_hist, dim3((unsigned)blocks), dim3(256), (size_t)64 * batch * 4, stream, points, (long long)n, (int)row_stride,
+                       (int)agent_col, (int)batch, live);
+    PCP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_agent_frame_live, dim3(1), dim3(64), 0, stream, live, (int)batch);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+extern "C" int pcp_zero_maps_unless(float *maps, int64_t map_elems, int32_t n_maps, const int32_t *flag_index_host, const int32_t *live,
+                                    void *stream_) {
+  if (!maps || !flag_index_host || !live || map_elems <= 0 || map_elems % 4 != 0 || n_maps <= 0 || n_maps > ZM_MAX || (((uintptr_t)maps) & 15))
+    return PCP_ERR_ARG;
+  ZmTable t;
+  for (int i = 0; i < ZM_MAX; i++) t.idx[i] = i < n_maps ? flag_index_host[i] : -1;
+  long long bx = (map_elems / 4 + 256 * 8 - 1) / (256 * 8);
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(k_zero_maps_unless, dim3((unsigned)bx, (unsigned)n_maps), dim3(256), 0, (hipStream_t)stream_, maps, (long long)map_elems, t,
+                     live);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
 extern "C" size_t pcp_select_transform_compact_workspace_bytes(int64_t n, int32_t n_slots) {
   if (n < 0 || n_slots <= 0 || n_slots > STC_MAX_SLOTS) return 0;
   return stc_layout(n, n_slots).total;

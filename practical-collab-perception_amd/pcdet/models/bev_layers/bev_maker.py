@@ -92,12 +92,22 @@ class BEVMaker(nn.Module):
         batch_size = batch_dict['batch_size']
         # which agents have points, and how many rows each: one sync, as in the reference (:156), but a histogram launch instead of a
         # sort; the rsu and car makers of one forward see the same (unmodified) points, so the second one reuses the answer
-        cached = batch_dict.get('_pcp_agent_ids', None)
-        if cached is not None and cached[0] is points:
-            agent_ids, agent_rows = cached[1], cached[2]
+        static = bool(batch_dict.get('_pcp_static_agents', False))
+        if static:
+            # hipGraph capture (pcdet/models/graphed.py): no host read.  Every agent the metadata lists is encoded for every frame, with the
+            # whole cloud as the row capacity; the maps of agents without a single row -- which the reference skips -- are zeroed and leave the
+            # fusion's softmax from device-side flags (pcp_agent_frame_live / pcp_zero_maps_unless / pcp_disco_weight_fuse_live)
+            if batch_dict.get('_pcp_agent_live', None) is None:
+                batch_dict['_pcp_agent_live'] = ops.agent_frame_live(points, -1, batch_size)
+            agent_ids = np.asarray(sorted({int(a) for meta in batch_dict['metadata'] for a in meta['se3_from_ego'].keys()}), dtype=np.int64)
+            agent_rows = None
         else:
-            agent_ids, agent_rows = ops.column_id_counts(points, -1)
-            batch_dict['_pcp_agent_ids'] = (points, agent_ids, agent_rows)
+            cached = batch_dict.get('_pcp_agent_ids', None)
+            if cached is not None and cached[0] is points:
+                agent_ids, agent_rows = cached[1], cached[2]
+            else:
+                agent_ids, agent_rows = ops.column_id_counts(points, -1)
+                batch_dict['_pcp_agent_ids'] = (points, agent_ids, agent_rows)
         batch_dict['bev_img'] = dict()
         jobs = []
         for agent_idx in agent_ids:
@@ -117,7 +127,7 @@ class BEVMaker(nn.Module):
                 continue
             # the reference derives the map's batch dimension from the largest frame index that has points (quirk of
             # pointpillar_scatter.py:17); reproduce it so downstream shapes match
-            jobs.append((int(agent_idx), poses, present, int(np.nonzero(present)[0].max()) + 1))
+            jobs.append((int(agent_idx), poses, present, batch_size if static else int(np.nonzero(present)[0].max()) + 1))
         if not jobs:
             return batch_dict
         # The agents share this maker's frozen chain and frames are independent in it (eval-mode BatchNorm, per-frame pillars and
@@ -126,14 +136,15 @@ class BEVMaker(nn.Module):
         # Round 3: the stacked cloud is the reference's own cat of `points[mask]` selections (a stable compaction, one call for all slots,
         # rows = what the agents really hold) instead of one full masked copy of the cloud per agent.
         n, c = points.shape
-        use_compact = self.compact and batch_size <= 64
+        use_compact = (self.compact or static) and batch_size <= 64
+        assert use_compact or not static, 'static agent discovery needs the compacting form (batch size <= 64)'
         group = max(1, min(len(jobs), self.max_agents_per_pass))
         if use_compact:
             group = max(1, min(group, 8, 64 // batch_size))
         for g0 in range(0, len(jobs), group):
             chunk = jobs[g0:g0 + group]
             if use_compact:
-                rows = sum(int(agent_rows[a]) for a, _p, _q, _l in chunk)
+                rows = n if static else sum(int(agent_rows[a]) for a, _p, _q, _l in chunk)
                 vfe_mod = self.module_list[0]
                 grid = ops.make_grid(vfe_mod.point_cloud_range, vfe_mod.voxel_size, vfe_mod.grid_size, batch_size * len(chunk))
                 ws = ops.rows_workspace(grid, max(rows, 1), vfe_mod.num_raw_point_features, points.device,

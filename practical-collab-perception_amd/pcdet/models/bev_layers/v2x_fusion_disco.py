@@ -156,10 +156,21 @@ class V2XMidFusionDisco(PackedModule):
                 warps = []
                 self._weight(pk, stack[0], stack[a], wbuf, a)
         ops.warp_nearest_batch(warps, self.cc)                 # fused weightor: every pair of the forward in ONE launch
+        live = batch_dict.get('_pcp_agent_live', None)
+        if live is not None and agents:
+            # hipGraph mode (BEVMaker static agent discovery): the maps of agents without rows / of frames behind an agent's last row do not
+            # exist in the reference (bev_maker.py:156-190) -- zeroed from the device-side flags
+            assert fuse_now, 'static agent discovery runs with the fused weightor'
+            idx = [int(agent_idx) * B + b_idx if agent_idx in meta['se3_from_ego'] else -1
+                   for agent_idx, _img in agents for b_idx, meta in enumerate(batch_dict['metadata'])]
+            ops.zero_maps_unless(stack[1:].view(len(agents) * B, H, W, self.cc), idx, live)
         fused = torch.empty((B, H, W, self.cc), dtype=torch.float32, device=dev)
         if fuse_now:
             wf = pk['wf']
-            ops.disco_weight_fuse([stack[a] for a in range(n_maps)], wf['w1'], wf['b1'], wf['w2'], wf['b2'], wf['w3'], wf['b3'], self.cc, fused)
+            # an agent without a single row is not in the reference's bev_img at all (:83): its map leaves the softmax (flag of its frame 0)
+            live_index = None if live is None else [-1] + [int(agent_idx) * B for agent_idx, _img in agents]
+            ops.disco_weight_fuse([stack[a] for a in range(n_maps)], wf['w1'], wf['b1'], wf['w2'], wf['b2'], wf['w3'], wf['b3'], self.cc, fused,
+                                  live_index=live_index, live=live)
         else:
             ops.softmax_fuse([stack[a] for a in range(n_maps)], wbuf, self.cc, fused)
         # the published map stays float32 also under PCP_CONV_ALGO=bf16 (the sharded detector and the heads read it as float)

@@ -4,7 +4,10 @@ At small batch the path is launch bound (~70 launches per frame through Python/c
 capturable by construction (no allocation, no sync, explicit stream), so the whole module chain -- point copy-in, pillariser,
 PFN, convolutions, HunterJr, decode, NMS -- becomes one graph replay per batch; only the final "how many boxes" host read
 stays outside.  Shapes are frozen at capture time (N points, batch size); feed a batch of another size eagerly.
-Not capturable: the DiscoNet BEVMaker's agent discovery (torch.unique(...).cpu(), as in the reference bev_maker.py:156).
+DiscoNet (round 5): the BEV makers' agent discovery -- torch.unique(...).cpu() in the reference (bev_maker.py:156), a histogram read-back in
+the eager path -- is replaced by device-side flags under capture: the makers run for every agent the metadata lists with the whole cloud as
+the row capacity, and pcp_zero_maps_unless zeroes the maps the reference would not have produced (`_pcp_static_agents`).  The agents'
+poses travel as kernel arguments: they are frozen at capture time like the shapes (a new pose set needs a new capture).
 """
 import torch
 
@@ -40,6 +43,8 @@ class GraphedDetector:
 
     def _run_modules(self):
         bd = {'points': self.static_points, 'batch_size': self.batch_size, 'metadata': self.metadata}
+        if any(type(m).__name__ == 'BEVMaker' for m in self.model.module_list):
+            bd['_pcp_static_agents'] = True                  # no host read inside the capture (see the module docstring)
         for m in self.model.module_list:
             bd = m(bd)
         self._last = bd

@@ -172,6 +172,8 @@ SYMBOLS = {
     'pcp_centerhead_decode': (c_i32, [ctypes.POINTER(Decode), vp, vp, c_sz, vp, vp, vp, vp, vp, vp]),
     'pcp_column_id_mask': (c_i32, [vp, ctypes.c_int64, c_i32, c_i32, vp, vp]),
     'pcp_column_id_counts': (c_i32, [vp, ctypes.c_int64, c_i32, c_i32, vp, vp]),
+    'pcp_agent_frame_live': (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, vp, vp]),
+    'pcp_zero_maps_unless': (c_i32, [vp, c_i64, c_i32, ctypes.POINTER(c_i32), vp, vp]),
     'pcp_select_transform_compact_workspace_bytes': (c_sz, [c_i64, c_i32]),
     'pcp_select_transform_compact': (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, ctypes.POINTER(c_f),
                                              ctypes.POINTER(ctypes.c_uint8), vp, c_i64, vp, c_sz, vp, ctypes.POINTER(Grid), vp, c_sz, vp]),
@@ -185,6 +187,7 @@ SYMBOLS = {
     'pcp_warp_nearest_batch': (c_i32, [vp, vp, ctypes.POINTER(c_f), c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
     'pcp_softmax_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, vp, c_i32, c_i64, c_i32, c_i32, c_i32, vp, vp]),
     'pcp_disco_weight_fuse': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, c_i32, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i32, vp, c_i32, vp]),
+    'pcp_disco_weight_fuse_live': (c_i32, [ctypes.POINTER(vp), c_i32, c_i32, c_i32, c_i64, vp, vp, vp, vp, vp, vp, vp, c_i32, ctypes.POINTER(c_i32), vp, vp]),
     'pcp_bev_sample_bilinear': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp,
                                         c_i32, vp]),
     'pcp_hunter_point_head': (c_i32, [vp, c_i32, c_i32, c_i32, c_i32, c_i32, vp, c_i64, c_i32, c_f, c_f, c_f, c_f, vp, vp, vp, vp, vp,

@@ -587,10 +587,11 @@ def softmax_fuse(maps, weights, channels, out):
     return out
 
 
-def disco_weight_fuse(maps, w1, b1, w2, b2, w3, b3, channels, out, logits=None):
+def disco_weight_fuse(maps, w1, b1, w2, b2, w3, b3, channels, out, logits=None, live_index=None, live=None):
     """the DiscoNet pixel weightor + softmax over the maps + weighted sum as one launch (include/pcp_hip.h: pcp_disco_weight_fuse).
-    maps: list of (..., ld_map) tensors sharing one pixel stride, maps[0] = ego; BN-folded float32 weights; out (..., ld_out)."""
-    _need_cuda(w1, b1, w2, b2, w3, b3, out, logits, *maps)
+    maps: list of (..., ld_map) tensors sharing one pixel stride, maps[0] = ego; BN-folded float32 weights; out (..., ld_out).
+    live_index / live: map a leaves the softmax when live_index[a] >= 0 and the device flag live[live_index[a]] is 0 (hipGraph mode)."""
+    _need_cuda(w1, b1, w2, b2, w3, b3, out, logits, live, *maps)
     _need_f32('pcp_disco_weight_fuse', out, logits, *maps)
     L = _lib.load()
     n = len(maps)
@@ -602,6 +603,12 @@ def disco_weight_fuse(maps, w1, b1, w2, b2, w3, b3, channels, out, logits=None):
     for t in (w1, b1, w2, b2, w3, b3):
         assert t.dtype == torch.float32 and t.is_contiguous()
     assert tuple(w1.shape) == (64, 2 * channels) and tuple(w2.shape) == (16, 64) and w3.numel() == 16 and b3.numel() == 1
+    if live_index is not None:
+        assert logits is None and live is not None and len(live_index) == n
+        idx = (ctypes.c_int32 * n)(*[int(v) for v in live_index])
+        check(L.pcp_disco_weight_fuse_live(arr, n, channels, ld_map, pixels, _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(out),
+                                           out.shape[-1], idx, _p(live), _stream()), 'pcp_disco_weight_fuse_live')
+        return out
     check(L.pcp_disco_weight_fuse(arr, n, channels, ld_map, pixels, _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(out), out.shape[-1],
                                   _p(logits), logits.shape[-1] if logits is not None else 0, _stream()), 'pcp_disco_weight_fuse')
     return out
@@ -691,6 +698,26 @@ def column_id_counts(points, col):
         raise _lib.PcpError('column %d holds %d agent ids outside 0..63: the BEV maker supports up to 64 agents' % (col, bad))
     ids = [i for i in range(64) if (mask >> i) & 1]
     return np.asarray(ids, dtype=np.int64), {i: vals[2 + i] for i in ids}
+
+
+def agent_frame_live(points, col, batch):
+    """device flags (64 * batch int32): agent a is encoded for frame b by the reference's BEV maker (include/pcp_hip.h); no host read"""
+    _need_cuda(points)
+    L = _lib.load()
+    n, stride = points.shape
+    live = torch.empty((64 * batch,), dtype=torch.int32, device=points.device)
+    check(L.pcp_agent_frame_live(_p(points), n, stride, col % stride, batch, _p(live), _stream()), 'pcp_agent_frame_live')
+    return live
+
+
+def zero_maps_unless(maps, flag_index, live):
+    """maps: contiguous (M, ...) float32; map m is zero-filled unless live[flag_index[m]] != 0 (flag_index[m] < 0: left alone)"""
+    _need_cuda(maps, live)
+    _need_f32('pcp_zero_maps_unless', maps)
+    L = _lib.load()
+    assert maps.is_contiguous() and len(flag_index) == maps.shape[0]
+    idx = (ctypes.c_int32 * len(flag_index))(*[int(v) for v in flag_index])
+    check(L.pcp_zero_maps_unless(_p(maps), maps[0].numel(), maps.shape[0], idx, _p(live), _stream()), 'pcp_zero_maps_unless')
 
 
 _STC_SCRATCH = {}

@@ -420,6 +420,36 @@ def test_hipgraph_replay_equals_eager(tag):
     assert torch.equal(out2[0]['pred_boxes'], eager2[0]['pred_boxes'])
 
 
+@pytest.mark.parametrize('drop', [None, 'agent_2_everywhere', 'agent_0_in_last_frame'])
+def test_hipgraph_replay_of_disconet_equals_eager(drop):
+    """DiscoNet under hipGraph.  The BEV makers' agent discovery (a host read in the reference, bev_maker.py:156, and in
+    the eager path) is decided on the device under capture; detections are bitwise those of the eager forward -- also when the replayed
+    cloud LACKS an agent the graph was captured with (the reference skips it: its maps are zeroed and leave the softmax, from device flags)
+    or an agent has no rows in one of its frames."""
+    from pcdet.models.graphed import GraphedDetector
+    g = load_golden('g1_disco.npz')
+    model = _build(g)
+    pts = torch.from_numpy(g['points']).cuda()
+    metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}]
+    gd = GraphedDetector(model, pts, 2, metadata)
+    feed = g['points'].copy()
+    if drop == 'agent_2_everywhere':
+        feed[feed[:, -1] == 2, 1:3] = 500.0                      # rows stay (the graph's shape is frozen) but leave the range ...
+        feed[feed[:, -1] == 2, -1] = 1                           # ... and belong to the ego: agent 2 holds no row
+    elif drop == 'agent_0_in_last_frame':
+        sel = (feed[:, -1] == 0) & (feed[:, 0] == 1)
+        feed[sel, -1] = 1
+    feed_t = torch.from_numpy(feed).cuda()
+    with torch.no_grad():
+        eager, _ = model({'points': feed_t.clone(), 'batch_size': 2, 'metadata': metadata})
+    for _ in range(2):
+        out = gd(feed_t)
+    torch.cuda.synchronize()
+    assert sum(e['pred_boxes'].shape[0] for e in eager) > 0
+    for b in range(2):
+        assert torch.equal(out[b]['pred_boxes'], eager[b]['pred_boxes']) and torch.equal(out[b]['pred_scores'], eager[b]['pred_scores'])
+
+
 @pytest.mark.parametrize('case', ['first_frame_empty', 'all_out_of_range', 'single_point', 'batch_of_one'])
 def test_degenerate_inputs_match_oracle(case):
     """edge cases the reference never tests: empty / ragged frames, nothing in range, one point, B = 1"""
