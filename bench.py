@@ -603,7 +603,7 @@ def main(argv=None):
         raise SystemExit('--train: use --config car | ego | early | disco')
     model = model.to(dev).eval()
     overlapped = False
-    if not args.plugin_default and not args.no_overlap and not args.graph and hasattr(model, 'overlap_makers') \
+    if not args.plugin_default and not args.no_overlap and hasattr(model, 'overlap_makers') \
             and any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
         overlapped = model.overlap_makers = True                 # frozen BEV-maker passes on their own HIP streams, joined in front of the fusion module
     if args.elide_dead_makers:

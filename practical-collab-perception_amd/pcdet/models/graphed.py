@@ -45,8 +45,13 @@ class GraphedDetector:
         bd = {'points': self.static_points, 'batch_size': self.batch_size, 'metadata': self.metadata}
         if any(type(m).__name__ == 'BEVMaker' for m in self.model.module_list):
             bd['_pcp_static_agents'] = True                  # no host read inside the capture (see the module docstring)
-        for m in self.model.module_list:
-            bd = m(bd)
+        if hasattr(self.model, '_run_modules'):
+            # the detector's own runner: the frozen BEV-maker passes on their own streams (forked from / joined to the capturing stream by
+            # events, so they become parallel branches of the graph) and one pillar list for the two VFEs that see the same cloud
+            bd = self.model._run_modules(bd)
+        else:
+            for m in self.model.module_list:
+                bd = m(bd)
         self._last = bd
         return bd['_pcp_pending_head']
 

@@ -420,15 +420,17 @@ def test_hipgraph_replay_equals_eager(tag):
     assert torch.equal(out2[0]['pred_boxes'], eager2[0]['pred_boxes'])
 
 
-@pytest.mark.parametrize('drop', [None, 'agent_2_everywhere', 'agent_0_in_last_frame'])
-def test_hipgraph_replay_of_disconet_equals_eager(drop):
+@pytest.mark.parametrize('drop,overlap', [(None, False), (None, True), ('agent_2_everywhere', True), ('agent_0_in_last_frame', False)])
+def test_hipgraph_replay_of_disconet_equals_eager(drop, overlap):
     """DiscoNet under hipGraph.  The BEV makers' agent discovery (a host read in the reference, bev_maker.py:156, and in
     the eager path) is decided on the device under capture; detections are bitwise those of the eager forward -- also when the replayed
     cloud LACKS an agent the graph was captured with (the reference skips it: its maps are zeroed and leave the softmax, from device flags)
-    or an agent has no rows in one of its frames."""
+    or an agent has no rows in one of its frames.  overlap: the BEV-maker passes on their own streams (CenterPoint.overlap_makers) are
+    captured as parallel branches of the graph (what bench.py --graph measures)."""
     from pcdet.models.graphed import GraphedDetector
     g = load_golden('g1_disco.npz')
     model = _build(g)
+    model.overlap_makers = overlap
     pts = torch.from_numpy(g['points']).cuda()
     metadata = [{'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}, {'se3_from_ego': {0: g['pose_0'], 2: g['pose_2']}}]
     gd = GraphedDetector(model, pts, 2, metadata)
