@@ -464,7 +464,7 @@ class AbiTimer:
         return out
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json')
+PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', 'r05_pmc_traffic.json')
 
 
 def pmc_traffic(config, kernel_label):
@@ -860,6 +860,10 @@ def main(argv=None):
         traffic, traffic_note = pmc_traffic(args.config, dom['kernel']) if (algo == 'auto' and not args.train) else (None, 'not collected for this mode')
         roof.update({'traffic': traffic, **({'traffic_note': traffic_note} if traffic_note else {}),
                      'avg_launch_us': round(1e3 * dom['ms'] / max(dom['launches'], 1), 2),
+                     'measured_in': 'the instrumented pass of this run: every launch between two HIP events on ONE stream, batch by batch (no '
+                                    'maker overlap, no batch pipelining) -- compare with the rocprofv3 summary of `bench.py --no-overlap '
+                                    '--no-pipeline` (profiles/r05_bench_disco_b4_single_stream_kernel_stats.csv), not with the overlapped run '
+                                    '(profiles/r05_bench_disco_b4_overlapped_kernel_stats.csv), whose kernels share the chip',
                      'launches_per_step': round(dom['launches_per_step'], 2),
                      'share_of_kernel_time': round(dom['ms'] / max(sum(f['ms'] for f in fams), 1e-9), 4)})
         mf = [f for f in fams if f['bound'] == 'mfma']

@@ -94,7 +94,9 @@ int pcp_pfn_scatter(const float *points, int64_t n, int32_t row_stride, int32_t 
  * descriptor per wave tile of pcp_pfn_rows.  Workspace: pcp_pillarise_rows_workspace_bytes (its front part is laid out as
  * pcp_voxelize lays it out: pcp_sparse_conv3x3_s2 and the training kernels read it unchanged).  flags: PCP_ROWS_CELLS_READY = the
  * rows' cell ids and histogram are already in the workspace (pcp_select_transform_compact with vox_grid; no unq_inv then),
- * PCP_ROWS_BUCKET_ORDER = also leave the bucket order (row indices grouped by pillar) for pcp_voxelize_row_order / the training path.
+ * PCP_ROWS_BUCKET_ORDER = also leave the bucket order (row indices grouped by pillar, pillars ascending) for pcp_voxelize_row_order; without
+ * it the records of single-point pillars lie behind those of all multi-point pillars (counters[2], [3] = records of multi-point pillars,
+ * single-point pillars; pcp_pfn_rows runs the singles through a path without per-pillar reductions).
  * pcp_pfn_rows: the fused feature build + PFN x2 + scatter of pcp_pfn_scatter on those records; one WAVE per ~30-point run of pillars,
  * no workgroup barriers, both layers on fp32 MFMA with the weights as the A operand.  canvas (B, ny, nx, 64): written COMPLETELY --
  * pillar rows and zero rows for the empty cells -- so it needs no zero fill and no pcp_canvas_clear; pillar_features (P, 64) or NULL.

@@ -463,7 +463,10 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
       PCP_CHECK_LAUNCH();
     }
   }
-  if (rows_raw) {
+  // Rows mode sets the single-point pillars apart (pcp_pfn_rows runs them without per-pillar reductions) -- unless the caller also wants the
+  // bucket order: its consumer (HunterJr's point head) walks it for the spatial locality of its BEV gathers, and two interleaved sweeps over
+  // the map (multi-point pillars, then singles) cost that kernel 15 % (measured on configs 1 - 3) where the PFN gains a third of that.
+  if (rows_raw && !want_bucket_order) {
     hipLaunchKernelGGL(k_cell_tile_sums<true>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, sc.tile_sums,
                        sc.tile_singles);
     PCP_CHECK_LAUNCH();

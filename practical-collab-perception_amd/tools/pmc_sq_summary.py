@@ -6,7 +6,7 @@ import json
 import sys
 from collections import defaultdict
 
-KEYS = [('k_wino4f', 'k_wino4f'), ('k_wino4h', 'k_wino4h'), ('k_wino4c', 'k_wino4c'), ('k_wgrad3x3<', 'k_wgrad3x3'), ('k_conv3x3<2,', 'k_conv3x3_direct<s2>'), ('k_pfn<', 'k_pfn'), ('k_sparse_conv_s2', 'k_sparse_conv_s2'),
+KEYS = [('k_wino4f', 'k_wino4f'), ('k_wino4h', 'k_wino4h'), ('k_wino4c', 'k_wino4c'), ('k_wgrad3x3<', 'k_wgrad3x3'), ('k_conv3x3<2,', 'k_conv3x3_direct<s2>'), ('k_pfn_rows', 'k_pfn_rows'), ('k_pfn<', 'k_pfn'), ('k_sparse_conv_s2', 'k_sparse_conv_s2'), ('k_cell_finish', 'k_cell_finish'), ('k_point_place', 'k_point_place'),
         ('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_w4_gemm', 'k_w4_gemm'), ('k_weight_fuse', 'k_weight_fuse'),
         ('k_stc_scatter', 'k_stc_scatter'), ('k_point_finish', 'k_point_finish'), ('k_point_cells', 'k_point_cells')]
 

@@ -13,7 +13,7 @@ from collections import defaultdict
 SOURCES = {'k_wino4f': 'wino4f.hip', 'k_wino4h': 'wino4h.hip', 'k_wino4c': 'wino4c.hip', 'k_conv3x3_wino<1>': 'wino.hip', 'k_conv3x3_wino<2>': 'wino.hip', 'k_wino_ws': 'wino_ws.hip',
            'k_w4_gemm': 'wino4.hip', 'k_w4_input': 'wino4.hip', 'k_w4_output': 'wino4.hip', 'k_conv3x3_direct<s1>': 'conv.hip',
            'k_conv3x3_direct<s2>': 'conv.hip', 'k_pointwise<plain>': 'conv.hip', 'k_pointwise<conv_k2s2>': 'conv.hip',
-           'k_pointwise<convT_k2s2>': 'conv.hip', 'k_pfn': 'pfn.hip', 'k_sparse_conv_s2': 'sparseconv.hip', 'k_point_head': 'pointhead.hip',
+           'k_pointwise<convT_k2s2>': 'conv.hip', 'k_pfn': 'pfn.hip', 'k_pfn_rows': 'pfn_rows.hip', 'k_point_cells': 'voxelize.hip', 'k_cell_finish': 'voxelize.hip', 'k_point_place': 'voxelize.hip', 'k_stc_scatter': 'voxelize.hip', 'k_sparse_conv_s2': 'sparseconv.hip', 'k_point_head': 'pointhead.hip',
            'k_head_grouped': 'headconv.hip'}
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc')
 
@@ -33,7 +33,8 @@ KEYS = [('k_conv3x3_wino<1>', 'k_conv3x3_wino<1>'), ('k_conv3x3_wino<2>', 'k_con
         ('k_w4_gemm', 'k_w4_gemm'), ('k_w4_input', 'k_w4_input'), ('k_w4_output', 'k_w4_output'),
         ('k_conv3x3<1,', 'k_conv3x3_direct<s1>'), ('k_conv3x3<2,', 'k_conv3x3_direct<s2>'),
         ('k_pointwise<0', 'k_pointwise<plain>'), ('k_pointwise<1', 'k_pointwise<conv_k2s2>'), ('k_pointwise<2', 'k_pointwise<convT_k2s2>'),
-        ('k_pfn<', 'k_pfn'), ('k_sparse_conv_s2', 'k_sparse_conv_s2'), ('k_point_head', 'k_point_head'), ('k_head_grouped', 'k_head_grouped')]
+        ('k_pfn_rows', 'k_pfn_rows'), ('k_pfn<', 'k_pfn'), ('k_point_cells', 'k_point_cells'), ('k_cell_finish', 'k_cell_finish'), ('k_point_place', 'k_point_place'),
+        ('k_stc_scatter', 'k_stc_scatter'), ('k_sparse_conv_s2', 'k_sparse_conv_s2'), ('k_point_head', 'k_point_head'), ('k_head_grouped', 'k_head_grouped')]
 
 
 def collect(path, counter):

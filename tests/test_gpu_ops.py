@@ -196,7 +196,7 @@ def test_pillarise_rows_bit_exact(case):
         pts[:, 3] = -1.0
     ref = opil.voxelize(pts, 5, PC_RANGE, VOXEL, GRID) if pts.shape[0] else None
     g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
-    res = ops.pillarise_rows(torch.from_numpy(pts).to(dev()), g, 5, want_inverse=True, want_counts=True, want_coords=True, bucket_order=True)
+    res = ops.pillarise_rows(torch.from_numpy(pts).to(dev()), g, 5, want_inverse=True, want_counts=True, want_coords=True)
     torch.cuda.synchronize()
     P, Nv = [int(v) for v in res.counters[:2].cpu()]
     if ref is None:
@@ -229,6 +229,28 @@ def test_pillarise_rows_bit_exact(case):
     a = np.concatenate([src[keep].view(np.int32), ref['inv'][:, None].astype(np.int32)], 1)
     b = np.concatenate([rows[:, :5].numpy().view(np.int32), rank[:, None]], 1)
     assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+
+
+def test_pillarise_rows_with_bucket_order_keeps_the_plain_pillar_order():
+    """PCP_ROWS_BUCKET_ORDER (HunterJr's configs): records and bucket order in pillar-rank order, single-point pillars NOT set apart (the
+    point head walks that order for the locality of its BEV gathers); the row order derived from it is a permutation of all rows"""
+    ops = _ops()
+    pts = synth.collate([synth.agent_cloud(1, 5000, 'car'), synth.agent_cloud(3, 30001, 'car', dist='ring')])
+    ref = opil.voxelize(pts, 5, PC_RANGE, VOXEL, GRID)
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, 2)
+    res = ops.pillarise_rows(torch.from_numpy(pts).to(dev()), g, 5, bucket_order=True)
+    torch.cuda.synchronize()
+    P, Nv, Nm, S = [int(v) for v in res.counters.cpu()]
+    assert (P, Nv) == (ref['unq'].shape[0], ref['inv'].shape[0]) and (Nm, S) == (0, 0) and res.has_bucket_order
+    import ctypes
+    L = __import__('pcp_amd.lib', fromlist=['lib']).load()
+    front = L.pcp_voxelize_workspace_bytes(ctypes.byref(g), pts.shape[0])
+    rows = res.workspace[front:front + pts.shape[0] * 32].view(torch.float32).view(-1, 8)[:Nv].cpu()
+    assert np.array_equal(rows[:, 5].view(torch.int32).numpy(), np.repeat(np.arange(P), ref['cnt']))
+    order = ops.voxelize_row_order(res).cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(pts.shape[0]))
+    kept = np.nonzero(ref['keep'])[0]
+    assert np.array_equal(np.sort(order[:Nv]), kept) and np.array_equal(ref['inv'][np.searchsorted(kept, order[:Nv])], np.repeat(np.arange(P), ref['cnt']))
 
 
 def _crowded_cloud(num_cols=8):
