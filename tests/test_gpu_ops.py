@@ -1059,6 +1059,27 @@ def test_decode_bbox_from_heatmap_adapter_equals_the_reference(fixture):
         assert bool(np.isin(gs, hm[b].reshape(-1).cpu().numpy()).all())
         assert_same_final_set(rb, rs, gb, gs, tol=1e-5)
         assert bool((out[b]['pred_labels'] == 0).all())
+    # the `vel` branch (reference :174-176, heads of the nuScenes CenterPoint configs): two more columns, gathered at the cell of each box --
+    # with vel := (column, row) index maps they must reproduce the cell the box centre was decoded from
+    Hh, Ww = hm.shape[2], hm.shape[3]
+    vel = torch.stack([torch.arange(Ww, device=d).float().view(1, 1, Ww).expand(2, Hh, Ww), torch.arange(Hh, device=d).float().view(1, Hh, 1).expand(2, Hh, Ww)], 1)
+    out9 = centernet_utils.decode_bbox_from_heatmap(
+        heatmap=hm, rot_cos=rot[:, 0:1], rot_sin=rot[:, 1:2], center=torch.from_numpy(g['head_center']).to(d),
+        center_z=torch.from_numpy(g['head_center_z']).to(d), dim=dim, point_cloud_range=g['meta']['pc_range'], voxel_size=g['meta']['voxel_size'],
+        feature_map_stride=g['meta']['model']['DENSE_HEAD']['TARGET_ASSIGNER_CONFIG']['FEATURE_MAP_STRIDE'], K=pp['MAX_OBJ_PER_SAMPLE'], vel=vel,
+        circle_nms=False, score_thresh=pp['SCORE_THRESH'], post_center_limit_range=torch.tensor(pp['POST_CENTER_LIMIT_RANGE']))
+    stride, vs, pr = g['meta']['model']['DENSE_HEAD']['TARGET_ASSIGNER_CONFIG']['FEATURE_MAP_STRIDE'], g['meta']['voxel_size'], g['meta']['pc_range']
+    ctr = torch.from_numpy(g['head_center']).to(d)
+    for b in range(2):
+        bx = out9[b]['pred_boxes']
+        assert bx.shape[1] == 9 and torch.equal(bx[:, :7], out[b]['pred_boxes'])
+        col, row = bx[:, 7].long(), bx[:, 8].long()
+        x_back = (col.float() + ctr[b, 0, row, col]) * stride * vs[0] + pr[0]
+        assert float((x_back - bx[:, 0]).abs().max()) < 1e-4
+    with pytest.raises(AssertionError):                           # the reference's own `assert False, 'not checked yet'` (:158-160)
+        centernet_utils.decode_bbox_from_heatmap(heatmap=hm, rot_cos=rot[:, 0:1], rot_sin=rot[:, 1:2], center=ctr, center_z=ctr[:, :1], dim=dim,
+                                                 point_cloud_range=pr, voxel_size=vs, feature_map_stride=stride, K=10, circle_nms=True,
+                                                 post_center_limit_range=torch.tensor(pp['POST_CENTER_LIMIT_RANGE']))
 
 
 @pytest.mark.parametrize('pixels,n_maps', [(64, 1), (1000, 3), (4096 + 17, 6), (200, 8)])
