@@ -110,6 +110,19 @@ int pcp_pillarise_rows(const float *points, int64_t n, int32_t row_stride, int32
 int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
                  const float *w1, const float *b1, float *pillar_features, float *canvas, void *stream);
 
+/* The PillarFeatureNet variants none of the reference's configs use (WITH_DISTANCE, USE_ABSLOTE_XYZ False, NUM_FILTERS other than
+ * [64, 64], any raw width) run as separate steps: pcp_voxelize, then
+ * pcp_pfn_features: the feature rows of dynamic_pillar_vfe.py:110-126 in BUCKET ORDER, `fw` floats per row (zero padded), composition by
+ *   flags: [points[:, 1:] or points[:, 4:], f_cluster, f_center, |xyz| if PCP_PFN_WITH_DISTANCE]; slot_pillar[s] = pillar rank of slot s;
+ * then per PFNLayerV2 (:35-46) pcp_pointwise (Linear + folded BatchNorm + ReLU), pcp_segment_max (torch_scatter.scatter_max) and, for all
+ * but the last layer, pcp_pfn_cat_pillar_max: out[r] = [y[r, :c], pillar_max[slot_pillar[r], :c], 0 ...]. */
+#define PCP_PFN_ABSOLUTE_XYZ 1u
+#define PCP_PFN_WITH_DISTANCE 2u
+int pcp_pfn_features(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, uint32_t flags, const pcp_grid_t *grid,
+                     const void *vox_workspace, int32_t fw, float *fbuf, int32_t *slot_pillar, void *stream);
+int pcp_pfn_cat_pillar_max(const float *y, int32_t ld_y, const float *pillar_max, int32_t ld_max, const int32_t *slot_pillar, int64_t rows,
+                           int32_t c, float *out, int32_t ld_out, void *stream);
+
 /* zero the canvas rows written by an earlier pcp_pfn_scatter (reads the pillar list still held in that call's
  * workspace; n = the point count of that call): P * 256 B instead of re-zeroing B * ny * nx * 256 B */
 int pcp_canvas_clear(const pcp_grid_t *grid, const void *workspace, int64_t n, float *canvas, void *stream);

@@ -51,8 +51,9 @@ def pillar_mean(xyz, inv, num_pillars):
     return acc / np.maximum(cnt, F32(1.0))[:, None]
 
 
-def point_features(points, num_raw, vox, pc_range, voxel_size):
-    """dynamic_pillar_vfe.py:110-126 -> (N', num_raw + 6) float32 = [raw (x,y,z,...), f_cluster(3), f_center(3)]."""
+def point_features(points, num_raw, vox, pc_range, voxel_size, use_absolute_xyz=True, with_distance=False):
+    """dynamic_pillar_vfe.py:110-126 -> (N', F) float32 = [raw (x,y,z,...) or raw[3:] (:117-120), f_cluster(3), f_center(3),
+    |xyz| if with_distance (:122-124)]."""
     pts = np.ascontiguousarray(points[:, :1 + num_raw], dtype=F32)[vox['keep']]
     xyz = pts[:, 1:4]
     mean = pillar_mean(xyz, vox['inv'], vox['unq'].shape[0])
@@ -66,7 +67,10 @@ def point_features(points, num_raw, vox, pc_range, voxel_size):
     f_center[:, 0] = xyz[:, 0] - (vox['cell_xy'][:, 0].astype(F32) * vx + x_off)
     f_center[:, 1] = xyz[:, 1] - (vox['cell_xy'][:, 1].astype(F32) * vy + y_off)
     f_center[:, 2] = xyz[:, 2] - z_off
-    return np.concatenate([pts[:, 1:], f_cluster, f_center], axis=1).astype(F32), mean
+    parts = [pts[:, 1:] if use_absolute_xyz else pts[:, 4:], f_cluster, f_center]
+    if with_distance:
+        parts.append(np.sqrt((xyz * xyz).sum(axis=1, dtype=F32), dtype=F32)[:, None])
+    return np.concatenate(parts, axis=1).astype(F32), mean
 
 
 def _bn_eval(x, st, prefix, eps):
@@ -78,13 +82,16 @@ def _bn_eval(x, st, prefix, eps):
 
 
 def pfn(features, inv, num_pillars, st, prefix='vfe', num_layers=2, eps=1e-3):
-    """PFNLayerV2 x num_layers (dynamic_pillar_vfe.py:35-46): Linear(no bias) -> BN1d(eval, eps 1e-3) -> ReLU ->
+    """PFNLayerV2 x num_layers (dynamic_pillar_vfe.py:35-46): Linear(no bias) -> BN1d(eval, eps 1e-3) [or Linear with bias] -> ReLU ->
     per-pillar max; non-last layers concatenate [x, x_max[inv]]."""
     x = features
     for li in range(num_layers):
         w = st['%s.pfn_layers.%d.linear.weight' % (prefix, li)].astype(F32)
         y = x @ w.T
-        y = _bn_eval(y, st, '%s.pfn_layers.%d.norm' % (prefix, li), eps)
+        if '%s.pfn_layers.%d.norm.weight' % (prefix, li) in st:
+            y = _bn_eval(y, st, '%s.pfn_layers.%d.norm' % (prefix, li), eps)
+        else:                                       # USE_NORM False: Linear keeps its bias (:26-32)
+            y = y + st['%s.pfn_layers.%d.linear.bias' % (prefix, li)].astype(F32)[None, :]
         y = np.maximum(y, F32(0))
         ymax = np.full((num_pillars, y.shape[1]), -np.inf, dtype=F32)
         np.maximum.at(ymax, inv, y)
@@ -107,7 +114,8 @@ def vfe_forward(points, st, arch, prefix='vfe'):
     """a1-a5 in one call.  Returns dict(vox, features, pillar_features, spatial_features)."""
     nr = arch['num_raw']
     vox = voxelize(points, nr, arch['pc_range'], arch['voxel_size'], arch['grid_size'])
-    feats, mean = point_features(points, nr, vox, arch['pc_range'], arch['voxel_size'])
+    feats, mean = point_features(points, nr, vox, arch['pc_range'], arch['voxel_size'], arch.get('use_absolute_xyz', True),
+                                 arch.get('with_distance', False))
     pf = pfn(feats, vox['inv'], vox['unq'].shape[0], st, prefix=prefix, num_layers=len(arch['vfe_filters']))
     bs = int(vox['coords'][:, 0].max()) + 1 if vox['coords'].shape[0] else 1
     canvas = scatter_to_bev(pf, vox['coords'], bs, int(arch['grid_size'][0]), int(arch['grid_size'][1]))

@@ -100,6 +100,85 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_feat(FeatParams p) {
   }
 }
 
+// The PillarFeatureNet variants no config of the reference uses (WITH_DISTANCE, USE_ABSLOTE_XYZ False, any raw width): the same feature
+// rows with the composition decided at run time (dynamic_pillar_vfe.py:117-126).  `fw` floats per row, zero padded.
+struct FeatAnyParams {
+  FeatParams b;
+  int num_raw, use_abs, with_dist, fw;
+};
+
+__global__ __launch_bounds__(PT_THREADS) void k_pfn_feat_any(FeatAnyParams q) {
+  const FeatParams &p = q.b;
+  __shared__ int pl_start[PT_PILLARS + 1];
+  __shared__ long long sum_fx[PT_PILLARS][3];
+  __shared__ float mean[PT_PILLARS][3];
+  const int P = p.counters[0];
+  const int r0 = blockIdx.x * PT_PILLARS;
+  if (r0 >= P) return;
+  const int np = min(PT_PILLARS, P - r0);
+  const int tid = threadIdx.x;
+  for (int i = tid; i <= np; i += PT_THREADS) pl_start[i] = p.pillar_start[r0 + i];
+  for (int i = tid; i < PT_PILLARS * 3; i += PT_THREADS) (&sum_fx[0][0])[i] = 0;
+  __syncthreads();
+  const int s0 = pl_start[0], s1 = pl_start[np];
+  for (int s = s0 + tid; s < s1; s += PT_THREADS) {
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+    const int pl = find_pillar(pl_start, np, s);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const long long v = __double2ll_rn((double)row[1 + a] * 16777216.0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sum_fx[pl][a]), (unsigned long long)v);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < np * 3; i += PT_THREADS) {
+    const int pl = i / 3, a = i % 3;
+    const int cnt = pl_start[pl + 1] - pl_start[pl];
+    mean[pl][a] = (float)(((double)sum_fx[pl][a] * (1.0 / 16777216.0)) / (double)cnt);
+  }
+  __syncthreads();
+  const int plane = p.g.nx * p.g.ny;
+  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
+  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
+  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
+  const int first = q.use_abs ? 0 : 3;            // points[:, 1:] or points[:, 4:]
+  const int nlead = q.num_raw - first;
+  for (int s = s0 + tid; s < s1; s += PT_THREADS) {
+    const int pl = find_pillar(pl_start, np, s);
+    const float *row = p.points + (long long)p.bucket_order[s] * p.stride;
+    float *o = p.fbuf + (long long)s * q.fw;
+    const float x = row[1], y = row[2], z = row[3];
+    for (int k = 0; k < nlead; k++) o[k] = row[1 + first + k];
+    const int rem = p.pillar_cell[r0 + pl] % plane;
+    const float cx = (float)(rem / p.g.ny), cy = (float)(rem % p.g.ny);
+    o[nlead + 0] = __fsub_rn(x, mean[pl][0]);
+    o[nlead + 1] = __fsub_rn(y, mean[pl][1]);
+    o[nlead + 2] = __fsub_rn(z, mean[pl][2]);
+    o[nlead + 3] = __fsub_rn(x, __fadd_rn(__fmul_rn(cx, p.g.voxel_x), x_off));
+    o[nlead + 4] = __fsub_rn(y, __fadd_rn(__fmul_rn(cy, p.g.voxel_y), y_off));
+    o[nlead + 5] = __fsub_rn(z, z_off);
+    int k = nlead + 6;
+    if (q.with_dist) o[k++] = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    for (; k < q.fw; k++) o[k] = 0.f;
+    p.slot_pillar[s] = r0 + pl;
+  }
+}
+
+// in_next[r] = [y[r, :c], pillar_max[slot_pillar[r], :c], 0...]: the concat at the end of a non-last PFNLayerV2 (dynamic_pillar_vfe.py:44-46)
+__global__ __launch_bounds__(PT_THREADS) void k_pfn_cat_pillar_max(const float *__restrict__ y, int ld_y, const float *__restrict__ pmax, int ld_max,
+                                                                   const int *__restrict__ slot_pillar, long long rows, int c,
+                                                                   float *__restrict__ out, int ld_out) {
+  const long long total = rows * ld_out;
+  for (long long i = (long long)blockIdx.x * PT_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * PT_THREADS) {
+    const long long r = i / ld_out;
+    const int k = (int)(i - r * ld_out);
+    float v = 0.f;
+    if (k < c) v = y[r * ld_y + k];
+    else if (k < 2 * c) v = pmax[(long long)slot_pillar[r] * ld_max + (k - c)];
+    out[i] = v;
+  }
+}
+
 // The four routing kernels: a SUB-GROUP of lanes per pillar (8 lanes x 4 channels for the 32-channel rows, 16 lanes x 4 channels for the
 // 64-channel rows), so a wave works on 8 / 4 pillars at once with 16-byte accesses; a pillar's rows (two on average) are walked in bucket
 // order by its own lanes, no cross-lane traffic.  (Rounds 1-3 gave a whole wave to a pillar: 64 lanes x 4 bytes per row and one pillar's
@@ -414,6 +493,39 @@ int pcp_mp_pfn_train_route_mid_grad(const pcp_grid_t *grid, const void *vox_work
                                     const int32_t *arg0, float *da0, void *stream) {
   if (din1_dtype != 0 && din1_dtype != 1) return PCP_ERR_ARG;
   return pfn_route_mid_impl(grid, vox_workspace, n, din1, din1_dtype, arg0, da0, stream);
+}
+
+int pcp_pfn_features(const float *points, int64_t n, int32_t row_stride, int32_t num_raw, uint32_t flags, const pcp_grid_t *grid,
+                     const void *vox_workspace, int32_t fw, float *fbuf, int32_t *slot_pillar, void *stream) {
+  if (!points || !grid || !vox_workspace || !fbuf || !slot_pillar || n < 0 || row_stride < 1 + num_raw || num_raw < 3) return PCP_ERR_ARG;
+  if (flags & ~(PCP_PFN_ABSOLUTE_XYZ | PCP_PFN_WITH_DISTANCE)) return PCP_ERR_ARG;
+  const int use_abs = (flags & PCP_PFN_ABSOLUTE_XYZ) ? 1 : 0, with_dist = (flags & PCP_PFN_WITH_DISTANCE) ? 1 : 0;
+  if (fw < num_raw - (use_abs ? 0 : 3) + 6 + with_dist) return PCP_ERR_ARG;
+  if (n == 0) return PCP_OK;
+  const WsView v = view_ws(vox_workspace, grid, n);
+  FeatAnyParams q;
+  q.b.points = points; q.b.stride = row_stride; q.b.g = *grid;
+  q.b.bucket_order = v.bucket_order; q.b.pillar_cell = v.pillar_cell; q.b.pillar_start = v.pillar_start; q.b.counters = v.counters;
+  q.b.fbuf = fbuf; q.b.slot_pillar = slot_pillar;
+  q.num_raw = num_raw; q.use_abs = use_abs; q.with_dist = with_dist; q.fw = fw;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  const int64_t max_pillars = n < cells ? n : cells;
+  const int blocks = (int)((max_pillars + PT_PILLARS - 1) / PT_PILLARS);
+  hipLaunchKernelGGL(k_pfn_feat_any, dim3(blocks), dim3(PT_THREADS), 0, (hipStream_t)stream, q);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+int pcp_pfn_cat_pillar_max(const float *y, int32_t ld_y, const float *pillar_max, int32_t ld_max, const int32_t *slot_pillar, int64_t rows,
+                           int32_t c, float *out, int32_t ld_out, void *stream) {
+  if (!y || !pillar_max || !slot_pillar || !out || rows < 0 || c < 1 || ld_y < c || ld_max < c || ld_out < 2 * c) return PCP_ERR_ARG;
+  if (rows == 0) return PCP_OK;
+  int64_t blocks = (rows * ld_out + PT_THREADS - 1) / PT_THREADS;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_pfn_cat_pillar_max, dim3((unsigned)blocks), dim3(PT_THREADS), 0, (hipStream_t)stream, y, ld_y, pillar_max, ld_max,
+                     slot_pillar, (long long)rows, c, out, ld_out);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
 }
 
 }  // extern "C"

@@ -47,14 +47,15 @@ class DynamicPillarVFE(VFETemplate):
         self.use_norm = self.model_cfg.USE_NORM
         self.with_distance = self.model_cfg.WITH_DISTANCE
         self.use_absolute_xyz = self.model_cfg.USE_ABSLOTE_XYZ
-        if self.with_distance or not self.use_absolute_xyz:
-            raise NotImplementedError('the fused PFN kernel covers USE_ABSLOTE_XYZ=True, WITH_DISTANCE=False (all five configs)')
-        if num_point_features not in (3, 4, 5, 11):
-            raise NotImplementedError('the fused PFN kernel is built for 3, 4, 5 or 11 raw point features (all five configs use 5 or 11)')
-        in_dim = num_point_features + 6
         self.num_filters = list(self.model_cfg.NUM_FILTERS)
-        if self.num_filters != [64, 64]:
-            raise NotImplementedError('the fused PFN kernel is built for NUM_FILTERS [64, 64] (all five configs)')
+        assert len(self.num_filters) > 0
+        in_dim = num_point_features + (6 if self.use_absolute_xyz else 3) + (1 if self.with_distance else 0)
+        # the one-launch PFN (pcp_pfn_rows) is built for the composition all five configs use; any other runs layer by layer
+        # (_forward_layers: pcp_pfn_features + pcp_pointwise + pcp_segment_max per PFNLayerV2)
+        self.fused = (self.use_absolute_xyz and not self.with_distance and self.num_filters == [64, 64]
+                      and num_point_features in (3, 4, 5, 11))
+        if num_point_features < 3:
+            raise NotImplementedError('a point row holds at least x, y, z')
         dims = [in_dim] + self.num_filters
         self.pfn_layers = nn.ModuleList([
             PFNLayerV2(dims[i], dims[i + 1], self.use_norm, last_layer=(i >= len(dims) - 2)) for i in range(len(dims) - 1)])
@@ -77,6 +78,9 @@ class DynamicPillarVFE(VFETemplate):
         self._workspace = None
 
     def _forward_train(self, batch_dict):
+        if not self.fused:
+            raise NotImplementedError('the HIP training path covers the PillarFeatureNet of the five configs (USE_ABSLOTE_XYZ, no '
+                                      'WITH_DISTANCE, NUM_FILTERS [64, 64]); this variant has inference kernels only')
         from ...train_path import VFETrain
         if getattr(self, '_pcp_train', None) is None:
             self._pcp_train = VFETrain(self)
@@ -89,6 +93,18 @@ class DynamicPillarVFE(VFETemplate):
         return self.num_filters[-1]
 
     def _build_packed(self):
+        if not self.fused:
+            layers = []
+            cin_pad = (self.pfn_layers[0].linear.in_features + 15) // 16 * 16
+            for layer in self.pfn_layers:
+                w, b = layer.folded()
+                cout = w.shape[0]
+                wp = torch.zeros((cout, cin_pad), dtype=torch.float32, device=w.device)
+                wp[:, :w.shape[1]] = w
+                packed, bias, cout_pad = pack.pack_plain(wp, b)
+                layers.append(dict(w=packed.contiguous(), b=bias.contiguous(), cin=cin_pad, cout=cout, cout_pad=cout_pad))
+                cin_pad = (2 * cout + 15) // 16 * 16
+            return dict(layers=layers)
         w0, b0 = self.pfn_layers[0].folded()
         w1, b1 = self.pfn_layers[1].folded()
         return dict(w0=w0.contiguous(), b0=b0.contiguous(), w1=w1.contiguous(), b1=b1.contiguous())
@@ -132,6 +148,29 @@ class DynamicPillarVFE(VFETemplate):
         share[key] = (vox, cur.record_event())
         return vox
 
+    def _forward_layers(self, batch_dict, points, grid):
+        """any PillarFeatureNet composition, one PFNLayerV2 at a time (reference :110-147); publishes pillar_features / voxel_coords like
+        the reference, PointPillarScatter writes the canvas from them"""
+        from pcp_amd import lib as _lib, train_ops as tops
+        nr = self.num_raw_point_features
+        vox = ops.voxelize(points, grid, want_inverse=False, want_counts=False)
+        num_pillars, rows = (int(v) for v in vox.counters[:2].tolist())
+        if rows == 0:
+            batch_dict['voxel_features'] = batch_dict['pillar_features'] = points.new_zeros((0, self.num_filters[-1]))
+            batch_dict['voxel_coords'] = vox.voxel_coords[:0]
+            return batch_dict
+        x, slot_pillar, _ = ops.pfn_features(points, vox, nr, self.use_absolute_xyz, self.with_distance)
+        layers = self.packed()['layers']
+        for i, lw in enumerate(layers):
+            y = ops.pointwise(x[:rows], lw['w'], lw['b'], _lib.PW_PLAIN, lw['cin'], lw['cout'], lw['cout_pad'], relu=True)
+            y_max, _ = tops.segment_max(y, slot_pillar, num_pillars, lw['cout'], rows=rows)
+            if i == len(layers) - 1:
+                break
+            x = ops.pfn_cat_pillar_max(y, y_max, slot_pillar, rows, lw['cout'])
+        batch_dict['voxel_features'] = batch_dict['pillar_features'] = y_max
+        batch_dict['voxel_coords'] = vox.voxel_coords[:num_pillars]
+        return batch_dict
+
     def forward(self, batch_dict, **kwargs):
         if self.training:
             return self._forward_train(batch_dict)
@@ -142,6 +181,8 @@ class DynamicPillarVFE(VFETemplate):
         if batch_size is None:                      # BEVMaker-style sub dicts carry only 'points' (bev_maker.py:196)
             batch_size = int(points[:, 0].max().item()) + 1 if points.shape[0] else 1
         grid = ops.make_grid(self.point_cloud_range, self.voxel_size, self.grid_size, batch_size)
+        if not self.fused:
+            return self._forward_layers(batch_dict, points, grid)
         pk = self.packed()
         dev = points.device
         nx, ny = self.grid_size[0], self.grid_size[1]

@@ -145,6 +145,8 @@ SYMBOLS = {
     'pcp_pillarise_rows_workspace_bytes': (c_sz, [ctypes.POINTER(Grid), c_i64, c_i32]),
     'pcp_pillarise_rows': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, c_sz, vp, vp, vp, vp, c_i32, vp]),
     'pcp_pfn_rows': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, c_i32, vp, vp, vp, vp, vp, vp, vp]),
+    'pcp_pfn_features': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.c_uint32, ctypes.POINTER(Grid), vp, c_i32, vp, vp, vp]),
+    'pcp_pfn_cat_pillar_max': (c_i32, [vp, c_i32, vp, c_i32, vp, c_i64, c_i32, vp, c_i32, vp]),
     'pcp_canvas_clear': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, vp, vp]),
     'pcp_fill_zero': (c_i32, [vp, c_sz, vp]),
     'pcp_conv3x3': (c_i32, [ctypes.POINTER(Conv3x3), vp, vp, vp, vp, vp]),

@@ -195,6 +195,34 @@ def pfn_rows(vox, w0, b0, w1, b1, canvas=None, pillar_features=None):
                          _p(canvas), _stream()), 'pcp_pfn_rows')
 
 
+def pfn_features(points, vox, num_raw, use_absolute_xyz=True, with_distance=False):
+    """feature rows of dynamic_pillar_vfe.py:110-126 in the bucket order `voxelize` left in vox.workspace, composition chosen at run time.
+    Returns (fbuf (N, fw) zero padded to a multiple of 16 floats, slot_pillar (N,) int32, true width)."""
+    _need_cuda(points)
+    L = _lib.load()
+    assert vox.has_bucket_order and points.dtype == torch.float32 and points.is_contiguous()
+    f = num_raw - (0 if use_absolute_xyz else 3) + 6 + (1 if with_distance else 0)
+    fw = (f + 15) // 16 * 16
+    rows = max(vox.n, 1)
+    fbuf = torch.empty((rows, fw), dtype=torch.float32, device=points.device)
+    slot_pillar = torch.empty((rows,), dtype=torch.int32, device=points.device)
+    flags = (1 if use_absolute_xyz else 0) | (2 if with_distance else 0)
+    check(L.pcp_pfn_features(_p(points), vox.n, vox.row_stride, num_raw, flags, ctypes.byref(vox.grid), _p(vox.workspace), fw, _p(fbuf),
+                             _p(slot_pillar), _stream()), 'pcp_pfn_features')
+    return fbuf, slot_pillar, f
+
+
+def pfn_cat_pillar_max(y, pillar_max, slot_pillar, rows, c):
+    """[y[:, :c], pillar_max[slot_pillar, :c]] padded with zeros to a multiple of 16 floats: the input rows of the next PFNLayerV2"""
+    _need_cuda(y, pillar_max, slot_pillar)
+    L = _lib.load()
+    ld_out = (2 * c + 15) // 16 * 16
+    out = torch.empty((max(rows, 1), ld_out), dtype=torch.float32, device=y.device)
+    check(L.pcp_pfn_cat_pillar_max(_p(y), y.shape[-1], _p(pillar_max), pillar_max.shape[-1], _p(slot_pillar), rows, c, _p(out), ld_out,
+                                   _stream()), 'pcp_pfn_cat_pillar_max')
+    return out
+
+
 def canvas_clear(vox, canvas):
     L = _lib.load()
     check(L.pcp_canvas_clear(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, _p(canvas), _stream()), 'pcp_canvas_clear')

@@ -666,6 +666,50 @@ def g7b_train_single(tag, yaml_name, layout):
     print('g7b saved', tag, os.path.getsize(path) // 1024, 'KiB')
 
 
+PFN_VARIANTS = {
+    # tag: (num_raw, USE_ABSLOTE_XYZ, WITH_DISTANCE, NUM_FILTERS, USE_NORM)
+    'dist': (5, True, True, [64, 64], True),
+    'rel': (5, False, False, [64, 64], True),
+    'one': (4, True, False, [64], True),
+    'three': (5, False, True, [32, 64, 128], True),
+    'wide_nonorm': (7, True, True, [48, 96], False),
+}
+
+
+def g16_pfn_variants():
+    """the reference's DynamicPillarVFE (+ PointPillarScatter) alone, with the compositions none of its configs use"""
+    rh.install()
+    from pcdet.models.backbones_3d.vfe.dynamic_pillar_vfe import DynamicPillarVFE
+    from pcdet.models.backbones_2d.map_to_bev.pointpillar_scatter import PointPillarScatter
+    assert DynamicPillarVFE.__module__.startswith('pcdet') and '/root/reference' in sys.modules[DynamicPillarVFE.__module__].__file__
+    out = {}
+    voxel = [0.2, 0.2, 8.0]
+    rng_pc = np.asarray(MINI_RANGE, dtype=np.float32)
+    grid = np.round((rng_pc[3:] - rng_pc[:3]) / np.asarray(voxel, dtype=np.float32)).astype(np.int64)
+    base = synth.collate(mini_points('lately', 2, 700, seed_shift=16))          # 11 raw columns
+    meta = {}
+    for tag, (nr, use_abs, with_dist, filters, use_norm) in PFN_VARIANTS.items():
+        mc = rh.AttrDict(NAME='DynPillarVFE', WITH_DISTANCE=with_dist, USE_ABSLOTE_XYZ=use_abs, USE_NORM=use_norm, NUM_FILTERS=filters)
+        vfe = DynamicPillarVFE(model_cfg=mc, num_point_features=nr, voxel_size=voxel, grid_size=grid, point_cloud_range=rng_pc).eval()
+        shapes = {'vfe.' + k: [int(x) for x in v.shape] for k, v in vfe.state_dict().items()}
+        filled = synth.fill_state_dict(shapes, scheme='he')
+        vfe.load_state_dict({k[len('vfe.'):]: torch.from_numpy(v) for k, v in filled.items()})
+        pts = np.ascontiguousarray(base[:, :1 + nr])
+        sc = PointPillarScatter(model_cfg=rh.AttrDict(NUM_BEV_FEATURES=filters[-1]), grid_size=grid)
+        with torch.no_grad():
+            bd = sc(vfe({'points': torch.from_numpy(pts.copy()), 'batch_size': 2}))
+        out[tag + '_points'] = pts
+        out[tag + '_pillar_features'] = bd['pillar_features'].numpy()
+        out[tag + '_voxel_coords'] = bd['voxel_coords'].numpy().astype(np.int32)
+        out[tag + '_spatial_sha'] = np.array(sha(bd['spatial_features'].numpy()))
+        meta[tag] = dict(num_raw=nr, use_absolute_xyz=use_abs, with_distance=with_dist, vfe_filters=filters, use_norm=use_norm,
+                         state_shapes=shapes)
+        print('g16', tag, 'P =', out[tag + '_voxel_coords'].shape[0], 'C =', out[tag + '_pillar_features'].shape[1])
+    out['meta_json'] = np.array(json.dumps(dict(variants=meta, pc_range=MINI_RANGE, voxel_size=voxel, grid_size=[int(g) for g in grid],
+                                                weight_scheme='he')))
+    np.savez_compressed(os.path.join(HERE, 'g16_pfn_variants.npz'), **out)
+
+
 def g8_exchange():
     """Lately-fusion exchange: runs the reference's own apply_se3_ and the lines of v2x_sim_dataset_ego.py:196-232
     (torch.unique + scatter(mean) through the shim) on seeded MoDAR boxes / foreground points.  points_in_boxes_gpu is CUDA-only in
@@ -1713,6 +1757,8 @@ if __name__ == '__main__':
         g7b_train_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately')
     if 'g8' in todo:
         g8_exchange()
+    if 'g16' in todo:
+        g16_pfn_variants()
     if 'g10' in todo:
         g10_lately_chain()
     if 'g11' in todo:

@@ -1536,3 +1536,53 @@ def test_vfe_never_adopts_a_shared_pillar_workspace_across_a_share_to_no_share_t
         got = cons({'points': pts, 'batch_size': 2})['_pcp_vfe']['canvas']
     torch.cuda.synchronize()
     assert torch.equal(want, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['dist', 'rel', 'one', 'three', 'wide_nonorm'])
+def test_pfn_variants_equal_the_references_module(tag):
+    """DynamicPillarVFE with the compositions no config of the reference uses (WITH_DISTANCE, USE_ABSLOTE_XYZ False, NUM_FILTERS of one /
+    three layers, USE_NORM False, 4 / 7 raw columns) runs layer by layer on the HIP kernels (pcp_pfn_features + pcp_pointwise +
+    pcp_segment_max + pcp_pfn_cat_pillar_max); against the outputs of the reference's own module (tests/golden/g16_pfn_variants.npz)"""
+    from oracle import pillars as opil
+    from pcdet.config import EasyDict
+    from pcdet.models.backbones_2d.map_to_bev.pointpillar_scatter import PointPillarScatter
+    from pcdet.models.backbones_3d.vfe.dynamic_pillar_vfe import DynamicPillarVFE
+    g = load_golden('g16_pfn_variants.npz')
+    v = g['meta']['variants'][tag]
+    cfg = EasyDict(NAME='DynPillarVFE', WITH_DISTANCE=v['with_distance'], USE_ABSLOTE_XYZ=v['use_absolute_xyz'], USE_NORM=v['use_norm'],
+                   NUM_FILTERS=v['vfe_filters'])
+    vfe = DynamicPillarVFE(model_cfg=cfg, num_point_features=v['num_raw'], voxel_size=g['meta']['voxel_size'], grid_size=g['meta']['grid_size'],
+                           point_cloud_range=g['meta']['pc_range'])
+    assert not vfe.fused
+    assert {'vfe.' + k: list(t.shape) for k, t in vfe.state_dict().items()} == v['state_shapes']        # the reference's names and shapes
+    st = synth.fill_state_dict(v['state_shapes'], scheme=g['meta']['weight_scheme'])
+    vfe.load_state_dict({k[len('vfe.'):]: torch.from_numpy(a) for k, a in st.items()})
+    vfe = vfe.cuda().eval()
+    scatter = PointPillarScatter(model_cfg=EasyDict(NUM_BEV_FEATURES=v['vfe_filters'][-1]), grid_size=g['meta']['grid_size'])
+    pts = torch.from_numpy(g[tag + '_points']).cuda()
+    with torch.no_grad():
+        bd = scatter(vfe({'points': pts, 'batch_size': 2}))
+    torch.cuda.synchronize()
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy(), g[tag + '_voxel_coords'])                     # integer work: bit exact
+    assert bd['pillar_features'].shape == g[tag + '_pillar_features'].shape
+    np.testing.assert_allclose(bd['pillar_features'].cpu().numpy(), g[tag + '_pillar_features'], rtol=1e-3, atol=1e-4)
+    # the canvas PointPillarScatter builds from them: against the oracle's (pinned on the same fixture, tests/test_oracle_pins.py)
+    arch = dict(num_raw=v['num_raw'], pc_range=g['meta']['pc_range'], voxel_size=g['meta']['voxel_size'], grid_size=g['meta']['grid_size'],
+                vfe_filters=v['vfe_filters'], use_absolute_xyz=v['use_absolute_xyz'], with_distance=v['with_distance'])
+    want = opil.vfe_forward(g[tag + '_points'], st, arch)['spatial_features']
+    got = bd['spatial_features'].cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4)
+    # an empty cloud and a cloud with every point outside the range
+    with torch.no_grad():
+        e = vfe({'points': pts[:0], 'batch_size': 2})
+        assert e['pillar_features'].shape == (0, v['vfe_filters'][-1]) and e['voxel_coords'].shape[0] == 0
+        far = pts[:16].clone()
+        far[:, 1] += 1000.0
+        e = vfe({'points': far, 'batch_size': 2})
+        assert e['pillar_features'].shape == (0, v['vfe_filters'][-1])
+    # no training kernels for the variants: says so instead of training something else
+    vfe.train()
+    with pytest.raises(NotImplementedError):
+        vfe({'points': pts, 'batch_size': 2})

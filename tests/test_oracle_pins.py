@@ -568,3 +568,18 @@ def test_g12_hunter_jr_training_step():
                 num += float(((mine - ref).astype(np.float64) ** 2).sum())
                 den += float((ref.astype(np.float64) ** 2).sum())
             assert num <= (1e-2 ** 2) * den, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize('tag', ['dist', 'rel', 'one', 'three', 'wide_nonorm'])
+def test_g16_pfn_variants_pinned_on_the_references_module(tag):
+    """tests/golden/g16_pfn_variants.npz: the reference's DynamicPillarVFE + PointPillarScatter run alone with the compositions none of its
+    configs use (WITH_DISTANCE, USE_ABSLOTE_XYZ False, one / three PFN layers, no BatchNorm, 4 and 7 raw columns)"""
+    g = load_golden('g16_pfn_variants.npz')
+    v = g['meta']['variants'][tag]
+    arch = dict(num_raw=v['num_raw'], pc_range=g['meta']['pc_range'], voxel_size=g['meta']['voxel_size'], grid_size=g['meta']['grid_size'],
+                vfe_filters=v['vfe_filters'], use_absolute_xyz=v['use_absolute_xyz'], with_distance=v['with_distance'])
+    st = synth.fill_state_dict(v['state_shapes'], scheme=g['meta']['weight_scheme'])
+    out = opil.vfe_forward(g[tag + '_points'], st, arch)
+    assert np.array_equal(out['vox']['coords'], g[tag + '_voxel_coords'])
+    assert out['pillar_features'].shape[1] == v['vfe_filters'][-1]
+    np.testing.assert_allclose(out['pillar_features'], g[tag + '_pillar_features'], rtol=1e-4, atol=1e-5)
