@@ -502,6 +502,24 @@ def hip_current_device():
     return int(d.value)
 
 
+def hip_device_identity():
+    """the PHYSICAL device this process launches on, as an integer made of its PCI domain:bus:device.function -- ordinals cannot tell two
+    ranks apart when the launcher gives every rank its own one-device view (ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES per rank: all see ordinal 0)"""
+    import ctypes
+    import torch
+    rt = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    d = ctypes.c_int(-1)
+    buf = ctypes.create_string_buffer(64)
+    if rt.hipGetDevice(ctypes.byref(d)) != 0 or rt.hipDeviceGetPCIBusId(buf, 64, d) != 0:
+        return -1
+    try:
+        dom, bus, rest = buf.value.decode().split(':')
+        devn, fn = rest.split('.')
+        return (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(devn, 16) << 3) | int(fn, 16)
+    except ValueError:
+        return -1
+
+
 def dry_run(args, world, rank):
     """PCP_BENCH_DRY_RUN=1 (tests/test_dist_cpu.py only): the launcher, rendezvous, barrier and max-over-ranks aggregation of this script
     with a sleep in place of the kernels -- no GPU, no library, backend gloo.  The line says so in `data`; it is never a measurement."""
@@ -580,7 +598,11 @@ def main(argv=None):
     # (ranks then share devices round-robin -- a functional check, not a measurement, and the line says so)
     n_dev = torch.cuda.device_count()
     backend = os.environ.get('PCP_BENCH_BACKEND', 'nccl')
-    if world > n_dev and backend == 'nccl':
+    # a launcher may hand every rank a one-device view (per-rank ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES): then each rank uses ITS ordinal 0 and
+    # the distinct-device check below goes by PCI address
+    isolated = (world > 1 and n_dev == 1 and any(os.environ.get(k) not in (None, '') for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES',
+                                                                                                   'CUDA_VISIBLE_DEVICES')))
+    if world > n_dev and backend == 'nccl' and not isolated:
         raise SystemExit('bench.py: %d ranks but %d GPUs visible (one rank per GPU; PCP_BENCH_BACKEND=gloo shares devices for a functional check)'
                          % (world, n_dev))
     dev_index = local_rank % n_dev if world > 1 else 0
@@ -792,8 +814,11 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0                                # time the host spends inside step() (enqueueing; no sync in there unless the mode reads back)
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         preds = step()
+        host_s += time.perf_counter() - h0
     if lately_pipe is not None:
         preds = lately_pipe.flush()
     if pipelined is not None:
@@ -803,24 +828,50 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    per_rank_ms, rank_devices = [round(1e3 * elapsed / args.steps, 4)], [hip_current_device()]
+    per_rank_ms, rank_devices, rank_pci = [round(1e3 * elapsed / args.steps, 4)], [hip_current_device()], [hip_device_identity()]
     if world > 1:
         # every rank's own time and the device its HIP runtime launches on (a straggler or two ranks on one device must be visible in the
         # line); `value` uses the MAX over ranks, as the contract says
-        info = torch.tensor([elapsed, float(hip_current_device())], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        info = torch.tensor([elapsed, float(hip_current_device()), float(hip_device_identity())], dtype=torch.float64,
+                            device=dev if backend == 'nccl' else 'cpu')
         gathered = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(gathered, info)
         per_rank_ms = [round(1e3 * float(g[0]) / args.steps, 4) for g in gathered]
         rank_devices = [int(g[1]) for g in gathered]
+        rank_pci = [int(g[2]) for g in gathered]
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        if backend == 'nccl' and sorted(rank_devices) != list(range(world)):
-            raise SystemExit('bench.py: ranks do not sit on distinct devices: %s' % rank_devices)
+        if backend == 'nccl' and (len(set(rank_pci)) != world if min(rank_pci) >= 0 else sorted(rank_devices) != list(range(world))):
+            raise SystemExit('bench.py: ranks do not sit on distinct devices: ordinals %s, PCI %s' % (rank_devices, rank_pci))
     n_boxes = int(sum(p['pred_boxes'].shape[0] for p in preds))
 
     # instrumented pass (HIP events around every C-ABI launch).  Training and agent-sharded steps contain collectives, so in those modes
     # every rank has to take part in the extra steps; only rank 0 records.
+    if os.environ.get('PCP_OP_CENSUS') and rank == 0 and world == 1:
+        # diagnostic: every ATen op two steps dispatch (the path's own kernels go through the C ABI and do not show here), by call site
+        import collections
+        import traceback
+        from torch.utils._python_dispatch import TorchDispatchMode
+        census = collections.Counter()
+
+        class Census(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, a=(), kw=None):
+                site = '?'
+                for fr in reversed(traceback.extract_stack(limit=14)[:-1]):
+                    if '/torch/' not in fr.filename and fr.name != '__torch_dispatch__':
+                        site = '%s:%d %s' % (os.path.relpath(fr.filename, REPO), fr.lineno, fr.name)
+                        break
+                census[(str(func), site)] += 1
+                return func(*a, **(kw or {}))
+        with Census():
+            for _ in range(2):
+                step()
+        torch.cuda.synchronize()
+        with open(os.environ['PCP_OP_CENSUS'], 'w') as f:
+            for (op, site), n in sorted(census.items(), key=lambda kv: -kv[1]):
+                f.write('%6.1f  %-38s %s\n' % (n / 2.0, op, site))
+
     INSTR_STEPS = 3
     timer = None
     was_pipelined = pipelined is not None or lately_pipe is not None
@@ -893,7 +944,8 @@ def main(argv=None):
                       (' [dead BEV-maker passes elided: NOT the headline]' if args.elide_dead_makers else ''),
             'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
             'dtype': {'bf16x3': 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
                       'bf16': 'bf16 training loop [--train only]: bf16 activation / gradient storage between the 3x3 layers, forward / data-gradient / '
                               'weight-gradient 3x3 convs (teachers included) on v_mfma_f32_32x32x16_bf16 with f32 accumulate; f32 master weights, BatchNorm '
@@ -909,7 +961,7 @@ def main(argv=None):
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
                        'ranks_seen_by_collective': ranks_seen, 'backend': backend if world > 1 else None,
-                       'per_rank_ms_per_step': per_rank_ms, 'rank_devices': rank_devices,
+                       'per_rank_ms_per_step': per_rank_ms, 'rank_devices': rank_devices, 'rank_pci_addresses': ['%04x:%02x:%02x.%x' % (v >> 16, (v >> 8) & 255, (v >> 3) & 31, v & 7) if v >= 0 else None for v in rank_pci],
                        'mode': ('plugin default (per-pillar API tensors materialised: one host sync per VFE; dense canvas)' if args.plugin_default else
                                 'pipeline: no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
                                 ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
