@@ -79,11 +79,17 @@ static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
 //                              consecutive): [raw 0 .. num_raw) | zero pad | pillar rank | cx << 16 | cy | (b * ny + cy) * nx + cx], rs = 8 (num_raw <= 5) or 16
 //   tile_desc  int2  [n/T + 2] wave tile t owns the pillars whose first slot lies in [T t, T (t + 1)): {first such pillar, its first slot};
 //                              written for every t with 0 < T t <= N' (entry 0 is {0, 0})
+//   crowd_list int4  [n/64 + 2] pillars of at least `crowd` records (default PCP_PFN_CROWD; counters[4] of them, in no particular order):
+//                              {first slot, records, pillar rank, canvas row}.  Their records carry the rank with the sign bit set: the wave
+//                              tiles of pcp_pfn_rows pass over them and a workgroup per pillar (k_pfn_crowd) runs them instead -- one wave
+//                              would otherwise walk thousands of records alone (LiDAR-like clouds: the cells next to the sensor)
 constexpr int PCP_PFN_TILE = 30;
+constexpr int PCP_PFN_CROWD = 192;              // default threshold; PCP_PFN_CROWD in the environment overrides (>= 64; 0 = never)
+constexpr int PCP_PFN_CROWD_MIN = 64;
 static inline int pcp_rows_stride(int num_raw) { return num_raw <= 5 ? 8 : 16; }
 struct RowsLayout {
   VoxLayout v;
-  size_t srows, tile_desc, total;
+  size_t srows, tile_desc, crowd_list, total;
 };
 static inline RowsLayout pcp_rows_layout(int64_t cells, int64_t n, int num_raw) {
   RowsLayout R;
@@ -92,6 +98,7 @@ static inline RowsLayout pcp_rows_layout(int64_t cells, int64_t n, int num_raw) 
   auto take = [&](size_t bytes) { size_t o = off; off = pcp_align_up(off + bytes, 256); return o; };
   R.srows = take((size_t)n * pcp_rows_stride(num_raw) * 4);
   R.tile_desc = take((size_t)(n / PCP_PFN_TILE + 2) * 8);
+  R.crowd_list = take((size_t)(n / PCP_PFN_CROWD_MIN + 2) * 16);
   R.total = off;
   return R;
 }

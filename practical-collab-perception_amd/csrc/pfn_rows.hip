@@ -31,6 +31,7 @@ namespace {
 
 constexpr int PR_THREADS = 256;                 // four independent waves; the workgroup exists only to share the launch
 constexpr int PR_T = PCP_PFN_TILE;
+constexpr int PR_GRP = 4;                      // column tiles past a tile's first 32 slots are loaded this many at a time
 constexpr int PR_MAXP = 32;                     // pillars per wave tile (<= PR_T: every owned pillar starts at a different slot of the window)
 
 struct PrParams {
@@ -38,6 +39,7 @@ struct PrParams {
   const int2 *tile_desc;
   const int *counters;                          // P, N'
   const int *cell_rank;                         // canvas mode: occupancy of the cells between this wave's pillars
+  const int4 *crowd_list;                       // pillars of many records {first slot, records, rank, canvas row}; counters[4] of them (k_pfn_crowd)
   const float *w0, *b0, *w1, *b1;
   float *pillar_features;                       // (P, 64) or null
   float *canvas;                                // (B, ny, nx, 64) or null
@@ -179,7 +181,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   const int per_wave = (n_units + n_waves - 1) / n_waves;
   const int u_begin = (blockIdx.x * 4 + wave) * per_wave;
   const int u_end = min(u_begin + per_wave, n_units);
-  if (u_begin >= u_end) return;
 
   auto first_slot = [&](int t) -> int {                        // first record of wave tile t; tiles past the multi-point records: Nm
     if (t == 0) return 0;
@@ -210,11 +211,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
       const int slot = a0 + 16 * j + n;
       if (slot < b0s) load_rec(dst[j], slot);
     }
-  };
-  // merged cell id of a record from its packed cell and canvas row, on the scalar unit (b = row / (nx * ny))
-  auto cell_scalar = [&](int cxcy, int crow) -> int {
-    const int fb = (int)(((unsigned long long)(unsigned)crow * p.plane_m) >> p.plane_sh);
-    return fb * plane + (cxcy >> 16) * p.g.ny + (cxcy & 0xffff);
   };
   // the features of a point (f_cluster = 0 for the only point of a pillar) and layer 0 on them: x^T (32 channels x 16 points) = W0 . f^T,
   // bias on the spare feature slot, ReLU
@@ -265,37 +261,12 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
     // one tile; `cur` holds its first 32 records, `nxt` receives the next tile's (the caller alternates the two buffers: no register copies)
     auto tile_body = [&](int t, Rec (&cur)[NPRE], Rec (&nxt)[NPRE]) {
       const int a = acur, bslot = anext;
-      // ---- prefetch: the next tile's records (its first slot arrived a tile ago), the first slot three tiles on, the occupancy of this
-      // tile's cell range
+      // ---- prefetch: the next tile's records (its first slot arrived a tile ago), the first slot three tiles on
       load_recs(nxt, bslot, ann);                              // behind the last tile: bslot == Nm, nothing is loaded
       const int an3 = first_slot(t + 3);
-      int lo = 0;
-      if (a > 0 && a < bslot)
-        lo = cell_scalar(__builtin_amdgcn_readfirstlane(__float_as_int(cur[0].q.z)), __builtin_amdgcn_readfirstlane(__float_as_int(cur[0].q.w)));
-      int occ = 0, hi = (int)p.cells;                         // cell range [lo, hi) of this tile: hi = the cell of the record behind it
-      if (p.canvas && a < bslot) {
-        if (lo + lane < (int)p.cells) occ = p.cell_rank[lo + lane];
-        if (bslot < Nm) hi = cell_scalar(rows_c[(long long)bslot * RS + RS - 2], rows_c[(long long)bslot * RS + RS - 1]);
-      }
       PR_MARK(0);
 
-      if (a >= bslot) {
-        // no multi-point pillar at all: nobody owns the canvas's empty cells, the first wave zero-fills them (slow, tiny clouds only)
-        if (t == 0 && Nm == 0 && p.canvas) {
-          for (int c0 = 0; c0 < (int)p.cells; c0 += 64) {
-            const int c = c0 + lane;
-            unsigned long long m = __ballot(c < (int)p.cells && p.cell_rank[c < (int)p.cells ? c : 0] < 0);
-            while (m) {
-              const int pos = __builtin_ctzll(m);
-              m &= m - 1;
-              const int cell = c0 + pos;
-              const int fb = div_magic(cell, p.plane_m, p.plane_sh), rem = cell - fb * plane;
-              const int cx = div_magic(rem, p.ny_m, p.ny_sh), cy = rem - cx * p.g.ny;
-              if (g == 0) *reinterpret_cast<f32x4 *>(p.canvas + (((long long)fb * p.g.ny + cy) * p.g.nx + cx) * 64 + 4 * n) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-          }
-        }
-      } else {
+      if (a < bslot) {
         const int ncol = (bslot - a + 15) >> 4;
         // local pillar index of every record: the number of pillar heads (rank differs from the record in front) up to it.  The ranks of
         // a tile are not consecutive (single-point pillars lie between them in rank order), the records are.
@@ -309,9 +280,25 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
           last_rank = __builtin_amdgcn_readlane(rk, 15);
           return valid ? lp : 0;
         };
+        // a record whose rank carries the sign bit belongs to a crowded pillar (pcp_common.h: crowd_list): k_pfn_crowd runs those, a
+        // workgroup per pillar; here they are passed over
+        auto rec_ok = [&](const Rec &r, int slot) -> bool { return slot < bslot && __float_as_int(r.q.y) >= 0; };
+        // column tile j (>= NPRE) lies inside ONE crowded pillar: the tile index in front of the one that holds the first record behind
+        // that pillar (every wave tile the pillar covers names its end), else j
+        auto crowd_jump = [&](int j, int rk, bool in) -> int {
+          const int rk0 = __builtin_amdgcn_readfirstlane(rk);
+          if (rk0 >= 0) return j;
+          if (__ballot(in && rk != rk0)) return j;
+          const int s0 = a + 16 * j;
+          const int tgt = first_slot(s0 / PR_T + 1);
+          if (tgt <= s0 + 16 || tgt > bslot) return j;
+          if (rows_c[(long long)(tgt - 1) * RS + RS - 3] != rk0) return j;
+          last_rank = rk0;
+          return (tgt - a) / 16 - 1;
+        };
         int lpj[NPRE];
 #pragma unroll
-        for (int j = 0; j < NPRE; j++) lpj[j] = (j < ncol) ? local_pillar(cur[j], a + 16 * j + n < bslot) : 0;
+        for (int j = 0; j < NPRE; j++) lpj[j] = (j < ncol) ? local_pillar(cur[j], rec_ok(cur[j], a + 16 * j + n)) : 0;
 
         // ---- phase A: fixed-point xyz sums and the point count of every pillar ---------------------------------------------------------
         auto phase_a = [&](const Rec &r, int lp) {
@@ -320,17 +307,38 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         };
 #pragma unroll
         for (int j = 0; j < NPRE; j++)
-          if (a + 16 * j + n < bslot) phase_a(cur[j], lpj[j]);
+          if (rec_ok(cur[j], a + 16 * j + n)) phase_a(cur[j], lpj[j]);
         {
           // crowded tiles: the records past the first 32 slots are read where they are used (twice: here and in phase C)
           const int heads0 = heads, last0 = last_rank;
-          for (int j = NPRE; j < ncol; j++) {
-            const int slot = a + 16 * j + n;
-            const bool valid = slot < bslot;
-            Rec r;
-            load_rec(r, valid ? slot : bslot - 1);
-            const int lp = local_pillar(r, valid);
-            if (valid) phase_a(r, lp);
+          // four column tiles per trip: their loads are issued together (one tile per trip left every load's latency exposed -- LiDAR-like
+          // clouds, where a third of the records sit past their tile's first 32 slots, ran at a quarter of the uniform cloud's rate)
+          for (int j0 = NPRE; j0 < ncol;) {
+            Rec rg[PR_GRP];
+#pragma unroll
+            for (int u = 0; u < PR_GRP; u++) {
+              const int slot = a + 16 * (j0 + u) + n;
+              load_rec(rg[u], slot < bslot ? slot : bslot - 1);
+            }
+            int next = j0 + PR_GRP;
+            bool jumped = false;
+#pragma unroll
+            for (int u = 0; u < PR_GRP; u++) {
+              const int j = j0 + u;
+              if (!jumped && j < ncol) {
+                const bool in = a + 16 * j + n < bslot;
+                const int rk = __float_as_int(rg[u].q.y);
+                const bool valid = in && rk >= 0;
+                const int lp = local_pillar(rg[u], valid);
+                if (valid) phase_a(rg[u], lp);
+                const int jn = crowd_jump(j, rk, in);
+                if (jn != j) {
+                  next = jn + 1;
+                  jumped = true;
+                }
+              }
+            }
+            j0 = next;
           }
           if (ncol > NPRE) {                                   // phase C walks the same records again from the same state
             heads = heads0;
@@ -405,14 +413,34 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         };
 #pragma unroll
         for (int j = 0; j < NPRE; j++)
-          if (j < ncol) phase_c(cur[j], lpj[j], a + 16 * j + n < bslot);
-        for (int j = NPRE; j < ncol; j++) {
-          const int slot = a + 16 * j + n;
-          const bool valid = slot < bslot;
-          Rec rr;
-          load_rec(rr, valid ? slot : bslot - 1);
-          const int lp = local_pillar(rr, valid);
-          phase_c(rr, lp, valid);
+          if (j < ncol) phase_c(cur[j], lpj[j], rec_ok(cur[j], a + 16 * j + n));
+        for (int j0 = NPRE; j0 < ncol;) {
+          Rec rg[PR_GRP];
+#pragma unroll
+          for (int u = 0; u < PR_GRP; u++) {
+            const int slot = a + 16 * (j0 + u) + n;
+            load_rec(rg[u], slot < bslot ? slot : bslot - 1);
+          }
+          int next = j0 + PR_GRP;
+          bool jumped = false;
+#pragma unroll
+          for (int u = 0; u < PR_GRP; u++) {
+            const int j = j0 + u;
+            if (!jumped && j < ncol) {
+              const bool in = a + 16 * j + n < bslot;
+              const int rk = __float_as_int(rg[u].q.y);
+              const bool valid = in && rk >= 0;
+              const int lp = local_pillar(rg[u], valid);
+              const int jn = crowd_jump(j, rk, in);
+              if (jn == j) {
+                phase_c(rg[u], lp, valid);                      // a column inside a crowded pillar does no arithmetic at all
+              } else {
+                next = jn + 1;
+                jumped = true;
+              }
+            }
+          }
+          j0 = next;
         }
         const int np = heads;                                  // pillars of the tile (<= PR_T: each starts at another slot of the window)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -422,8 +450,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         // stores below (data-dependent loops), so any later wait on a load would be vmcnt(0) and would sit behind them.  From here to the
         // top of the next tile no vector load is waited for.
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
-        unsigned long long empty0 = 0ULL;
-        if (p.canvas) empty0 = __ballot(lo + lane < hi && occ < 0);
         // ---- phase D: per 16 pillars: out = relu(b1 + W1[:, 32:] . xmax + dmax), 16-byte stores; the LDS words are reset as they are read ----
         for (int k = 0; k * 16 < np; k++) {
           const int lp = n + 16 * k;
@@ -475,34 +501,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(sum) + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
 
         PR_MARK(4);
-        // ---- phase E (canvas): zero rows for the empty cells of this wave's cell range --------------------------------------------------
-        if (p.canvas) {
-          // range: from the tile's first pillar (from cell 0 for the tile that holds record 0) up to the first multi-point pillar behind it
-          for (int c0 = lo; c0 < hi; c0 += 64) {
-            unsigned long long m = empty0;
-            if (c0 != lo) {
-              const int c = c0 + lane;
-              m = __ballot(c < hi && p.cell_rank[c < hi ? c : lo] < 0);
-            }
-            while (m) {
-              // four empty cells per store instruction: lane group g takes the g-th lowest set bit
-              int pos[4];
-#pragma unroll
-              for (int q = 0; q < 4; q++) {
-                pos[q] = m ? __builtin_ctzll(m) : -1;
-                m &= m - 1;
-              }
-              const int mine = g == 0 ? pos[0] : (g == 1 ? pos[1] : (g == 2 ? pos[2] : pos[3]));
-              if (mine >= 0) {
-                const int cell = c0 + mine;
-                const int fb = div_magic(cell, p.plane_m, p.plane_sh), rem = cell - fb * plane;
-                const int cx = div_magic(rem, p.ny_m, p.ny_sh), cy = rem - cx * p.g.ny;
-                const long long row = ((long long)fb * p.g.ny + cy) * p.g.nx + cx;
-                *reinterpret_cast<f32x4 *>(p.canvas + row * 64 + 4 * n) = f32x4{0.f, 0.f, 0.f, 0.f};
-              }
-            }
-          }
-        }
       }
       PR_MARK(5);
       acur = anext;
@@ -574,12 +572,241 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
       if (u + 1 < s_end) unit_body(u + 1, recn, rec);
     }
   }
+  // =================================== canvas: zero rows for the empty cells ==================================================================
+  // Every wave takes an equal slice of the cell -> rank table, whatever the cloud looks like.  (First form of this round: a tile filled the
+  // cells between ITS pillars -- even work on a uniform cloud, but in a LiDAR-like cloud the few multi-point pillars of the outskirts
+  // owned tens of thousands of empty cells each: +240 us on the 6-agent cloud.)  Last in the wave's work, so nothing waits behind the
+  // stores; eight 64-cell chunks of the table per trip (one wait per trip: hipcc cannot count the data-dependent stores in between).
+  if (p.canvas) {
+    const long long per = (((p.cells + n_waves - 1) / n_waves) + 63) & ~63LL;
+    const long long c_begin = (long long)(blockIdx.x * 4 + wave) * per;
+    const long long c_end = c_begin + per < p.cells ? c_begin + per : p.cells;
+    for (long long cb = c_begin; cb < c_end; cb += 512) {
+      int occ[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const long long c = cb + 64 * k + lane;
+        occ[k] = c < c_end ? p.cell_rank[c] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        unsigned long long m = __ballot(occ[k] < 0);
+        const int c0 = (int)(cb + 64 * k);
+        while (m) {
+          // four empty cells per store instruction: lane group g takes the g-th lowest set bit
+          int pos[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            pos[q] = m ? __builtin_ctzll(m) : -1;
+            m &= m - 1;
+          }
+          const int mine = g == 0 ? pos[0] : (g == 1 ? pos[1] : (g == 2 ? pos[2] : pos[3]));
+          if (mine >= 0) {
+            const int cell = c0 + mine;
+            const int fb = div_magic(cell, p.plane_m, p.plane_sh), rem = cell - fb * plane;
+            const int cx = div_magic(rem, p.ny_m, p.ny_sh), cy = rem - cx * p.g.ny;
+            const long long row = ((long long)fb * p.g.ny + cy) * p.g.nx + cx;
+            *reinterpret_cast<f32x4 *>(p.canvas + row * 64 + 4 * n) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    }
+  }
 #ifdef PR_STAMP
   if (stamp && lane == 0) {
     for (int k = 0; k < 8; k++) pr_dbg[k] = st_acc[k];
     pr_dbg[8] = (unsigned long long)max(min(u_end, n_tiles) - u_begin, 0);
   }
 #endif
+}
+
+// ---- crowded pillars: one workgroup per pillar ------------------------------------------------------------------------------------------------
+// A LiDAR-like cloud puts hundreds to thousands of points into the cells next to the sensor.  The wave that owns such a pillar in k_pfn_rows
+// would walk all of its records alone (5 000 records = 312 column tiles ~ 0.2 ms on one wave while the chip is done).  The pillariser lists
+// every pillar of at least `crowd` records (default PCP_PFN_CROWD = 192) and tags its records; k_pfn_rows passes over them; here the eight
+// waves of a workgroup share the pillar's column tiles: fixed-point sums -> mean (one barrier), then features -> layer 0 -> point half of
+// layer 1 with the running maxima kept in REGISTERS across the tiles (every record is the same pillar: no LDS atomics per point), one
+// cross-lane + cross-wave reduction at the end, the pillar half of layer 1 on wave 0.  Same operations in the same order per point, exact
+// integer sums, order-free maxima: BIT-identical to what the owner wave of k_pfn_rows computes for the same pillar.
+constexpr int PC_WAVES = 8;
+constexpr int PC_THREADS = PC_WAVES * 64;
+
+template <int NUM_RAW>
+__global__ __launch_bounds__(PC_THREADS) void k_pfn_crowd(PrParams p) {
+  constexpr int RS = NUM_RAW <= 5 ? 8 : 16;
+  constexpr int S0 = l0_steps<NUM_RAW>();
+  constexpr int F = NUM_RAW + 6;
+  __shared__ unsigned long long s_sum[4];
+  __shared__ float s_mean[4];
+  __shared__ float s_x[32], s_d[64];
+  const int n_crowd = p.counters[4];
+  if ((int)blockIdx.x >= n_crowd) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  float w0f[2][S0];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int s = 0; s < S0; s++) {
+      const int fi = feat_index<NUM_RAW>(s, g);
+      w0f[b][s] = fi >= 0 ? p.w0[(16 * b + n) * F + fi] : (fi == -2 ? p.b0[16 * b + n] : 0.f);
+    }
+  f32x4 w1a[4][2], w1b[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const float *wr = p.w1 + (16 * r + n) * 64 + 16 * b + 4 * g;
+      w1a[r][b] = *reinterpret_cast<const f32x4 *>(wr);
+      w1b[r][b] = *reinterpret_cast<const f32x4 *>(wr + 32);
+    }
+  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
+  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
+  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
+  const float vsel = g == 0 ? p.g.voxel_x : (g == 1 ? p.g.voxel_y : 0.f);
+  const float osel = g == 0 ? x_off : (g == 1 ? y_off : z_off);
+  const int acol = g < 3 ? g : 3;
+
+  for (int e = blockIdx.x; e < n_crowd; e += gridDim.x) {
+    const int4 ent = p.crowd_list[e];
+    const int start = ent.x, cnt = ent.y;
+    const int ncol = (cnt + 15) >> 4;
+    if (tid < 4) s_sum[tid] = 0ULL;
+    if (tid < 32) s_x[tid] = 0.f;
+    if (tid < 64) s_d[tid] = -__builtin_inff();
+    __syncthreads();
+    // ---- fixed-point sums of x, y, z (the count is known) -> mean, exactly the arithmetic of k_pfn_rows' phases A and B ---------------------
+    {
+      long long part = 0;
+      if (g < 3)
+        for (int j = wave; j < ncol; j += PC_WAVES) {
+          const int slot = start + 16 * j + n;
+          if (slot < start + cnt) part += fixed24(p.srows[(long long)slot * RS + g]);
+        }
+      if (g < 3) __hip_atomic_fetch_add(&s_sum[g], (unsigned long long)part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (tid < 3) {
+      const double c = (double)(unsigned)cnt, sd = (double)(long long)s_sum[tid] * (1.0 / 16777216.0);
+      double rc = __builtin_amdgcn_rcp(c);
+      rc = __builtin_fma(__builtin_fma(-c, rc, 1.0), rc, rc);
+      double qd = sd * rc;
+      qd = __builtin_fma(__builtin_fma(-c, qd, sd), rc, qd);
+      s_mean[tid] = (float)qd;
+    }
+    __syncthreads();
+    const float mean = s_mean[acol < 3 ? acol : 0];
+    // ---- per 16 points: features -> layer 0 -> point half of layer 1; maxima in registers --------------------------------------------------
+    float xm0[4] = {0.f, 0.f, 0.f, 0.f}, xm1[4] = {0.f, 0.f, 0.f, 0.f};
+    float dm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) dm[r][i] = -__builtin_inff();
+    for (int j = wave; j < ncol; j += PC_WAVES) {
+      const int slot = start + 16 * j + n;
+      const bool valid = slot < start + cnt;
+      const float *src = p.srows + (long long)(valid ? slot : start + cnt - 1) * RS;
+      const float av = src[acol];
+      const f32x4 q = *reinterpret_cast<const f32x4 *>(src + RS - 4);
+      float e4 = 0.f, e5 = 0.f, e6g = 0.f, e10 = 0.f;
+      if (RS == 16) {
+        e4 = src[4];
+        e5 = src[5];
+        e6g = src[6 + g];
+        e10 = src[10];
+      }
+      const int cxcy = __float_as_int(q.z);
+      const float cf = (float)(g == 0 ? (cxcy >> 16) : (cxcy & 0xffff));
+      const float centre = __fadd_rn(__fmul_rn(cf, vsel), osel);
+      const float cluster = __fsub_rn(av, mean);
+      float f[S0];
+      const float raw4 = RS == 8 ? q.x : e4;
+      f[0] = (g < 3 || NUM_RAW > 3) ? av : 1.f;
+      f[1] = g < 3 ? cluster : (NUM_RAW > 4 ? raw4 : (NUM_RAW > 3 ? 1.f : 0.f));
+      f[2] = g < 3 ? __fsub_rn(av, centre) : (NUM_RAW > 5 ? e5 : (NUM_RAW > 4 ? 1.f : 0.f));
+      if (S0 > 3) f[3] = e6g;
+      if (S0 > 4) f[4] = g == 0 ? e10 : (g == 1 ? 1.f : 0.f);
+      f32x4a x0 = f32x4a{0.f, 0.f, 0.f, 0.f}, x1 = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < S0; s++) {
+        x0 = mfma16(w0f[0][s], f[s], x0);
+        x1 = mfma16(w0f[1][s], f[s], x1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        x0[i] = relu_f(x0[i]);
+        x1[i] = relu_f(x1[i]);
+      }
+      f32x4a dacc[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) dacc[r] = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][0][i], x0[i], dacc[r]);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][1][i], x1[i], dacc[r]);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          xm0[i] = fmaxf(xm0[i], x0[i]);
+          xm1[i] = fmaxf(xm1[i], x1[i]);
+#pragma unroll
+          for (int r = 0; r < 4; r++) dm[r][i] = fmaxf(dm[r][i], dacc[r][i]);
+        }
+      }
+    }
+    // lane (n, g) holds channels 4 g + i (x0), 16 + 4 g + i (x1), 16 r + 4 g + i (d) of ITS points: maxima over the 16 lanes n and the waves
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __hip_atomic_fetch_max(&s_x[4 * g + i], xm0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_max(&s_x[16 + 4 * g + i], xm1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int r = 0; r < 4; r++) __hip_atomic_fetch_max(&s_d[16 * r + 4 * g + i], dm[r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    // ---- the pillar half of layer 1 (one pillar: column 0 of the 16-column tile), bias, ReLU, stores ---------------------------------------
+    if (wave == 0) {
+      f32x4a o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.b1 + 16 * r + 4 * g);
+        o[r] = f32x4a{bv.x, bv.y, bv.z, bv.w};
+      }
+      float b0v[4], b1v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        b0v[i] = n == 0 ? s_x[4 * g + i] : 0.f;
+        b1v[i] = n == 0 ? s_x[16 + 4 * g + i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][0][i], b0v[i], o[r]);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][1][i], b1v[i], o[r]);
+      if (n == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          f32x4 v;
+          v.x = relu_f(o[r][0] + s_d[16 * r + 4 * g + 0]);
+          v.y = relu_f(o[r][1] + s_d[16 * r + 4 * g + 1]);
+          v.z = relu_f(o[r][2] + s_d[16 * r + 4 * g + 2]);
+          v.w = relu_f(o[r][3] + s_d[16 * r + 4 * g + 3]);
+          if (p.pillar_features) *reinterpret_cast<f32x4 *>(p.pillar_features + (long long)ent.z * 64 + 16 * r + 4 * g) = v;
+          if (p.canvas) *reinterpret_cast<f32x4 *>(p.canvas + (long long)ent.w * 64 + 16 * r + 4 * g) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -605,6 +832,7 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   p.tile_desc = (const int2 *)(ws + R.tile_desc);
   p.counters = (const int *)(ws + R.v.counters);
   p.cell_rank = (const int *)(ws + R.v.cell_rank);
+  p.crowd_list = (const int4 *)(ws + R.crowd_list);
   p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
   p.pillar_features = pillar_features;
   p.canvas = canvas;
@@ -615,6 +843,10 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   magic_div((unsigned)grid->ny, &p.ny_m, &p.ny_sh);
   static const int wps = [] { const char *e = getenv("PCP_PFN_WPS"); return e ? atoi(e) : 2; }();     // A/B knob (tools/bench_frontend.py)
   int blocks = (p.n_tiles_max + 3) / 4;
+  if (canvas) {                                 // the waves also share the canvas's empty cells: at most ~512 cells each, however small the cloud
+    const int64_t by_cells = (cells + 4 * 512 - 1) / (4 * 512);
+    if (by_cells > blocks) blocks = (int)(by_cells < 256 * wps ? by_cells : 256 * wps);
+  }
   if (blocks > 256 * wps) blocks = 256 * wps;
   hipStream_t stream = (hipStream_t)stream_;
 #define PCP_PFN_ROWS(NR)                                                                                            \
@@ -630,6 +862,15 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
     default: return PCP_ERR_UNSUPPORTED;
   }
 #undef PCP_PFN_ROWS
+  PCP_CHECK_LAUNCH();
+  // the crowded pillars the wave tiles passed over (none in most clouds: the workgroups read the list length and leave)
+  const dim3 cgrid(128);
+  switch (num_raw) {
+    case 5: hipLaunchKernelGGL(k_pfn_crowd<5>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
+    case 11: hipLaunchKernelGGL(k_pfn_crowd<11>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL(k_pfn_crowd<3>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
+    default: hipLaunchKernelGGL(k_pfn_crowd<4>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
+  }
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -8,6 +8,7 @@
 //
 // HBM traffic per call: points read twice (n * row_stride * 4 B, second pass only column 0..2 -> same lines),
 // 4 dense int32 tables of B*nx*ny (1 MiB each at 512x512), and O(n) int32 side arrays.
+#include <stdlib.h>
 #include "pcp_common.h"
 
 namespace {
@@ -81,7 +82,10 @@ struct CellScanOut {
   int *cell_rank, *pillar_cell, *pillar_start, *voxel_coords, *unq_cnt, *counters_ws, *counters_out;
   int2 *cell_rs;
   int2 *tile_desc;               // rows mode only
+  int4 *crowd_list;              // rows mode only: pillars of >= crowd records {first slot, records, rank, canvas row}; counters_ws[4] of them
+  int crowd;                     // threshold (0: none)
 };
+constexpr int CROWD_TAG = 0x40000000;      // on a cell's first slot in cell_rs: its records carry the rank with the sign bit set
 
 __device__ __forceinline__ void load_cell_counts(const int *__restrict__ cell_count, long long base, long long cells, int (&cnt)[CS_ITEMS]) {
   if (base + CS_ITEMS <= cells) {
@@ -104,9 +108,10 @@ __device__ __forceinline__ u64 pack_cell_seg(int cnt) {
 
 template <bool SEG>
 __global__ __launch_bounds__(SCAN_THREADS) void k_cell_tile_sums(const int *__restrict__ cell_count, long long cells, u64 *__restrict__ tile_sums,
-                                                                 unsigned *__restrict__ tile_singles) {
+                                                                 unsigned *__restrict__ tile_singles, int *__restrict__ crowd_count) {
   __shared__ u64 wave_tot[SCAN_THREADS / 64];
   __shared__ unsigned wave_one[SCAN_THREADS / 64];
+  if (crowd_count && blockIdx.x == 0 && threadIdx.x == 0) *crowd_count = 0;      // k_cell_finish (the next launch) appends to the list
   int cnt[CS_ITEMS];
   load_cell_counts(cell_count, (long long)blockIdx.x * CS_TILE + (long long)threadIdx.x * CS_ITEMS, cells, cnt);
   u64 s = 0;
@@ -235,7 +240,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cell_finish(const int *__restr
       // index behind ALL multi-point records, whose number only the last workgroup knows: the point pass adds counters[2])
       const int start = single ? (int)(0x80000000u | (v1[i] + blk1)) : (int)(e & 0xffffffffULL);
       rank_out[i] = rank;
-      o.cell_rs[c] = make_int2(rank, start);
+      const bool crowded = o.crowd_list && o.crowd > 0 && cnt[i] >= o.crowd;
+      o.cell_rs[c] = make_int2(rank, crowded ? (start | CROWD_TAG) : start);
+      if (crowded) {
+        const int b = (int)(c / plane), rem = (int)(c % plane);
+        const int cx = rem / g.ny, cy = rem % g.ny;
+        const int at = atomicAdd(&o.counters_ws[4], 1);
+        o.crowd_list[at] = make_int4(start, cnt[i], rank, (b * g.ny + cy) * g.nx + cx);
+      }
       o.pillar_cell[rank] = (int)c;
       o.pillar_start[rank] = start;
       if (o.voxel_coords) {
@@ -318,8 +330,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_place(const float *__res
   const int cell = point_cell[r];
   if (cell < 0) return;
   const int2 rs = cell_rs[cell];
-  const int slot = rs.y < 0 ? counters[2] + (rs.y & 0x7fffffff) : rs.y + point_rank[r];      // tagged: a single-point pillar (rows mode)
-  emit_point<RS>(points, stride, num_raw, g, r, cell, rs.x, slot, bucket_order, srows);
+  const bool crowded = rs.y >= 0 && (rs.y & CROWD_TAG);
+  const int slot = rs.y < 0 ? counters[2] + (rs.y & 0x7fffffff) : (rs.y & ~CROWD_TAG) + point_rank[r];      // tagged: a single-point pillar (rows mode)
+  emit_point<RS>(points, stride, num_raw, g, r, cell, crowded ? (int)(rs.x | 0x80000000u) : rs.x, slot, bucket_order, srows);
 }
 
 // last pass over points with the stable compaction position -> unq_inv
@@ -347,8 +360,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_finish(const float *__re
     if (cell[i] < 0) continue;
     const int2 rs = cell_rs[cell[i]];
     unq_inv[v[i] + blk] = (long long)rs.x;
-    const int slot = rs.y < 0 ? counters[2] + (rs.y & 0x7fffffff) : rs.y + prank[i];
-    emit_point<RS>(points, stride, num_raw, g, base + i, cell[i], rs.x, slot, bucket_order, srows);
+    const bool crowded = rs.y >= 0 && (rs.y & CROWD_TAG);
+    const int slot = rs.y < 0 ? counters[2] + (rs.y & 0x7fffffff) : (rs.y & ~CROWD_TAG) + prank[i];
+    emit_point<RS>(points, stride, num_raw, g, base + i, cell[i], crowded ? (int)(rs.x | 0x80000000u) : rs.x, slot, bucket_order, srows);
   }
 }
 
@@ -412,6 +426,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__res
   }
 }
 
+// pillars of at least this many records are listed for k_pfn_crowd (pcp_common.h); PCP_PFN_CROWD=<n> overrides (0: never)
+inline int crowd_threshold() {
+  const char *e = getenv("PCP_PFN_CROWD");
+  if (!e || !*e) return PCP_PFN_CROWD;
+  const int v = atoi(e);
+  if (v <= 0) return 0;
+  return v < PCP_PFN_CROWD_MIN ? PCP_PFN_CROWD_MIN : v;
+}
+
 // The pillariser: zero fill of the histogram, k_point_cells, k_cell_tile_sums, k_cell_finish, k_point_place (five launches; round 4: six).
 // cells_ready: cell_count / point_cell / point_rank were filled by the caller's own pass over the rows (pcp_select_transform_compact emits them
 // while the transformed row is in registers): three launches.  The stable compaction position (unq_inv)
@@ -427,6 +450,7 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   if (rows_raw && (rows_raw < 3 || rows_raw > 13 || row_stride < 1 + rows_raw || grid->nx > 65535 || grid->ny > 65535)) return PCP_ERR_ARG;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
   if (cells >= (1LL << 31) || n >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
+  if (rows_raw && n >= (1LL << 30)) return PCP_ERR_UNSUPPORTED;                   // bit 30 of a first slot tags the crowded pillars
   const int64_t n_alloc = n > 0 ? n : 1;
   VoxLayout L = pcp_vox_layout(cells, n_alloc);
   RowsLayout R;
@@ -451,6 +475,9 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   o.counters_ws = (int *)(ws + L.counters);
   o.counters_out = counters;
   o.tile_desc = rows_raw ? (int2 *)(ws + R.tile_desc) : nullptr;
+  o.crowd_list = rows_raw ? (int4 *)(ws + R.crowd_list) : nullptr;
+  o.crowd = rows_raw ? crowd_threshold() : 0;
+  int *crowd_count = rows_raw ? o.counters_ws + 4 : nullptr;
   int *bucket_order = (want_bucket_order || !rows_raw) ? (int *)(ws + L.bucket_order) : nullptr;
   float *srows = rows_raw ? (float *)(ws + R.srows) : nullptr;
   const int rs = rows_raw ? pcp_rows_stride(rows_raw) : 0;
@@ -468,13 +495,13 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   // the map (multi-point pillars, then singles) cost that kernel 15 % (measured on configs 1 - 3) where the PFN gains a third of that.
   if (rows_raw && !want_bucket_order) {
     hipLaunchKernelGGL(k_cell_tile_sums<true>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, sc.tile_sums,
-                       sc.tile_singles);
+                       sc.tile_singles, crowd_count);
     PCP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_cell_finish<true>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, *grid,
                        sc.tile_sums, sc.tile_singles, sc.n_ctiles, o);
   } else {
     hipLaunchKernelGGL(k_cell_tile_sums<false>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, sc.tile_sums,
-                       sc.tile_singles);
+                       sc.tile_singles, crowd_count);
     PCP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_cell_finish<false>, dim3(sc.n_ctiles), dim3(SCAN_THREADS), 0, stream, cell_count, (long long)cells, *grid,
                        sc.tile_sums, sc.tile_singles, sc.n_ctiles, o);

@@ -1,7 +1,7 @@
 """Micro-benchmark of the VFE stage, rounds 1-4 form against the round-5 form, on the synthetic clouds of bench.py:
   old: pcp_voxelize + pcp_pfn_scatter (+ pcp_canvas_clear for a dense canvas)
   new: pcp_pillarise_rows + pcp_pfn_rows (the canvas is written completely: no clear)
-usage: bench_frontend.py [frames=4] [agents=1|6] [dense=0|1]"""
+usage: bench_frontend.py [frames=4] [agents=1|6] [dense=0|1] [dist=uniform|ring]"""
 import sys
 from pathlib import Path
 
@@ -29,10 +29,11 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     agents = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dense = int(sys.argv[3]) if len(sys.argv) > 3 else (1 if agents > 1 else 0)
+    dist = sys.argv[4] if len(sys.argv) > 4 else 'uniform'
     d = torch.device('cuda:0')
     frames = []
     for b in range(B):
-        clouds = [synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b) for a in range(agents)]
+        clouds = [synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b, dist=dist) for a in range(agents)]
         frames.append(np.concatenate(clouds, 0))
     pts = torch.from_numpy(synth.collate(frames)).to(d)
     grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], B)

@@ -213,7 +213,10 @@ def test_pillarise_rows_bit_exact(case):
     import ctypes
     front = L.pcp_voxelize_workspace_bytes(ctypes.byref(g), max(pts.shape[0], 1))
     rows = res.workspace[front:front + max(pts.shape[0], 1) * 32].view(torch.float32).view(-1, 8)[:Nv].cpu()
-    rank = rows[:, 5].view(torch.int32).numpy()
+    tagged = rows[:, 5].view(torch.int32).numpy()
+    rank = tagged & 0x7fffffff
+    # the sign bit marks the records of crowded pillars (>= PCP_PFN_CROWD = 192 records: k_pfn_crowd runs those), and only those
+    assert np.array_equal(tagged < 0, ref['cnt'][rank] >= 192)
     # slot order: the multi-point pillars ascending (runs of cnt records), then the single-point pillars ascending
     multi, single = np.nonzero(ref['cnt'] > 1)[0], np.nonzero(ref['cnt'] == 1)[0]
     assert np.array_equal(rank, np.concatenate([np.repeat(multi, ref['cnt'][multi]), single]))
@@ -246,7 +249,9 @@ def test_pillarise_rows_with_bucket_order_keeps_the_plain_pillar_order():
     L = __import__('pcp_amd.lib', fromlist=['lib']).load()
     front = L.pcp_voxelize_workspace_bytes(ctypes.byref(g), pts.shape[0])
     rows = res.workspace[front:front + pts.shape[0] * 32].view(torch.float32).view(-1, 8)[:Nv].cpu()
-    assert np.array_equal(rows[:, 5].view(torch.int32).numpy(), np.repeat(np.arange(P), ref['cnt']))
+    tagged = rows[:, 5].view(torch.int32).numpy()                                      # sign bit: records of crowded pillars (>= 192 records)
+    assert np.array_equal(tagged & 0x7fffffff, np.repeat(np.arange(P), ref['cnt']))
+    assert np.array_equal(tagged < 0, np.repeat(ref['cnt'] >= 192, ref['cnt'])) and bool((tagged < 0).any())
     order = ops.voxelize_row_order(res).cpu().numpy()
     assert np.array_equal(np.sort(order), np.arange(pts.shape[0]))
     kept = np.nonzero(ref['keep'])[0]
@@ -323,6 +328,55 @@ def test_pfn_rows_matches_oracle(layout, num_raw, n):
     ops.pfn_rows(vox2, w0, b0, w1, b1, canvas=None, pillar_features=pf2)
     torch.cuda.synchronize()
     assert torch.equal(pf, pf2)
+
+
+@pytest.mark.parametrize('num_raw,bucket_order', [(5, False), (5, True), (11, False)])
+def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num_raw, bucket_order, monkeypatch):
+    """pillars of at least PCP_PFN_CROWD records (default 192) are listed by the pillariser, passed over by the wave tiles of k_pfn_rows and
+    run by k_pfn_crowd, a workgroup per pillar: the same operations per point, exact sums, order-free maxima -- bit for bit what the wave tiles
+    compute when nothing is listed (PCP_PFN_CROWD=0), at every threshold, with and without the bucket order, next to the reference oracle"""
+    ops = _ops()
+    rs = np.random.RandomState(11)
+    ncol = 8 if num_raw == 5 else 14
+    base = _crowded_cloud(ncol)
+    extra = []
+
+    def cell_points(b, cx, cy, k):
+        q = np.zeros((k, ncol), np.float32)
+        q[:, 0] = b
+        q[:, 1] = -51.2 + 0.2 * cx + rs.uniform(0.01, 0.19, k)
+        q[:, 2] = -51.2 + 0.2 * cy + rs.uniform(0.01, 0.19, k)
+        q[:, 3] = rs.uniform(-8, 0, k)
+        q[:, 4:] = rs.uniform(0, 1, (k, ncol - 4))
+        extra.append(q)
+    for i, k in enumerate((5000, 1024, 257, 256, 255, 96, 65, 64, 63)):      # around every threshold used below, neighbours in the slot order
+        cell_points(1, 40 + i, 40, k)
+    cell_points(1, 0, 0, 300)                                                  # the very first pillar of a frame
+    cell_points(3, 511, 511, 400)                                              # and the very last one of the cloud
+    ring = synth.collate([synth.agent_cloud(5, 20000, 'car' if num_raw == 5 else 'lately', dist='ring')])
+    ring[:, 0] = 2
+    pts = np.concatenate([base] + extra + [ring[:, :ncol]], 0)
+    pts = pts[rs.permutation(pts.shape[0])]
+    st, (w0, b0, w1, b1) = _folded_vfe(num_raw)
+    d = dev()
+    pd = torch.from_numpy(pts).to(d)
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, 4)
+    outs = {}
+    for thr in ('0', '64', '192', '100000'):
+        monkeypatch.setenv('PCP_PFN_CROWD', thr)
+        vox = ops.pillarise_rows(pd, g, num_raw, want_coords=True, bucket_order=bucket_order)
+        P = int(vox.counters[0])
+        canvas = torch.full((4, 512, 512, 64), float('nan'), device=d)
+        pf = torch.full((P, 64), float('nan'), device=d)
+        ops.pfn_rows(vox, w0, b0, w1, b1, canvas=canvas, pillar_features=pf)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(pf).any()) and not bool(torch.isnan(canvas).any())
+        outs[thr] = (pf.clone(), canvas.clone(), vox.voxel_coords[:P].clone())
+    for thr in ('64', '192', '100000'):
+        assert torch.equal(outs[thr][0], outs['0'][0]) and torch.equal(outs[thr][1], outs['0'][1]) and torch.equal(outs[thr][2], outs['0'][2])
+    arch = dict(num_raw=num_raw, pc_range=PC_RANGE, voxel_size=VOXEL, grid_size=GRID, vfe_filters=[64, 64])
+    ref = opil.vfe_forward(pts, st, arch)
+    np.testing.assert_allclose(outs['192'][0].cpu().numpy(), ref['pillar_features'], rtol=1e-4, atol=2e-5)
 
 
 def test_pfn_rows_empty_cloud_and_single_point():
