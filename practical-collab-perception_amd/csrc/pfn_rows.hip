@@ -16,8 +16,10 @@
 //   * both layers run on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand and 16 points as the B operand: the accumulator of layer 0
 //     (lane (n, g): channels 16 b + 4 g + i of point n) IS the B operand of layer 1 -- no LDS round trip, no shuffle; the layer-0 bias rides
 //     on a spare feature slot; a lane ends with four consecutive channels of one pillar: 16-byte stores;
-//   * dense clouds: the wave also zero-fills the EMPTY cells between its pillars (it reads the 30 - 60 entries of the cell -> rank table
-//     that cover its range), so the canvas is written exactly once -- no clear-by-list pass, no zero fill.
+//   * dense canvas: every wave also zero-fills the EMPTY cells of an equal slice of the cell -> rank table (last in its work), so the canvas
+//     is written exactly once -- no clear-by-list pass, no zero fill;
+//   * pillars of >= 192 records (LiDAR-like clouds: the cells next to the sensor) are passed over by the wave tiles and run by k_pfn_crowd
+//     below, a workgroup per pillar (bit-identical results).
 // Order independence (bitwise reproducible results whatever the arrival order inside a pillar): means accumulate in 2^-24 fixed point
 // (integer adds commute), maxima are order independent, every per-point product has a fixed summation order.
 //
