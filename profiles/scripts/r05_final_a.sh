@@ -9,6 +9,7 @@ PY
 run r05_bench_disco --steps 20 --warmup 5
 run r05_bench_disco_batch_by_batch --steps 20 --warmup 5 --no-pipeline --no-cpu-baseline
 run r05_bench_disco_optin --steps 20 --warmup 5 --no-cpu-baseline --optin
+run r05_bench_disco_ring --steps 20 --warmup 5 --dist ring --no-cpu-baseline
 run r05_bench_car --config car --steps 20 --warmup 5 --no-cpu-baseline
 run r05_bench_ego --config ego --steps 20 --warmup 5 --no-cpu-baseline
 run r05_bench_early --config early --steps 20 --warmup 5 --no-cpu-baseline
