@@ -1,5 +1,5 @@
 """In-kernel s_memtime stamps of one k_pfn_rows wave (build: csrc/build_variant.sh prstamp "-DPR_STAMP=<workgroup>"): shader cycles per phase,
-summed over the wave's tiles.  usage: stamp_pfn_rows.py [frames=4] [agents=6] [dense=1].  Diagnostic tool, not part of the product path."""
+summed over the wave's tiles.  usage: stamp_pfn_rows.py [frames=4] [agents=6] [dense=1] [dist=uniform|ring].  Diagnostic tool, not part of the product path."""
 import ctypes
 import os
 import sys
@@ -16,8 +16,9 @@ from pcp_amd import ops, synth  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 agents = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dense = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+dist = sys.argv[4] if len(sys.argv) > 4 else 'uniform'
 d = torch.device('cuda:0')
-frames = [np.concatenate([synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b) for a in range(agents)], 0) for b in range(B)]
+frames = [np.concatenate([synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b, dist=dist) for a in range(agents)], 0) for b in range(B)]
 pts = torch.from_numpy(synth.collate(frames)).to(d)
 grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], B)
 w0 = torch.randn(32, 11, device=d) * 0.1
@@ -41,3 +42,13 @@ for rep in range(4):
     tot = sum(buf[k] for k in range(6))
     print('rep %d: %.1f us, %d tiles of the stamped wave, %d cycles per tile: ' % (rep, e0.elapsed_time(e1) * 1e3, tiles, tot // tiles)
           + '  '.join('%s %d' % (names[k], buf[k] // tiles) for k in range(6)))
+
+# every wave's cycles in its three parts (tiles | singles | canvas fill): how even is the work?
+wc = (ctypes.c_ulonglong * (4096 * 3))()
+raw.pcp_debug_read_pfn_wave_cycles(wc, 4096 * 3 * 8)
+w = np.array(list(wc), dtype=np.float64).reshape(4096, 3)
+w = w[w.sum(1) > 0]
+tot = w.sum(1)
+print('%d waves: cycles per wave min %.0f  median %.0f  mean %.0f  p99 %.0f  max %.0f   (tiles mean %.0f max %.0f | singles mean %.0f max %.0f | fill mean %.0f max %.0f)'
+      % (w.shape[0], tot.min(), np.median(tot), tot.mean(), np.percentile(tot, 99), tot.max(), w[:, 0].mean(), w[:, 0].max(), w[:, 1].mean(), w[:, 1].max(),
+         w[:, 2].mean(), w[:, 2].max()))

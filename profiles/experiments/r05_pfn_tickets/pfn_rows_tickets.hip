@@ -42,6 +42,7 @@ struct PrParams {
   const int *counters;                          // P, N'
   const int *cell_rank;                         // canvas mode: occupancy of the cells between this wave's pillars
   const int4 *crowd_list;                       // pillars of many records {first slot, records, rank, canvas row}; counters[4] of them (k_pfn_crowd)
+  int *tickets;                                 // 8 chunk counters (one per XCD, 64 bytes apart) + waves done at [128], or null (equal runs); zero between launches
   const float *w0, *b0, *w1, *b1;
   float *pillar_features;                       // (P, 64) or null
   float *canvas;                                // (B, ny, nx, 64) or null
@@ -178,12 +179,61 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   const cint_p desc_c = (cint_p)(unsigned long long)p.tile_desc;
   const cint_p rows_c = (cint_p)(unsigned long long)p.srows;
 
-  // a wave owns a CONTIGUOUS run of work units: wave tiles first, then the units of singles
-  const int n_units = n_tiles + n_sing;
+  // Work distribution.  Half of a wave's even share of the tiles is its own contiguous run -- nothing in front of its first record load, no
+  // draw until that run ends -- and the other half of the tiles is dealt out in chunks of four from ticket counters: the waves that got
+  // cheap tiles take more of them.  (Equal contiguous runs alone -- the form without `tickets` -- leave the slowest wave at 1.16 x the mean
+  // on a uniform cloud and 1.8 x on a LiDAR-like one, where the tiles of the medium-sized pillars pay 16-way LDS atomics:
+  // tools/stamp_pfn_rows.py.)  Eight counters, one per XCD's workgroups, on lines of their own, chunks interleaved over them: thousands of
+  // draws on ONE address cost more than the imbalance (+ 64 us on the uniform 6-agent cloud).  The draw for the next chunk is issued at the
+  // top of a tile and read behind that tile's own vmcnt(0), so it is never waited for.  The singles keep equal runs (they cost the same).
+  constexpr int CH_T = 4, BIG = 0x7fffffff, TK_STRIDE = 16, TK_DONE = 8 * TK_STRIDE;
   const int n_waves = gridDim.x * 4;
-  const int per_wave = (n_units + n_waves - 1) / n_waves;
-  const int u_begin = (blockIdx.x * 4 + wave) * per_wave;
-  const int u_end = min(u_begin + per_wave, n_units);
+  const int gw = blockIdx.x * 4 + wave;
+  const bool dyn = p.tickets != nullptr;
+  const int xcd = blockIdx.x & 7;
+  struct Stream {
+    int cur, end, next, raw;          // ids [cur, end) of the chunk in hand; base of the next chunk (-1: not drawn yet); the draw's return
+    int dyn_base;                     // first tile of the dealt-out half
+    bool pending;
+  };
+  auto stream_init = [&](Stream &st, int n_items) {
+    const int per = (n_items + n_waves - 1) / n_waves;
+    const int own = dyn ? max((per + 1) / 2, 1) : per;          // the wave's own run
+    st.cur = gw * own;
+    st.end = min(st.cur + own, dyn ? n_waves * own : n_items);
+    st.dyn_base = n_waves * own;
+    st.next = dyn ? -1 : BIG;
+    st.raw = 0;
+    st.pending = false;
+  };
+  auto stream_next = [&](Stream &st, int n_items) -> int {               // the wave's next item id, BIG behind the last one
+    if (st.cur >= st.end) {
+      if (st.next == BIG || st.next < 0) return BIG;                     // (next < 0 cannot happen: a draw is resolved a tile after it is issued)
+      st.cur = st.next;
+      st.end = st.next + CH_T;
+      st.next = -1;
+    }
+    if (st.cur >= n_items) {                                              // tickets only grow: nothing this wave can still draw is in range
+      st.cur = st.end = 0;
+      st.next = BIG;
+      return BIG;
+    }
+    return st.cur++;
+  };
+  auto stream_draw = [&](Stream &st) {                                    // ask for the next chunk (lane 0 draws; the value is read later)
+    if (dyn && st.next == -1 && !st.pending && st.end - st.cur <= 3) {
+      int v = 0;
+      if (lane == 0) v = __hip_atomic_fetch_add(&p.tickets[xcd * TK_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st.raw = v;
+      st.pending = true;
+    }
+  };
+  auto stream_resolve = [&](Stream &st) {
+    if (st.pending) {
+      st.next = st.dyn_base + (__builtin_amdgcn_readfirstlane(st.raw) * 8 + xcd) * CH_T;
+      st.pending = false;
+    }
+  };
 
   auto first_slot = [&](int t) -> int {                        // first record of wave tile t; tiles past the multi-point records: Nm
     if (t == 0) return 0;
@@ -251,9 +301,21 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 #endif
 
   // =================================== wave tiles over the records of multi-point pillars ===================================================
-  const int t_begin = u_begin, t_end = min(u_end, n_tiles);
-  if (t_begin < t_end) {
-    int acur = first_slot(t_begin), anext = first_slot(t_begin + 1), ann = first_slot(t_begin + 2);
+  Stream ts;
+  stream_init(ts, n_tiles);
+  auto span = [&](int q, int &a, int &b) {                     // records [a, b) of wave tile q
+    a = b = Nm;
+    if (q != BIG) {
+      a = first_slot(q);
+      b = first_slot(q + 1);
+    }
+  };
+  int q0 = stream_next(ts, n_tiles), q1 = stream_next(ts, n_tiles), q2 = stream_next(ts, n_tiles);
+  if (q0 != BIG) {
+    int a0, b0, a1, b1, a2, b2;
+    span(q0, a0, b0);
+    span(q1, a1, b1);
+    span(q2, a2, b2);
     Rec bufa[NPRE], bufb[NPRE];
 #pragma unroll
     for (int j = 0; j < NPRE; j++) {
@@ -261,14 +323,20 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
       bufa[j].q = bufb[j].q = f32x4{0.f, 0.f, 0.f, 0.f};
       bufa[j].e4 = bufa[j].e5 = bufa[j].e6g = bufa[j].e10 = bufb[j].e4 = bufb[j].e5 = bufb[j].e6g = bufb[j].e10 = 0.f;
     }
-    load_recs(bufa, acur, anext);
+    load_recs(bufa, a0, b0);
+#ifdef PR_STAMP
+    int tiles_done = 0;
+#endif
 
     // one tile; `cur` holds its first 32 records, `nxt` receives the next tile's (the caller alternates the two buffers: no register copies)
-    auto tile_body = [&](int t, Rec (&cur)[NPRE], Rec (&nxt)[NPRE]) {
-      const int a = acur, bslot = anext;
-      // ---- prefetch: the next tile's records (its first slot arrived a tile ago), the first slot three tiles on
-      load_recs(nxt, bslot, ann);                              // behind the last tile: bslot == Nm, nothing is loaded
-      const int an3 = first_slot(t + 3);
+    auto tile_body = [&](Rec (&cur)[NPRE], Rec (&nxt)[NPRE]) {
+      const int a = a0, bslot = b0;
+      // ---- prefetch: the next tile's records (its span arrived a tile ago), the span of the tile three on, the ticket of the next chunk
+      load_recs(nxt, a1, b1);                                  // behind the last tile: a1 == b1 == Nm, nothing is loaded
+      const int q3 = stream_next(ts, n_tiles);
+      int a3, b3;
+      span(q3, a3, b3);
+      stream_draw(ts);
       PR_MARK(0);
 
       if (a < bslot) {
@@ -455,6 +523,7 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         // stores below (data-dependent loops), so any later wait on a load would be vmcnt(0) and would sit behind them.  From here to the
         // top of the next tile no vector load is waited for.
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        stream_resolve(ts);
         // ---- phase D: per 16 pillars: out = relu(b1 + W1[:, 32:] . xmax + dmax), 16-byte stores; the LDS words are reset as they are read ----
         for (int k = 0; k * 16 < np; k++) {
           const int lp = n + 16 * k;
@@ -507,15 +576,24 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 
         PR_MARK(4);
       }
+      stream_resolve(ts);                                      // a tile without records: no store is pending, the draw is all that is waited for
       PR_MARK(5);
-      acur = anext;
-      anext = ann;
-      ann = an3;
+      q0 = q1; q1 = q2; q2 = q3;
+      a0 = a1; b0 = b1;
+      a1 = a2; b1 = b2;
+      a2 = a3; b2 = b3;
+#ifdef PR_STAMP
+      tiles_done++;
+#endif
     };
-    for (int t = t_begin; t < t_end; t += 2) {
-      tile_body(t, bufa, bufb);
-      if (t + 1 < t_end) tile_body(t + 1, bufb, bufa);
+    while (q0 != BIG) {
+      tile_body(bufa, bufb);
+      if (q0 == BIG) break;
+      tile_body(bufb, bufa);
     }
+#ifdef PR_STAMP
+    if (stamp && lane == 0) pr_dbg[8] = (unsigned long long)tiles_done;
+#endif
   }
 
 #ifdef PR_STAMP
@@ -524,8 +602,10 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   // =================================== single-point pillars: 64 per unit, no per-pillar reduction ============================================
   // The only point of a pillar is its own mean (f_cluster = 0, exactly what scatter_mean of one value gives) and its own maximum:
   // out = relu(b1 + (W1[:, :32] + W1[:, 32:]) . relu(W0 f + b0)) -- one 32-deep product instead of two, no LDS traffic at all.
-  const int s_begin = max(u_begin, n_tiles) - n_tiles, s_end = u_end - n_tiles;
-  if (s_begin < s_end) {
+  const int s_per = (n_sing + n_waves - 1) / n_waves;
+  int u0 = gw * s_per;
+  const int u_end = min(u0 + s_per, n_sing);
+  if (u0 < u_end) {
     f32x4 w1c[4][2];
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -542,8 +622,9 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         if (slot < Nv) load_rec(dst[j], slot);
       }
     };
-    auto unit_body = [&](int unit, Rec (&cur)[4], Rec (&nxt)[4]) {
-      if (unit + 1 < s_end) load4(nxt, unit + 1);
+    auto unit_body = [&](Rec (&cur)[4], Rec (&nxt)[4]) {
+      const int unit = u0;
+      if (unit + 1 < u_end) load4(nxt, unit + 1);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const bool valid = Nm + 64 * unit + 16 * j + n < Nv;
@@ -573,11 +654,13 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
           }
         }
       }
+      u0 = unit + 1;
     };
-    load4(rec, s_begin);
-    for (int u = s_begin; u < s_end; u += 2) {
-      unit_body(u, rec, recn);
-      if (u + 1 < s_end) unit_body(u + 1, recn, rec);
+    load4(rec, u0);
+    while (u0 < u_end) {
+      unit_body(rec, recn);
+      if (u0 >= u_end) break;
+      unit_body(recn, rec);
     }
   }
 #ifdef PR_STAMP
@@ -623,6 +706,16 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
       }
     }
   }
+  // the last wave to get here leaves the counters at zero for the next launch on them (every wave has made its last draw before it counts
+  // itself done)
+  if (dyn && lane == 0) {
+    const int done = __hip_atomic_fetch_add(&p.tickets[TK_DONE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == n_waves - 1) {
+#pragma unroll
+      for (int x = 0; x < 8; x++) __hip_atomic_store(&p.tickets[x * TK_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.tickets[TK_DONE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 #ifdef PR_STAMP
   if (lane == 0 && blockIdx.x * 4 + wave < 4096) {
     const unsigned long long wave_t3 = __builtin_amdgcn_s_memtime();
@@ -633,7 +726,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   }
   if (stamp && lane == 0) {
     for (int k = 0; k < 8; k++) pr_dbg[k] = st_acc[k];
-    pr_dbg[8] = (unsigned long long)max(min(u_end, n_tiles) - u_begin, 0);
   }
 #endif
 }
@@ -838,9 +930,10 @@ extern "C" int pcp_debug_read_pfn_wave_cycles(void *dst, size_t bytes) {
 }
 #endif
 
-extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
-                            const float *w1, const float *b1, float *pillar_features, float *canvas, void *stream_) {
+static int pfn_rows_impl(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
+                         const float *w1, const float *b1, float *pillar_features, float *canvas, int32_t *tickets, void *stream_) {
   if (!grid || !workspace || !w0 || !b0 || !w1 || !b1 || n < 0) return PCP_ERR_ARG;
+  if (((uintptr_t)tickets) & 3) return PCP_ERR_ARG;
   if ((((uintptr_t)w1) & 15) || (((uintptr_t)b1) & 15) || (((uintptr_t)pillar_features) & 15) || (((uintptr_t)canvas) & 15)) return PCP_ERR_ARG;
   if (grid->batch_size <= 0 || grid->nx <= 0 || grid->ny <= 0 || grid->nx > 65535 || grid->ny > 65535) return PCP_ERR_ARG;
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
@@ -854,6 +947,7 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   p.counters = (const int *)(ws + R.v.counters);
   p.cell_rank = (const int *)(ws + R.v.cell_rank);
   p.crowd_list = (const int4 *)(ws + R.crowd_list);
+  p.tickets = tickets;
   p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
   p.pillar_features = pillar_features;
   p.canvas = canvas;
@@ -894,4 +988,15 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   }
   PCP_CHECK_LAUNCH();
   return PCP_OK;
+}
+
+extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
+                            const float *w1, const float *b1, float *pillar_features, float *canvas, void *stream) {
+  return pfn_rows_impl(grid, workspace, n, num_raw, w0, b0, w1, b1, pillar_features, canvas, nullptr, stream);
+}
+
+extern "C" int pcp_pfn_rows_balanced(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
+                                     const float *w1, const float *b1, float *pillar_features, float *canvas, int32_t *tickets, void *stream) {
+  if (!tickets) return PCP_ERR_ARG;
+  return pfn_rows_impl(grid, workspace, n, num_raw, w0, b0, w1, b1, pillar_features, canvas, tickets, stream);
 }
