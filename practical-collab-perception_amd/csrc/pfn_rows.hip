@@ -33,7 +33,6 @@ namespace {
 
 constexpr int PR_THREADS = 256;                 // four independent waves; the workgroup exists only to share the launch
 constexpr int PR_T = PCP_PFN_TILE;
-constexpr int PR_GRP = 4;                      // column tiles past a tile's first 32 slots are loaded this many at a time
 constexpr int PR_MAXP = 32;                     // pillars per wave tile (<= PR_T: every owned pillar starts at a different slot of the window)
 
 struct PrParams {
@@ -248,6 +247,7 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   unsigned long long wave_t1 = wave_t0, wave_t2 = wave_t0;
   const bool stamp = blockIdx.x == PR_STAMP && wave == 0;
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  int st_cols = 0, st_pillars = 0;
 #endif
 
   // =================================== wave tiles over the records of multi-point pillars ===================================================
@@ -276,10 +276,12 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         // local pillar index of every record: the number of pillar heads (rank differs from the record in front) up to it.  The ranks of
         // a tile are not consecutive (single-point pillars lie between them in rank order), the records are.
         int heads = 0, last_rank = -1;
+        unsigned head_mask = 0;                                  // heads of the column tile local_pillar saw last
         auto local_pillar = [&](const Rec &r, bool valid) -> int {
           const int rk = __float_as_int(r.q.y);
           const int prev = __builtin_amdgcn_update_dpp(last_rank, rk, 0x111, 0xf, 0xf, false);      // row_shr:1, lane n = 0 keeps last_rank
           const unsigned long long hm = __ballot(valid && rk != prev) & 0xffffULL;                    // row g = 0 (all four rows agree)
+          head_mask = (unsigned)hm;
           const int lp = heads + __builtin_popcountll(hm & ((2ULL << n) - 1ULL)) - 1;
           heads += __builtin_popcountll(hm);
           last_rank = __builtin_amdgcn_readlane(rk, 15);
@@ -301,9 +303,36 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
           last_rank = rk0;
           return (tgt - a) / 16 - 1;
         };
+        // The column tiles past a tile's first 32 slots (pillars longer than the window), one per trip of ONE loop (the code of a column tile
+        // exists once: unrolled groups of four had grown the kernel to 95 KB, past the 64 KB instruction cache); the next column tile's
+        // records are requested before the current one is worked on.  col(rec, j) handles one column tile and returns crowd_jump's answer.
+        auto load_col = [&](Rec &r, int j) {
+          const int slot = a + 16 * j + n;
+          load_rec(r, slot < bslot ? slot : bslot - 1);
+        };
+        auto walk_cols = [&](auto &&col) {
+          if (NPRE >= ncol) return;
+          Rec rc, rn;
+          int j = NPRE;
+          load_col(rc, j);
+          rn = rc;
+          while (true) {
+            if (j + 1 < ncol) load_col(rn, j + 1);
+            const int jn = col(rc, j);
+            const int next = jn + 1;
+            if (next >= ncol) break;
+            if (jn != j) load_col(rn, next);                     // a jump over a crowded pillar: the prefetched column tile is not the next one
+            rc = rn;
+            j = next;
+          }
+        };
         int lpj[NPRE];
+        bool onej[NPRE];                                         // the column tile holds records of ONE pillar (no head behind lane 0)
 #pragma unroll
-        for (int j = 0; j < NPRE; j++) lpj[j] = (j < ncol) ? local_pillar(cur[j], rec_ok(cur[j], a + 16 * j + n)) : 0;
+        for (int j = 0; j < NPRE; j++) {
+          lpj[j] = (j < ncol) ? local_pillar(cur[j], rec_ok(cur[j], a + 16 * j + n)) : 0;
+          onej[j] = (head_mask & 0xfffeu) == 0;
+        }
 
         // ---- phase A: fixed-point xyz sums and the point count of every pillar ---------------------------------------------------------
         auto phase_a = [&](const Rec &r, int lp) {
@@ -316,35 +345,14 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         {
           // crowded tiles: the records past the first 32 slots are read where they are used (twice: here and in phase C)
           const int heads0 = heads, last0 = last_rank;
-          // four column tiles per trip: their loads are issued together (one tile per trip left every load's latency exposed -- LiDAR-like
-          // clouds, where a third of the records sit past their tile's first 32 slots, ran at a quarter of the uniform cloud's rate)
-          for (int j0 = NPRE; j0 < ncol;) {
-            Rec rg[PR_GRP];
-#pragma unroll
-            for (int u = 0; u < PR_GRP; u++) {
-              const int slot = a + 16 * (j0 + u) + n;
-              load_rec(rg[u], slot < bslot ? slot : bslot - 1);
-            }
-            int next = j0 + PR_GRP;
-            bool jumped = false;
-#pragma unroll
-            for (int u = 0; u < PR_GRP; u++) {
-              const int j = j0 + u;
-              if (!jumped && j < ncol) {
-                const bool in = a + 16 * j + n < bslot;
-                const int rk = __float_as_int(rg[u].q.y);
-                const bool valid = in && rk >= 0;
-                const int lp = local_pillar(rg[u], valid);
-                if (valid) phase_a(rg[u], lp);
-                const int jn = crowd_jump(j, rk, in);
-                if (jn != j) {
-                  next = jn + 1;
-                  jumped = true;
-                }
-              }
-            }
-            j0 = next;
-          }
+          walk_cols([&](const Rec &r, int j) -> int {
+            const bool in = a + 16 * j + n < bslot;
+            const int rk = __float_as_int(r.q.y);
+            const bool valid = in && rk >= 0;
+            const int lp = local_pillar(r, valid);
+            if (valid) phase_a(r, lp);
+            return crowd_jump(j, rk, in);
+          });
           if (ncol > NPRE) {                                   // phase C walks the same records again from the same state
             heads = heads0;
             last_rank = last0;
@@ -382,14 +390,55 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         PR_MARK(2);
         // ---- phase C: per 16 points: features -> layer 0 -> running max -> point half of layer 1 -> running max --------------------------
         int *pinfo = reinterpret_cast<int *>(sum) + PR_MAXP * 4;     // [pillar][4] ints in the upper half of the sums' memory: rank, canvas row
-        auto phase_c = [&](const Rec &rr, int lp, bool valid) {
+        // maxima over the 16 lanes of a row (the 16 points of a column tile) by four rotations, eight values at a time: v = max(ror(v), v) as
+        // ONE v_max_f32_dpp per value and step (the compiler's form of the same is five instructions and a hazard nop), the eight values
+        // interleaved so that a value's next step sits eight instructions behind its last write (DPP reads need two wait states)
+#define PR_ROR8(N)                                                                                                     \
+  asm volatile("v_max_f32_dpp %0, %0, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %1, %1, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %2, %2, %2 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %3, %3, %3 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %4, %4, %4 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %5, %5, %5 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %6, %6, %6 row_ror:" #N " row_mask:0xf bank_mask:0xf\n\t"                               \
+               "v_max_f32_dpp %7, %7, %7 row_ror:" #N " row_mask:0xf bank_mask:0xf"                                    \
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
+        auto row_max8 = [&](float (&v)[8]) {
+          asm volatile("s_nop 1" ::: "memory");
+          PR_ROR8(8);
+          PR_ROR8(4);
+          PR_ROR8(2);
+          PR_ROR8(1);
+        };
+        // `one` (wave uniform): every record of the column tile belongs to one pillar -- its 16 lanes would hit each LDS word of the running
+        // maxima 16 at a time (serialised: the tiles of a LiDAR-like cloud's medium-sized pillars ran at a third of the rate); the maxima are
+        // taken across the lanes first and lane 0 of each row alone goes to the LDS
+        auto phase_c = [&](const Rec &rr, int lp, bool valid, bool one) {
           const int col = (lp + skew) & 31;
           float *xb = xmax + (4 * g) * 32 + col, *db = dmax + (4 * g) * 32 + col;     // + compile-time offsets per (block, i)
           if (g == 3 && valid) *reinterpret_cast<float2 *>(&pinfo[lp * 4]) = make_float2(rr.q.y, rr.q.w);   // every point of the pillar writes the same pair
           const float mean = meanf[lp * 4 + acol];
           f32x4a x0, x1;
           layer0(rr, __fsub_rn(rr.a, mean), x0, x1);
-          if (valid) {
+#ifdef PR_DIAG_NO_CMAX
+          if (x0[0] == 1.2345e30f)                               // timing-only build: never true, keeps the arithmetic
+#endif
+          if (one) {
+            float m[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              m[i] = valid ? x0[i] : 0.f;
+              m[4 + i] = valid ? x1[i] : 0.f;
+            }
+            row_max8(m);
+            if (valid && n == 0) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                __hip_atomic_fetch_max(&xb[i * 32], m[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&xb[(16 + i) * 32], m[4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          } else if (valid) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
               __hip_atomic_fetch_max(&xb[i * 32], x0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -408,7 +457,28 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
           for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][1][i], x1[i], dacc[r]);
-          if (valid) {
+#ifdef PR_DIAG_NO_CMAX
+          if (dacc[0][0] == 1.2345e30f)
+#endif
+          if (one) {
+#pragma unroll
+            for (int rh = 0; rh < 2; rh++) {
+              float m[8];
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                m[i] = valid ? dacc[2 * rh][i] : -__builtin_inff();
+                m[4 + i] = valid ? dacc[2 * rh + 1][i] : -__builtin_inff();
+              }
+              row_max8(m);
+              if (valid && n == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                  __hip_atomic_fetch_max(&db[(16 * (2 * rh) + i) * 32], m[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __hip_atomic_fetch_max(&db[(16 * (2 * rh + 1) + i) * 32], m[4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              }
+            }
+          } else if (valid) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -418,35 +488,22 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         };
 #pragma unroll
         for (int j = 0; j < NPRE; j++)
-          if (j < ncol) phase_c(cur[j], lpj[j], rec_ok(cur[j], a + 16 * j + n));
-        for (int j0 = NPRE; j0 < ncol;) {
-          Rec rg[PR_GRP];
-#pragma unroll
-          for (int u = 0; u < PR_GRP; u++) {
-            const int slot = a + 16 * (j0 + u) + n;
-            load_rec(rg[u], slot < bslot ? slot : bslot - 1);
-          }
-          int next = j0 + PR_GRP;
-          bool jumped = false;
-#pragma unroll
-          for (int u = 0; u < PR_GRP; u++) {
-            const int j = j0 + u;
-            if (!jumped && j < ncol) {
-              const bool in = a + 16 * j + n < bslot;
-              const int rk = __float_as_int(rg[u].q.y);
-              const bool valid = in && rk >= 0;
-              const int lp = local_pillar(rg[u], valid);
-              const int jn = crowd_jump(j, rk, in);
-              if (jn == j) {
-                phase_c(rg[u], lp, valid);                      // a column inside a crowded pillar does no arithmetic at all
-              } else {
-                next = jn + 1;
-                jumped = true;
-              }
-            }
-          }
-          j0 = next;
+          if (j < ncol) phase_c(cur[j], lpj[j], rec_ok(cur[j], a + 16 * j + n), onej[j]);
+        walk_cols([&](const Rec &r, int j) -> int {
+          const bool in = a + 16 * j + n < bslot;
+          const int rk = __float_as_int(r.q.y);
+          const bool valid = in && rk >= 0;
+          const int lp = local_pillar(r, valid);
+          const int jn = crowd_jump(j, rk, in);
+          if (jn == j) phase_c(r, lp, valid, (head_mask & 0xfffeu) == 0);      // (a column inside a crowded pillar does no arithmetic at all)
+          return jn;
+        });
+#ifdef PR_STAMP
+        if (stamp) {
+          st_cols += ncol;
+          st_pillars += heads;
         }
+#endif
         const int np = heads;                                  // pillars of the tile (<= PR_T: each starts at another slot of the window)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -512,9 +569,11 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
       anext = ann;
       ann = an3;
     };
-    for (int t = t_begin; t < t_end; t += 2) {
+    // ONE copy of the tile's code (alternating the two record buffers between two copies doubled the kernel; the copy below is 10 - 18 moves)
+    for (int t = t_begin; t < t_end; t++) {
       tile_body(t, bufa, bufb);
-      if (t + 1 < t_end) tile_body(t + 1, bufb, bufa);
+#pragma unroll
+      for (int j = 0; j < NPRE; j++) bufa[j] = bufb[j];
     }
   }
 
@@ -633,6 +692,8 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   }
   if (stamp && lane == 0) {
     for (int k = 0; k < 8; k++) pr_dbg[k] = st_acc[k];
+    pr_dbg[9] = (unsigned long long)st_cols;
+    pr_dbg[10] = (unsigned long long)st_pillars;
     pr_dbg[8] = (unsigned long long)max(min(u_end, n_tiles) - u_begin, 0);
   }
 #endif

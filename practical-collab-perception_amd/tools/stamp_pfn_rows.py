@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 PKG = Path(__file__).resolve().parent.parent
-os.environ['PCP_HIP_LIB'] = str(PKG / 'lib' / 'variants' / 'libpcp_hip_prstamp.so')
+os.environ['PCP_HIP_LIB'] = str(PKG / 'lib' / 'variants' / ('libpcp_hip_prstamp%s.so' % os.environ.get('PCP_STAMP_VARIANT', '')))
 sys.path.insert(0, str(PKG))
 from pcp_amd import ops, synth  # noqa: E402
 
@@ -41,7 +41,7 @@ for rep in range(4):
     tiles = max(int(buf[8]), 1)
     tot = sum(buf[k] for k in range(6))
     print('rep %d: %.1f us, %d tiles of the stamped wave, %d cycles per tile: ' % (rep, e0.elapsed_time(e1) * 1e3, tiles, tot // tiles)
-          + '  '.join('%s %d' % (names[k], buf[k] // tiles) for k in range(6)))
+          + '  '.join('%s %d' % (names[k], buf[k] // tiles) for k in range(6)) + '   [%d column tiles, %d pillars in those tiles]' % (buf[9], buf[10]))
 
 # every wave's cycles in its three parts (tiles | singles | canvas fill): how even is the work?
 wc = (ctypes.c_ulonglong * (4096 * 3))()
@@ -52,3 +52,6 @@ tot = w.sum(1)
 print('%d waves: cycles per wave min %.0f  median %.0f  mean %.0f  p99 %.0f  max %.0f   (tiles mean %.0f max %.0f | singles mean %.0f max %.0f | fill mean %.0f max %.0f)'
       % (w.shape[0], tot.min(), np.median(tot), tot.mean(), np.percentile(tot, 99), tot.max(), w[:, 0].mean(), w[:, 0].max(), w[:, 1].mean(), w[:, 1].max(),
          w[:, 2].mean(), w[:, 2].max()))
+w0 = np.array(list(wc), dtype=np.float64).reshape(4096, 3)[::4]          # wave 0 of every workgroup: the one a -DPR_STAMP=<wg> build stamps
+order = np.argsort(-w0[:, 0])
+print('workgroups whose wave 0 spends most cycles in its tiles:', [(int(i), int(w0[i, 0])) for i in order[:6]], ' median', int(np.median(w0[w0[:, 0] > 0, 0])))
