@@ -923,7 +923,10 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   p.n_tiles_max = (int)(n / PR_T + 1);
   magic_div((unsigned)(grid->nx * grid->ny), &p.plane_m, &p.plane_sh);
   magic_div((unsigned)grid->ny, &p.ny_m, &p.ny_sh);
-  static const int wps = [] { const char *e = getenv("PCP_PFN_WPS"); return e ? atoi(e) : 2; }();     // A/B knob (tools/bench_frontend.py)
+  // waves per SIMD the build is held to: three fit since the kernel shrank to 168 registers (5 raw columns; 11 would spill) and pay on the
+  // large clouds (-3 % at 1.2 - 1.4 M points, -6 % on the LiDAR-like one), two stay better on small ones (+7 % at 240 k); PCP_PFN_WPS overrides
+  static const int wps_env = [] { const char *e = getenv("PCP_PFN_WPS"); return e ? atoi(e) : 0; }();
+  const int wps = wps_env ? wps_env : ((num_raw <= 5 && n >= 600000) ? 3 : 2);
   int blocks = (p.n_tiles_max + 3) / 4;
   if (canvas) {                                 // the waves also share the canvas's empty cells: at most ~512 cells each, however small the cloud
     const int64_t by_cells = (cells + 4 * 512 - 1) / (4 * 512);
