@@ -81,7 +81,7 @@ static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
 //                              written for every t with 0 < T t <= N' (entry 0 is {0, 0})
 //   crowd_list int4  [n/64 + 2] pillars of at least `crowd` records (default PCP_PFN_CROWD; counters[4] of them, in no particular order):
 //                              {first slot, records, pillar rank, canvas row}.  Their records carry the rank with the sign bit set: the wave
-//                              tiles of pcp_pfn_rows pass over them and a workgroup per pillar (k_pfn_crowd) runs them instead -- one wave
+//                              tiles of pcp_pfn_rows pass over them and a workgroup per pillar (pfn_crowd_run, the front workgroups of k_pfn_rows) runs them instead -- one wave
 //                              would otherwise walk thousands of records alone (LiDAR-like clouds: the cells next to the sensor)
 constexpr int PCP_PFN_TILE = 30;
 constexpr int PCP_PFN_CROWD = 192;              // default threshold; PCP_PFN_CROWD in the environment overrides (>= 64; 0 = never)

@@ -18,7 +18,7 @@
 //     on a spare feature slot; a lane ends with four consecutive channels of one pillar: 16-byte stores;
 //   * dense canvas: every wave also zero-fills the EMPTY cells of an equal slice of the cell -> rank table (last in its work), so the canvas
 //     is written exactly once -- no clear-by-list pass, no zero fill;
-//   * pillars of >= 192 records (LiDAR-like clouds: the cells next to the sensor) are passed over by the wave tiles and run by k_pfn_crowd
+//   * pillars of >= 192 records (LiDAR-like clouds: the cells next to the sensor) are passed over by the wave tiles and run by pfn_crowd_run
 //     below, a workgroup per pillar (bit-identical results).
 // Order independence (bitwise reproducible results whatever the arrival order inside a pillar): means accumulate in 2^-24 fixed point
 // (integer adds commute), maxima are order independent, every per-point product has a fixed summation order.
@@ -40,13 +40,14 @@ struct PrParams {
   const int2 *tile_desc;
   const int *counters;                          // P, N'
   const int *cell_rank;                         // canvas mode: occupancy of the cells between this wave's pillars
-  const int4 *crowd_list;                       // pillars of many records {first slot, records, rank, canvas row}; counters[4] of them (k_pfn_crowd)
+  const int4 *crowd_list;                       // pillars of many records {first slot, records, rank, canvas row}; counters[4] of them (pfn_crowd_run)
   const float *w0, *b0, *w1, *b1;
   float *pillar_features;                       // (P, 64) or null
   float *canvas;                                // (B, ny, nx, 64) or null
   pcp_grid_t g;
   long long cells;
   int n_tiles_max;                              // tiles the host sized the grid for (ceil(n / T) + 1)
+  int crowd_blocks;                             // workgroups at the front of the grid that run the crowded pillars
   unsigned long long plane_m, ny_m;             // exact division of a cell id (< 2^31) by nx * ny and by ny: (c * m) >> sh
   int plane_sh, ny_sh;
 };
@@ -114,6 +115,213 @@ __device__ unsigned long long pr_wave_cycles[4096 * 3];        // per wave of th
 #define PR_MARK(k) do {} while (0)
 #endif
 
+// ---- crowded pillars: one workgroup per pillar ------------------------------------------------------------------------------------------------
+// A LiDAR-like cloud puts hundreds to thousands of points into the cells next to the sensor.  The wave that owns such a pillar in k_pfn_rows
+// would walk all of its records alone (5 000 records = 312 column tiles ~ 0.2 ms on one wave while the chip is done).  The pillariser lists
+// every pillar of at least `crowd` records (default PCP_PFN_CROWD = 192) and tags its records; the wave tiles pass over them; the FIRST
+// workgroups of k_pfn_rows' own grid (they start first and run beside the tile workgroups: as a launch of its own behind the tiles the same
+// work cost 94 us on the 6-agent ring cloud, next to 135 us for all the tiles) take them instead, the four waves of a workgroup sharing a
+// pillar's column tiles: fixed-point sums -> mean (one barrier), then features -> layer 0 -> point half of
+// layer 1 with the running maxima kept in REGISTERS across the tiles (every record is the same pillar: no LDS atomics per point), one
+// cross-lane + cross-wave reduction at the end, the pillar half of layer 1 on wave 0.  Same operations in the same order per point, exact
+// integer sums, order-free maxima: BIT-identical to what the owner wave of k_pfn_rows computes for the same pillar.
+// worker = index of this workgroup among the n_workers crowd workgroups; PC_WAVES waves each; the shared words are the caller's
+template <int NUM_RAW, int PC_WAVES>
+__device__ __forceinline__ void pfn_crowd_run(const PrParams &p, int worker, int n_workers, unsigned long long *s_sum, float *s_mean, float *s_x,
+                                              float *s_d) {
+  constexpr int RS = NUM_RAW <= 5 ? 8 : 16;
+  constexpr int S0 = l0_steps<NUM_RAW>();
+  constexpr int F = NUM_RAW + 6;
+  const int n_crowd = p.counters[4];
+  if (worker >= n_crowd) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  float w0f[2][S0];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int s = 0; s < S0; s++) {
+      const int fi = feat_index<NUM_RAW>(s, g);
+      w0f[b][s] = fi >= 0 ? p.w0[(16 * b + n) * F + fi] : (fi == -2 ? p.b0[16 * b + n] : 0.f);
+    }
+  f32x4 w1a[4][2], w1b[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const float *wr = p.w1 + (16 * r + n) * 64 + 16 * b + 4 * g;
+      w1a[r][b] = *reinterpret_cast<const f32x4 *>(wr);
+      w1b[r][b] = *reinterpret_cast<const f32x4 *>(wr + 32);
+    }
+  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
+  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
+  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
+  const float vsel = g == 0 ? p.g.voxel_x : (g == 1 ? p.g.voxel_y : 0.f);
+  const float osel = g == 0 ? x_off : (g == 1 ? y_off : z_off);
+  const int acol = g < 3 ? g : 3;
+
+  for (int e = worker; e < n_crowd; e += n_workers) {
+    const int4 ent = p.crowd_list[e];
+    const int start = ent.x, cnt = ent.y;
+    const int ncol = (cnt + 15) >> 4;
+    if (tid < 4) s_sum[tid] = 0ULL;
+    if (tid < 32) s_x[tid] = 0.f;
+    if (tid < 64) s_d[tid] = -__builtin_inff();
+    __syncthreads();
+    // ---- fixed-point sums of x, y, z (the count is known) -> mean, exactly the arithmetic of k_pfn_rows' phases A and B ---------------------
+    {
+      long long part = 0;
+      if (g < 3)
+        for (int j0 = wave; j0 < ncol; j0 += 4 * PC_WAVES) {                 // four loads in flight per lane
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int slot = start + 16 * (j0 + u * PC_WAVES) + n;
+            v[u] = slot < start + cnt ? p.srows[(long long)slot * RS + g] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (start + 16 * (j0 + u * PC_WAVES) + n < start + cnt) part += fixed24(v[u]);
+        }
+      if (g < 3) __hip_atomic_fetch_add(&s_sum[g], (unsigned long long)part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (tid < 3) {
+      const double c = (double)(unsigned)cnt, sd = (double)(long long)s_sum[tid] * (1.0 / 16777216.0);
+      double rc = __builtin_amdgcn_rcp(c);
+      rc = __builtin_fma(__builtin_fma(-c, rc, 1.0), rc, rc);
+      double qd = sd * rc;
+      qd = __builtin_fma(__builtin_fma(-c, qd, sd), rc, qd);
+      s_mean[tid] = (float)qd;
+    }
+    __syncthreads();
+    const float mean = s_mean[acol < 3 ? acol : 0];
+    // ---- per 16 points: features -> layer 0 -> point half of layer 1; maxima in registers --------------------------------------------------
+    float xm0[4] = {0.f, 0.f, 0.f, 0.f}, xm1[4] = {0.f, 0.f, 0.f, 0.f};
+    float dm[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) dm[r][i] = -__builtin_inff();
+    // the record of the wave's next column tile is requested before the current one is worked on
+    struct CRec { float av; f32x4 q; float e4, e5, e6g, e10; };
+    auto crec_load = [&](CRec &r, int j) {
+      const int slot = start + 16 * j + n;
+      const float *src = p.srows + (long long)(slot < start + cnt ? slot : start + cnt - 1) * RS;
+      r.av = src[acol];
+      r.q = *reinterpret_cast<const f32x4 *>(src + RS - 4);
+      r.e4 = r.e5 = r.e6g = r.e10 = 0.f;
+      if (RS == 16) {
+        r.e4 = src[4];
+        r.e5 = src[5];
+        r.e6g = src[6 + g];
+        r.e10 = src[10];
+      }
+    };
+    CRec rcur, rnext;
+    if (wave < ncol) crec_load(rcur, wave);
+    rnext = rcur;
+    for (int j = wave; j < ncol; j += PC_WAVES) {
+      if (j + PC_WAVES < ncol) crec_load(rnext, j + PC_WAVES);
+      const bool valid = start + 16 * j + n < start + cnt;
+      const float av = rcur.av;
+      const f32x4 q = rcur.q;
+      const float e4 = rcur.e4, e5 = rcur.e5, e6g = rcur.e6g, e10 = rcur.e10;
+      const int cxcy = __float_as_int(q.z);
+      const float cf = (float)(g == 0 ? (cxcy >> 16) : (cxcy & 0xffff));
+      const float centre = __fadd_rn(__fmul_rn(cf, vsel), osel);
+      const float cluster = __fsub_rn(av, mean);
+      float f[S0];
+      const float raw4 = RS == 8 ? q.x : e4;
+      f[0] = (g < 3 || NUM_RAW > 3) ? av : 1.f;
+      f[1] = g < 3 ? cluster : (NUM_RAW > 4 ? raw4 : (NUM_RAW > 3 ? 1.f : 0.f));
+      f[2] = g < 3 ? __fsub_rn(av, centre) : (NUM_RAW > 5 ? e5 : (NUM_RAW > 4 ? 1.f : 0.f));
+      if (S0 > 3) f[3] = e6g;
+      if (S0 > 4) f[4] = g == 0 ? e10 : (g == 1 ? 1.f : 0.f);
+      f32x4a x0 = f32x4a{0.f, 0.f, 0.f, 0.f}, x1 = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < S0; s++) {
+        x0 = mfma16(w0f[0][s], f[s], x0);
+        x1 = mfma16(w0f[1][s], f[s], x1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        x0[i] = relu_f(x0[i]);
+        x1[i] = relu_f(x1[i]);
+      }
+      f32x4a dacc[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) dacc[r] = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][0][i], x0[i], dacc[r]);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][1][i], x1[i], dacc[r]);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          xm0[i] = fmaxf(xm0[i], x0[i]);
+          xm1[i] = fmaxf(xm1[i], x1[i]);
+#pragma unroll
+          for (int r = 0; r < 4; r++) dm[r][i] = fmaxf(dm[r][i], dacc[r][i]);
+        }
+      }
+      rcur = rnext;
+    }
+    // lane (n, g) holds channels 4 g + i (x0), 16 + 4 g + i (x1), 16 r + 4 g + i (d) of ITS points: maxima over the 16 lanes n and the waves
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __hip_atomic_fetch_max(&s_x[4 * g + i], xm0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_max(&s_x[16 + 4 * g + i], xm1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int r = 0; r < 4; r++) __hip_atomic_fetch_max(&s_d[16 * r + 4 * g + i], dm[r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    // ---- the pillar half of layer 1 (one pillar: column 0 of the 16-column tile), bias, ReLU, stores ---------------------------------------
+    if (wave == 0) {
+      f32x4a o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.b1 + 16 * r + 4 * g);
+        o[r] = f32x4a{bv.x, bv.y, bv.z, bv.w};
+      }
+      float b0v[4], b1v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        b0v[i] = n == 0 ? s_x[4 * g + i] : 0.f;
+        b1v[i] = n == 0 ? s_x[16 + 4 * g + i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][0][i], b0v[i], o[r]);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][1][i], b1v[i], o[r]);
+      if (n == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          f32x4 v;
+          v.x = relu_f(o[r][0] + s_d[16 * r + 4 * g + 0]);
+          v.y = relu_f(o[r][1] + s_d[16 * r + 4 * g + 1]);
+          v.z = relu_f(o[r][2] + s_d[16 * r + 4 * g + 2]);
+          v.w = relu_f(o[r][3] + s_d[16 * r + 4 * g + 3]);
+          if (p.pillar_features) *reinterpret_cast<f32x4 *>(p.pillar_features + (long long)ent.z * 64 + 16 * r + 4 * g) = v;
+          if (p.canvas) *reinterpret_cast<f32x4 *>(p.canvas + (long long)ent.w * 64 + 16 * r + 4 * g) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
 // WPS: waves per SIMD the register allocation is held to (3: 168 registers, 2: 256)
 template <int NUM_RAW, int WPS>
 __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
@@ -131,6 +339,12 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
+  // the first workgroups of the grid take the crowded pillars (see pfn_crowd_run), all others the wave tiles
+  if ((int)blockIdx.x < p.crowd_blocks) {
+    pfn_crowd_run<NUM_RAW, 4>(p, blockIdx.x, p.crowd_blocks, s_sum[0], s_xmax[0], s_xmax[1], s_dmax[0]);
+    return;
+  }
+  const int bid = blockIdx.x - p.crowd_blocks, n_blocks = gridDim.x - p.crowd_blocks;     // this workgroup among those of the wave tiles
   unsigned long long *sum = s_sum[wave];
   float *meanf = reinterpret_cast<float *>(sum);              // [pillar][4]: mean x, y, z | canvas row (int bits); aliases the sums
   float *xmax = s_xmax[wave];
@@ -179,9 +393,9 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 
   // a wave owns a CONTIGUOUS run of work units: wave tiles first, then the units of singles
   const int n_units = n_tiles + n_sing;
-  const int n_waves = gridDim.x * 4;
+  const int n_waves = n_blocks * 4;
   const int per_wave = (n_units + n_waves - 1) / n_waves;
-  const int u_begin = (blockIdx.x * 4 + wave) * per_wave;
+  const int u_begin = (bid * 4 + wave) * per_wave;
   const int u_end = min(u_begin + per_wave, n_units);
 
   auto first_slot = [&](int t) -> int {                        // first record of wave tile t; tiles past the multi-point records: Nm
@@ -245,7 +459,7 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 #ifdef PR_STAMP
   const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
   unsigned long long wave_t1 = wave_t0, wave_t2 = wave_t0;
-  const bool stamp = blockIdx.x == PR_STAMP && wave == 0;
+  const bool stamp = bid == PR_STAMP && wave == 0;
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
   int st_cols = 0, st_pillars = 0;
 #endif
@@ -287,7 +501,7 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
           last_rank = __builtin_amdgcn_readlane(rk, 15);
           return valid ? lp : 0;
         };
-        // a record whose rank carries the sign bit belongs to a crowded pillar (pcp_common.h: crowd_list): k_pfn_crowd runs those, a
+        // a record whose rank carries the sign bit belongs to a crowded pillar (pcp_common.h: crowd_list): pfn_crowd_run runs those, a
         // workgroup per pillar; here they are passed over
         auto rec_ok = [&](const Rec &r, int slot) -> bool { return slot < bslot && __float_as_int(r.q.y) >= 0; };
         // column tile j (>= NPRE) lies inside ONE crowded pillar: the tile index in front of the one that holds the first record behind
@@ -649,7 +863,7 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   // stores; eight 64-cell chunks of the table per trip (one wait per trip: hipcc cannot count the data-dependent stores in between).
   if (p.canvas) {
     const long long per = (((p.cells + n_waves - 1) / n_waves) + 63) & ~63LL;
-    const long long c_begin = (long long)(blockIdx.x * 4 + wave) * per;
+    const long long c_begin = (long long)(bid * 4 + wave) * per;
     const long long c_end = c_begin + per < p.cells ? c_begin + per : p.cells;
     for (long long cb = c_begin; cb < c_end; cb += 512) {
       int occ[8];
@@ -683,9 +897,9 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
     }
   }
 #ifdef PR_STAMP
-  if (lane == 0 && blockIdx.x * 4 + wave < 4096) {
+  if (lane == 0 && bid * 4 + wave < 4096) {
     const unsigned long long wave_t3 = __builtin_amdgcn_s_memtime();
-    const int gw = blockIdx.x * 4 + wave;
+    const int gw = bid * 4 + wave;
     pr_wave_cycles[3 * gw] = wave_t1 - wave_t0;
     pr_wave_cycles[3 * gw + 1] = wave_t2 - wave_t1;
     pr_wave_cycles[3 * gw + 2] = wave_t3 - wave_t2;
@@ -697,195 +911,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
     pr_dbg[8] = (unsigned long long)max(min(u_end, n_tiles) - u_begin, 0);
   }
 #endif
-}
-
-// ---- crowded pillars: one workgroup per pillar ------------------------------------------------------------------------------------------------
-// A LiDAR-like cloud puts hundreds to thousands of points into the cells next to the sensor.  The wave that owns such a pillar in k_pfn_rows
-// would walk all of its records alone (5 000 records = 312 column tiles ~ 0.2 ms on one wave while the chip is done).  The pillariser lists
-// every pillar of at least `crowd` records (default PCP_PFN_CROWD = 192) and tags its records; k_pfn_rows passes over them; here the eight
-// waves of a workgroup share the pillar's column tiles: fixed-point sums -> mean (one barrier), then features -> layer 0 -> point half of
-// layer 1 with the running maxima kept in REGISTERS across the tiles (every record is the same pillar: no LDS atomics per point), one
-// cross-lane + cross-wave reduction at the end, the pillar half of layer 1 on wave 0.  Same operations in the same order per point, exact
-// integer sums, order-free maxima: BIT-identical to what the owner wave of k_pfn_rows computes for the same pillar.
-constexpr int PC_WAVES = 8;
-constexpr int PC_THREADS = PC_WAVES * 64;
-
-template <int NUM_RAW>
-__global__ __launch_bounds__(PC_THREADS) void k_pfn_crowd(PrParams p) {
-  constexpr int RS = NUM_RAW <= 5 ? 8 : 16;
-  constexpr int S0 = l0_steps<NUM_RAW>();
-  constexpr int F = NUM_RAW + 6;
-  __shared__ unsigned long long s_sum[4];
-  __shared__ float s_mean[4];
-  __shared__ float s_x[32], s_d[64];
-  const int n_crowd = p.counters[4];
-  if ((int)blockIdx.x >= n_crowd) return;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g = lane >> 4;
-  float w0f[2][S0];
-#pragma unroll
-  for (int b = 0; b < 2; b++)
-#pragma unroll
-    for (int s = 0; s < S0; s++) {
-      const int fi = feat_index<NUM_RAW>(s, g);
-      w0f[b][s] = fi >= 0 ? p.w0[(16 * b + n) * F + fi] : (fi == -2 ? p.b0[16 * b + n] : 0.f);
-    }
-  f32x4 w1a[4][2], w1b[4][2];
-#pragma unroll
-  for (int r = 0; r < 4; r++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      const float *wr = p.w1 + (16 * r + n) * 64 + 16 * b + 4 * g;
-      w1a[r][b] = *reinterpret_cast<const f32x4 *>(wr);
-      w1b[r][b] = *reinterpret_cast<const f32x4 *>(wr + 32);
-    }
-  const float x_off = __fadd_rn(p.g.voxel_x * 0.5f, p.g.min_x);
-  const float y_off = __fadd_rn(p.g.voxel_y * 0.5f, p.g.min_y);
-  const float z_off = __fadd_rn(p.g.voxel_z * 0.5f, p.g.min_z);
-  const float vsel = g == 0 ? p.g.voxel_x : (g == 1 ? p.g.voxel_y : 0.f);
-  const float osel = g == 0 ? x_off : (g == 1 ? y_off : z_off);
-  const int acol = g < 3 ? g : 3;
-
-  for (int e = blockIdx.x; e < n_crowd; e += gridDim.x) {
-    const int4 ent = p.crowd_list[e];
-    const int start = ent.x, cnt = ent.y;
-    const int ncol = (cnt + 15) >> 4;
-    if (tid < 4) s_sum[tid] = 0ULL;
-    if (tid < 32) s_x[tid] = 0.f;
-    if (tid < 64) s_d[tid] = -__builtin_inff();
-    __syncthreads();
-    // ---- fixed-point sums of x, y, z (the count is known) -> mean, exactly the arithmetic of k_pfn_rows' phases A and B ---------------------
-    {
-      long long part = 0;
-      if (g < 3)
-        for (int j = wave; j < ncol; j += PC_WAVES) {
-          const int slot = start + 16 * j + n;
-          if (slot < start + cnt) part += fixed24(p.srows[(long long)slot * RS + g]);
-        }
-      if (g < 3) __hip_atomic_fetch_add(&s_sum[g], (unsigned long long)part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    if (tid < 3) {
-      const double c = (double)(unsigned)cnt, sd = (double)(long long)s_sum[tid] * (1.0 / 16777216.0);
-      double rc = __builtin_amdgcn_rcp(c);
-      rc = __builtin_fma(__builtin_fma(-c, rc, 1.0), rc, rc);
-      double qd = sd * rc;
-      qd = __builtin_fma(__builtin_fma(-c, qd, sd), rc, qd);
-      s_mean[tid] = (float)qd;
-    }
-    __syncthreads();
-    const float mean = s_mean[acol < 3 ? acol : 0];
-    // ---- per 16 points: features -> layer 0 -> point half of layer 1; maxima in registers --------------------------------------------------
-    float xm0[4] = {0.f, 0.f, 0.f, 0.f}, xm1[4] = {0.f, 0.f, 0.f, 0.f};
-    float dm[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) dm[r][i] = -__builtin_inff();
-    for (int j = wave; j < ncol; j += PC_WAVES) {
-      const int slot = start + 16 * j + n;
-      const bool valid = slot < start + cnt;
-      const float *src = p.srows + (long long)(valid ? slot : start + cnt - 1) * RS;
-      const float av = src[acol];
-      const f32x4 q = *reinterpret_cast<const f32x4 *>(src + RS - 4);
-      float e4 = 0.f, e5 = 0.f, e6g = 0.f, e10 = 0.f;
-      if (RS == 16) {
-        e4 = src[4];
-        e5 = src[5];
-        e6g = src[6 + g];
-        e10 = src[10];
-      }
-      const int cxcy = __float_as_int(q.z);
-      const float cf = (float)(g == 0 ? (cxcy >> 16) : (cxcy & 0xffff));
-      const float centre = __fadd_rn(__fmul_rn(cf, vsel), osel);
-      const float cluster = __fsub_rn(av, mean);
-      float f[S0];
-      const float raw4 = RS == 8 ? q.x : e4;
-      f[0] = (g < 3 || NUM_RAW > 3) ? av : 1.f;
-      f[1] = g < 3 ? cluster : (NUM_RAW > 4 ? raw4 : (NUM_RAW > 3 ? 1.f : 0.f));
-      f[2] = g < 3 ? __fsub_rn(av, centre) : (NUM_RAW > 5 ? e5 : (NUM_RAW > 4 ? 1.f : 0.f));
-      if (S0 > 3) f[3] = e6g;
-      if (S0 > 4) f[4] = g == 0 ? e10 : (g == 1 ? 1.f : 0.f);
-      f32x4a x0 = f32x4a{0.f, 0.f, 0.f, 0.f}, x1 = f32x4a{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < S0; s++) {
-        x0 = mfma16(w0f[0][s], f[s], x0);
-        x1 = mfma16(w0f[1][s], f[s], x1);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        x0[i] = relu_f(x0[i]);
-        x1[i] = relu_f(x1[i]);
-      }
-      f32x4a dacc[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) dacc[r] = f32x4a{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][0][i], x0[i], dacc[r]);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) dacc[r] = mfma16(w1a[r][1][i], x1[i], dacc[r]);
-      if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          xm0[i] = fmaxf(xm0[i], x0[i]);
-          xm1[i] = fmaxf(xm1[i], x1[i]);
-#pragma unroll
-          for (int r = 0; r < 4; r++) dm[r][i] = fmaxf(dm[r][i], dacc[r][i]);
-        }
-      }
-    }
-    // lane (n, g) holds channels 4 g + i (x0), 16 + 4 g + i (x1), 16 r + 4 g + i (d) of ITS points: maxima over the 16 lanes n and the waves
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      __hip_atomic_fetch_max(&s_x[4 * g + i], xm0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_max(&s_x[16 + 4 * g + i], xm1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-      for (int r = 0; r < 4; r++) __hip_atomic_fetch_max(&s_d[16 * r + 4 * g + i], dm[r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    // ---- the pillar half of layer 1 (one pillar: column 0 of the 16-column tile), bias, ReLU, stores ---------------------------------------
-    if (wave == 0) {
-      f32x4a o[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(p.b1 + 16 * r + 4 * g);
-        o[r] = f32x4a{bv.x, bv.y, bv.z, bv.w};
-      }
-      float b0v[4], b1v[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        b0v[i] = n == 0 ? s_x[4 * g + i] : 0.f;
-        b1v[i] = n == 0 ? s_x[16 + 4 * g + i] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][0][i], b0v[i], o[r]);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = mfma16(w1b[r][1][i], b1v[i], o[r]);
-      if (n == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          f32x4 v;
-          v.x = relu_f(o[r][0] + s_d[16 * r + 4 * g + 0]);
-          v.y = relu_f(o[r][1] + s_d[16 * r + 4 * g + 1]);
-          v.z = relu_f(o[r][2] + s_d[16 * r + 4 * g + 2]);
-          v.w = relu_f(o[r][3] + s_d[16 * r + 4 * g + 3]);
-          if (p.pillar_features) *reinterpret_cast<f32x4 *>(p.pillar_features + (long long)ent.z * 64 + 16 * r + 4 * g) = v;
-          if (p.canvas) *reinterpret_cast<f32x4 *>(p.canvas + (long long)ent.w * 64 + 16 * r + 4 * g) = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
 }
 
 }  // namespace
@@ -933,6 +958,10 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
     if (by_cells > blocks) blocks = (int)(by_cells < 256 * wps ? by_cells : 256 * wps);
   }
   if (blocks > 256 * wps) blocks = 256 * wps;
+  // the crowded pillars the wave tiles pass over run on workgroups at the FRONT of the same grid (none in most clouds: those workgroups
+  // read the list length and leave)
+  p.crowd_blocks = 64;
+  blocks += p.crowd_blocks;
   hipStream_t stream = (hipStream_t)stream_;
 #define PCP_PFN_ROWS(NR)                                                                                            \
   do {                                                                                                              \
@@ -948,14 +977,6 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   }
 #undef PCP_PFN_ROWS
   PCP_CHECK_LAUNCH();
-  // the crowded pillars the wave tiles passed over (none in most clouds: the workgroups read the list length and leave)
-  const dim3 cgrid(128);
-  switch (num_raw) {
-    case 5: hipLaunchKernelGGL(k_pfn_crowd<5>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
-    case 11: hipLaunchKernelGGL(k_pfn_crowd<11>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL(k_pfn_crowd<3>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
-    default: hipLaunchKernelGGL(k_pfn_crowd<4>, cgrid, dim3(PC_THREADS), 0, stream, p); break;
-  }
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -215,7 +215,7 @@ def test_pillarise_rows_bit_exact(case):
     rows = res.workspace[front:front + max(pts.shape[0], 1) * 32].view(torch.float32).view(-1, 8)[:Nv].cpu()
     tagged = rows[:, 5].view(torch.int32).numpy()
     rank = tagged & 0x7fffffff
-    # the sign bit marks the records of crowded pillars (>= PCP_PFN_CROWD = 192 records: k_pfn_crowd runs those), and only those
+    # the sign bit marks the records of crowded pillars (>= PCP_PFN_CROWD = 192 records: pfn_crowd_run runs those), and only those
     assert np.array_equal(tagged < 0, ref['cnt'][rank] >= 192)
     # slot order: the multi-point pillars ascending (runs of cnt records), then the single-point pillars ascending
     multi, single = np.nonzero(ref['cnt'] > 1)[0], np.nonzero(ref['cnt'] == 1)[0]
@@ -333,7 +333,7 @@ def test_pfn_rows_matches_oracle(layout, num_raw, n):
 @pytest.mark.parametrize('num_raw,bucket_order', [(5, False), (5, True), (11, False)])
 def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num_raw, bucket_order, monkeypatch):
     """pillars of at least PCP_PFN_CROWD records (default 192) are listed by the pillariser, passed over by the wave tiles of k_pfn_rows and
-    run by k_pfn_crowd, a workgroup per pillar: the same operations per point, exact sums, order-free maxima -- bit for bit what the wave tiles
+    run by the front workgroups of the same grid, a workgroup per pillar: the same operations per point, exact sums, order-free maxima -- bit for bit what the wave tiles
     compute when nothing is listed (PCP_PFN_CROWD=0), at every threshold, with and without the bucket order, next to the reference oracle"""
     ops = _ops()
     rs = np.random.RandomState(11)
