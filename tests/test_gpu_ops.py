@@ -379,6 +379,50 @@ def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num
     np.testing.assert_allclose(outs['192'][0].cpu().numpy(), ref['pillar_features'], rtol=1e-4, atol=2e-5)
 
 
+def test_pfn_rows_with_a_whole_cloud_in_one_cell(monkeypatch):
+    """the degenerate end of the crowded-pillar path: 20 000 points in ONE cell (plus a handful elsewhere, before and behind it in the slot
+    order), as the only frame of the batch and again as frame 1 of 2.  Bit for bit the wave tiles' result (PCP_PFN_CROWD=0); against the
+    oracle at the north star's 1e-3: its scatter_mean adds 20 000 float32 values in index order (the reference's own float32 atomics do no
+    better), the kernel's sums are exact"""
+    ops = _ops()
+    rs = np.random.RandomState(3)
+    st, (w0, b0, w1, b1) = _folded_vfe(5)
+    arch = dict(num_raw=5, pc_range=PC_RANGE, voxel_size=VOXEL, grid_size=GRID, vfe_filters=[64, 64])
+    d = dev()
+    for B, frame in ((1, 0), (2, 1)):
+        k = 20000
+        q = np.zeros((k + 7, 8), np.float32)
+        q[:, 0] = frame
+        q[:k, 1] = -51.2 + 0.2 * 300 + rs.uniform(0.0, 0.2, k)
+        q[:k, 2] = -51.2 + 0.2 * 17 + rs.uniform(0.0, 0.2, k)
+        q[k:, 1] = rs.uniform(-50, 50, 7)
+        q[k:, 2] = rs.uniform(-50, 50, 7)
+        q[k + 5:, 1:3] = q[k + 4, 1:3]                            # a three-point pillar somewhere else
+        q[:, 3] = rs.uniform(-8, 0, k + 7)
+        q[:, 4:] = rs.uniform(0, 1, (k + 7, 4))
+        pts = q[rs.permutation(k + 7)]
+        ref = opil.vfe_forward(pts, st, arch)
+        g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
+        vox = ops.pillarise_rows(torch.from_numpy(pts).to(d), g, 5, want_coords=True)
+        P = int(vox.counters[0])
+        assert P == ref['pillar_features'].shape[0]
+        canvas = torch.full((B, 512, 512, 64), float('nan'), device=d)
+        pf = torch.full((P, 64), float('nan'), device=d)
+        ops.pfn_rows(vox, w0, b0, w1, b1, canvas=canvas, pillar_features=pf)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(pf.cpu().numpy(), ref['pillar_features'], rtol=1e-3, atol=2e-4)
+        assert not bool(torch.isnan(canvas).any()) and int((canvas != 0).any(-1).sum()) <= P
+        vc = vox.voxel_coords[:P].long()
+        assert torch.equal(canvas[vc[:, 0], vc[:, 2], vc[:, 3]], pf)
+        monkeypatch.setenv('PCP_PFN_CROWD', '0')
+        vox0 = ops.pillarise_rows(torch.from_numpy(pts).to(d), g, 5)
+        pf0 = torch.full((P, 64), float('nan'), device=d)
+        ops.pfn_rows(vox0, w0, b0, w1, b1, canvas=None, pillar_features=pf0)
+        torch.cuda.synchronize()
+        monkeypatch.delenv('PCP_PFN_CROWD')
+        assert torch.equal(pf0, pf)
+
+
 def test_pfn_rows_empty_cloud_and_single_point():
     ops = _ops()
     _st, (w0, b0, w1, b1) = _folded_vfe(5)
