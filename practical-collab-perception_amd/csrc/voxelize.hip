@@ -963,21 +963,91 @@ __global__ __launch_bounds__(256) void k_row_order(const int *__restrict__ point
 // A point's slot inside its pillar comes from the histogram atomic of pass 1, so the ORDER of a pillar's points in the bucket order changes
 // from run to run.  Inference does not see it (per-pillar max / fixed-point mean are order independent); the training path's per-point
 // GEMMs sum over the rows in bucket order, so their last bits would.  One thread per pillar sorts its run by point index (runs are a few
-// points long; insertion sort): the bucket order becomes a function of the input alone.
+// points long; insertion sort): the bucket order becomes a function of the input alone.  Runs of more than SORT_SHORT points (a LiDAR-like
+// cloud has cells with hundreds to thousands: one thread's insertion sort of 5 000 points in global memory took a SECOND) are ranked by the
+// whole workgroup instead: an element's place is the number of smaller ones (the keys are distinct), counted against LDS tiles of the run,
+// four elements per thread and pass; the sorted run is staged in the (by then idle) point_rank array and copied back.
 namespace {
-__global__ __launch_bounds__(256) void k_sort_runs(const int *__restrict__ pillar_start, const int *__restrict__ counters,
-                                                  int *__restrict__ bucket_order) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= counters[0]) return;
-  const int s0 = pillar_start[p], s1 = pillar_start[p + 1];
-  for (int i = s0 + 1; i < s1; ++i) {
-    const int v = bucket_order[i];
-    int j = i - 1;
-    while (j >= s0 && bucket_order[j] > v) {
-      bucket_order[j + 1] = bucket_order[j];
-      --j;
+constexpr int SORT_SHORT = 16, SORT_TILE = 2048, SORT_EPT = 4;
+
+// the workgroup ranks one long run (see above)
+__device__ __forceinline__ void sort_long_run(int s0, int cnt, int *__restrict__ bucket_order, int *__restrict__ scratch, int *tile) {
+  const int tid = threadIdx.x;
+  for (int base = 0; base < cnt; base += 256 * SORT_EPT) {
+    int v[SORT_EPT], rank[SORT_EPT];
+#pragma unroll
+    for (int u = 0; u < SORT_EPT; ++u) {
+      const int e = base + u * 256 + tid;
+      v[u] = e < cnt ? bucket_order[s0 + e] : 0x7fffffff;
+      rank[u] = 0;
     }
-    bucket_order[j + 1] = v;
+    for (int tb = 0; tb < cnt; tb += SORT_TILE) {
+      const int tn = min(SORT_TILE, cnt - tb);
+      __syncthreads();
+      for (int j = tid; j < tn; j += 256) tile[j] = bucket_order[s0 + tb + j];
+      __syncthreads();
+      for (int j = 0; j < tn; ++j) {
+        const int w = tile[j];                                    // broadcast read
+#pragma unroll
+        for (int u = 0; u < SORT_EPT; ++u) rank[u] += w < v[u] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SORT_EPT; ++u)
+      if (base + u * 256 + tid < cnt) scratch[s0 + rank[u]] = v[u];
+  }
+  __syncthreads();                                                 // the whole sorted run is in scratch; nobody reads the unsorted one any more
+  for (int j = tid; j < cnt; j += 256) bucket_order[s0 + j] = scratch[s0 + j];
+  __syncthreads();
+}
+
+// short runs: one thread each; long runs go to a list (capacity list_cap; a workgroup sorts the ones that do not fit itself, at the end)
+__global__ __launch_bounds__(256) void k_sort_runs(const int *__restrict__ pillar_start, const int *__restrict__ counters,
+                                                  int *__restrict__ bucket_order, int *__restrict__ scratch, int *__restrict__ long_list,
+                                                  int list_cap, int *__restrict__ long_count) {
+  __shared__ int own_list[256];
+  __shared__ int n_own;
+  __shared__ int tile[SORT_TILE];
+  const int tid = threadIdx.x;
+  if (tid == 0) n_own = 0;
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * blockDim.x + tid;
+  if (p < counters[0]) {
+    const int s0 = pillar_start[p], s1 = pillar_start[p + 1];
+    if (s1 - s0 <= SORT_SHORT) {
+      for (int i = s0 + 1; i < s1; ++i) {
+        const int v = bucket_order[i];
+        int j = i - 1;
+        while (j >= s0 && bucket_order[j] > v) {
+          bucket_order[j + 1] = bucket_order[j];
+          --j;
+        }
+        bucket_order[j + 1] = v;
+      }
+    } else {
+      const int at = atomicAdd(long_count, 1);
+      if (at < list_cap) long_list[at] = (int)p;
+      else own_list[atomicAdd(&n_own, 1)] = (int)p;
+    }
+  }
+  __syncthreads();
+  const int nl = n_own;
+  for (int li = 0; li < nl; ++li) {
+    const int q = own_list[li];
+    sort_long_run(pillar_start[q], pillar_start[q + 1] - pillar_start[q], bucket_order, scratch, tile);
+  }
+}
+
+// one workgroup per listed run, grid-stride: the long runs of a LiDAR-like cloud sit next to each other in pillar order -- left to the
+// workgroup that found them, a few workgroups sorted hundreds of runs each (4.9 ms), spread over the chip they take tens of microseconds
+__global__ __launch_bounds__(256) void k_sort_long_runs(const int *__restrict__ pillar_start, int *__restrict__ bucket_order,
+                                                       int *__restrict__ scratch, const int *__restrict__ long_list, int list_cap,
+                                                       const int *__restrict__ long_count) {
+  __shared__ int tile[SORT_TILE];
+  const int nl = min(*long_count, list_cap);
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int q = long_list[li];
+    sort_long_run(pillar_start[q], pillar_start[q + 1] - pillar_start[q], bucket_order, scratch, tile);
   }
 }
 }  // namespace
@@ -989,8 +1059,18 @@ extern "C" int pcp_voxelize_sort_pillar_rows(const pcp_grid_t *grid, void *works
   const VoxLayout L = pcp_vox_layout(cells, n);
   char *ws = (char *)workspace;
   const int64_t max_pillars = n < cells ? n : cells;
-  hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((max_pillars + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
-                     (const int *)(ws + L.pillar_start), (const int *)(ws + L.counters), (int *)(ws + L.bucket_order));
+  // the list of long runs lives in the histogram (idle once the cell passes are done; the next pillarisation refills it), its length in
+  // counters[6]
+  int *long_list = (int *)(ws + L.cell_count);
+  int *long_count = (int *)(ws + L.counters) + 6;
+  const int list_cap = (int)(cells < (1LL << 30) ? cells : (1LL << 30));
+  hipStream_t st = (hipStream_t)stream_;
+  if (pcp_zero_async(long_count, sizeof(int), st) != PCP_OK) return PCP_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((max_pillars + 255) / 256)), dim3(256), 0, st, (const int *)(ws + L.pillar_start),
+                     (const int *)(ws + L.counters), (int *)(ws + L.bucket_order), (int *)(ws + L.point_rank), long_list, list_cap, long_count);
+  PCP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sort_long_runs, dim3(1024), dim3(256), 0, st, (const int *)(ws + L.pillar_start), (int *)(ws + L.bucket_order),
+                     (int *)(ws + L.point_rank), (const int *)long_list, list_cap, (const int *)long_count);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -1685,6 +1685,15 @@ def test_voxelize_sort_pillar_rows_makes_the_bucket_order_a_function_of_the_inpu
     pts[:, 1:3] = rng.uniform(-6.0, 6.0, (n, 2))                    # 60 x 60 cells of 0.2 m: ~5 points per pillar and frame
     pts[:, 3] = rng.uniform(-7.0, -1.0, n)
     pts[rng.rand(n) < 0.05, 1] = 500.0                              # out of range rows
+    # crowded cells (a LiDAR-like cloud has them next to the sensor): runs longer than one thread sorts alone are ranked by the workgroup --
+    # around its limits: 33 (> SORT_SHORT), 300, 2 049 (> one LDS tile), 5 000 (several passes of 1 024 elements)
+    at = 0
+    for k, (cxk, cyk) in zip((5000, 2049, 300, 33, 32), ((10, 10), (11, 10), (12, 10), (13, 10), (14, 10))):
+        pts[at:at + k, 0] = 1
+        pts[at:at + k, 1] = -51.2 + 0.2 * cxk + rng.uniform(0.01, 0.19, k)
+        pts[at:at + k, 2] = -51.2 + 0.2 * cyk + rng.uniform(0.01, 0.19, k)
+        at += k
+    pts = pts[rng.permutation(n)]
     points = torch.from_numpy(pts).to(d)
     grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], 2)
     orders = []
