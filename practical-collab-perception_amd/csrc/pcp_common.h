@@ -49,9 +49,12 @@ struct VoxLayout {
   size_t pillar_cell;   // int32 [n]       merged id of pillar r
   size_t pillar_start;  // int32 [n + 1]   first slot of pillar r (pillar_start[P] = N')
   size_t block_sums;    // int32 [3 * nblk_max + 8]
-  size_t counters;      // int32 [PCP_VOX_COUNTERS] copy of the public counters (device side)
+  size_t counters;      // int32 [16]      [0..3] the public counters (device side), [4] crowded pillars listed (rows mode), [6] long pillars listed
+  size_t long_list;     // int32 [n / PCP_LONG_PILLAR + 2]  ranks of the pillars of more than PCP_LONG_PILLAR points, in no particular order: the
+                        //                 training kernels give each of them a workgroup (one lane group walking 5 000 points took milliseconds)
   size_t total;
 };
+constexpr int PCP_LONG_PILLAR = 16;
 
 static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
   VoxLayout L;
@@ -68,6 +71,7 @@ static inline VoxLayout pcp_vox_layout(int64_t cells, int64_t n) {
   int64_t nblk = (cells + 1023) / 1024 + (n + 1023) / 1024 + 2;
   L.block_sums = take((size_t)(3 * nblk + 8) * 4);
   L.counters = take(64);
+  L.long_list = take((size_t)(n / PCP_LONG_PILLAR + 2) * 4);
   L.total = off;
   return L;
 }

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_mid(const int *__restrict__
   const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
   for (long long p = t >> 3; p < P; p += nt >> 3) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
+    if (se - sb > PCP_LONG_PILLAR) continue;                        // k_pfnt_mid_long: a workgroup per long pillar
     f32x4 best = f32x4{-1.f, -1.f, -1.f, -1.f};
     i32x4 arg = i32x4{se, se, se, se};
     for (int s = sb; s < se; ++s) {
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_out(const int *__restrict__
   const int plane = g.nx * g.ny;
   for (long long p = t >> 4; p < P; p += nt >> 4) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
+    if (se - sb > PCP_LONG_PILLAR) continue;                        // k_pfnt_out_long
     f32x4 best = f32x4{-1.f, -1.f, -1.f, -1.f};
     i32x4 arg = i32x4{sb, sb, sb, sb};
     for (int s = sb; s < se; ++s) {
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_out(const int *__rest
   const int plane = g.nx * g.ny;
   for (long long p = t >> 4; p < P; p += nt >> 4) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
+    if (se - sb > PCP_LONG_PILLAR) continue;                        // k_pfnt_route_out_long
     f32x4 gv;
     if (dcanvas) {
       const int cell = pillar_cell[p];
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_mid(const int *__rest
   const int c = (int)(t & 7) * 4;
   for (long long p = t >> 3; p < P; p += nt >> 3) {
     const int sb = pillar_start[p], se = pillar_start[p + 1];
+    if (se - sb > PCP_LONG_PILLAR) continue;                        // k_pfnt_route_mid_long
     // fixed summation order (ascending slot)
     f32x4 dm = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = sb; s < se; ++s) dm += Row4<RT>::ld(din1 + (long long)s * C1 + C0 + c);
@@ -323,7 +327,184 @@ __global__ __launch_bounds__(PT_THREADS) void k_pfnt_route_mid(const int *__rest
   }
 }
 
-struct WsView { const int *bucket_order, *pillar_cell, *pillar_start, *counters; };
+// ---- pillars of more than PCP_LONG_PILLAR points: a workgroup each --------------------------------------------------------------------------
+// The four kernels above give a pillar one group of 8 / 16 lanes that walks its points one after the other: fine for the handful of points a
+// pillar usually has, milliseconds for the cells next to the sensor of a LiDAR-like cloud (hundreds to thousands of points; the wave waits
+// for its longest pillar).  The pillariser lists those pillars (VoxLayout::long_list); here 256 threads = 32 (mid) / 16 (out) row slots x the
+// channel lanes share one listed pillar: every row slot walks rows s = sb + slot, + slots, ..., the per-slot results are combined in LDS in a
+// FIXED order (max: larger value, then smaller slot index -- the first row in bucket order still wins a tie; sums: slot 0, 1, 2, ...), so the
+// results are reproducible; the sums of route_mid are grouped differently from the sequential loop (last-bit differences).
+constexpr int PL_THREADS = 256;
+constexpr int PL_BLOCKS = 1024;                                  // grid-stride over the list
+
+template <typename RT>
+__global__ __launch_bounds__(PL_THREADS) void k_pfnt_mid_long(const int *__restrict__ pillar_start, const int *__restrict__ long_list,
+                                                             const int *__restrict__ counters, const float *__restrict__ x0,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             RT *__restrict__ in1, int *__restrict__ arg0) {
+  constexpr int SLOTS = PL_THREADS / 8;                            // 32 row slots x 8 lanes of four channels
+  __shared__ float s_best[SLOTS][C0];
+  __shared__ int s_arg[SLOTS][C0];
+  const int tid = threadIdx.x, slot = tid >> 3, c = (tid & 7) * 4;
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+  const int nl = counters[6];
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int p = long_list[li];
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    f32x4 best = f32x4{-1.f, -1.f, -1.f, -1.f};
+    i32x4 arg = i32x4{se, se, se, se};
+    for (int s = sb + slot; s < se; s += SLOTS) {
+      const f32x4 x = *reinterpret_cast<const f32x4 *>(x0 + (long long)s * C0 + c);
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = fmaxf(fmaf(x[i], sc[i], sh[i]), 0.f);
+        if (v[i] > best[i]) { best[i] = v[i]; arg[i] = s; }
+      }
+      Row4<RT>::st(in1 + (long long)s * C1 + c, v);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_best[slot][c + i] = best[i]; s_arg[slot][c + i] = arg[i]; }
+    __syncthreads();
+    // every thread combines the 32 slots of its four channels itself (same result in all of them: no second broadcast)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float b = -1.f;
+      int a = se;
+      for (int k = 0; k < SLOTS; ++k) {
+        const float v = s_best[k][c + i];
+        const int av = s_arg[k][c + i];
+        if (v > b || (v == b && av < a)) { b = v; a = av; }
+      }
+      best[i] = b;
+      arg[i] = a;
+    }
+    if (slot == 0) *reinterpret_cast<i32x4 *>(arg0 + (long long)p * C0 + c) = arg;
+    for (int s = sb + slot; s < se; s += SLOTS) Row4<RT>::st(in1 + (long long)s * C1 + C0 + c, best);
+    __syncthreads();
+  }
+}
+
+template <typename CT, typename RT>
+__global__ __launch_bounds__(PL_THREADS) void k_pfnt_out_long(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
+                                                             const int *__restrict__ long_list, const int *__restrict__ counters,
+                                                             pcp_grid_t g, const RT *__restrict__ x1, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, float *__restrict__ pf, int *__restrict__ arg1,
+                                                             CT *__restrict__ canvas) {
+  constexpr int SLOTS = PL_THREADS / 16;                           // 16 row slots x 16 lanes of four channels
+  __shared__ float s_best[SLOTS][C1];
+  __shared__ int s_arg[SLOTS][C1];
+  const int tid = threadIdx.x, slot = tid >> 4, c = (tid & 15) * 4;
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+  const int plane = g.nx * g.ny;
+  const int nl = counters[6];
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int p = long_list[li];
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    f32x4 best = f32x4{-1.f, -1.f, -1.f, -1.f};
+    i32x4 arg = i32x4{sb, sb, sb, sb};
+    for (int s = sb + slot; s < se; s += SLOTS) {
+      const f32x4 x = Row4<RT>::ld(x1 + (long long)s * C1 + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = fmaxf(fmaf(x[i], sc[i], sh[i]), 0.f);
+        if (v > best[i]) { best[i] = v; arg[i] = s; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_best[slot][c + i] = best[i]; s_arg[slot][c + i] = arg[i]; }
+    __syncthreads();
+    if (slot == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float b = -1.f;
+        int a = sb;
+        for (int k = 0; k < SLOTS; ++k) {
+          const float v = s_best[k][c + i];
+          const int av = s_arg[k][c + i];
+          if (v > b || (v == b && v >= 0.f && av < a)) { b = v; a = av; }
+        }
+        best[i] = b;
+        arg[i] = a;
+      }
+      if (pf) *reinterpret_cast<f32x4 *>(pf + (long long)p * C1 + c) = best;
+      *reinterpret_cast<i32x4 *>(arg1 + (long long)p * C1 + c) = arg;
+      if (canvas) {
+        const int cell = pillar_cell[p];
+        const int b = cell / plane, rem = cell % plane;
+        const int cx = rem / g.ny, cy = rem % g.ny;
+        Row4<CT>::st(canvas + (((long long)b * g.ny + cy) * g.nx + cx) * C1 + c, best);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename CT, typename RT>
+__global__ __launch_bounds__(PL_THREADS) void k_pfnt_route_out_long(const int *__restrict__ pillar_start, const int *__restrict__ pillar_cell,
+                                                                   const int *__restrict__ long_list, const int *__restrict__ counters,
+                                                                   pcp_grid_t g, const CT *__restrict__ dcanvas, const float *__restrict__ dpf,
+                                                                   const int *__restrict__ arg1, RT *__restrict__ dz1) {
+  constexpr int SLOTS = PL_THREADS / 16;
+  const int tid = threadIdx.x, slot = tid >> 4, c = (tid & 15) * 4;
+  const int plane = g.nx * g.ny;
+  const int nl = counters[6];
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int p = long_list[li];
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    f32x4 gv;
+    if (dcanvas) {
+      const int cell = pillar_cell[p];
+      const int b = cell / plane, rem = cell % plane;
+      const int cx = rem / g.ny, cy = rem % g.ny;
+      gv = Row4<CT>::ld(dcanvas + (((long long)b * g.ny + cy) * g.nx + cx) * C1 + c);
+    } else {
+      gv = *reinterpret_cast<const f32x4 *>(dpf + (long long)p * C1 + c);
+    }
+    const i32x4 arg = *reinterpret_cast<const i32x4 *>(arg1 + (long long)p * C1 + c);
+    for (int s = sb + slot; s < se; s += SLOTS) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = arg[i] == s ? gv[i] : 0.f;
+      Row4<RT>::st(dz1 + (long long)s * C1 + c, v);
+    }
+  }
+}
+
+template <typename RT>
+__global__ __launch_bounds__(PL_THREADS) void k_pfnt_route_mid_long(const int *__restrict__ pillar_start, const int *__restrict__ long_list,
+                                                                   const int *__restrict__ counters, const RT *__restrict__ din1,
+                                                                   const int *__restrict__ arg0, float *__restrict__ da0) {
+  constexpr int SLOTS = PL_THREADS / 8;
+  __shared__ float s_sum[SLOTS][C0];
+  const int tid = threadIdx.x, slot = tid >> 3, c = (tid & 7) * 4;
+  const int nl = counters[6];
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    const int p = long_list[li];
+    const int sb = pillar_start[p], se = pillar_start[p + 1];
+    f32x4 dm = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = sb + slot; s < se; s += SLOTS) dm += Row4<RT>::ld(din1 + (long long)s * C1 + C0 + c);      // ascending rows of this slot
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_sum[slot][c + i] = dm[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = 0.f;
+      for (int k = 0; k < SLOTS; ++k) t += s_sum[k][c + i];                                                  // slots in ascending order
+      dm[i] = t;
+    }
+    const i32x4 a = *reinterpret_cast<const i32x4 *>(arg0 + (long long)p * C0 + c);
+    for (int s = sb + slot; s < se; s += SLOTS) {
+      f32x4 v = Row4<RT>::ld(din1 + (long long)s * C1 + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (s == a[i] ? dm[i] : 0.f);
+      *reinterpret_cast<f32x4 *>(da0 + (long long)s * C0 + c) = v;
+    }
+    __syncthreads();
+  }
+}
+
+struct WsView { const int *bucket_order, *pillar_cell, *pillar_start, *counters, *long_list; };
 
 inline WsView view_ws(const void *workspace, const pcp_grid_t *grid, int64_t n) {
   const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
@@ -334,6 +515,7 @@ inline WsView view_ws(const void *workspace, const pcp_grid_t *grid, int64_t n) 
   v.pillar_cell = (const int *)(ws + L.pillar_cell);
   v.pillar_start = (const int *)(ws + L.pillar_start);
   v.counters = (const int *)(ws + L.counters);
+  v.long_list = (const int *)(ws + L.long_list);
   return v;
 }
 
@@ -386,6 +568,14 @@ static int pfn_train_mid_impl(const pcp_grid_t *grid, const void *vox_workspace,
     hipLaunchKernelGGL(k_pfnt_mid<float>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, x0, scale0, shift0,
                        (float *)in1, arg0);
   PCP_CHECK_LAUNCH();
+  // the listed long pillars (none in most clouds: the workgroups read the list length and leave)
+  if (in1_bf16)
+    hipLaunchKernelGGL(k_pfnt_mid_long<__bf16>, dim3(PL_BLOCKS), dim3(PL_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.long_list, v.counters, x0,
+                       scale0, shift0, (__bf16 *)in1, arg0);
+  else
+    hipLaunchKernelGGL(k_pfnt_mid_long<float>, dim3(PL_BLOCKS), dim3(PL_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.long_list, v.counters, x0,
+                       scale0, shift0, (float *)in1, arg0);
+  PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
@@ -417,6 +607,16 @@ static int pfn_train_out_impl(const pcp_grid_t *grid, const void *vox_workspace,
     if (x1_bf16) PCP_PFNT_OUT(float, __bf16); else PCP_PFNT_OUT(float, float);
   }
 #undef PCP_PFNT_OUT
+  PCP_CHECK_LAUNCH();
+#define PCP_PFNT_OUT_LONG(CT, RT)                                                                                                          \
+  hipLaunchKernelGGL((k_pfnt_out_long<CT, RT>), dim3(PL_BLOCKS), dim3(PL_THREADS), 0, st, v.pillar_start, v.pillar_cell, v.long_list, v.counters, \
+                     *grid, (const RT *)x1, scale1, shift1, pillar_features, arg1, (CT *)canvas)
+  if (canvas_bf16) {
+    if (x1_bf16) PCP_PFNT_OUT_LONG(__bf16, __bf16); else PCP_PFNT_OUT_LONG(__bf16, float);
+  } else {
+    if (x1_bf16) PCP_PFNT_OUT_LONG(float, __bf16); else PCP_PFNT_OUT_LONG(float, float);
+  }
+#undef PCP_PFNT_OUT_LONG
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
@@ -453,6 +653,16 @@ static int pfn_route_out_impl(const pcp_grid_t *grid, const void *vox_workspace,
   }
 #undef PCP_PFNT_ROUTE
   PCP_CHECK_LAUNCH();
+#define PCP_PFNT_ROUTE_LONG(CT, RT)                                                                                                        \
+  hipLaunchKernelGGL((k_pfnt_route_out_long<CT, RT>), dim3(PL_BLOCKS), dim3(PL_THREADS), 0, s, v.pillar_start, v.pillar_cell, v.long_list,      \
+                     v.counters, *grid, (const CT *)dcanvas, dpillar, arg1, (RT *)dz1)
+  if (dcanvas_bf16) {
+    if (dz1_bf16) PCP_PFNT_ROUTE_LONG(__bf16, __bf16); else PCP_PFNT_ROUTE_LONG(__bf16, float);
+  } else {
+    if (dz1_bf16) PCP_PFNT_ROUTE_LONG(float, __bf16); else PCP_PFNT_ROUTE_LONG(float, float);
+  }
+#undef PCP_PFNT_ROUTE_LONG
+  PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
 
@@ -480,6 +690,13 @@ static int pfn_route_mid_impl(const pcp_grid_t *grid, const void *vox_workspace,
   else
     hipLaunchKernelGGL(k_pfnt_route_mid<float>, gridd, dim3(PT_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.counters, (const float *)din1,
                        arg0, da0);
+  PCP_CHECK_LAUNCH();
+  if (din1_bf16)
+    hipLaunchKernelGGL(k_pfnt_route_mid_long<__bf16>, dim3(PL_BLOCKS), dim3(PL_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.long_list,
+                       v.counters, (const __bf16 *)din1, arg0, da0);
+  else
+    hipLaunchKernelGGL(k_pfnt_route_mid_long<float>, dim3(PL_BLOCKS), dim3(PL_THREADS), 0, (hipStream_t)stream, v.pillar_start, v.long_list,
+                       v.counters, (const float *)din1, arg0, da0);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -83,6 +83,7 @@ struct CellScanOut {
   int2 *cell_rs;
   int2 *tile_desc;               // rows mode only
   int4 *crowd_list;              // rows mode only: pillars of >= crowd records {first slot, records, rank, canvas row}; counters_ws[4] of them
+  int *long_list;                // ranks of the pillars of more than PCP_LONG_PILLAR points; counters_ws[6] of them
   int crowd;                     // threshold (0: none)
 };
 constexpr int CROWD_TAG = 0x40000000;      // on a cell's first slot in cell_rs: its records carry the rank with the sign bit set
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cell_tile_sums(const int *__re
                                                                  unsigned *__restrict__ tile_singles, int *__restrict__ crowd_count) {
   __shared__ u64 wave_tot[SCAN_THREADS / 64];
   __shared__ unsigned wave_one[SCAN_THREADS / 64];
-  if (crowd_count && blockIdx.x == 0 && threadIdx.x == 0) *crowd_count = 0;      // k_cell_finish (the next launch) appends to the list
+  if (crowd_count && blockIdx.x == 0 && threadIdx.x == 0) {                      // k_cell_finish (the next launch) appends to the lists
+    crowd_count[0] = 0;                                                           // counters_ws[4]: crowded pillars (rows mode)
+    crowd_count[2] = 0;                                                           // counters_ws[6]: long pillars
+  }
   int cnt[CS_ITEMS];
   load_cell_counts(cell_count, (long long)blockIdx.x * CS_TILE + (long long)threadIdx.x * CS_ITEMS, cells, cnt);
   u64 s = 0;
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_cell_finish(const int *__restr
       rank_out[i] = rank;
       const bool crowded = o.crowd_list && o.crowd > 0 && cnt[i] >= o.crowd;
       o.cell_rs[c] = make_int2(rank, crowded ? (start | CROWD_TAG) : start);
+      if (cnt[i] > PCP_LONG_PILLAR) o.long_list[atomicAdd(&o.counters_ws[6], 1)] = rank;
       if (crowded) {
         const int b = (int)(c / plane), rem = (int)(c % plane);
         const int cx = rem / g.ny, cy = rem % g.ny;
@@ -477,7 +482,8 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   o.tile_desc = rows_raw ? (int2 *)(ws + R.tile_desc) : nullptr;
   o.crowd_list = rows_raw ? (int4 *)(ws + R.crowd_list) : nullptr;
   o.crowd = rows_raw ? crowd_threshold() : 0;
-  int *crowd_count = rows_raw ? o.counters_ws + 4 : nullptr;
+  o.long_list = (int *)(ws + L.long_list);
+  int *crowd_count = o.counters_ws + 4;              // the two list lengths (counters_ws[4], [6]) are zeroed by k_cell_tile_sums in every mode
   int *bucket_order = (want_bucket_order || !rows_raw) ? (int *)(ws + L.bucket_order) : nullptr;
   float *srows = rows_raw ? (float *)(ws + R.srows) : nullptr;
   const int rs = rows_raw ? pcp_rows_stride(rows_raw) : 0;
@@ -963,12 +969,12 @@ __global__ __launch_bounds__(256) void k_row_order(const int *__restrict__ point
 // A point's slot inside its pillar comes from the histogram atomic of pass 1, so the ORDER of a pillar's points in the bucket order changes
 // from run to run.  Inference does not see it (per-pillar max / fixed-point mean are order independent); the training path's per-point
 // GEMMs sum over the rows in bucket order, so their last bits would.  One thread per pillar sorts its run by point index (runs are a few
-// points long; insertion sort): the bucket order becomes a function of the input alone.  Runs of more than SORT_SHORT points (a LiDAR-like
+// points long; insertion sort): the bucket order becomes a function of the input alone.  Runs of more than PCP_LONG_PILLAR points (a LiDAR-like
 // cloud has cells with hundreds to thousands: one thread's insertion sort of 5 000 points in global memory took a SECOND) are ranked by the
 // whole workgroup instead: an element's place is the number of smaller ones (the keys are distinct), counted against LDS tiles of the run,
 // four elements per thread and pass; the sorted run is staged in the (by then idle) point_rank array and copied back.
 namespace {
-constexpr int SORT_SHORT = 16, SORT_TILE = 2048, SORT_EPT = 4;
+constexpr int SORT_TILE = 2048, SORT_EPT = 4;
 
 // the workgroup ranks one long run (see above)
 __device__ __forceinline__ void sort_long_run(int s0, int cnt, int *__restrict__ bucket_order, int *__restrict__ scratch, int *tile) {
@@ -1001,50 +1007,31 @@ __device__ __forceinline__ void sort_long_run(int s0, int cnt, int *__restrict__
   __syncthreads();
 }
 
-// short runs: one thread each; long runs go to a list (capacity list_cap; a workgroup sorts the ones that do not fit itself, at the end)
+// short runs: one thread each (the long ones are on the pillariser's list: k_sort_long_runs)
 __global__ __launch_bounds__(256) void k_sort_runs(const int *__restrict__ pillar_start, const int *__restrict__ counters,
-                                                  int *__restrict__ bucket_order, int *__restrict__ scratch, int *__restrict__ long_list,
-                                                  int list_cap, int *__restrict__ long_count) {
-  __shared__ int own_list[256];
-  __shared__ int n_own;
-  __shared__ int tile[SORT_TILE];
-  const int tid = threadIdx.x;
-  if (tid == 0) n_own = 0;
-  __syncthreads();
-  const long long p = (long long)blockIdx.x * blockDim.x + tid;
-  if (p < counters[0]) {
-    const int s0 = pillar_start[p], s1 = pillar_start[p + 1];
-    if (s1 - s0 <= SORT_SHORT) {
-      for (int i = s0 + 1; i < s1; ++i) {
-        const int v = bucket_order[i];
-        int j = i - 1;
-        while (j >= s0 && bucket_order[j] > v) {
-          bucket_order[j + 1] = bucket_order[j];
-          --j;
-        }
-        bucket_order[j + 1] = v;
-      }
-    } else {
-      const int at = atomicAdd(long_count, 1);
-      if (at < list_cap) long_list[at] = (int)p;
-      else own_list[atomicAdd(&n_own, 1)] = (int)p;
+                                                  int *__restrict__ bucket_order) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= counters[0]) return;
+  const int s0 = pillar_start[p], s1 = pillar_start[p + 1];
+  if (s1 - s0 > PCP_LONG_PILLAR) return;
+  for (int i = s0 + 1; i < s1; ++i) {
+    const int v = bucket_order[i];
+    int j = i - 1;
+    while (j >= s0 && bucket_order[j] > v) {
+      bucket_order[j + 1] = bucket_order[j];
+      --j;
     }
-  }
-  __syncthreads();
-  const int nl = n_own;
-  for (int li = 0; li < nl; ++li) {
-    const int q = own_list[li];
-    sort_long_run(pillar_start[q], pillar_start[q + 1] - pillar_start[q], bucket_order, scratch, tile);
+    bucket_order[j + 1] = v;
   }
 }
 
 // one workgroup per listed run, grid-stride: the long runs of a LiDAR-like cloud sit next to each other in pillar order -- left to the
 // workgroup that found them, a few workgroups sorted hundreds of runs each (4.9 ms), spread over the chip they take tens of microseconds
 __global__ __launch_bounds__(256) void k_sort_long_runs(const int *__restrict__ pillar_start, int *__restrict__ bucket_order,
-                                                       int *__restrict__ scratch, const int *__restrict__ long_list, int list_cap,
-                                                       const int *__restrict__ long_count) {
+                                                       int *__restrict__ scratch, const int *__restrict__ long_list,
+                                                       const int *__restrict__ counters) {
   __shared__ int tile[SORT_TILE];
-  const int nl = min(*long_count, list_cap);
+  const int nl = counters[6];
   for (int li = blockIdx.x; li < nl; li += gridDim.x) {
     const int q = long_list[li];
     sort_long_run(pillar_start[q], pillar_start[q + 1] - pillar_start[q], bucket_order, scratch, tile);
@@ -1059,18 +1046,12 @@ extern "C" int pcp_voxelize_sort_pillar_rows(const pcp_grid_t *grid, void *works
   const VoxLayout L = pcp_vox_layout(cells, n);
   char *ws = (char *)workspace;
   const int64_t max_pillars = n < cells ? n : cells;
-  // the list of long runs lives in the histogram (idle once the cell passes are done; the next pillarisation refills it), its length in
-  // counters[6]
-  int *long_list = (int *)(ws + L.cell_count);
-  int *long_count = (int *)(ws + L.counters) + 6;
-  const int list_cap = (int)(cells < (1LL << 30) ? cells : (1LL << 30));
   hipStream_t st = (hipStream_t)stream_;
-  if (pcp_zero_async(long_count, sizeof(int), st) != PCP_OK) return PCP_ERR_LAUNCH;
   hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((max_pillars + 255) / 256)), dim3(256), 0, st, (const int *)(ws + L.pillar_start),
-                     (const int *)(ws + L.counters), (int *)(ws + L.bucket_order), (int *)(ws + L.point_rank), long_list, list_cap, long_count);
+                     (const int *)(ws + L.counters), (int *)(ws + L.bucket_order));
   PCP_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_sort_long_runs, dim3(1024), dim3(256), 0, st, (const int *)(ws + L.pillar_start), (int *)(ws + L.bucket_order),
-                     (int *)(ws + L.point_rank), (const int *)long_list, list_cap, (const int *)long_count);
+                     (int *)(ws + L.point_rank), (const int *)(ws + L.long_list), (const int *)(ws + L.counters));
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

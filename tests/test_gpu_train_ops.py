@@ -357,7 +357,10 @@ def test_distill_loss_and_gradient():
 # PFN (train mode) through the module-level driver
 # ---------------------------------------------------------------------------------------------------------------------
 
-def test_vfe_train_forward_backward_matches_autograd():
+@pytest.mark.parametrize('crowded', [False, True])
+def test_vfe_train_forward_backward_matches_autograd(crowded):
+    """crowded: cells of 17 ... 1 500 points on top of the fixture's cloud -- the pillariser lists pillars of more than 16 points and the
+    training kernels give each a workgroup (k_pfnt_*_long, k_sort_long_runs) instead of one lane group walking all its points"""
     from helpers import arch_of, load_golden
     from oracle import pillars as opil
     from oracle import train as otr
@@ -373,6 +376,20 @@ def test_vfe_train_forward_backward_matches_autograd():
     vfe = model.vfe.to(DEV).train()
     tl.StepClock.tick()
     pts = g['points']
+    if crowded:
+        rs = np.random.RandomState(17)
+        x_lo, y_lo = float(arch['pc_range'][0]), float(arch['pc_range'][1])
+        extra = []
+        for i, k in enumerate((17, 16, 40, 300, 1500, 33)):
+            q = np.zeros((k, pts.shape[1]), np.float32)
+            q[:, 0] = i % 2
+            q[:, 1] = x_lo + 0.2 * (20 + 3 * i) + rs.uniform(0.01, 0.19, k)
+            q[:, 2] = y_lo + 0.2 * (31 + i) + rs.uniform(0.01, 0.19, k)
+            q[:, 3] = rs.uniform(-6.0, -1.0, k)
+            q[:, 4:] = pts[rs.randint(0, pts.shape[0], k), 4:]
+            extra.append(q)
+        pts = np.concatenate([pts] + extra, 0)
+        pts = np.ascontiguousarray(pts[rs.permutation(pts.shape[0])])
     bd = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 2}
     drv = VFETrain(vfe)
     bd = drv.forward(bd)
