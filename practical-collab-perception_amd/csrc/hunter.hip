@@ -57,8 +57,9 @@ __global__ void k_bilinear(const float *__restrict__ bev, int batch, int h, int 
 }
 
 struct ScLayout {
-  size_t cell_count, cell_fill, cell_start, point_cell, bucket, total;
+  size_t cell_count, cell_fill, cell_start, point_cell, bucket, big_list, total;
 };
+constexpr int SC_BIG = 256;                 // cells of more rows than this are listed by the scan and summed by k_sc_mean_big
 inline ScLayout sc_layout(long long cells, long long n) {
   ScLayout L;
   size_t off = 0;
@@ -68,6 +69,7 @@ inline ScLayout sc_layout(long long cells, long long n) {
   L.cell_start = take((size_t)(cells + 1) * 4);
   L.point_cell = take((size_t)(n > 0 ? n : 1) * 4);
   L.bucket = take((size_t)(n > 0 ? n : 1) * 4);
+  L.big_list = take((size_t)((n > 0 ? n : 1) / SC_BIG + 2) * 4);          // [0] = count, then the cells
   L.total = off;
   return L;
 }
@@ -91,11 +93,16 @@ __global__ void k_sc_cells(const float *__restrict__ points, long long n, int st
 
 // exclusive scan of the per-cell counts (B*H*W = 65 536 cells at 4 frames) in one workgroup: 64 cells per thread (16 independent
 // 16-byte loads in flight), 65 536 per round -- one round, three barriers at 4 frames
-__global__ __launch_bounds__(1024) void k_sc_scan(const int *__restrict__ cell_count, long long cells, int *__restrict__ cell_start) {
+__global__ __launch_bounds__(1024) void k_sc_scan(const int *__restrict__ cell_count, long long cells, int *__restrict__ cell_start,
+                                                  int *__restrict__ big_list) {
   constexpr int IT = 64;
   __shared__ int wave_sum[16];
   __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+  __shared__ int n_big;
+  if (threadIdx.x == 0) {
+    carry_s = 0;
+    n_big = 0;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = 0; base < cells; base += 1024 * IT) {
@@ -113,7 +120,10 @@ __global__ __launch_bounds__(1024) void k_sc_scan(const int *__restrict__ cell_c
     }
     int local = 0;
 #pragma unroll
-    for (int i = 0; i < IT; i++) local += v[i];
+    for (int i = 0; i < IT; i++) {
+      local += v[i];
+      if (v[i] > SC_BIG) big_list[1 + atomicAdd(&n_big, 1)] = (int)(idx + i);      // crowded cells: k_sc_mean_big (any order)
+    }
     int incl = local;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -152,7 +162,10 @@ __global__ __launch_bounds__(1024) void k_sc_scan(const int *__restrict__ cell_c
     if (threadIdx.x == 0) carry_s = carry + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) cell_start[cells] = carry_s;
+  if (threadIdx.x == 0) {
+    cell_start[cells] = carry_s;
+    big_list[0] = n_big;
+  }
 }
 
 __global__ void k_sc_fill(const int *__restrict__ point_cell, long long n, const int *__restrict__ cell_start,
@@ -178,6 +191,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_sc_mean(const int *__restrict__ 
     for (int q = threadIdx.x; q < c4; q += SC_THREADS) orow[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
+  if (cnt > SC_BIG) return;                      // listed by the scan: k_sc_mean_big
   const bool sorted = cnt <= SC_SORT_CAP;
   if (sorted) {
     int cap = 2;
@@ -208,6 +222,92 @@ __global__ __launch_bounds__(SC_THREADS) void k_sc_mean(const int *__restrict__ 
     float fc = (float)cnt;
     acc.x /= fc; acc.y /= fc; acc.z /= fc; acc.w /= fc;
     orow[q] = acc;
+  }
+}
+
+// Crowded cells (more than SC_BIG rows: the cells under the sensor of a LiDAR-like cloud hold thousands): a 512-thread workgroup per listed
+// cell, 512 / c4 ROW SLOTS (slot s takes the rows s, s + slots, ... in ascending order, eight loads in flight), the slot sums added in slot
+// order -- the one-workgroup-of-128 walk above kept 12 KB in flight per cell and took 0.8 ms on the 60 k-point ring cloud.  Up to
+// SC_BIG_SORT rows the cell's rows are first sorted by point index (as above), so the result is a function of the input alone; it is
+// grouped differently from the sequential index_add_ (last bits).
+constexpr int SC_BIG_THREADS = 512;
+constexpr int SC_BIG_SORT = 4096;
+
+__global__ __launch_bounds__(SC_BIG_THREADS) void k_sc_mean_big(const int *__restrict__ cell_start, const int *__restrict__ bucket,
+                                                               const int *__restrict__ big_list, const float *__restrict__ feat, int ld_feat,
+                                                               int c4, float *__restrict__ out, int ld_out) {
+  __shared__ int ids[SC_BIG_SORT];
+  extern __shared__ float4 part[];                                  // [slots][c4]
+  const int n_big = big_list[0];
+  const int slots = c4 <= SC_BIG_THREADS ? SC_BIG_THREADS / c4 : 0;
+  for (int li = blockIdx.x; li < n_big; li += gridDim.x) {
+    const long long cell = big_list[1 + li];
+    const int s0 = cell_start[cell], cnt = cell_start[cell + 1] - s0;
+    const bool sorted = cnt <= SC_BIG_SORT;
+    if (sorted) {
+      int cap = 2;
+      while (cap < cnt) cap <<= 1;
+      for (int i = threadIdx.x; i < cap; i += SC_BIG_THREADS) ids[i] = i < cnt ? bucket[s0 + i] : 0x7fffffff;
+      __syncthreads();
+      for (int k = 2; k <= cap; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = threadIdx.x; t < cap / 2; t += SC_BIG_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int q = i | j;
+            const bool asc = (i & k) == 0;
+            const int a = ids[i], b = ids[q];
+            if ((a > b) == asc) { ids[i] = b; ids[q] = a; }
+          }
+          __syncthreads();
+        }
+    }
+    float4 *orow = reinterpret_cast<float4 *>(out + cell * ld_out);
+    if (slots == 0) {                                               // wider than the workgroup: a thread per channel quad, round robin
+      for (int q = threadIdx.x; q < c4; q += SC_BIG_THREADS) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < cnt; k++) {
+          const int pid = sorted ? ids[k] : bucket[s0 + k];
+          const float4 v = *reinterpret_cast<const float4 *>(feat + (long long)pid * ld_feat + q * 4);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const float fc = (float)cnt;
+        orow[q] = make_float4(acc.x / fc, acc.y / fc, acc.z / fc, acc.w / fc);
+      }
+      __syncthreads();
+      continue;
+    }
+    const int q = threadIdx.x % c4, slot = threadIdx.x / c4;
+    if (slot < slots) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int k = slot;
+      for (; k + 7 * slots < cnt; k += 8 * slots) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int pid = sorted ? ids[k + u * slots] : bucket[s0 + k + u * slots];
+          v[u] = *reinterpret_cast<const float4 *>(feat + (long long)pid * ld_feat + q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; k < cnt; k += slots) {
+        const int pid = sorted ? ids[k] : bucket[s0 + k];
+        const float4 v = *reinterpret_cast<const float4 *>(feat + (long long)pid * ld_feat + q * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      part[slot * c4 + q] = acc;
+    }
+    __syncthreads();
+    if (slot == 0) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sl = 0; sl < slots; sl++) {
+        const float4 v = part[sl * c4 + q];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      const float fc = (float)cnt;
+      orow[q] = make_float4(t.x / fc, t.y / fc, t.z / fc, t.w / fc);
+    }
+    __syncthreads();
   }
 }
 
@@ -366,7 +466,8 @@ extern "C" int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_
                        min_x, min_y, pix_x, pix_y, cell_count, point_cell);
     PCP_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_sc_scan, dim3(1), dim3(1024), 0, st, cell_count, cells, cell_start);
+  int *big_list = (int *)(ws + L.big_list);
+  hipLaunchKernelGGL(k_sc_scan, dim3(1), dim3(1024), 0, st, cell_count, cells, cell_start, big_list);
   PCP_CHECK_LAUNCH();
   if (n > 0) {
     hipLaunchKernelGGL(k_sc_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, point_cell, (long long)n, cell_start,
@@ -375,6 +476,12 @@ extern "C" int pcp_bev_scatter_mean(const float *points, int64_t n, int32_t row_
   }
   hipLaunchKernelGGL(k_sc_mean, dim3((unsigned)cells), dim3(SC_THREADS), 0, st, cell_start, bucket, feat, ld_feat, c / 4, out,
                      ld_out);
+  PCP_CHECK_LAUNCH();
+  // the crowded cells the kernel above left out (none in most clouds: the workgroups read the list length and leave)
+  const int c4 = c / 4;
+  const size_t part_bytes = (size_t)(c4 <= SC_BIG_THREADS ? (SC_BIG_THREADS / c4) * c4 : 1) * sizeof(float4);
+  hipLaunchKernelGGL(k_sc_mean_big, dim3(256), dim3(SC_BIG_THREADS), part_bytes, st, cell_start, bucket, (const int *)big_list, feat, ld_feat, c4,
+                     out, ld_out);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }
