@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5 final measurements, part A: bench lines of every config (inference, training fp32 / bf16), B = 1 latency lines (eager and hipGraph)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r5final; mkdir -p $O; cd $R
-run() { name=$1; shift; timeout 500 python bench.py "$@" < /dev/null 2>/dev/null | grep '^{' > $O/$name.json; python - $O/$name.json <<'PY'
+run() { name=$1; shift; sec=--no-secondary; [ "$name" = r05_bench_disco ] && sec=; timeout 500 python bench.py "$@" $sec < /dev/null 2>/dev/null | grep '^{' > $O/$name.json; python - $O/$name.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read()); print(sys.argv[1].split('/')[-1], d.get('value'), d.get('unit'), d.get('ms_per_step', d.get('p50_ms')))
 PY

@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r5final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python3 $R/bench.py "$@" > $O/prof_$name.log 2>&1 < /dev/null
   f=$(ls $O/prof_$name/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/r05_bench_disco_b4_${name}_kernel_stats.csv && head -6 "$f" | cut -c1-150; rm -rf $O/prof_$name; }
-prof overlapped --steps 15 --warmup 3 --no-cpu-baseline
-prof single_stream --steps 15 --warmup 3 --no-cpu-baseline --no-overlap --no-pipeline
+prof overlapped --steps 15 --warmup 3 --no-cpu-baseline --no-secondary
+prof single_stream --steps 15 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap --no-pipeline
 grep '^{' $O/prof_single_stream.log | tail -1 > $O/r05_bench_disco_single_stream.json
 for a in "4 6 1" "20 1 0" "4 1 0"; do
   tag=$(echo $a | tr " " _)

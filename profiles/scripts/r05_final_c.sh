@@ -3,7 +3,7 @@
 # and the SQ / LDS counters of the dominant kernels; every --pmc pass on its own with --kernel-trace only, the program directly after `--`
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=gpurun_out/r5pmcfinal; mkdir -p $R/$O
 cd /tmp && export TMPDIR=/tmp
-pass() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$O/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-pipeline > $R/$O/$name.log 2>&1 < /dev/null; }
+pass() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$O/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-overlap --no-pipeline > $R/$O/$name.log 2>&1 < /dev/null; }
 pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/busy; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift
-  timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/p_$name -- python3 $R/bench.py "$@" --no-cpu-baseline > $O/$name.log 2>&1 < /dev/null
+  timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/p_$name -- python3 $R/bench.py "$@" --no-cpu-baseline --no-secondary > $O/$name.log 2>&1 < /dev/null
   f=$(ls $O/p_$name/*/*kernel_trace.csv 2>/dev/null | head -1)
   echo "== $name: $(grep '^{' $O/$name.log | tail -1 | cut -c1-160)"
   python3 $R/practical-collab-perception_amd/tools/gpu_busy.py "$f" 0.4
