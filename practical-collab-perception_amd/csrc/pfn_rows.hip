@@ -103,6 +103,7 @@ __device__ __forceinline__ long long fixed24(float a) {
 // over its tiles; read by tools/stamp_pfn_rows.py.  No stamp executes in the product build.
 __device__ unsigned long long pr_dbg[16];
 __device__ unsigned long long pr_wave_cycles[4096 * 3];        // per wave of the grid: cycles in the tiles | in the singles | in the canvas fill
+__device__ unsigned int pr_tile_cycles[65536 * 4];             // per wave tile (the first 65536): cycles, records, pillars, column tiles walked
 #define PR_MARK(k)                                                \
   do {                                                            \
     if (stamp) {                                                  \
@@ -391,12 +392,26 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   const cint_p desc_c = (cint_p)(unsigned long long)p.tile_desc;
   const cint_p rows_c = (cint_p)(unsigned long long)p.srows;
 
-  // a wave owns a CONTIGUOUS run of work units: wave tiles first, then the units of singles
-  const int n_units = n_tiles + n_sing;
+  // Work distribution: the wave tiles are dealt out in CHUNKS of PR_CHUNK consecutive tiles, chunk k of wave w = chunk number k * waves + w,
+  // so every wave's tiles sample the whole cloud (the tiles of a LiDAR-like frame's middle hold the long pillars and cost 2 - 4 x the
+  // others; as ONE contiguous run per wave -- the first form -- they all sat in a few waves' runs).  Inside a chunk the tiles are
+  // consecutive and share their boundary slot.  No counters, no atomics (profiles/experiments/r05_pfn_tickets: what drawing chunks at run
+  // time costs).  Measured (tools/bench_frontend.py, three alternating runs per build on one box): chunks of 1, 2, 4 tiles and the
+  // contiguous runs are within 2 % of each other on both clouds -- per-tile stamps (tools/stamp_pfn_rows.py) show why: the slowest wave is
+  // set by single tiles of 130 - 220 records (one wave walks 9 - 14 column tiles, 58 k cycles against 15 k for a two-column tile), which
+  // no static deal evens out.  Chunks of 2: with 4 the stride of a wave's chunks (waves * 4 tiles) came within 7 % of 1.5 frames of the
+  // 6-agent cloud, and two of a wave's three chunks fell on the same part of a frame.
+  // The singles keep one contiguous run per wave (they all cost the same); the canvas fill is interleaved like the tiles.
+#ifndef PR_CHUNK_N
+#define PR_CHUNK_N 2
+#endif
+  constexpr int PR_CHUNK = PR_CHUNK_N, BIG = 0x7fffffff;
   const int n_waves = n_blocks * 4;
-  const int per_wave = (n_units + n_waves - 1) / n_waves;
-  const int u_begin = (bid * 4 + wave) * per_wave;
-  const int u_end = min(u_begin + per_wave, n_units);
+  const int gw = bid * 4 + wave;
+  auto next_tile = [&](int q) -> int {                          // the tile this wave takes after tile q (BIG: none)
+    const int nq = ((q + 1) % PR_CHUNK != 0) ? q + 1 : q + 1 + (n_waves - 1) * PR_CHUNK;
+    return nq < n_tiles ? nq : BIG;
+  };
 
   auto first_slot = [&](int t) -> int {                        // first record of wave tile t; tiles past the multi-point records: Nm
     if (t == 0) return 0;
@@ -465,9 +480,21 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 #endif
 
   // =================================== wave tiles over the records of multi-point pillars ===================================================
-  const int t_begin = u_begin, t_end = min(u_end, n_tiles);
-  if (t_begin < t_end) {
-    int acur = first_slot(t_begin), anext = first_slot(t_begin + 1), ann = first_slot(t_begin + 2);
+  int q0 = gw * PR_CHUNK < n_tiles ? gw * PR_CHUNK : BIG;
+  if (q0 != BIG) {
+    // the records [a, b) of the tile in hand and of the two behind it in this wave's sequence
+    auto span = [&](int q, int prev_q, int prev_b, int &a, int &b) {
+      a = b = Nm;
+      if (q != BIG) {
+        a = (q == prev_q + 1) ? prev_b : first_slot(q);          // consecutive tiles share the boundary
+        b = first_slot(q + 1);
+      }
+    };
+    int q1 = next_tile(q0), q2 = q1 == BIG ? BIG : next_tile(q1);
+    int a0, b0, a1, b1, a2, b2;
+    span(q0, -2, 0, a0, b0);
+    span(q1, q0, b0, a1, b1);
+    span(q2, q1, b1, a2, b2);
     Rec bufa[NPRE], bufb[NPRE];
 #pragma unroll
     for (int j = 0; j < NPRE; j++) {
@@ -475,14 +502,23 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
       bufa[j].q = bufb[j].q = f32x4{0.f, 0.f, 0.f, 0.f};
       bufa[j].e4 = bufa[j].e5 = bufa[j].e6g = bufa[j].e10 = bufb[j].e4 = bufb[j].e5 = bufb[j].e6g = bufb[j].e10 = 0.f;
     }
-    load_recs(bufa, acur, anext);
+    load_recs(bufa, a0, b0);
+#ifdef PR_STAMP
+    int tiles_done = 0;
+#endif
 
-    // one tile; `cur` holds its first 32 records, `nxt` receives the next tile's (the caller alternates the two buffers: no register copies)
-    auto tile_body = [&](int t, Rec (&cur)[NPRE], Rec (&nxt)[NPRE]) {
-      const int a = acur, bslot = anext;
-      // ---- prefetch: the next tile's records (its first slot arrived a tile ago), the first slot three tiles on
-      load_recs(nxt, bslot, ann);                              // behind the last tile: bslot == Nm, nothing is loaded
-      const int an3 = first_slot(t + 3);
+    // one tile; `cur` holds its first 32 records, `nxt` receives the next tile's
+    auto tile_body = [&](Rec (&cur)[NPRE], Rec (&nxt)[NPRE]) {
+      const int a = a0, bslot = b0;
+#ifdef PR_STAMP
+      const unsigned long long tile_t0 = __builtin_amdgcn_s_memtime();
+      int tile_pillars = 0, tile_walked = 0;
+#endif
+      // ---- prefetch: the next tile's records (its span arrived a tile ago), the span of the tile three on
+      load_recs(nxt, a1, b1);                                  // behind the last tile: a1 == b1 == Nm, nothing is loaded
+      const int q3 = q2 == BIG ? BIG : next_tile(q2);
+      int a3, b3;
+      span(q3, q2, b2, a3, b3);
       PR_MARK(0);
 
       if (a < bslot) {
@@ -717,6 +753,8 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
           st_cols += ncol;
           st_pillars += heads;
         }
+        tile_pillars = heads;
+        tile_walked = ncol;
 #endif
         const int np = heads;                                  // pillars of the tile (<= PR_T: each starts at another slot of the window)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -779,16 +817,31 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
         PR_MARK(4);
       }
       PR_MARK(5);
-      acur = anext;
-      anext = ann;
-      ann = an3;
+#ifdef PR_STAMP
+      if (lane == 0 && q0 < 65536) {
+        pr_tile_cycles[4 * q0] = (unsigned)(__builtin_amdgcn_s_memtime() - tile_t0);
+        pr_tile_cycles[4 * q0 + 1] = (unsigned)(bslot - a);
+        pr_tile_cycles[4 * q0 + 2] = (unsigned)tile_pillars;
+        pr_tile_cycles[4 * q0 + 3] = (unsigned)tile_walked;
+      }
+#endif
+      q0 = q1; q1 = q2; q2 = q3;
+      a0 = a1; b0 = b1;
+      a1 = a2; b1 = b2;
+      a2 = a3; b2 = b3;
+#ifdef PR_STAMP
+      tiles_done++;
+#endif
     };
     // ONE copy of the tile's code (alternating the two record buffers between two copies doubled the kernel; the copy below is 10 - 18 moves)
-    for (int t = t_begin; t < t_end; t++) {
-      tile_body(t, bufa, bufb);
+    while (q0 != BIG) {
+      tile_body(bufa, bufb);
 #pragma unroll
       for (int j = 0; j < NPRE; j++) bufa[j] = bufb[j];
     }
+#ifdef PR_STAMP
+    if (stamp && lane == 0) pr_dbg[8] = (unsigned long long)tiles_done;
+#endif
   }
 
 #ifdef PR_STAMP
@@ -797,7 +850,8 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   // =================================== single-point pillars: 64 per unit, no per-pillar reduction ============================================
   // The only point of a pillar is its own mean (f_cluster = 0, exactly what scatter_mean of one value gives) and its own maximum:
   // out = relu(b1 + (W1[:, :32] + W1[:, 32:]) . relu(W0 f + b0)) -- one 32-deep product instead of two, no LDS traffic at all.
-  const int s_begin = max(u_begin, n_tiles) - n_tiles, s_end = u_end - n_tiles;
+  const int s_per = (n_sing + n_waves - 1) / n_waves;
+  const int s_begin = gw * s_per, s_end = min(s_begin + s_per, n_sing);
   if (s_begin < s_end) {
     f32x4 w1c[4][2];
 #pragma unroll
@@ -857,25 +911,25 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
   wave_t2 = __builtin_amdgcn_s_memtime();
 #endif
   // =================================== canvas: zero rows for the empty cells ==================================================================
-  // Every wave takes an equal slice of the cell -> rank table, whatever the cloud looks like.  (First form of this round: a tile filled the
+  // Every wave takes an equal share of the cell -> rank table, whatever the cloud looks like.  (First form of this round: a tile filled the
   // cells between ITS pillars -- even work on a uniform cloud, but in a LiDAR-like cloud the few multi-point pillars of the outskirts
   // owned tens of thousands of empty cells each: +240 us on the 6-agent cloud.)  Last in the wave's work, so nothing waits behind the
-  // stores; eight 64-cell chunks of the table per trip (one wait per trip: hipcc cannot count the data-dependent stores in between).
+  // stores; eight 64-cell pieces of the table per trip (one wait per trip: hipcc cannot count the data-dependent stores in between).
   if (p.canvas) {
-    const long long per = (((p.cells + n_waves - 1) / n_waves) + 63) & ~63LL;
-    const long long c_begin = (long long)(bid * 4 + wave) * per;
-    const long long c_end = c_begin + per < p.cells ? c_begin + per : p.cells;
-    for (long long cb = c_begin; cb < c_end; cb += 512) {
+    // 64-cell pieces of the table, piece k of wave w = piece number k * waves + w (a wave's pieces sample the whole canvas: the empty
+    // outskirts and the full middle of a LiDAR-like frame cost every wave the same); eight pieces per trip
+    const long long c_end = p.cells;
+    for (long long cb = (long long)gw * 64; cb < c_end; cb += (long long)n_waves * 512) {
       int occ[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const long long c = cb + 64 * k + lane;
+        const long long c = cb + (long long)n_waves * 64 * k + lane;
         occ[k] = c < c_end ? p.cell_rank[c] : 0;
       }
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         unsigned long long m = __ballot(occ[k] < 0);
-        const int c0 = (int)(cb + 64 * k);
+        const int c0 = (int)(cb + (long long)n_waves * 64 * k);
         while (m) {
           // four empty cells per store instruction: lane group g takes the g-th lowest set bit
           int pos[4];
@@ -899,7 +953,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 #ifdef PR_STAMP
   if (lane == 0 && bid * 4 + wave < 4096) {
     const unsigned long long wave_t3 = __builtin_amdgcn_s_memtime();
-    const int gw = bid * 4 + wave;
     pr_wave_cycles[3 * gw] = wave_t1 - wave_t0;
     pr_wave_cycles[3 * gw + 1] = wave_t2 - wave_t1;
     pr_wave_cycles[3 * gw + 2] = wave_t3 - wave_t2;
@@ -908,7 +961,6 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
     for (int k = 0; k < 8; k++) pr_dbg[k] = st_acc[k];
     pr_dbg[9] = (unsigned long long)st_cols;
     pr_dbg[10] = (unsigned long long)st_pillars;
-    pr_dbg[8] = (unsigned long long)max(min(u_end, n_tiles) - u_begin, 0);
   }
 #endif
 }
@@ -918,6 +970,9 @@ __global__ __launch_bounds__(PR_THREADS, WPS) void k_pfn_rows(PrParams p) {
 #ifdef PR_STAMP
 extern "C" int pcp_debug_read_pfn_rows(void *dst, size_t bytes) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pr_dbg), bytes) == hipSuccess ? 0 : 3;
+}
+extern "C" int pcp_debug_read_pfn_tile_cycles(void *dst, size_t bytes) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pr_tile_cycles), bytes) == hipSuccess ? 0 : 3;
 }
 extern "C" int pcp_debug_read_pfn_wave_cycles(void *dst, size_t bytes) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pr_wave_cycles), bytes) == hipSuccess ? 0 : 3;

@@ -55,3 +55,21 @@ print('%d waves: cycles per wave min %.0f  median %.0f  mean %.0f  p99 %.0f  max
 w0 = np.array(list(wc), dtype=np.float64).reshape(4096, 3)[::4]          # wave 0 of every workgroup: the one a -DPR_STAMP=<wg> build stamps
 order = np.argsort(-w0[:, 0])
 print('workgroups whose wave 0 spends most cycles in its tiles:', [(int(i), int(w0[i, 0])) for i in order[:6]], ' median', int(np.median(w0[w0[:, 0] > 0, 0])))
+
+# every tile's cycles against what it holds: which tiles are the expensive ones?
+tc = (ctypes.c_uint * (65536 * 4))()
+raw.pcp_debug_read_pfn_tile_cycles(tc, 65536 * 4 * 4)
+t = np.array(list(tc), dtype=np.int64).reshape(65536, 4)
+t = t[t[:, 0] > 0]
+print('%d tiles: cycles mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %d' % ((t.shape[0], t[:, 0].mean()) + tuple(np.percentile(t[:, 0], [50, 90, 99])) + (t[:, 0].max(),)))
+for lo, hi in [(0, 1), (1, 17), (17, 33), (33, 49), (49, 65), (65, 129), (129, 257), (257, 1 << 30)]:
+    m = (t[:, 1] >= lo) & (t[:, 1] < hi)
+    if m.any():
+        print('  records [%d, %d): %6d tiles, cycles mean %7.0f (sum %5.1f %%), pillars mean %.1f' % (lo, hi, m.sum(), t[m, 0].mean(), 100.0 * t[m, 0].sum() / t[:, 0].sum(), t[m, 2].mean()))
+for lo, hi in [(0, 1), (1, 2), (2, 4), (4, 8), (8, 16), (16, 33)]:
+    m = (t[:, 2] >= lo) & (t[:, 2] < hi) & (t[:, 1] >= 17) & (t[:, 1] < 49)
+    if m.any():
+        print('  17..48 records, pillars [%d, %d): %6d tiles, cycles mean %7.0f' % (lo, hi, m.sum(), t[m, 0].mean()))
+# where the tiles of the slowest decile lie
+idx = np.nonzero(np.array(list(tc), dtype=np.int64).reshape(65536, 4)[:, 0] > np.percentile(t[:, 0], 95))[0]
+print('  tiles above p95: histogram of tile index / 1024:', np.bincount(idx // 1024).tolist())
