@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 atomic_rate.hip -o atomic_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -24,25 +25,43 @@ __global__ __launch_bounds__(256) void k_pass(const float *__restrict__ pts, int
       if (MODE == 2) { table[c] = 1; rank_out[r] = 0; }
       if (MODE == 3) rank_out[r] = 0;
       if (MODE == 4) rank_out[r] = __hip_atomic_fetch_add(&table[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (MODE == 5) {                                         // 32 x 32 transpose inside every 4-KB block of the table: neighbouring cells on different lines
+        const int cp = (c & ~0x3ff) | ((c & 31) << 5) | ((c >> 5) & 31);
+        rank_out[r] = atomicAdd(&table[cp], 1);
+      }
+      if (MODE == 6) {                                         // neighbouring cells 64 KB apart (16 k cells): different lines AND different 4-KB pages
+        const int cp = (c & ~0x7ffff) | ((c & 31) << 14) | ((c >> 5) & 0x3fff);
+        rank_out[r] = atomicAdd(&table[cp], 1);
+      }
     }
   }
 }
 
-int main() {
+int main(int argc, char **argv) {
+  const bool ring = argc > 1 && argv[1][0] == 'r';
   const int frames = 4, n = 1440000, stride = 7, cells = frames * 512 * 512;
   std::vector<float> h((size_t)n * stride);
   srand(1);
   for (int r = 0; r < n; r++) {
     h[(size_t)r * stride] = (float)(r / (n / frames));
-    h[(size_t)r * stride + 1] = -51.2f + 102.4f * (rand() / (RAND_MAX + 1.0f));
-    h[(size_t)r * stride + 2] = -51.2f + 102.4f * (rand() / (RAND_MAX + 1.0f));
+    if (ring) {                                                // the LiDAR-like cloud of bench.py --dist ring: r = 70 u^2 around the sensor
+      const float u = rand() / (RAND_MAX + 1.0f), th = 6.2831853f * (rand() / (RAND_MAX + 1.0f));
+      float x = 70.f * u * u * cosf(th), y = 70.f * u * u * sinf(th);
+      if (fabsf(x) >= 51.2f || fabsf(y) >= 51.2f) x = y = 0.f;
+      h[(size_t)r * stride + 1] = x;
+      h[(size_t)r * stride + 2] = y;
+    } else {
+      h[(size_t)r * stride + 1] = -51.2f + 102.4f * (rand() / (RAND_MAX + 1.0f));
+      h[(size_t)r * stride + 2] = -51.2f + 102.4f * (rand() / (RAND_MAX + 1.0f));
+    }
   }
   float *pts; int *table, *cell, *rank;
   hipMalloc(&pts, h.size() * 4); hipMalloc(&table, cells * 4); hipMalloc(&cell, n * 4); hipMalloc(&rank, n * 4);
   hipMemcpy(pts, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char *names[5] = {"returning atomicAdd (agent scope)", "non-returning atomic add", "plain store", "rows only", "returning atomic, workgroup scope"};
-  for (int mode = 0; mode < 5; mode++) {
+  const char *names[7] = {"returning atomicAdd (agent scope)", "non-returning atomic add", "plain store", "rows only", "returning atomic, workgroup scope",
+                          "returning atomic, table transposed in 4-KB blocks", "returning atomic, neighbours 64 KB apart"};
+  for (int mode = 0; mode < 7; mode++) {
     float best = 1e9f;
     for (int rep = 0; rep < 6; rep++) {
       hipMemsetAsync(table, 0, cells * 4, 0);
@@ -53,11 +72,13 @@ int main() {
       if (mode == 2) hipLaunchKernelGGL(k_pass<2>, dim3(blocks), dim3(256), 0, 0, pts, n, stride, table, cell, rank, cells);
       if (mode == 3) hipLaunchKernelGGL(k_pass<3>, dim3(blocks), dim3(256), 0, 0, pts, n, stride, table, cell, rank, cells);
       if (mode == 4) hipLaunchKernelGGL(k_pass<4>, dim3(blocks), dim3(256), 0, 0, pts, n, stride, table, cell, rank, cells);
+      if (mode == 5) hipLaunchKernelGGL(k_pass<5>, dim3(blocks), dim3(256), 0, 0, pts, n, stride, table, cell, rank, cells);
+      if (mode == 6) hipLaunchKernelGGL(k_pass<6>, dim3(blocks), dim3(256), 0, 0, pts, n, stride, table, cell, rank, cells);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (rep > 0 && ms < best) best = ms;
     }
-    printf("%-36s %7.1f us\n", names[mode], best * 1e3f);
+    printf("%-52s %7.1f us\n", names[mode], best * 1e3f);
   }
   return 0;
 }
