@@ -87,6 +87,9 @@ def parse_args(argv=None):
                     'bit-identical; reported under its own metric name, never the headline')
     ap.add_argument('--layer-table', default=None, help='write the per-shape table of the instrumented pass (kernel, shape, launches per step, '
                     'us per launch, executed TFLOP/s) to this file')
+    ap.add_argument('--host-input', action='store_true', help='informational: the batch lives in PINNED HOST memory and is uploaded over PCIe every '
+                    'step (asynchronously, on the pipelined runner\'s side stream) instead of being resident in HBM -- the PCIe-inclusive rate '
+                    'of DESIGN 4; never the headline')
     ap.add_argument('--optin', action='store_true', help='also time the same workload with the OPT-IN split-bf16 conv arithmetic (informational)')
     ap.add_argument('--graph', action='store_true', help='replay the whole forward as one hipGraph (launch-bound small batches)')
     ap.add_argument('--conv-algo', default=None, choices=['auto', 'direct', 'winograd', 'winograd4', 'winograd4f', 'winograd4h', 'winograd4c', 'bf16x3', 'bf16'],
@@ -741,6 +744,11 @@ def main(argv=None):
         work_bufs = [work, torch.empty_like(pristine)]
         work.copy_(pristine)
         pipelined.prepare(work, batch, metas)       # setup: every replica builds its packed weights / buffers once, before the W warm-up steps
+    host_pristine = None
+    if args.host_input:
+        if pipelined is None:
+            raise SystemExit('--host-input measures the pipelined inference runner (car / ego / early / disco without --no-pipeline / --graph / --train)')
+        host_pristine = pristine.cpu().pin_memory()
     pipe_state = {'n': 0}
     lately_pipe = None
     if (lately is not None and not args.no_pipeline and not args.latency and not args.plugin_default and not args.graph
@@ -756,7 +764,7 @@ def main(argv=None):
         if pipelined is not None:
             i = pipe_state['n']
             pipe_state['n'] = i + 1
-            return pipelined.submit(work_bufs[i & 1], batch, metas, copy_from=pristine)      # pred_dicts of the PREVIOUS step
+            return pipelined.submit(work_bufs[i & 1], batch, metas, copy_from=host_pristine if host_pristine is not None else pristine)      # pred_dicts of the PREVIOUS step
         if sharded_runner is not None:
             _frames, preds_local = sharded_runner(pristine, batch, metas)
             return preds_local
@@ -951,7 +959,8 @@ def main(argv=None):
                       'bf16': 'bf16 training loop [--train only]: bf16 activation / gradient storage between the 3x3 layers, forward / data-gradient / '
                               'weight-gradient 3x3 convs (teachers included) on v_mfma_f32_32x32x16_bf16 with f32 accumulate; f32 master weights, BatchNorm '
                               'statistics, 1x1 / k2s2 layers, PFN, losses and optimizer'}.get(algo, 'f32'),
-            'data': 'synthetic' + (' (ring distribution)' if args.dist == 'ring' else ''),
+            'data': 'synthetic' + (' (ring distribution)' if args.dist == 'ring' else '')
+                    + (' -- INFORMATIONAL: batch uploaded from pinned host memory every step (--host-input)' if args.host_input else ''),
             'config': {'workload': conf['name'] if not args.train else ('v2x_pointpillar_disco TRAINING iteration (3 frozen BEV makers + '
                        'trainable VFE/backbone/fusion/head forward+backward, CenterNet + distillation losses, clip, Adam one-cycle)'
                        if args.config == 'disco' else conf['name'] + ' -- TRAINING iteration (VFE/backbone/%shead forward+backward, CenterNet '
