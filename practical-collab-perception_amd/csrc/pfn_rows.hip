@@ -1015,7 +1015,8 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   if (blocks > 256 * wps) blocks = 256 * wps;
   // the crowded pillars the wave tiles pass over run on workgroups at the FRONT of the same grid (none in most clouds: those workgroups
   // read the list length and leave)
-  p.crowd_blocks = 64;
+  static const int cb_env = [] { const char *e = getenv("PCP_PFN_CROWD_BLOCKS"); return e ? atoi(e) : 0; }();      // diagnostic override
+  p.crowd_blocks = cb_env > 0 ? cb_env : 128;         // 64 -> 128: 6-agent ring cloud 230 -> 197 us (more than 128: nothing); no crowded pillar, no cost
   blocks += p.crowd_blocks;
   hipStream_t stream = (hipStream_t)stream_;
 #define PCP_PFN_ROWS(NR)                                                                                            \
