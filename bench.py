@@ -438,11 +438,25 @@ class AbiTimer:
         """-> list of dicts sorted by time: label, ms_per_step, launches_per_step, executed/algorithmic flops per step, bound, peak"""
         import torch
         torch.cuda.synchronize()
+        # What an event pair itself reads with NOTHING between the two records (tools/event_overhead.py: 4.5 us on MI355X, p10 - p90
+        # 4.44 - 4.60, the same on an idle and on a busy queue; a one-element fill between them reads 6.2 us).  It is in every bracketed
+        # launch's elapsed time and not in the kernel's duration as rocprofv3 reports it (k_wino4c: 103.7 us bracketed, 99.7 us in the
+        # rocprofv3 summary of the same run), so it is measured here, in this process, and taken off every launch; the raw sums are kept.
+        s = torch.cuda.current_stream()
+        trials = []
+        for _ in range(64):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            e1.record(s)
+            trials.append((e0, e1))
+        torch.cuda.synchronize()
+        self.bracket_ms = float(sorted(a.elapsed_time(b) for a, b in trials)[len(trials) // 2])
         fam = {}
 
-        def add(label, ms, ex, alg, bound, peak):
-            f = fam.setdefault(label, dict(kernel=label, ms=0.0, launches=0, exec_flops=0.0, alg_flops=0.0, bound=bound, peak=peak))
-            f['ms'] += ms
+        def add(label, ms_raw, ex, alg, bound, peak):
+            f = fam.setdefault(label, dict(kernel=label, ms=0.0, ms_raw=0.0, launches=0, exec_flops=0.0, alg_flops=0.0, bound=bound, peak=peak))
+            f['ms'] += max(ms_raw - self.bracket_ms, 0.0)
+            f['ms_raw'] += ms_raw
             f['launches'] += 1
             f['exec_flops'] += ex or 0.0
             f['alg_flops'] += alg or 0.0
@@ -452,7 +466,7 @@ class AbiTimer:
             add(label, ms, ex, alg, bound, peak)
             if shape:
                 L = self.layers.setdefault((label.split(' ')[0], shape), [0.0, 0, 0.0, 0.0])
-                L[0] += ms
+                L[0] += max(ms - self.bracket_ms, 0.0)
                 L[1] += 1
                 L[2] += ex or 0.0
                 L[3] += alg or 0.0
@@ -464,6 +478,7 @@ class AbiTimer:
         out = sorted(fam.values(), key=lambda f: -f['ms'])
         for f in out:
             f['ms_per_step'] = f['ms'] / steps
+            f['ms_raw_per_step'] = f['ms_raw'] / steps
             f['launches_per_step'] = f['launches'] / steps
         return out
 
@@ -911,8 +926,11 @@ def main(argv=None):
             ach = dom['exec_flops'] / (dom['ms'] * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(ach, 3), 'peak': dom['peak'], 'unit': 'TFLOP/s',
                     'frac': round(ach / dom['peak'], 4),
+                    'frac_uncorrected': round(dom['exec_flops'] / (dom['ms_raw'] * 1e-3) / 1e12 / dom['peak'], 4),
                     'note': 'achieved = flops this kernel EXECUTES on the matrix pipe (Winograd F(2x2): 16 products per 2x2 tile, F(4x4): 36 per 4x4 tile, padding included) / '
-                            'its HIP-event time; algorithmic_tflops = flops of the equivalent direct convolution / the same time',
+                            'its HIP-event time, each launch less the time an EMPTY event pair reads in this process (event_bracket_overhead_us; '
+                            'frac_uncorrected and avg_launch_us_uncorrected keep the raw bracket); algorithmic_tflops = flops of the equivalent direct '
+                            'convolution / the same time',
                     'algorithmic_tflops': round(dom['alg_flops'] / (dom['ms'] * 1e-3) / 1e12, 3)}
         else:
             roof = {'bound': 'hbm' if dom['bound'] == 'hbm' else 'latency', 'kernel': dom['kernel'], 'achieved': None, 'peak': HBM_PEAK_GBS,
@@ -920,6 +938,8 @@ def main(argv=None):
         traffic, traffic_note = pmc_traffic(args.config, dom['kernel']) if (algo == 'auto' and not args.train) else (None, 'not collected for this mode')
         roof.update({'traffic': traffic, **({'traffic_note': traffic_note} if traffic_note else {}),
                      'avg_launch_us': round(1e3 * dom['ms'] / max(dom['launches'], 1), 2),
+                     'avg_launch_us_uncorrected': round(1e3 * dom['ms_raw'] / max(dom['launches'], 1), 2),
+                     'event_bracket_overhead_us': round(1e3 * timer.bracket_ms, 2),
                      'measured_in': 'the instrumented pass of this run: every launch between two HIP events on ONE stream, batch by batch (no '
                                     'maker overlap, no batch pipelining) -- compare with the rocprofv3 summary of `bench.py --no-overlap '
                                     '--no-pipeline` (profiles/r05_bench_disco_b4_single_stream_kernel_stats.csv), not with the overlapped run '
@@ -937,6 +957,7 @@ def main(argv=None):
         # the HBM-bound VFE stage -- pillariser + fused PFN / scatter (+ canvas clear) -- against the HBM peak; (iii): the
         # latency-bound tail (decode + rotated NMS + gather) in microseconds per step
         vfe_ms = sum(f['ms_per_step'] for f in fams if f['kernel'].split(' ')[0] in ('pcp_voxelize', 'k_pfn', 'pcp_canvas_clear', 'pcp_select_transform_compact', 'pcp_pillarise_rows', 'k_pfn_rows'))
+        vfe_ms_raw = sum(f['ms_raw_per_step'] for f in fams if f['kernel'].split(' ')[0] in ('pcp_voxelize', 'k_pfn', 'pcp_canvas_clear', 'pcp_select_transform_compact', 'pcp_pillarise_rows', 'k_pfn_rows'))
         vfe_bytes = timer.vfe_bytes / INSTR_STEPS
         vfe_roof = None
         if vfe_ms > 0 and vfe_bytes > 0:
@@ -944,8 +965,10 @@ def main(argv=None):
             vfe_roof = {'bound': 'hbm', 'stage': 'pillarise (+ agent selection) + fused PFN + scatter / pillar rows, all VFE passes of the step',
                         'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                         'algorithmic_mb_per_step': round(vfe_bytes / 1e6, 2), 'ms_per_step': round(vfe_ms, 4),
+                        'ms_per_step_uncorrected': round(vfe_ms_raw, 4), 'frac_uncorrected': round(vfe_bytes / (vfe_ms_raw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         'note': 'algorithmic bytes (SURVEY 8(d) row 1): points read once + 16 B per pillar + the dense canvas or the 256-B pillar rows; '
-                                'time = HIP events around the launches of the instrumented single-stream pass'}
+                                'time = HIP events around the C-ABI calls of the instrumented single-stream pass, each less the empty event pair '
+                                '(roofline.event_bracket_overhead_us); *_uncorrected keep the raw brackets'}
         decode_nms_us = round(1e3 * sum(f['ms_per_step'] for f in fams if f['kernel'].split(' ')[0] in
                                         ('pcp_centerhead_decode', 'pcp_nms_rotated', 'pcp_nms_normal', 'pcp_gather_detections', 'pcp_anchor_decode', 'pcp_topk_boxes')), 1)
         line = {
