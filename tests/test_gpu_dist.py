@@ -347,6 +347,13 @@ def test_bench_pipelined_default_and_batch_by_batch_agree(tmp_path):
     assert 'software-pipelined' in piped['config']['mode'] and 'software-pipelined' not in plain['config']['mode']
     assert piped['config']['final_boxes_last_step'] == plain['config']['final_boxes_last_step'] > 0
     assert piped['roofline']['kernel'] == plain['roofline']['kernel'] and piped['roofline']['next_mfma_kernels']
+    # per-launch times are HIP-event brackets less what an empty event pair reads in the same process; the raw values ride along
+    for line in (piped, plain):
+        r, h = line['roofline'], line['roofline_hbm']
+        assert 0.5 < r['event_bracket_overhead_us'] < 25.0
+        assert abs((r['avg_launch_us_uncorrected'] - r['avg_launch_us']) - r['event_bracket_overhead_us']) < 0.05
+        assert r['frac_uncorrected'] < r['frac'] < 1.0 and h['frac_uncorrected'] < h['frac'] < 1.0
+        assert h['ms_per_step'] < h['ms_per_step_uncorrected']
     rows = table.read_text().splitlines()
     assert rows[0].split()[:2] == ['kernel', 'shape'] and any(r.startswith('k_wino4c') for r in rows[1:])
 
