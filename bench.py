@@ -1,7 +1,7 @@
 """bench.py -- frames/s of the PointPillars collaborative-perception hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config disco|car|ego|early|lately6] [--batch B] [--dist uniform|ring]
-                    [--no-pipeline] [--pipeline-replicas R] [--layer-table FILE]
+                    [--no-pipeline] [--pipeline-replicas R] [--layer-table FILE] [--host-input] [--no-secondary]
 
 A "step" is one pass of the hot path (points resident in HBM -> final boxes) over one batch of B synthetic frames per GPU.
 Default workload = the one BASELINE.json's metric is quoted on ("60k-pt cloud, 6 agents"): v2x_pointpillar_disco.yaml, mid fusion of
@@ -13,7 +13,9 @@ queued before the box counts of step i are read on the host, the BEV-maker strea
 alternate between --pipeline-replicas (2) copies of the model on their own HIP streams.  All K steps AND their K host reads lie inside the
 timed region (the last read is flushed before the closing synchronize); every step's detections are bit-identical to the batch-by-batch
 ones (GPU tests).  --no-pipeline measures batch by batch: every step ends in its own host read.  --layer-table FILE writes the per-shape
-kernel table of the instrumented pass.
+kernel table of the instrumented pass.  --host-input uploads the batch from pinned host memory every step (the PCIe-inclusive rate,
+informational); the default line also carries `secondary_ring`, the same command on the LiDAR-like cloud (--no-secondary skips it).
+Per-launch times of the roofline blocks are HIP-event brackets less what an empty event pair reads in this process (raw: *_uncorrected).
 
 --gpus N > 1: bench.py starts N ranks ITSELF (a `python -m torch.distributed.run` child, spawned before this process touches the GPU)
 unless it already runs under a launcher (WORLD_SIZE set; it then insists on WORLD_SIZE == N).  One rank per GPU, backend nccl (= RCCL).
