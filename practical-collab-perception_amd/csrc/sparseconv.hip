@@ -303,18 +303,21 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_conv_s2(SpParams p) {
 #pragma unroll
       for (int it = 0; it < 2; it++) {
         const float *at = it == 0 ? at0 : at1;
-        f32x4 a[2][4];
-#pragma unroll
-        for (int rtile = 0; rtile < 2; rtile++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) a[rtile][j] = *reinterpret_cast<const f32x4 *>(at + (rtile * 16 + m16) * SP_ALD + 16 * j + 4 * q4);
 #pragma unroll
         for (int rtile = 0; rtile < 2; rtile++) {
           f32x4c c = {0.f, 0.f, 0.f, 0.f};
+          // a row tile without rows (the second tile of an item of at most 16 rows -- the thin outskirts of a LiDAR-like frame put one to
+          // five rows into a tap -- and both tiles of the item past an odd count) is passed over: its products would multiply zero rows
+          // and be added nowhere.  Wave-uniform branch.
+          if (rows_i[it] > 16 * rtile) {
+            f32x4 a[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++)
+            for (int j = 0; j < 4; j++) a[j] = *reinterpret_cast<const f32x4 *>(at + (rtile * 16 + m16) * SP_ALD + 16 * j + 4 * q4);
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rtile][j][kk], (it == 0 ? w0 : w1)[j][kk], c, 0, 0, 0);
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+              for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][kk], (it == 0 ? w0 : w1)[j][kk], c, 0, 0, 0);
+          }
           cv[it][rtile] = c;
         }
       }

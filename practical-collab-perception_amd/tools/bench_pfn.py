@@ -1,5 +1,5 @@
 """Micro-benchmark of the pillariser + fused PFN/scatter (pcp_voxelize, pcp_pfn_scatter) on the synthetic clouds of bench.py:
-usage: bench_pfn.py [frames=4] [agents=1|6]   (agents = 6: the merged 360k-point cloud of early fusion / DiscoNet's main branch)"""
+usage: bench_pfn.py [frames=4] [agents=1|6] [dist=uniform|ring]   (agents = 6: the merged 360k-point cloud of early fusion / DiscoNet's main branch)"""
 import sys
 from pathlib import Path
 
@@ -25,10 +25,11 @@ def timeit(fn, iters=20):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     agents = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    dist = sys.argv[3] if len(sys.argv) > 3 else 'uniform'
     d = torch.device('cuda:0')
     frames = []
     for b in range(B):
-        clouds = [synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b) for a in range(agents)]
+        clouds = [synth.agent_cloud(a, 60000, 'car', seed=synth.SEED_BASE + b, dist=dist) for a in range(agents)]
         frames.append(np.concatenate(clouds, 0))
     pts = torch.from_numpy(synth.collate(frames)).to(d)
     grid = ops.make_grid([-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1], B)
