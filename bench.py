@@ -152,6 +152,21 @@ def build_model(cfg):
     return model, state, ds
 
 
+def set_pipeline_mode(model, overlap=True, dense_first_layer=False):
+    """the mode every bench.py line without --plugin-default measures (tests/test_gpu_bench_mode.py pins it on reference fixtures through this
+    very function): no per-pillar API tensors, buffers kept across frames, the first backbone layer from the pillar list where the cloud is
+    sparse, the frozen BEV-maker passes of a DiscoNet forward on their own HIP streams.  Returns whether the makers are overlapped."""
+    overlapped = False
+    if overlap and hasattr(model, 'overlap_makers') and any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
+        overlapped = model.overlap_makers = True                 # frozen BEV-maker passes on their own HIP streams, joined in front of the fusion module
+    for m in model.modules():
+        if hasattr(m, 'materialize_pillars'):
+            m.materialize_pillars = False       # per-pillar API tensors are not consumed downstream (SURVEY 8(d))
+            m.reuse_buffers = True
+            m.sparse_first_layer = not dense_first_layer   # sparse clouds: first backbone layer from the pillar list, no dense canvas
+    return overlapped
+
+
 def make_points(conf, batch, rank, dist='uniform'):
     """B frames per rank; frame f of rank r uses agent streams 1000*r + 10*f + a (distinct data on every rank)."""
     import numpy as np
@@ -646,19 +661,12 @@ def main(argv=None):
         raise SystemExit('--train: use --config car | ego | early | disco')
     model = model.to(dev).eval()
     overlapped = False
-    if not args.plugin_default and not args.no_overlap and hasattr(model, 'overlap_makers') \
-            and any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
-        overlapped = model.overlap_makers = True                 # frozen BEV-maker passes on their own HIP streams, joined in front of the fusion module
     if args.elide_dead_makers:
         if args.train or not hasattr(model, 'elide_dead_makers'):
             raise SystemExit('--elide-dead-makers: DiscoNet inference only')
         model.elide_dead_makers = True
     if not args.plugin_default:
-        for m in model.modules():
-            if hasattr(m, 'materialize_pillars'):
-                m.materialize_pillars = False       # per-pillar API tensors are not consumed downstream
-                m.reuse_buffers = True
-                m.sparse_first_layer = not args.dense_first_layer   # sparse clouds: first backbone layer from the pillar list, no dense canvas
+        overlapped = set_pipeline_mode(model, overlap=not args.no_overlap, dense_first_layer=args.dense_first_layer)
     pts_np, metas = make_points(conf, batch, rank, args.dist)
     pristine = torch.from_numpy(pts_np).to(dev)
     work = torch.empty_like(pristine)

@@ -7,7 +7,9 @@
  *     *_workspace_bytes() query; nothing is allocated, freed or synchronised inside a call (hipGraph-capturable);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
  *   - the return value is a status (PCP_OK = 0); the library never calls exit() (the reference's op does:
- *     pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-38) and keeps no global mutable state (re-entrant);
+ *     pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-38), never reads the environment, and is re-entrant: what a launch does is a function
+ *     of its arguments and of the option table below (A/B and diagnostic overrides the host sets explicitly; all default to "built-in
+ *     rule"), plus a read-only cache of each device's CU count keyed by device ordinal;
  *   - dense maps are NHWC float32 ("pixel-major": channels contiguous), the layout the MFMA implicit-GEMM tiles read
  *     coalesced; the Python host exposes them to callers as NCHW-shaped channels_last views.
  *
@@ -35,6 +37,21 @@ enum {
 
 int pcp_abi_version(void);
 const char *pcp_status_string(int status);
+
+/* The only process-wide mutable state of the library: integer overrides of built-in launch rules, for A/B measurements and tests.
+ * value < 0 restores the built-in rule (the initial state of every option); reads and writes are atomic, a launch reads an option once.
+ * The Python host (pcp_amd/lib.py) maps the PCP_* environment variables of earlier rounds onto these ONCE, when it loads the library. */
+enum {
+  PCP_OPT_PFN_CROWD = 0,        /* pcp_pillarise_rows: records from which a pillar gets a workgroup of pcp_pfn_rows (0 = never; >= 64; built-in 192) */
+  PCP_OPT_PFN_CROWD_BLOCKS = 1, /* pcp_pfn_rows: workgroups at the front of the grid that run the crowded pillars (built-in 128) */
+  PCP_OPT_PFN_WPS = 2,          /* pcp_pfn_rows: waves per SIMD the launch is held to, 2 or 3 (built-in: by cloud size) */
+  PCP_OPT_WINO4C_NW = 3,        /* pcp_conv3x3_winograd4c: 8 = the eight-wave 128-channel form where cout_pad % 128 == 0 (built-in: four waves) */
+  PCP_OPT_MP_TH16_MIN = 4,      /* pcp_mp_conv3x3: work items from which the 16-row item is used (built-in 256) */
+  PCP_OPT_MP_DIAG = 5,          /* pcp_mp_conv3x3: timing-only diagnostic builds of the kernel body (built-in 0) */
+  PCP_OPT_COUNT = 6
+};
+int pcp_set_option(int32_t option, int64_t value);
+int64_t pcp_get_option(int32_t option);          /* the override, or -1 while the built-in rule applies (also for an unknown option) */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a1 / a4  dynamic pillarisation.
@@ -113,6 +130,15 @@ int pcp_pillarise_rows(const float *points, int64_t n, int32_t row_stride, int32
                        int32_t *counters, int32_t flags, void *stream);
 int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, const float *w0, const float *b0,
                  const float *w1, const float *b1, float *pillar_features, float *canvas, void *stream);
+/* The reference's index tensors ON DEMAND from the workspace a pcp_pillarise_rows (num_raw as in that call, any flags, outputs NULL or not) or a
+ * pcp_voxelize (num_raw = 0) with the same grid and n left behind -- the tables pcp_pfn_rows / pcp_sparse_conv3x3_s2 read, so what comes out is
+ * the pillar list the maps were computed from (dynamic_pillar_vfe.py:104-108, 137-147).  Every output may be NULL:
+ *   voxel_coords (n, 4) int32, first P rows written: [b, 0, y, x];  row_rank (n,) int32: pillar rank of input row i, -1 for a masked row
+ *   (unq_inv = row_rank[row_rank >= 0]);  slot_rank / slot_canvas_row (n,) int32, first N' written (num_raw > 0 only): pillar rank and canvas row
+ *   (b * ny + y) * nx + x carried by the record in slot s of the pillar-ordered rows;  counters (PCP_VOX_COUNTERS,) int32 as the workspace holds
+ *   them: P, N', records of multi-point pillars, single-point pillars. */
+int pcp_pillar_index_export(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, int32_t *voxel_coords,
+                            int32_t *row_rank, int32_t *slot_rank, int32_t *slot_canvas_row, int32_t *counters, void *stream);
 
 /* The PillarFeatureNet variants none of the reference's configs use (WITH_DISTANCE, USE_ABSLOTE_XYZ False, NUM_FILTERS other than
  * [64, 64], any raw width) run as separate steps: pcp_voxelize, then

@@ -544,12 +544,8 @@ int mc_tile_rows(const pcp_mp_conv3x3_t *d) {
   // 16-row items (8 waves, two per SIMD) once they give every CU an item, else 8-row items (4 waves): 128->128 @128^2 x 4 frames 21.7 vs
   // 25.9 us with 256 sixteen-row items, 256->256 @64^2 30.3 vs 24.0 us with only 128 of them
   const long long big = (long long)d->batch * ((d->in_h + 15) / 16) * ((d->in_w + MC_TW - 1) / MC_TW) * (d->cout_pad / MC_BN);
-  static long long min16 = 0;                                    // PCP_MP_TH16_MIN: A/B knob for the item-size rule
-  if (min16 == 0) {
-    const char *e = getenv("PCP_MP_TH16_MIN");
-    min16 = e ? atoll(e) : 256;
-    if (min16 <= 0) min16 = 256;
-  }
+  long long min16 = pcp_option(PCP_OPT_MP_TH16_MIN, 256);        // A/B knob for the item-size rule
+  if (min16 <= 0) min16 = 256;
   return big >= min16 ? 16 : 8;
 }
 
@@ -641,12 +637,8 @@ int pcp_mp_conv3x3(const pcp_mp_conv3x3_t *d, const void *in, const void *w_pack
       p.n_items = d->batch * p.tiles_y * p.tiles_x * p.n_nb;
       p.n_slices = d->cin / MC_CK;
       p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
-      { const char *e = getenv("PCP_MP_DIAG"); p.diag = e ? atoi(e) : 0; }
-      static int n_cu = 0;                                        // one process drives one device (bench.py / tools: one rank per GPU)
-      if (n_cu == 0) {
-        int dev = 0, v = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-      }
+      p.diag = (int)pcp_option(PCP_OPT_MP_DIAG, 0);
+      const int n_cu = pcp_current_device_cus();                  // cached per device ordinal (abi.hip)
       const int nwg = p.n_items < n_cu ? p.n_items : n_cu;
       const bool ob = d->out_dtype == PCP_DT_BF16;
       if (th == 16) {

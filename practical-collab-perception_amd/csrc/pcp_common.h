@@ -15,6 +15,10 @@
 
 static inline size_t pcp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// abi.hip: the override of option `option` (PCP_OPT_*, include/pcp_hip.h) or `builtin` while none is set; the CU count of the current device
+__attribute__((visibility("hidden"))) long long pcp_option(int option, long long builtin);
+__attribute__((visibility("hidden"))) int pcp_current_device_cus();
+
 // Zero fill as a KERNEL node (hipMemsetAsync nodes replayed incorrectly inside captured hipGraphs on this stack: the second
 // replay of a graph containing them faulted, profiles/scripts/debug/dbg_graph.py): 16-byte stores, grid-stride.
 __global__ static void pcp_k_zero(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, size_t ntail) {

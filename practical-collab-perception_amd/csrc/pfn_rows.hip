@@ -1004,9 +1004,9 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   magic_div((unsigned)(grid->nx * grid->ny), &p.plane_m, &p.plane_sh);
   magic_div((unsigned)grid->ny, &p.ny_m, &p.ny_sh);
   // waves per SIMD the build is held to: three fit since the kernel shrank to 168 registers (5 raw columns; 11 would spill) and pay on the
-  // large clouds (-3 % at 1.2 - 1.4 M points, -6 % on the LiDAR-like one), two stay better on small ones (+7 % at 240 k); PCP_PFN_WPS overrides
-  static const int wps_env = [] { const char *e = getenv("PCP_PFN_WPS"); return e ? atoi(e) : 0; }();
-  const int wps = wps_env ? wps_env : ((num_raw <= 5 && n >= 600000) ? 3 : 2);
+  // large clouds (-3 % at 1.2 - 1.4 M points, -6 % on the LiDAR-like one), two stay better on small ones (+7 % at 240 k); PCP_OPT_PFN_WPS overrides
+  const int wps_opt = (int)pcp_option(PCP_OPT_PFN_WPS, 0);
+  const int wps = (wps_opt == 2 || wps_opt == 3) ? wps_opt : ((num_raw <= 5 && n >= 600000) ? 3 : 2);
   int blocks = (p.n_tiles_max + 3) / 4;
   if (canvas) {                                 // the waves also share the canvas's empty cells: at most ~512 cells each, however small the cloud
     const int64_t by_cells = (cells + 4 * 512 - 1) / (4 * 512);
@@ -1015,8 +1015,8 @@ extern "C" int pcp_pfn_rows(const pcp_grid_t *grid, const void *workspace, int64
   if (blocks > 256 * wps) blocks = 256 * wps;
   // the crowded pillars the wave tiles pass over run on workgroups at the FRONT of the same grid (none in most clouds: those workgroups
   // read the list length and leave)
-  static const int cb_env = [] { const char *e = getenv("PCP_PFN_CROWD_BLOCKS"); return e ? atoi(e) : 0; }();      // diagnostic override
-  p.crowd_blocks = cb_env > 0 ? cb_env : 128;         // 64 -> 128: 6-agent ring cloud 230 -> 197 us (more than 128: nothing); no crowded pillar, no cost
+  const int cb_opt = (int)pcp_option(PCP_OPT_PFN_CROWD_BLOCKS, 0);                                                  // diagnostic override
+  p.crowd_blocks = (cb_opt > 0 && cb_opt <= 4096) ? cb_opt : 128;         // 64 -> 128: 6-agent ring cloud 230 -> 197 us (more than 128: nothing); no crowded pillar, no cost
   blocks += p.crowd_blocks;
   hipStream_t stream = (hipStream_t)stream_;
 #define PCP_PFN_ROWS(NR)                                                                                            \

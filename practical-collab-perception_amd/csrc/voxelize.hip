@@ -431,13 +431,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__res
   }
 }
 
-// pillars of at least this many records are listed for k_pfn_crowd (pcp_common.h); PCP_PFN_CROWD=<n> overrides (0: never)
+// pillars of at least this many records are listed for k_pfn_crowd (pcp_common.h); PCP_OPT_PFN_CROWD overrides (0: never)
 inline int crowd_threshold() {
-  const char *e = getenv("PCP_PFN_CROWD");
-  if (!e || !*e) return PCP_PFN_CROWD;
-  const int v = atoi(e);
+  const long long v = pcp_option(PCP_OPT_PFN_CROWD, PCP_PFN_CROWD);
   if (v <= 0) return 0;
-  return v < PCP_PFN_CROWD_MIN ? PCP_PFN_CROWD_MIN : v;
+  return v < PCP_PFN_CROWD_MIN ? PCP_PFN_CROWD_MIN : (int)(v > 0x3fffffff ? 0x3fffffff : v);
 }
 
 // The pillariser: zero fill of the histogram, k_point_cells, k_cell_tile_sums, k_cell_finish, k_point_place (five launches; round 4: six).
@@ -1067,6 +1065,68 @@ extern "C" int pcp_voxelize_row_order(const pcp_grid_t *grid, const void *worksp
   if (pcp_zero_async(cursor_scratch, sizeof(int32_t), stream) != PCP_OK) return PCP_ERR_LAUNCH;
   hipLaunchKernelGGL(k_row_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int *)(ws + L.point_cell),
                      (const int *)(ws + L.bucket_order), (const int *)(ws + L.counters), (long long)n, order, cursor_scratch);
+  PCP_CHECK_LAUNCH();
+  return PCP_OK;
+}
+
+// ---- the reference's index tensors, on demand, from a pillar list that was built WITHOUT them ---------------------------------------------------
+// The pipeline mode (bench.py, tools/test.py --fast) calls pcp_pillarise_rows with voxel_coords = unq_inv = NULL: nothing downstream reads them.
+// pcp_pillar_index_export rebuilds them from what that call left in the workspace -- the very tables pcp_pfn_rows / pcp_sparse_conv3x3_s2 consume
+// (point_cell, cell_rank, pillar_cell, the records) -- so a caller (a late `batch_dict['voxel_coords']` reader, the parity tests) can have
+// dynamic_pillar_vfe.py:104-108,137-147's tensors for exactly the pillar list the maps were computed from.
+namespace {
+
+__global__ __launch_bounds__(256) void k_index_export(long long n, pcp_grid_t g, const int *__restrict__ point_cell, const int *__restrict__ cell_rank,
+                                                      const int *__restrict__ pillar_cell, const int *__restrict__ counters_ws,
+                                                      const float *__restrict__ srows, int rs, int *__restrict__ voxel_coords,
+                                                      int *__restrict__ row_rank, int *__restrict__ slot_rank, int *__restrict__ slot_canvas_row,
+                                                      int *__restrict__ counters_out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r == 0 && counters_out) {
+#pragma unroll
+    for (int i = 0; i < PCP_VOX_COUNTERS; i++) counters_out[i] = counters_ws[i];
+  }
+  if (r >= n) return;
+  if (row_rank) {
+    const int c = point_cell[r];
+    row_rank[r] = c >= 0 ? cell_rank[c] : -1;
+  }
+  if (voxel_coords && r < counters_ws[0]) {
+    const int c = pillar_cell[r];
+    const int plane = g.nx * g.ny;
+    const int b = c / plane, rem = c - b * plane;
+    const int cx = rem / g.ny, cy = rem - cx * g.ny;
+    *reinterpret_cast<int4 *>(voxel_coords + 4 * r) = make_int4(b, 0, cy, cx);
+  }
+  if (srows && r < counters_ws[1]) {
+    if (slot_rank) slot_rank[r] = __float_as_int(srows[r * rs + rs - 3]) & 0x7fffffff;        // the sign bit tags the records of crowded pillars
+    if (slot_canvas_row) slot_canvas_row[r] = __float_as_int(srows[r * rs + rs - 1]);
+  }
+}
+
+}  // namespace
+
+extern "C" int pcp_pillar_index_export(const pcp_grid_t *grid, const void *workspace, int64_t n, int32_t num_raw, int32_t *voxel_coords,
+                                       int32_t *row_rank, int32_t *slot_rank, int32_t *slot_canvas_row, int32_t *counters, void *stream_) {
+  if (!grid || !workspace || n < 0 || grid->nx <= 0 || grid->ny <= 0 || grid->batch_size <= 0) return PCP_ERR_ARG;
+  if (num_raw != 0 && (num_raw < 3 || num_raw > 13)) return PCP_ERR_ARG;
+  if ((slot_rank || slot_canvas_row) && num_raw == 0) return PCP_ERR_ARG;                        // a pcp_voxelize workspace holds no records
+  if (((uintptr_t)voxel_coords) & 15) return PCP_ERR_ARG;
+  const int64_t cells = (int64_t)grid->batch_size * grid->nx * grid->ny;
+  if (cells >= (1LL << 31) || n >= (1LL << 31)) return PCP_ERR_UNSUPPORTED;
+  const int64_t n_alloc = n > 0 ? n : 1;
+  const VoxLayout L = pcp_vox_layout(cells, n_alloc);
+  const char *ws = (const char *)workspace;
+  const float *srows = nullptr;
+  int rs = 0;
+  if (num_raw) {
+    const RowsLayout R = pcp_rows_layout(cells, n_alloc, num_raw);
+    srows = (const float *)(ws + R.srows);
+    rs = pcp_rows_stride(num_raw);
+  }
+  hipLaunchKernelGGL(k_index_export, dim3((unsigned)((n_alloc + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, (long long)n, *grid,
+                     (const int *)(ws + L.point_cell), (const int *)(ws + L.cell_rank), (const int *)(ws + L.pillar_cell),
+                     (const int *)(ws + L.counters), srows, rs, voxel_coords, row_rank, slot_rank, slot_canvas_row, counters);
   PCP_CHECK_LAUNCH();
   return PCP_OK;
 }

@@ -578,8 +578,7 @@ extern "C" int pcp_conv3x3_winograd4c(const pcp_conv3x3_t *d, const float *in, c
   // 297.6 us) and 15 - 28 % behind on 64^2 maps whose 128-channel items cover the chip 0.5 or 1.25 times; inside bench.py -- two replicas'
   // kernels sharing the chip -- a dispatch rule that picks it only where it wins measured 374.6 against 376.6 frames/s without it, so the
   // default stays the 64-channel form (profiles/r04_wino4c_ab.txt).  Same weights, same bits.
-  const char *env = getenv("PCP_WINO4C_NW");
-  const bool wide = env && atoi(env) == 8 && d->cout_pad % 128 == 0;      // layers without whole 128-channel blocks keep the 64-channel form
+  const bool wide = pcp_option(PCP_OPT_WINO4C_NW, 4) == 8 && d->cout_pad % 128 == 0;      // layers without whole 128-channel blocks keep the 64-channel form
   const long long blocks = (long long)p.n_spatial * (d->cout_pad / (wide ? 128 : 64));
   if (blocks <= 0 || blocks > 0x7fffffffLL) return PCP_ERR_ARG;
   if (wide) hipLaunchKernelGGL(k_wino4c<8>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream_, p);

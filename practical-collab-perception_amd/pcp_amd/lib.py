@@ -139,6 +139,9 @@ PW_PLAIN, PW_SPACE2DEPTH, PW_DEPTH2SPACE = 0, 1, 2
 SYMBOLS = {
     'pcp_abi_version': (c_i32, []),
     'pcp_status_string': (ctypes.c_char_p, [c_i32]),
+    'pcp_set_option': (c_i32, [c_i32, c_i64]),
+    'pcp_get_option': (c_i64, [c_i32]),
+    'pcp_pillar_index_export': (c_i32, [ctypes.POINTER(Grid), vp, c_i64, c_i32, vp, vp, vp, vp, vp, vp]),
     'pcp_voxelize_workspace_bytes': (c_sz, [ctypes.POINTER(Grid), c_i64]),
     'pcp_voxelize': (c_i32, [vp, c_i64, c_i32, ctypes.POINTER(Grid), vp, c_sz, vp, vp, vp, vp, vp]),
     'pcp_pfn_scatter': (c_i32, [vp, c_i64, c_i32, c_i32, ctypes.POINTER(Grid), vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -307,6 +310,12 @@ SYMBOLS.update({
     'pcp_mp_pointwise_wgrad': (c_i32, [ctypes.POINTER(MpRowMap), ctypes.POINTER(MpRowMap), c_i64, vp, c_sz, vp, c_i32, c_i32, vp]),
 })
 
+# PCP_OPT_* of include/pcp_hip.h.  The C library never reads the environment; the PCP_* variables of earlier rounds are mapped onto the option
+# table ONCE, here, when the library is loaded (set_option() changes an option later, e.g. from a test)
+OPTIONS = {'pfn_crowd': 0, 'pfn_crowd_blocks': 1, 'pfn_wps': 2, 'wino4c_nw': 3, 'mp_th16_min': 4, 'mp_diag': 5}
+_OPTION_ENV = {'PCP_PFN_CROWD': 'pfn_crowd', 'PCP_PFN_CROWD_BLOCKS': 'pfn_crowd_blocks', 'PCP_PFN_WPS': 'pfn_wps', 'PCP_WINO4C_NW': 'wino4c_nw',
+               'PCP_MP_TH16_MIN': 'mp_th16_min', 'PCP_MP_DIAG': 'mp_diag'}
+
 _LIB = None
 
 
@@ -330,8 +339,21 @@ def load():
         fn.argtypes = args
     if lib.pcp_abi_version() != 1:
         raise PcpError('libpcp_hip.so ABI version mismatch')
+    for env, name in _OPTION_ENV.items():
+        v = os.environ.get(env, '')
+        if v.strip():
+            if lib.pcp_set_option(OPTIONS[name], int(v)) != 0:
+                raise PcpError('%s=%s: pcp_set_option refused it' % (env, v))
     _LIB = lib
     return lib
+
+
+def set_option(name, value):
+    """override a built-in launch rule of the library (A/B runs, tests); value None restores the rule.  Returns the previous override (None = rule)."""
+    lib = load()
+    prev = int(lib.pcp_get_option(OPTIONS[name]))
+    check(lib.pcp_set_option(OPTIONS[name], -1 if value is None else int(value)), 'pcp_set_option')
+    return None if prev < 0 else prev
 
 
 def check(status, what):

@@ -179,6 +179,43 @@ def pillarise_rows(points, grid, num_raw, want_inverse=False, want_counts=False,
     return res
 
 
+def pillar_index_export_async(vox, want_records=False):
+    """pcp_pillar_index_export on the current stream, no host read: (voxel_coords (cap, 4), row_rank (cap,), counters (4,), slot_rank,
+    slot_canvas_row) as device tensors (the last two None unless want_records on a rows workspace); only the first P / n / N' entries hold data"""
+    L = _lib.load()
+    dev = vox.workspace.device
+    cap = max(vox.n, 1)
+    num_raw = int(getattr(vox, 'num_raw', 0) or 0)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    row_rank = torch.empty((cap,), dtype=torch.int32, device=dev)
+    counters = torch.empty((4,), dtype=torch.int32, device=dev)
+    slot_rank = torch.empty((cap,), dtype=torch.int32, device=dev) if (want_records and num_raw) else None
+    slot_row = torch.empty((cap,), dtype=torch.int32, device=dev) if (want_records and num_raw) else None
+    check(L.pcp_pillar_index_export(ctypes.byref(vox.grid), _p(vox.workspace), vox.n, num_raw, _p(coords), _p(row_rank), _p(slot_rank),
+                                    _p(slot_row), _p(counters), _stream()), 'pcp_pillar_index_export')
+    return coords, row_rank, counters, slot_rank, slot_row
+
+
+def pillar_index_export(vox, want_records=False):
+    """the reference's index tensors from the workspace of a pillariser call that did not write them (pipeline mode): returns
+    (voxel_coords (P, 4) int32 [b, 0, y, x], unq_inv (N',) int64, counters (4,) numpy) -- one host read -- and, with want_records, the
+    (slot_rank, slot_canvas_row) int32 tensors of the pillar-ordered records pcp_pfn_rows consumes (rows workspaces only)."""
+    coords, row_rank, counters, slot_rank, slot_row = pillar_index_export_async(vox, want_records)
+    cnt = counters.cpu().numpy()
+    num_pillars, kept = int(cnt[0]), int(cnt[1])
+    rr = row_rank[:vox.n]
+    inv = rr[rr >= 0].to(torch.int64)
+    assert inv.numel() == kept, (inv.numel(), kept)
+    if want_records:
+        return coords[:num_pillars], inv, cnt, (None if slot_rank is None else slot_rank[:kept]), (None if slot_row is None else slot_row[:kept])
+    return coords[:num_pillars], inv, cnt
+
+
+def set_option(name, value):
+    """pcp_set_option: override (or with None restore) a built-in launch rule; returns the previous override"""
+    return _lib.set_option(name, value)
+
+
 def pfn_rows(vox, w0, b0, w1, b1, canvas=None, pillar_features=None):
     """fused PFN + scatter on the records pillarise_rows left in vox.workspace.  canvas (B, ny, nx, 64) is written completely (pillar
     rows and zero rows): torch.empty is enough."""

@@ -18,3 +18,17 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def lib_option():
+    """set (name, value) / restore (name, None) an option of the library's table (pcp_set_option); everything touched is restored afterwards"""
+    from pcp_amd import lib
+    touched = {}
+
+    def setter(name, value):
+        prev = lib.set_option(name, value)
+        touched.setdefault(name, prev)
+    yield setter
+    for name, prev in touched.items():
+        lib.set_option(name, prev)

@@ -164,11 +164,11 @@ def test_reference_outputs_with_the_wide_layers_forced_onto_winograd4(tag, monke
         assert (128, 384) in calls and (384, 384) in calls
 
 
-def test_reference_outputs_with_the_128_channel_form_of_wino4c(monkeypatch):
-    """PCP_WINO4C_NW=8 (opt-in): every fused-F(4x4) layer with whole 128-channel output blocks runs as one eight-wave workgroup per CU with a
+def test_reference_outputs_with_the_128_channel_form_of_wino4c(monkeypatch, lib_option):
+    """option wino4c_nw = 8 (opt-in; PCP_WINO4C_NW=8 in the environment when the library is loaded): every fused-F(4x4) layer with whole 128-channel output blocks runs as one eight-wave workgroup per CU with a
     shared input transform; same bits, so the DiscoNet goldens hold unchanged"""
     monkeypatch.setenv('PCP_CONV_ALGO', 'winograd4c')
-    monkeypatch.setenv('PCP_WINO4C_NW', '8')
+    lib_option('wino4c_nw', 8)
     test_disco_mid_fusion_matches_reference_outputs()
 
 

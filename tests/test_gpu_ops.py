@@ -331,10 +331,10 @@ def test_pfn_rows_matches_oracle(layout, num_raw, n):
 
 
 @pytest.mark.parametrize('num_raw,bucket_order', [(5, False), (5, True), (11, False)])
-def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num_raw, bucket_order, monkeypatch):
+def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num_raw, bucket_order, lib_option):
     """pillars of at least PCP_PFN_CROWD records (default 192) are listed by the pillariser, passed over by the wave tiles of k_pfn_rows and
     run by the front workgroups of the same grid, a workgroup per pillar: the same operations per point, exact sums, order-free maxima -- bit for bit what the wave tiles
-    compute when nothing is listed (PCP_PFN_CROWD=0), at every threshold, with and without the bucket order, next to the reference oracle"""
+    compute when nothing is listed (option pfn_crowd = 0), at every threshold, with and without the bucket order, next to the reference oracle"""
     ops = _ops()
     rs = np.random.RandomState(11)
     ncol = 8 if num_raw == 5 else 14
@@ -363,7 +363,7 @@ def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num
     g = ops.make_grid(PC_RANGE, VOXEL, GRID, 4)
     outs = {}
     for thr in ('0', '64', '192', '100000'):
-        monkeypatch.setenv('PCP_PFN_CROWD', thr)
+        lib_option('pfn_crowd', int(thr))
         vox = ops.pillarise_rows(pd, g, num_raw, want_coords=True, bucket_order=bucket_order)
         P = int(vox.counters[0])
         canvas = torch.full((4, 512, 512, 64), float('nan'), device=d)
@@ -379,9 +379,9 @@ def test_pfn_rows_crowded_pillars_on_their_own_workgroups_give_the_same_bits(num
     np.testing.assert_allclose(outs['192'][0].cpu().numpy(), ref['pillar_features'], rtol=1e-4, atol=2e-5)
 
 
-def test_pfn_rows_with_a_whole_cloud_in_one_cell(monkeypatch):
+def test_pfn_rows_with_a_whole_cloud_in_one_cell(lib_option):
     """the degenerate end of the crowded-pillar path: 20 000 points in ONE cell (plus a handful elsewhere, before and behind it in the slot
-    order), as the only frame of the batch and again as frame 1 of 2.  Bit for bit the wave tiles' result (PCP_PFN_CROWD=0); against the
+    order), as the only frame of the batch and again as frame 1 of 2.  Bit for bit the wave tiles' result (option pfn_crowd = 0); against the
     oracle at the north star's 1e-3: its scatter_mean adds 20 000 float32 values in index order (the reference's own float32 atomics do no
     better), the kernel's sums are exact"""
     ops = _ops()
@@ -414,12 +414,12 @@ def test_pfn_rows_with_a_whole_cloud_in_one_cell(monkeypatch):
         assert not bool(torch.isnan(canvas).any()) and int((canvas != 0).any(-1).sum()) <= P
         vc = vox.voxel_coords[:P].long()
         assert torch.equal(canvas[vc[:, 0], vc[:, 2], vc[:, 3]], pf)
-        monkeypatch.setenv('PCP_PFN_CROWD', '0')
+        lib_option('pfn_crowd', 0)
         vox0 = ops.pillarise_rows(torch.from_numpy(pts).to(d), g, 5)
         pf0 = torch.full((P, 64), float('nan'), device=d)
         ops.pfn_rows(vox0, w0, b0, w1, b1, canvas=None, pillar_features=pf0)
         torch.cuda.synchronize()
-        monkeypatch.delenv('PCP_PFN_CROWD')
+        lib_option('pfn_crowd', None)
         assert torch.equal(pf0, pf)
 
 
@@ -941,14 +941,14 @@ def test_conv3x3_winograd4f_channel_windows_and_bad_arguments(kernel):
 @pytest.mark.parametrize('nw', ['4', '8'])
 @pytest.mark.parametrize('cin,cout,h,w,batch', [(64, 64, 32, 32, 1), (128, 128, 48, 80, 2), (16, 52, 37, 50, 2), (384, 64, 16, 32, 1), (72, 132, 20, 100, 3),
                                                  (64, 384, 33, 47, 1), (8, 128, 16, 16, 1)])
-def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch, nw, monkeypatch):
+def test_wino4c_gives_the_bits_of_wino4h(cin, cout, h, w, batch, nw, lib_option):
     """k_wino4c multiplies the same products in the same k order as k_wino4h and runs the same transform operations per lane: bitwise equal,
     in its 64-channel form (two four-wave workgroups per CU) and in its 128-channel form (one eight-wave workgroup, shared input transform;
-    PCP_WINO4C_NW=8 selects the 128-channel form wherever cout_pad is a multiple of 128)"""
+    option wino4c_nw = 8 selects the 128-channel form wherever cout_pad is a multiple of 128)"""
     ops = _ops()
     from pcp_amd import lib, pack
     d = dev()
-    monkeypatch.setenv('PCP_WINO4C_NW', nw)
+    lib_option('wino4c_nw', int(nw))
     x = ops.as_nhwc(torch.from_numpy(_rand(291, (batch, cin, h, w))).to(d))
     wt = torch.from_numpy(_rand(292, (cout, cin, 3, 3), -0.05, 0.05))
     b = torch.from_numpy(_rand(293, (cout,), -0.2, 0.2))
