@@ -1784,42 +1784,90 @@ class VfeSpy:
         out[tag + '_vfe_names'] = np.array(json.dumps(names))
 
 
+def _g17_forward(build, make_bd, disco, seg_shift=None):
+    import time
+    cfg, model, shapes = build()
+    if seg_shift is not None:
+        with torch.no_grad():
+            model.corrector.point_head.seg[0].bias -= torch.tensor(seg_shift, dtype=torch.float32)
+    bd = make_bd()
+    before = bd['points'].clone()
+    logits, hooks, seen, snaps = {}, [], [], {}
+    if getattr(model, 'corrector', None) is not None:
+        hooks.append(model.corrector.point_head.register_forward_hook(lambda m, a, o: logits.update(cls=o[1].detach().clone(), flow=o[2].detach().clone())))
+    if disco:
+        hooks.append(model.bev_maker_car.module_list[0].register_forward_pre_hook(lambda m, args: seen.append(args[0]['points'].detach().clone())))
+    t0 = time.time()
+    with torch.no_grad(), VfeSpy(model) as spy:
+        for name, mod in zip(_module_names(model), model.module_list):
+            bd = mod(bd)
+            if name == 'backbone_2d':
+                snaps['backbone_out'] = bd['spatial_features_2d'].detach().clone()
+    for h in hooks:
+        h.remove()
+    return dict(cfg=cfg, model=model, shapes=shapes, bd=bd, before=before, logits=logits, seen=seen, snaps=snaps, spy=spy, secs=time.time() - t0)
+
+
+def _hunter_verdicts(model, logits, after, seg_extra=0.0):
+    """(mask of the rows HunterJr corrects, rows whose verdict could flip under 1e-4 of noise, corrected rows whose BEV coordinate lies within
+    2e-4 pixel (0.16 mm; the corrected xyz of two fp32 implementations differ by ~0.03 mm) of a pixel boundary -- such a row may be scattered into the neighbouring pixel by any other fp32 implementation)"""
+    cls = logits['cls'].clone()
+    cls[:, 2] -= seg_extra
+    p = torch.sigmoid(cls)
+    top, idx = torch.max(p, dim=1)
+    two = torch.topk(p, 2, dim=1)[0]
+    thr_p = float(model.corrector.thresh_point_cls_prob)
+    other = torch.maximum(p[:, 0], p[:, 1])
+    near = ((idx == 2) & ((top - thr_p).abs() < 1e-4)) | (((p[:, 2] - other).abs() < 1e-4) & (top > thr_p - 1e-4))
+    mask = (top > thr_p) & (idx == 2)
+    edge = torch.zeros_like(mask)
+    if after is not None:
+        pr = model.corrector.point_cloud_range
+        pix = float(model.corrector.voxel_size[0]) * float(model.corrector.bev_image_stride)
+        c = (torch.from_numpy(after[:, 1:3].copy()) - torch.tensor([float(pr[0]), float(pr[1])])) / pix
+        edge = mask & (((c - torch.round(c)).abs() < 2e-4).any(dim=1))
+    return mask, near, edge
+
+
 def _g17_case(tag, out, build, make_bd, disco=False):
     """build() -> (cfg, model, shapes) under the current WEIGHT_SCHEME; make_bd() -> a fresh batch dict.  Tunes the gain as _g13_run does,
-    runs the reference forward under the spies, stores digests of everything on the path and the robust final sets."""
+    runs the reference forward under the spies, stores digests of everything on the path and the robust final sets.
+    With a HunterJr corrector the dynamic-foreground logit's bias is shifted (as g10 / g13_chain do) until about 1 % of the rows are
+    corrected and none of them is an fp32 coin toss: with the tuned gain EVERY row would be corrected by a flow of metres, and 60 000
+    moved points always include a few within 1e-5 of a BEV pixel boundary (bev_scatter's .long(), hunter_toolbox.py:84)."""
     global WEIGHT_SCHEME
-    import time
     chosen = None
     for gain in G13_GAINS:
         WEIGHT_SCHEME = 'gain:%g' % gain
-        cfg, model, shapes = build()
-        bd = make_bd()
-        before = bd['points'].clone()
-        logits = {}
-        hooks = []
-        if getattr(model, 'corrector', None) is not None:
-            hooks.append(model.corrector.point_head.register_forward_hook(lambda m, a, o: logits.update(cls=o[1].detach().clone(), flow=o[2].detach().clone())))
-        seen = []
-        if disco:
-            hooks.append(model.bev_maker_car.module_list[0].register_forward_pre_hook(lambda m, args: seen.append(args[0]['points'].detach().clone())))
-        t0 = time.time()
-        with torch.no_grad(), VfeSpy(model) as spy:
-            snaps = {}
-            for name, mod in zip(_module_names(model), model.module_list):
-                bd = mod(bd)
-                if name == 'backbone_2d':
-                    snaps['backbone_out'] = bd['spatial_features_2d'].detach().clone()
-        for h in hooks:
-            h.remove()
+        r = _g17_forward(build, make_bd, disco)
+        model = r['model']
         pd0 = model.dense_head.forward_ret_dict['pred_dicts'][0]
         sd, dmax = float(pd0['hm'].std()), float(pd0['dim'].abs().max())
         print('   g17 %-12s gain %.1f: hm logits %.2f .. %.2f (std %.3f), |dim logits| <= %.2f   [%.0f s]'
-              % (tag, gain, float(pd0['hm'].min()), float(pd0['hm'].max()), sd, dmax, time.time() - t0))
+              % (tag, gain, float(pd0['hm'].min()), float(pd0['hm'].max()), sd, dmax, r['secs']))
         if 0.15 <= sd <= 0.9 and dmax <= 3.5:
             chosen = gain
             break
     if chosen is None:
         raise RuntimeError('g17 %s: no gain gives a usable head map' % tag)
+    seg_shift = None
+    if r['logits']:
+        # the shift of the dynamic-foreground bias that leaves ~1 % of the rows corrected, then nudged until no corrected row is a coin toss
+        cls = r['logits']['cls']
+        margin = torch.minimum(cls[:, 2] - torch.maximum(cls[:, 0], cls[:, 1]), cls[:, 2] - float(np.log(0.3 / 0.7)))
+        base = float(torch.sort(margin, descending=True)[0][max(1, margin.shape[0] // 100)])
+        for attempt in range(40):
+            seg_shift = [0.0, 0.0, round(base + 0.013 * attempt, 4)]
+            r = _g17_forward(build, make_bd, disco, seg_shift)
+            mask, near, edge = _hunter_verdicts(r['model'], r['logits'], r['bd']['points'].numpy())
+            print('   g17 %-12s seg bias shift %.4f: %d rows corrected, %d near the verdict, %d near a BEV pixel boundary'
+                  % (tag, seg_shift[2], int(mask.sum()), int(near.sum()), int(edge.sum())))
+            if int(mask.sum()) >= 100 and int(near.sum()) == 0 and int(edge.sum()) == 0:
+                break
+        else:
+            raise RuntimeError('g17 %s: no seg bias shift gives a well-conditioned HunterJr correction' % tag)
+        out[tag + '_seg_bias_shift'] = np.array(seg_shift, dtype=np.float32)
+    cfg, model, shapes, bd, before, logits, seen, snaps, spy = (r[k] for k in ('cfg', 'model', 'shapes', 'bd', 'before', 'logits', 'seen', 'snaps', 'spy'))
     B = int(bd['batch_size'])
     head = model.dense_head
     pred_dicts = [{k: v.detach().clone() for k, v in pd.items()} for pd in head.forward_ret_dict['pred_dicts']]
@@ -1858,24 +1906,16 @@ def _g17_case(tag, out, build, make_bd, disco=False):
             out['%s_car_agent_%d_rows' % (tag, a)] = np.array(ap.shape[0])
             out['%s_car_agent_%d_xyz_sha' % (tag, a)] = np.array(sha(ap[:, 1:4].astype(np.float32)))
     if logits:
-        # HunterJr (hunter_jr.py:251-264): rows whose dynamic-foreground verdict could flip under 1e-4 of float noise are listed, all other
-        # rows' corrected xyz are demanded to 1e-4
-        p = torch.sigmoid(logits['cls'])
-        top, idx = torch.max(p, dim=1)
-        two = torch.topk(p, 2, dim=1)[0]
-        thr_p = float(model.corrector.thresh_point_cls_prob)
-        near = ((top - thr_p).abs() < 1e-4) | (((two[:, 0] - two[:, 1]) < 1e-4) & (top > thr_p - 1e-4))
-        mask = (top > thr_p) & (idx == 2)
+        # HunterJr (hunter_jr.py:251-264): the rows it corrects, their xyz afterwards (demanded to 1e-4), every other row bit for bit
         after = bd['points'].numpy()
+        mask, near, edge = _hunter_verdicts(model, logits, after)
+        assert int(near.sum()) == 0 and int(edge.sum()) == 0
         changed = np.nonzero(mask.numpy())[0].astype(np.int32)
         assert np.array_equal(np.nonzero((after != before.numpy()).any(1))[0], changed[(after[changed] != before.numpy()[changed]).any(1)])
-        out[tag + '_hunter_near_rows'] = np.nonzero(near.numpy())[0].astype(np.int32)
         out[tag + '_hunter_dyn_rows'] = np.array(int(mask.sum()))
-        keep = changed if changed.shape[0] <= 20000 else changed[:: (changed.shape[0] + 19999) // 20000]
-        out[tag + '_hunter_rows'] = keep
-        out[tag + '_hunter_xyz_after'] = after[keep, 1:4].copy()
-        out[tag + '_hunter_untouched_sha'] = np.array(sha(after[~mask.numpy()]))
-        print('   g17 %-12s HunterJr: %d of %d rows corrected, %d near the verdict' % (tag, int(mask.sum()), after.shape[0], int(near.sum())))
+        out[tag + '_hunter_rows'] = changed
+        out[tag + '_hunter_xyz_after'] = after[changed, 1:4].copy()
+        print('   g17 %-12s HunterJr: %d of %d rows corrected, flow |max| %.2f m' % (tag, int(mask.sum()), after.shape[0], float(logits['flow'][mask].abs().max())))
     print('g17', tag, 'N', int(before.shape[0]), 'vfe calls', [(c['name'], c['coords'].shape[0]) for c in spy.calls], 'thr %.6f' % thr,
           'finals', [int(d['pred_boxes'].shape[0]) for d in finals])
     return thr, cfg, shapes

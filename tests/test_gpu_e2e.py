@@ -696,6 +696,12 @@ def test_full_size_against_reference_digests(tag, yaml_name, layout, n_agents, p
     if pipeline:
         # 60 k points on 262 k cells takes the sparse first layer; the merged 360 k-point cloud stays on the dense canvas
         assert (batch['spatial_features'] is None) == (n_agents == 1)
+        # no index tensor was written in this mode: read the pillar list back from the workspace the PFN / sparse conv consumed
+        from pcp_amd import ops
+        vc, inv, _cnt = ops.pillar_index_export(vox)
+        assert vc.shape[0] == int(g[tag + '_P'])
+        assert sha(vc.cpu().numpy().astype(np.int32)) == str(g[tag + '_coords_sha'])          # bit exact at full size, bench mode
+        assert sha(inv.cpu().numpy().astype(np.int64)) == str(g[tag + '_inv_sha'])
     else:
         vc = batch['voxel_coords'].cpu().numpy()
         assert vc.shape[0] == int(g[tag + '_P'])
@@ -764,8 +770,11 @@ def test_disco_full_size_against_reference_digests(pipeline):
     assert sorted(batch['bev_img'].keys()) == [0, 2, 3, 4, 5]
     if not pipeline:
         vc = batch['voxel_coords'].cpu().numpy()
-        assert vc.shape[0] == int(g['voxel_P'])
-        assert hashlib.sha256(np.ascontiguousarray(vc.astype(np.int32)).tobytes()).hexdigest() == str(g['coords_sha'])
+    else:
+        from pcp_amd import ops
+        vc = ops.pillar_index_export(batch['_pcp_vfe']['vox'])[0].cpu().numpy()      # the ego branch's pillar list, from the workspace
+    assert vc.shape[0] == int(g['voxel_P'])
+    assert hashlib.sha256(np.ascontiguousarray(vc.astype(np.int32)).tobytes()).hexdigest() == str(g['coords_sha'])
     for aid in (0, 2, 3, 4, 5):                                                  # every probe pixel of every agent's map: 1e-3
         a = batch['bev_img'][aid].cpu().numpy()
         np.testing.assert_allclose(a[0, ::8, ::8, ::8], g['bev_%d_probe' % aid], rtol=0, atol=1e-3)
