@@ -73,6 +73,9 @@ def parse_args(argv=None):
                     '(about 53.6k pillars per 60k points) or the LiDAR-like ring (r = 70 u^2; 20-30k pillars)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the informational second measurement on the LiDAR-like cloud (--dist ring)')
+    ap.add_argument('--no-configs', action='store_true', help='skip the `configs` block (the default N = 1 disco line also times BASELINE configs 1 - 4 and '
+                    "config 5's bf16 training loop, each in a bounded child process)")
+    ap.add_argument('--cpu-baseline-budget', type=float, default=25.0, help='seconds of host-core time the oracle may spend on the cpu_baseline sample')
     ap.add_argument('--dense-first-layer', action='store_true', help='A/B switch: always write the dense canvas and run the first backbone '
                     'layer as the dense stride-2 conv (default in pipeline mode: from the pillar list when the cloud is sparse)')
     ap.add_argument('--plugin-default', action='store_true', help='measure the mode tools/test.py gets WITHOUT --fast: per-pillar API tensors '
@@ -556,6 +559,87 @@ def hip_device_identity():
         return -1
 
 
+def pin_rank_to_cpus(local_rank, local_world):
+    """One rank per GPU means N Python hosts on one box: each rank is confined to its own slice of the CPUs this process may run on
+    (contiguous, equal shares; in-process os.sched_setaffinity BEFORE anything touches the GPU -- never taskset / numactl, which would be an
+    exec hop), so the enqueueing threads of different ranks never migrate onto each other.  PCP_BENCH_AFFINITY=0 leaves the mask alone.
+    Returns the CPUs this rank runs on (None where the platform has no affinity call)."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if local_world <= 1 or os.environ.get('PCP_BENCH_AFFINITY', '1') == '0' or len(avail) < local_world:
+        return avail
+    per = len(avail) // local_world
+    mine = avail[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
+def _cpu_list(cpus):
+    """[0, 1, 2, 3, 8] -> '0-3,8'"""
+    if not cpus:
+        return ''
+    out, a, b = [], cpus[0], cpus[0]
+    for c in cpus[1:]:
+        if c == b + 1:
+            b = c
+            continue
+        out.append('%d-%d' % (a, b) if b > a else '%d' % a)
+        a = b = c
+    out.append('%d-%d' % (a, b) if b > a else '%d' % a)
+    return ','.join(out)
+
+
+# BASELINE.json's other workloads, each timed by a bounded child run of this script (a fresh process started with subprocess -- never an exec)
+CONFIG_CHILDREN = [
+    ('car', ['--config', 'car'], 10.0, 'config 2 (and config 1 = its cpu_baseline: the CPU path of the same workload on this box)'),
+    ('ego', ['--config', 'ego'], 6.0, 'config 3, ego pass only'),
+    ('lately6', ['--config', 'lately6'], 12.0, 'config 3 end to end on one GPU (5 remote basic_car passes -> MoDAR ingestion -> basic_ego pass)'),
+    ('early', ['--config', 'early'], 6.0, 'config 4 on one GPU (the union of 6 clouds per frame)'),
+    ('disco_train_bf16', ['--config', 'disco', '--train', '--conv-algo', 'bf16', '--steps', '10', '--warmup', '3'], 0.0,
+     "config 5's training loop in bf16 (forward + backward + clip + Adam one-cycle step per iteration)"),
+]
+
+
+def summarize_line(r, note=None):
+    """the entry of `configs` for one measured JSON line of this script"""
+    roof = r.get('roofline') or {}
+    hbm = r.get('roofline_hbm') or {}
+    out = {'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': r['steps'], 'warmup': r['warmup'],
+           'frames_per_step': (r.get('config') or {}).get('frames_per_gpu_per_step'), 'dtype': r['dtype'].split(' ')[0],
+           'workload': (r.get('config') or {}).get('workload'),
+           'dominant_kernel': (roof.get('kernel') or '').split(' ')[0] or None, 'roofline_bound': roof.get('bound'), 'roofline_frac': roof.get('frac'),
+           'roofline_achieved': roof.get('achieved'), 'roofline_unit': roof.get('unit'),
+           'vfe_stage_hbm_frac': hbm.get('frac'), 'vfe_stage_ms_per_step': hbm.get('ms_per_step'),
+           'host_cpu_ms_per_step': r.get('host_cpu_ms_per_step'), 'final_boxes_last_step': (r.get('config') or {}).get('final_boxes_last_step'),
+           'cpu_baseline': r.get('cpu_baseline')}
+    if 'loss_last_step' in (r.get('config') or {}):
+        out['loss_last_step'] = r['config']['loss_last_step']
+    if note:
+        out['note'] = note
+    return out
+
+
+def run_config_children(steps, warmup, timeout_s=240):
+    out = {}
+    for name, extra, cpu_budget, note in CONFIG_CHILDREN:
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(min(steps, 20)), '--warmup', str(min(warmup, 5))] + extra + \
+              ['--no-secondary', '--no-configs'] + (['--cpu-baseline-budget', str(cpu_budget)] if cpu_budget > 0 else ['--no-cpu-baseline'])
+        t0 = time.time()
+        try:
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, check=False)
+            rl = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
+            if res.returncode != 0 or not rl:
+                out[name] = {'error': 'child exited with %d: %s' % (res.returncode, res.stderr.decode()[-300:])}
+                continue
+            out[name] = summarize_line(json.loads(rl[-1]), note)
+            out[name]['child_wall_s'] = round(time.time() - t0, 1)
+        except Exception as e:                                         # the headline line must not depend on these extras
+            out[name] = {'error': repr(e)[:300]}
+    return out
+
+
 def dry_run(args, world, rank):
     """PCP_BENCH_DRY_RUN=1 (tests/test_dist_cpu.py only): the launcher, rendezvous, barrier and max-over-ranks aggregation of this script
     with a sleep in place of the kernels -- no GPU, no library, backend gloo.  The line says so in `data`; it is never a measurement."""
@@ -577,6 +661,13 @@ def dry_run(args, world, rank):
     elapsed = time.perf_counter() - t0
     seen = 1
     layout = {'workload': 'dry run'}
+    mine = pin_rank_to_cpus(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
+    if world > 1:
+        masks = [None] * world
+        dist.all_gather_object(masks, _cpu_list(mine or []))
+        layout['rank_cpu_affinity'] = masks
+    else:
+        layout['rank_cpu_affinity'] = [_cpu_list(mine or [])]
     if world > 1 and args.shard == 'agent':
         # the row split of --shard agent (agent % world) and the exchanges of the sharded runners on CPU tensors: ranks without an
         # agent contribute empty row blocks, ranks without a frame still take part in every collective
@@ -620,10 +711,13 @@ def main(argv=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('PCP_BENCH_DRY_RUN') == '1':
         return dry_run(args, world, rank)
+    my_cpus = pin_rank_to_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))      # before anything touches the GPU
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    if world > 1 and my_cpus:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(my_cpus))))
 
     if args.conv_algo is not None:
         if args.conv_algo == 'bf16' and not args.train:
@@ -848,7 +942,8 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    host_s = 0.0                                # time the host spends inside step() (enqueueing; no sync in there unless the mode reads back)
+    cpu_thread0, cpu_proc0 = time.thread_time(), time.process_time()
+    host_s = 0.0                                # wall time the host spends inside step() (enqueueing AND, pipelined, blocking on the previous step's read)
     for _ in range(args.steps):
         h0 = time.perf_counter()
         preds = step()
@@ -857,13 +952,17 @@ def main(argv=None):
         preds = lately_pipe.flush()
     if pipelined is not None:
         preds = pipelined.flush()               # the last step's host read: all K reads lie inside the timed region
+    host_cpu_thread_s, host_cpu_proc_s = time.thread_time() - cpu_thread0, time.process_time() - cpu_proc0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     per_rank_ms, rank_devices, rank_pci = [round(1e3 * elapsed / args.steps, 4)], [hip_current_device()], [hip_device_identity()]
+    rank_cpus = [_cpu_list(my_cpus or [])]
     if world > 1:
+        rank_cpus = [None] * world
+        dist.all_gather_object(rank_cpus, _cpu_list(my_cpus or []))
         # every rank's own time and the device its HIP runtime launches on (a straggler or two ranks on one device must be visible in the
         # line); `value` uses the MAX over ranks, as the contract says
         info = torch.tensor([elapsed, float(hip_current_device()), float(hip_device_identity())], dtype=torch.float64,
@@ -987,6 +1086,10 @@ def main(argv=None):
             'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 4),
+            # CPU time, not wall time: what the enqueueing Python thread burns per step (time.thread_time) and the whole process incl. the
+            # HIP runtime's helper threads (time.process_time) -- the headroom a host core has beside the GPU's ms_per_step
+            'host_cpu_ms_per_step': round(1e3 * host_cpu_thread_s / args.steps, 4),
+            'host_cpu_all_threads_ms_per_step': round(1e3 * host_cpu_proc_s / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frame' else 'strong', 'vs_baseline': None,
             'dtype': {'bf16x3': 'f32 tensors; 3x3 conv products as split bf16 (3 MFMAs, 16 mantissa bits), f32 accumulate [opt-in]',
                       'bf16': 'bf16 training loop [--train only]: bf16 activation / gradient storage between the 3x3 layers, forward / data-gradient / '
@@ -1004,7 +1107,7 @@ def main(argv=None):
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
                        ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
                        'ranks_seen_by_collective': ranks_seen, 'backend': backend if world > 1 else None,
-                       'per_rank_ms_per_step': per_rank_ms, 'rank_devices': rank_devices, 'rank_pci_addresses': ['%04x:%02x:%02x.%x' % (v >> 16, (v >> 8) & 255, (v >> 3) & 31, v & 7) if v >= 0 else None for v in rank_pci],
+                       'per_rank_ms_per_step': per_rank_ms, 'rank_devices': rank_devices, 'rank_cpu_affinity': rank_cpus, 'rank_pci_addresses': ['%04x:%02x:%02x.%x' % (v >> 16, (v >> 8) & 255, (v >> 3) & 31, v & 7) if v >= 0 else None for v in rank_pci],
                        'mode': ('plugin default (per-pillar API tensors materialised: one host sync per VFE; dense canvas)' if args.plugin_default else
                                 'pipeline: no per-pillar API tensors (their host sync), buffers kept across frames, first backbone layer ' +
                                 ('as the dense stride-2 conv on the canvas' if args.dense_first_layer else
@@ -1078,9 +1181,9 @@ def main(argv=None):
             set_algo('auto')
         if not args.no_cpu_baseline and world == 1:                    # rank 0 at N = 1 only (the contract); N > 1 lines carry null
             if args.config == 'lately6':
-                line['cpu_baseline'] = cpu_baseline_lately(car_cfg, car_state, cfg, state, lately_frames[0])
+                line['cpu_baseline'] = cpu_baseline_lately(car_cfg, car_state, cfg, state, lately_frames[0], budget_s=args.cpu_baseline_budget)
             else:
-                line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas)
+                line['cpu_baseline'] = cpu_baseline(conf, cfg, state, pts_np, metas, budget_s=args.cpu_baseline_budget)
         else:
             line['cpu_baseline'] = None
         if (world == 1 and args.dist == 'uniform' and not args.no_secondary and not args.train and not args.graph and not args.latency
@@ -1101,6 +1204,17 @@ def main(argv=None):
                 'vfe_stage_ms_per_step': (r.get('roofline_hbm') or {}).get('ms_per_step'),
                 'note': 'the same command with --dist ring (r = 70 u^2: 48 % of the points in multi-point pillars, ~850 in the cell under the '
                         'sensor); NOT the headline'}
+        if (world == 1 and args.config == 'disco' and args.dist == 'uniform' and not args.no_configs and not args.train and not args.graph
+                and not args.latency and args.shard == 'frame' and algo == 'auto' and not args.plugin_default and not args.elide_dead_makers
+                and not args.host_input and not args.no_pipeline):
+            # every BASELINE.json workload in the one line the driver records: this run's headline (config 5 inference) + bounded child runs
+            # of configs 1 - 4 and of config 5's bf16 training loop
+            line['configs'] = {'disco': summarize_line(line, 'config 5 inference: the headline of this line')}
+            line['configs'].update(run_config_children(args.steps, args.warmup))
+            car = line['configs'].get('car') or {}
+            if car.get('cpu_baseline'):
+                line['configs']['car_cpu_reference_path'] = dict(car['cpu_baseline'], note='config 1: the CPU path (oracle restatement of the reference modules, '
+                                                                 'kind "port") of v2x_pointpillar_basic_car on 1 x 60k points, timed on this box\'s host cores')
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

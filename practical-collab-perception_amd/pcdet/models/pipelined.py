@@ -74,6 +74,7 @@ class PipelinedDetector:
         self.side = None
         self._pending = None          # (ob, os_, ol, counts_host, event, batch_size)
         self._pinned = {}             # two pinned count buffers per batch size, used alternately
+        self._events = None           # two blocking events, used alternately (at most two batches are pending: the one being read and the newest)
         self._n = 0
         # PCP_PIPELINE_EARLY_MAKERS=0: the maker streams of batch i+1 wait for the main stream (i.e. for batch i's tail), as `model()` does
         self.early_makers = os.environ.get('PCP_PIPELINE_EARLY_MAKERS', '1') != '0'
@@ -130,7 +131,13 @@ class PipelinedDetector:
             counts_host = self._pinned[key][self._n & 1]
             self._n += 1
             counts_host.copy_(cnt, non_blocking=True)
-            ev = main.record_event()
+            # a BLOCKING event (hipEventBlockingSync): the host thread that waits for batch i-1's counts sleeps instead of spinning on the
+            # event -- with one Python host per GPU and eight GPUs per box, a spinning waiter is a core taken from another rank's enqueueing
+            ev = self._events[self._n & 1] if self._events else None
+            if ev is None:
+                self._events = [torch.cuda.Event(blocking=True), torch.cuda.Event(blocking=True)]
+                ev = self._events[self._n & 1]
+            ev.record(main)
         prev, self._pending = self._pending, (ob, os_, ol, counts_host, ev, batch_size)
         return self._finish(prev)
 

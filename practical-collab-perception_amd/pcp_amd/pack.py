@@ -167,24 +167,6 @@ def repack_winograd4f_to_4c(packed):
     return v.permute(0, 3, 1, 6, 4, 2, 5).contiguous().view(S, cout_pad // 16, 18, 64, 4)
 
 
-def winograd4_reference(x, packed, bias, cout):
-    """Plain-torch evaluation of the packed F(4x4,3x3) form with the transforms of csrc/wino4.hip (validates matrices + layout on the
-    CPU): x (B, cin, H, W), H, W multiples of 4."""
-    _p36, cout_pad, cin = packed.shape
-    u = packed.view(6, 6, cout_pad, cin)[:, :, :cout]                               # [i, j, cout, cin]
-    B, _, H, W = x.shape
-    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
-    BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
-                       [0, 4, 0, -5, 0, 1]], dtype=x.dtype)
-    AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=x.dtype)
-    d = xp.unfold(2, 6, 4).unfold(3, 6, 4)                                        # [B, cin, H/4, W/4, 6, 6]
-    v = torch.einsum('ia,bcyxae,je->bcyxij', BT, d, BT)
-    m = torch.einsum('ijnc,bcyxij->bnyxij', u.to(x.dtype), v)
-    y = torch.einsum('ki,bnyxij,lj->bnyxkl', AT, m, AT)                          # [B, cout, H/4, W/4, 4, 4]
-    out = y.permute(0, 1, 2, 4, 3, 5).reshape(B, cout, H, W)
-    return out + bias[:cout].to(x.dtype).view(1, -1, 1, 1)
-
-
 def pack_conv3x3_sparse_s2(w, bias):
     """w: [cout <= 64, 64, 3, 3] (BN-folded) -> [9 (ky*3+kx)][64][64 (cin)] for pcp_sparse_conv3x3_s2 (rows >= cout zero)."""
     cout, cin = w.shape[0], w.shape[1]
@@ -208,23 +190,6 @@ def pack_conv3x3_bf16x3(w, bias):
     x = x.view(2, cout_pad // 64, 64, cin // CK, 2, 8, 9)                          # (hl, ct, n, s, h, j, tap)
     packed = x.permute(3, 1, 0, 6, 4, 2, 5).contiguous()                           # (s, ct, hl, tap, h, n, j)
     return packed.view(torch.int16), pad_bias(bias, cout_pad), cout_pad
-
-
-def winograd_reference(x, packed, bias, cout):
-    """Plain-torch evaluation of the packed Winograd form (validates transforms + layout on the CPU): x (B, cin, H, W), H, W even."""
-    nsl, _sixteen, cout_pad, _ck = packed.shape
-    cin = nsl * WINO_CK
-    u = packed.permute(2, 0, 3, 1).reshape(cout_pad, cin, 4, 4)[:cout]           # [cout, cin, i, j]
-    B, _, H, W = x.shape
-    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
-    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=x.dtype)
-    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=x.dtype)
-    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                        # [B, cin, H/2, W/2, 4, 4]
-    v = torch.einsum('ia,bcyxae,je->bcyxij', BT, d, BT)
-    m = torch.einsum('ncij,bcyxij->bnyxij', u, v)
-    y = torch.einsum('ia,bnyxae,je->bnyxij', AT, m, AT)                           # [B, cout, H/2, W/2, 2, 2]
-    out = y.permute(0, 1, 2, 4, 3, 5).reshape(B, cout, H, W)
-    return out + bias[:cout].view(1, -1, 1, 1)
 
 
 def pack_plain(w, bias):
@@ -255,16 +220,3 @@ def pack_convT2x2_s2(w, bias):
 def pack_convT1x1(w, bias):
     """ConvTranspose2d(k=1, s=1): w [cin, cout, 1, 1] == 1x1 conv with the transposed matrix."""
     return pack_plain(w[:, :, 0, 0].t().contiguous(), bias)
-
-
-# ---- reference evaluation of the packed forms in plain torch (used by CPU tests to validate the layouts) -----------------
-
-def unpack_conv3x3(packed, cout, cin):
-    nsl, _nine, cout_pad, _ck = packed.shape
-    w = packed.permute(2, 0, 3, 1).reshape(cout_pad, nsl * CK, 3, 3)
-    return w[:cout, :cin]
-
-
-def unpack_plain(packed, cout):
-    nsl, n_pad, _ck = packed.shape
-    return packed.permute(1, 0, 2).reshape(n_pad, nsl * CK)[:cout]

@@ -154,6 +154,19 @@ def test_bench_gpus_8_dry_run(shard):
     assert r.returncode == 0, r.stderr[-2000:]
     assert line['n_gpus'] == 8 and line['ranks_seen_by_collective'] == 8 and 'DRY RUN' in line['data']
     assert line['ms_per_step'] >= 2 * 8 * 0.9                                    # the slowest rank sleeps 2 ms x 8 per step: MAX over ranks
+    # every rank confined itself to its own slice of the host's CPUs (in-process sched_setaffinity from LOCAL_RANK, before any GPU call)
+    masks = line['config']['rank_cpu_affinity']
+    assert len(masks) == 8 and all(masks)
+    if len(os.sched_getaffinity(0)) >= 8:
+        cpu_sets = []
+        for m in masks:
+            cpus = set()
+            for part in m.split(','):
+                a, _, b = part.partition('-')
+                cpus.update(range(int(a), int(b or a) + 1))
+            cpu_sets.append(cpus)
+        assert all(not (cpu_sets[i] & cpu_sets[j]) for i in range(8) for j in range(i + 1, 8)), masks
+        assert len({len(c) for c in cpu_sets}) == 1
     if shard == 'agent':
         assert line['config']['rows_per_rank'] == [4, 4, 4, 4, 4, 4, 0, 0] and line['config']['frames_per_rank'] == [1, 1, 1, 1, 0, 0, 0, 0]
 

@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import pack_eval
 from helpers import load_golden
 from pcp_amd import pack, synth
 
@@ -101,7 +102,7 @@ def test_bn_folding_and_conv3x3_packing_roundtrip():
     wf, bf = pack.fold_bn(w, gamma, beta, mean, var, 1e-3)
     packed, bp, cpad = pack.pack_conv3x3(wf, bf)
     assert packed.shape == (cin // 16, 9, cpad, 16) and cpad == 64 and bp.shape == (64,)
-    w_back = pack.unpack_conv3x3(packed, cout, cin)
+    w_back = pack_eval.unpack_conv3x3(packed, cout, cin)
     got = F.conv2d(x, w_back, bp[:cout], padding=1)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
     assert float(packed[:, :, cout:].abs().max()) == 0.0            # padded output channels are zero
@@ -116,7 +117,7 @@ def test_winograd4_packing_evaluates_to_the_convolution():
     x = torch.from_numpy(synth.uniform(7, 3, 2 * cin * 8 * 12, -1, 1).reshape(2, cin, 8, 12))
     packed, bp, cpad = pack.pack_conv3x3_winograd4(w, b)
     assert packed.shape == (36, 128, cin) and cpad == 128 and float(packed[:, cout:].abs().max()) == 0.0
-    got = pack.winograd4_reference(x.double(), packed.double(), bp.double(), cout)
+    got = pack_eval.winograd4_reference(x.double(), packed.double(), bp.double(), cout)
     want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=5e-6)      # U is rounded to fp32 once; A^T amplifies by <= 8 x 8
 
@@ -128,14 +129,14 @@ def test_pointwise_packings_match_torch_convs():
     # Conv2d k2 s2: K ordered (tap, cin)
     w = torch.from_numpy(synth.uniform(2, 2, cout * cin * 4, -0.1, 0.1).reshape(cout, cin, 2, 2))
     packed, _, cpad = pack.pack_conv2x2_s2(w, b)
-    mat = pack.unpack_plain(packed, cout)                            # (cout, 4*cin)
+    mat = pack_eval.unpack_plain(packed, cout)                            # (cout, 4*cin)
     xs = torch.stack([x[:, :, ky::2, kx::2] for ky in range(2) for kx in range(2)], 1).reshape(1, 4 * cin, 3, 4)
     got = torch.einsum('nk,bkhw->bnhw', mat, xs)
     np.testing.assert_allclose(got.numpy(), F.conv2d(x, w, None, stride=2).numpy(), rtol=1e-5, atol=1e-5)
     # ConvTranspose2d k2 s2: N ordered (tap, cout_pad)
     wt = torch.from_numpy(synth.uniform(2, 3, cin * cout * 4, -0.1, 0.1).reshape(cin, cout, 2, 2))
     packed, _, cpad = pack.pack_convT2x2_s2(wt, b)
-    mat = pack.unpack_plain(packed, 4 * cpad)                        # (4*cpad, cin)
+    mat = pack_eval.unpack_plain(packed, 4 * cpad)                        # (4*cpad, cin)
     y = torch.einsum('nk,bkhw->bnhw', mat, x).reshape(1, 2, 2, cpad, 6, 8)[:, :, :, :cout]
     out = torch.zeros(1, cout, 12, 16)
     for ky in range(2):
@@ -295,7 +296,7 @@ def test_winograd_ws_packing_holds_the_same_transformed_weights():
     u_old = pold.permute(2, 0, 3, 1).reshape(cpo, 64, 4, 4)[:100]
     assert torch.equal(u, u_old)
     x = torch.randn((1, 64, 8, 8), generator=g)
-    got = pack.winograd_reference(x, pold, bws, 100)
+    got = pack_eval.winograd_reference(x, pold, bws, 100)
     assert float((got - F.conv2d(x, w, b, padding=1)).abs().max()) < 1e-4
 
 
@@ -456,3 +457,78 @@ def test_deferred_batchnorm_counters_are_flushed_before_state_dict_and_dropped_o
     m.load_state_dict(sd)
     tl.StepClock.tick()
     assert int(m.bn.num_batches_tracked) == 7
+
+
+REF_CALLERS = ['tools/test.py', 'tools/train.py', 'tools/eval_utils/eval_utils.py', 'tools/train_utils/train_utils.py']
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='build container only: reads the reference callers (never on the GPU box)')
+def test_the_references_unchanged_callers_bind_to_this_package():
+    """INTEGRATION.md section A invites a maintainer to keep the reference's own tools/ scripts and swap the package underneath.  By AST, for
+    the four caller files: (1) every name they import from pcdet.* / eval_utils / train_utils.* exists in this build's module of the same
+    path; (2) every attribute they read off an imported module (common_utils.create_logger, cfg.ROOT_DIR is data, ...) exists for the
+    imported utility modules; (3) every call of a boundary function (train_model, build_network, build_dataloader, build_optimizer,
+    build_scheduler, eval_one_epoch, model_fn_decorator, load_data_to_gpu) passes only keywords -- and no more positionals -- than this
+    build's function of that name accepts."""
+    import ast
+    import importlib
+    import inspect
+    import sys
+    tools = os.path.join(REPO, 'practical-collab-perception_amd', 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    boundary = {}
+    checked_calls = 0
+    for rel in REF_CALLERS:
+        tree = ast.parse(open(os.path.join('/root/reference', rel)).read())
+        imported_mods = {}
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split('.')[0] in ('pcdet', 'eval_utils', 'train_utils'):
+                mod = importlib.import_module(node.module)
+                for alias in node.names:
+                    if not hasattr(mod, alias.name):
+                        try:                                                    # `from eval_utils import eval_utils`: a submodule
+                            importlib.import_module(node.module + '.' + alias.name)
+                        except ImportError:
+                            pass
+                    assert hasattr(mod, alias.name), '%s: `from %s import %s` does not resolve in this build' % (rel, node.module, alias.name)
+                    obj = getattr(mod, alias.name)
+                    if inspect.ismodule(obj):
+                        imported_mods[alias.asname or alias.name] = obj
+                    elif callable(obj):
+                        boundary[alias.asname or alias.name] = obj
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id in imported_mods:
+                mod = imported_mods[node.value.id]
+                if node.attr == 'commu_utils' or mod.__name__.endswith('commu_utils'):
+                    continue
+                assert hasattr(mod, node.attr), '%s: %s.%s is used by the reference caller and missing here' % (rel, mod.__name__, node.attr)
+                if callable(getattr(mod, node.attr)):
+                    boundary['%s.%s' % (node.value.id, node.attr)] = getattr(mod, node.attr)
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            name = node.func.id if isinstance(node.func, ast.Name) else (
+                '%s.%s' % (node.func.value.id, node.func.attr) if isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name) else None)
+            fn = boundary.get(name)
+            if fn is None or inspect.isclass(fn):
+                continue
+            try:
+                sig = inspect.signature(fn)
+            except (TypeError, ValueError):
+                continue
+            params = sig.parameters
+            if any(p.kind == p.VAR_KEYWORD for p in params.values()):
+                accepted = None
+            else:
+                accepted = {n for n, p in params.items() if p.kind in (p.POSITIONAL_OR_KEYWORD, p.KEYWORD_ONLY)}
+            for kw in node.keywords:
+                if kw.arg is not None and accepted is not None:
+                    assert kw.arg in accepted, '%s:%d %s(... %s=...) is not accepted by this build (%s)' % (rel, node.lineno, name, kw.arg, sig)
+            n_pos = sum(1 for p in params.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD))
+            if not any(p.kind == p.VAR_POSITIONAL for p in params.values()):
+                assert len(node.args) <= n_pos, '%s:%d %s takes %d positionals here, the reference passes %d' % (rel, node.lineno, name, n_pos, len(node.args))
+            checked_calls += 1
+    assert {'train_model', 'build_network', 'build_dataloader', 'build_optimizer', 'build_scheduler', 'model_fn_decorator',
+            'load_data_to_gpu'} <= set(boundary), sorted(boundary)
+    assert 'eval_utils.eval_one_epoch' in boundary and checked_calls >= 12, (checked_calls, sorted(boundary))
