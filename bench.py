@@ -87,6 +87,9 @@ def parse_args(argv=None):
                     "previous step's box counts are read; all K steps and their K reads still lie inside the timed region)")
     ap.add_argument('--pipeline-replicas', type=int, default=2, help='pipelined inference: 2 = consecutive steps alternate between the model and a '
                     'deep copy of it on two HIP streams (step i+1 may run beside step i); 1 = one model, steps in order on one stream')
+    ap.add_argument('--pipeline-graph', action='store_true', help='pipelined inference: each replica replays its whole forward as ONE hipGraph per step '
+                    '(captured once per buffer / batch size / pose set; the host then spends ~0.3 ms per step instead of enqueueing ~210 launches); '
+                    'bitwise the eager pipelined detections')
     ap.add_argument('--elide-dead-makers', action='store_true', help='DiscoNet inference: skip the BEV-maker passes whose output nothing reads '
                     '(reference quirk F3: the rsu map is overwritten by the car maker, bev_img_early feeds only the training loss); pred_dicts are '
                     'bit-identical; reported under its own metric name, never the headline')
@@ -859,7 +862,7 @@ def main(argv=None):
         shared_device = world > 1 and backend == 'gloo'            # functional check: several ranks on one GPU -- no second replica each
         if shared_device:
             args.pipeline_replicas = 1
-        pipelined = PipelinedDetector(model, replicas=max(1, args.pipeline_replicas))
+        pipelined = PipelinedDetector(model, replicas=max(1, args.pipeline_replicas), graph=args.pipeline_graph)
         work_bufs = [work, torch.empty_like(pristine)]
         work.copy_(pristine)
         pipelined.prepare(work, batch, metas)       # setup: every replica builds its packed weights / buffers once, before the W warm-up steps
@@ -1105,7 +1108,7 @@ def main(argv=None):
                        'points_per_frame': int(pts_np.shape[0] // batch), 'point_distribution': args.dist,
                        'parallelism': ('agent-sharded x%d: ragged all-gather of points%s, frames dealt to ranks' % (world, ' + all-gather of compressed BEV maps' if args.config == 'disco' else ''))
                        if args.shard == 'agent' else ('replicas x%d (frame-sharded)' % world) if not args.train else
-                       ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph),
+                       ('data parallel x%d, one RCCL all-reduce of the flat fp32 gradient per step' % world), 'hipgraph': bool(args.graph or (was_pipelined and args.pipeline_graph)),
                        'ranks_seen_by_collective': ranks_seen, 'backend': backend if world > 1 else None,
                        'per_rank_ms_per_step': per_rank_ms, 'rank_devices': rank_devices, 'rank_cpu_affinity': rank_cpus, 'rank_pci_addresses': ['%04x:%02x:%02x.%x' % (v >> 16, (v >> 8) & 255, (v >> 3) & 31, v & 7) if v >= 0 else None for v in rank_pci],
                        'mode': ('plugin default (per-pillar API tensors materialised: one host sync per VFE; dense canvas)' if args.plugin_default else

@@ -87,7 +87,8 @@ class BEVMaker(nn.Module):
 
     @torch.no_grad()
     def forward_rsu_car(self, batch_dict):
-        self.eval()
+        if self.training:                       # never after train() below; kept for a caller that flips the flag by hand
+            self.eval()
         points = batch_dict['points']
         batch_size = batch_dict['batch_size']
         # which agents have points, and how many rows each: one sync, as in the reference (:156), but a histogram launch instead of a
@@ -170,7 +171,8 @@ class BEVMaker(nn.Module):
 
     @torch.no_grad()
     def forward_early(self, batch_dict):
-        self.eval()
+        if self.training:
+            self.eval()
         batch_dict['bev_img_early'] = self._run_chain(batch_dict['points'], batch_dict['batch_size'], vox_share=batch_dict.get('_pcp_vox_share'))
         return batch_dict
 

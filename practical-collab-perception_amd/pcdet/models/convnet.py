@@ -20,15 +20,26 @@ WINOGRAD4_MIN_WORKGROUPS = 512
 CONV_ALGO = os.environ.get('PCP_CONV_ALGO', 'auto')          # auto | direct | winograd (F(2x2) only) | winograd4 | winograd4f | winograd4h | winograd4c | bf16x3 (opt-in: split-bf16 products)
 
 
+_ENV_DATA = getattr(os.environ, '_data', None)           # CPython's backing dict of os.environ (bytes keys on POSIX)
+_ENV_KEY = os.environ.encodekey('PCP_CONV_ALGO') if hasattr(os.environ, 'encodekey') else None
+
+
 def conv_algo():
     """'bf16' (plain bf16 products) is the mixed-precision TRAINING mode (bench.py refuses it without --train): like autocast it also
     covers the frozen teachers' forward passes inside a training iteration; in this module it selects the same launches as 'bf16x3'
-    with single products"""
+    with single products.
+    Read from the environment at every call (tests and bench.py --optin switch it between forwards) -- through the backing dict:
+    os.environ.get() encodes the key and decodes the value every time, ~450 calls and half a millisecond of host time per DiscoNet step."""
+    if _ENV_DATA is not None and _ENV_KEY is not None:
+        v = _ENV_DATA.get(_ENV_KEY)
+        if v is None:
+            return CONV_ALGO
+        return os.environ.decodevalue(v) if isinstance(v, bytes) else v
     return os.environ.get('PCP_CONV_ALGO', CONV_ALGO)
 
 
 def _plain_bf16():
-    return os.environ.get('PCP_CONV_ALGO', CONV_ALGO) == 'bf16'
+    return conv_algo() == 'bf16'
 
 
 # fused F(4x4,3x3) (csrc/wino4f.hip: one workgroup per CU = 16 x 32 pixels x 64 channels): measured against the fused F(2x2) kernel on MI355X

@@ -38,33 +38,43 @@ def warp_theta(dst_se3_src, h, w, pc_range_min, pix_size, return_ambiguous=False
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # All warps of a forward at once.  warp_theta above is ~20 torch-CPU dispatches per (agent, frame) pair (77 us each: 1.5 ms of host time
-# per DiscoNet step at 20 pairs); here the same float32 arithmetic runs vectorised in numpy over every pair of the forward.
-# Rounding order reproduced (checked against warp_theta on random poses at first use, on THIS machine: _calibrated()):
+# per DiscoNet step at 20 pairs, 120 scalar reads); here the same float32 arithmetic runs vectorised in numpy over every pair of the forward.
+# Rounding order reproduced:
 #   t_pix_norm = 2.0 * ((t - pc_min) / pix) / h - 1.0        elementwise IEEE float32 ops in this order
-#   R^T . t_pix_norm                                          torch's (2, 2) @ (2, 1) matmul = a k-ordered fused chain fma(a1, b1, a0 * b0)
-#                                                             (200 000 random cases bit-equal; mul + add or the reverse fused order differ in
-#                                                             ~25 % of them) -- emulated as float32(float64(a0 * b0 as float32) + a1 * b1 in
-#                                                             float64): the float64 product of two float32 is exact
+#   R^T . t_pix_norm                                          torch's (2, 2) @ (2, 1) matmul -- whose rounding depends on the HOST: on the
+#                                                             build container (MKL with FMA kernels) it is the fused chain fma(a1, b1, rn(a0 * b0)),
+#                                                             on the MI355X boxes (MKL on an AMD EPYC: no FMA path) it is rn(a0 * b0) + rn(a1 * b1)
+#                                                             (2 000 random poses each, 0 mismatches for the matching form, ~25 % for the others).
+# _form() finds out which form THIS machine's torch uses (256 random poses against warp_theta, once per map geometry); only if none of the
+# known forms matches are the pairs evaluated through torch one at a time.
 # ---------------------------------------------------------------------------------------------------------------------------------------
 _CAL = {}
+_FORMS = ('fma_k1', 'mul_add', 'fma_k0', 'exact')
 
 
-def _thetas_numpy(se3_list, h, pc_range_min, pix_size):
+def _thetas_numpy(se3_list, h, pc_range_min, pix_size, form='fma_k1'):
     T32 = np.stack([np.linalg.inv(np.asarray(T, dtype=np.float64)) for T in se3_list]).astype(np.float32)      # (n, 4, 4), as ego_se3_agent
     rot = T32[:, :2, :2]
     t = T32[:, :2, 3]
     f32 = np.float32
     tp = f32(2.0) * ((t - f32(pc_range_min)) / f32(pix_size)) / f32(h) - f32(1.0)                            # (n, 2)
     rt = np.transpose(rot, (0, 2, 1))                                                                        # R^T
-    first = (rt[:, :, 0] * tp[:, 0:1]).astype(np.float32)                                                    # round(a0 * b0)
-    y = (first.astype(np.float64) + rt[:, :, 1].astype(np.float64) * tp[:, 1:2].astype(np.float64)).astype(np.float32)
+    a0, a1 = rt[:, :, 0].astype(np.float64), rt[:, :, 1].astype(np.float64)                                  # products of two float32 are exact in float64
+    b0, b1 = tp[:, 0:1].astype(np.float64), tp[:, 1:2].astype(np.float64)
+    if form == 'fma_k1':
+        y = ((a0 * b0).astype(np.float32).astype(np.float64) + a1 * b1).astype(np.float32)
+    elif form == 'mul_add':
+        y = ((a0 * b0).astype(np.float32) + (a1 * b1).astype(np.float32)).astype(np.float32)
+    elif form == 'fma_k0':
+        y = ((a1 * b1).astype(np.float32).astype(np.float64) + a0 * b0).astype(np.float32)
+    else:
+        y = (a0 * b0 + a1 * b1).astype(np.float32)
     theta = np.concatenate([rt, -y[:, :, None]], axis=2)                                                     # (n, 2, 3)
     return np.ascontiguousarray(theta.reshape(len(se3_list), 6), dtype=np.float32)
 
 
-def _calibrated(h, pc_range_min, pix_size):
-    """True when the numpy form reproduces warp_theta bit for bit on 256 random rigid poses with this map geometry (it does wherever
-    torch's small matmul is the fused chain above; anywhere else the torch form is used, one pair at a time)"""
+def _form(h, pc_range_min, pix_size):
+    """the rounding form that reproduces warp_theta bit for bit on 256 random rigid poses with this map geometry on THIS machine, or None"""
     key = (int(h), float(pc_range_min), float(pix_size))
     if key not in _CAL:
         rng = np.random.RandomState(97)
@@ -75,10 +85,17 @@ def _calibrated(h, pc_range_min, pix_size):
             T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
             T[:3, 3] = rng.uniform(-60, 60, 3)
             poses.append(T)
-        fast = _thetas_numpy(poses, h, pc_range_min, pix_size)
         slow = np.array([warp_theta(ego_se3_agent(T), h, h, pc_range_min, pix_size) for T in poses], dtype=np.float32)
-        _CAL[key] = bool(np.array_equal(fast, slow))
+        _CAL[key] = None
+        for form in _FORMS:
+            if np.array_equal(_thetas_numpy(poses, h, pc_range_min, pix_size, form), slow):
+                _CAL[key] = form
+                break
     return _CAL[key]
+
+
+def _calibrated(h, pc_range_min, pix_size):
+    return _form(h, pc_range_min, pix_size) is not None
 
 
 def warp_thetas(se3_from_ego_list, h, w, pc_range_min, pix_size):
@@ -86,6 +103,7 @@ def warp_thetas(se3_from_ego_list, h, w, pc_range_min, pix_size):
     dst_se3_src = float32(inv(se3_from_ego)), :93)"""
     if not se3_from_ego_list:
         return []
-    if _calibrated(h, pc_range_min, pix_size):
-        return [[float(v) for v in row] for row in _thetas_numpy(se3_from_ego_list, h, pc_range_min, pix_size)]
+    form = _form(h, pc_range_min, pix_size)
+    if form is not None:
+        return [[float(v) for v in row] for row in _thetas_numpy(se3_from_ego_list, h, pc_range_min, pix_size, form)]
     return [warp_theta(ego_se3_agent(T), h, w, pc_range_min, pix_size) for T in se3_from_ego_list]

@@ -10,8 +10,20 @@ from . import lib as _lib
 from .lib import Conv3x3, Decode, DetHead, Grid, Pointwise, check
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_CUR_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
+def current_stream_handle():
+    """the hipStream_t (as an int) torch launches on right now.  torch.cuda.current_stream() builds a Stream object (~8 us); a forward
+    asks ~120 times per batch, which was a millisecond of host time per DiscoNet step -- the raw query is 20 x cheaper"""
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return int(_RAW_STREAM(_CUR_DEVICE()))
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(current_stream_handle())
 
 
 def _p(t):
@@ -404,7 +416,7 @@ def _w4_workspace(device, nbytes):
     frames); the three launches of a call consume it in stream order, so consecutive calls on the same stream share it and concurrent
     streams (CenterPoint.overlap_makers) each get their own.  A buffer that is outgrown stays referenced: a captured hipGraph may have
     its address baked in."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)      # one buffer per launch stream: concurrent streams never share it
+    key = (device, current_stream_handle())      # one buffer per launch stream: concurrent streams never share it
     buf = _W4_WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
@@ -809,7 +821,7 @@ def select_transform_compact(points, agent_col, agents, poses, present, out_rows
         out = torch.empty((max(int(out_rows), 1), stride), dtype=torch.float32, device=points.device)
     assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[1] == stride and out.shape[0] >= out_rows
     need = L.pcp_select_transform_compact_workspace_bytes(n, S)
-    key = (points.device, torch.cuda.current_stream(points.device).cuda_stream)      # one scratch per launch stream (overlapped makers)
+    key = (points.device, current_stream_handle())      # one scratch per launch stream (overlapped makers)
     ws = _STC_SCRATCH.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
