@@ -562,36 +562,7 @@ def hip_device_identity():
         return -1
 
 
-def pin_rank_to_cpus(local_rank, local_world):
-    """One rank per GPU means N Python hosts on one box: each rank is confined to its own slice of the CPUs this process may run on
-    (contiguous, equal shares; in-process os.sched_setaffinity BEFORE anything touches the GPU -- never taskset / numactl, which would be an
-    exec hop), so the enqueueing threads of different ranks never migrate onto each other.  PCP_BENCH_AFFINITY=0 leaves the mask alone.
-    Returns the CPUs this rank runs on (None where the platform has no affinity call)."""
-    try:
-        avail = sorted(os.sched_getaffinity(0))
-    except AttributeError:
-        return None
-    if local_world <= 1 or os.environ.get('PCP_BENCH_AFFINITY', '1') == '0' or len(avail) < local_world:
-        return avail
-    per = len(avail) // local_world
-    mine = avail[local_rank * per:(local_rank + 1) * per]
-    os.sched_setaffinity(0, mine)
-    return mine
-
-
-def _cpu_list(cpus):
-    """[0, 1, 2, 3, 8] -> '0-3,8'"""
-    if not cpus:
-        return ''
-    out, a, b = [], cpus[0], cpus[0]
-    for c in cpus[1:]:
-        if c == b + 1:
-            b = c
-            continue
-        out.append('%d-%d' % (a, b) if b > a else '%d' % a)
-        a = b = c
-    out.append('%d-%d' % (a, b) if b > a else '%d' % a)
-    return ','.join(out)
+from pcp_amd.hostcpu import cpu_list as _cpu_list, pin_rank_to_cpus  # noqa: E402  (no torch, no GPU: plain os / sysfs)
 
 
 # BASELINE.json's other workloads, each timed by a bounded child run of this script (a fresh process started with subprocess -- never an exec)

@@ -45,6 +45,9 @@ def init_dist_pytorch(tcp_port=None, local_rank=None, backend='nccl'):
     """one process per GPU; reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun)."""
     if local_rank is None:
         local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    # one Python host per GPU: confine this rank to its own physical cores BEFORE the first GPU call (in-process, no taskset / numactl hop)
+    from pcp_amd.hostcpu import pin_rank_to_cpus
+    pin_rank_to_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
