@@ -1173,6 +1173,20 @@ def main(argv=None):
                 r = json.loads(rl[-1]) if rl else None
             except Exception:                                              # the headline line must not depend on this extra
                 r = None
+            # the same command with every replica's forward replayed as ONE hipGraph per step (PipelinedDetector(graph=True)): what the host
+            # costs when it does not enqueue ~210 launches per step itself -- the configuration for hosts with few cores per GPU
+            try:
+                res_g = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(min(args.steps, 20)), '--warmup',
+                                        str(min(args.warmup, 5)), '--no-cpu-baseline', '--no-secondary', '--no-configs', '--pipeline-graph'],
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=False)
+                gl = [ln for ln in res_g.stdout.decode().splitlines() if ln.startswith('{')]
+                rg = json.loads(gl[-1]) if gl else None
+            except Exception:
+                rg = None
+            line['secondary_pipeline_graph'] = None if (rg is None or args.pipeline_graph) else {
+                'value': rg['value'], 'unit': rg['unit'], 'ms_per_step': rg['ms_per_step'], 'steps': rg['steps'],
+                'host_cpu_ms_per_step': rg.get('host_cpu_ms_per_step'), 'host_cpu_all_threads_ms_per_step': rg.get('host_cpu_all_threads_ms_per_step'),
+                'note': 'the same command with --pipeline-graph (one hipGraph replay per step and replica; bitwise the eager detections); NOT the headline'}
             line['secondary_ring'] = None if r is None else {
                 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': r['steps'],
                 'vfe_stage_ms_per_step': (r.get('roofline_hbm') or {}).get('ms_per_step'),

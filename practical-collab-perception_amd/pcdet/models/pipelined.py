@@ -239,10 +239,10 @@ class PipelinedDetector:
     @staticmethod
     def _wait(ev):
         """hipEventSynchronize spins (with the blocking flag it yields in a loop: still a busy core, measured with time.thread_time); the
-        batch waited for is the PREVIOUS one while the newest is already queued, so nothing is lost by sleeping in 0.2 ms steps instead"""
+        batch waited for is the PREVIOUS one while the newest is already queued, so nothing is lost by sleeping in 0.1 ms steps instead"""
         import time
         while not ev.query():
-            time.sleep(2e-4)
+            time.sleep(1e-4)
 
     @classmethod
     def _finish(cls, p):
