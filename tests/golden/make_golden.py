@@ -1829,7 +1829,7 @@ def _hunter_verdicts(model, logits, after, seg_extra=0.0):
     return mask, near, edge
 
 
-def _g17_case(tag, out, build, make_bd, disco=False):
+def _g17_case(tag, out, build, make_bd, disco=False, head_stride=1):
     """build() -> (cfg, model, shapes) under the current WEIGHT_SCHEME; make_bd() -> a fresh batch dict.  Tunes the gain as _g13_run does,
     runs the reference forward under the spies, stores digests of everything on the path and the robust final sets.
     With a HunterJr corrector the dynamic-foreground logit's bias is shifted (as g10 / g13_chain do) until about 1 % of the rows are
@@ -1878,7 +1878,8 @@ def _g17_case(tag, out, build, make_bd, disco=False):
     out[tag + '_points_sha'] = np.array(sha(before.numpy()))
     spy.dump(out, tag, disco)
     for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
-        out['%s_head_%s' % (tag, name)] = pred_dicts[0][name].numpy().copy()
+        out['%s_head_%s' % (tag, name)] = pred_dicts[0][name].numpy()[:, :, ::head_stride, ::head_stride].copy()
+    out[tag + '_head_stride'] = np.array(head_stride)
     sf = bd['spatial_features_2d'].numpy()
     out[tag + '_sf2d_probe'] = sf[:, :, ::16, ::16].copy()
     out[tag + '_sf2d_sum'] = sf.astype(np.float64).sum((0, 2, 3))
@@ -1983,6 +1984,29 @@ def g17_disco_b4():
         WEIGHT_SCHEME = 'survey'
 
 
+def g17_bench_b4():
+    """tests/golden/g2_bench_b4.npz: the batches bench.py times for BASELINE configs 2 - 4 (`configs` of its line) -- bench.make_points(CONFIGS[c],
+    4, rank 0) for c in car / ego / early -- through the reference's own forward; head maps stored on every second pixel"""
+    global WEIGHT_SCHEME
+    sys.path.insert(0, REPO)
+    import bench
+    out = {}
+    try:
+        for tag in ('car', 'ego', 'early'):
+            conf = bench.CONFIGS[tag]
+            pts, _metas = bench.make_points(conf, 4, 0)
+
+            def build(yaml_name=conf['yaml']):
+                cfg = rh.load_cfg(yaml_name, {})
+                model, _ds = rh.build_model(cfg)
+                return cfg, model, fill_weights(model)
+            _g17_case(tag, out, build, lambda: {'points': torch.from_numpy(pts.copy()), 'batch_size': 4, 'metadata': [{} for _ in range(4)]}, head_stride=2)
+        out['meta_json'] = np.array(json.dumps(dict(noise=G13_NOISE, trials=G13_TRIALS, batch=4, source='bench.make_points(CONFIGS[c], 4, 0)')))
+        np.savez_compressed(os.path.join(HERE, 'g2_bench_b4.npz'), **out)
+    finally:
+        WEIGHT_SCHEME = 'survey'
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4']
     torch.set_num_threads(8)
@@ -1990,6 +2014,8 @@ if __name__ == '__main__':
         g17_ring_full()
     if 'g17b' in todo:
         g17_disco_b4()
+    if 'g17c' in todo:
+        g17_bench_b4()
     if 'g13' in todo:
         g13_conditioned()
     if 'g13c' in todo:

@@ -123,8 +123,9 @@ def _check_disco_pillars(g, tag, passes, B):
 
 def _check_maps(g, tag, model, batch, disco):
     hd = model.dense_head.forward_ret_dict['pred_dicts'][0]
-    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):                      # every pixel of every head map of every frame
-        np.testing.assert_allclose(hd[name].float().cpu().numpy(), g['%s_head_%s' % (tag, name)], rtol=0, atol=1e-3, err_msg=name)
+    hs = int(g[tag + '_head_stride']) if (tag + '_head_stride') in g else 1     # 1: every pixel of every head map of every frame
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        np.testing.assert_allclose(hd[name].float().cpu().numpy()[:, :, ::hs, ::hs], g['%s_head_%s' % (tag, name)], rtol=0, atol=1e-3, err_msg=name)
     sf = batch['spatial_features_2d'].float().cpu().numpy()
     np.testing.assert_allclose(sf[:, :, ::16, ::16], g[tag + '_sf2d_probe'], rtol=0, atol=1e-3)
     np.testing.assert_allclose(sf.max(axis=(0, 2, 3)), g[tag + '_sf2d_max'], rtol=0, atol=1e-3)
@@ -241,6 +242,40 @@ def test_the_headline_batch_of_bench_py_against_the_reference(dist):
     g = load_golden('g2_disco_full_b4.npz')
     pts, metas = bench.make_points(bench.CONFIGS['disco'], 4, 0, dist)
     _disco_case(g, dist, pts, metas, 4)
+
+
+@pytest.mark.parametrize('tag', ['car', 'ego', 'early'])
+def test_the_bench_batches_of_configs_2_to_4_against_the_reference(tag):
+    """bench.make_points(CONFIGS[tag], 4, rank 0): the B = 4 batches behind the `configs` entries of bench.py's line (car incl. HunterJr's
+    in-place correction of the batch's points), reference fixtures tests/golden/g2_bench_b4.npz"""
+    import bench
+    g = load_golden('g2_bench_b4.npz')
+    conf = bench.CONFIGS[tag]
+    seg = g[tag + '_seg_bias_shift'] if (tag + '_seg_bias_shift') in g else None
+    model = _model(conf['yaml'], str(g[tag + '_weight_scheme']), float(g[tag + '_score_thresh']), seg)
+    pts, metas = bench.make_points(conf, 4, 0)
+    assert pts.shape[0] == int(g[tag + '_N']) and _sha(pts) == str(g[tag + '_points_sha'])
+    metas = [{} for _ in range(4)]
+    dev_pts = torch.from_numpy(pts).cuda()
+    batch = {'points': dev_pts.clone(), 'batch_size': 4, 'metadata': metas}
+    with torch.no_grad(), PillarSpy() as spy:
+        pred, _ = model(batch)
+    passes = spy.passes()
+    assert len(passes) == 1 and int(g[tag + '_vfe_calls']) == 1 and passes[0]['frames'] == 4
+    _check_vfe_pass(g, tag + '_vfe_0_', passes[0]['coords'], passes[0]['inv'])
+    _check_maps(g, tag, model, batch, disco=False)
+    _check_final_sets(g, tag, pred)
+    if seg is not None:
+        after = batch['points'].cpu().numpy()
+        rows = g[tag + '_hunter_rows']
+        assert rows.shape[0] == int(g[tag + '_hunter_dyn_rows']) and rows.shape[0] >= 100
+        assert np.array_equal(np.nonzero((after != pts).any(1))[0], rows)
+        np.testing.assert_allclose(after[rows, 1:4], g[tag + '_hunter_xyz_after'], rtol=0, atol=1e-4)
+    got, _bufs = _pipelined_rounds(model, dev_pts, 4, metas)
+    for preds in got:
+        _check_final_sets(g, tag, preds)
+        _same_bits(preds, got[0])
+    _same_bits(got[0], pred)
 
 
 @pytest.mark.parametrize('frames,n_per,dist', [(4, 360000, 'uniform'), (4, 360000, 'ring'), (20, 60000, 'uniform'), (20, 60000, 'ring')])
