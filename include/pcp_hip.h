@@ -48,7 +48,9 @@ enum {
   PCP_OPT_WINO4C_NW = 3,        /* pcp_conv3x3_winograd4c: 8 = the eight-wave 128-channel form where cout_pad % 128 == 0 (built-in: four waves) */
   PCP_OPT_MP_TH16_MIN = 4,      /* pcp_mp_conv3x3: work items from which the 16-row item is used (built-in 256) */
   PCP_OPT_MP_DIAG = 5,          /* pcp_mp_conv3x3: timing-only diagnostic builds of the kernel body (built-in 0) */
-  PCP_OPT_COUNT = 6
+  PCP_OPT_VOX_AGGREGATE = 6,    /* pcp_voxelize / pcp_pillarise_rows: 1 = count a workgroup's rows in an LDS hash table first, one global atomic per distinct
+                                   (workgroup, cell) pair (built-in); 0 = one global atomic per row (rounds 1 - 5) */
+  PCP_OPT_COUNT = 7
 };
 int pcp_set_option(int32_t option, int64_t value);
 int64_t pcp_get_option(int32_t option);          /* the override, or -1 while the built-in rule applies (also for an unknown option) */

@@ -18,7 +18,8 @@ extern "C" const char *pcp_status_string(int status) {
 #include <atomic>
 
 namespace {
-std::atomic<long long> g_option[PCP_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+std::atomic<long long> g_option[PCP_OPT_COUNT] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static_assert(PCP_OPT_COUNT == 7, "one initialiser per option");
 constexpr int MAX_DEVICES = 64;
 std::atomic<int> g_cus[MAX_DEVICES];          // 0 = not asked yet
 }  // namespace

@@ -398,27 +398,71 @@ inline ScanScratch scan_scratch(char *ws, const VoxLayout &L, int64_t cells, int
   return s;
 }
 
-// pass 1 over points: cell id per row, per-cell histogram (its return value = the row's slot inside its cell), kept rows per 1024-row tile
+// pass 1 over points: cell id per row, per-cell histogram (its return value = the row's slot inside its cell), kept rows per 1024-row tile.
+// AGG (round 6): the 1024 rows of a workgroup are first counted in an LDS hash table keyed by cell (open addressing, 2048 slots), then ONE global
+// atomic per distinct (workgroup, cell) pair reserves that many slots of the cell and every row takes base + its rank in the table entry.
+// A uniform cloud gains nothing (its 1024 rows hit 1024 different cells: +4 us on 1.44 M rows), but the cell under a LiDAR holds hundreds of
+// points per frame and agent, and same-address atomics serialise at the memory side: pcp_pillarise_rows on the 6-agent ring cloud 204 -> 136 us
+// (profiles/r06_vox_aggregate_ab.txt).  The slot order inside a cell stays "arrival order", which nothing downstream depends on (exact
+// fixed-point sums, order-free maxima; the training path sorts the rows of a pillar by row index).  Not applied to the makers' compaction
+// (k_stc_scatter): in the agents' own frames every (agent, frame) has its own hot cell, the contention is a sixth of the merged cloud's, and
+// the table cost that register-heavy kernel 17 us per launch on the uniform cloud for nothing on the ring (measured, reverted).
+constexpr int VOX_HT = 2048;
+
+template <bool AGG>
 __global__ __launch_bounds__(SCAN_THREADS) void k_point_cells(const float *__restrict__ points, long long n, int stride,
                                                               pcp_grid_t g, int *__restrict__ cell_count,
                                                               int *__restrict__ point_cell, int *__restrict__ point_rank,
                                                               int *__restrict__ pt_block_sums) {
   __shared__ int wave_tot[SCAN_THREADS / 64];
+  __shared__ int h_key[AGG ? VOX_HT : 1], h_cnt[AGG ? VOX_HT : 1];
   long long base = (long long)blockIdx.x * SCAN_TILE;
   int valid = 0;
+  if (AGG) {
+    for (int e = threadIdx.x; e < VOX_HT; e += SCAN_THREADS) {
+      h_key[e] = -1;
+      h_cnt[e] = 0;
+    }
+    __syncthreads();
+  }
+  int hslot[SCAN_ITEMS], hloc[SCAN_ITEMS];
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
     long long r = base + i * SCAN_THREADS + threadIdx.x;     // coalesced over rows
+    hslot[i] = -1;
+    hloc[i] = 0;
     if (r < n) {
       int c = point_to_cell(points + r * stride, g);
       point_cell[r] = c;
       if (c >= 0) {
-        // the histogram atomic's return value IS the row's slot inside its cell: the last pass needs no second atomic pass (and no
-        // second zeroed table); the order inside a cell is arrival order either way
-        point_rank[r] = atomicAdd(&cell_count[c], 1);
+        if (AGG) {
+          unsigned h = ((unsigned)c * 2654435761u) >> 21;                    // 11 bits
+          while (true) {
+            const int prev = atomicCAS(&h_key[h], -1, c);
+            if (prev == -1 || prev == c) break;
+            h = (h + 1) & (VOX_HT - 1);
+          }
+          hslot[i] = (int)h;
+          hloc[i] = atomicAdd(&h_cnt[h], 1);
+        } else {
+          // the histogram atomic's return value IS the row's slot inside its cell: the last pass needs no second atomic pass (and no
+          // second zeroed table); the order inside a cell is arrival order either way
+          point_rank[r] = atomicAdd(&cell_count[c], 1);
+        }
         valid++;
       }
     }
+  }
+  if (AGG) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < VOX_HT; e += SCAN_THREADS) {
+      const int c = h_key[e];
+      if (c >= 0) h_cnt[e] = atomicAdd(&cell_count[c], h_cnt[e]);            // the entry now holds the first slot its rows take in the cell
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+      if (hslot[i] >= 0) point_rank[base + i * SCAN_THREADS + threadIdx.x] = h_cnt[hslot[i]] + hloc[i];
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
@@ -489,8 +533,12 @@ int vox_passes(const float *points, int64_t n, int32_t row_stride, const pcp_gri
   if (!cells_ready) {
     if (pcp_zero_async(cell_count, (size_t)cells * 4, stream) != PCP_OK) return PCP_ERR_LAUNCH;
     if (sc.n_pblk > 0) {
-      hipLaunchKernelGGL(k_point_cells, dim3(sc.n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
-                         *grid, cell_count, point_cell, point_rank, sc.pt_bs);
+      if (pcp_option(PCP_OPT_VOX_AGGREGATE, 1) != 0)
+        hipLaunchKernelGGL(k_point_cells<true>, dim3(sc.n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
+                           *grid, cell_count, point_cell, point_rank, sc.pt_bs);
+      else
+        hipLaunchKernelGGL(k_point_cells<false>, dim3(sc.n_pblk), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride,
+                           *grid, cell_count, point_cell, point_rank, sc.pt_bs);
       PCP_CHECK_LAUNCH();
     }
   }

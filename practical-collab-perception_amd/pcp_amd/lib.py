@@ -312,9 +312,9 @@ SYMBOLS.update({
 
 # PCP_OPT_* of include/pcp_hip.h.  The C library never reads the environment; the PCP_* variables of earlier rounds are mapped onto the option
 # table ONCE, here, when the library is loaded (set_option() changes an option later, e.g. from a test)
-OPTIONS = {'pfn_crowd': 0, 'pfn_crowd_blocks': 1, 'pfn_wps': 2, 'wino4c_nw': 3, 'mp_th16_min': 4, 'mp_diag': 5}
+OPTIONS = {'pfn_crowd': 0, 'pfn_crowd_blocks': 1, 'pfn_wps': 2, 'wino4c_nw': 3, 'mp_th16_min': 4, 'mp_diag': 5, 'vox_aggregate': 6}
 _OPTION_ENV = {'PCP_PFN_CROWD': 'pfn_crowd', 'PCP_PFN_CROWD_BLOCKS': 'pfn_crowd_blocks', 'PCP_PFN_WPS': 'pfn_wps', 'PCP_WINO4C_NW': 'wino4c_nw',
-               'PCP_MP_TH16_MIN': 'mp_th16_min', 'PCP_MP_DIAG': 'mp_diag'}
+               'PCP_MP_TH16_MIN': 'mp_th16_min', 'PCP_MP_DIAG': 'mp_diag', 'PCP_VOX_AGGREGATE': 'vox_aggregate'}
 
 _LIB = None
 
