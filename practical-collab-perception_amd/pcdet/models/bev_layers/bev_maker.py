@@ -158,7 +158,10 @@ class BEVMaker(nn.Module):
                 stacked = self._stack_buf[:max(rows, 1)]
                 ops.select_transform_compact(points, c - 1, [a for a, _p, _q, _l in chunk], np.stack([p_ for _a, p_, _q, _l in chunk]),
                                              np.stack([q for _a, _p, q, _l in chunk]), rows, out=stacked, vox_grid=grid, vox_workspace=ws)
-                bev = self._run_chain(stacked[:rows], batch_size * len(chunk), vox_ready=dict(workspace=ws), bf16_map=True)
+                # static agent discovery: `rows` is the CAPACITY (the whole cloud); the rows the chunk's agents really hold are about their share
+                # of it -- the estimate only picks the first backbone layer's form (pillar list vs dense canvas), both give the same bits
+                hint = n * len(chunk) / float(len(agent_ids) + 1) if static else None
+                bev = self._run_chain(stacked[:rows], batch_size * len(chunk), vox_ready=dict(workspace=ws), valid_points_hint=hint, bf16_map=True)
             else:
                 stacked = points.new_empty((len(chunk) * n, c))
                 for slot, (agent_idx, poses, present, _last) in enumerate(chunk):

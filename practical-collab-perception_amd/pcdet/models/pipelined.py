@@ -132,6 +132,8 @@ class PipelinedDetector:
             main.wait_event(ready)
             if copy_from is not None and self.early_makers:
                 bd['_pcp_points_ready'] = ready              # the BEV-maker streams start from here, not from the main stream's position
+        if self._has_makers and os.environ.get('PCP_PIPELINE_STATIC_AGENTS') == '1':
+            bd['_pcp_static_agents'] = True                  # diagnostic: the graph mode's device-side agent discovery in the eager runner
         with torch.cuda.stream(main):
             head.defer_finalize = True
             try:
@@ -180,10 +182,15 @@ class PipelinedDetector:
             if self._has_makers or any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
                 d['_pcp_static_agents'] = True
             head.defer_finalize = True
+            # the BEV-maker passes are captured IN SEQUENCE on the replica's stream, not as parallel branches: replaying a graph with
+            # three side branches per replica measured 10.84 ms per headline step against 10.43 ms for the sequential capture (hipGraph
+            # schedules the branches' kernels with gaps; the eager runner's overlapped makers are worth 1 % -- profiles/r06_pipeline_graph_ab.txt)
+            overlap, model.overlap_makers = getattr(model, 'overlap_makers', False), False
             try:
                 d = model._run_modules(d)
             finally:
                 head.defer_finalize = False
+                model.overlap_makers = overlap
             return head.gather_pending(d['_pcp_pending_head'], batch_size)
         with torch.cuda.stream(main):
             run()                                            # lazy allocations / packed forms of the static form happen here, not under capture
