@@ -224,7 +224,10 @@ def cpu_baseline(conf, cfg, state, batch_points, metas, budget_s=25.0):
         spent += time.time() - t1
         runs += 1
     return dict(value=round(runs / spent, 4), unit='frames/s', cores=cores, kind='port',
-                sample='%d x 1 frame (%d points), oracle/model.py forward incl. decode+NMS, torch CPU threads=%d' % (runs, pts.shape[0], cores))
+                sample='%d x 1 frame (%d points), oracle/model.py forward incl. decode+NMS, torch CPU threads=%d' % (runs, pts.shape[0], cores),
+                note='the oracle is the parity checker (numpy np.add.at / np.maximum.at scatter paths, torch-CPU convolutions), not a tuned CPU '
+                     'implementation: per core it is slower than the reference\'s own torch modules, which BASELINE.md section 2 timed in the build '
+                     'container on 8 cores (basic_car 0.76, basic_ego 2.9, early 0.70, disco ~0.2 frames/s)')
 
 
 def cpu_baseline_lately(car_cfg, car_state, ego_cfg, ego_state, frame, budget_s=30.0):

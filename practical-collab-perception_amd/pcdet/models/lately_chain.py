@@ -158,7 +158,8 @@ class PipelinedChain:
         if p is None:
             return None
         ob, os_, ol, host, ev, B = p
-        ev.synchronize()
+        from .pipelined import PipelinedDetector
+        PipelinedDetector._wait(ev)                                  # sleeps in 0.1 ms steps instead of spinning on the event
         cur = torch.cuda.current_stream()
         for t in (ob, os_, ol):
             t.record_stream(cur)

@@ -348,3 +348,71 @@ def test_graph_mode_of_the_pipelined_runner_returns_the_bits_of_the_eager_one(ca
         for pa, pb in zip(preds, want[i % 3]):
             assert torch.equal(pa['pred_boxes'], pb['pred_boxes'])
     assert want[0][0]['pred_boxes'].shape[0] >= 8
+
+
+def test_the_lately6_batch_of_bench_py_against_the_chained_reference():
+    """config 3 end to end at the batch bench.py --config lately6 times: 4 frames x (ego + 5 remote agents) x 60 000 points, agent streams
+    10 f + a -- tests/golden/g13_chain_full_b4.npz (make_golden.py g13cb4: the reference's twenty basic_car passes, its ingestion lines,
+    its basic_ego pass).  The device-side chain in pipeline mode, then bench.py's runner (PipelinedChain, two replicas, two input sets used
+    alternately): the MoDAR boxes of every remote pass and the ego pass's final sets EXACTLY (count, one-to-one at 1e-3)."""
+    import bench
+    from pcdet.models import build_network_from_meta
+    from pcdet.models.lately_chain import LatelyFusionChain, PipelinedChain
+    g = load_golden('g13_chain_full_b4.npz')
+    meta = g['meta']
+    assert meta['full'] and meta['n_points'] == 60000 and meta['frames'] == 4 and meta['base_agent'] == 0
+    car = build_network_from_meta(meta['car'])
+    st = synth.fill_state_dict(meta['car']['state_shapes'], scheme=str(g['car_weight_scheme']))
+    st['corrector.point_head.seg.0.bias'] = st['corrector.point_head.seg.0.bias'].copy()
+    st['corrector.point_head.seg.0.bias'][0] -= np.float32(meta['car_seg_bias_shift'])
+    # the fixture's HunterJr corrects ~0.04 % of the rows, none of them an fp32 coin toss (make_golden.g13_chain, full='b4'): same arithmetic as
+    # the generator's in-place `bias[2] = orig - shift` (float32(float64 difference))
+    st['corrector.point_head.seg.0.bias'][2] = np.float32(float(st['corrector.point_head.seg.0.bias'][2]) - float(g['car_seg_dyn_shift']))
+    car.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    ego = build_network_from_meta(meta['ego'])
+    ego.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(meta['ego']['state_shapes'], scheme=str(g['ego_weight_scheme'])).items()})
+    rem = meta['remote_agents']
+    frames = []
+    for f in range(4):                                                           # bench.main's lately_frames for rank 0, verbatim
+        cl = lambda a: synth.agent_cloud(agent=10 * f + a, n_points=60000, layout='car')
+        frames.append(dict(ego=cl(1), remote=[cl(a) for a in rem], target_se3_lidar=[np.linalg.inv(synth.agent_pose(a)) for a in rem],
+                           max_sweep_idx=10.0))
+        for s_, a in enumerate(rem):
+            assert np.array_equal(g['target_se3_lidar_%d_%d' % (f, s_)], np.linalg.inv(synth.agent_pose(a))) and float(g['max_sweep_idx_%d' % f]) == 10.0
+    chain = LatelyFusionChain(car.cuda().eval(), ego.cuda().eval(), pipeline=True)
+    dev_ = torch.device('cuda', 0)
+    inputs = LatelyFusionChain.build_inputs(frames, dev_)
+    pristine = inputs['remote_points'].clone()
+    preds = chain(inputs)
+    torch.cuda.synchronize()
+
+    def check(preds_):
+        for b in range(4):
+            rb, rs = g['ego_boxes_%d' % b], g['ego_scores_%d' % b]
+            assert rb.shape[0] >= 20
+            assert_same_final_set(rb, rs, preds_[b]['pred_boxes'].cpu().numpy(), preds_[b]['pred_scores'].cpu().numpy(), tol=1e-3)
+            assert np.array_equal(np.sort(preds_[b]['pred_labels'].cpu().numpy()), np.sort(g['ego_labels_%d' % b]))
+    ob, os_, _ol, cnt = [t.cpu().numpy() for t in chain.last['detections']]
+    for f in range(4):
+        for s_ in range(len(rem)):
+            grp, want = f * len(rem) + s_, g['modar_%d_%d' % (f, s_)]
+            assert want.shape[0] >= 25
+            assert_same_final_set(want[:, :7], want[:, 7], ob[grp, :int(cnt[grp])], os_[grp, :int(cnt[grp])], tol=1e-3)
+    check(preds)
+    pipe = PipelinedChain(chain, replicas=2)
+    sets = [inputs, dict(inputs, remote_points=pristine.clone())]
+    for st_ in sets:
+        st_['remote_points'].copy_(pristine)
+    pipe.prepare(sets)
+    got = []
+    for i in range(4):
+        cur = sets[i & 1]
+        cur['remote_points'].copy_(pristine)
+        out = pipe.submit(cur)
+        if out is not None:
+            got.append(out)
+    got.append(pipe.flush())
+    assert len(got) == 4
+    for preds_ in got:
+        check(preds_)
+        _same_bits(preds_, got[0])
