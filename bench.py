@@ -191,6 +191,26 @@ def make_points(conf, batch, rank, dist='uniform'):
     return synth.collate(clouds), metas
 
 
+def make_gt_boxes(batch, rank):
+    """the ground-truth boxes of the training steps bench.py times: (batch, 40, 8) float32, frame f holds 40 - 3 f boxes [x, y, z, dx, dy, dz,
+    heading, class 1], the rest are zero rows (tests/golden/make_golden.py g7fb4 feeds the same boxes to the reference's train step)"""
+    import numpy as np
+    from pcp_amd import synth
+    gt = np.zeros((batch, 40, 8), dtype=np.float32)
+    for f in range(batch):
+        n = 40 - 3 * f
+        sd = synth.SEED_BASE + 900 + 100 * rank + f
+        gt[f, :n, 0] = synth.uniform(sd, 1, n, -50.0, 50.0)
+        gt[f, :n, 1] = synth.uniform(sd, 2, n, -50.0, 50.0)
+        gt[f, :n, 2] = synth.uniform(sd, 3, n, -3.0, -1.0)
+        gt[f, :n, 3] = synth.uniform(sd, 4, n, 3.0, 5.5)
+        gt[f, :n, 4] = synth.uniform(sd, 5, n, 1.5, 2.5)
+        gt[f, :n, 5] = synth.uniform(sd, 6, n, 1.4, 2.0)
+        gt[f, :n, 6] = synth.uniform(sd, 7, n, -3.14159, 3.14159)
+        gt[f, :n, 7] = 1.0
+    return gt
+
+
 def cpu_baseline(conf, cfg, state, batch_points, metas, budget_s=25.0):
     """oracle forward on the host cores: 1 frame per run (B=1), as many runs as fit the budget (at least 1)."""
     import torch
@@ -772,18 +792,7 @@ def main(argv=None):
         from pcp_amd import synth
         opt = build_optimizer(model, cfg.OPTIMIZATION)
         sched, _ = build_scheduler(opt, 1000, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
-        gt = np.zeros((batch, 40, 8), dtype=np.float32)
-        for f in range(batch):
-            n = 40 - 3 * f
-            sd = synth.SEED_BASE + 900 + 100 * rank + f
-            gt[f, :n, 0] = synth.uniform(sd, 1, n, -50.0, 50.0)
-            gt[f, :n, 1] = synth.uniform(sd, 2, n, -50.0, 50.0)
-            gt[f, :n, 2] = synth.uniform(sd, 3, n, -3.0, -1.0)
-            gt[f, :n, 3] = synth.uniform(sd, 4, n, 3.0, 5.5)
-            gt[f, :n, 4] = synth.uniform(sd, 5, n, 1.5, 2.5)
-            gt[f, :n, 5] = synth.uniform(sd, 6, n, 1.4, 2.0)
-            gt[f, :n, 6] = synth.uniform(sd, 7, n, -3.14159, 3.14159)
-            gt[f, :n, 7] = 1.0
+        gt = make_gt_boxes(batch, rank)
         train_state = dict(opt=opt, sched=sched, gt=torch.from_numpy(gt).to(dev), it=0)
         if args.config == 'car':
             # configs 1 / 2 train HunterJr: foreground points with (sweep, instance) columns and the per-sweep motion of every instance

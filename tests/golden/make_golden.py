@@ -552,9 +552,11 @@ def g7_train():
     print('g7 saved', os.path.getsize(os.path.join(HERE, 'g7_train.npz')) // 1024, 'KiB')
 
 
-def g7_train_full():
+def g7_train_full(b4=False):
     """Config 5 training at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid, one frame, 12 GT boxes): ONE iteration of the
-    reference's train step; loss terms, gradient norm and per-tensor gradient digests."""
+    reference's train step; loss terms, gradient norm and per-tensor gradient digests.
+    b4=True (round 6): the batch bench.py --train times -- bench.make_points(CONFIGS['disco'], 4, 0) with bench.make_gt_boxes(4, 0) -- into
+    g7_train_full_b4.npz."""
     tmp = tempfile.mkdtemp()
     empty = os.path.join(tmp, 'empty.pth')
     torch.save({'model_state': {}}, empty)
@@ -591,7 +593,15 @@ def g7_train_full():
     lr_scheduler.step(0)
     model.train()
     optimizer.zero_grad()
-    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}], 'gt_boxes': torch.from_numpy(gt.copy())}
+    B = 1
+    metas = [{'se3_from_ego': poses}]
+    if b4:
+        sys.path.insert(0, REPO)
+        import bench
+        B = 4
+        pts, metas = bench.make_points(bench.CONFIGS['disco'], 4, 0)
+        gt = bench.make_gt_boxes(4, 0)
+    bd = {'points': torch.from_numpy(pts.copy()), 'batch_size': B, 'metadata': metas, 'gt_boxes': torch.from_numpy(gt.copy())}
     ret, tb, _disp = model(bd)
     loss = ret['loss']
     loss.backward()
@@ -605,7 +615,8 @@ def g7_train_full():
     out['grad_norm'] = np.array(float(norm))
     out['optimization_json'] = np.array(json.dumps(rh.to_plain(cfg.OPTIMIZATION)))
     print('g7 full: loss', float(loss), 'norm', float(norm), tb)
-    np.savez_compressed(os.path.join(HERE, 'g7_train_full.npz'), **out)
+    out['batch'] = np.array(B)
+    np.savez_compressed(os.path.join(HERE, 'g7_train_full_b4.npz' if b4 else 'g7_train_full.npz'), **out)
 
 
 def g7b_train_single(tag, yaml_name, layout):
@@ -2080,6 +2091,8 @@ if __name__ == '__main__':
         g7_train()
     if 'g7f' in todo:
         g7_train_full()
+    if 'g7fb4' in todo:
+        g7_train_full(b4=True)
     if 'g7b' in todo:
         g7b_train_single('ego', 'v2x_pointpillar_basic_ego.yaml', 'lately')
     if 'g8' in todo:

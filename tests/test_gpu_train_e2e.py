@@ -173,13 +173,30 @@ def test_mixed_precision_bf16_training_step_tracks_the_fp32_reference(monkeypatc
     assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
-def _full_size_disco(monkeypatch, algo):
+def _full_size_batch(g):
+    """(points, metadata, batch size) of a full-size training fixture: one frame of agents 0 - 5 (g7_train_full) or, for the b4 fixture, the
+    batch bench.py --train times (bench.make_points(CONFIGS['disco'], 4, 0); the fixture's gt_boxes are bench.make_gt_boxes(4, 0))"""
+    if 'batch' in g and int(g['batch']) == 4:
+        import bench
+        pts, metas = bench.make_points(bench.CONFIGS['disco'], 4, 0)
+        assert np.array_equal(g['gt_boxes'], bench.make_gt_boxes(4, 0))
+        return pts, metas, 4
+    agents = (0, 1, 2, 3, 4, 5)
+    clouds = []
+    for a in agents:
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    return synth.collate([np.concatenate(clouds, axis=0)]), [{'se3_from_ego': {a: g['pose_%d' % a] for a in agents if a != 1}}], 1
+
+
+def _full_size_disco(monkeypatch, algo, fixture='g7_train_full.npz'):
     sys.path.insert(0, os.path.join(REPO, 'practical-collab-perception_amd', 'tools'))
     from train_utils.optimization import build_optimizer, build_scheduler
     from pcdet.config import EasyDict, cfg_from_yaml_file
     from pcdet.models import DatasetInfo, build_network
     monkeypatch.setenv('PCP_CONV_ALGO', algo)
-    g = load_golden('g7_train_full.npz')
+    g = load_golden(fixture)
     cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_disco.yaml'),
                              EasyDict())
     for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
@@ -192,23 +209,18 @@ def _full_size_disco(monkeypatch, algo):
     model = model.to(DEV)
     ocfg = EasyDict(json.loads(str(g['optimization_json'])))
     opt = build_optimizer(model, ocfg)
-    agents = (0, 1, 2, 3, 4, 5)
-    clouds = []
-    for a in agents:
-        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
-        c[:, -1] = float(a)
-        clouds.append(c)
-    pts = synth.collate([np.concatenate(clouds, axis=0)])
-    poses = {a: g['pose_%d' % a] for a in agents if a != 1}
-    batch = lambda: {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}],
+    pts, metas, B = _full_size_batch(g)
+    batch = lambda: {'points': torch.from_numpy(pts).to(DEV), 'batch_size': B, 'metadata': metas,
                      'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}
     return g, model, opt, ocfg, batch, build_scheduler
 
 
-def test_bf16_full_size_first_iteration_tracks_the_reference(monkeypatch):
+@pytest.mark.parametrize('fixture', ['g7_train_full.npz', 'g7_train_full_b4.npz'])
+def test_bf16_full_size_first_iteration_tracks_the_reference(monkeypatch, fixture):
     """config 5 at BASELINE's full size in the bf16 loop -- the first-iteration loss of the reference's own train step
-    (golden g7_train_full) to 1 %, the clipped-gradient norm to 5 %"""
-    g, model, opt, ocfg, batch, build_scheduler = _full_size_disco(monkeypatch, 'bf16')
+    (golden g7_train_full; round 6: g7_train_full_b4 = the four-frame batch bench.py --train --conv-algo bf16 times) to 1 %, the
+    clipped-gradient norm to 5 %"""
+    g, model, opt, ocfg, batch, build_scheduler = _full_size_disco(monkeypatch, 'bf16', fixture)
     sched, _ = build_scheduler(opt, 5, ocfg.NUM_EPOCHS, -1, ocfg)
     sched.step(0)
     model.train()
@@ -407,8 +419,10 @@ def test_training_step_degenerate_batches():
         assert bool(torch.isfinite(opt.flat_p).all())
 
 
-def test_disco_full_size_training_iteration_matches_the_reference():
-    """Config 5 at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid): one iteration of the reference's own train step
+@pytest.mark.parametrize('fixture', ['g7_train_full.npz', 'g7_train_full_b4.npz'])
+def test_disco_full_size_training_iteration_matches_the_reference(fixture):
+    """(g7_train_full_b4, round 6: the four-frame batch and the GT boxes bench.py --train times, through the reference's own train step)
+    Config 5 at BASELINE's full size (6 agents x 60 000 points, 512 x 512 grid): one iteration of the reference's own train step
     (tests/golden/g7_train_full.npz) -- loss terms to 5e-4 (fp32 summation order over 16 384 heat-map cells and train-mode BatchNorm
     statistics over one frame: the CPU reference itself is no more reproducible than that), clipped-gradient norm to 5e-3, per-tensor
     gradient norms to 3e-2 of the largest (the per-element comparison against the float64 oracle lives on the mini fixture)."""
@@ -416,7 +430,7 @@ def test_disco_full_size_training_iteration_matches_the_reference():
     from train_utils.optimization import build_optimizer, build_scheduler
     from pcdet.config import EasyDict, cfg_from_yaml_file
     from pcdet.models import DatasetInfo, build_network
-    g = load_golden('g7_train_full.npz')
+    g = load_golden(fixture)
     cfg = cfg_from_yaml_file(os.path.join(REPO, 'practical-collab-perception_amd', 'tools', 'cfgs', 'v2x_sim_models', 'v2x_pointpillar_disco.yaml'),
                              EasyDict())
     for key in ('BEV_MAKER_RSU', 'BEV_MAKER_CAR', 'BEV_MAKER_EARLY'):
@@ -430,20 +444,12 @@ def test_disco_full_size_training_iteration_matches_the_reference():
     ocfg = EasyDict(json.loads(str(g['optimization_json'])))
     opt = build_optimizer(model, ocfg)
     sched, _ = build_scheduler(opt, 5, ocfg.NUM_EPOCHS, -1, ocfg)
-    agents = (0, 1, 2, 3, 4, 5)
-    clouds = []
-    for a in agents:
-        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco')
-        c[:, -1] = float(a)
-        clouds.append(c)
-    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    pts, metas, B = _full_size_batch(g)
     assert pts.shape[0] == int(g['N'])
-    poses = {a: g['pose_%d' % a] for a in agents if a != 1}
     sched.step(0)
     model.train()
     opt.zero_grad()
-    batch = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': 1, 'metadata': [{'se3_from_ego': poses}],
-             'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}
+    batch = {'points': torch.from_numpy(pts).to(DEV), 'batch_size': B, 'metadata': metas, 'gt_boxes': torch.from_numpy(g['gt_boxes']).to(DEV)}
     ret, tb, _disp = model(batch)
     ret['loss'].backward()
     lv = float(ret['loss'].detach())
