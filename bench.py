@@ -529,7 +529,8 @@ class AbiTimer:
         return out
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', 'r05_pmc_traffic.json')
+PROFILE_ROUND = 'r06'
+PMC_TRAFFIC_JSON = os.path.join(REPO, 'profiles', PROFILE_ROUND + '_pmc_traffic.json')
 
 
 def pmc_traffic(config, kernel_label):
@@ -1037,8 +1038,8 @@ def main(argv=None):
                      'event_bracket_overhead_us': round(1e3 * timer.bracket_ms, 2),
                      'measured_in': 'the instrumented pass of this run: every launch between two HIP events on ONE stream, batch by batch (no '
                                     'maker overlap, no batch pipelining) -- compare with the rocprofv3 summary of `bench.py --no-overlap '
-                                    '--no-pipeline` (profiles/r05_bench_disco_b4_single_stream_kernel_stats.csv), not with the overlapped run '
-                                    '(profiles/r05_bench_disco_b4_overlapped_kernel_stats.csv), whose kernels share the chip',
+                                    '--no-pipeline` (profiles/' + PROFILE_ROUND + '_bench_disco_b4_single_stream_kernel_stats.csv), not with the overlapped run '
+                                    '(profiles/' + PROFILE_ROUND + '_bench_disco_b4_overlapped_kernel_stats.csv), whose kernels share the chip',
                      'launches_per_step': round(dom['launches_per_step'], 2),
                      'share_of_kernel_time': round(dom['ms'] / max(sum(f['ms'] for f in fams), 1e-9), 4)})
         mf = [f for f in fams if f['bound'] == 'mfma']

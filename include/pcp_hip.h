@@ -120,9 +120,9 @@ int pcp_pfn_scatter(const float *points, int64_t n, int32_t row_stride, int32_t 
  * no workgroup barriers, both layers on fp32 MFMA with the weights as the A operand.  canvas (B, ny, nx, 64): written COMPLETELY --
  * pillar rows and zero rows for the empty cells -- so it needs no zero fill and no pcp_canvas_clear; pillar_features (P, 64) or NULL.
  * num_raw in {3, 4, 5, 11}; nx, ny <= 65535.  Must follow pcp_pillarise_rows on the same workspace and stream.
- * Pillars of at least 192 records (PCP_PFN_CROWD=<n> in the environment overrides, >= 64; 0 = never) are listed in the workspace by
+ * Pillars of at least 192 records (option PCP_OPT_PFN_CROWD overrides, >= 64; 0 = never) are listed in the workspace by
  * pcp_pillarise_rows, their records tagged (sign bit of the rank field): pcp_pfn_rows runs those on the first 128 workgroups of its grid
- * (PCP_PFN_CROWD_BLOCKS=<n> overrides), a workgroup per pillar
+ * (option PCP_OPT_PFN_CROWD_BLOCKS overrides), a workgroup per pillar
  * (bit-identical results; a LiDAR-like cloud has cells with hundreds of points next to the sensor). */
 #define PCP_ROWS_CELLS_READY 1
 #define PCP_ROWS_BUCKET_ORDER 2
