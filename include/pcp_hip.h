@@ -7,7 +7,8 @@
  *     *_workspace_bytes() query; nothing is allocated, freed or synchronised inside a call (hipGraph-capturable);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
  *   - the return value is a status (PCP_OK = 0); the library never calls exit() (the reference's op does:
- *     pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-38), never reads the environment, and is re-entrant: what a launch does is a function
+ *     pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-38), never reads the environment (no source of it calls getenv; hipcub's radix sort
+ *     inside the training entry pcp_hunter_losses brings rocPRIM's own ROCPRIM_USE_ATOMIC_BLOCK_ID query along), and is re-entrant: what a launch does is a function
  *     of its arguments and of the option table below (A/B and diagnostic overrides the host sets explicitly; all default to "built-in
  *     rule"), plus a read-only cache of each device's CU count keyed by device ordinal;
  *   - dense maps are NHWC float32 ("pixel-major": channels contiguous), the layout the MFMA implicit-GEMM tiles read

@@ -533,3 +533,50 @@ def test_the_references_unchanged_callers_bind_to_this_package():
     assert {'train_model', 'build_network', 'build_dataloader', 'build_optimizer', 'build_scheduler', 'model_fn_decorator',
             'load_data_to_gpu'} <= set(boundary), sorted(boundary)
     assert 'eval_utils.eval_one_epoch' in boundary and checked_calls >= 12, (checked_calls, sorted(boundary))
+
+
+def test_option_table_round_trip_and_env_mapping(monkeypatch):
+    """pcp_set_option / pcp_get_option need no GPU: defaults read -1 ("built-in rule"), a set value reads back, a negative value restores the
+    rule, an unknown option is refused -- and the library itself never reads the environment (the Python host maps PCP_* once at load)."""
+    import ctypes
+    from pcp_amd import lib
+    L = lib.load()
+    assert set(lib.OPTIONS.values()) == set(range(len(lib.OPTIONS)))
+    for name, idx in lib.OPTIONS.items():
+        assert L.pcp_get_option(idx) == -1, name
+    prev = lib.set_option('pfn_crowd', 64)
+    assert prev is None and L.pcp_get_option(lib.OPTIONS['pfn_crowd']) == 64
+    assert lib.set_option('pfn_crowd', None) == 64 and L.pcp_get_option(lib.OPTIONS['pfn_crowd']) == -1
+    assert L.pcp_set_option(len(lib.OPTIONS), 1) != 0 and L.pcp_set_option(-1, 1) != 0 and L.pcp_get_option(99) == -1
+    monkeypatch.setenv('PCP_PFN_CROWD', '128')                    # set AFTER the load: the library must not see it
+    assert L.pcp_get_option(lib.OPTIONS['pfn_crowd']) == -1
+    # no source of the library calls getenv (the one import of the symbol in the shared object comes from a rocPRIM header -- hipcub's
+    # DeviceRadixSort inside the training entry pcp_hunter_losses reads ROCPRIM_USE_ATOMIC_BLOCK_ID, rocprim/device/detail/ordered_block_id.hpp)
+    csrc = os.path.join(REPO, 'practical-collab-perception_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h')):
+            assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+    # the export entry point validates its arguments without touching a device
+    g = lib.Grid(-51.2, -51.2, -8.0, 0.2, 0.2, 8.0, 512, 512, 1)
+    assert L.pcp_pillar_index_export(ctypes.byref(g), None, 10, 5, None, None, None, None, None, None) != 0
+    assert L.pcp_pillar_index_export(ctypes.byref(g), ctypes.c_void_p(256), 10, 2, None, None, None, None, None, None) != 0       # num_raw < 3
+
+
+def test_rank_affinity_slices_whole_cores(monkeypatch):
+    from pcp_amd import hostcpu
+    assert hostcpu.cpu_list([0, 1, 2, 3, 8, 10, 11]) == '0-3,8,10-11' and hostcpu.cpu_list([]) == ''
+    avail = sorted(os.sched_getaffinity(0))
+    try:
+        cores = hostcpu._physical_cores(avail)
+        assert sorted(c for core in cores for c in core) == avail and all(core == sorted(core) for core in cores)
+        assert hostcpu.pin_rank_to_cpus(0, 1) == avail                                  # one rank: mask untouched
+        assert hostcpu.pin_rank_to_cpus(5, 2) == avail                                  # nonsense rank: mask untouched
+        monkeypatch.setenv('PCP_AFFINITY', '0')
+        assert hostcpu.pin_rank_to_cpus(0, 2) == avail
+        monkeypatch.delenv('PCP_AFFINITY')
+        if len(cores) >= 2:
+            mine = hostcpu.pin_rank_to_cpus(1, 2)
+            per = len(cores) // 2
+            assert mine == sorted(c for core in cores[per:2 * per] for c in core) and sorted(os.sched_getaffinity(0)) == mine
+    finally:
+        os.sched_setaffinity(0, avail)
