@@ -2027,25 +2027,27 @@ def g17_disco_b4():
         WEIGHT_SCHEME = 'survey'
 
 
-def g17_bench_b4():
+def g17_bench_b4(dist='uniform'):
     """tests/golden/g2_bench_b4.npz: the batches bench.py times for BASELINE configs 2 - 4 (`configs` of its line) -- bench.make_points(CONFIGS[c],
-    4, rank 0) for c in car / ego / early -- through the reference's own forward; head maps stored on every second pixel"""
+    4, rank 0) for c in car / ego / early -- through the reference's own forward; head maps stored on every second pixel.
+    dist='ring': the same batches of `bench.py --dist ring` (car: HunterJr's bev_scatter with thousands of points per pixel in four frames; early:
+    the merged 6-agent ring cloud) into g2_bench_b4_ring.npz"""
     global WEIGHT_SCHEME
     sys.path.insert(0, REPO)
     import bench
     out = {}
     try:
-        for tag in ('car', 'ego', 'early'):
+        for tag in (('car', 'ego', 'early') if dist == 'uniform' else ('car', 'early')):
             conf = bench.CONFIGS[tag]
-            pts, _metas = bench.make_points(conf, 4, 0)
+            pts, _metas = bench.make_points(conf, 4, 0, dist)
 
             def build(yaml_name=conf['yaml']):
                 cfg = rh.load_cfg(yaml_name, {})
                 model, _ds = rh.build_model(cfg)
                 return cfg, model, fill_weights(model)
             _g17_case(tag, out, build, lambda: {'points': torch.from_numpy(pts.copy()), 'batch_size': 4, 'metadata': [{} for _ in range(4)]}, head_stride=2)
-        out['meta_json'] = np.array(json.dumps(dict(noise=G13_NOISE, trials=G13_TRIALS, batch=4, source='bench.make_points(CONFIGS[c], 4, 0)')))
-        np.savez_compressed(os.path.join(HERE, 'g2_bench_b4.npz'), **out)
+        out['meta_json'] = np.array(json.dumps(dict(noise=G13_NOISE, trials=G13_TRIALS, batch=4, dist=dist, source='bench.make_points(CONFIGS[c], 4, 0, dist)')))
+        np.savez_compressed(os.path.join(HERE, 'g2_bench_b4.npz' if dist == 'uniform' else 'g2_bench_b4_ring.npz'), **out)
     finally:
         WEIGHT_SCHEME = 'survey'
 
@@ -2059,6 +2061,8 @@ if __name__ == '__main__':
         g17_disco_b4()
     if 'g17c' in todo:
         g17_bench_b4()
+    if 'g17d' in todo:
+        g17_bench_b4('ring')
     if 'g13' in todo:
         g13_conditioned()
     if 'g13c' in todo:

@@ -244,16 +244,16 @@ def test_the_headline_batch_of_bench_py_against_the_reference(dist):
     _disco_case(g, dist, pts, metas, 4)
 
 
-@pytest.mark.parametrize('tag', ['car', 'ego', 'early'])
-def test_the_bench_batches_of_configs_2_to_4_against_the_reference(tag):
-    """bench.make_points(CONFIGS[tag], 4, rank 0): the B = 4 batches behind the `configs` entries of bench.py's line (car incl. HunterJr's
-    in-place correction of the batch's points), reference fixtures tests/golden/g2_bench_b4.npz"""
+@pytest.mark.parametrize('tag,dist', [('car', 'uniform'), ('ego', 'uniform'), ('early', 'uniform'), ('car', 'ring'), ('early', 'ring')])
+def test_the_bench_batches_of_configs_2_to_4_against_the_reference(tag, dist):
+    """bench.make_points(CONFIGS[tag], 4, rank 0, dist): the B = 4 batches behind the `configs` entries of bench.py's line (car incl. HunterJr's
+    in-place correction of the batch's points) and their `--dist ring` forms, reference fixtures tests/golden/g2_bench_b4{,_ring}.npz"""
     import bench
-    g = load_golden('g2_bench_b4.npz')
+    g = load_golden('g2_bench_b4.npz' if dist == 'uniform' else 'g2_bench_b4_ring.npz')
     conf = bench.CONFIGS[tag]
     seg = g[tag + '_seg_bias_shift'] if (tag + '_seg_bias_shift') in g else None
     model = _model(conf['yaml'], str(g[tag + '_weight_scheme']), float(g[tag + '_score_thresh']), seg)
-    pts, metas = bench.make_points(conf, 4, 0)
+    pts, metas = bench.make_points(conf, 4, 0, dist)
     assert pts.shape[0] == int(g[tag + '_N']) and _sha(pts) == str(g[tag + '_points_sha'])
     metas = [{} for _ in range(4)]
     dev_pts = torch.from_numpy(pts).cuda()

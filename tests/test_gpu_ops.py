@@ -1726,3 +1726,52 @@ def test_voxelize_sort_pillar_rows_makes_the_bucket_order_a_function_of_the_inpu
     assert (np.diff(m) >= 0).all()                                   # grouped by pillar, pillars ascending
     same = np.diff(m) == 0
     assert (np.diff(o)[same] > 0).all() and same.sum() > 10000       # ascending point index inside every pillar
+
+
+@pytest.mark.parametrize('case', ['car_1x60k', 'batch3_ragged', 'empty', 'all_masked', 'edges', 'ring_crowded'])
+@pytest.mark.parametrize('aggregate', [0, 1])
+def test_pillar_index_export_rebuilds_what_the_pillariser_would_have_written(case, aggregate, lib_option):
+    """pcp_pillar_index_export on the workspace of a pcp_pillarise_rows call WITHOUT index outputs (the pipeline mode) and of a pcp_voxelize call
+    (num_raw = 0: no records) == the voxel_coords / unq_inv the same pillariser writes when asked, == the oracle; with the histogram pass's
+    LDS pre-aggregation on and off (option vox_aggregate: the pillar lists are bit-identical)."""
+    ops = _ops()
+    lib_option('vox_aggregate', aggregate)
+    B = 1
+    if case == 'car_1x60k':
+        pts = synth.collate([synth.agent_cloud(0, 60000, 'car')])
+    elif case == 'batch3_ragged':
+        B = 3
+        pts = synth.collate([synth.agent_cloud(1, 5000, 'car'), synth.agent_cloud(2, 17, 'car'), synth.agent_cloud(3, 30001, 'car', dist='ring')])
+    elif case == 'ring_crowded':
+        B = 2
+        pts = synth.collate([np.concatenate([synth.agent_cloud(a, 40000, 'car', dist='ring') for a in range(3)], 0),
+                             synth.agent_cloud(9, 60000, 'car', dist='ring')])
+    elif case == 'empty':
+        pts = np.zeros((0, 8), np.float32)
+    elif case == 'all_masked':
+        pts = synth.collate([synth.agent_cloud(0, 1000, 'car')])
+        pts[:, 1] += 500.0
+    else:
+        xs = np.array([-51.2, -51.200001, 51.2, 51.199997, 0.0, 0.2, 0.19999999, -0.2, 0.6000000238, 0.6, np.nan, np.inf, -np.inf, 10.0], np.float32)
+        pts = np.zeros((xs.shape[0] * 2, 8), np.float32)
+        pts[:xs.shape[0], 1], pts[:xs.shape[0], 2] = xs, 1.0
+        pts[xs.shape[0]:, 1], pts[xs.shape[0]:, 2] = 1.0, xs
+        pts[:, 3] = -1.0
+    g = ops.make_grid(PC_RANGE, VOXEL, GRID, B)
+    pd = torch.from_numpy(pts).to(dev())
+    full = ops.pillarise_rows(pd, g, 5, want_inverse=True, want_coords=True)
+    P, kept = int(full.counters[0]), int(full.counters[1])
+    bare = ops.pillarise_rows(pd, g, 5)                                   # no index outputs: what bench.py / --fast run
+    coords, inv, cnt, slot_rank, slot_row = ops.pillar_index_export(bare, want_records=True)
+    assert int(cnt[0]) == P and int(cnt[1]) == kept
+    assert torch.equal(coords, full.voxel_coords[:P]) and torch.equal(inv, full.unq_inv[:kept])
+    assert torch.equal(torch.bincount(slot_rank.long(), minlength=P), torch.bincount(inv, minlength=P)) if kept else slot_rank.numel() == 0
+    if P:
+        want_row = (coords[:, 0].long() * GRID[1] + coords[:, 2].long()) * GRID[0] + coords[:, 3].long()
+        assert torch.equal(slot_row.long(), want_row[slot_rank.long()])
+    vox = ops.voxelize(pd, g, want_inverse=False, want_counts=False)      # the rounds 1 - 4 pillariser: same front tables, no records
+    c2, i2, n2 = ops.pillar_index_export(vox)
+    assert int(n2[0]) == P and torch.equal(c2, coords) and torch.equal(i2, inv)
+    if pts.shape[0]:
+        ref = opil.voxelize(pts, 5, PC_RANGE, VOXEL, GRID)
+        assert np.array_equal(coords.cpu().numpy(), ref['coords']) and np.array_equal(inv.cpu().numpy(), ref['inv'])
