@@ -383,6 +383,10 @@ int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t w, int32_t
  * forward, v2x_fusion_disco.py:88-101): src_host / dst_host are HOST arrays of device pointers, theta_host n_jobs x 6 floats. */
 int pcp_warp_nearest_batch(const float *const *src_host, float *const *dst_host, const float *theta_host, int32_t n_jobs, int32_t h,
                            int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream);
+/* Round 6: the same launch with the affines in DEVICE memory (theta_dev: n_jobs x 6 floats) -- inside a captured hipGraph the poses are then
+ * data, not kernel arguments: the host rewrites the table before a replay and one capture serves every pose set. */
+int pcp_warp_nearest_batch_dev(const float *const *src_host, float *const *dst_host, const float *theta_dev, int32_t n_jobs, int32_t h,
+                               int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream);
 /* maps_host: HOST array of n_agents (<= 16) DEVICE pointers, each (pixels, ld_map); weights: (pixels, ld_w) logits, one
  * column per agent; out[p, :] = sum_a softmax_a(weights[p, :])[a] * maps[a][p, :] */
 int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const float *weights, int32_t ld_w, int64_t pixels,
@@ -485,6 +489,12 @@ int pcp_select_transform_compact(const float *points, int64_t n, int32_t row_str
                                  const float *agents_host, int32_t batch, const float *poses_host, const uint8_t *present_host,
                                  float *out, int64_t out_rows, void *workspace, size_t workspace_bytes, int32_t *slot_start,
                                  const pcp_grid_t *vox_grid, void *vox_workspace, size_t vox_workspace_bytes, void *stream);
+/* Round 6: the same with the pose table (n_slots * batch x 12 floats) and the presence flags (n_slots * batch bytes) in DEVICE memory: under a
+ * captured hipGraph they are refreshed by the host before a replay (which agents exist at all -- agents_host, n_slots -- stays structure). */
+int pcp_select_transform_compact_dev(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
+                                     const float *agents_host, int32_t batch, const float *poses_dev, const uint8_t *present_dev,
+                                     float *out, int64_t out_rows, void *workspace, size_t workspace_bytes, int32_t *slot_start,
+                                     const pcp_grid_t *vox_grid, void *vox_workspace, size_t vox_workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * SURVEY 8(f) rows 1-2  lately-fusion exchange: producer rows and ego-side MoDAR ingestion.

@@ -79,11 +79,18 @@ struct WarpJobs {
   Theta th[WARP_MAX_JOBS];
 };
 
-__global__ void k_warp_nearest_batch(WarpJobs jobs, int h, int w, int c4, int ld_src, int ld_dst, int accumulate) {
+// theta_dev (nullable): the 2 x 3 affines of the jobs in DEVICE memory (6 floats per job, job-major, entry `theta_first + blockIdx.y`) instead of the
+// kernel argument -- a captured hipGraph then serves every pose set: the host refreshes the table before it replays (pcp_warp_nearest_batch_dev)
+__global__ void k_warp_nearest_batch(WarpJobs jobs, int h, int w, int c4, int ld_src, int ld_dst, int accumulate, const float *__restrict__ theta_dev,
+                                     int theta_first) {
   const int j = blockIdx.y;
   const float *__restrict__ src = jobs.src[j];
   float *__restrict__ dst = jobs.dst[j];
-  const Theta th = jobs.th[j];
+  Theta th = jobs.th[j];
+  if (theta_dev) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) th.t[i] = theta_dev[(theta_first + j) * 6 + i];
+  }
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)h * w * c4;
   if (t >= total) return;
@@ -161,9 +168,9 @@ extern "C" int pcp_warp_nearest(const float *src, float *dst, int32_t h, int32_t
   return PCP_OK;
 }
 
-extern "C" int pcp_warp_nearest_batch(const float *const *src_host, float *const *dst_host, const float *theta_host, int32_t n_jobs,
-                                      int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream_) {
-  if (!src_host || !dst_host || !theta_host || n_jobs <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (ld_src & 3) || (ld_dst & 3))
+static int warp_batch_impl(const float *const *src_host, float *const *dst_host, const float *theta_host, const float *theta_dev, int32_t n_jobs,
+                           int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream_) {
+  if (!src_host || !dst_host || (!theta_host && !theta_dev) || n_jobs <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (ld_src & 3) || (ld_dst & 3))
     return PCP_ERR_ARG;
   const long long total = (long long)h * w * (c / 4);
   for (int j0 = 0; j0 < n_jobs; j0 += WARP_MAX_JOBS) {
@@ -173,13 +180,25 @@ extern "C" int pcp_warp_nearest_batch(const float *const *src_host, float *const
       if (!src_host[j0 + j] || !dst_host[j0 + j] || src_host[j0 + j] == dst_host[j0 + j]) return PCP_ERR_ARG;
       jobs.src[j] = src_host[j0 + j];
       jobs.dst[j] = dst_host[j0 + j];
-      for (int i = 0; i < 6; i++) jobs.th[j].t[i] = theta_host[(j0 + j) * 6 + i];
+      for (int i = 0; i < 6; i++) jobs.th[j].t[i] = theta_host ? theta_host[(j0 + j) * 6 + i] : 0.f;
     }
     hipLaunchKernelGGL(k_warp_nearest_batch, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream_, jobs, h, w,
-                       c / 4, ld_src, ld_dst, accumulate);
+                       c / 4, ld_src, ld_dst, accumulate, theta_dev, j0);
     PCP_CHECK_LAUNCH();
   }
   return PCP_OK;
+}
+
+extern "C" int pcp_warp_nearest_batch(const float *const *src_host, float *const *dst_host, const float *theta_host, int32_t n_jobs,
+                                      int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream_) {
+  if (!theta_host) return PCP_ERR_ARG;
+  return warp_batch_impl(src_host, dst_host, theta_host, nullptr, n_jobs, h, w, c, ld_src, ld_dst, accumulate, stream_);
+}
+
+extern "C" int pcp_warp_nearest_batch_dev(const float *const *src_host, float *const *dst_host, const float *theta_dev, int32_t n_jobs,
+                                          int32_t h, int32_t w, int32_t c, int32_t ld_src, int32_t ld_dst, int32_t accumulate, void *stream_) {
+  if (!theta_dev) return PCP_ERR_ARG;
+  return warp_batch_impl(src_host, dst_host, nullptr, theta_dev, n_jobs, h, w, c, ld_src, ld_dst, accumulate, stream_);
 }
 
 extern "C" int pcp_softmax_fuse(const float *const *maps_host, int32_t n_agents, const float *weights, int32_t ld_w,

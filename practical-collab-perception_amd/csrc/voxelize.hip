@@ -628,7 +628,9 @@ struct StcTable {
   int n_slots, batch;
 };
 
-__device__ __forceinline__ int stc_slot_of(const float *row, int agent_col, const StcTable &t) {
+// dev_present / dev_m (nullable, pcp_select_transform_compact_dev): the presence flags and poses in DEVICE memory instead of the kernel argument, so
+// that a captured hipGraph serves every pose set (the host refreshes the two small tables before it replays the graph)
+__device__ __forceinline__ int stc_slot_of(const float *row, int agent_col, const StcTable &t, const unsigned char *__restrict__ dev_present = nullptr) {
   const float a = row[agent_col];
   const int ai = (a > -1.f && a < 64.f) ? (int)a : -1;      // ids outside 0..63 never reach here (pcp_column_id_counts reports them)
   const int b = (int)row[0];
@@ -636,19 +638,20 @@ __device__ __forceinline__ int stc_slot_of(const float *row, int agent_col, cons
 #pragma unroll
   for (int k = 0; k < STC_MAX_SLOTS; k++)
     if (k < t.n_slots && ai == t.agent[k]) s = k;
-  if (s >= 0 && !(b >= 0 && b < t.batch && t.present[s * t.batch + b])) s = -1;
+  if (s >= 0 && !(b >= 0 && b < t.batch && (dev_present ? dev_present[s * t.batch + b] : t.present[s * t.batch + b]))) s = -1;
   return s;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_stc_count(const float *__restrict__ points, long long n, int stride, int agent_col,
-                                                            StcTable t, int n_tiles, int *__restrict__ tile_cnt) {
+                                                            StcTable t, int n_tiles, int *__restrict__ tile_cnt,
+                                                            const unsigned char *__restrict__ dev_present) {
   __shared__ int cnt[SCAN_ITEMS][SCAN_THREADS / 64][STC_MAX_SLOTS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)blockIdx.x * SCAN_TILE;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
     const long long r = base + i * SCAN_THREADS + threadIdx.x;
-    const int s = r < n ? stc_slot_of(points + r * stride, agent_col, t) : -1;
+    const int s = r < n ? stc_slot_of(points + r * stride, agent_col, t, dev_present) : -1;
 #pragma unroll
     for (int k = 0; k < STC_MAX_SLOTS; k++) {
       const unsigned long long bal = __ballot(s == k);
@@ -671,7 +674,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
                                                               int *__restrict__ slot_start_out, float *__restrict__ out,
                                                               long long out_rows, int emit_cells, pcp_grid_t g,
                                                               int *__restrict__ cell_count, int *__restrict__ point_cell,
-                                                              int *__restrict__ point_rank) {
+                                                              int *__restrict__ point_rank, const float *__restrict__ dev_m,
+                                                              const unsigned char *__restrict__ dev_present) {
   __shared__ int cnt[SCAN_ITEMS][SCAN_THREADS / 64][STC_MAX_SLOTS];       // rows kept per (item, wave, slot) -> exclusive prefix
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)blockIdx.x * SCAN_TILE;
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
     const long long r = base + i * SCAN_THREADS + threadIdx.x;
-    slot[i] = r < n ? stc_slot_of(points + r * stride, agent_col, t) : -1;
+    slot[i] = r < n ? stc_slot_of(points + r * stride, agent_col, t, dev_present) : -1;
     rank[i] = 0;
 #pragma unroll
     for (int k = 0; k < STC_MAX_SLOTS; k++) {
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_stc_scatter(const float *__res
       if (pos < out_rows) {                             // the host sized `out` from the same column: always true
         float *o = out + pos * stride;
         const int b = (int)row[0];
-        const float *T = t.m[s * t.batch + b];
+        const float *T = dev_m ? dev_m + 12 * (s * t.batch + b) : t.m[s * t.batch + b];
         const float x = row[1], y = row[2], z = row[3];
         const float fb = row[0] + (float)(s * t.batch);
         // bev_maker.py:179 `p @ R^T + t` on the reference's CPU path (torch -> BLAS sgemm, K = 3) is, bit for bit, the FMA chain
@@ -919,15 +923,16 @@ extern "C" size_t pcp_select_transform_compact_workspace_bytes(int64_t n, int32_
   return stc_layout(n, n_slots).total;
 }
 
-extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
-                                            const float *agents_host, int32_t batch, const float *poses_host,
-                                            const uint8_t *present_host, float *out, int64_t out_rows, void *workspace,
-                                            size_t workspace_bytes, int32_t *slot_start, const pcp_grid_t *vox_grid,
-                                            void *vox_workspace, size_t vox_workspace_bytes, void *stream_) {
+static int stc_impl(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots, const float *agents_host, int32_t batch,
+                    const float *poses_host, const uint8_t *present_host, const float *poses_dev, const uint8_t *present_dev, float *out,
+                    int64_t out_rows, void *workspace, size_t workspace_bytes, int32_t *slot_start, const pcp_grid_t *vox_grid, void *vox_workspace,
+                    size_t vox_workspace_bytes, void *stream_) {
   if (n < 0 || row_stride < 4 || agent_col < 0 || agent_col >= row_stride || n_slots <= 0 || n_slots > STC_MAX_SLOTS || batch <= 0 ||
       n_slots * batch > STC_MAX_POSES || out_rows < 0 || n >= (1LL << 31) || out_rows >= (1LL << 31))
     return PCP_ERR_ARG;
-  if (!agents_host || !poses_host || !present_host || !workspace || (out_rows > 0 && !out) || (n > 0 && !points) || points == out)
+  const bool dev_tables = poses_dev != nullptr;
+  if (dev_tables ? !present_dev : (!poses_host || !present_host)) return PCP_ERR_ARG;
+  if (!agents_host || !workspace || (out_rows > 0 && !out) || (n > 0 && !points) || points == out)
     return PCP_ERR_ARG;
   const StcLayout L = stc_layout(n, n_slots);
   if (workspace_bytes < L.total) return PCP_ERR_WORKSPACE;
@@ -937,8 +942,8 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
   t.batch = batch;
   for (int k = 0; k < STC_MAX_SLOTS; k++) t.agent[k] = k < n_slots ? (int)agents_host[k] : -2;
   for (int i = 0; i < STC_MAX_POSES; i++) {
-    t.present[i] = i < n_slots * batch ? present_host[i] : 0;
-    for (int k = 0; k < 12; k++) t.m[i][k] = i < n_slots * batch ? poses_host[i * 12 + k] : 0.f;
+    t.present[i] = (!dev_tables && i < n_slots * batch) ? present_host[i] : 0;
+    for (int k = 0; k < 12; k++) t.m[i][k] = (!dev_tables && i < n_slots * batch) ? poses_host[i * 12 + k] : 0.f;
   }
   pcp_grid_t g;
   int *cell_count = nullptr, *point_cell = nullptr, *point_rank = nullptr;
@@ -964,18 +969,38 @@ extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int3
   const int n_blocks = (int)((span + SCAN_TILE - 1) / SCAN_TILE);
   if (n_tiles > 0) {
     hipLaunchKernelGGL(k_stc_count, dim3(n_tiles), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, (int)agent_col, t,
-                       n_tiles, tile_cnt);
+                       n_tiles, tile_cnt, (const unsigned char *)present_dev);
     PCP_CHECK_LAUNCH();
   }
   if (n_blocks > 0) {
     hipLaunchKernelGGL(k_stc_scatter, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, points, (long long)n, (int)row_stride, (int)agent_col, t,
                        n_tiles, tile_cnt, slot_start, out, (long long)out_rows, vox_grid ? 1 : 0, g, cell_count,
-                       point_cell, point_rank);
+                       point_cell, point_rank, poses_dev, (const unsigned char *)present_dev);
     PCP_CHECK_LAUNCH();
   } else if (slot_start && pcp_zero_async(slot_start, (size_t)(n_slots + 1) * 4, stream) != PCP_OK) {
     return PCP_ERR_LAUNCH;
   }
   return PCP_OK;
+}
+
+extern "C" int pcp_select_transform_compact(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
+                                            const float *agents_host, int32_t batch, const float *poses_host,
+                                            const uint8_t *present_host, float *out, int64_t out_rows, void *workspace,
+                                            size_t workspace_bytes, int32_t *slot_start, const pcp_grid_t *vox_grid,
+                                            void *vox_workspace, size_t vox_workspace_bytes, void *stream_) {
+  if (!poses_host || !present_host) return PCP_ERR_ARG;
+  return stc_impl(points, n, row_stride, agent_col, n_slots, agents_host, batch, poses_host, present_host, nullptr, nullptr, out, out_rows, workspace,
+                  workspace_bytes, slot_start, vox_grid, vox_workspace, vox_workspace_bytes, stream_);
+}
+
+extern "C" int pcp_select_transform_compact_dev(const float *points, int64_t n, int32_t row_stride, int32_t agent_col, int32_t n_slots,
+                                                const float *agents_host, int32_t batch, const float *poses_dev,
+                                                const uint8_t *present_dev, float *out, int64_t out_rows, void *workspace,
+                                                size_t workspace_bytes, int32_t *slot_start, const pcp_grid_t *vox_grid,
+                                                void *vox_workspace, size_t vox_workspace_bytes, void *stream_) {
+  if (!poses_dev || !present_dev) return PCP_ERR_ARG;
+  return stc_impl(points, n, row_stride, agent_col, n_slots, agents_host, batch, nullptr, nullptr, poses_dev, present_dev, out, out_rows, workspace,
+                  workspace_bytes, slot_start, vox_grid, vox_workspace, vox_workspace_bytes, stream_);
 }
 
 

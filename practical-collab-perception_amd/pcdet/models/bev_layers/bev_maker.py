@@ -82,6 +82,53 @@ class BEVMaker(nn.Module):
             d = m(d)
         return d['spatial_features_2d']
 
+    # ---- static agent discovery (hipGraph capture): everything the host derives from the metadata alone ------------------------------------
+    def _static_jobs(self, metadata, batch_size):
+        """[(agent id, poses (B, 12) float32, present (B,) uint8)] for every agent this maker encodes, from the metadata only (no device
+        read): the agents any frame lists, in ascending order; rsu makers take agent 0 only, the ego (1) is nobody's"""
+        agent_ids = sorted({int(a) for meta in metadata for a in meta['se3_from_ego'].keys()})
+        jobs = []
+        for agent_idx in agent_ids:
+            if agent_idx == 1 or (self.maker_type == 'rsu' and agent_idx != 0):
+                continue
+            if self.only_agents is not None and int(agent_idx) not in self.only_agents:
+                continue
+            poses = np.zeros((batch_size, 12), dtype=np.float32)
+            present = np.zeros((batch_size,), dtype=np.uint8)
+            for b_idx, meta in enumerate(metadata):
+                T = meta['se3_from_ego'].get(int(agent_idx), None)
+                if T is None:
+                    continue
+                poses[b_idx] = np.asarray(T, dtype=np.float64)[:3, :4].astype(np.float32).reshape(-1)
+                present[b_idx] = 1
+            if present.any():
+                jobs.append((int(agent_idx), poses, present))
+        return jobs, len(agent_ids)
+
+    def _group_size(self, n_jobs, batch_size, use_compact=True):
+        group = max(1, min(n_jobs, self.max_agents_per_pass))
+        if use_compact:
+            group = max(1, min(group, 8, 64 // batch_size))
+        return group
+
+    def pose_arrays(self, metadata, batch_size):
+        """name -> host array: what a static (graph-mode) forward of this maker hands to the pose table, from the metadata alone -- the
+        runner refreshes the table with these before it replays a captured forward (pcdet/models/pipelined.py)"""
+        out = {}
+        if self.maker_type == 'early':
+            return out
+        jobs, _n = self._static_jobs(metadata, batch_size)
+        group = self._group_size(len(jobs), batch_size)
+        for g0 in range(0, len(jobs), group):
+            chunk = jobs[g0:g0 + group]
+            out['%s.poses.%d' % (self.maker_type, g0)] = np.stack([p_ for _a, p_, _q in chunk])
+            out['%s.present.%d' % (self.maker_type, g0)] = np.stack([q for _a, _p, q in chunk])
+        return out
+
+    def static_agent_order(self, metadata, batch_size):
+        """the keys of batch_dict['bev_img'] a static forward of this maker leaves, in order"""
+        return [a for a, _p, _q in self._static_jobs(metadata, batch_size)[0]]
+
     # False (PCP_BEVMAKER_COMPACT=0): round 2's form, one full masked copy of the cloud per agent; kept for A/B runs and the equality test
     compact = os.environ.get('PCP_BEVMAKER_COMPACT', '1') != '0'
 
@@ -111,7 +158,11 @@ class BEVMaker(nn.Module):
                 batch_dict['_pcp_agent_ids'] = (points, agent_ids, agent_rows)
         batch_dict['bev_img'] = dict()
         jobs = []
-        for agent_idx in agent_ids:
+        if static:
+            # the same function pose_arrays() uses: what the graph-mode runner writes into the pose table matches what this forward reads
+            sjobs, _n_listed = self._static_jobs(batch_dict['metadata'], batch_size)
+            jobs = [(a, p_, q, batch_size) for a, p_, q in sjobs]
+        for agent_idx in (() if static else agent_ids):
             if agent_idx == 1 or (self.maker_type == 'rsu' and agent_idx != 0):
                 continue
             if self.only_agents is not None and int(agent_idx) not in self.only_agents:
@@ -139,9 +190,7 @@ class BEVMaker(nn.Module):
         n, c = points.shape
         use_compact = (self.compact or static) and batch_size <= 64
         assert use_compact or not static, 'static agent discovery needs the compacting form (batch size <= 64)'
-        group = max(1, min(len(jobs), self.max_agents_per_pass))
-        if use_compact:
-            group = max(1, min(group, 8, 64 // batch_size))
+        group = self._group_size(len(jobs), batch_size, use_compact)
         for g0 in range(0, len(jobs), group):
             chunk = jobs[g0:g0 + group]
             if use_compact:
@@ -156,8 +205,16 @@ class BEVMaker(nn.Module):
                         or self._stack_buf.device != points.device or not vfe_mod.reuse_buffers):
                     self._stack_buf = points.new_empty((max(rows, 1), c))
                 stacked = self._stack_buf[:max(rows, 1)]
-                ops.select_transform_compact(points, c - 1, [a for a, _p, _q, _l in chunk], np.stack([p_ for _a, p_, _q, _l in chunk]),
-                                             np.stack([q for _a, _p, q, _l in chunk]), rows, out=stacked, vox_grid=grid, vox_workspace=ws)
+                poses_h, present_h = np.stack([p_ for _a, p_, _q, _l in chunk]), np.stack([q for _a, _p, q, _l in chunk])
+                table = batch_dict.get('_pcp_pose_table', None) if static else None
+                poses_d = present_d = None
+                if table is not None:
+                    # graph mode: poses and presence flags live in device memory the runner refreshes before every replay (one capture serves
+                    # every pose set); the names and the chunking are those of pose_arrays()
+                    poses_d = table.slot('%s.poses.%d' % (self.maker_type, g0), poses_h)
+                    present_d = table.slot('%s.present.%d' % (self.maker_type, g0), present_h)
+                ops.select_transform_compact(points, c - 1, [a for a, _p, _q, _l in chunk], poses_h, present_h, rows, out=stacked, vox_grid=grid,
+                                             vox_workspace=ws, poses_dev=poses_d, present_dev=present_d)
                 # static agent discovery: `rows` is the CAPACITY (the whole cloud); the rows the chunk's agents really hold are about their share
                 # of it -- the estimate only picks the first backbone layer's form (pillar list vs dense canvas), both give the same bits
                 hint = n * len(chunk) / float(len(agent_ids) + 1) if static else None

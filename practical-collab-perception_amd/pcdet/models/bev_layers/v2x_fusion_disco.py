@@ -118,11 +118,24 @@ class V2XMidFusionDisco(PackedModule):
         train_tape(batch_dict).append(('v2x_mid_fusion', self._pcp_train.backward))
         return batch_dict
 
+    @staticmethod
+    def _warp_pairs(agent_order, metadata):
+        """(agent, frame) pairs that are warped, in launch order: agents as batch_dict['bev_img'] lists them, frames ascending, pairs whose frame
+        does not list the agent left out"""
+        return [(a, b) for a in agent_order for b, meta in enumerate(metadata) if a in meta['se3_from_ego']]
+
+    def theta_array(self, metadata, agent_order, h, w):
+        """(pairs, 6) float32: the affines a static forward hands to the pose table as 'fusion.thetas', from the metadata alone"""
+        pairs = self._warp_pairs(agent_order, metadata)
+        th = fusion_host.warp_thetas([metadata[b]['se3_from_ego'][a] for a, b in pairs], h, w, self.pc_min, self.pix_size)
+        return np.asarray(th, dtype=np.float32).reshape(len(pairs), 6)
+
     def forward(self, batch_dict):
         if self.training:
             return self._forward_train(batch_dict)
         pk = self.packed()
         ego_in = ops.as_nhwc(batch_dict['spatial_features_2d'])
+        self._last_map_hw = (int(ego_in.shape[1]), int(ego_in.shape[2]))
         B, H, W, _ = ego_in.shape
         agents = list(batch_dict['bev_img'].items())
         n_maps = 1 + len(agents)
@@ -140,10 +153,9 @@ class V2XMidFusionDisco(PackedModule):
         pre = batch_dict.get('bev_img_compressed', None)      # agent-sharded execution: maps compressed on the agent's own GPU
         warps = []                                             # (source map, destination map, theta) of every (agent, frame) pair
         # the 2 x 3 affine of every pair, all at once on the host (the poses are metadata: nothing on the device is waited for)
-        pairs = [(agent_idx, b_idx) for agent_idx, _img in agents for b_idx, meta in enumerate(batch_dict['metadata'])
-                 if agent_idx in meta['se3_from_ego']]
-        thetas = dict(zip(pairs, fusion_host.warp_thetas([batch_dict['metadata'][b]['se3_from_ego'][a_] for a_, b in pairs], H, W, self.pc_min,
-                                                         self.pix_size)))
+        pairs = self._warp_pairs([agent_idx for agent_idx, _img in agents], batch_dict['metadata'])
+        theta_list = fusion_host.warp_thetas([batch_dict['metadata'][b]['se3_from_ego'][a_] for a_, b in pairs], H, W, self.pc_min, self.pix_size)
+        thetas = dict(zip(pairs, theta_list))
         for a, (agent_idx, bev_img) in enumerate(agents, start=1):
             comp = pre[agent_idx] if pre is not None else self._compress(pk, ops.as_nhwc(bev_img))
             for b_idx, meta in enumerate(batch_dict['metadata']):
@@ -155,7 +167,14 @@ class V2XMidFusionDisco(PackedModule):
                 ops.warp_nearest_batch(warps, self.cc)         # this agent's frames in one launch, then its weight logits
                 warps = []
                 self._weight(pk, stack[0], stack[a], wbuf, a)
-        ops.warp_nearest_batch(warps, self.cc)                 # fused weightor: every pair of the forward in ONE launch
+        table = batch_dict.get('_pcp_pose_table', None)
+        theta_dev = None
+        if table is not None and warps:
+            # graph mode: the affines live in device memory the runner refreshes before every replay (theta_array() computes the same rows in
+            # the same order from the metadata alone); only the fused weightor's single launch is captured this way
+            assert fuse_now and len(warps) == len(pairs), 'graph mode: every listed (agent, frame) pair is warped in the one fused launch'
+            theta_dev = table.slot('fusion.thetas', np.asarray([th for _s, _d, th in warps], dtype=np.float32).reshape(len(warps), 6))
+        ops.warp_nearest_batch(warps, self.cc, theta_dev=theta_dev)   # fused weightor: every pair of the forward in ONE launch
         live = batch_dict.get('_pcp_agent_live', None)
         if live is not None and agents:
             # hipGraph mode (BEVMaker static agent discovery): the maps of agents without rows / of frames behind an agent's last row do not

@@ -132,6 +132,28 @@ class CenterPoint(Detector3DTemplate):
             join_all()
         return batch_dict
 
+    def pose_arrays(self, metadata, batch_size):
+        """name -> host array: every pose-derived launch parameter of a static (graph-mode) forward, from the metadata alone -- the BEV makers'
+        pose / presence tables and the fusion module's warp affines, under the names the modules use with the pose table"""
+        from ..bev_layers.bev_maker import BEVMaker
+        out = {}
+        makers = [m for m in self.module_list if isinstance(m, BEVMaker)]
+        dead = self._dead_makers(makers)
+        last = None
+        for m in makers:
+            if id(m) in dead:
+                continue
+            out.update(m.pose_arrays(metadata, batch_size))
+            if m.maker_type in ('rsu', 'car'):
+                last = m                                     # every rsu / car maker REPLACES batch_dict['bev_img'] (SURVEY F3)
+        fusion = getattr(self, 'v2x_mid_fusion', None)
+        if fusion is not None and last is not None and getattr(fusion, '_last_map_hw', None) is not None:
+            order = last.static_agent_order(metadata, batch_size)
+            th = fusion.theta_array(metadata, order, *fusion._last_map_hw)
+            if th.shape[0]:
+                out['fusion.thetas'] = th
+        return out
+
     def forward(self, batch_dict):
         batch_dict = self._run_modules(batch_dict)
         if self.training:

@@ -15,18 +15,57 @@ Same kernels, same inputs, same order per batch: every batch's pred_dicts are bi
 (`points` of submit(), refilled through `copy_from`); not for training.
 
 graph=True (round 6): each replica's whole forward -- static agent discovery, BEV-maker streams as parallel branches, trunk, fusion, head, decode,
-NMS, the gather of the detections -- is captured ONCE per (replica, points buffer, batch size, pose set) as a hipGraph and replayed per batch: the
+NMS, the gather of the detections -- is captured ONCE per (replica, points buffer, batch size, agent-presence pattern) as a hipGraph and replayed per batch: the
 Python host then spends ~0.3 ms per batch (copy-in, one graph launch, the counts copy, an event) instead of enqueueing ~210 launches through
 ctypes (3.8 ms measured), which is what keeps eight one-rank-per-GPU hosts from competing for cores.  Same kernels, same arguments, same order:
 bitwise the eager pipelined detections (tests/test_gpu_bench_mode.py, test_gpu_e2e.py).  What a capture freezes: the row count of the batch,
-the batch size and the agents' poses (kernel arguments) -- a batch that differs in any of them gets its own capture (kept, up to a small
-number), so the mode suits fixed-shape streams (bench.py; a dataloader that pads its clouds to a capacity with frame index -1 rows).
+the batch size and WHICH agents each frame's metadata lists -- a batch that differs in any of them gets its own capture (kept, up to a small
+number).  The agents' POSES are data: the makers' pose tables and the fusion's warp affines live in device memory (`PoseTable`,
+pcp_select_transform_compact_dev / pcp_warp_nearest_batch_dev) that the runner refreshes from the batch's metadata before every replay, so
+one capture serves every pose set.  The mode suits fixed-shape streams (bench.py; a dataloader that pads its clouds to a capacity with
+frame index -1 rows).
 """
 import os
 
 import torch
 
 from pcp_amd import ops
+
+
+class PoseTable:
+    """Device-resident copies of the pose-derived launch parameters of a captured forward (graph mode).  While the forward is warmed and
+    captured, the modules ask `slot(name, host_array)` for the device tensor their kernels read (BEVMaker: pose / presence tables of
+    pcp_select_transform_compact_dev; V2XMidFusionDisco: the affines of pcp_warp_nearest_batch_dev).  Before a replay the runner computes the
+    same arrays from the new batch's metadata (`model.pose_arrays`) and `upload`s them: two pinned staging buffers per entry, used
+    alternately, one async copy each on the replica's stream in front of the replay -- the copies stay OUTSIDE the graph."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}                     # name -> dict(host=[pinned, pinned], dev=tensor)
+
+    def slot(self, name, host_array):
+        import numpy as np
+        a = np.ascontiguousarray(host_array)
+        ent = self.entries.get(name)
+        if ent is None:
+            t = torch.from_numpy(a.copy())
+            ent = self.entries[name] = dict(host=[t.clone().pin_memory(), t.clone().pin_memory()], dev=torch.empty(t.shape, dtype=t.dtype, device=self.device))
+        assert tuple(ent['dev'].shape) == a.shape and ent['host'][0].numpy().dtype == a.dtype, (name, a.shape, tuple(ent['dev'].shape))
+        if not torch.cuda.is_current_stream_capturing():
+            ent['host'][0].numpy()[...] = a                  # the warm pass reads real values; under capture the table is left as uploaded
+            ent['dev'].copy_(ent['host'][0], non_blocking=True)
+        return ent['dev']
+
+    def upload(self, arrays, which):
+        """arrays: name -> host array (every entry of the table must be given); `which` alternates 0 / 1 between consecutive uploads"""
+        import numpy as np
+        assert set(arrays) == set(self.entries), (sorted(arrays), sorted(self.entries))
+        for name, a in arrays.items():
+            ent = self.entries[name]
+            a = np.ascontiguousarray(a)
+            assert tuple(ent['dev'].shape) == a.shape, (name, a.shape, tuple(ent['dev'].shape))
+            ent['host'][which].numpy()[...] = a
+            ent['dev'].copy_(ent['host'][which], non_blocking=True)
 
 
 class PipelinedDetector:
@@ -159,28 +198,24 @@ class PipelinedDetector:
 
     # ---- graph mode ---------------------------------------------------------------------------------------------------------------------
     @staticmethod
-    def _pose_digest(metadata):
-        import hashlib
-        import numpy as np
-        h = hashlib.blake2b(digest_size=8)
-        for meta in metadata:
-            poses = meta.get('se3_from_ego', None) if isinstance(meta, dict) else None
-            h.update(b'|')
-            if poses:
-                for a in sorted(poses):
-                    h.update(str(int(a)).encode())
-                    h.update(np.ascontiguousarray(poses[a], dtype=np.float64).tobytes())
-        return h.digest()
+    def _structure_key(metadata):
+        """which agents each frame's metadata lists: the part of the metadata a capture freezes (it decides the maker passes, the warped pairs
+        and the zero-filled maps).  The POSES themselves are data: they live in the graph's pose table and are refreshed before every replay."""
+        return tuple(tuple(sorted(int(a) for a in (meta.get('se3_from_ego', None) or {}))) if isinstance(meta, dict) else () for meta in metadata)
 
     def _capture(self, model, main, bd):
         """one eager forward in the capture's form (static agent discovery: no host read), then the capture itself, both on the replica's stream"""
         head = model.dense_head
         batch_size = bd['batch_size']
 
+        table = PoseTable(bd['points'].device) if hasattr(model, 'pose_arrays') else None
+
         def run():
             d = dict(bd)
             if self._has_makers or any(type(m).__name__ == 'BEVMaker' for m in model.module_list):
                 d['_pcp_static_agents'] = True
+                if table is not None:
+                    d['_pcp_pose_table'] = table
             head.defer_finalize = True
             # the BEV-maker passes are captured IN SEQUENCE on the replica's stream, not as parallel branches: replaying a graph with
             # three side branches per replica measured 10.84 ms per headline step against 10.43 ms for the sequential capture (hipGraph
@@ -198,11 +233,13 @@ class PipelinedDetector:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=main):
             ob, os_, ol, cnt = run()
-        return dict(graph=g, ob=ob, os=os_, ol=ol, cnt=cnt)
+        if table is not None and not table.entries:
+            table = None                                     # a model without pose-derived parameters (single-agent configs)
+        return dict(graph=g, ob=ob, os=os_, ol=ol, cnt=cnt, table=table, uploads=0)
 
     def _submit_graph(self, r, model, main, bd, copy_from):
         points, batch_size = bd['points'], bd['batch_size']
-        key = (r, points.data_ptr(), tuple(points.shape), int(batch_size), self._pose_digest(bd['metadata']))
+        key = (r, points.data_ptr(), tuple(points.shape), int(batch_size), self._structure_key(bd['metadata']))
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= self.MAX_GRAPHS:
@@ -214,6 +251,11 @@ class PipelinedDetector:
         with torch.cuda.stream(main):
             if copy_from is not None:
                 points.copy_(copy_from, non_blocking=True)
+            if ent['table'] is not None:
+                # this batch's poses -> the device tables the captured kernels read (host arithmetic only; a staging buffer is reused two
+                # uploads later, when the batch that read it has been waited for)
+                ent['table'].upload(model.pose_arrays(bd['metadata'], batch_size), ent['uploads'] & 1)
+                ent['uploads'] += 1
             ent['graph'].replay()
             cnt = ent['cnt']
             ckey = (tuple(cnt.shape), cnt.dtype)

@@ -182,6 +182,9 @@ SYMBOLS = {
     'pcp_select_transform_compact_workspace_bytes': (c_sz, [c_i64, c_i32]),
     'pcp_select_transform_compact': (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, ctypes.POINTER(c_f),
                                              ctypes.POINTER(ctypes.c_uint8), vp, c_i64, vp, c_sz, vp, ctypes.POINTER(Grid), vp, c_sz, vp]),
+    'pcp_select_transform_compact_dev': (c_i32, [vp, c_i64, c_i32, c_i32, c_i32, ctypes.POINTER(c_f), c_i32, vp, vp, vp, c_i64, vp, c_sz, vp,
+                                                 ctypes.POINTER(Grid), vp, c_sz, vp]),
+    'pcp_warp_nearest_batch_dev': (c_i32, [vp, vp, vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, vp]),
     'pcp_voxelize_cells_ready': (c_i32, [vp, c_i64, c_i32, ctypes.POINTER(Grid), vp, c_sz, vp, vp, vp, vp]),
     'pcp_gather_detections': (c_i32, [ctypes.POINTER(DetHead), c_i32, c_i32, c_i32, vp, vp, vp, vp, vp]),
     'pcp_nms_workspace_bytes': (c_sz, [c_i32, c_i32]),

@@ -632,7 +632,7 @@ def warp_nearest(src, dst, theta, channels, accumulate=False, src_ch_off=0, dst_
                                 th, 1 if accumulate else 0, _stream()), 'pcp_mp_warp_nearest')
 
 
-def warp_nearest_batch(jobs, channels, accumulate=False):
+def warp_nearest_batch(jobs, channels, accumulate=False, theta_dev=None):
     """jobs: list of (src, dst, theta) with (H, W, ld) single-frame maps of ONE geometry; all the warps in one launch (pcp_warp_nearest_batch),
     pixel for pixel what warp_nearest gives job by job"""
     if not jobs:
@@ -647,6 +647,13 @@ def warp_nearest_batch(jobs, channels, accumulate=False):
     n = len(jobs)
     src = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_, _d, _t in jobs])
     dst = (ctypes.c_void_p * n)(*[d_.data_ptr() for _s, d_, _t in jobs])
+    if theta_dev is not None:
+        # the affines in device memory (graph mode: pcp_warp_nearest_batch_dev), job-major like `jobs`
+        _need_cuda(theta_dev)
+        assert theta_dev.dtype == torch.float32 and theta_dev.is_contiguous() and theta_dev.numel() == 6 * n
+        check(L.pcp_warp_nearest_batch_dev(src, dst, _p(theta_dev), n, H, W, channels, ld_s, ld_d, 1 if accumulate else 0, _stream()),
+              'pcp_warp_nearest_batch_dev')
+        return
     th = (ctypes.c_float * (6 * n))(*[float(v) for _s, _d, t in jobs for v in t])
     check(L.pcp_warp_nearest_batch(src, dst, th, n, H, W, channels, ld_s, ld_d, 1 if accumulate else 0, _stream()), 'pcp_warp_nearest_batch')
 
@@ -801,7 +808,7 @@ _STC_SCRATCH = {}
 
 
 def select_transform_compact(points, agent_col, agents, poses, present, out_rows, out=None, vox_grid=None, vox_workspace=None,
-                             slot_start=None):
+                             slot_start=None, poses_dev=None, present_dev=None):
     """Stable compaction of the rows of `agents` (list of ids, <= 8 slots) into one stacked cloud (include/pcp_hip.h:
     pcp_select_transform_compact).  poses: (slots, B, 12) float32 numpy; present: (slots, B) uint8; out_rows: capacity of `out`
     (>= the rows that will be kept: the sum of the agents' row counts).  Returns out (out_rows, C): slot s's rows behind slot s-1's,
@@ -827,6 +834,16 @@ def select_transform_compact(points, agent_col, agents, poses, present, out_rows
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
         _STC_SCRATCH[key] = ws
     gref = ctypes.byref(vox_grid) if vox_grid is not None else None
+    if poses_dev is not None:
+        # pose table / presence flags in device memory (graph mode: pcp_select_transform_compact_dev); `poses` / `present` only give the shapes
+        _need_cuda(poses_dev, present_dev)
+        assert poses_dev.dtype == torch.float32 and poses_dev.is_contiguous() and poses_dev.numel() == S * B * 12
+        assert present_dev.dtype == torch.uint8 and present_dev.is_contiguous() and present_dev.numel() == S * B
+        check(L.pcp_select_transform_compact_dev(_p(points), n, stride, agent_col % stride, S, ag.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), B,
+                                                 _p(poses_dev), _p(present_dev), _p(out), int(out_rows), _p(ws), ws.numel(), _p(slot_start), gref,
+                                                 _p(vox_workspace), vox_workspace.numel() if vox_workspace is not None else 0, _stream()),
+              'pcp_select_transform_compact_dev')
+        return out
     check(L.pcp_select_transform_compact(_p(points), n, stride, agent_col % stride, S, ag.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), B,
                                          poses.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                          pres.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _p(out), int(out_rows), _p(ws), ws.numel(),

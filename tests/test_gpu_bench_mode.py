@@ -302,8 +302,8 @@ def test_pillarise_rows_bit_exact_at_the_launch_sizes_of_the_headline(frames, n_
 @pytest.mark.parametrize('replicas', [1, 2])
 def test_graph_mode_of_the_pipelined_runner_returns_the_bits_of_the_eager_one(case, replicas):
     """PipelinedDetector(graph=True): every replica replays its whole forward as one hipGraph (static agent discovery, maker streams as
-    branches).  Many batches of DIFFERENT clouds of one shape through the same captures: bitwise what batch-by-batch model(batch_dict)
-    returns -- at the mini size, at BASELINE's full size, with HunterJr correcting the batch's points in place inside the graph."""
+    branches).  Many batches of DIFFERENT clouds AND DIFFERENT agent poses of one shape through the same captures: bitwise what batch-by-batch
+    model(batch_dict) returns -- at the mini size, at BASELINE's full size, with HunterJr correcting the batch's points in place inside the graph."""
     import bench
     from pcdet.models.pipelined import PipelinedDetector
     from test_gpu_e2e import _g13_model, _g13_points
@@ -318,23 +318,39 @@ def test_graph_mode_of_the_pipelined_runner_returns_the_bits_of_the_eager_one(ca
     else:
         metadata = [{} for _ in range(B)]
     base = torch.from_numpy(pts.copy()).cuda()
-    variants = []
+    variants, metas = [], []
     for k in range(3):
         v = base.clone()
         v[:, 1:3] += 0.011 * k
         variants.append(v)
+        # every variant also moves the agents: the POSES are data of a captured forward (device-side pose tables refreshed before each
+        # replay), so the three pose sets below run through the same two captures
+        mk = []
+        for meta in metadata:
+            poses = {}
+            for a, T in meta.get('se3_from_ego', {}).items():
+                yaw, dx = 0.013 * k * (1 + a), 0.17 * k
+                R = np.array([[np.cos(yaw), -np.sin(yaw), 0, dx], [np.sin(yaw), np.cos(yaw), 0, -0.5 * dx], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+                poses[a] = R @ np.asarray(T, dtype=np.float64)
+            mk.append({'se3_from_ego': poses} if 'se3_from_ego' in meta else {})
+        metas.append(mk)
     want = []
-    for v in variants:
+    for v, mk in zip(variants, metas):
         with torch.no_grad():
-            pred, _ = model({'points': v.clone(), 'batch_size': B, 'metadata': metadata})
+            pred, _ = model({'points': v.clone(), 'batch_size': B, 'metadata': mk})
         torch.cuda.synchronize()
         want.append([{k: t.clone() for k, t in p.items()} for p in pred])
+    if case.startswith('disco'):
+        # the pose change alone moves the detections (so a replay that kept the capture's poses could not pass below)
+        with torch.no_grad():
+            frozen, _ = model({'points': variants[2].clone(), 'batch_size': B, 'metadata': metas[0]})
+        assert frozen[0]['pred_scores'].shape != want[2][0]['pred_scores'].shape or not torch.equal(frozen[0]['pred_scores'], want[2][0]['pred_scores'])
     pipe = PipelinedDetector(model, replicas=replicas, graph=True)
     bufs = [torch.empty_like(base), torch.empty_like(base)]
     got, held = [], []
     n_batches = 9
     for i in range(n_batches):
-        out = pipe.submit(bufs[i & 1], B, metadata, copy_from=variants[i % 3])
+        out = pipe.submit(bufs[i & 1], B, metas[i % 3], copy_from=variants[i % 3])
         if out is not None:
             got.append(out)
             held.append([{k: t for k, t in p.items()} for p in out])        # kept alive while later replays overwrite the graphs' static outputs
