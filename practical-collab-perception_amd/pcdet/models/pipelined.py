@@ -68,6 +68,33 @@ class PoseTable:
             ent['dev'].copy_(ent['host'][which], non_blocking=True)
 
 
+class PaddedPoints:
+    """Fixed-shape input for the graph mode: a batch's rows at the front of a (capacity, C) buffer, the rows behind them with frame index -1
+    (every kernel of the path drops such rows: the pillariser's mask, the agent selection, HunterJr's guards) and agent id -1.  Two buffers,
+    used alternately -- the buffer's address is part of a capture's key, and the forward of batch i may still read its buffer while batch
+    i + 1 is prepared."""
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self.bufs = [None, None]
+        self.n = 0
+
+    def fill(self, points):
+        n, c = points.shape
+        if n > self.capacity:
+            raise ValueError('batch of %d rows exceeds the padded capacity %d' % (n, self.capacity))
+        k = self.n & 1
+        self.n += 1
+        buf = self.bufs[k]
+        if buf is None or buf.shape[1] != c or buf.device != points.device:
+            buf = self.bufs[k] = torch.zeros((self.capacity, c), dtype=torch.float32, device=points.device)
+        buf[:n].copy_(points)
+        if n < self.capacity:
+            buf[n:, 0] = -1.0
+            buf[n:, c - 1] = -1.0
+        return buf
+
+
 class PipelinedDetector:
     @staticmethod
     def supports(model):

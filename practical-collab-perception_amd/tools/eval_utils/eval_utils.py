@@ -17,15 +17,27 @@ def eval_one_epoch(cfg, args, model, dataloader, epoch_id, logger, dist_test=Fal
     t_start = time.time()
     # --fast (MI355X pipeline mode): consecutive batches software-pipelined -- the detections of batch i are read back while batch i+1 is
     # queued (pcdet/models/pipelined.py; same detections, bit for bit).  Not with --infer_time (a per-batch wall time needs the sync).
-    pipe, waiting = None, None
+    pipe, waiting, padded = None, None, None
+    capacity = int(getattr(args, 'fast_capacity', 0) or 0)
     if getattr(args, 'fast', False) and not getattr(args, 'infer_time', False):
-        from pcdet.models.pipelined import PipelinedDetector
+        from pcdet.models.pipelined import PaddedPoints, PipelinedDetector
         if PipelinedDetector.supports(model):
-            pipe = PipelinedDetector(model, replicas=2)         # batches alternate between the model and a copy on their own streams
+            # batches alternate between the model and a copy on their own streams.  --fast_capacity N (round 6): every batch is padded to N rows
+            # (frame index -1 behind the real ones) and each replica's forward is replayed as ONE hipGraph -- the poses of a DiscoNet batch are
+            # device-side data refreshed per batch, so one capture per (batch size, set of agents) serves the whole epoch
+            pipe = PipelinedDetector(model, replicas=2, graph=capacity > 0)
+            padded = PaddedPoints(capacity) if capacity > 0 else None
     for batch_dict in dataloader:
         load_data_to_gpu(batch_dict)
         if pipe is not None:
-            prev = pipe.submit(batch_dict['points'], batch_dict['batch_size'], batch_dict.get('metadata', None), extra=batch_dict)
+            pts = batch_dict['points']
+            if padded is not None:
+                if pts.shape[0] > padded.capacity:               # a larger batch than promised: a new capacity (and new captures) from here on
+                    logger.info('--fast_capacity %d is below a batch of %d rows: padding to %d from here on'
+                                % (padded.capacity, pts.shape[0], (pts.shape[0] + 4095) // 4096 * 4096))
+                    padded = PaddedPoints((pts.shape[0] + 4095) // 4096 * 4096)
+                pts = padded.fill(pts)
+            prev = pipe.submit(pts, batch_dict['batch_size'], batch_dict.get('metadata', None), extra=batch_dict)
             if prev is not None:
                 det_annos += dataset.generate_prediction_dicts(waiting, prev, class_names)
             waiting = batch_dict

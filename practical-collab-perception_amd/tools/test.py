@@ -38,6 +38,9 @@ def parse_config():
     p.add_argument('--infer_time', action='store_true', default=False)
     p.add_argument('--fast', action='store_true', help='MI355X pipeline mode: no per-pillar API tensors, persistent buffers, first backbone layer from the pillar list, '
                                                      'BEV-maker passes of a DiscoNet forward on their own HIP streams')
+    p.add_argument('--fast_capacity', type=int, default=0, help='with --fast: pad every batch to this many rows (frame index -1 behind the real '
+                   'ones) and replay each model replica\'s forward as one hipGraph per batch (host cost ~0.3 ms per batch instead of ~200 kernel '
+                   'launches); the agents\' poses stay per-batch data.  0 = eager launches')
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem

@@ -1401,7 +1401,8 @@ def test_recall_record_with_ground_truth_in_eval():
 @pytest.mark.parametrize('yaml_name,fast', [('v2x_pointpillar_basic_car.yaml', False), ('v2x_pointpillar_basic_ego.yaml', True),
                                             ('v2x_pointpillar_basic_ego_early.yaml', True), ('v2x_pointpillar_disco.yaml', True),
                                             ('v2x_pointpillar_disco.yaml', False), ('v2x_pointpillar_anchor.yaml', False),
-                                            ('v2x_late_fusion.yaml', False)])
+                                            ('v2x_late_fusion.yaml', False), ('v2x_pointpillar_basic_car.yaml', 'graph'),
+                                            ('v2x_pointpillar_basic_ego_early.yaml', 'graph')])
 def test_tools_test_py_runs_every_shipped_config(yaml_name, fast):
     """tools/test.py (the reference's command line) on a small synthetic set for every shipped YAML, plugin-default and `--fast`
     (pipeline mode incl. the overlapped BEV makers): exit code 0 and the evaluation report of eval_utils.eval_one_epoch"""
@@ -1412,6 +1413,7 @@ def test_tools_test_py_runs_every_shipped_config(yaml_name, fast):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tools = os.path.join(repo, 'practical-collab-perception_amd', 'tools')
     cmd = [sys.executable, 'test.py', '--cfg_file', 'cfgs/v2x_sim_models/' + yaml_name, '--batch_size', '2'] + (['--fast'] if fast else []) + \
+          (['--fast_capacity', '80000'] if fast == 'graph' else []) + \
           ['--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '6000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '6']
     r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
@@ -1425,7 +1427,8 @@ def test_tools_test_py_runs_every_shipped_config(yaml_name, fast):
 def test_tools_test_py_fast_mode_pipelines_batches_and_reports_the_same_detections():
     """`tools/test.py --fast` runs the eval loop through pcdet/models/pipelined.py (batch i read back while batch i+1 is queued); the
     evaluation report -- detections over frames, per-class counts -- equals the one of the batch-by-batch loop (`--fast --infer_time`
-    keeps the per-batch synchronisation)"""
+    keeps the per-batch synchronisation) and the one of `--fast --fast_capacity N` (batches padded to N rows, every forward one hipGraph replay,
+    the synthetic loader's per-frame poses refreshed in the device-side pose tables; the 7th frame's odd batch gets its own capture)"""
     import os
     import re
     import subprocess
@@ -1433,7 +1436,7 @@ def test_tools_test_py_fast_mode_pipelines_batches_and_reports_the_same_detectio
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tools = os.path.join(repo, 'practical-collab-perception_amd', 'tools')
     reports = []
-    for extra in ([], ['--infer_time']):
+    for extra in ([], ['--infer_time'], ['--fast_capacity', '80000']):      # the last: padded batches, one hipGraph replay per batch and replica
         cmd = [sys.executable, 'test.py', '--cfg_file', 'cfgs/v2x_sim_models/v2x_pointpillar_disco.yaml', '--batch_size', '2', '--fast'] + extra + \
               ['--set', 'DATA_CONFIG.SYNTHETIC.POINTS_PER_AGENT', '6000', 'DATA_CONFIG.SYNTHETIC.NUM_FRAMES', '7']
         r = subprocess.run(cmd, cwd=tools, capture_output=True, text=True, timeout=900)
@@ -1442,7 +1445,7 @@ def test_tools_test_py_fast_mode_pipelines_batches_and_reports_the_same_detectio
         m = re.search(r'(\d+) detections over (\d+) frames.*', out)
         assert m is not None and int(m.group(2)) == 7, out[-1500:]
         reports.append(m.group(0))
-    assert reports[0] == reports[1], reports
+    assert reports[0] == reports[1] == reports[2], reports
 
 
 # ---- regression tests of the ADVICE r3 fixes -----------------------------------------------------------------------------
