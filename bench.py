@@ -619,7 +619,7 @@ def summarize_line(r, note=None):
     return out
 
 
-def run_config_children(steps, warmup, timeout_s=240):
+def run_config_children(steps, warmup, timeout_s=120):
     out = {}
     for name, extra, cpu_budget, note in CONFIG_CHILDREN:
         cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(min(steps, 20)), '--warmup', str(min(warmup, 5))] + extra + \
@@ -1197,7 +1197,7 @@ def main(argv=None):
             try:
                 res_g = subprocess.run([sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(min(args.steps, 20)), '--warmup',
                                         str(min(args.warmup, 5)), '--no-cpu-baseline', '--no-secondary', '--no-configs', '--pipeline-graph'],
-                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=False)
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120, check=False)
                 gl = [ln for ln in res_g.stdout.decode().splitlines() if ln.startswith('{')]
                 rg = json.loads(gl[-1]) if gl else None
             except Exception:
