@@ -583,3 +583,66 @@ def test_g16_pfn_variants_pinned_on_the_references_module(tag):
     assert np.array_equal(out['vox']['coords'], g[tag + '_voxel_coords'])
     assert out['pillar_features'].shape[1] == v['vfe_filters'][-1]
     np.testing.assert_allclose(out['pillar_features'], g[tag + '_pillar_features'], rtol=1e-4, atol=1e-5)
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_g2_ring_full_oracle_forward_of_basic_car_on_the_lidar_like_cloud():
+    """round 6: the ORACLE on the ring cloud at full size (pillars of ~850 points: np.add.at means in index order, HunterJr's bev_scatter with
+    thousands of points per pixel) against what the reference produced on it (tests/golden/g2_ring_full.npz): pillar indices by SHA-256,
+    every head map, the corrected points, the exact final set.  The GPU op tests on crowded pillars compare with this oracle."""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    g = load_golden('g2_ring_full.npz')
+    cfg = bench.load_cfg('v2x_pointpillar_basic_car.yaml')
+    cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = float(g['car_score_thresh'])
+    model, _state, _ds = bench.build_model(cfg)
+    state = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, scheme=str(g['car_weight_scheme']))
+    state['corrector.point_head.seg.0.bias'] = state['corrector.point_head.seg.0.bias'] - g['car_seg_bias_shift'].astype(np.float32)
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    arch = omodel.arch_from_cfg(plain(cfg.MODEL), list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), list(vs))
+    pts = synth.collate([synth.agent_cloud(agent=0, n_points=60000, layout='car', dist='ring')])
+    assert _sha(pts) == str(g['car_points_sha'])
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = omodel.forward(pts, state, arch, metadata=[{}])
+    assert _sha(np.asarray(out['voxel_coords']).astype(np.int32)) == str(g['car_vfe_0_coords_sha'])
+    assert _sha(np.asarray(out['unq_inv']).astype(np.int64)) == str(g['car_vfe_0_inv_sha'])
+    cnt = np.bincount(np.asarray(out['unq_inv']))
+    assert int(cnt.max()) == int(g['car_vfe_0_cnt_max']) and int(cnt.max()) > 500          # the crowded cell under the sensor
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        np.testing.assert_allclose(np.asarray(out['head_maps'][name]), g['car_head_' + name], rtol=0, atol=3e-4)
+    after = out['hunter']['points'].numpy()
+    rows = g['car_hunter_rows']
+    assert np.array_equal(np.nonzero((after != pts).any(1))[0], rows)
+    np.testing.assert_allclose(after[rows, 1:4], g['car_hunter_xyz_after'], rtol=0, atol=1e-5)
+    fb = out['final_box_dicts'][0]
+    assert_same_final_set(g['car_boxes_0'], g['car_scores_0'], np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
+
+
+@pytest.mark.parametrize('dist', ['uniform', 'ring'])
+def test_g2_disco_b4_oracle_pillariser_on_the_headline_batch(dist):
+    """the oracle's pillariser on the merged clouds of the headline's own batch (4 frames x 6 agents x 60 000 points) == the reference's ego-branch
+    VFE call recorded in tests/golden/g2_disco_full_b4.npz, bit for bit"""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    g = load_golden('g2_disco_full_b4.npz')
+    pts, _metas = bench.make_points(bench.CONFIGS['disco'], 4, 0, dist)
+    assert _sha(pts) == str(g[dist + '_points_sha'])
+    vox = opil.voxelize(pts, 5, [-51.2, -51.2, -8.0, 51.2, 51.2, 0.0], [0.2, 0.2, 8.0], [512, 512, 1])
+    k = dist + '_vfe_7_'                                                            # call 7 = the trainable branch's VFE on all points
+    assert vox['coords'].shape[0] == int(g[k + 'P']) and vox['inv'].shape[0] == int(g[k + 'kept'])
+    assert _sha(vox['coords'].astype(np.int32)) == str(g[k + 'coords_sha']) and _sha(vox['inv'].astype(np.int64)) == str(g[k + 'inv_sha'])
