@@ -646,3 +646,48 @@ def test_g2_disco_b4_oracle_pillariser_on_the_headline_batch(dist):
     k = dist + '_vfe_7_'                                                            # call 7 = the trainable branch's VFE on all points
     assert vox['coords'].shape[0] == int(g[k + 'P']) and vox['inv'].shape[0] == int(g[k + 'kept'])
     assert _sha(vox['coords'].astype(np.int32)) == str(g[k + 'coords_sha']) and _sha(vox['inv'].astype(np.int64)) == str(g[k + 'inv_sha'])
+
+
+def test_g2_ring_full_oracle_forward_of_disconet_on_the_lidar_like_cloud():
+    """the oracle's DiscoNet forward on the six merged ring clouds at full size against the reference's (tests/golden/g2_ring_full.npz, case
+    'disco'): the ego branch's pillar SHAs (124 995 pillars, ~5 000 points in the hottest cell), the per-agent and fused map probes, every
+    head map, the exact final set"""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    g = load_golden('g2_ring_full.npz')
+    cfg = bench.load_cfg('v2x_pointpillar_disco.yaml')
+    cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH = float(g['disco_score_thresh'])
+    model, _state, _ds = bench.build_model(cfg)
+    state = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, scheme=str(g['disco_weight_scheme']))
+
+    def plain(d):
+        if isinstance(d, dict):
+            return {k: plain(v) for k, v in d.items()}
+        if isinstance(d, (list, tuple)):
+            return [plain(v) for v in d]
+        return d
+    vs = [p.VOXEL_SIZE for p in cfg.DATA_CONFIG.DATA_PROCESSOR if 'VOXEL_SIZE' in p][0]
+    arch = omodel.arch_from_cfg(plain(cfg.MODEL), list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), list(vs))
+    clouds = []
+    for a in range(6):
+        c = synth.agent_cloud(agent=a, n_points=60000, layout='disco', dist='ring')
+        c[:, -1] = float(a)
+        clouds.append(c)
+    pts = synth.collate([np.concatenate(clouds, axis=0)])
+    assert _sha(pts) == str(g['disco_points_sha'])
+    poses = {a: g['disco_pose_%d' % a] for a in (0, 2, 3, 4, 5)}
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = omodel.forward(pts, state, arch, metadata=[{'se3_from_ego': poses}])
+    assert _sha(np.asarray(out['voxel_coords']).astype(np.int32)) == str(g['disco_vfe_7_coords_sha'])
+    assert int(g['disco_vfe_7_cnt_max']) > 3000
+    for aid in (0, 2, 3, 4, 5):
+        a = out['bev_img'][aid].numpy()
+        np.testing.assert_allclose(a[:, ::8, ::8, ::8], g['disco_bev_%d_probe' % aid], rtol=0, atol=3e-4)
+    sf = np.asarray(out['spatial_features_2d'])
+    np.testing.assert_allclose(sf[:, :, ::16, ::16], g['disco_sf2d_probe'], rtol=0, atol=5e-4)
+    for name in ('center', 'center_z', 'dim', 'rot', 'hm'):
+        np.testing.assert_allclose(np.asarray(out['head_maps'][name]), g['disco_head_' + name], rtol=0, atol=5e-4)
+    fb = out['final_box_dicts'][0]
+    assert_same_final_set(g['disco_boxes_0'], g['disco_scores_0'], np.asarray(fb['pred_boxes']), np.asarray(fb['pred_scores']), tol=1e-3)
