@@ -153,7 +153,8 @@ class PipelinedDetector:
         self._events = None           # two blocking events, used alternately (at most two batches are pending: the one being read and the newest)
         self._n = 0
         self.graph = bool(graph)
-        self._graphs = {}             # (replica, points ptr, shape, batch size, pose digest) -> captured forward
+        self._graphs = {}             # (replica, points ptr, shape, batch size, agent-presence pattern) -> captured forward
+        self._evicted = []            # captures that made room for newer ones, kept alive until a device synchronisation
         # PCP_PIPELINE_EARLY_MAKERS=0: the maker streams of batch i+1 wait for the main stream (i.e. for batch i's tail), as `model()` does
         self.early_makers = os.environ.get('PCP_PIPELINE_EARLY_MAKERS', '1') != '0'
         self._has_makers = any(type(m).__name__ == 'BEVMaker' and m.maker_type in ('rsu', 'car') for m in model.module_list)
@@ -270,7 +271,12 @@ class PipelinedDetector:
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= self.MAX_GRAPHS:
-                self._graphs.pop(next(iter(self._graphs)))
+                # the oldest capture makes room.  Its last replay may still be running (it can even be the pending batch's): the entry is parked,
+                # and parked entries are only dropped behind a device synchronisation -- destroying an executing graph is not defined
+                self._evicted.append(self._graphs.pop(next(iter(self._graphs))))
+                if len(self._evicted) > 4:
+                    torch.cuda.synchronize()
+                    del self._evicted[:-1]
             if copy_from is not None:
                 with torch.cuda.stream(main):
                     points.copy_(copy_from, non_blocking=True)     # the capture's eager pass reads real points
