@@ -432,3 +432,38 @@ def test_the_lately6_batch_of_bench_py_against_the_chained_reference():
     for preds_ in got:
         check(preds_)
         _same_bits(preds_, got[0])
+
+
+def test_graph_mode_evicts_old_captures_safely_when_shapes_keep_changing():
+    """more distinct batch shapes than the runner keeps captures for (MAX_GRAPHS lowered to 3): the oldest capture is parked, not destroyed under a
+    running replay, and every batch still equals the eager forward bit for bit"""
+    import bench
+    from pcdet.models.pipelined import PipelinedDetector
+    from test_gpu_e2e import _g13_model, _g13_points
+    g = load_golden('g13_conditioned.npz')
+    model = _g13_model(g, 'ego')
+    bench.set_pipeline_mode(model)
+    pts, B = _g13_points('ego')
+    base = torch.from_numpy(pts.copy()).cuda()
+    sizes = [base.shape[0] - 37 * k for k in range(9)]
+    want = []
+    for n in sizes:
+        with torch.no_grad():
+            pred, _ = model({'points': base[:n].clone(), 'batch_size': B, 'metadata': [{} for _ in range(B)]})
+        torch.cuda.synchronize()
+        want.append([{k: t.clone() for k, t in p.items()} for p in pred])
+    pipe = PipelinedDetector(model, replicas=2, graph=True)
+    pipe.MAX_GRAPHS = 3
+    bufs = [base[:n].clone() for n in sizes]
+    got = []
+    for rnd in range(2):
+        for i, n in enumerate(sizes):
+            out = pipe.submit(bufs[i], B, [{} for _ in range(B)], copy_from=base[:n])
+            if out is not None:
+                got.append(out)
+    got.append(pipe.flush())
+    assert len(got) == 2 * len(sizes) and len(pipe._graphs) <= 3 and len(pipe._evicted) >= 1
+    for j, preds in enumerate(got):
+        for pa, pb in zip(preds, want[j % len(sizes)]):
+            for k in ('pred_boxes', 'pred_scores', 'pred_labels'):
+                assert pa[k].shape == pb[k].shape and torch.equal(pa[k], pb[k]), (j, k)
