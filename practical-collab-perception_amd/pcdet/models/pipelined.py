@@ -172,7 +172,10 @@ class PipelinedDetector:
         if self.side is None:
             self.side = torch.cuda.Stream()
             if len(self.models) > 1 or self.graph:           # a capture needs a stream of its own (never the legacy default stream)
-                self.mains = [torch.cuda.Stream() for _ in self.models]
+                # PCP_PIPELINE_PRIO (diagnostic): 'trunk' = the replicas' streams above the BEV-maker streams, 'first' = replica 0 above replica 1
+                prio = os.environ.get('PCP_PIPELINE_PRIO', '')
+                pr = [(-1 if (prio == 'trunk' or (prio == 'first' and i == 0)) else 0) for i in range(len(self.models))]
+                self.mains = [torch.cuda.Stream(priority=p_) for p_ in pr]
         r = self._n % len(self.models)
         model = self.models[r]
         head = model.dense_head
